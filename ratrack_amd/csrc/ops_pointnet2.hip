@@ -1,0 +1,575 @@
+// ops_pointnet2.hip -- the ten pointnet2 ops + knn_point as gfx950 HIP kernels (C ABI in
+// include/rtk_pointnet2.h).  Written for CDNA4: 64-lane wavefronts, DPP wave reductions, source
+// clouds staged in LDS as SoA, one wave per serial problem instead of one thread.
+//
+// Bit-exactness contract: every distance goes through rtk_sqdist() (explicit __fmaf_rn chain) and
+// the file is compiled with -ffp-contract=off, so nothing else is fused; results equal
+// oracle/pointnet2_ref.c bit for bit on indices and on three_nn / three_interpolate floats.
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "rtk_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void rtk_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *rtk_last_error(void) { return g_err; }
+extern "C" int rtk_version(void) { return (0 << 16) | 3; }
+
+// ------------------------------------------------------------------------------------------------
+// wave64 reductions on DPP (no LDS, no barriers).  row_shr:1,2,4,8 leave each row's maximum in its
+// lane 15; row_bcast:15 / row_bcast:31 carry it across rows so lane 63 holds the wave result.
+// Lanes without a valid DPP source keep `old` (= their own value), which is a no-op for max.
+// ------------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_mov(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void key_max_step(unsigned &hi, unsigned &lo) {
+    const unsigned h2 = dpp_mov<CTRL, ROW_MASK>(hi);
+    const unsigned l2 = dpp_mov<CTRL, ROW_MASK>(lo);
+    const bool take = (h2 > hi) || (h2 == hi && l2 > lo);
+    hi = take ? h2 : hi;
+    lo = take ? l2 : lo;
+}
+
+// max over the wave of the 64-bit key (hi:lo); result is wave-uniform (read from lane 63).
+__device__ __forceinline__ void wave_key_max(unsigned &hi, unsigned &lo) {
+    key_max_step<0x111, 0xf>(hi, lo);  // row_shr:1
+    key_max_step<0x112, 0xf>(hi, lo);  // row_shr:2
+    key_max_step<0x114, 0xf>(hi, lo);  // row_shr:4
+    key_max_step<0x118, 0xf>(hi, lo);  // row_shr:8
+    key_max_step<0x142, 0xa>(hi, lo);  // row_bcast:15 -> rows 1,3
+    key_max_step<0x143, 0xc>(hi, lo);  // row_bcast:31 -> rows 2,3
+    hi = (unsigned)__builtin_amdgcn_readlane((int)hi, 63);
+    lo = (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+}
+
+// ------------------------------------------------------------------------------------------------
+// furthest point sampling   (reference: sampling_gpu.cu:94-209)
+//
+// The reference runs one CUDA block per sample with 2^floor(log2 n) threads and 511 block-wide
+// shared-memory tree reductions.  Here one WAVE owns one sample: its n <= 64*PPL points and their
+// running min-distances live in registers, the per-round argmax is a DPP reduction of the key
+// (float bits of d2 : ~rank) and the winner's coordinates come back with v_readlane -- no LDS, no
+// barrier in the 511-round dependent chain.  rank(k) = (k mod block, k div block) reproduces the
+// reference's tie rule (lower tid wins in the tree, first k wins inside a thread).
+// ------------------------------------------------------------------------------------------------
+template <int PPL>
+__global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, const float *__restrict__ xyz,
+                                                      float *__restrict__ temp, int *__restrict__ idxs) {
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    xyz += (size_t)b * n * 3;
+    temp += (size_t)b * n;
+    idxs += (size_t)b * m;
+
+    float x[PPL], y[PPL], z[PPL], t[PPL];
+    unsigned nrank[PPL];  // ~rank (0 for padding so that it never wins)
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const int k = lane + 64 * i;
+        const bool ok = k < n;
+        x[i] = ok ? xyz[k * 3 + 0] : 0.f;
+        y[i] = ok ? xyz[k * 3 + 1] : 0.f;
+        z[i] = ok ? xyz[k * 3 + 2] : 0.f;
+        t[i] = ok ? temp[k] : 0.f;
+        const unsigned rank = ((unsigned)(k % block) << 16) | (unsigned)(k / block);
+        nrank[i] = ok ? ~rank : 0u;
+    }
+    if (lane == 0) idxs[0] = 0;
+    int old = 0;
+    for (int j = 1; j < m; ++j) {
+        const int ol = old & 63, os = old >> 6;  // wave-uniform
+        float ox = 0.f, oy = 0.f, oz = 0.f;
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) {
+            if (os == i) {
+                ox = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[i]), ol));
+                oy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y[i]), ol));
+                oz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z[i]), ol));
+            }
+        }
+        unsigned hi = 0u, lo = 0u;
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) {
+            const float d = rtk_sqdist(x[i], y[i], z[i], ox, oy, oz);
+            const float d2 = fminf(d, t[i]);
+            t[i] = d2;
+            const unsigned h = nrank[i] ? __float_as_uint(d2) : 0u;
+            const bool take = (h > hi) || (h == hi && nrank[i] > lo);
+            hi = take ? h : hi;
+            lo = take ? nrank[i] : lo;
+        }
+        wave_key_max(hi, lo);
+        const unsigned rank = ~lo;
+        old = (int)((rank & 0xffffu) * (unsigned)block + (rank >> 16));
+        if (lane == 0) idxs[j] = old;
+    }
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const int k = lane + 64 * i;
+        if (k < n) temp[k] = t[i];
+    }
+}
+
+// General fallback for n > 2048: one 256-thread workgroup per sample, min-distances in global memory.
+__global__ __launch_bounds__(256) void fps_block_kernel(int n, int m, int block, const float *__restrict__ xyz,
+                                                        float *__restrict__ temp, int *__restrict__ idxs) {
+    __shared__ unsigned s_hi[4], s_lo[4];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    xyz += (size_t)b * n * 3;
+    temp += (size_t)b * n;
+    idxs += (size_t)b * m;
+    if (tid == 0) idxs[0] = 0;
+    int old = 0;
+    for (int j = 1; j < m; ++j) {
+        const float ox = xyz[old * 3 + 0], oy = xyz[old * 3 + 1], oz = xyz[old * 3 + 2];
+        unsigned hi = 0u, lo = 0u;
+        for (int k = tid; k < n; k += 256) {
+            const float d = rtk_sqdist(xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2], ox, oy, oz);
+            const float d2 = fminf(d, temp[k]);
+            temp[k] = d2;
+            const unsigned nr = ~(((unsigned)(k % block) << 16) | (unsigned)(k / block));
+            const unsigned h = __float_as_uint(d2);
+            const bool take = (h > hi) || (h == hi && nr > lo);
+            hi = take ? h : hi;
+            lo = take ? nr : lo;
+        }
+        wave_key_max(hi, lo);
+        if (lane == 0) { s_hi[wave] = hi; s_lo[wave] = lo; }
+        __syncthreads();
+        hi = s_hi[0]; lo = s_lo[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const bool take = (s_hi[w] > hi) || (s_hi[w] == hi && s_lo[w] > lo);
+            hi = take ? s_hi[w] : hi;
+            lo = take ? s_lo[w] : lo;
+        }
+        const unsigned rank = ~lo;
+        old = (int)((rank & 0xffffu) * (unsigned)block + (rank >> 16));
+        if (tid == 0) idxs[j] = old;
+        __syncthreads();
+    }
+}
+
+static int fps_block_size(int n) {  // cuda_utils.h:10-14 (host code in the reference as well)
+    const int pow_2 = (int)(log((double)n) / log(2.0));
+    int t = 1 << pow_2;
+    if (t > 1024) t = 1024;
+    if (t < 1) t = 1;
+    return t;
+}
+
+extern "C" int rtk_furthest_point_sampling(int b, int n, int npoint, const float *xyz, float *temp, int *idx,
+                                           rtk_stream_t stream) {
+    RTK_REQUIRE(b > 0 && n > 0 && xyz && temp && idx, "furthest_point_sampling: bad arguments (b=%d n=%d)", b, n);
+    if (npoint <= 0) return RTK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int block = fps_block_size(n);
+    RTK_REQUIRE(n / block < 65536, "furthest_point_sampling: n=%d too large", n);
+    if (n <= 64 * 4) fps_wave_kernel<4><<<b, 64, 0, s>>>(n, npoint, block, xyz, temp, idx);
+    else if (n <= 64 * 8) fps_wave_kernel<8><<<b, 64, 0, s>>>(n, npoint, block, xyz, temp, idx);
+    else if (n <= 64 * 16) fps_wave_kernel<16><<<b, 64, 0, s>>>(n, npoint, block, xyz, temp, idx);
+    else if (n <= 64 * 32) fps_wave_kernel<32><<<b, 64, 0, s>>>(n, npoint, block, xyz, temp, idx);
+    else fps_block_kernel<<<b, 256, 0, s>>>(n, npoint, block, xyz, temp, idx);
+    RTK_CHECK_LAUNCH("furthest_point_sampling");
+    return RTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gather_points / grad   (sampling_gpu.cu:8-24, 46-63)
+// ------------------------------------------------------------------------------------------------
+__global__ void gather_points_kernel(int c, int n, int m, const float *__restrict__ points,
+                                     const int *__restrict__ idx, float *__restrict__ out) {
+    const int bs = blockIdx.z, ci = blockIdx.y, pt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pt >= m) return;
+    out[((size_t)bs * c + ci) * m + pt] = points[((size_t)bs * c + ci) * n + idx[(size_t)bs * m + pt]];
+}
+
+__global__ void gather_points_grad_kernel(int c, int n, int m, const float *__restrict__ grad_out,
+                                          const int *__restrict__ idx, float *__restrict__ grad_points) {
+    const int bs = blockIdx.z, ci = blockIdx.y, pt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pt >= m) return;
+    atomicAdd(grad_points + ((size_t)bs * c + ci) * n + idx[(size_t)bs * m + pt], grad_out[((size_t)bs * c + ci) * m + pt]);
+}
+
+extern "C" int rtk_gather_points(int b, int c, int n, int npoint, const float *points, const int *idx, float *out,
+                                 rtk_stream_t stream) {
+    RTK_REQUIRE(b > 0 && c > 0 && n > 0 && npoint > 0 && points && idx && out, "gather_points: bad arguments");
+    RTK_REQUIRE(c <= 65535 && b <= 65535, "gather_points: c/b exceed grid limits");
+    gather_points_kernel<<<dim3(rtk_divup(npoint, 256), c, b), 256, 0, (hipStream_t)stream>>>(c, n, npoint, points, idx, out);
+    RTK_CHECK_LAUNCH("gather_points");
+    return RTK_OK;
+}
+
+extern "C" int rtk_gather_points_grad(int b, int c, int n, int npoint, const float *grad_out, const int *idx,
+                                      float *grad_points, rtk_stream_t stream) {
+    RTK_REQUIRE(b > 0 && c > 0 && n > 0 && npoint > 0 && grad_out && idx && grad_points, "gather_points_grad: bad arguments");
+    RTK_REQUIRE(c <= 65535 && b <= 65535, "gather_points_grad: c/b exceed grid limits");
+    gather_points_grad_kernel<<<dim3(rtk_divup(npoint, 256), c, b), 256, 0, (hipStream_t)stream>>>(c, n, npoint, grad_out, idx, grad_points);
+    RTK_CHECK_LAUNCH("gather_points_grad");
+    return RTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ball query   (ball_query_gpu.cu:9-45)
+//
+// Reference: one thread per centroid, serial O(n) scan over AoS points.  Here: the sample's cloud is
+// staged once per workgroup in LDS as SoA; a wave takes one centroid at a time, its 64 lanes test
+// 64 consecutive points, __ballot gives the hit mask and popcount-below gives each hit its rank in
+// index order -- the "first nsample in index order" semantics without any serial scan -- and the
+// scan stops (wave-uniformly) once nsample hits are found.
+// ------------------------------------------------------------------------------------------------
+#define BQ_WAVES 4
+#define BQ_CENTROIDS_PER_WAVE 8
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(64 * BQ_WAVES) void ball_query_kernel(int n, int m, float radius2, int nsample,
+                                                                    const float *__restrict__ new_xyz,
+                                                                    const float *__restrict__ xyz,
+                                                                    int *__restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bs = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    xyz += (size_t)bs * n * 3;
+    float *sx = smem, *sy = smem + n, *sz = smem + 2 * n;
+    if (USE_LDS) {
+        for (int k = tid; k < n; k += 64 * BQ_WAVES) {
+            sx[k] = xyz[k * 3 + 0];
+            sy[k] = xyz[k * 3 + 1];
+            sz[k] = xyz[k * 3 + 2];
+        }
+        __syncthreads();
+    }
+    const int c0 = (blockIdx.x * BQ_WAVES + wave) * BQ_CENTROIDS_PER_WAVE;
+    for (int ci = 0; ci < BQ_CENTROIDS_PER_WAVE; ++ci) {
+        const int pt = c0 + ci;
+        if (pt >= m) break;
+        const float *q = new_xyz + ((size_t)bs * m + pt) * 3;
+        const float qx = q[0], qy = q[1], qz = q[2];
+        int *out = idx + ((size_t)bs * m + pt) * nsample;
+        int cnt = 0, first = -1;
+        for (int base = 0; base < n && cnt < nsample; base += 64) {
+            const int k = base + lane;
+            bool hit = false;
+            if (k < n) {
+                const float px = USE_LDS ? sx[k] : xyz[k * 3 + 0];
+                const float py = USE_LDS ? sy[k] : xyz[k * 3 + 1];
+                const float pz = USE_LDS ? sz[k] : xyz[k * 3 + 2];
+                hit = rtk_sqdist(qx, qy, qz, px, py, pz) < radius2;
+            }
+            const unsigned long long mask = __ballot(hit);
+            if (mask) {
+                if (first < 0) first = base + __builtin_ctzll(mask);
+                const int rank = cnt + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                if (hit && rank < nsample) out[rank] = k;
+                cnt += __builtin_popcountll(mask);
+            }
+        }
+        if (first >= 0 && cnt < nsample) {
+            for (int l = cnt + lane; l < nsample; l += 64) out[l] = first;  // slots after the hits repeat the first hit
+        }
+    }
+}
+
+extern "C" int rtk_ball_query(int b, int n, int npoint, float radius, int nsample, const float *new_xyz,
+                              const float *xyz, int *idx, rtk_stream_t stream) {
+    RTK_REQUIRE(b > 0 && n > 0 && npoint > 0 && nsample > 0 && new_xyz && xyz && idx, "ball_query: bad arguments");
+    RTK_REQUIRE(b <= 65535, "ball_query: b exceeds grid limits");
+    const float r2 = radius * radius;  // fp32 product, as ball_query_gpu.cu:23
+    dim3 grid(rtk_divup(npoint, BQ_WAVES * BQ_CENTROIDS_PER_WAVE), b);
+    const size_t lds = (size_t)n * 3 * sizeof(float);
+    if (lds <= 64 * 1024)
+        ball_query_kernel<true><<<grid, 64 * BQ_WAVES, lds, (hipStream_t)stream>>>(n, npoint, r2, nsample, new_xyz, xyz, idx);
+    else
+        ball_query_kernel<false><<<grid, 64 * BQ_WAVES, 0, (hipStream_t)stream>>>(n, npoint, r2, nsample, new_xyz, xyz, idx);
+    RTK_CHECK_LAUNCH("ball_query");
+    return RTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// group_points / grad   (group_points_gpu.cu:47-66, 8-25)
+// ------------------------------------------------------------------------------------------------
+__global__ void group_points_kernel(int c, int n, int sn, const float *__restrict__ points,
+                                    const int *__restrict__ idx, float *__restrict__ out) {
+    const int bs = blockIdx.z, ci = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= sn) return;
+    out[((size_t)bs * c + ci) * sn + t] = points[((size_t)bs * c + ci) * n + idx[(size_t)bs * sn + t]];
+}
+
+__global__ void group_points_grad_kernel(int c, int n, int sn, const float *__restrict__ grad_out,
+                                         const int *__restrict__ idx, float *__restrict__ grad_points) {
+    const int bs = blockIdx.z, ci = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= sn) return;
+    atomicAdd(grad_points + ((size_t)bs * c + ci) * n + idx[(size_t)bs * sn + t], grad_out[((size_t)bs * c + ci) * sn + t]);
+}
+
+extern "C" int rtk_group_points(int b, int c, int n, int npoint, int nsample, const float *points, const int *idx,
+                                float *out, rtk_stream_t stream) {
+    RTK_REQUIRE(b > 0 && c > 0 && n > 0 && npoint > 0 && nsample > 0 && points && idx && out, "group_points: bad arguments");
+    RTK_REQUIRE(c <= 65535 && b <= 65535, "group_points: c/b exceed grid limits");
+    const int sn = npoint * nsample;
+    group_points_kernel<<<dim3(rtk_divup(sn, 256), c, b), 256, 0, (hipStream_t)stream>>>(c, n, sn, points, idx, out);
+    RTK_CHECK_LAUNCH("group_points");
+    return RTK_OK;
+}
+
+extern "C" int rtk_group_points_grad(int b, int c, int n, int npoint, int nsample, const float *grad_out,
+                                     const int *idx, float *grad_points, rtk_stream_t stream) {
+    RTK_REQUIRE(b > 0 && c > 0 && n > 0 && npoint > 0 && nsample > 0 && grad_out && idx && grad_points,
+                "group_points_grad: bad arguments");
+    RTK_REQUIRE(c <= 65535 && b <= 65535, "group_points_grad: c/b exceed grid limits");
+    const int sn = npoint * nsample;
+    group_points_grad_kernel<<<dim3(rtk_divup(sn, 256), c, b), 256, 0, (hipStream_t)stream>>>(c, n, sn, grad_out, idx, grad_points);
+    RTK_CHECK_LAUNCH("group_points_grad");
+    return RTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// three_nn   (interpolate_gpu.cu:81-124)
+// best* in the reference are doubles initialised to 1e40 and narrowed to float on store; a float
+// compare against +inf is the same predicate (d < 1e40  <=>  d < inf for every float d) and
+// (float)1e40 == inf, so float state reproduces it exactly.  Known cloud staged in LDS (SoA).
+// ------------------------------------------------------------------------------------------------
+template <bool USE_LDS>
+__global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float *__restrict__ unknown,
+                                                       const float *__restrict__ known, float *__restrict__ dist2,
+                                                       int *__restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bs = blockIdx.y, tid = threadIdx.x;
+    known += (size_t)bs * m * 3;
+    float *sx = smem, *sy = smem + m, *sz = smem + 2 * m;
+    if (USE_LDS) {
+        for (int k = tid; k < m; k += 256) {
+            sx[k] = known[k * 3 + 0];
+            sy[k] = known[k * 3 + 1];
+            sz[k] = known[k * 3 + 2];
+        }
+        __syncthreads();
+    }
+    const int pt = blockIdx.x * 256 + tid;
+    if (pt >= n) return;
+    const float *u = unknown + ((size_t)bs * n + pt) * 3;
+    const float ux = u[0], uy = u[1], uz = u[2];
+    float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+    int i1 = 0, i2 = 0, i3 = 0;
+    for (int k = 0; k < m; ++k) {
+        const float kx = USE_LDS ? sx[k] : known[k * 3 + 0];
+        const float ky = USE_LDS ? sy[k] : known[k * 3 + 1];
+        const float kz = USE_LDS ? sz[k] : known[k * 3 + 2];
+        const float d = rtk_sqdist(ux, uy, uz, kx, ky, kz);
+        if (d < b1) {
+            b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k;
+        } else if (d < b2) {
+            b3 = b2; i3 = i2; b2 = d; i2 = k;
+        } else if (d < b3) {
+            b3 = d; i3 = k;
+        }
+    }
+    float *od = dist2 + ((size_t)bs * n + pt) * 3;
+    int *oi = idx + ((size_t)bs * n + pt) * 3;
+    od[0] = b1; od[1] = b2; od[2] = b3;
+    oi[0] = i1; oi[1] = i2; oi[2] = i3;
+}
+
+extern "C" int rtk_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
+                            rtk_stream_t stream) {
+    RTK_REQUIRE(b > 0 && n > 0 && m > 0 && unknown && known && dist2 && idx, "three_nn: bad arguments");
+    RTK_REQUIRE(b <= 65535, "three_nn: b exceeds grid limits");
+    dim3 grid(rtk_divup(n, 256), b);
+    const size_t lds = (size_t)m * 3 * sizeof(float);
+    if (lds <= 64 * 1024)
+        three_nn_kernel<true><<<grid, 256, lds, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx);
+    else
+        three_nn_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx);
+    RTK_CHECK_LAUNCH("three_nn");
+    return RTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// knn   (interpolate_gpu.cu:9-57)  -- exported by the reference, unused on its live path.
+// Straight restatement: ascending insertion list per query thread (k <= 200, as the reference).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void knn_kernel(int n, int m, int k, const float *__restrict__ unknown,
+                                                 const float *__restrict__ known, float *__restrict__ dist2,
+                                                 int *__restrict__ idx) {
+    const int bs = blockIdx.y, pt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pt >= n) return;
+    const float *u = unknown + ((size_t)bs * n + pt) * 3;
+    known += (size_t)bs * m * 3;
+    const float ux = u[0], uy = u[1], uz = u[2];
+    float best[200];
+    int besti[200];
+    for (int i = 0; i < k; ++i) { best[i] = INFINITY; besti[i] = 0; }
+    for (int i = 0; i < m; ++i) {
+        const float d = rtk_sqdist(ux, uy, uz, known[i * 3 + 0], known[i * 3 + 1], known[i * 3 + 2]);
+        if (!(d < best[k - 1])) continue;
+        int j = k - 1;
+        while (j > 0 && d < best[j - 1]) { best[j] = best[j - 1]; besti[j] = besti[j - 1]; --j; }
+        best[j] = d;
+        besti[j] = i;
+    }
+    float *od = dist2 + ((size_t)bs * n + pt) * k;
+    int *oi = idx + ((size_t)bs * n + pt) * k;
+    for (int i = 0; i < k; ++i) { od[i] = best[i]; oi[i] = besti[i]; }
+}
+
+extern "C" int rtk_knn(int b, int n, int m, int k, const float *unknown, const float *known, float *dist2, int *idx,
+                       rtk_stream_t stream) {
+    RTK_REQUIRE(b > 0 && n > 0 && m > 0 && unknown && known && dist2 && idx, "knn: bad arguments");
+    RTK_REQUIRE(k >= 1 && k <= 200, "knn: k=%d outside [1,200] (the reference's fixed best[200])", k);
+    RTK_REQUIRE(b <= 65535, "knn: b exceeds grid limits");
+    knn_kernel<<<dim3(rtk_divup(n, 64), b), 64, 0, (hipStream_t)stream>>>(n, m, k, unknown, known, dist2, idx);
+    RTK_CHECK_LAUNCH("knn");
+    return RTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// three_interpolate / grad   (interpolate_gpu.cu:149-169, 192-214)
+// ------------------------------------------------------------------------------------------------
+__global__ void three_interpolate_kernel(int c, int m, int n, const float *__restrict__ points,
+                                         const int *__restrict__ idx, const float *__restrict__ weight,
+                                         float *__restrict__ out) {
+    const int bs = blockIdx.z, ci = blockIdx.y, pt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pt >= n) return;
+    const float *w = weight + ((size_t)bs * n + pt) * 3;
+    const int *id = idx + ((size_t)bs * n + pt) * 3;
+    const float *p = points + ((size_t)bs * c + ci) * m;
+    out[((size_t)bs * c + ci) * n + pt] = __fmaf_rn(w[2], p[id[2]], __fmaf_rn(w[1], p[id[1]], __fmul_rn(w[0], p[id[0]])));
+}
+
+__global__ void three_interpolate_grad_kernel(int c, int n, int m, const float *__restrict__ grad_out,
+                                              const int *__restrict__ idx, const float *__restrict__ weight,
+                                              float *__restrict__ grad_points) {
+    const int bs = blockIdx.z, ci = blockIdx.y, pt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pt >= n) return;
+    const float g = grad_out[((size_t)bs * c + ci) * n + pt];
+    const float *w = weight + ((size_t)bs * n + pt) * 3;
+    const int *id = idx + ((size_t)bs * n + pt) * 3;
+    float *gp = grad_points + ((size_t)bs * c + ci) * m;
+    atomicAdd(gp + id[0], __fmul_rn(g, w[0]));
+    atomicAdd(gp + id[1], __fmul_rn(g, w[1]));
+    atomicAdd(gp + id[2], __fmul_rn(g, w[2]));
+}
+
+extern "C" int rtk_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
+                                     const float *weight, float *out, rtk_stream_t stream) {
+    RTK_REQUIRE(b > 0 && c > 0 && m > 0 && n > 0 && points && idx && weight && out, "three_interpolate: bad arguments");
+    RTK_REQUIRE(c <= 65535 && b <= 65535, "three_interpolate: c/b exceed grid limits");
+    three_interpolate_kernel<<<dim3(rtk_divup(n, 256), c, b), 256, 0, (hipStream_t)stream>>>(c, m, n, points, idx, weight, out);
+    RTK_CHECK_LAUNCH("three_interpolate");
+    return RTK_OK;
+}
+
+extern "C" int rtk_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                          const float *weight, float *grad_points, rtk_stream_t stream) {
+    RTK_REQUIRE(b > 0 && c > 0 && m > 0 && n > 0 && grad_out && idx && weight && grad_points,
+                "three_interpolate_grad: bad arguments");
+    RTK_REQUIRE(c <= 65535 && b <= 65535, "three_interpolate_grad: c/b exceed grid limits");
+    three_interpolate_grad_kernel<<<dim3(rtk_divup(n, 256), c, b), 256, 0, (hipStream_t)stream>>>(c, n, m, grad_out, idx, weight, grad_points);
+    RTK_CHECK_LAUNCH("three_interpolate_grad");
+    return RTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// knn_point   (utils/model_utils/model_utils.py:17-39,85-99: square_distance + torch.topk)
+//
+// The reference materialises the (B,S,N) distance matrix with a matmul and runs torch.topk on it.
+// Here a thread owns a query, walks the LDS-staged SoA cloud and keeps the K best in a register
+// insertion network with static indices (K is a template constant, so nothing spills to scratch).
+// Distances follow the expansion formula of the arithmetic contract so the neighbour SET equals the
+// CPU reference's; output order is (distance, index) ascending.
+// ------------------------------------------------------------------------------------------------
+template <int K, bool USE_LDS>
+__global__ __launch_bounds__(256) void knn_point_kernel(int s, int n, int k, const float *__restrict__ query,
+                                                        const float *__restrict__ points, int64_t *__restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bs = blockIdx.y, tid = threadIdx.x;
+    points += (size_t)bs * n * 3;
+    float *sx = smem, *sy = smem + n, *sz = smem + 2 * n, *sn = smem + 3 * n;
+    if (USE_LDS) {
+        for (int j = tid; j < n; j += 256) {
+            const float px = points[j * 3 + 0], py = points[j * 3 + 1], pz = points[j * 3 + 2];
+            sx[j] = px; sy[j] = py; sz[j] = pz;
+            sn[j] = __fadd_rn(__fadd_rn(__fmul_rn(px, px), __fmul_rn(py, py)), __fmul_rn(pz, pz));
+        }
+        __syncthreads();
+    }
+    const int qi = blockIdx.x * 256 + tid;
+    if (qi >= s) return;
+    const float *q = query + ((size_t)bs * s + qi) * 3;
+    const float qx = q[0], qy = q[1], qz = q[2];
+    const float qn = __fadd_rn(__fadd_rn(__fmul_rn(qx, qx), __fmul_rn(qy, qy)), __fmul_rn(qz, qz));
+    float best[K];
+    int besti[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) { best[i] = INFINITY; besti[i] = 0x7fffffff; }
+    for (int j = 0; j < n; ++j) {
+        float px, py, pz, pn;
+        if (USE_LDS) {
+            px = sx[j]; py = sy[j]; pz = sz[j]; pn = sn[j];
+        } else {
+            px = points[j * 3 + 0]; py = points[j * 3 + 1]; pz = points[j * 3 + 2];
+            pn = __fadd_rn(__fadd_rn(__fmul_rn(px, px), __fmul_rn(py, py)), __fmul_rn(pz, pz));
+        }
+        const float dot = __fmaf_rn(qz, pz, __fmaf_rn(qy, py, __fmul_rn(qx, px)));
+        float d = __fadd_rn(__fadd_rn(__fmul_rn(-2.f, dot), qn), pn);
+        d = d > 0.f ? d : 0.f;  // torch.maximum(dist, 0)
+        // only the first k slots are live: slot k-1 is the current worst
+        bool ins = false;
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+            if (i == k - 1) ins = d < best[i];
+        if (ins) {
+#pragma unroll
+            for (int i = 0; i < K; ++i)
+                if (i == k - 1) { best[i] = d; besti[i] = j; }
+#pragma unroll
+            for (int i = K - 1; i > 0; --i) {
+                if (i <= k - 1) {
+                    const bool sw = best[i] < best[i - 1];  // strict: equal distances keep index order
+                    const float tb = best[i]; const int ti = besti[i];
+                    best[i] = sw ? best[i - 1] : tb; besti[i] = sw ? besti[i - 1] : ti;
+                    best[i - 1] = sw ? tb : best[i - 1]; besti[i - 1] = sw ? ti : besti[i - 1];
+                }
+            }
+        }
+    }
+    int64_t *o = idx + ((size_t)bs * s + qi) * k;
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+        if (i < k) o[i] = besti[i];
+}
+
+extern "C" int rtk_knn_point(int b, int s, int n, int k, const float *query, const float *points, int64_t *idx,
+                             rtk_stream_t stream) {
+    RTK_REQUIRE(b > 0 && s > 0 && n > 0 && query && points && idx, "knn_point: bad arguments");
+    RTK_REQUIRE(k >= 1 && k <= 32 && k <= n, "knn_point: k=%d outside [1, min(32, n=%d)]", k, n);
+    RTK_REQUIRE(b <= 65535, "knn_point: b exceeds grid limits");
+    dim3 grid(rtk_divup(s, 256), b);
+    const size_t lds = (size_t)n * 4 * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    const bool use_lds = lds <= 64 * 1024;
+    if (k <= 16) {
+        if (use_lds) knn_point_kernel<16, true><<<grid, 256, lds, st>>>(s, n, k, query, points, idx);
+        else knn_point_kernel<16, false><<<grid, 256, 0, st>>>(s, n, k, query, points, idx);
+    } else {
+        if (use_lds) knn_point_kernel<32, true><<<grid, 256, lds, st>>>(s, n, k, query, points, idx);
+        else knn_point_kernel<32, false><<<grid, 256, 0, st>>>(s, n, k, query, points, idx);
+    }
+    RTK_CHECK_LAUNCH("knn_point");
+    return RTK_OK;
+}

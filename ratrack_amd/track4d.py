@@ -1,0 +1,112 @@
+"""Track4D: the RaTrack model top (reference: models/track4d.py:13-106) with its Python API kept --
+`Track4D(args)`, `backbone(pc1, pc2, feature1, feature2, h)` -> 7-tuple, `forward(...)` -> 10-tuple,
+reference state-dict keys -- on top of the gfx950 kernels.
+
+Scope: `backbone()` is the hot path and is batch-general.  The post-backbone half of
+the reference's forward (CPU DBSCAN clustering, Affinity MLP, log-Sinkhorn association,
+models/track4d.py:56-63,108-223) is B=1 host-side logic ranked "next" in SURVEY.md 8(f); forward()
+returns the backbone results with empty association structures until that row is built.
+"""
+import torch
+import torch.nn as nn
+
+from .model_utils import FeatureCorrelator, FlowDecoder, PNHead
+
+
+class Affinity(nn.Module):
+    """Object-pair affinity MLP (models/track4d.py:226-246).  Not on the backbone path; kept so that
+    reference checkpoints load with identical keys."""
+
+    def __init__(self, emb_dims=137):
+        super().__init__()
+        d = emb_dims
+        self.affinity = nn.Sequential(nn.Linear(d, d * 4), nn.ReLU(), nn.Linear(d * 4, d * 2), nn.ReLU(),
+                                      nn.Linear(d * 2, d // 2), nn.ReLU(), nn.Linear(d // 2, d // 4), nn.ReLU(),
+                                      nn.Linear(d // 4, 1), nn.Sigmoid())
+
+    def forward(self, src_embedding, tgt_embedding):
+        return self.affinity((src_embedding - tgt_embedding)[0])
+
+
+class Track4D(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.rigid_thres = args.rigid_thres
+        self.rigid_pcs = 0.25
+        self.npoints = args.num_points          # stored, unused -- as in the reference
+        fc_inch = 2 * 128
+        self.pn_head = PNHead(args.npoints, 5)
+        self.fc_layer = FeatureCorrelator(16, in_channel=fc_inch * 2 + 3, mlp=[fc_inch, fc_inch, fc_inch])
+        self.fd_layer = FlowDecoder(fc_inch=fc_inch, args=args)
+        self.affinity = Affinity(141)
+        self.register_parameter("bin_score", nn.Parameter(torch.tensor(1.)))
+        self.max_id = 0
+        self._fused = None     # lazily built fused inference engine (ratrack_amd.fused)
+        self.use_fused = True
+
+    # ---- hot path ---------------------------------------------------------------------------------
+    def backbone(self, pc1, pc2, feature1, feature2, h):
+        """pc (B,3,N), feature (B,2,N) = (RCS, v_r), h (5,B,128) or None ->
+        (flow (B,3,N), h, cls (B,N), cor_features (B,256,N), pc1_features (B,256,N),
+         pc2_features (B,256,N), prop_features (B,128,N)).  models/track4d.py:67-106."""
+        if self.use_fused and not self.training and not torch.is_grad_enabled():
+            eng = self._fused_engine()
+            if eng is not None:
+                return eng.backbone(pc1, pc2, feature1, feature2, h)
+        xyz1_new, f1 = self.pn_head(pc1.permute(0, 2, 1).contiguous(), feature1)
+        xyz2_new, f2 = self.pn_head(pc2.permute(0, 2, 1).contiguous(), feature2)
+        g1 = torch.max(f1, -1)[0].unsqueeze(2).expand(-1, -1, pc1.size(2))
+        g2 = torch.max(f2, -1)[0].unsqueeze(2).expand(-1, -1, pc2.size(2))
+        pc1_features = torch.cat((f1, g1), dim=1)
+        pc2_features = torch.cat((f2, g2), dim=1)
+        cor_features = self.fc_layer(pc1, pc2, pc1_features, pc2_features)
+        output, h, prop_features, cls = self.fd_layer(pc1, feature1, pc1_features, cor_features, h)
+        return output, h, cls, cor_features, pc1_features, pc2_features, prop_features
+
+    def _fused_engine(self):
+        if self._fused is None:
+            try:
+                from . import fused
+            except ImportError:
+                self._fused = False
+            else:
+                self._fused = fused.FusedBackbone(self)
+        return self._fused or None
+
+    def invalidate_fused(self):
+        """Call after changing weights (load_state_dict does it automatically)."""
+        self._fused = None
+
+    def load_state_dict(self, *a, **k):
+        self._fused = None
+        return super().load_state_dict(*a, **k)
+
+    def train(self, mode=True):
+        if mode:
+            self._fused = None      # folded BN constants go stale once training resumes
+        return super().train(mode)
+
+    def forward(self, pc1, pc2, feature1, feature2, h, objects_prev=None):
+        """Reference 10-tuple (models/track4d.py:49-65).  Detection/association is not built yet
+        (SURVEY.md 8(f) ranks 1-2): the association members come back empty."""
+        output, h, cls, cor, pc1_features, pc2_features, prop = self.backbone(pc1, pc2, feature1, feature2, h)
+        pc1_warp = pc1 + output
+        aff_list, aff_mat, indices1, confs = [], torch.zeros(1, 0, 0, device=pc1.device), None, []
+        objects, timeout_obj_curr, objects_curr = dict(), dict(), []
+        return h, pc1_warp, cls, aff_list, aff_mat, indices1, confs, objects, timeout_obj_curr, objects_curr
+
+
+class Args(dict):
+    """Attribute-style config (the reference's EasyDict, utils/parser_util.py:12-35); defaults are the
+    hot-path keys of configs.yaml (:5,:25,:31,:33)."""
+
+    def __init__(self, **kw):
+        base = dict(num_points=256, npoints=512, rigid_thres=0.15, min_obj_points=2)
+        base.update(kw)
+        super().__init__(base)
+        self.__dict__ = self
+
+
+def init_model(args=None, device="cuda"):
+    """Counterpart of models/model.py:17-43 (factory; no DataParallel -- see ratrack_amd/ddp.py)."""
+    return Track4D(args or Args()).to(device)
