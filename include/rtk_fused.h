@@ -1,0 +1,94 @@
+/*
+ * rtk_fused.h -- C ABI of the fused inference stages of librtk_hip.so.
+ *
+ * These entry points have no single counterpart in the reference: each one replaces a SEQUENCE of
+ * framework ops + pointnet2_cuda calls that the reference issues from Python, fused
+ * into one gfx950 kernel working on point-major (row = point, contiguous channels) fp32 tensors:
+ *
+ *   rtk_pointwise_mlp   [three_nn weights + three_interpolate + cat skip] -> [Conv 1x1 + BN + act] x L
+ *                       (lib/pointnet2_modules.py:140-158, lib/pytorch_utils.py:20-32,
+ *                        utils/model_utils/model_utils.py:308-357, nn.Linear bottlenecks :414-418)
+ *   rtk_sa_scale        group (xyz - centroid || features) -> SharedMLP -> max over the ball
+ *                       (lib/pointnet2_utils.py:269-292 + lib/pointnet2_modules.py:37-53)
+ *   rtk_cost_volume     kNN gather -> 3-layer MLP -> WeightNet -> weighted sum over neighbours
+ *                       (utils/model_utils/model_utils.py:216-236)
+ *   rtk_patch_cost      kNN gather -> WeightNet -> weighted sum          (model_utils.py:238-248)
+ *
+ * BatchNorm (eval mode) is folded into the packed weights/bias on the host; weights use the
+ * fragment-major packing documented in ratrack_amd/csrc/fused_common.h.  Same conventions as
+ * rtk_pointnet2.h: caller-allocated device buffers, explicit stream, 0 / negative status.
+ */
+#ifndef RTK_FUSED_H
+#define RTK_FUSED_H
+
+#include "rtk_pointnet2.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTK_MAX_SRC 4
+#define RTK_MAX_LAYERS 4
+
+/* One input segment of a concatenated per-point feature vector. */
+typedef struct {
+    const float *ptr;  /* (rows, pitch) point-major, or (samples, pitch) when per_sample != 0 */
+    int pitch;         /* floats per row, multiple of 4, buffer readable up to ceil4(channels) */
+    int channels;      /* valid channels; the segment occupies ceil16(channels) input slots */
+    int per_sample;    /* 1: row index = sample (broadcast over the sample's points) */
+} rtk_src_t;
+
+/* One 1x1-conv layer with folded BN: y = act(W x + b).  w_packed is [cin16][cout16][64][4] floats. */
+typedef struct {
+    const float *w_packed;
+    const float *bias; /* 16*cout16 floats (zero padded) */
+    int cin16, cout16; /* channel counts in units of 16 */
+    int act;           /* RTK_ACT_* (0 none, 1 relu, 2 leaky 0.1, 3 sigmoid) */
+} rtk_layer_t;
+
+/* Optional first segment produced by three-NN inverse-distance interpolation. */
+typedef struct {
+    const float *known_feats; /* (samples * m, pitch) point-major */
+    int pitch, channels, m;
+    const int *idx;       /* (rows, 3) int32, indices into the sample's m known points */
+    const float *dist2;   /* (rows, 3) squared distances from rtk_three_nn */
+} rtk_interp_t;
+
+/* rows = total points (samples * rows_per_sample).  Input vector = [interp segment (optional)] ||
+ * srcs[0] || srcs[1] ...; each segment padded to a multiple of 16 channels.  sample_bias (optional,
+ * (samples, 16*layers[0].cout16)) is added to layer 0's pre-activation.  Output: point-major
+ * (rows, out_pitch) at channel offset 0, or channel-major (samples, out_channels, rows_per_sample)
+ * when out_channel_major != 0; only out_channels channels are written. */
+RTK_EXPORT int rtk_pointwise_mlp(int rows, int rows_per_sample, const rtk_interp_t *interp, int nsrc,
+                                 const rtk_src_t *srcs, const float *sample_bias, int nlayers,
+                                 const rtk_layer_t *layers, float *out, int out_pitch, int out_channels,
+                                 int out_channel_major, rtk_stream_t stream);
+
+/* One scale of a set-abstraction level.  q (samples*n, q_pitch): per-point layer-1 projection of the
+ * features (BN scale folded); layer 1 = relu(q[idx] + Wx.(xyz[idx] - centroid) + b1) with
+ * w1xyz_packed the [1][c1_16][64][4] image of [Wx | b1]; then nlayers more packed layers; the last
+ * one's bias+ReLU is applied after the max over the nsample neighbours.  idx from rtk_ball_query.
+ * out (samples*npoint, out_pitch) receives 16*last.cout16 channels at out_offset. */
+RTK_EXPORT int rtk_sa_scale(int samples, int n, int npoint, int nsample, const float *xyz,
+                            const float *new_xyz, const int *idx, const float *q, int q_pitch, int c1_16,
+                            const float *w1xyz_packed, int nlayers, const rtk_layer_t *layers, float *out,
+                            int out_pitch, int out_offset, rtk_stream_t stream);
+
+/* Point-to-patch cost volume for k = 16 neighbours.  p1 (samples*n1, 256) / p2 (samples*n2, 256):
+ * first-layer projections of the query / neighbour features (bias folded into p1);
+ * layer 1 = leaky(p1[i] + p2[idx] + Wd.(xyz2[idx] - xyz1[i])), then layers[0..1] (256->256, leaky),
+ * WeightNet wn[0..2] (3->8->8->256, ReLU) on the same direction vectors, out = sum_k wn * feat. */
+RTK_EXPORT int rtk_cost_volume(int samples, int n1, int n2, const float *xyz1, const float *xyz2,
+                               const int64_t *knn_idx, const float *p1, const float *p2,
+                               const float *wd_packed, const rtk_layer_t *layers,
+                               const rtk_layer_t *wn, float *out, int out_pitch, rtk_stream_t stream);
+
+/* Patch-to-patch aggregation: out[i] = sum_k WeightNet(xyz[idx[i,k]] - xyz[i]) * feat[idx[i,k]]. */
+RTK_EXPORT int rtk_patch_cost(int samples, int n, const float *xyz, const int64_t *knn_idx,
+                              const float *feat, int feat_pitch, const rtk_layer_t *wn, float *out,
+                              int out_pitch, int out_channel_major, rtk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTK_FUSED_H */

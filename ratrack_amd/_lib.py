@@ -44,19 +44,28 @@ def load():
         lib = ctypes.CDLL(SO_PATH)
     except OSError as e:  # e.g. libamdhip64 missing
         raise RtkError("cannot load %s: %s" % (SO_PATH, e))
-    for name, argtypes in SIGNATURES.items():
-        fn = getattr(lib, name)
-        fn.argtypes = argtypes
-        fn.restype = _c_int
     lib.rtk_last_error.restype = ctypes.c_char_p
     lib.rtk_version.restype = _c_int
     _lib = lib
     return lib
 
 
+_bound = {}
+
+
+def _fn(name):
+    fn = _bound.get(name)
+    if fn is None:
+        fn = getattr(load(), name)        # AttributeError if the library does not export it
+        fn.argtypes = SIGNATURES[name]
+        fn.restype = _c_int
+        _bound[name] = fn
+    return fn
+
+
 def call(name, *args):
     lib = load()
-    rc = getattr(lib, name)(*args)
+    rc = _fn(name)(*args)
     if rc != 0:
         raise RtkError("%s failed (%d): %s" % (name, rc, lib.rtk_last_error().decode()))
     return rc

@@ -1,0 +1,215 @@
+// fused_common.h -- the "activation-stationary" fp32 MFMA micro-kernel every fused stage is built on.
+//
+// A wave owns a tile of 16 POSITIONS (points, or the 16 neighbours of one point).  Activations live
+// in registers in the C/D layout of v_mfma_f32_16x16x4_f32 and never leave them between layers:
+//
+//     lane = 16*g + j   (g = 0..3, j = 0..15)          h[u][r] = H[channel 16u + 4g + r][position j]
+//
+// A layer Y = W.X is computed transposed, Y^T tiles = W (A operand) x H (B operand):
+//     A[i][k=g] = W[16v + i][16u + 4g + r],   B[k=g][j] = h[u][r],   D -> acc[v][r'] = Y[16v + 4g + r'][j]
+// The contraction index inside one MFMA is the lane group g, so the k-order is a fixed permutation
+// of the channel order -- legal because the weights are packed on the host with the same permutation
+// (pack_layer() in ratrack_amd/fused.py: packed[u][v][lane][r] = W[16v + (lane&15)][16u + 4(lane>>4) + r]).
+// The D layout of layer L is exactly the B layout of layer L+1: bias + activation are applied in
+// place and the next layer starts, with zero shuffles, zero LDS traffic for activations.
+//
+// fp32-input MFMA is bit-for-bit an fmaf chain (MI355X guide), so the only difference to the
+// reference's conv2d is the summation ORDER; parity is within fp32 rounding (tests: 1e-4 rel).
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+#define RTK_ACT_NONE 0
+#define RTK_ACT_RELU 1
+#define RTK_ACT_LEAKY 2    // LeakyReLU(0.1)
+#define RTK_ACT_SIGMOID 3
+
+__device__ __forceinline__ f4 f4_zero() { return (f4){0.f, 0.f, 0.f, 0.f}; }
+
+__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ float act1(float x, int act) {
+    switch (act) {
+        case RTK_ACT_RELU: return fmaxf(x, 0.f);
+        case RTK_ACT_LEAKY: return x > 0.f ? x : 0.1f * x;
+        case RTK_ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
+        default: return x;
+    }
+}
+
+__device__ __forceinline__ f4 act4(f4 x, int act) {
+    return (f4){act1(x.x, act), act1(x.y, act), act1(x.z, act), act1(x.w, act)};
+}
+
+// Activation of a whole accumulator set.  `act` is wave-uniform (a kernel argument): branch once per
+// layer instead of letting the compiler evaluate every variant per element and select.
+template <int V>
+__device__ __forceinline__ void apply_act(f4 (&acc)[V], int act) {
+    if (act == RTK_ACT_RELU) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] = (f4){fmaxf(acc[v].x, 0.f), fmaxf(acc[v].y, 0.f), fmaxf(acc[v].z, 0.f), fmaxf(acc[v].w, 0.f)};
+    } else if (act == RTK_ACT_LEAKY) {
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+            acc[v] = (f4){fmaxf(acc[v].x, 0.1f * acc[v].x), fmaxf(acc[v].y, 0.1f * acc[v].y), fmaxf(acc[v].z, 0.1f * acc[v].z),
+                          fmaxf(acc[v].w, 0.1f * acc[v].w)};
+    } else if (act == RTK_ACT_SIGMOID) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] = act4(acc[v], RTK_ACT_SIGMOID);
+    }
+}
+
+// acc[v] += W[16v..16v+15][:] . h     W fragments read as one 16-byte load per (u, v) from `w`
+// (global or LDS pointer to the packed image [U][V][64] f4).  V independent accumulators are
+// interleaved in groups of 4 so that back-to-back MFMAs never depend on each other.
+template <int U, int V>
+__device__ __forceinline__ void mlp_layer(const f4 *__restrict__ w, int lane, const f4 (&h)[U], f4 (&acc)[V]) {
+    constexpr int G = V >= 4 ? 4 : V;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int v0 = 0; v0 < V; v0 += G) {
+            f4 a[G];
+#pragma unroll
+            for (int q = 0; q < G; ++q)
+                if (v0 + q < V) a[q] = w[(u * V + v0 + q) * 64 + lane];
+#pragma unroll
+            for (int q = 0; q < G; ++q) if (v0 + q < V) acc[v0 + q] = mfma4(a[q].x, h[u].x, acc[v0 + q]);
+#pragma unroll
+            for (int q = 0; q < G; ++q) if (v0 + q < V) acc[v0 + q] = mfma4(a[q].y, h[u].y, acc[v0 + q]);
+#pragma unroll
+            for (int q = 0; q < G; ++q) if (v0 + q < V) acc[v0 + q] = mfma4(a[q].z, h[u].z, acc[v0 + q]);
+#pragma unroll
+            for (int q = 0; q < G; ++q) if (v0 + q < V) acc[v0 + q] = mfma4(a[q].w, h[u].w, acc[v0 + q]);
+        }
+    }
+}
+
+// ---- LDS weight stream ----------------------------------------------------------------------------
+// The packed weights of a whole layer chain form one blob of NF fragments (1 fragment = one (u, v)
+// A-operand image = 64 lanes x 16 B = 1 KiB).  The workgroup streams the blob cyclically through a
+// double buffer of F fragments per half with global_load_lds (HBM/L2 -> LDS, no VGPR round trip):
+// while the waves run MFMAs on chunk k, chunk k+1 lands in the other half.  One barrier per chunk.
+// Fragment indices are compile-time constants after unrolling, so every `fi % F == 0` test folds.
+template <int NW, int F>
+struct WStream {
+    const f4 *blob;  // global, NF fragments
+    f4 *lds;         // 2 * F * 64 f4
+    int nf, nchunks, cur, buf, wave, lane;
+
+    __device__ __forceinline__ void issue(int chunk, int into) {
+        const int f0 = chunk * F;
+#pragma unroll
+        for (int i = 0; i < (F + NW - 1) / NW; ++i) {
+            const int f = wave + i * NW;
+            if (f < F && f0 + f < nf) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(blob + (size_t)(f0 + f) * 64 + lane),
+                                                 (__attribute__((address_space(3))) void *)(lds + (into * F + f) * 64), 16, 0, 0);
+            }
+        }
+    }
+    __device__ __forceinline__ void start(const f4 *blob_, f4 *lds_, int nf_, int wave_, int lane_) {
+        blob = blob_; lds = lds_; nf = nf_; wave = wave_; lane = lane_;
+        nchunks = (nf + F - 1) / F;
+        cur = 0; buf = 0;
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (nchunks > 1) issue(1, 1);
+    }
+    // move from the resident chunk to the next one (cyclic)
+    __device__ __forceinline__ void next() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf ^= 1;
+        cur = cur + 1 == nchunks ? 0 : cur + 1;
+        issue(cur + 1 == nchunks ? 0 : cur + 1, buf ^ 1);
+    }
+    __device__ __forceinline__ f4 frag(int f_in_chunk) const { return lds[(buf * F + f_in_chunk) * 64 + lane]; }
+    __device__ __forceinline__ void finish() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+
+// acc[v] += W . h with the weights coming from the stream; FBASE = index of the layer's first fragment
+// in the blob.  All waves of the workgroup must call this together (it contains barriers).
+// Software-pipelined by hand: the fragments of group i+1 are read from LDS while the 4*G MFMAs of
+// group i issue; sched_barrier keeps hipcc from hoisting more reads (it otherwise pulls a whole
+// chunk of fragments into registers and spills).
+template <int U, int V, int FBASE, int NW, int F>
+__device__ __forceinline__ void mlp_layer_ws(WStream<NW, F> &ws, const f4 (&h)[U], f4 (&acc)[V]) {
+    constexpr int G = V >= 4 ? 4 : V;
+    constexpr int GV = (V + G - 1) / G;     // groups per u
+    constexpr int NG = U * GV;
+    f4 a[2][G];
+    auto load_group = [&](int gi, f4 (&dst)[G]) {
+        const int u = gi / GV, v0 = (gi % GV) * G;
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            if (v0 + q < V) {
+                const int fi = FBASE + u * V + v0 + q;
+                if (fi % F == 0 && fi != 0) ws.next();
+                dst[q] = ws.frag(fi % F);
+            }
+        }
+    };
+    load_group(0, a[0]);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        const int u = gi / GV, v0 = (gi % GV) * G;
+        if (gi + 1 < NG) load_group(gi + 1, a[(gi + 1) & 1]);
+        f4(&c)[G] = a[gi & 1];
+#pragma unroll
+        for (int q = 0; q < G; ++q) if (v0 + q < V) acc[v0 + q] = mfma4(c[q].x, h[u].x, acc[v0 + q]);
+#pragma unroll
+        for (int q = 0; q < G; ++q) if (v0 + q < V) acc[v0 + q] = mfma4(c[q].y, h[u].y, acc[v0 + q]);
+#pragma unroll
+        for (int q = 0; q < G; ++q) if (v0 + q < V) acc[v0 + q] = mfma4(c[q].z, h[u].z, acc[v0 + q]);
+#pragma unroll
+        for (int q = 0; q < G; ++q) if (v0 + q < V) acc[v0 + q] = mfma4(c[q].w, h[u].w, acc[v0 + q]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// bias fragment of this lane for output block v: channels 16v + 4g .. +3
+__device__ __forceinline__ f4 bias_frag(const float *__restrict__ bias, int v, int g) {
+    return *reinterpret_cast<const f4 *>(bias + 16 * v + 4 * g);
+}
+
+// ---- reductions over the 16 positions of a tile (the 16 lanes of a DPP row) ---------------------
+// row_ror rotates within a 16-lane row, so 4 steps leave the full-row result in every lane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
+__device__ __forceinline__ float row_max16(float v) {
+    v = fmaxf(v, dpp_f<0x128>(v));  // row_ror:8
+    v = fmaxf(v, dpp_f<0x124>(v));  // row_ror:4
+    v = fmaxf(v, dpp_f<0x122>(v));  // row_ror:2
+    v = fmaxf(v, dpp_f<0x121>(v));  // row_ror:1
+    return v;
+}
+
+__device__ __forceinline__ float row_sum16(float v) {
+    v += dpp_f<0x128>(v);
+    v += dpp_f<0x124>(v);
+    v += dpp_f<0x122>(v);
+    v += dpp_f<0x121>(v);
+    return v;
+}
+
+// max over aligned sub-groups of GROUP (4 or 8) lanes within the row
+template <int GROUP>
+__device__ __forceinline__ float row_max_group(float v) {
+    if (GROUP >= 16) return row_max16(v);
+    // quad_perm / row_ror do not respect sub-group boundaries for 8; use xor-style swaps via ds_swizzle-free DPP:
+    // row_ror would mix groups, so use quad_perm for 1,2 and row_half_mirror-free shuffles for 4.
+    v = fmaxf(v, dpp_f<0xB1>(v));   // quad_perm:[1,0,3,2]  (xor 1)
+    v = fmaxf(v, dpp_f<0x4E>(v));   // quad_perm:[2,3,0,1]  (xor 2)
+    if (GROUP >= 8) {
+        // xor 4 inside each 8-lane half: row_half_mirror (0x141) maps lane i -> 7 - i within each half;
+        // after the quad reductions every quad is uniform, so mirroring reaches the other quad.
+        v = fmaxf(v, dpp_f<0x141>(v));
+    }
+    return v;
+}

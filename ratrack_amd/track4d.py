@@ -70,7 +70,8 @@ class Track4D(nn.Module):
             except ImportError:
                 self._fused = False
             else:
-                self._fused = fused.FusedBackbone(self)
+                cls = getattr(fused, "FusedBackbone", None)
+                self._fused = cls(self) if cls is not None else False
         return self._fused or None
 
     def invalidate_fused(self):

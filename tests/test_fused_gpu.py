@@ -1,0 +1,122 @@
+"""GPU: the fused stages (include/rtk_fused.h) against fp64 references of the same op on seeded data."""
+import numpy as np
+import pytest
+import torch
+
+from ratrack_amd import fused as F
+from ratrack_amd import pointnet2_utils as PU
+
+from _util import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def ref_act(x, act):
+    if act == F.ACT_RELU:
+        return torch.relu(x)
+    if act == F.ACT_LEAKY:
+        return torch.nn.functional.leaky_relu(x, 0.1)
+    if act == F.ACT_SIGMOID:
+        return torch.sigmoid(x)
+    return x
+
+
+@pytest.mark.parametrize("rows,n,cin,widths,acts", [
+    (2 * 256, 256, 64, [96], [F.ACT_NONE]),
+    (3 * 242, 242, 96, [192], [F.ACT_NONE]),          # partial last tile, tiles straddling samples
+    (2 * 512, 512, 128, [64], [F.ACT_RELU]),
+    (5 * 256, 256, 128, [256], [F.ACT_NONE]),
+    (2 * 256, 256, 256, [128, 64, 32, 1], [F.ACT_RELU, F.ACT_RELU, F.ACT_RELU, F.ACT_SIGMOID]),
+    (70 * 256, 256, 128, [128, 64, 32, 3], [F.ACT_RELU, F.ACT_RELU, F.ACT_RELU, F.ACT_NONE]),   # > one pass of the grid
+])
+def test_pointwise_chain(rows, n, cin, widths, acts):
+    torch.manual_seed(rows + cin)
+    x = torch.randn(rows, cin, dtype=torch.float64)
+    layers, cur = [], cin
+    for w_, a in zip(widths, acts):
+        layers.append((torch.randn(w_, cur, dtype=torch.float64) / cur ** 0.5, torch.randn(w_, dtype=torch.float64) * 0.1, a))
+        cur = w_
+    sb = torch.randn(rows // n, F.ceil16(widths[0]), dtype=torch.float64) * 0.3
+    ref = x
+    for i, (w, b, a) in enumerate(layers):
+        ref = ref @ w.T + b
+        if i == 0:
+            ref = ref + sb[:, :widths[0]].repeat_interleave(n, 0)
+        ref = ref_act(ref, a)
+    chain = F.Chain(layers, DEV)
+    out = torch.full((rows, F.ceil16(widths[-1]) + 4), -7.0, device=DEV)
+    F.pointwise_mlp(rows, n, [(x.float().to(DEV).contiguous(), cin, False)], chain, out, sample_bias=sb.float().to(DEV).contiguous())
+    got = out[:, :widths[-1]].double().cpu()
+    assert rel_err(got, ref) < 2e-6
+    assert (out[:, widths[-1]:] == -7.0).all()          # nothing written beyond out_channels
+    # channel-major output variant
+    out_cm = torch.empty(rows // n, widths[-1], n, device=DEV)
+    F.pointwise_mlp(rows, n, [(x.float().to(DEV).contiguous(), cin, False)], chain, out_cm, sample_bias=sb.float().to(DEV).contiguous(),
+                    channel_major=True)
+    assert rel_err(out_cm.permute(0, 2, 1).reshape(rows, -1).double().cpu(), ref) < 2e-6
+
+
+def test_pointwise_multi_source_and_broadcast():
+    """[2 raw channels (padded slot) || 128 local || per-sample 256] -> 32, as the decoder's embedding projection."""
+    torch.manual_seed(1)
+    B, n = 3, 256
+    raw = torch.randn(B * n, 4, dtype=torch.float64)
+    raw[:, 2:] = 0
+    loc = torch.randn(B * n, 128, dtype=torch.float64)
+    cor = torch.randn(B * n, 256, dtype=torch.float64)
+    w = torch.randn(32, 16 + 128 + 256, dtype=torch.float64) * 0.05
+    b = torch.randn(32, dtype=torch.float64)
+    xin = torch.cat([torch.nn.functional.pad(raw, (0, 12)), loc, cor], 1)
+    ref = xin @ w.T + b
+    chain = F.Chain([(w, b, F.ACT_NONE)], DEV)
+    out = torch.empty(B * n, 32, device=DEV)
+    f = lambda t: t.float().to(DEV).contiguous()
+    F.pointwise_mlp(B * n, n, [(f(raw), 2, False), (f(loc), 128, False), (f(cor), 256, False)], chain, out)
+    assert rel_err(out.double().cpu(), ref) < 2e-6
+    # per-sample broadcast source
+    glob = torch.randn(B, 128, dtype=torch.float64)
+    ws = [torch.randn(128, 256, dtype=torch.float64) * 0.05, torch.randn(64, 128, dtype=torch.float64) * 0.1,
+          torch.randn(32, 64, dtype=torch.float64) * 0.1, torch.randn(3, 32, dtype=torch.float64) * 0.1]
+    ref2 = torch.cat([loc, glob.repeat_interleave(n, 0)], 1)
+    for i, w_ in enumerate(ws):
+        ref2 = ref2 @ w_.T
+        if i < 3:
+            ref2 = torch.relu(ref2)
+    chain2 = F.Chain([(w_, torch.zeros(w_.shape[0], dtype=torch.float64), F.ACT_RELU if i < 3 else F.ACT_NONE)
+                      for i, w_ in enumerate(ws)], DEV)
+    out2 = torch.empty(B * n, 4, device=DEV)
+    F.pointwise_mlp(B * n, n, [(f(loc), 128, False), (f(glob), 128, True)], chain2, out2, out_channels=3)
+    assert rel_err(out2[:, :3].double().cpu(), ref2) < 2e-6
+
+
+@pytest.mark.parametrize("n_unknown,m,cint,cskip", [(512, 512, 64, 64), (512, 512, 128, 32), (256, 512, 128, 0), (242, 512, 128, 0)])
+def test_pointwise_interp_prologue(n_unknown, m, cint, cskip):
+    """FP module: three_nn weights + three_interpolate + cat(skip) + conv/BN/ReLU in one kernel."""
+    torch.manual_seed(n_unknown + cint)
+    B = 2
+    unknown = torch.randn(B, n_unknown, 3) * 5
+    known = torch.randn(B, m, 3) * 5
+    known[:, :50] = unknown[:, :50]                 # exact matches: w0 == 1 after normalisation
+    kf = torch.randn(B, m, cint)
+    skip = torch.randn(B, n_unknown, cskip) if cskip else None
+    w = torch.randn(128, cint + cskip, dtype=torch.float64) * 0.1
+    b = torch.randn(128, dtype=torch.float64) * 0.1
+    from ratrack_amd import pointnet2_hip
+    d2 = torch.empty(B, n_unknown, 3, device=DEV)
+    idx = torch.empty(B, n_unknown, 3, dtype=torch.int32, device=DEV)
+    pointnet2_hip.three_nn_wrapper(B, n_unknown, m, unknown.to(DEV), known.to(DEV), d2, idx)
+    # reference in fp64 with the module path's formula
+    dist = torch.sqrt(d2.cpu().double())
+    r = 1.0 / (dist + 1e-8)
+    wgt = r / r.sum(2, keepdim=True)
+    gathered = torch.stack([kf[bb][idx[bb].cpu().long()] for bb in range(B)]).double()     # (B,n,3,C)
+    interp = (gathered * wgt[..., None]).sum(2)
+    xin = torch.cat([interp, skip.double()], 2) if cskip else interp
+    ref = torch.relu(xin.reshape(B * n_unknown, -1) @ w.T + b)
+    chain = F.Chain([(w, b, F.ACT_RELU)], DEV)
+    out = torch.empty(B * n_unknown, 128, device=DEV)
+    srcs = [(skip.reshape(B * n_unknown, cskip).to(DEV).contiguous(), cskip, False)] if cskip else []
+    F.pointwise_mlp(B * n_unknown, n_unknown, srcs, chain, out,
+                    interp=(kf.reshape(B * m, cint).to(DEV).contiguous(), cint, m, idx.reshape(-1, 3), d2.reshape(-1, 3)))
+    assert rel_err(out.double().cpu(), ref) < 5e-6
