@@ -18,6 +18,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 #define RTK_ACT_NONE 0
@@ -91,58 +93,68 @@ __device__ __forceinline__ void mlp_layer(const f4 *__restrict__ w, int lane, co
 // A-operand image = 64 lanes x 16 B = 1 KiB).  The workgroup streams the blob cyclically through a
 // double buffer of F fragments per half with global_load_lds (HBM/L2 -> LDS, no VGPR round trip):
 // while the waves run MFMAs on chunk k, chunk k+1 lands in the other half.  One barrier per chunk.
-// Fragment indices are compile-time constants after unrolling, so every `fi % F == 0` test folds.
-template <int NW, int F>
+// Fragment indices are compile-time constants (index_sequence expansion), so every `fi % F == 0`
+// test and every bounds check folds away.
+template <int NW, int F, int NF>
 struct WStream {
-    const f4 *blob;  // global, NF fragments
-    f4 *lds;         // 2 * F * 64 f4
-    int nf, nchunks, cur, buf, wave, lane;
+    static constexpr int NCHUNKS = (NF + F - 1) / F;
+    const char *blob;  // wave-uniform base of the packed weights
+    f4 *lds;           // 2 * F * 64 f4
+    unsigned lane_off; // byte offset of this lane's 16-byte slot inside fragment `wave`
+    int cur, buf, wave, lane;
 
+    // chunk index is wave-uniform; `into` selects the half of the double buffer.  The source address is
+    // written as (uniform 64-bit base) + (32-bit per-lane offset) so that it selects the SGPR-base form of
+    // global_load_lds and there is no per-call 64-bit VGPR address for the compiler to hoist and spill.
     __device__ __forceinline__ void issue(int chunk, int into) {
-        const int f0 = chunk * F;
+        const char *base = blob + (size_t)chunk * F * 1024;
 #pragma unroll
         for (int i = 0; i < (F + NW - 1) / NW; ++i) {
             const int f = wave + i * NW;
-            if (f < F && f0 + f < nf) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(blob + (size_t)(f0 + f) * 64 + lane),
+            bool ok = f < F;
+            if (NF % F != 0) ok = ok && (chunk * F + f < NF);   // only the last chunk of a ragged blob is partial
+            if (ok) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (size_t)i * NW * 1024 + lane_off),
                                                  (__attribute__((address_space(3))) void *)(lds + (into * F + f) * 64), 16, 0, 0);
             }
         }
     }
-    __device__ __forceinline__ void start(const f4 *blob_, f4 *lds_, int nf_, int wave_, int lane_) {
-        blob = blob_; lds = lds_; nf = nf_; wave = wave_; lane = lane_;
-        nchunks = (nf + F - 1) / F;
+    __device__ __forceinline__ void start(const f4 *blob_, f4 *lds_, int wave_, int lane_) {
+        lds = lds_; wave = wave_; lane = lane_;
+        blob = reinterpret_cast<const char *>(blob_);
+        lane_off = (unsigned)(wave * 64 + lane) * 16u;
         cur = 0; buf = 0;
         issue(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (nchunks > 1) issue(1, 1);
+        if (NCHUNKS > 1) issue(1, 1);
     }
     // move from the resident chunk to the next one (cyclic)
     __device__ __forceinline__ void next() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         buf ^= 1;
-        cur = cur + 1 == nchunks ? 0 : cur + 1;
-        issue(cur + 1 == nchunks ? 0 : cur + 1, buf ^ 1);
+        cur = cur + 1 == NCHUNKS ? 0 : cur + 1;
+        // `cur` is a compile-time constant at every call site; hide that, otherwise hipcc precomputes the
+        // 64-bit source address of every load of every chunk outside the tile loop and spills them all.
+        asm volatile("" : "+s"(cur));
+        issue(cur + 1 == NCHUNKS ? 0 : cur + 1, buf ^ 1);
     }
     __device__ __forceinline__ f4 frag(int f_in_chunk) const { return lds[(buf * F + f_in_chunk) * 64 + lane]; }
     __device__ __forceinline__ void finish() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 
-// acc[v] += W . h with the weights coming from the stream; FBASE = index of the layer's first fragment
-// in the blob.  All waves of the workgroup must call this together (it contains barriers).
-// Software-pipelined by hand: the fragments of group i+1 are read from LDS while the 4*G MFMAs of
-// group i issue; sched_barrier keeps hipcc from hoisting more reads (it otherwise pulls a whole
-// chunk of fragments into registers and spills).
-template <int U, int V, int FBASE, int NW, int F>
-__device__ __forceinline__ void mlp_layer_ws(WStream<NW, F> &ws, const f4 (&h)[U], f4 (&acc)[V]) {
-    constexpr int G = V >= 4 ? 4 : V;
-    constexpr int GV = (V + G - 1) / G;     // groups per u
-    constexpr int NG = U * GV;
-    f4 a[2][G];
-    auto load_group = [&](int gi, f4 (&dst)[G]) {
-        const int u = gi / GV, v0 = (gi % GV) * G;
+// One group step of a layer: read the fragments of group GI+1 from LDS (crossing into the next chunk
+// of the stream if needed) while the 4*G MFMAs of group GI issue.  GI is a template constant so that
+// h[u], acc[v] and the a[] ping-pong are all statically indexed (nothing can fall to scratch).
+template <int U, int V, int FBASE, int GI, class WS, int F>
+struct LayerStep {
+    static constexpr int G = V >= 4 ? 4 : V;
+    static constexpr int GV = (V + G - 1) / G;
+    static constexpr int NG = U * GV;
+    template <int GJ>
+    static __device__ __forceinline__ void load(WS &ws, f4 (&dst)[G]) {
+        constexpr int u = GJ / GV, v0 = (GJ % GV) * G;
 #pragma unroll
         for (int q = 0; q < G; ++q) {
             if (v0 + q < V) {
@@ -151,13 +163,11 @@ __device__ __forceinline__ void mlp_layer_ws(WStream<NW, F> &ws, const f4 (&h)[U
                 dst[q] = ws.frag(fi % F);
             }
         }
-    };
-    load_group(0, a[0]);
-#pragma unroll
-    for (int gi = 0; gi < NG; ++gi) {
-        const int u = gi / GV, v0 = (gi % GV) * G;
-        if (gi + 1 < NG) load_group(gi + 1, a[(gi + 1) & 1]);
-        f4(&c)[G] = a[gi & 1];
+    }
+    static __device__ __forceinline__ void run(WS &ws, const f4 (&h)[U], f4 (&acc)[V], f4 (&a)[2][G]) {
+        constexpr int u = GI / GV, v0 = (GI % GV) * G;
+        if constexpr (GI + 1 < NG) load<GI + 1>(ws, a[(GI + 1) & 1]);
+        f4(&c)[G] = a[GI & 1];
 #pragma unroll
         for (int q = 0; q < G; ++q) if (v0 + q < V) acc[v0 + q] = mfma4(c[q].x, h[u].x, acc[v0 + q]);
 #pragma unroll
@@ -168,6 +178,39 @@ __device__ __forceinline__ void mlp_layer_ws(WStream<NW, F> &ws, const f4 (&h)[U
         for (int q = 0; q < G; ++q) if (v0 + q < V) acc[v0 + q] = mfma4(c[q].w, h[u].w, acc[v0 + q]);
         __builtin_amdgcn_sched_barrier(0);
     }
+};
+
+template <int U, int V, int FBASE, class WS, int F, int... GI>
+__device__ __forceinline__ void mlp_layer_ws_impl(WS &ws, const f4 (&h)[U], f4 (&acc)[V], std::integer_sequence<int, GI...>) {
+    constexpr int G = V >= 4 ? 4 : V;
+    f4 a[2][G];
+    LayerStep<U, V, FBASE, 0, WS, F>::template load<0>(ws, a[0]);
+    (LayerStep<U, V, FBASE, GI, WS, F>::run(ws, h, acc, a), ...);
+}
+
+// acc[v] += W . h with the weights coming from the stream; FBASE = index of the layer's first fragment
+// in the blob.  All waves of the workgroup must call this together (it contains barriers).
+template <int U, int V, int FBASE, int NW, int F, int NF>
+__device__ __forceinline__ void mlp_layer_ws(WStream<NW, F, NF> &ws, const f4 (&h)[U], f4 (&acc)[V]) {
+    constexpr int G = V >= 4 ? 4 : V;
+    constexpr int NG = U * ((V + G - 1) / G);
+    mlp_layer_ws_impl<U, V, FBASE, WStream<NW, F, NF>, F>(ws, h, acc, std::make_integer_sequence<int, NG>{});
+}
+
+// Weights resident in LDS (image [U][V][64] f4 at `w`): same pipeline without the stream.
+struct WResident {
+    const f4 *w;
+    int lane;
+    __device__ __forceinline__ void next() {}
+    __device__ __forceinline__ f4 frag(int f) const { return w[f * 64 + lane]; }
+};
+
+template <int U, int V>
+__device__ __forceinline__ void mlp_layer_res(const f4 *w, int lane, const f4 (&h)[U], f4 (&acc)[V]) {
+    constexpr int G = V >= 4 ? 4 : V;
+    constexpr int NG = U * ((V + G - 1) / G);
+    WResident wr{w, lane};
+    mlp_layer_ws_impl<U, V, 0, WResident, (1 << 30)>(wr, h, acc, std::make_integer_sequence<int, NG>{});
 }
 
 // bias fragment of this lane for output block v: channels 16v + 4g .. +3

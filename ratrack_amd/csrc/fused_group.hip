@@ -1,0 +1,384 @@
+// fused_group.hip -- the neighbourhood stages of the backbone as single kernels:
+//
+//   rtk_sa_scale     QueryAndGroup + SharedMLP + max_pool2d of one MSG scale
+//                    (lib/pointnet2_utils.py:269-292, lib/pointnet2_modules.py:37-53)
+//   rtk_cost_volume  point-to-patch cost volume of FeatureCorrelator (model_utils.py:216-236)
+//   rtk_patch_cost   patch-to-patch aggregation (model_utils.py:238-248)
+//
+// The reference materialises the grouped tensor (B, C+3, S, ns) -- 539 MB for the 514-channel level --
+// and every activation after it.  Here a wave owns 16 (centroid, neighbour) pairs; the grouped
+// features never exist in memory: layer 1 is  q[idx] + Wx.(xyz[idx] - centroid) + b  where q is the
+// per-POINT projection of the features (linearity of the 1x1 conv) and the 3-channel offset term is
+// one MFMA k-step whose C-in is the gathered q row; every following layer runs register-to-register
+// (fused_common.h) and the neighbourhood reduction (max / weighted sum) is a DPP row reduction.
+#include <string.h>
+
+#include "rtk_common.h"
+#include "fused_common.h"
+#include "rtk_fused.h"
+
+// The single k-step "offset" layer: A operand image [V][64] floats, lane (g, i) holds W4[16v + i][g] with
+// W4 = [Wx | b] (Cout x 4); B operand: lane (g, j) holds (dx, dy, dz, 1)[g] of pair j.
+
+__device__ __forceinline__ f4 f4_max(f4 a, f4 b) { return (f4){fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)}; }
+__device__ __forceinline__ f4 f4_relu(f4 a) { return (f4){fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)}; }
+
+// =================================================================================================
+// rtk_sa_scale
+// =================================================================================================
+struct SaParams {
+    int samples, n, npoint;
+    const float *xyz, *new_xyz;
+    const int *idx;
+    const float *q;
+    int q_pitch;
+    const float *w1;        // offset layer image [V1][64]
+    const f4 *blob;         // layers 2(,3): packed, contiguous
+    const float *bias2, *bias3;
+    float *out;
+    int out_pitch, out_offset;
+};
+
+// NS = neighbours per centroid; V1/V2/V3 = layer widths / 16 (V3 = 0: two-layer MLP).
+template <int NS, int V1, int V2, int V3>
+__global__ __launch_bounds__(256) void sa_scale_kernel(const SaParams P) {
+    constexpr int NF = V1 * V2 + V2 * V3;
+    constexpr int VL = V3 ? V3 : V2;                 // width of the last layer
+    constexpr int TILES = NS > 16 ? NS / 16 : 1;     // tiles per work unit (NS = 32: one centroid = 2 tiles)
+    constexpr int CPT = NS >= 16 ? 1 : 16 / NS;      // centroids per tile
+    __shared__ __attribute__((aligned(16))) f4 s_w[NF * 64];
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    for (int i = threadIdx.x; i < NF * 64; i += blockDim.x) s_w[i] = P.blob[i];
+    float w1[V1];
+#pragma unroll
+    for (int v = 0; v < V1; ++v) w1[v] = P.w1[v * 64 + lane];
+    __syncthreads();
+
+    const long total_centroids = (long)P.samples * P.npoint;
+    const long units = (total_centroids + CPT - 1) / CPT;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int slot0 = j % NS;                         // neighbour slot of this lane within the first tile
+    for (long unit = wave; unit < units; unit += nwaves) {
+        long c = unit * CPT + (NS >= 16 ? 0 : j / NS);        // centroid of this lane (global index)
+        const bool valid = c < total_centroids;
+        if (!valid) c = total_centroids - 1;
+        const int b = (int)(c / P.npoint);
+        const float cg = g < 3 ? P.new_xyz[c * 3 + g] : 0.f;
+        f4 best[VL];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            const int slot = slot0 + 16 * t;
+            const int id = P.idx[c * NS + slot];
+            const long src = (long)b * P.n + id;
+            // offset operand: (neighbour - centroid) component g, or 1 for the bias column
+            const float bop = g < 3 ? __fsub_rn(P.xyz[src * 3 + g], cg) : 1.0f;
+            f4 a1[V1];
+            const float *qrow = P.q + src * P.q_pitch + 4 * g;
+#pragma unroll
+            for (int v = 0; v < V1; ++v) a1[v] = *reinterpret_cast<const f4 *>(qrow + 16 * v);
+#pragma unroll
+            for (int v = 0; v < V1; ++v) a1[v] = mfma4(w1[v], bop, a1[v]);      // + Wx.d + b1 (one MFMA k-step, C-in = q row)
+#pragma unroll
+            for (int v = 0; v < V1; ++v) a1[v] = f4_relu(a1[v]);
+            f4 a2[V2];
+            if constexpr (V3 == 0) {
+#pragma unroll
+                for (int v = 0; v < V2; ++v) a2[v] = f4_zero();     // last layer: bias + ReLU after the max
+                mlp_layer_res<V1, V2>(s_w, lane, a1, a2);
+#pragma unroll
+                for (int v = 0; v < V2; ++v) best[v] = t == 0 ? a2[v] : f4_max(best[v], a2[v]);
+            } else {
+#pragma unroll
+                for (int v = 0; v < V2; ++v) a2[v] = bias_frag(P.bias2, v, g);
+                mlp_layer_res<V1, V2>(s_w, lane, a1, a2);
+#pragma unroll
+                for (int v = 0; v < V2; ++v) a2[v] = f4_relu(a2[v]);
+                f4 a3[V3 ? V3 : 1];
+#pragma unroll
+                for (int v = 0; v < V3; ++v) a3[v] = f4_zero();
+                mlp_layer_res<V2, (V3 ? V3 : 1)>(s_w + V1 * V2 * 64, lane, a2, a3);
+#pragma unroll
+                for (int v = 0; v < V3; ++v) best[v] = t == 0 ? a3[v] : f4_max(best[v], a3[v]);
+            }
+        }
+        // max over the neighbours of each centroid (DPP within the 16-lane row), then bias + ReLU
+        const float *bl = V3 ? P.bias3 : P.bias2;
+#pragma unroll
+        for (int v = 0; v < VL; ++v) {
+            f4 m;
+            m.x = row_max_group<(NS > 16 ? 16 : NS)>(best[v].x);
+            m.y = row_max_group<(NS > 16 ? 16 : NS)>(best[v].y);
+            m.z = row_max_group<(NS > 16 ? 16 : NS)>(best[v].z);
+            m.w = row_max_group<(NS > 16 ? 16 : NS)>(best[v].w);
+            best[v] = f4_relu(m + bias_frag(bl, v, g));
+        }
+        if (valid && slot0 == 0) {
+            float *o = P.out + c * P.out_pitch + P.out_offset + 4 * g;
+#pragma unroll
+            for (int v = 0; v < VL; ++v) *reinterpret_cast<f4 *>(o + 16 * v) = best[v];
+        }
+    }
+}
+
+extern "C" int rtk_sa_scale(int samples, int n, int npoint, int nsample, const float *xyz, const float *new_xyz,
+                            const int *idx, const float *q, int q_pitch, int c1_16, const float *w1xyz_packed,
+                            int nlayers, const rtk_layer_t *layers, float *out, int out_pitch, int out_offset,
+                            rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && n > 0 && npoint > 0 && xyz && new_xyz && idx && q && w1xyz_packed && layers && out,
+                "sa_scale: bad arguments");
+    RTK_REQUIRE(nlayers == 1 || nlayers == 2, "sa_scale: nlayers=%d (1 or 2 layers after the offset layer)", nlayers);
+    RTK_REQUIRE(q_pitch % 4 == 0 && out_pitch % 4 == 0 && out_offset % 4 == 0, "sa_scale: pitches/offset must be multiples of 4");
+    RTK_REQUIRE(layers[0].cin16 == c1_16 && (nlayers == 1 || (layers[1].cin16 == layers[0].cout16 &&
+                layers[1].w_packed == layers[0].w_packed + (size_t)layers[0].cin16 * layers[0].cout16 * 256)),
+                "sa_scale: layer chain mismatch / not contiguous");
+    SaParams P;
+    P.samples = samples; P.n = n; P.npoint = npoint;
+    P.xyz = xyz; P.new_xyz = new_xyz; P.idx = idx; P.q = q; P.q_pitch = q_pitch;
+    P.w1 = w1xyz_packed;
+    P.blob = reinterpret_cast<const f4 *>(layers[0].w_packed);
+    P.bias2 = layers[0].bias;
+    P.bias3 = nlayers == 2 ? layers[1].bias : nullptr;
+    P.out = out; P.out_pitch = out_pitch; P.out_offset = out_offset;
+    const int v1 = c1_16, v2 = layers[0].cout16, v3 = nlayers == 2 ? layers[1].cout16 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    const long centroids = (long)samples * npoint;
+    const int cpt = nsample >= 16 ? 1 : 16 / nsample;
+    const long units = (centroids + cpt - 1) / cpt;
+    int blocks = (int)((units + 3) / 4);
+    if (blocks > 2048) blocks = 2048;
+    const long key = (((long)nsample * 32 + v1) * 32 + v2) * 32 + v3;
+#define SA_CASE(ns, a, b, c)                                              \
+    case (((long)(ns) * 32 + (a)) * 32 + (b)) * 32 + (c):                 \
+        sa_scale_kernel<ns, a, b, c><<<blocks, 256, 0, s>>>(P);           \
+        break;
+    switch (key) {
+        SA_CASE(4, 1, 1, 2)     // sa1 scale 0: r=2,  ns=4,  16-16-32
+        SA_CASE(8, 1, 1, 2)     // sa1 scale 1: r=4,  ns=8,  16-16-32
+        SA_CASE(8, 2, 2, 0)     // sa2 scale 0: r=4,  ns=8,  32-32
+        SA_CASE(16, 2, 4, 0)    // sa2 scale 1: r=8,  ns=16, 32-64
+        SA_CASE(16, 4, 4, 0)    // sa3 scale 0: r=8,  ns=16, 64-64
+        SA_CASE(32, 4, 4, 0)    // sa3 scale 1: r=16, ns=32, 64-64
+        default:
+            rtk_set_error("sa_scale: no kernel instance for nsample=%d widths=(%d,%d,%d)x16", nsample, v1, v2, v3);
+            return RTK_ERR_UNSUPPORTED;
+    }
+#undef SA_CASE
+    RTK_CHECK_LAUNCH("sa_scale");
+    return RTK_OK;
+}
+
+// =================================================================================================
+// WeightNet on direction vectors (model_utils.py:359-390, bn=False): 3 -> 8 -> 8 -> C, ReLU after
+// every conv.  Layer a is the single k-step offset layer ([Wa | ba] image), layer b one 16x16
+// fragment, layer c [1][VC] fragments.  Returns relu(Wc.relu(Wb.relu(Wa.d+ba)+bb)+bc)[16v..] for one v.
+// =================================================================================================
+struct WnWeights {
+    const float *wa;   // [1][64] offset image (8 outputs padded to 16)
+    const f4 *wb;      // 1 fragment
+    const f4 *wc;      // VC fragments
+    const float *bb, *bc;
+};
+
+__device__ __forceinline__ f4 weightnet_hidden(const WnWeights &W, int lane, int g, float bop) {
+    f4 t1 = f4_zero();
+    t1 = mfma4(W.wa[lane], bop, t1);
+    t1 = f4_relu(t1);
+    f4 t2 = bias_frag(W.bb, 0, g);
+    const f4 fb = W.wb[lane];
+    t2 = mfma4(fb.x, t1.x, t2);
+    t2 = mfma4(fb.y, t1.y, t2);
+    t2 = mfma4(fb.z, t1.z, t2);
+    t2 = mfma4(fb.w, t1.w, t2);
+    return f4_relu(t2);
+}
+
+__device__ __forceinline__ f4 weightnet_out(const WnWeights &W, int lane, int g, int v, f4 t2) {
+    f4 o = bias_frag(W.bc, v, g);
+    const f4 fc = W.wc[v * 64 + lane];
+    o = mfma4(fc.x, t2.x, o);
+    o = mfma4(fc.y, t2.y, o);
+    o = mfma4(fc.z, t2.z, o);
+    o = mfma4(fc.w, t2.w, o);
+    return f4_relu(o);
+}
+
+// =================================================================================================
+// rtk_cost_volume
+// =================================================================================================
+#define CV_NW 4
+#define CV_F 32
+#define CV_V 16          // 256 channels
+
+struct CvParams {
+    int samples, n1, n2;
+    const float *xyz1, *xyz2;
+    const int64_t *knn;
+    const float *p1, *p2;
+    const float *wd;              // offset layer image [16][64] ([Wd | 0])
+    const f4 *blob;               // layers 2,3 (256 + 256 fragments)
+    const float *bias2, *bias3;
+    WnWeights wn;
+    float *out;
+    int out_pitch;
+};
+
+__global__ __launch_bounds__(64 * CV_NW, 2) void cost_volume_kernel(const CvParams P) {
+    __shared__ __attribute__((aligned(16))) f4 s_w[2 * CV_F * 64];
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    const int wave_in_wg = threadIdx.x >> 6;
+    const long npts = (long)P.samples * P.n1;
+    const long per_iter = (long)gridDim.x * CV_NW;
+    const int iters = (int)((npts + per_iter - 1) / per_iter);
+    constexpr int NF = 2 * CV_V * CV_V;
+    WStream<CV_NW, CV_F, NF> ws;
+    ws.start(P.blob, s_w, wave_in_wg, lane);
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("" ::: "memory");   // keep loop-invariant weight/bias loads inside the loop (registers are the scarce resource)
+        long i = ((long)it * gridDim.x + blockIdx.x) * CV_NW + wave_in_wg;      // query point (global index)
+        const bool valid = i < npts;
+        if (!valid) i = npts - 1;
+        const int b = (int)(i / P.n1);
+        const long nb = (long)b * P.n2 + (long)P.knn[i * 16 + j];               // neighbour j in pc2
+        const float bop = g < 3 ? __fsub_rn(P.xyz2[nb * 3 + g], P.xyz1[i * 3 + g]) : 1.0f;
+        // layer 1: leaky(p1[i] + p2[nb] + Wd.d)     (bias folded into p1)
+        f4 h[CV_V];
+        {
+            const float *r1 = P.p1 + i * 256 + 4 * g, *r2 = P.p2 + nb * 256 + 4 * g;
+#pragma unroll
+            for (int v = 0; v < CV_V; ++v)
+                h[v] = *reinterpret_cast<const f4 *>(r1 + 16 * v) + *reinterpret_cast<const f4 *>(r2 + 16 * v);
+#pragma unroll
+            for (int v = 0; v < CV_V; ++v) h[v] = mfma4(P.wd[v * 64 + lane], bop, h[v]);
+            apply_act<CV_V>(h, RTK_ACT_LEAKY);
+        }
+        f4 a[CV_V];
+#pragma unroll
+        for (int v = 0; v < CV_V; ++v) a[v] = bias_frag(P.bias2, v, g);
+        mlp_layer_ws<CV_V, CV_V, 0>(ws, h, a);
+        apply_act<CV_V>(a, RTK_ACT_LEAKY);
+#pragma unroll
+        for (int v = 0; v < CV_V; ++v) h[v] = bias_frag(P.bias3, v, g);
+        mlp_layer_ws<CV_V, CV_V, CV_V * CV_V>(ws, a, h);
+        apply_act<CV_V>(h, RTK_ACT_LEAKY);
+        ws.next();   // wrap the stream to chunk 0 (NF > F)
+        // WeightNet(direction) and the weighted sum over the 16 neighbours
+        const f4 t2 = weightnet_hidden(P.wn, lane, g, bop);
+        float *o = P.out + i * P.out_pitch + 4 * g;
+#pragma unroll
+        for (int v = 0; v < CV_V; ++v) {
+            const f4 w = weightnet_out(P.wn, lane, g, v, t2);
+            f4 r;
+            r.x = row_sum16(w.x * h[v].x);
+            r.y = row_sum16(w.y * h[v].y);
+            r.z = row_sum16(w.z * h[v].z);
+            r.w = row_sum16(w.w * h[v].w);
+            if (valid && j == 0) *reinterpret_cast<f4 *>(o + 16 * v) = r;
+        }
+    }
+    ws.finish();
+}
+
+static int fill_wn(WnWeights &W, const rtk_layer_t *wn, const char *who) {
+    // wn[0]: offset image (w_packed = [1][64] floats, cout16 = 1); wn[1]: 16->16 (1 fragment); wn[2]: 16 -> C
+    if (!wn || !wn[0].w_packed || !wn[1].w_packed || !wn[2].w_packed || !wn[1].bias || !wn[2].bias ||
+        wn[1].cin16 != 1 || wn[1].cout16 != 1 || wn[2].cin16 != 1) {
+        rtk_set_error("%s: bad WeightNet layers", who);
+        return RTK_ERR_INVALID;
+    }
+    W.wa = wn[0].w_packed;
+    W.wb = reinterpret_cast<const f4 *>(wn[1].w_packed);
+    W.wc = reinterpret_cast<const f4 *>(wn[2].w_packed);
+    W.bb = wn[1].bias;
+    W.bc = wn[2].bias;
+    return RTK_OK;
+}
+
+extern "C" int rtk_cost_volume(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
+                               const float *p1, const float *p2, const float *wd_packed, const rtk_layer_t *layers,
+                               const rtk_layer_t *wn, float *out, int out_pitch, rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && n1 > 0 && n2 >= 16 && xyz1 && xyz2 && knn_idx && p1 && p2 && wd_packed && layers && out,
+                "cost_volume: bad arguments");
+    RTK_REQUIRE(layers[0].cin16 == 16 && layers[0].cout16 == 16 && layers[1].cin16 == 16 && layers[1].cout16 == 16 &&
+                layers[1].w_packed == layers[0].w_packed + 256 * 256, "cost_volume: expects two contiguous 256x256 layers");
+    RTK_REQUIRE(out_pitch % 4 == 0 && out_pitch >= 256, "cost_volume: bad out_pitch");
+    CvParams P;
+    P.samples = samples; P.n1 = n1; P.n2 = n2;
+    P.xyz1 = xyz1; P.xyz2 = xyz2; P.knn = knn_idx; P.p1 = p1; P.p2 = p2; P.wd = wd_packed;
+    P.blob = reinterpret_cast<const f4 *>(layers[0].w_packed);
+    P.bias2 = layers[0].bias; P.bias3 = layers[1].bias;
+    if (fill_wn(P.wn, wn, "cost_volume") != RTK_OK) return RTK_ERR_INVALID;
+    RTK_REQUIRE(wn[2].cout16 == 16, "cost_volume: WeightNet must produce 256 channels");
+    P.out = out; P.out_pitch = out_pitch;
+    const long npts = (long)samples * n1;
+    int blocks = (int)((npts + CV_NW - 1) / CV_NW);
+    if (blocks > 512) blocks = 512;
+    cost_volume_kernel<<<blocks, 64 * CV_NW, 0, (hipStream_t)stream>>>(P);
+    RTK_CHECK_LAUNCH("cost_volume");
+    return RTK_OK;
+}
+
+// =================================================================================================
+// rtk_patch_cost
+// =================================================================================================
+struct PcParams {
+    int samples, n;
+    const float *xyz;
+    const int64_t *knn;
+    const float *feat;
+    int feat_pitch;
+    WnWeights wn;
+    float *out;
+    int out_pitch, out_cm;
+};
+
+__global__ __launch_bounds__(256) void patch_cost_kernel(const PcParams P) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const long npts = (long)P.samples * P.n;
+    for (long i = wave; i < npts; i += nwaves) {
+        const int b = (int)(i / P.n);
+        const long nb = (long)b * P.n + (long)P.knn[i * 16 + j];
+        const float bop = g < 3 ? __fsub_rn(P.xyz[nb * 3 + g], P.xyz[i * 3 + g]) : 1.0f;
+        const f4 t2 = weightnet_hidden(P.wn, lane, g, bop);
+        const float *fr = P.feat + nb * P.feat_pitch + 4 * g;
+#pragma unroll
+        for (int v = 0; v < CV_V; ++v) {
+            const f4 w = weightnet_out(P.wn, lane, g, v, t2);
+            const f4 f = *reinterpret_cast<const f4 *>(fr + 16 * v);
+            f4 r;
+            r.x = row_sum16(w.x * f.x);
+            r.y = row_sum16(w.y * f.y);
+            r.z = row_sum16(w.z * f.z);
+            r.w = row_sum16(w.w * f.w);
+            if (j == 0) {
+                if (!P.out_cm) {
+                    *reinterpret_cast<f4 *>(P.out + i * P.out_pitch + 16 * v + 4 * g) = r;
+                } else {
+                    float *o = P.out + ((long)b * 256 + 16 * v + 4 * g) * P.n + (i - (long)b * P.n);
+                    o[0] = r.x; o[P.n] = r.y; o[2 * (long)P.n] = r.z; o[3 * (long)P.n] = r.w;
+                }
+            }
+        }
+    }
+}
+
+extern "C" int rtk_patch_cost(int samples, int n, const float *xyz, const int64_t *knn_idx, const float *feat,
+                              int feat_pitch, const rtk_layer_t *wn, float *out, int out_pitch, int out_channel_major,
+                              rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && n >= 16 && xyz && knn_idx && feat && out && feat_pitch % 4 == 0 && feat_pitch >= 256,
+                "patch_cost: bad arguments");
+    RTK_REQUIRE(out_channel_major || (out_pitch % 4 == 0 && out_pitch >= 256), "patch_cost: bad out_pitch");
+    PcParams P;
+    P.samples = samples; P.n = n; P.xyz = xyz; P.knn = knn_idx; P.feat = feat; P.feat_pitch = feat_pitch;
+    if (fill_wn(P.wn, wn, "patch_cost") != RTK_OK) return RTK_ERR_INVALID;
+    RTK_REQUIRE(wn[2].cout16 == 16, "patch_cost: WeightNet must produce 256 channels");
+    P.out = out; P.out_pitch = out_pitch; P.out_cm = out_channel_major;
+    const long npts = (long)samples * n;
+    int blocks = (int)((npts + 3) / 4);
+    if (blocks > 2048) blocks = 2048;
+    patch_cost_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(P);
+    RTK_CHECK_LAUNCH("patch_cost");
+    return RTK_OK;
+}

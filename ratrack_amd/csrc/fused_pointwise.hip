@@ -73,8 +73,8 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void pointwise_mlp_kernel(const PwPa
     const int tiles_per_iter = gridDim.x * PW_NW;
     const int iters = (ntiles + tiles_per_iter - 1) / tiles_per_iter;   // identical for every workgroup (barriers inside)
     constexpr int NF = U * V1 + V1 * V2 + V2 * V3 + V3 * V4;
-    WStream<PW_NW, PW_F> ws;
-    ws.start(reinterpret_cast<const f4 *>(P.layer[0].w_packed), s_w, NF, wave_in_wg, lane);
+    WStream<PW_NW, PW_F, NF> ws;
+    ws.start(reinterpret_cast<const f4 *>(P.layer[0].w_packed), s_w, wave_in_wg, lane);
 
     // 16-channel slot where each segment starts (wave-uniform)
     int ustart[RTK_MAX_SRC + 1];
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void pointwise_mlp_kernel(const PwPa
     const int uend = ustart[RTK_MAX_SRC];
 
     for (int it = 0; it < iters; ++it) {
+        asm volatile("" ::: "memory");   // keep loop-invariant loads/addresses inside the loop (registers are the scarce resource)
         const int t = (it * gridDim.x + blockIdx.x) * PW_NW + wave_in_wg;
         const int p_raw = t * 16 + j;
         const bool valid = p_raw < P.rows;

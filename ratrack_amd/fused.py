@@ -41,7 +41,7 @@ _lib.SIGNATURES.update({
     "rtk_pointwise_mlp": [_ci, _ci, ctypes.POINTER(_Interp), _ci, ctypes.POINTER(_Src), _vp, _ci, ctypes.POINTER(_Layer), _vp,
                           _ci, _ci, _ci, _vp],
     "rtk_sa_scale": [_ci] * 4 + [_vp] * 4 + [_ci, _ci, _vp, _ci, ctypes.POINTER(_Layer), _vp, _ci, _ci, _vp],
-    "rtk_cost_volume": [_ci] * 3 + [_vp] * 7 + [ctypes.POINTER(_Layer), ctypes.POINTER(_Layer), _vp, _ci, _vp],
+    "rtk_cost_volume": [_ci] * 3 + [_vp] * 6 + [ctypes.POINTER(_Layer), ctypes.POINTER(_Layer), _vp, _ci, _vp],
     "rtk_patch_cost": [_ci] * 2 + [_vp] * 3 + [_ci, ctypes.POINTER(_Layer), _vp, _ci, _ci, _vp],
 })
 
@@ -108,22 +108,293 @@ class Chain:
         self.cout16 = meta[-1][1]
 
 
-def pointwise_mlp(rows, rows_per_sample, srcs, chain, out, out_channels=None, sample_bias=None, interp=None,
-                  channel_major=False):
-    """srcs: list of (tensor2d (rows_or_samples, pitch), channels, per_sample).  out: (rows, pitch) point-major or
-    (samples, C, n) channel-major.  interp: (known_feats (samples*m, pitch), channels, m, idx (rows,3) int32, dist2 (rows,3))."""
+def _colptr(t, col=0):
+    """(data pointer, pitch) of a 2-D row-major view starting at column `col`."""
+    assert t.dim() == 2 and t.stride(1) == 1 and t.dtype == torch.float32
+    return t.data_ptr() + 4 * col, t.stride(0)
+
+
+def pointwise(rows, rows_per_sample, srcs, chain, out, out_channels=None, sample_bias=None, interp=None, channel_major=False):
+    """Like pointwise_mlp but sources are (2-D tensor or column-sliced view, channels, per_sample)."""
     arr = (_Src * max(len(srcs), 1))()
+    keep = []
     for i, (t, ch, per) in enumerate(srcs):
-        assert t.dtype == torch.float32 and t.is_contiguous() and t.device.type == "cuda"
-        arr[i].ptr, arr[i].pitch, arr[i].channels, arr[i].per_sample = t.data_ptr(), t.shape[-1], ch, int(per)
+        ptr, pitch = _colptr(t)
+        arr[i].ptr, arr[i].pitch, arr[i].channels, arr[i].per_sample = ptr, pitch, ch, int(per)
+        keep.append(t)
     ip = None
     if interp is not None:
         kf, ch, m, idx, d2 = interp
-        it = _Interp(kf.data_ptr(), kf.shape[-1], ch, m, idx.data_ptr(), d2.data_ptr())
-        ip = ctypes.pointer(it)
+        ptr, pitch = _colptr(kf)
+        ip = ctypes.pointer(_Interp(ptr, pitch, ch, m, idx.data_ptr(), d2.data_ptr()))
     oc = out_channels if out_channels is not None else chain.cout
-    pitch = 0 if channel_major else out.shape[-1]
+    if channel_major:
+        optr, opitch = out.data_ptr(), 0
+    else:
+        optr, opitch = _colptr(out)
     _lib.call("rtk_pointwise_mlp", rows, rows_per_sample, ip, len(srcs), arr,
-              sample_bias.data_ptr() if sample_bias is not None else None, chain.n, chain.arr, out.data_ptr(), pitch, oc,
+              sample_bias.data_ptr() if sample_bias is not None else None, chain.n, chain.arr, optr, opitch, oc,
               int(channel_major), _stream())
     return out
+
+
+pointwise_mlp = pointwise
+
+
+def offset_image(w4, device):
+    """[Wx | b] (Cout, 4) -> A-operand image of the single k-step offset layer: img[v][16g+i] = W4[16v+i][g]."""
+    cout = w4.shape[0]
+    V = ceil16(cout) // 16
+    wp = torch.zeros(V * 16, 4, dtype=torch.float32, device=device)
+    wp[:cout] = w4.float().to(device)
+    return wp.reshape(V, 16, 4).permute(0, 2, 1).contiguous().reshape(-1)
+
+
+class _WeightNet:
+    """WeightNet(3 -> 8 -> 8 -> 256), bn=False (model_utils.py:359-390) in kernel form."""
+
+    def __init__(self, sd, prefix, device):
+        g = lambda k: sd[prefix + k].double()
+        wa, ba = g(".mlp_convs.0.weight").reshape(8, 3), g(".mlp_convs.0.bias")
+        wb, bb = g(".mlp_convs.1.weight").reshape(8, 8), g(".mlp_convs.1.bias")
+        wc, bc = g(".mlp_convs.2.weight").reshape(-1, 8), g(".mlp_convs.2.bias")
+        self.wa = offset_image(torch.cat([wa, ba[:, None]], 1), device)
+        self.wb, self.bb = pack_layer(wb.to(device)), pad_bias(bb.to(device), 8)
+        self.wc, self.bc = pack_layer(wc.to(device)), pad_bias(bc.to(device), wc.shape[0])
+        arr = (_Layer * 3)()
+        arr[0].w_packed, arr[0].cin16, arr[0].cout16 = self.wa.data_ptr(), 1, 1
+        arr[1].w_packed, arr[1].bias, arr[1].cin16, arr[1].cout16 = self.wb.data_ptr(), self.bb.data_ptr(), 1, 1
+        arr[2].w_packed, arr[2].bias, arr[2].cin16, arr[2].cout16 = self.wc.data_ptr(), self.bc.data_ptr(), 1, ceil16(wc.shape[0]) // 16
+        self.arr = arr
+
+
+class _SAScale:
+    """One MSG scale: offset image + packed layers 2(,3) + the per-point projection matrix of layer 1."""
+
+    def __init__(self, sd, prefix, nsample, radius, device):
+        self.nsample, self.radius = nsample, float(radius)
+        ws = []
+        i = 0
+        while (prefix + ".layer%d.conv.weight" % i) in sd:
+            ws.append(fold_bn(sd[prefix + ".layer%d.conv.weight" % i], prefix + ".layer%d.bn.bn" % i, sd))
+            i += 1
+        w1, b1 = ws[0]
+        self.c1 = w1.shape[0]
+        self.wf = w1[:, 3:]                                         # (C1, Cf) acts on the features -> per-point projection
+        self.w1img = offset_image(torch.cat([w1[:, :3], b1[:, None]], 1), device)
+        self.chain = Chain([(w, b, ACT_RELU) for w, b in ws[1:]], device)
+        self.cout = ws[-1][0].shape[0]
+
+
+class _PNHeadWeights:
+    """Folded / composed weights of one PNHead (model_utils.py:393-424)."""
+
+    RADII = [[2, 4], [4, 8], [8, 16]]
+    NSAMPLES = [[4, 8], [8, 16], [16, 32]]
+
+    def __init__(self, sd, prefix, device):
+        d = lambda k: sd[prefix + k].double()
+        self.scales = [[_SAScale(sd, "%ssa%d.mlps.%d" % (prefix, l + 1, s), self.NSAMPLES[l][s], self.RADII[l][s], device)
+                        for s in range(2)] for l in range(3)]
+        # projection of the raw level-0 features for sa1 (both scales side by side); the caller supplies the split
+        self.wq1 = torch.cat([self.scales[0][0].wf, self.scales[0][1].wf], 0)            # (32, Cf)
+        # level transitions: nn.Linear bottleneck composed with the next level's layer-1 feature projection
+        self.trans = []
+        for l in (1, 2):
+            wl, bl = d("linear%d.weight" % l), d("linear%d.bias" % l)
+            rows, bias = [wl], [bl]
+            for s in range(2):
+                wf = self.scales[l][s].wf
+                rows.append(wf @ wl)
+                bias.append(wf @ bl)
+            self.trans.append(Chain([(torch.cat(rows, 0), torch.cat(bias, 0), ACT_NONE)], device))
+        self.lin3 = Chain([(d("linear3.weight"), d("linear3.bias"), ACT_NONE)], device)
+        self.fp = {}
+        for name in ("fp3", "fp2", "fp1"):
+            w, b = fold_bn(sd[prefix + name + ".mlp.layer0.conv.weight"], prefix + name + ".mlp.layer0.bn.bn", sd)
+            self.fp[name] = Chain([(w, b, ACT_RELU)], device)
+
+
+class Geometry:
+    """FPS centroids, ball-query indices and three-NN tables of one batch of clouds (feature independent,
+    so the decoder's PNHead over pc1 reuses the encoder's)."""
+
+    def __init__(self, xyz, npoint):
+        S_, n, _ = xyz.shape
+        dev = xyz.device
+        self.n, self.samples, self.npoint = n, S_, npoint
+        self.xyz = [xyz]
+        for lvl in range(3):
+            src = self.xyz[-1]
+            idx = torch.empty(S_, npoint, dtype=torch.int32, device=dev)
+            temp = torch.full((S_, src.shape[1]), 1e10, dtype=torch.float32, device=dev)
+            _native.furthest_point_sampling_wrapper(S_, src.shape[1], npoint, src, temp, idx)
+            # gather the centroids (B,S,3): plain indexing is the gather kernel's job on a (B,3,N) layout; here rows
+            new_xyz = torch.gather(src, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+            self.xyz.append(new_xyz)
+        self.ball = []
+        for lvl in range(3):
+            row = []
+            for s in range(2):
+                ns, r = _PNHeadWeights.NSAMPLES[lvl][s], _PNHeadWeights.RADII[lvl][s]
+                bidx = torch.zeros(S_, npoint, ns, dtype=torch.int32, device=dev)
+                _native.ball_query_wrapper(S_, self.xyz[lvl].shape[1], npoint, float(r), ns, self.xyz[lvl + 1], self.xyz[lvl], bidx)
+                row.append(bidx)
+            self.ball.append(row)
+        self.nn = {}
+        for name, (u, k) in {"fp3": (2, 3), "fp2": (1, 2), "fp1": (0, 1)}.items():
+            nu, m = self.xyz[u].shape[1], self.xyz[k].shape[1]
+            d2 = torch.empty(S_, nu, 3, dtype=torch.float32, device=dev)
+            idx = torch.empty(S_, nu, 3, dtype=torch.int32, device=dev)
+            _native.three_nn_wrapper(S_, nu, m, self.xyz[u], self.xyz[k], d2, idx)
+            self.nn[name] = (d2, idx, m)
+
+    def head(self, count):
+        """View on the first `count` samples (the pc1 half)."""
+        g = object.__new__(Geometry)
+        g.n, g.samples, g.npoint = self.n, count, self.npoint
+        g.xyz = [x[:count] for x in self.xyz]
+        g.ball = [[b[:count] for b in row] for row in self.ball]
+        g.nn = {k: (d2[:count], idx[:count], m) for k, (d2, idx, m) in self.nn.items()}
+        return g
+
+
+def sa_scale(geo, W, lvl, s, q, qcol, out, out_offset):
+    """One MSG scale (level lvl, scale s) of PNHead weights W on geometry geo; q[:, qcol:] holds its layer-1 projection."""
+    sc = W.scales[lvl][s]
+    qptr, qpitch = _colptr(q, qcol)
+    optr, opitch = _colptr(out)
+    src, dst = geo.xyz[lvl], geo.xyz[lvl + 1]
+    _lib.call("rtk_sa_scale", geo.samples, src.shape[1], geo.npoint, sc.nsample, src.data_ptr(), dst.data_ptr(),
+              geo.ball[lvl][s].data_ptr(), qptr, qpitch, ceil16(sc.c1) // 16, sc.w1img.data_ptr(),
+              sc.chain.n, sc.chain.arr, optr, opitch, out_offset, _stream())
+
+
+def run_pnhead(W, geo, q1):
+    """q1 (samples*n, 32): per-point sa1 layer-1 projections (scale 0 | scale 1).  Returns l0_points (samples*n, 128)."""
+    S_, n, S = geo.samples, geo.n, geo.npoint
+    dev = q1.device
+    new = lambda rows, c: torch.empty(rows, c, dtype=torch.float32, device=dev)
+    sa1 = new(S_ * S, 64)
+    sa_scale(geo, W, 0, 0, q1, 0, sa1, 0)
+    sa_scale(geo, W, 0, 1, q1, 16, sa1, 32)
+    t1 = pointwise(S_ * S, S, [(sa1, 64, False)], W.trans[0], new(S_ * S, 96))        # l1_points | q2_s0 | q2_s1
+    sa2 = new(S_ * S, 96)
+    sa_scale(geo, W, 1, 0, t1, 32, sa2, 0)
+    sa_scale(geo, W, 1, 1, t1, 64, sa2, 32)
+    t2 = pointwise(S_ * S, S, [(sa2, 96, False)], W.trans[1], new(S_ * S, 192))       # l2_points | q3_s0 | q3_s1
+    sa3 = new(S_ * S, 128)
+    sa_scale(geo, W, 2, 0, t2, 64, sa3, 0)
+    sa_scale(geo, W, 2, 1, t2, 128, sa3, 64)
+    l3 = pointwise(S_ * S, S, [(sa3, 128, False)], W.lin3, new(S_ * S, 64))
+    d2, idx, m = geo.nn["fp3"]
+    f3 = pointwise(S_ * S, S, [(t2[:, 0:64], 64, False)], W.fp["fp3"], new(S_ * S, 128),
+                   interp=(l3, 64, m, idx.reshape(-1, 3), d2.reshape(-1, 3)))
+    d2, idx, m = geo.nn["fp2"]
+    f2 = pointwise(S_ * S, S, [(t1[:, 0:32], 32, False)], W.fp["fp2"], new(S_ * S, 128),
+                   interp=(f3, 128, m, idx.reshape(-1, 3), d2.reshape(-1, 3)))
+    d2, idx, m = geo.nn["fp1"]
+    return pointwise(S_ * n, n, [], W.fp["fp1"], new(S_ * n, 128), interp=(f2, 128, m, idx.reshape(-1, 3), d2.reshape(-1, 3)))
+
+
+class FusedBackbone:
+    """Eval-mode Track4D.backbone (models/track4d.py:67-106) on the fused kernels."""
+
+    def __init__(self, model):
+        sd = {k: v.detach() for k, v in model.state_dict().items()}
+        dev = next(model.parameters()).device
+        self.dev = dev
+        self.npoint = model.pn_head.sa1.npoint
+        self.gru = model.fd_layer.torchGRU
+        self.enc = _PNHeadWeights(sd, "pn_head.", dev)
+        self.dec = _PNHeadWeights(sd, "fd_layer.mse.", dev)
+        z = lambda n: torch.zeros(n, dtype=torch.float64, device=sd["bin_score"].device)
+        # encoder sa1 projection of the raw (RCS, v_r) features
+        self.enc_q1 = Chain([(self.enc.wq1, z(32), ACT_NONE)], dev)
+        # cost volume (fc_layer): conv0 split by input segment [f1 loc|glob (256) || f2 loc|glob (256) || dir (3)]
+        w0 = sd["fc_layer.mlp_convs.0.weight"].double().reshape(256, 515)
+        b0 = sd["fc_layer.mlp_convs.0.bias"].double()
+        self.p1_loc = Chain([(w0[:, 0:128], z(256), ACT_NONE)], dev)
+        self.p1_glob = Chain([(w0[:, 128:256], b0, ACT_NONE)], dev)          # per-sample term, carries the bias
+        self.p2_loc = Chain([(w0[:, 256:384], z(256), ACT_NONE)], dev)
+        self.p2_glob = Chain([(w0[:, 384:512], z(256), ACT_NONE)], dev)
+        self.cv_wd = offset_image(torch.cat([w0[:, 512:515], z(256)[:, None]], 1), dev)
+        self.cv_layers = Chain([(sd["fc_layer.mlp_convs.%d.weight" % i].double().reshape(256, 256),
+                                 sd["fc_layer.mlp_convs.%d.bias" % i].double(), ACT_LEAKY) for i in (1, 2)], dev)
+        self.wn1 = _WeightNet(sd, "fc_layer.weightnet1", dev)
+        self.wn2 = _WeightNet(sd, "fc_layer.weightnet2", dev)
+        # heads
+        def predictor(prefix, first_cols):
+            layers = []
+            for i in range(3):
+                w, b = fold_bn(sd["%s.sf_mlp.%d.0.weight" % (prefix, i)], "%s.sf_mlp.%d.1" % (prefix, i), sd)
+                layers.append([w, b, ACT_RELU])
+            return layers
+        cp = predictor("fd_layer.cp", None)
+        wl, bl = sd["fd_layer.cp.linear.weight"].double(), sd["fd_layer.cp.linear.bias"].double()
+        wc2 = sd["fd_layer.cp.conv2.weight"].double().reshape(3, 32)
+        cp.append([wl @ wc2, bl, ACT_SIGMOID])                              # conv2 (no bias) then Linear(3,1): one linear map
+        self.cls_head = Chain([tuple(x) for x in cp], dev)
+        fp = predictor("fd_layer.fp", None)
+        w_first = fp[0][0]
+        self.flow_glob = Chain([(w_first[:, 128:256], fp[0][1], ACT_NONE)], dev)   # per-sample GRU term + folded BN shift
+        fp[0] = [w_first[:, 0:128], z(128), ACT_RELU]
+        fp.append([sd["fd_layer.fp.conv2.weight"].double().reshape(3, 32), z(3), ACT_NONE])
+        self.flow_head = Chain([tuple(x) for x in fp], dev)
+        # decoder embeddings [feature1 (2) || pc1 local (128) || pc1 global (128) || cor (256)] -> mse.sa1 projections
+        wq = self.dec.wq1                                                    # (32, 514)
+        wq_pad = torch.zeros(32, 16, dtype=torch.float64, device=wq.device)
+        wq_pad[:, :2] = wq[:, 0:2]
+        self.dec_q1 = Chain([(torch.cat([wq_pad, wq[:, 2:130], wq[:, 258:514]], 1), z(32), ACT_NONE)], dev)
+        self.dec_q1_glob = Chain([(wq[:, 130:258], z(32), ACT_NONE)], dev)
+
+    # --------------------------------------------------------------------------------------------------
+    def backbone(self, pc1, pc2, feature1, feature2, h):
+        B, _, N = pc1.shape
+        dev = pc1.device
+        new = lambda rows, c: torch.empty(rows, c, dtype=torch.float32, device=dev)
+        xyz = torch.cat([pc1, pc2], 0).permute(0, 2, 1).contiguous()                       # (2B,N,3)
+        raw = torch.zeros(2 * B, N, 4, dtype=torch.float32, device=dev)
+        raw[:, :, :2] = torch.cat([feature1, feature2], 0).permute(0, 2, 1)
+        raw = raw.reshape(2 * B * N, 4)
+        geo = Geometry(xyz, self.npoint)
+        # ---- encoder over both frames at once (same weights; eval-mode BN is per-element) --------------
+        q1 = pointwise(2 * B * N, N, [(raw, 2, False)], self.enc_q1, new(2 * B * N, 32))
+        loc = run_pnhead(self.enc, geo, q1)                                              # (2B*N, 128)
+        glob = loc.view(2 * B, N, 128).amax(1)                                             # (2B,128)
+        f1, f2, g1, g2 = loc[:B * N], loc[B * N:], glob[:B].contiguous(), glob[B:].contiguous()
+        # ---- cost volume ---------------------------------------------------------------------------------
+        sb1 = pointwise(B, 1, [(g1, 128, False)], self.p1_glob, new(B, 256))
+        sb2 = pointwise(B, 1, [(g2, 128, False)], self.p2_glob, new(B, 256))
+        p1 = pointwise(B * N, N, [(f1, 128, False)], self.p1_loc, new(B * N, 256), sample_bias=sb1)
+        p2 = pointwise(B * N, N, [(f2, 128, False)], self.p2_loc, new(B * N, 256), sample_bias=sb2)
+        x1, x2 = xyz[:B], xyz[B:]
+        knn1 = torch.empty(B, N, 16, dtype=torch.int64, device=dev)
+        _native.knn_point_wrapper(B, N, N, 16, x1, x2, knn1)
+        knn2 = torch.empty(B, N, 16, dtype=torch.int64, device=dev)
+        _native.knn_point_wrapper(B, N, N, 16, x1, x1, knn2)
+        cor1 = new(B * N, 256)
+        _lib.call("rtk_cost_volume", B, N, N, x1.data_ptr(), x2.data_ptr(), knn1.data_ptr(), p1.data_ptr(), p2.data_ptr(),
+                  self.cv_wd.data_ptr(), self.cv_layers.arr, self.wn1.arr, cor1.data_ptr(), 256, _stream())
+        cor = new(B * N, 256)
+        _lib.call("rtk_patch_cost", B, N, x1.data_ptr(), knn2.data_ptr(), cor1.data_ptr(), 256, self.wn2.arr, cor.data_ptr(), 256, 0,
+                  _stream())
+        # ---- decoder -------------------------------------------------------------------------------------
+        cls = torch.empty(B, N, dtype=torch.float32, device=dev)
+        pointwise(B * N, N, [(cor, 256, False)], self.cls_head, cls, out_channels=1, channel_major=True)
+        sbq = pointwise(B, 1, [(g1, 128, False)], self.dec_q1_glob, new(B, 32))
+        q1d = pointwise(B * N, N, [(raw[:B * N], 2, False), (f1, 128, False), (cor, 256, False)], self.dec_q1, new(B * N, 32),
+                        sample_bias=sbq)
+        prop = run_pnhead(self.dec, geo.head(B), q1d)                                     # (B*N,128)
+        gfeat = prop.view(B, N, 128).amax(1)
+        if h is None:
+            h = torch.zeros(5, B, 128, device=dev, dtype=torch.float32)
+        gout, h_out = self.gru(gfeat.unsqueeze(0), h)
+        sbf = pointwise(B, 1, [(gout[0].contiguous(), 128, False)], self.flow_glob, new(B, 128))
+        flow = torch.empty(B, 3, N, dtype=torch.float32, device=dev)
+        pointwise(B * N, N, [(prop, 128, False)], self.flow_head, flow, out_channels=3, sample_bias=sbf, channel_major=True)
+        # ---- API layouts (B,C,N) -------------------------------------------------------------------------
+        cm = lambda t, c: t.view(B, N, c).permute(0, 2, 1).contiguous()
+        pc1_features = torch.cat([cm(f1, 128), g1.unsqueeze(2).expand(-1, -1, N)], 1)
+        pc2_features = torch.cat([cm(f2, 128), g2.unsqueeze(2).expand(-1, -1, N)], 1)
+        return flow, h_out, cls, cm(cor, 256), pc1_features, pc2_features, cm(prop, 128)

@@ -120,3 +120,98 @@ def test_pointwise_interp_prologue(n_unknown, m, cint, cskip):
     F.pointwise_mlp(B * n_unknown, n_unknown, srcs, chain, out,
                     interp=(kf.reshape(B * m, cint).to(DEV).contiguous(), cint, m, idx.reshape(-1, 3), d2.reshape(-1, 3)))
     assert rel_err(out.double().cpu(), ref) < 5e-6
+
+
+# ---- stage kernels against the module path (HIP ops + PyTorch dense layers) on the golden inputs --------------
+def _net():
+    from ratrack_amd.track4d import Args, Track4D
+    from _util import reference_state_dict
+    net = Track4D(Args()).to(DEV).eval()
+    net.load_state_dict(reference_state_dict(DEV), strict=True)
+    return net
+
+
+@pytest.mark.parametrize("name", ["eval_b2_n256", "eval_b1_n242", "eval_b1_n1024", "eval_b1_n256_dups"])
+def test_fused_pnhead_matches_modules(name):
+    from _util import inputs_of, load_case
+    case = load_case(name)
+    net = _net()
+    pc1, pc2, f1, f2 = inputs_of(case, DEV)
+    B, _, N = pc1.shape
+    with torch.no_grad():
+        _, ref = net.pn_head(pc1.permute(0, 2, 1).contiguous(), f1)          # (B,128,N)
+        eng = F.FusedBackbone(net)
+        xyz = pc1.permute(0, 2, 1).contiguous()
+        raw = torch.zeros(B, N, 4, device=DEV)
+        raw[:, :, :2] = f1.permute(0, 2, 1)
+        raw = raw.reshape(B * N, 4)
+        geo = F.Geometry(xyz, 512)
+        q1 = F.pointwise(B * N, N, [(raw, 2, False)], eng.enc_q1, torch.empty(B * N, 32, device=DEV))
+        got = F.run_pnhead(eng.enc, geo, q1).view(B, N, 128).permute(0, 2, 1)
+    assert rel_err(got.cpu(), ref.cpu()) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["eval_b2_n256", "eval_b1_n242", "eval_b1_n1024"])
+def test_fused_cost_volume_matches_modules(name):
+    from _util import inputs_of, load_case
+    case = load_case(name)
+    net = _net()
+    pc1, pc2, f1, f2 = inputs_of(case, DEV)
+    B, _, N = pc1.shape
+    torch.manual_seed(0)
+    feat1 = torch.randn(B, 256, N, device=DEV)
+    feat2 = torch.randn(B, 256, N, device=DEV)
+    feat1[:, 128:] = feat1[:, 128:, :1]      # global halves are constant over points, as in the model
+    feat2[:, 128:] = feat2[:, 128:, :1]
+    with torch.no_grad():
+        ref = net.fc_layer(pc1, pc2, feat1, feat2)                             # (B,256,N)
+        eng = F.FusedBackbone(net)
+        new = lambda r, c: torch.empty(r, c, device=DEV)
+        pm = lambda t: t.permute(0, 2, 1).reshape(B * N, -1).contiguous()
+        l1, l2 = pm(feat1[:, :128]), pm(feat2[:, :128])
+        g1, g2 = feat1[:, 128:, 0].contiguous(), feat2[:, 128:, 0].contiguous()
+        sb1 = F.pointwise(B, 1, [(g1, 128, False)], eng.p1_glob, new(B, 256))
+        sb2 = F.pointwise(B, 1, [(g2, 128, False)], eng.p2_glob, new(B, 256))
+        p1 = F.pointwise(B * N, N, [(l1, 128, False)], eng.p1_loc, new(B * N, 256), sample_bias=sb1)
+        p2 = F.pointwise(B * N, N, [(l2, 128, False)], eng.p2_loc, new(B * N, 256), sample_bias=sb2)
+        x1 = pc1.permute(0, 2, 1).contiguous()
+        x2 = pc2.permute(0, 2, 1).contiguous()
+        k1 = PU.knn_point(16, x2, x1)
+        k2 = PU.knn_point(16, x1, x1)
+        from ratrack_amd import _lib
+        cor1 = new(B * N, 256)
+        _lib.call("rtk_cost_volume", B, N, N, x1.data_ptr(), x2.data_ptr(), k1.data_ptr(), p1.data_ptr(), p2.data_ptr(),
+                  eng.cv_wd.data_ptr(), eng.cv_layers.arr, eng.wn1.arr, cor1.data_ptr(), 256, F._stream())
+        cor = new(B * N, 256)
+        _lib.call("rtk_patch_cost", B, N, x1.data_ptr(), k2.data_ptr(), cor1.data_ptr(), 256, eng.wn2.arr, cor.data_ptr(), 256, 0, F._stream())
+        got = cor.view(B, N, 256).permute(0, 2, 1)
+    assert rel_err(got.cpu(), ref.cpu()) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["eval_b2_n256", "eval_b1_n242", "eval_b1_n1024", "eval_b1_n256_dups"])
+def test_fused_backbone_matches_golden(name):
+    """The product's default eval path (fused kernels) against the reference-graph golden vectors."""
+    from _util import RTOL, assert_close, inputs_of, load_case
+    case = load_case(name)
+    net = _net()
+    assert net.use_fused
+    pc1, pc2, f1, f2 = inputs_of(case, DEV)
+    with torch.no_grad():
+        flow, h, cls, cor, pf1, pf2, prop = net.backbone(pc1, pc2, f1, f2, None)
+        assert net._fused, "fused engine was not used"
+        flow2, h2, *_ = net.backbone(pc1, pc2, f1, f2, h)
+    cpu = lambda t: t.float().cpu().numpy()
+    assert flow.shape == case["flow"].shape and cls.shape == case["cls"].shape
+    assert_close(cpu(flow), case["flow"], RTOL, "flow")
+    assert_close(cpu(cls), case["cls"], RTOL, "cls")
+    assert_close(cpu(h), case["h_out"], RTOL, "h")
+    assert_close(cpu(cor[:, :, ::8]), case["cor_s8"], RTOL, "cor")
+    assert_close(cpu(prop[:, :, ::8]), case["prop_s8"], RTOL, "prop")
+    assert_close(cpu(pf1[:, :, ::8]), case["pc1_features_s8"], RTOL, "pc1_features")
+    assert_close(cpu(pf2[:, :, ::8]), case["pc2_features_s8"], RTOL, "pc2_features")
+    assert_close(cpu(flow2), case["flow_step2"], RTOL, "flow step 2")
+    assert_close(cpu(h2), case["h_out_step2"], RTOL, "h step 2")
+    gt = torch.from_numpy(case["in_gt_warp"]).to(DEV)
+    epe = float(torch.sqrt(((pc1[:1] + flow[:1] - gt[:1]) ** 2).sum(1) + 1e-20).mean())
+    ref = float(case["metric_sf_vals"][list(case["metric_sf_keys"]).index("epe")])
+    assert abs(epe - ref) <= 1e-4 * max(ref, 1.0), (epe, ref)
