@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Headline benchmark: radar frame-pairs/s of the RaTrack backbone forward (eval) at B=64, N=256 per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one Track4D.backbone() pass (PointNet++ MSG encoder over both frames, kNN cost volume,
+decoder PNHead, GRU, scene-flow + motion-segmentation heads) over one synthetic batch of B frame-pairs
+already resident in HBM.  One process per GPU; frame-pairs are independent, so ranks run disjoint
+batches with no data-path collective (weak scaling); the timed region is bracketed by a barrier +
+synchronize on both sides and the maximum over ranks is reported.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      the dominant kernel (cost_volume_kernel) against the fp32 MFMA peak, duration measured
+                live with HIP events on the launch stream during the timed region;
+  cpu_baseline  the CPU oracle (oracle/track4d_ref.py: C restatement of the native ops + PyTorch-CPU
+                dense layers) timed on this box's host cores on a bounded sample (N=1 run only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work per frame-pair forward (fp32, weights excluded)
+ALG_BYTES_PER_PAIR = {256: 14154240, 1024: 25293312}
+ALG_FLOPS_PER_PAIR = {256: 4.003e9, 1024: 10.790e9}
+FP32_PEAK_TFLOPS = 157.3      # MI355X fp32 vector == fp32-input MFMA peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def cost_volume_flops_per_pair(n, k=16):
+    """Work of the stage the dominant kernel implements, counted in the reference's own arithmetic
+    (model_utils.py:226-236; SURVEY.md Appendix B 'stage 1' minus the layer-1 feature part, which this
+    design evaluates per point in separate launches): per (point, neighbour) pair
+    layers 2+3 (2 x 256 x 256) + layer-1 direction term (3 x 256) + WeightNet (2136) + weighted sum (256) MACs."""
+    macs = k * n * (2 * 256 * 256 + 3 * 256 + 2136 + 256)
+    return 2.0 * macs
+
+
+def cpu_baseline(batch, n, budget_s=20.0):
+    from oracle import track4d_ref as R
+    from ratrack_amd import synth
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from ratrack_amd.track4d import Args, Track4D
+    net = Track4D(Args())
+    synth.fill_state_dict(net.state_dict())
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    d = synth.make_frame_pairs(batch, n, case_id=99)
+    t = {k: torch.from_numpy(v) for k, v in d.items() if k != "gt_cls"}
+    with torch.no_grad():
+        R.backbone(sd, t["pc1"], t["pc2"], t["feature1"], t["feature2"], None)       # warm-up
+        runs, t0 = 0, time.perf_counter()
+        while True:
+            R.backbone(sd, t["pc1"], t["pc2"], t["feature1"], t["feature2"], None)
+            runs += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or runs >= 20:
+                break
+    return {"value": round(batch * runs / el, 3), "unit": "frame-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d forward passes of the CPU oracle at B=%d, N=%d (%.1f s)" % (runs, batch, n, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64, help="frame-pairs per GPU per step")
+    ap.add_argument("--npoints", type=int, default=256, help="radar points per frame")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)      # RCCL
+    assert a.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, world)
+
+    from ratrack_amd import synth
+    from ratrack_amd.track4d import Args, Track4D
+
+    net = Track4D(Args()).to(dev).eval()
+    synth.fill_state_dict(net.state_dict())
+    net.invalidate_fused()
+    d = synth.make_frame_pairs(a.batch, a.npoints, case_id=1000 + rank)          # every rank its own batch
+    pc1, pc2 = torch.from_numpy(d["pc1"]).to(dev), torch.from_numpy(d["pc2"]).to(dev)
+    f1, f2 = torch.from_numpy(d["feature1"]).to(dev), torch.from_numpy(d["feature2"]).to(dev)
+    h = torch.zeros(5, a.batch, 128, device=dev)
+
+    eng = None
+    with torch.no_grad():
+        out = net.backbone(pc1, pc2, f1, f2, h)
+        eng = net._fused
+        assert eng, "fused engine not active"
+        step = lambda: net.backbone(pc1, pc2, f1, f2, h)
+        if not a.no_graph and hasattr(eng, "capture"):
+            gstep = eng.capture(pc1, pc2, f1, f2, h)
+            step = lambda: gstep(pc1, pc2, f1, f2, h)
+
+        def barrier():
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(a.warmup):
+            step()
+        eng.kernel_events = []                      # (start, stop) HIP events around the dominant kernel
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        events, eng.kernel_events = eng.kernel_events, None
+        if not events:                              # graph replay: time the dominant kernel on the same stream right after
+            events = eng.time_dominant_kernel(20)
+
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    kern_ms = sum(s.elapsed_time(e) for s, e in events) / max(len(events), 1)
+
+    if rank == 0:
+        pairs_per_s = a.batch * world * a.steps / elapsed
+        cv_flops = cost_volume_flops_per_pair(a.npoints) * a.batch
+        achieved = cv_flops / (kern_ms * 1e-3) / 1e12
+        res = {
+            "metric": "radar frame-pairs/sec (backbone forward, eval) at B=%d,N=%d per GPU" % (a.batch, a.npoints),
+            "value": round(pairs_per_s, 1),
+            "unit": "frame-pairs/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Track4D.backbone forward, B=%d frame-pairs x N=%d points per GPU, S=512 centroids, "
+                                   "eval-mode BN, random-init weights, hipGraph=%s" % (a.batch, a.npoints, not a.no_graph),
+                       "global_batch": a.batch * world, "parallelism": "replicas x%d (no collective on the forward path)" % world},
+            "roofline": {"kernel": "cost_volume_kernel", "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel_ms": round(kern_ms, 4), "flops_per_launch": cv_flops},
+            "whole_path": {"hbm_frac_algorithmic": round(pairs_per_s / world * ALG_BYTES_PER_PAIR.get(a.npoints, 0) / (HBM_PEAK_GBS * 1e9), 5),
+                           "fp32_frac_algorithmic": round(pairs_per_s / world * ALG_FLOPS_PER_PAIR.get(a.npoints, 0) / (FP32_PEAK_TFLOPS * 1e12), 5)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(8, a.npoints)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

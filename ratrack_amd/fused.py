@@ -305,7 +305,12 @@ class FusedBackbone:
         dev = next(model.parameters()).device
         self.dev = dev
         self.npoint = model.pn_head.sa1.npoint
-        self.gru = model.fd_layer.torchGRU
+        # 5-layer GRU on a length-1 sequence (model_utils.py:279,296) as explicit gate arithmetic: (r,z,n) order
+        self.gru_w = [(sd["fd_layer.torchGRU.weight_ih_l%d" % l].float().t().contiguous(), sd["fd_layer.torchGRU.bias_ih_l%d" % l].float(),
+                       sd["fd_layer.torchGRU.weight_hh_l%d" % l].float().t().contiguous(), sd["fd_layer.torchGRU.bias_hh_l%d" % l].float())
+                      for l in range(5)]
+        self.kernel_events = None      # set to a list to record (start, stop) events around the dominant kernel
+        self._last_cv = None
         self.enc = _PNHeadWeights(sd, "pn_head.", dev)
         self.dec = _PNHeadWeights(sd, "fd_layer.mse.", dev)
         z = lambda n: torch.zeros(n, dtype=torch.float64, device=sd["bin_score"].device)
@@ -374,8 +379,15 @@ class FusedBackbone:
         knn2 = torch.empty(B, N, 16, dtype=torch.int64, device=dev)
         _native.knn_point_wrapper(B, N, N, 16, x1, x1, knn2)
         cor1 = new(B * N, 256)
-        _lib.call("rtk_cost_volume", B, N, N, x1.data_ptr(), x2.data_ptr(), knn1.data_ptr(), p1.data_ptr(), p2.data_ptr(),
-                  self.cv_wd.data_ptr(), self.cv_layers.arr, self.wn1.arr, cor1.data_ptr(), 256, _stream())
+        self._last_cv = (B, N, x1, x2, knn1, p1, p2, cor1)
+        ev = self.kernel_events
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self._cost_volume(*self._last_cv)
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1))
         cor = new(B * N, 256)
         _lib.call("rtk_patch_cost", B, N, x1.data_ptr(), knn2.data_ptr(), cor1.data_ptr(), 256, self.wn2.arr, cor.data_ptr(), 256, 0,
                   _stream())
@@ -389,8 +401,8 @@ class FusedBackbone:
         gfeat = prop.view(B, N, 128).amax(1)
         if h is None:
             h = torch.zeros(5, B, 128, device=dev, dtype=torch.float32)
-        gout, h_out = self.gru(gfeat.unsqueeze(0), h)
-        sbf = pointwise(B, 1, [(gout[0].contiguous(), 128, False)], self.flow_glob, new(B, 128))
+        gout, h_out = self._gru_step(gfeat, h)
+        sbf = pointwise(B, 1, [(gout, 128, False)], self.flow_glob, new(B, 128))
         flow = torch.empty(B, 3, N, dtype=torch.float32, device=dev)
         pointwise(B * N, N, [(prop, 128, False)], self.flow_head, flow, out_channels=3, sample_bias=sbf, channel_major=True)
         # ---- API layouts (B,C,N) -------------------------------------------------------------------------
@@ -398,3 +410,61 @@ class FusedBackbone:
         pc1_features = torch.cat([cm(f1, 128), g1.unsqueeze(2).expand(-1, -1, N)], 1)
         pc2_features = torch.cat([cm(f2, 128), g2.unsqueeze(2).expand(-1, -1, N)], 1)
         return flow, h_out, cls, cm(cor, 256), pc1_features, pc2_features, cm(prop, 128)
+
+    # --------------------------------------------------------------------------------------------------
+    def _cost_volume(self, B, N, x1, x2, knn1, p1, p2, cor1):
+        _lib.call("rtk_cost_volume", B, N, N, x1.data_ptr(), x2.data_ptr(), knn1.data_ptr(), p1.data_ptr(), p2.data_ptr(),
+                  self.cv_wd.data_ptr(), self.cv_layers.arr, self.wn1.arr, cor1.data_ptr(), 256, _stream())
+
+    def _gru_step(self, x, h):
+        outs = []
+        for l, (wih, bih, whh, bhh) in enumerate(self.gru_w):
+            gi = torch.addmm(bih, x, wih)
+            gh = torch.addmm(bhh, h[l], whh)
+            i_r, i_z, i_n = gi.chunk(3, 1)
+            h_r, h_z, h_n = gh.chunk(3, 1)
+            r = torch.sigmoid(i_r + h_r)
+            z = torch.sigmoid(i_z + h_z)
+            n = torch.tanh(i_n + r * h_n)
+            x = (1 - z) * n + z * h[l]
+            outs.append(x)
+        return x.contiguous(), torch.stack(outs, 0)
+
+    def time_dominant_kernel(self, iters=20):
+        """(start, stop) HIP-event pairs around `iters` launches of the cost-volume kernel on the current
+        stream, on the operands of the last backbone() call."""
+        assert self._last_cv is not None, "run backbone() first"
+        ev = []
+        for _ in range(iters):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._cost_volume(*self._last_cv)
+            e1.record()
+            ev.append((e0, e1))
+        torch.cuda.synchronize()
+        return ev
+
+    def capture(self, pc1, pc2, feature1, feature2, h):
+        """Capture one backbone() into a hipGraph (all launches, ours and the glue ops, are on the capture
+        stream).  Returns step(pc1=None, ...) -> outputs: new inputs are copied into the static buffers."""
+        static = [t.clone() for t in (pc1, pc2, feature1, feature2, h)]
+        saved, self.kernel_events = self.kernel_events, None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self.backbone(*static)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            outs = self.backbone(*static)
+        self.kernel_events = saved
+
+        def step(*new_inputs):
+            for dst, src in zip(static, new_inputs):
+                if src is not None:
+                    dst.copy_(src, non_blocking=True)
+            graph.replay()
+            return outs
+        step.graph = graph
+        return step
