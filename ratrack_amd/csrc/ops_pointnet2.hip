@@ -29,30 +29,42 @@ extern "C" int rtk_version(void) { return (0 << 16) | 3; }
 // ------------------------------------------------------------------------------------------------
 // wave64 reductions on DPP (no LDS, no barriers).  row_shr:1,2,4,8 leave each row's maximum in its
 // lane 15; row_bcast:15 / row_bcast:31 carry it across rows so lane 63 holds the wave result.
-// Lanes without a valid DPP source keep `old` (= their own value), which is a no-op for max.
+// Lanes without a valid DPP source read 0 (bound_ctrl) / keep old = 0, the identity of unsigned max,
+// so each step is one v_max_u32 with a DPP operand.
 // ------------------------------------------------------------------------------------------------
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned dpp_mov(unsigned v) {
-    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+__device__ __forceinline__ unsigned dpp_max_u32(unsigned v) {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+    return v > o ? v : o;
 }
 
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = dpp_max_u32<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_max_u32<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_max_u32<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_max_u32<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_max_u32<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+    v = dpp_max_u32<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// 64-bit key variant (used by the n > 2048 fallback)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ void key_max_step(unsigned &hi, unsigned &lo) {
-    const unsigned h2 = dpp_mov<CTRL, ROW_MASK>(hi);
-    const unsigned l2 = dpp_mov<CTRL, ROW_MASK>(lo);
+    const unsigned h2 = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROW_MASK, 0xf, false);
+    const unsigned l2 = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROW_MASK, 0xf, false);
     const bool take = (h2 > hi) || (h2 == hi && l2 > lo);
     hi = take ? h2 : hi;
     lo = take ? l2 : lo;
 }
 
-// max over the wave of the 64-bit key (hi:lo); result is wave-uniform (read from lane 63).
 __device__ __forceinline__ void wave_key_max(unsigned &hi, unsigned &lo) {
-    key_max_step<0x111, 0xf>(hi, lo);  // row_shr:1
-    key_max_step<0x112, 0xf>(hi, lo);  // row_shr:2
-    key_max_step<0x114, 0xf>(hi, lo);  // row_shr:4
-    key_max_step<0x118, 0xf>(hi, lo);  // row_shr:8
-    key_max_step<0x142, 0xa>(hi, lo);  // row_bcast:15 -> rows 1,3
-    key_max_step<0x143, 0xc>(hi, lo);  // row_bcast:31 -> rows 2,3
+    key_max_step<0x111, 0xf>(hi, lo);
+    key_max_step<0x112, 0xf>(hi, lo);
+    key_max_step<0x114, 0xf>(hi, lo);
+    key_max_step<0x118, 0xf>(hi, lo);
+    key_max_step<0x142, 0xa>(hi, lo);
+    key_max_step<0x143, 0xc>(hi, lo);
     hi = (unsigned)__builtin_amdgcn_readlane((int)hi, 63);
     lo = (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
 }
@@ -61,67 +73,82 @@ __device__ __forceinline__ void wave_key_max(unsigned &hi, unsigned &lo) {
 // furthest point sampling   (reference: sampling_gpu.cu:94-209)
 //
 // The reference runs one CUDA block per sample with 2^floor(log2 n) threads and 511 block-wide
-// shared-memory tree reductions.  Here one WAVE owns one sample: its n <= 64*PPL points and their
-// running min-distances live in registers, the per-round argmax is a DPP reduction of the key
-// (float bits of d2 : ~rank) and the winner's coordinates come back with v_readlane -- no LDS, no
-// barrier in the 511-round dependent chain.  rank(k) = (k mod block, k div block) reproduces the
-// reference's tie rule (lower tid wins in the tree, first k wins inside a thread).
+// shared-memory tree reductions.  Here one WAVE owns one sample and the 511-round dependent chain
+// contains no barrier:
+//   * the n <= 64*PPL points and their running min-distances live in registers, laid out in the
+//     reference's TIE ORDER: position p = 64*slot + lane enumerates the points by (k mod block, k div block),
+//     so "ties -> lower tid, then first k" becomes "ties -> smallest position";
+//   * the round's maximum is a 6-instruction DPP max of the distance bits (non-negative floats order
+//     like unsigned ints); the winner is the first set bit of the first non-empty ballot(t == max)
+//     over the slots -- no index travels through the reduction;
+//   * the winner's (x, y, z, k) comes back with one uniform-address LDS read;
+//   * once the maximum is 0 every remaining pick is point 0 (all distances stay 0, position 0 wins
+//     every tie), so over-sampled levels (n < npoint, or duplicated points) stop early -- exact.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int fps_pos_to_index(int p, int block, int q, int rem) {
+    // positions sorted by (k mod block, k div block); residues r < rem own q+1 points, the others q
+    const int lim = rem * (q + 1);
+    int r, jj;
+    if (p < lim) { r = p / (q + 1); jj = p % (q + 1); }
+    else { const int pp = p - lim; r = rem + pp / q; jj = pp % q; }
+    return r + jj * block;
+}
+
 template <int PPL>
 __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, const float *__restrict__ xyz,
                                                       float *__restrict__ temp, int *__restrict__ idxs) {
+    extern __shared__ __attribute__((aligned(16))) float4 s_pt[];   // (x, y, z, bits(k)) by position
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
     xyz += (size_t)b * n * 3;
     temp += (size_t)b * n;
     idxs += (size_t)b * m;
+    const int q = n / block, rem = n % block;
 
-    float x[PPL], y[PPL], z[PPL], t[PPL];
-    unsigned nrank[PPL];  // ~rank (0 for padding so that it never wins)
+    float x[PPL], y[PPL], z[PPL];
+    unsigned t[PPL];   // min-distance bits; 0 for padding (can never equal a positive maximum)
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
-        const int k = lane + 64 * i;
-        const bool ok = k < n;
+        const int p = lane + 64 * i;
+        const bool ok = p < n;
+        const int k = ok ? fps_pos_to_index(p, block, q, rem) : 0;
         x[i] = ok ? xyz[k * 3 + 0] : 0.f;
         y[i] = ok ? xyz[k * 3 + 1] : 0.f;
         z[i] = ok ? xyz[k * 3 + 2] : 0.f;
-        t[i] = ok ? temp[k] : 0.f;
-        const unsigned rank = ((unsigned)(k % block) << 16) | (unsigned)(k / block);
-        nrank[i] = ok ? ~rank : 0u;
+        t[i] = ok ? __float_as_uint(temp[k]) : 0u;
+        if (ok) s_pt[p] = make_float4(x[i], y[i], z[i], __int_as_float(k));
     }
+    __syncthreads();
     if (lane == 0) idxs[0] = 0;
-    int old = 0;
-    for (int j = 1; j < m; ++j) {
-        const int ol = old & 63, os = old >> 6;  // wave-uniform
-        float ox = 0.f, oy = 0.f, oz = 0.f;
+    float4 o = s_pt[0];   // position 0 is always point 0
+    int j = 1;
+    for (; j < m; ++j) {
+        unsigned mloc = 0u;
 #pragma unroll
         for (int i = 0; i < PPL; ++i) {
-            if (os == i) {
-                ox = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[i]), ol));
-                oy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y[i]), ol));
-                oz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z[i]), ol));
-            }
+            const bool ok = lane + 64 * i < n;
+            const float d = rtk_sqdist(x[i], y[i], z[i], o.x, o.y, o.z);
+            const float d2 = fminf(d, __uint_as_float(t[i]));
+            t[i] = ok ? __float_as_uint(d2) : 0u;
+            mloc = t[i] > mloc ? t[i] : mloc;
         }
-        unsigned hi = 0u, lo = 0u;
+        const unsigned M = wave_max_u32(mloc);
+        if (M == 0u) break;                       // exhausted: every remaining pick is index 0
+        int pos = 0;
+        bool found = false;
 #pragma unroll
         for (int i = 0; i < PPL; ++i) {
-            const float d = rtk_sqdist(x[i], y[i], z[i], ox, oy, oz);
-            const float d2 = fminf(d, t[i]);
-            t[i] = d2;
-            const unsigned h = nrank[i] ? __float_as_uint(d2) : 0u;
-            const bool take = (h > hi) || (h == hi && nrank[i] > lo);
-            hi = take ? h : hi;
-            lo = take ? nrank[i] : lo;
+            const unsigned long long mask = __ballot(t[i] == M);
+            if (!found && mask) { pos = 64 * i + __builtin_ctzll(mask); found = true; }
         }
-        wave_key_max(hi, lo);
-        const unsigned rank = ~lo;
-        old = (int)((rank & 0xffffu) * (unsigned)block + (rank >> 16));
-        if (lane == 0) idxs[j] = old;
+        o = s_pt[pos];
+        if (lane == 0) idxs[j] = __float_as_int(o.w);
     }
+    for (int jj = j + lane; jj < m; jj += 64) idxs[jj] = 0;
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
-        const int k = lane + 64 * i;
-        if (k < n) temp[k] = t[i];
+        const int p = lane + 64 * i;
+        if (p < n) temp[__float_as_int(s_pt[p].w)] = __uint_as_float(t[i]);
     }
 }
 
@@ -180,10 +207,11 @@ extern "C" int rtk_furthest_point_sampling(int b, int n, int npoint, const float
     hipStream_t s = (hipStream_t)stream;
     const int block = fps_block_size(n);
     RTK_REQUIRE(n / block < 65536, "furthest_point_sampling: n=%d too large", n);
-    if (n <= 64 * 4) fps_wave_kernel<4><<<b, 64, 0, s>>>(n, npoint, block, xyz, temp, idx);
-    else if (n <= 64 * 8) fps_wave_kernel<8><<<b, 64, 0, s>>>(n, npoint, block, xyz, temp, idx);
-    else if (n <= 64 * 16) fps_wave_kernel<16><<<b, 64, 0, s>>>(n, npoint, block, xyz, temp, idx);
-    else if (n <= 64 * 32) fps_wave_kernel<32><<<b, 64, 0, s>>>(n, npoint, block, xyz, temp, idx);
+    const size_t lds = (size_t)n * sizeof(float4);
+    if (n <= 64 * 4) fps_wave_kernel<4><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx);
+    else if (n <= 64 * 8) fps_wave_kernel<8><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx);
+    else if (n <= 64 * 16) fps_wave_kernel<16><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx);
+    else if (n <= 64 * 32) fps_wave_kernel<32><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx);
     else fps_block_kernel<<<b, 256, 0, s>>>(n, npoint, block, xyz, temp, idx);
     RTK_CHECK_LAUNCH("furthest_point_sampling");
     return RTK_OK;
@@ -339,10 +367,95 @@ extern "C" int rtk_group_points_grad(int b, int c, int n, int npoint, int nsampl
 }
 
 // ------------------------------------------------------------------------------------------------
+// K-smallest selection as branch-free sorting networks over 16 lanes per query.
+//
+// The reference scans all candidates serially per query thread (three_nn, knn) or materialises the
+// (B,S,N) distance matrix and calls torch.topk (knn_point).  Here the 16 lanes of a DPP row share a
+// query: each lane sorts / merges its share of the candidates in registers with compare-exchange
+// networks on 64-bit keys (distance bits : index) -- non-negative floats order like unsigned ints, so
+// one v_cmp_lt_u64 implements "smaller distance, ties -> smaller index", exactly the order a serial
+// strict-< scan produces -- and 4 DPP row_shl steps merge the 16 partial lists into lane 0.
+// No divergence, no scratch (all register indices are static after unrolling).
+// ------------------------------------------------------------------------------------------------
+#define KEY_INF_D 0x7f800000u
+#define KEY_INF_I 0x7fffffff
+
+__device__ __forceinline__ void kv_cex(unsigned &da, int &ia, unsigned &db, int &ib) {   // (a, b) -> (min, max)
+    const unsigned long long ka = ((unsigned long long)da << 32) | (unsigned)ia;
+    const unsigned long long kb = ((unsigned long long)db << 32) | (unsigned)ib;
+    const bool sw = kb < ka;
+    const unsigned td = da; const int ti = ia;
+    da = sw ? db : da; ia = sw ? ib : ia;
+    db = sw ? td : db; ib = sw ? ti : ib;
+}
+
+template <int K>
+__device__ __forceinline__ void kv_bitonic_sort(unsigned (&d)[K], int (&i)[K]) {   // ascending
+#pragma unroll
+    for (int k = 2; k <= K; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int a = 0; a < K; ++a) {
+                const int l = a ^ j;
+                if (l > a) {
+                    if ((a & k) == 0) kv_cex(d[a], i[a], d[l], i[l]);
+                    else kv_cex(d[l], i[l], d[a], i[a]);
+                }
+            }
+        }
+    }
+}
+
+// best <- the K smallest of (best U other), both ascending on entry, ascending on exit
+template <int K>
+__device__ __forceinline__ void kv_merge_low(unsigned (&d)[K], int (&i)[K], const unsigned (&od)[K], const int (&oi)[K]) {
+#pragma unroll
+    for (int a = 0; a < K; ++a) {   // half-cleaner against the reversed other list: keeps the K smallest (bitonic)
+        const unsigned long long ka = ((unsigned long long)d[a] << 32) | (unsigned)i[a];
+        const unsigned long long kb = ((unsigned long long)od[K - 1 - a] << 32) | (unsigned)oi[K - 1 - a];
+        const bool sw = kb < ka;
+        d[a] = sw ? od[K - 1 - a] : d[a];
+        i[a] = sw ? oi[K - 1 - a] : i[a];
+    }
+#pragma unroll
+    for (int j = K >> 1; j > 0; j >>= 1) {
+#pragma unroll
+        for (int a = 0; a < K; ++a) {
+            const int l = a ^ j;
+            if (l > a) kv_cex(d[a], i[a], d[l], i[l]);
+        }
+    }
+}
+
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_pull(unsigned v) {   // row_shl:n -> lane i reads lane i+n of its row
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+// merge the lists of the 16 lanes of a row into lane 0 of the row
+template <int K>
+__device__ __forceinline__ void kv_row_merge(unsigned (&d)[K], int (&i)[K]) {
+    unsigned od[K];
+    int oi[K];
+#pragma unroll
+    for (int a = 0; a < K; ++a) { od[a] = dpp_pull<0x101>(d[a]); oi[a] = (int)dpp_pull<0x101>((unsigned)i[a]); }
+    kv_merge_low<K>(d, i, od, oi);
+#pragma unroll
+    for (int a = 0; a < K; ++a) { od[a] = dpp_pull<0x102>(d[a]); oi[a] = (int)dpp_pull<0x102>((unsigned)i[a]); }
+    kv_merge_low<K>(d, i, od, oi);
+#pragma unroll
+    for (int a = 0; a < K; ++a) { od[a] = dpp_pull<0x104>(d[a]); oi[a] = (int)dpp_pull<0x104>((unsigned)i[a]); }
+    kv_merge_low<K>(d, i, od, oi);
+#pragma unroll
+    for (int a = 0; a < K; ++a) { od[a] = dpp_pull<0x108>(d[a]); oi[a] = (int)dpp_pull<0x108>((unsigned)i[a]); }
+    kv_merge_low<K>(d, i, od, oi);
+}
+
+// ------------------------------------------------------------------------------------------------
 // three_nn   (interpolate_gpu.cu:81-124)
-// best* in the reference are doubles initialised to 1e40 and narrowed to float on store; a float
-// compare against +inf is the same predicate (d < 1e40  <=>  d < inf for every float d) and
-// (float)1e40 == inf, so float state reproduces it exactly.  Known cloud staged in LDS (SoA).
+// Output: the 3 smallest squared distances ascending + indices, ties -> earlier index; fewer than 3
+// known points leave (+inf, 0) in the unfilled slots (the reference's double 1e40 narrowed to float).
 // ------------------------------------------------------------------------------------------------
 template <bool USE_LDS>
 __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float *__restrict__ unknown,
@@ -360,36 +473,43 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float
         }
         __syncthreads();
     }
-    const int pt = blockIdx.x * 256 + tid;
-    if (pt >= n) return;
+    const int li = tid & 15;
+    const int pt_raw = blockIdx.x * 16 + (tid >> 4);
+    const int pt = pt_raw < n ? pt_raw : n - 1;
     const float *u = unknown + ((size_t)bs * n + pt) * 3;
     const float ux = u[0], uy = u[1], uz = u[2];
-    float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
-    int i1 = 0, i2 = 0, i3 = 0;
-    for (int k = 0; k < m; ++k) {
+    unsigned d[4] = {KEY_INF_D, KEY_INF_D, KEY_INF_D, KEY_INF_D};
+    int i[4] = {KEY_INF_I, KEY_INF_I, KEY_INF_I, KEY_INF_I};
+    for (int k = li; k < m; k += 16) {
         const float kx = USE_LDS ? sx[k] : known[k * 3 + 0];
         const float ky = USE_LDS ? sy[k] : known[k * 3 + 1];
         const float kz = USE_LDS ? sz[k] : known[k * 3 + 2];
-        const float d = rtk_sqdist(ux, uy, uz, kx, ky, kz);
-        if (d < b1) {
-            b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k;
-        } else if (d < b2) {
-            b3 = b2; i3 = i2; b2 = d; i2 = k;
-        } else if (d < b3) {
-            b3 = d; i3 = k;
+        const float dd = rtk_sqdist(ux, uy, uz, kx, ky, kz);
+        if (dd < INFINITY) {    // the reference's `d < 1e40` predicate: inf / NaN never enter
+            d[3] = __float_as_uint(dd); i[3] = k;
+            kv_cex(d[2], i[2], d[3], i[3]);
+            kv_cex(d[1], i[1], d[2], i[2]);
+            kv_cex(d[0], i[0], d[1], i[1]);
         }
     }
-    float *od = dist2 + ((size_t)bs * n + pt) * 3;
-    int *oi = idx + ((size_t)bs * n + pt) * 3;
-    od[0] = b1; od[1] = b2; od[2] = b3;
-    oi[0] = i1; oi[1] = i2; oi[2] = i3;
+    d[3] = KEY_INF_D; i[3] = KEY_INF_I;
+    kv_row_merge<4>(d, i);
+    if (li == 0 && pt_raw < n) {
+        float *od = dist2 + ((size_t)bs * n + pt) * 3;
+        int *oi = idx + ((size_t)bs * n + pt) * 3;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            od[a] = __uint_as_float(d[a]);
+            oi[a] = d[a] == KEY_INF_D ? 0 : i[a];
+        }
+    }
 }
 
 extern "C" int rtk_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
                             rtk_stream_t stream) {
     RTK_REQUIRE(b > 0 && n > 0 && m > 0 && unknown && known && dist2 && idx, "three_nn: bad arguments");
     RTK_REQUIRE(b <= 65535, "three_nn: b exceeds grid limits");
-    dim3 grid(rtk_divup(n, 256), b);
+    dim3 grid(rtk_divup(n, 16), b);
     const size_t lds = (size_t)m * 3 * sizeof(float);
     if (lds <= 64 * 1024)
         three_nn_kernel<true><<<grid, 256, lds, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx);
@@ -488,8 +608,8 @@ extern "C" int rtk_three_interpolate_grad(int b, int c, int n, int m, const floa
 // knn_point   (utils/model_utils/model_utils.py:17-39,85-99: square_distance + torch.topk)
 //
 // The reference materialises the (B,S,N) distance matrix with a matmul and runs torch.topk on it.
-// Here a thread owns a query, walks the LDS-staged SoA cloud and keeps the K best in a register
-// insertion network with static indices (K is a template constant, so nothing spills to scratch).
+// Here 16 lanes share a query: each lane takes candidates j = lane + 16c in chunks of K, sorts the
+// chunk with a bitonic network and merges it into its running K-best; kv_row_merge folds the 16 lists.
 // Distances follow the expansion formula of the arithmetic contract so the neighbour SET equals the
 // CPU reference's; output order is (distance, index) ascending.
 // ------------------------------------------------------------------------------------------------
@@ -508,50 +628,46 @@ __global__ __launch_bounds__(256) void knn_point_kernel(int s, int n, int k, con
         }
         __syncthreads();
     }
-    const int qi = blockIdx.x * 256 + tid;
-    if (qi >= s) return;
+    const int li = tid & 15;
+    const int qi_raw = blockIdx.x * 16 + (tid >> 4);
+    const int qi = qi_raw < s ? qi_raw : s - 1;
     const float *q = query + ((size_t)bs * s + qi) * 3;
     const float qx = q[0], qy = q[1], qz = q[2];
     const float qn = __fadd_rn(__fadd_rn(__fmul_rn(qx, qx), __fmul_rn(qy, qy)), __fmul_rn(qz, qz));
-    float best[K];
-    int besti[K];
+    unsigned bd[K];
+    int bi[K];
 #pragma unroll
-    for (int i = 0; i < K; ++i) { best[i] = INFINITY; besti[i] = 0x7fffffff; }
-    for (int j = 0; j < n; ++j) {
-        float px, py, pz, pn;
-        if (USE_LDS) {
-            px = sx[j]; py = sy[j]; pz = sz[j]; pn = sn[j];
-        } else {
-            px = points[j * 3 + 0]; py = points[j * 3 + 1]; pz = points[j * 3 + 2];
-            pn = __fadd_rn(__fadd_rn(__fmul_rn(px, px), __fmul_rn(py, py)), __fmul_rn(pz, pz));
-        }
-        const float dot = __fmaf_rn(qz, pz, __fmaf_rn(qy, py, __fmul_rn(qx, px)));
-        float d = __fadd_rn(__fadd_rn(__fmul_rn(-2.f, dot), qn), pn);
-        d = d > 0.f ? d : 0.f;  // torch.maximum(dist, 0)
-        // only the first k slots are live: slot k-1 is the current worst
-        bool ins = false;
+    for (int a = 0; a < K; ++a) { bd[a] = KEY_INF_D; bi[a] = KEY_INF_I; }
+    for (int base = 0; base < n; base += 16 * K) {
+        unsigned cd[K];
+        int ci[K];
 #pragma unroll
-        for (int i = 0; i < K; ++i)
-            if (i == k - 1) ins = d < best[i];
-        if (ins) {
-#pragma unroll
-            for (int i = 0; i < K; ++i)
-                if (i == k - 1) { best[i] = d; besti[i] = j; }
-#pragma unroll
-            for (int i = K - 1; i > 0; --i) {
-                if (i <= k - 1) {
-                    const bool sw = best[i] < best[i - 1];  // strict: equal distances keep index order
-                    const float tb = best[i]; const int ti = besti[i];
-                    best[i] = sw ? best[i - 1] : tb; besti[i] = sw ? besti[i - 1] : ti;
-                    best[i - 1] = sw ? tb : best[i - 1]; besti[i - 1] = sw ? ti : besti[i - 1];
+        for (int a = 0; a < K; ++a) {
+            const int j = base + li + 16 * a;
+            cd[a] = KEY_INF_D; ci[a] = KEY_INF_I;
+            if (j < n) {
+                float px, py, pz, pn;
+                if (USE_LDS) { px = sx[j]; py = sy[j]; pz = sz[j]; pn = sn[j]; }
+                else {
+                    px = points[j * 3 + 0]; py = points[j * 3 + 1]; pz = points[j * 3 + 2];
+                    pn = __fadd_rn(__fadd_rn(__fmul_rn(px, px), __fmul_rn(py, py)), __fmul_rn(pz, pz));
                 }
+                const float dot = __fmaf_rn(qz, pz, __fmaf_rn(qy, py, __fmul_rn(qx, px)));
+                float dd = __fadd_rn(__fadd_rn(__fmul_rn(-2.f, dot), qn), pn);
+                dd = dd > 0.f ? dd : 0.f;  // torch.maximum(dist, 0)
+                cd[a] = __float_as_uint(dd); ci[a] = j;
             }
         }
+        kv_bitonic_sort<K>(cd, ci);
+        kv_merge_low<K>(bd, bi, cd, ci);
     }
-    int64_t *o = idx + ((size_t)bs * s + qi) * k;
+    kv_row_merge<K>(bd, bi);
+    if (li == 0 && qi_raw < s) {
+        int64_t *o = idx + ((size_t)bs * s + qi) * k;
 #pragma unroll
-    for (int i = 0; i < K; ++i)
-        if (i < k) o[i] = besti[i];
+        for (int a = 0; a < K; ++a)
+            if (a < k) o[a] = bi[a];
+    }
 }
 
 extern "C" int rtk_knn_point(int b, int s, int n, int k, const float *query, const float *points, int64_t *idx,
@@ -559,7 +675,7 @@ extern "C" int rtk_knn_point(int b, int s, int n, int k, const float *query, con
     RTK_REQUIRE(b > 0 && s > 0 && n > 0 && query && points && idx, "knn_point: bad arguments");
     RTK_REQUIRE(k >= 1 && k <= 32 && k <= n, "knn_point: k=%d outside [1, min(32, n=%d)]", k, n);
     RTK_REQUIRE(b <= 65535, "knn_point: b exceeds grid limits");
-    dim3 grid(rtk_divup(s, 256), b);
+    dim3 grid(rtk_divup(s, 16), b);
     const size_t lds = (size_t)n * 4 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     const bool use_lds = lds <= 64 * 1024;
