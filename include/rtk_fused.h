@@ -88,6 +88,32 @@ RTK_EXPORT int rtk_patch_cost(int samples, int n, const float *xyz, const int64_
                               const float *feat, int feat_pitch, const rtk_layer_t *wn, float *out,
                               int out_pitch, int out_channel_major, rtk_stream_t stream);
 
+/* Layout glue of Track4D.backbone (models/track4d.py:104-105): (B,3,N)/(B,2,N) channel-major inputs of both
+ * frames -> xyz (2B,N,3) and raw (2B,N,4) = (RCS, v_r, 0, 0) point-major, frame 1 first. */
+RTK_EXPORT int rtk_prepare_inputs(int b, int n, const float *pc1, const float *pc2, const float *feature1,
+                                  const float *feature2, float *xyz, float *raw, rtk_stream_t stream);
+
+/* furthest_point_sample + gather_operation of a set-abstraction level in one launch
+ * (lib/pointnet2_modules.py:30-35): same selection rule as rtk_furthest_point_sampling with the
+ * min-distance scratch held on chip (initialised to 1e10).  idx (B,npoint) int32, new_xyz (B,npoint,3);
+ * nuniq (B) int32 (optional) = number of picks made before the cloud was exhausted (every later pick is
+ * point 0, i.e. a duplicate of centroid 0). */
+RTK_EXPORT int rtk_fps_centroids(int b, int n, int npoint, const float *xyz, int *idx, float *new_xyz, int *nuniq,
+                                 rtk_stream_t stream);
+
+/* One time step of nn.GRU(hidden, hidden, layers) on a length-1 sequence (model_utils.py:279,296).
+ * x (B,H); h_in, h_out (L,B,H); w_ih, w_hh TRANSPOSED (L,H,3H) = weight_{ih,hh}_l{l}.T, gate order (r,z,n);
+ * b_ih, b_hh (L,3H); y (B,H) = h_out[L-1].  H <= 128. */
+RTK_EXPORT int rtk_gru_step(int b, int layers, int hidden, const float *x, const float *h_in, const float *w_ih,
+                            const float *w_hh, const float *b_ih, const float *b_hh, float *h_out, float *y,
+                            rtk_stream_t stream);
+
+/* (rows = samples*n, pitch) point-major -> (samples, channels, n) channel-major at channel offset
+ * dst_channel_offset of a (samples, dst_channels, n) tensor; per_sample != 0 broadcasts a (samples, pitch)
+ * source over the n points (the global-feature halves of pc{1,2}_features, models/track4d.py:89-95). */
+RTK_EXPORT int rtk_to_channel_major(int samples, int n, int channels, const float *src, int src_pitch, int per_sample,
+                                    float *dst, int dst_channels, int dst_channel_offset, rtk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,122 @@
+// fused_misc.hip -- the small stages around the MFMA kernels, written so that one backbone() issues a few
+// dozen launches instead of the ~500 framework ops of the reference graph:
+// input layout, FPS+gather, the GRU step, channel-major output layout.
+#include <math.h>
+
+#include "rtk_common.h"
+#include "rtk_fused.h"
+
+// ------------------------------------------------------------------------------------------------
+// rtk_prepare_inputs
+// ------------------------------------------------------------------------------------------------
+__global__ void prepare_inputs_kernel(int b, int n, const float *__restrict__ pc1, const float *__restrict__ pc2,
+                                      const float *__restrict__ f1, const float *__restrict__ f2, float *__restrict__ xyz,
+                                      float *__restrict__ raw) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2L * b * n) return;
+    const int s = (int)(t / n), p = (int)(t % n);
+    const bool second = s >= b;
+    const int sb = second ? s - b : s;
+    const float *pc = second ? pc2 : pc1;
+    const float *f = second ? f2 : f1;
+    xyz[t * 3 + 0] = pc[((long)sb * 3 + 0) * n + p];
+    xyz[t * 3 + 1] = pc[((long)sb * 3 + 1) * n + p];
+    xyz[t * 3 + 2] = pc[((long)sb * 3 + 2) * n + p];
+    *reinterpret_cast<float4 *>(raw + t * 4) = make_float4(f[((long)sb * 2 + 0) * n + p], f[((long)sb * 2 + 1) * n + p], 0.f, 0.f);
+}
+
+extern "C" int rtk_prepare_inputs(int b, int n, const float *pc1, const float *pc2, const float *feature1,
+                                  const float *feature2, float *xyz, float *raw, rtk_stream_t stream) {
+    RTK_REQUIRE(b > 0 && n > 0 && pc1 && pc2 && feature1 && feature2 && xyz && raw, "prepare_inputs: bad arguments");
+    const long total = 2L * b * n;
+    prepare_inputs_kernel<<<rtk_divup(total, 256), 256, 0, (hipStream_t)stream>>>(b, n, pc1, pc2, feature1, feature2, xyz, raw);
+    RTK_CHECK_LAUNCH("prepare_inputs");
+    return RTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rtk_gru_step: one workgroup per sample, 3H threads.  Thread t owns gate row t of both matrices; weights come
+// TRANSPOSED (L, H, 3H) so that the 3H threads read consecutive addresses (L2-resident: 1.9 MB shared by all
+// workgroups); the H-vectors live in LDS.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(384) void gru_step_kernel(int b, int layers, int hidden, const float *__restrict__ x,
+                                                       const float *__restrict__ h_in, const float *__restrict__ w_ih,
+                                                       const float *__restrict__ w_hh, const float *__restrict__ b_ih,
+                                                       const float *__restrict__ b_hh, float *__restrict__ h_out,
+                                                       float *__restrict__ y) {
+    __shared__ float s_x[128], s_h[128], s_gi[384], s_gh[384];
+    const int s = blockIdx.x, t = threadIdx.x, H = hidden;
+    if (t < H) s_x[t] = x[(long)s * H + t];
+    for (int l = 0; l < layers; ++l) {
+        if (t < H) s_h[t] = h_in[((long)l * b + s) * H + t];
+        __syncthreads();
+        if (t < 3 * H) {
+            // transposed weights (L, H, 3H): consecutive threads read consecutive addresses
+            const float *wi = w_ih + (long)l * H * 3 * H + t;
+            const float *wh = w_hh + (long)l * H * 3 * H + t;
+            float ai = b_ih[l * 3 * H + t], ah = b_hh[l * 3 * H + t];
+#pragma unroll 8
+            for (int k = 0; k < H; ++k) {
+                ai = fmaf(wi[(long)k * 3 * H], s_x[k], ai);
+                ah = fmaf(wh[(long)k * 3 * H], s_h[k], ah);
+            }
+            s_gi[t] = ai;
+            s_gh[t] = ah;
+        }
+        __syncthreads();
+        if (t < H) {
+            const float r = 1.f / (1.f + expf(-(s_gi[t] + s_gh[t])));
+            const float z = 1.f / (1.f + expf(-(s_gi[H + t] + s_gh[H + t])));
+            const float nn = tanhf(s_gi[2 * H + t] + r * s_gh[2 * H + t]);
+            const float hn = (1.f - z) * nn + z * s_h[t];
+            h_out[((long)l * b + s) * H + t] = hn;
+            s_x[t] = hn;                      // input of the next layer
+            if (l == layers - 1) y[(long)s * H + t] = hn;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int rtk_gru_step(int b, int layers, int hidden, const float *x, const float *h_in, const float *w_ih,
+                            const float *w_hh, const float *b_ih, const float *b_hh, float *h_out, float *y,
+                            rtk_stream_t stream) {
+    RTK_REQUIRE(b > 0 && layers > 0 && hidden > 0 && hidden <= 128 && hidden % 4 == 0 && x && h_in && w_ih && w_hh && b_ih &&
+                b_hh && h_out && y, "gru_step: bad arguments (hidden=%d)", hidden);
+    gru_step_kernel<<<b, 384, 0, (hipStream_t)stream>>>(b, layers, hidden, x, h_in, w_ih, w_hh, b_ih, b_hh, h_out, y);
+    RTK_CHECK_LAUNCH("gru_step");
+    return RTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rtk_to_channel_major: 32x32 tiles through LDS so that both the point-major reads and the
+// channel-major writes are coalesced.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void to_channel_major_kernel(int n, int channels, const float *__restrict__ src, int src_pitch,
+                                                               int per_sample, float *__restrict__ dst, int dst_channels,
+                                                               int dst_off) {
+    __shared__ float tile[32][33];
+    const int s = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        float v = 0.f;
+        if (p < n && c < channels) v = src[(per_sample ? (long)s : (long)s * n + p) * src_pitch + c];
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        if (p < n && c < channels) dst[((long)s * dst_channels + dst_off + c) * n + p] = tile[tx][r];
+    }
+}
+
+extern "C" int rtk_to_channel_major(int samples, int n, int channels, const float *src, int src_pitch, int per_sample,
+                                    float *dst, int dst_channels, int dst_channel_offset, rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && n > 0 && channels > 0 && src && dst && src_pitch >= channels && dst_channel_offset >= 0 &&
+                dst_channel_offset + channels <= dst_channels && samples <= 65535, "to_channel_major: bad arguments");
+    dim3 grid(rtk_divup(n, 32), rtk_divup(channels, 32), samples);
+    to_channel_major_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(n, channels, src, src_pitch, per_sample, dst, dst_channels,
+                                                                    dst_channel_offset);
+    RTK_CHECK_LAUNCH("to_channel_major");
+    return RTK_OK;
+}

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include "rtk_common.h"
+#include "rtk_fused.h"
 
 // ------------------------------------------------------------------------------------------------
 // error plumbing
@@ -96,13 +97,15 @@ __device__ __forceinline__ int fps_pos_to_index(int p, int block, int q, int rem
 
 template <int PPL>
 __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, const float *__restrict__ xyz,
-                                                      float *__restrict__ temp, int *__restrict__ idxs) {
+                                                      float *__restrict__ temp, int *__restrict__ idxs,
+                                                      float *__restrict__ new_xyz, int *__restrict__ nuniq) {
     extern __shared__ __attribute__((aligned(16))) float4 s_pt[];   // (x, y, z, bits(k)) by position
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
     xyz += (size_t)b * n * 3;
-    temp += (size_t)b * n;
+    if (temp) temp += (size_t)b * n;
     idxs += (size_t)b * m;
+    if (new_xyz) new_xyz += (size_t)b * m * 3;
     const int q = n / block, rem = n % block;
 
     float x[PPL], y[PPL], z[PPL];
@@ -115,12 +118,16 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, c
         x[i] = ok ? xyz[k * 3 + 0] : 0.f;
         y[i] = ok ? xyz[k * 3 + 1] : 0.f;
         z[i] = ok ? xyz[k * 3 + 2] : 0.f;
-        t[i] = ok ? __float_as_uint(temp[k]) : 0u;
+        t[i] = ok ? __float_as_uint(temp ? temp[k] : 1e10f) : 0u;
         if (ok) s_pt[p] = make_float4(x[i], y[i], z[i], __int_as_float(k));
     }
     __syncthreads();
-    if (lane == 0) idxs[0] = 0;
     float4 o = s_pt[0];   // position 0 is always point 0
+    if (lane == 0) {
+        idxs[0] = 0;
+        if (new_xyz) { new_xyz[0] = o.x; new_xyz[1] = o.y; new_xyz[2] = o.z; }
+    }
+    const float4 p0 = o;
     int j = 1;
     for (; j < m; ++j) {
         unsigned mloc = 0u;
@@ -142,13 +149,22 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, c
             if (!found && mask) { pos = 64 * i + __builtin_ctzll(mask); found = true; }
         }
         o = s_pt[pos];
-        if (lane == 0) idxs[j] = __float_as_int(o.w);
+        if (lane == 0) {
+            idxs[j] = __float_as_int(o.w);
+            if (new_xyz) { new_xyz[j * 3 + 0] = o.x; new_xyz[j * 3 + 1] = o.y; new_xyz[j * 3 + 2] = o.z; }
+        }
     }
-    for (int jj = j + lane; jj < m; jj += 64) idxs[jj] = 0;
+    if (nuniq && lane == 0) nuniq[b] = j;
+    for (int jj = j + lane; jj < m; jj += 64) {
+        idxs[jj] = 0;
+        if (new_xyz) { new_xyz[jj * 3 + 0] = p0.x; new_xyz[jj * 3 + 1] = p0.y; new_xyz[jj * 3 + 2] = p0.z; }
+    }
+    if (temp) {
 #pragma unroll
-    for (int i = 0; i < PPL; ++i) {
-        const int p = lane + 64 * i;
-        if (p < n) temp[__float_as_int(s_pt[p].w)] = __uint_as_float(t[i]);
+        for (int i = 0; i < PPL; ++i) {
+            const int p = lane + 64 * i;
+            if (p < n) temp[__float_as_int(s_pt[p].w)] = __uint_as_float(t[i]);
+        }
     }
 }
 
@@ -200,20 +216,38 @@ static int fps_block_size(int n) {  // cuda_utils.h:10-14 (host code in the refe
     return t;
 }
 
+static int fps_launch(int b, int n, int npoint, const float *xyz, float *temp, int *idx, float *new_xyz, int *nuniq,
+                      hipStream_t s) {
+    const int block = fps_block_size(n);
+    RTK_REQUIRE(n / block < 65536, "furthest_point_sampling: n=%d too large", n);
+    const size_t lds = (size_t)n * sizeof(float4);
+    if (n <= 64 * 4) fps_wave_kernel<4><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq);
+    else if (n <= 64 * 8) fps_wave_kernel<8><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq);
+    else if (n <= 64 * 16) fps_wave_kernel<16><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq);
+    else if (n <= 64 * 32) fps_wave_kernel<32><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq);
+    else return 1;   // caller falls back to the block kernel
+    return 0;
+}
+
 extern "C" int rtk_furthest_point_sampling(int b, int n, int npoint, const float *xyz, float *temp, int *idx,
                                            rtk_stream_t stream) {
     RTK_REQUIRE(b > 0 && n > 0 && xyz && temp && idx, "furthest_point_sampling: bad arguments (b=%d n=%d)", b, n);
     if (npoint <= 0) return RTK_OK;
     hipStream_t s = (hipStream_t)stream;
-    const int block = fps_block_size(n);
-    RTK_REQUIRE(n / block < 65536, "furthest_point_sampling: n=%d too large", n);
-    const size_t lds = (size_t)n * sizeof(float4);
-    if (n <= 64 * 4) fps_wave_kernel<4><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx);
-    else if (n <= 64 * 8) fps_wave_kernel<8><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx);
-    else if (n <= 64 * 16) fps_wave_kernel<16><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx);
-    else if (n <= 64 * 32) fps_wave_kernel<32><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx);
-    else fps_block_kernel<<<b, 256, 0, s>>>(n, npoint, block, xyz, temp, idx);
+    const int rc = fps_launch(b, n, npoint, xyz, temp, idx, nullptr, nullptr, s);
+    if (rc < 0) return rc;
+    if (rc == 1) fps_block_kernel<<<b, 256, 0, s>>>(n, npoint, fps_block_size(n), xyz, temp, idx);
     RTK_CHECK_LAUNCH("furthest_point_sampling");
+    return RTK_OK;
+}
+
+extern "C" int rtk_fps_centroids(int b, int n, int npoint, const float *xyz, int *idx, float *new_xyz, int *nuniq,
+                                 rtk_stream_t stream) {
+    RTK_REQUIRE(b > 0 && n > 0 && npoint > 0 && xyz && idx && new_xyz, "fps_centroids: bad arguments (b=%d n=%d)", b, n);
+    RTK_REQUIRE(n <= 2048, "fps_centroids: n=%d > 2048 (use rtk_furthest_point_sampling + rtk_gather_points)", n);
+    const int rc = fps_launch(b, n, npoint, xyz, nullptr, idx, new_xyz, nuniq, (hipStream_t)stream);
+    if (rc < 0) return rc;
+    RTK_CHECK_LAUNCH("fps_centroids");
     return RTK_OK;
 }
 

@@ -43,6 +43,10 @@ _lib.SIGNATURES.update({
     "rtk_sa_scale": [_ci] * 4 + [_vp] * 4 + [_ci, _ci, _vp, _ci, ctypes.POINTER(_Layer), _vp, _ci, _ci, _vp],
     "rtk_cost_volume": [_ci] * 3 + [_vp] * 6 + [ctypes.POINTER(_Layer), ctypes.POINTER(_Layer), _vp, _ci, _vp],
     "rtk_patch_cost": [_ci] * 2 + [_vp] * 3 + [_ci, ctypes.POINTER(_Layer), _vp, _ci, _ci, _vp],
+    "rtk_prepare_inputs": [_ci] * 2 + [_vp] * 6 + [_vp],
+    "rtk_fps_centroids": [_ci] * 3 + [_vp] * 4 + [_vp],
+    "rtk_gru_step": [_ci] * 3 + [_vp] * 8 + [_vp],
+    "rtk_to_channel_major": [_ci] * 3 + [_vp, _ci, _ci, _vp, _ci, _ci, _vp],
 })
 
 
@@ -224,28 +228,45 @@ class Geometry:
         dev = xyz.device
         self.n, self.samples, self.npoint = n, S_, npoint
         self.xyz = [xyz]
+        self.nuniq = []
+        # one int32 workspace for the 3 FPS index rows, the 3 exhausted-cloud counters, the 6 ball-query tables
+        # (zero-initialised once: the caller-zero-inits contract of ball_query, lib/pointnet2_utils.py:246)
+        # and the 3 three-NN index tables
+        ns_all = [ns for row in _PNHeadWeights.NSAMPLES for ns in row]
+        nn_rows = [npoint, npoint, n]
+        sizes = [S_ * npoint] * 3 + [S_] * 3 + [S_ * npoint * ns for ns in ns_all] + [S_ * r * 3 for r in nn_rows]
+        ws = torch.zeros(sum(sizes), dtype=torch.int32, device=dev)
+        parts = list(torch.split(ws, sizes))
+        fps_idx, cnt, ball, nn_idx = parts[0:3], parts[3:6], parts[6:12], parts[12:15]
         for lvl in range(3):
             src = self.xyz[-1]
-            idx = torch.empty(S_, npoint, dtype=torch.int32, device=dev)
-            temp = torch.full((S_, src.shape[1]), 1e10, dtype=torch.float32, device=dev)
-            _native.furthest_point_sampling_wrapper(S_, src.shape[1], npoint, src, temp, idx)
-            # gather the centroids (B,S,3): plain indexing is the gather kernel's job on a (B,3,N) layout; here rows
-            new_xyz = torch.gather(src, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+            new_xyz = torch.empty(S_, npoint, 3, dtype=torch.float32, device=dev)
+            if src.shape[1] <= 2048:
+                _lib.call("rtk_fps_centroids", S_, src.shape[1], npoint, src.data_ptr(), fps_idx[lvl].data_ptr(), new_xyz.data_ptr(),
+                          cnt[lvl].data_ptr(), _stream())
+            else:   # large clouds: generic FPS + gather
+                idx = fps_idx[lvl].view(S_, npoint)
+                temp = torch.full((S_, src.shape[1]), 1e10, dtype=torch.float32, device=dev)
+                _native.furthest_point_sampling_wrapper(S_, src.shape[1], npoint, src, temp, idx)
+                new_xyz = torch.gather(src, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
             self.xyz.append(new_xyz)
+            self.nuniq.append(cnt[lvl])
         self.ball = []
         for lvl in range(3):
             row = []
             for s in range(2):
                 ns, r = _PNHeadWeights.NSAMPLES[lvl][s], _PNHeadWeights.RADII[lvl][s]
-                bidx = torch.zeros(S_, npoint, ns, dtype=torch.int32, device=dev)
+                bidx = ball[lvl * 2 + s].view(S_, npoint, ns)
                 _native.ball_query_wrapper(S_, self.xyz[lvl].shape[1], npoint, float(r), ns, self.xyz[lvl + 1], self.xyz[lvl], bidx)
                 row.append(bidx)
             self.ball.append(row)
         self.nn = {}
-        for name, (u, k) in {"fp3": (2, 3), "fp2": (1, 2), "fp1": (0, 1)}.items():
+        d2_all = torch.empty(sum(nn_rows) * S_ * 3, dtype=torch.float32, device=dev)
+        d2_parts = torch.split(d2_all, [S_ * r * 3 for r in nn_rows])
+        for i, (name, (u, k)) in enumerate({"fp3": (2, 3), "fp2": (1, 2), "fp1": (0, 1)}.items()):
             nu, m = self.xyz[u].shape[1], self.xyz[k].shape[1]
-            d2 = torch.empty(S_, nu, 3, dtype=torch.float32, device=dev)
-            idx = torch.empty(S_, nu, 3, dtype=torch.int32, device=dev)
+            d2 = d2_parts[i].view(S_, nu, 3)
+            idx = nn_idx[i].view(S_, nu, 3)
             _native.three_nn_wrapper(S_, nu, m, self.xyz[u], self.xyz[k], d2, idx)
             self.nn[name] = (d2, idx, m)
 
@@ -255,6 +276,7 @@ class Geometry:
         g.n, g.samples, g.npoint = self.n, count, self.npoint
         g.xyz = [x[:count] for x in self.xyz]
         g.ball = [[b[:count] for b in row] for row in self.ball]
+        g.nuniq = [c[:count] for c in self.nuniq]
         g.nn = {k: (d2[:count], idx[:count], m) for k, (d2, idx, m) in self.nn.items()}
         return g
 
@@ -305,10 +327,11 @@ class FusedBackbone:
         dev = next(model.parameters()).device
         self.dev = dev
         self.npoint = model.pn_head.sa1.npoint
-        # 5-layer GRU on a length-1 sequence (model_utils.py:279,296) as explicit gate arithmetic: (r,z,n) order
-        self.gru_w = [(sd["fd_layer.torchGRU.weight_ih_l%d" % l].float().t().contiguous(), sd["fd_layer.torchGRU.bias_ih_l%d" % l].float(),
-                       sd["fd_layer.torchGRU.weight_hh_l%d" % l].float().t().contiguous(), sd["fd_layer.torchGRU.bias_hh_l%d" % l].float())
-                      for l in range(5)]
+        # 5-layer GRU on a length-1 sequence (model_utils.py:279,296): transposed weights for rtk_gru_step
+        g = lambda k: torch.stack([sd["fd_layer.torchGRU.%s_l%d" % (k, l)].float() for l in range(5)])
+        self.gru_wih = g("weight_ih").transpose(1, 2).contiguous()      # (L, H, 3H)
+        self.gru_whh = g("weight_hh").transpose(1, 2).contiguous()
+        self.gru_bih, self.gru_bhh = g("bias_ih").contiguous(), g("bias_hh").contiguous()
         self.kernel_events = None      # set to a list to record (start, stop) events around the dominant kernel
         self._last_cv = None
         self.enc = _PNHeadWeights(sd, "pn_head.", dev)
@@ -358,10 +381,13 @@ class FusedBackbone:
         B, _, N = pc1.shape
         dev = pc1.device
         new = lambda rows, c: torch.empty(rows, c, dtype=torch.float32, device=dev)
-        xyz = torch.cat([pc1, pc2], 0).permute(0, 2, 1).contiguous()                       # (2B,N,3)
-        raw = torch.zeros(2 * B, N, 4, dtype=torch.float32, device=dev)
-        raw[:, :, :2] = torch.cat([feature1, feature2], 0).permute(0, 2, 1)
-        raw = raw.reshape(2 * B * N, 4)
+        xyz = torch.empty(2 * B, N, 3, dtype=torch.float32, device=dev)
+        raw = new(2 * B * N, 4)
+        # keep the (possibly copied) contiguous inputs referenced until the launch is enqueued: a temporary freed
+        # between two .data_ptr() calls could be recycled by the allocator for the next temporary
+        ins = [t.contiguous() for t in (pc1, pc2, feature1, feature2)]
+        _lib.call("rtk_prepare_inputs", B, N, ins[0].data_ptr(), ins[1].data_ptr(), ins[2].data_ptr(), ins[3].data_ptr(),
+                  xyz.data_ptr(), raw.data_ptr(), _stream())
         geo = Geometry(xyz, self.npoint)
         # ---- encoder over both frames at once (same weights; eval-mode BN is per-element) --------------
         q1 = pointwise(2 * B * N, N, [(raw, 2, False)], self.enc_q1, new(2 * B * N, 32))
@@ -406,10 +432,18 @@ class FusedBackbone:
         flow = torch.empty(B, 3, N, dtype=torch.float32, device=dev)
         pointwise(B * N, N, [(prop, 128, False)], self.flow_head, flow, out_channels=3, sample_bias=sbf, channel_major=True)
         # ---- API layouts (B,C,N) -------------------------------------------------------------------------
-        cm = lambda t, c: t.view(B, N, c).permute(0, 2, 1).contiguous()
-        pc1_features = torch.cat([cm(f1, 128), g1.unsqueeze(2).expand(-1, -1, N)], 1)
-        pc2_features = torch.cat([cm(f2, 128), g2.unsqueeze(2).expand(-1, -1, N)], 1)
-        return flow, h_out, cls, cm(cor, 256), pc1_features, pc2_features, cm(prop, 128)
+        def cm(dst, off, src, ch, per_sample=False):
+            _lib.call("rtk_to_channel_major", B, N, ch, src.data_ptr(), src.stride(0), int(per_sample), dst.data_ptr(), dst.shape[1], off,
+                      _stream())
+        pc1_features = torch.empty(B, 256, N, dtype=torch.float32, device=dev)
+        pc2_features = torch.empty(B, 256, N, dtype=torch.float32, device=dev)
+        cor_cm = torch.empty(B, 256, N, dtype=torch.float32, device=dev)
+        prop_cm = torch.empty(B, 128, N, dtype=torch.float32, device=dev)
+        cm(pc1_features, 0, f1, 128); cm(pc1_features, 128, g1, 128, True)
+        cm(pc2_features, 0, f2, 128); cm(pc2_features, 128, g2, 128, True)
+        cm(cor_cm, 0, cor, 256)
+        cm(prop_cm, 0, prop, 128)
+        return flow, h_out, cls, cor_cm, pc1_features, pc2_features, prop_cm
 
     # --------------------------------------------------------------------------------------------------
     def _cost_volume(self, B, N, x1, x2, knn1, p1, p2, cor1):
@@ -417,18 +451,13 @@ class FusedBackbone:
                   self.cv_wd.data_ptr(), self.cv_layers.arr, self.wn1.arr, cor1.data_ptr(), 256, _stream())
 
     def _gru_step(self, x, h):
-        outs = []
-        for l, (wih, bih, whh, bhh) in enumerate(self.gru_w):
-            gi = torch.addmm(bih, x, wih)
-            gh = torch.addmm(bhh, h[l], whh)
-            i_r, i_z, i_n = gi.chunk(3, 1)
-            h_r, h_z, h_n = gh.chunk(3, 1)
-            r = torch.sigmoid(i_r + h_r)
-            z = torch.sigmoid(i_z + h_z)
-            n = torch.tanh(i_n + r * h_n)
-            x = (1 - z) * n + z * h[l]
-            outs.append(x)
-        return x.contiguous(), torch.stack(outs, 0)
+        L, B, H = h.shape
+        h_out = torch.empty_like(h)
+        y = torch.empty(B, H, dtype=torch.float32, device=h.device)
+        h = h.contiguous()
+        _lib.call("rtk_gru_step", B, L, H, x.data_ptr(), h.data_ptr(), self.gru_wih.data_ptr(), self.gru_whh.data_ptr(),
+                  self.gru_bih.data_ptr(), self.gru_bhh.data_ptr(), h_out.data_ptr(), y.data_ptr(), _stream())
+        return y, h_out
 
     def time_dominant_kernel(self, iters=20):
         """(start, stop) HIP-event pairs around `iters` launches of the cost-volume kernel on the current

@@ -215,3 +215,52 @@ def test_fused_backbone_matches_golden(name):
     epe = float(torch.sqrt(((pc1[:1] + flow[:1] - gt[:1]) ** 2).sum(1) + 1e-20).mean())
     ref = float(case["metric_sf_vals"][list(case["metric_sf_keys"]).index("epe")])
     assert abs(epe - ref) <= 1e-4 * max(ref, 1.0), (epe, ref)
+
+
+def test_misc_kernels():
+    """prepare_inputs, fps_centroids (+ exhausted-cloud counter), gru_step, to_channel_major."""
+    from oracle import pointnet2_ref as P
+    from ratrack_amd import _lib, synth
+    torch.manual_seed(3)
+    B, N = 3, 242
+    d = synth.make_frame_pairs(B, N, 11)
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in d.items() if k != "gt_cls"}
+    xyz = torch.empty(2 * B, N, 3, device=DEV)
+    raw = torch.empty(2 * B * N, 4, device=DEV)
+    _lib.call("rtk_prepare_inputs", B, N, t["pc1"].data_ptr(), t["pc2"].data_ptr(), t["feature1"].data_ptr(), t["feature2"].data_ptr(),
+              xyz.data_ptr(), raw.data_ptr(), F._stream())
+    assert torch.equal(xyz, torch.cat([t["pc1"], t["pc2"]]).permute(0, 2, 1))
+    assert torch.equal(raw.view(2 * B, N, 4)[:, :, :2], torch.cat([t["feature1"], t["feature2"]]).permute(0, 2, 1))
+    assert (raw.view(2 * B, N, 4)[:, :, 2:] == 0).all()
+    # fps + gather + counter
+    idx = torch.empty(2 * B, 512, dtype=torch.int32, device=DEV)
+    nxyz = torch.empty(2 * B, 512, 3, device=DEV)
+    cnt = torch.empty(2 * B, dtype=torch.int32, device=DEV)
+    _lib.call("rtk_fps_centroids", 2 * B, N, 512, xyz.data_ptr(), idx.data_ptr(), nxyz.data_ptr(), cnt.data_ptr(), F._stream())
+    ref = P.fps(xyz.cpu(), 512)
+    assert torch.equal(idx.cpu(), ref)
+    assert torch.equal(nxyz.cpu(), torch.gather(xyz.cpu(), 1, ref.long().unsqueeze(-1).expand(-1, -1, 3)))
+    assert (cnt.cpu() == N).all()              # N distinct points, then exhausted
+    # GRU step vs torch.nn.GRU (CPU)
+    gru = torch.nn.GRU(128, 128, 5)
+    x, h = torch.randn(4, 128), torch.randn(5, 4, 128)
+    with torch.no_grad():
+        y_ref, h_ref = gru(x.unsqueeze(0), h)
+    st = lambda k: torch.stack([getattr(gru, "%s_l%d" % (k, l)).detach() for l in range(5)])
+    wih, whh = st("weight_ih").transpose(1, 2).contiguous().to(DEV), st("weight_hh").transpose(1, 2).contiguous().to(DEV)
+    bih, bhh = st("bias_ih").contiguous().to(DEV), st("bias_hh").contiguous().to(DEV)
+    h_out, y = torch.empty(5, 4, 128, device=DEV), torch.empty(4, 128, device=DEV)
+    xd, hd = x.to(DEV), h.to(DEV)        # keep the device copies alive across the asynchronous launch
+    _lib.call("rtk_gru_step", 4, 5, 128, xd.data_ptr(), hd.data_ptr(), wih.data_ptr(), whh.data_ptr(), bih.data_ptr(),
+              bhh.data_ptr(), h_out.data_ptr(), y.data_ptr(), F._stream())
+    e1, e2 = rel_err(h_out.cpu(), h_ref), rel_err(y.cpu(), y_ref[0])
+    assert e1 < 1e-5 and e2 < 1e-5, (e1, e2)
+    # layout
+    src = torch.randn(B * N, 132, device=DEV)
+    dst = torch.full((B, 200, N), -1.0, device=DEV)
+    _lib.call("rtk_to_channel_major", B, N, 100, src.data_ptr(), 132, 0, dst.data_ptr(), 200, 50, F._stream())
+    assert torch.equal(dst[:, 50:150], src[:, :100].view(B, N, 100).permute(0, 2, 1))
+    assert (dst[:, :50] == -1).all() and (dst[:, 150:] == -1).all()
+    g = torch.randn(B, 128, device=DEV)
+    _lib.call("rtk_to_channel_major", B, N, 128, g.data_ptr(), 128, 1, dst.data_ptr(), 200, 0, F._stream())
+    assert torch.equal(dst[:, :128], g.unsqueeze(2).expand(-1, -1, N))
