@@ -219,16 +219,59 @@ class _PNHeadWeights:
             self.fp[name] = Chain([(w, b, ACT_RELU)], device)
 
 
+CHECK_FPS_IDENTITY = bool(int(__import__("os").environ.get("RTK_CHECK_FPS_IDENTITY", "0")))
+
+
+def fps_identity_holds(n, npoint):
+    """True when furthest-point sampling of `npoint` out of `n` points is provably the identity permutation GIVEN
+    that the cloud is itself the output of a previous FPS (levels 2 and 3 of PNHead, model_utils.py:415-417):
+    n == npoint and n a power of two <= 1024.
+
+    Proof sketch.  Let P[0..n) be the centroids of the previous level in selection order.  Run FPS on P.  By
+    induction the selected prefix is P[0..j): the running min-distances are then bit-identical to the previous
+    run's (same formula on the same coordinates, rtk_sqdist), so P[j] -- the previous run's arg-max over a superset
+    of the remaining candidates -- still attains the maximum M.  If M > 0 every already selected position has
+    distance 0 < M, so the lowest tied position is j, and with block = 2^floor(log2 n) = n the reference's tie
+    rule (k mod block, k) IS position order: pick j.  If M = 0 the cloud is exhausted and every later pick is
+    index 0 in both runs, whose coordinates equal P[j] (a copy of P[0]) -- the gathered centroids are again P.
+    Hence new_xyz == xyz bit for bit, and the exhausted-cloud counter carries over.  RTK_CHECK_FPS_IDENTITY=1
+    re-runs the full kernel and asserts it; tests/test_fused_gpu.py::test_fps_identity does so on every fixture."""
+    return n == npoint and n <= 1024 and (n & (n - 1)) == 0
+
+
+def _check_fps_identity(src, npoint, cnt_prev):
+    S_ = src.shape[0]
+    idx = torch.empty(S_, npoint, dtype=torch.int32, device=src.device)
+    out = torch.empty(S_, npoint, 3, dtype=torch.float32, device=src.device)
+    cnt = torch.empty(S_, dtype=torch.int32, device=src.device)
+    _lib.call("rtk_fps_centroids", S_, src.shape[1], npoint, src.data_ptr(), idx.data_ptr(), out.data_ptr(), cnt.data_ptr(), _stream())
+    assert torch.equal(out, src), "FPS identity violated: level centroids differ from the source cloud"
+    assert torch.equal(cnt, cnt_prev.view(-1)), "FPS identity violated: exhausted-cloud counters differ"
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class Geometry:
     """FPS centroids, ball-query indices and three-NN tables of one batch of clouds (feature independent,
     so the decoder's PNHead over pc1 reuses the encoder's)."""
 
-    def __init__(self, xyz, npoint):
+    def __init__(self, xyz, npoint, side=None, knn_frames=0):
+        """xyz (S_,n,3).  With `side` (a torch.cuda.Stream) every geometry kernel is enqueued on that stream, forked from
+        the current one, and consumers call wait(stage) -- the feature kernels overlap the latency-bound FPS chain.
+        knn_frames = B > 0: also the two kNN tables of the cost volume, frame 1 = xyz[:B], frame 2 = xyz[B:]."""
         S_, n, _ = xyz.shape
         dev = xyz.device
         self.n, self.samples, self.npoint = n, S_, npoint
         self.xyz = [xyz]
         self.nuniq = []
+        self.events = {}
+        # ---- all workspaces are allocated on the CURRENT stream, before the fork ------------------------------
         # one int32 workspace for the 3 FPS index rows, the 3 exhausted-cloud counters, the 6 ball-query tables
         # (zero-initialised once: the caller-zero-inits contract of ball_query, lib/pointnet2_utils.py:246)
         # and the 3 three-NN index tables
@@ -238,37 +281,79 @@ class Geometry:
         ws = torch.zeros(sum(sizes), dtype=torch.int32, device=dev)
         parts = list(torch.split(ws, sizes))
         fps_idx, cnt, ball, nn_idx = parts[0:3], parts[3:6], parts[6:12], parts[12:15]
-        for lvl in range(3):
-            src = self.xyz[-1]
-            new_xyz = torch.empty(S_, npoint, 3, dtype=torch.float32, device=dev)
-            if src.shape[1] <= 2048:
-                _lib.call("rtk_fps_centroids", S_, src.shape[1], npoint, src.data_ptr(), fps_idx[lvl].data_ptr(), new_xyz.data_ptr(),
-                          cnt[lvl].data_ptr(), _stream())
-            else:   # large clouds: generic FPS + gather
-                idx = fps_idx[lvl].view(S_, npoint)
-                temp = torch.full((S_, src.shape[1]), 1e10, dtype=torch.float32, device=dev)
-                _native.furthest_point_sampling_wrapper(S_, src.shape[1], npoint, src, temp, idx)
-                new_xyz = torch.gather(src, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
-            self.xyz.append(new_xyz)
-            self.nuniq.append(cnt[lvl])
-        self.ball = []
-        for lvl in range(3):
-            row = []
-            for s in range(2):
-                ns, r = _PNHeadWeights.NSAMPLES[lvl][s], _PNHeadWeights.RADII[lvl][s]
-                bidx = ball[lvl * 2 + s].view(S_, npoint, ns)
-                _native.ball_query_wrapper(S_, self.xyz[lvl].shape[1], npoint, float(r), ns, self.xyz[lvl + 1], self.xyz[lvl], bidx)
-                row.append(bidx)
-            self.ball.append(row)
-        self.nn = {}
+        new_xyz = [torch.empty(S_, npoint, 3, dtype=torch.float32, device=dev) for _ in range(3)]
         d2_all = torch.empty(sum(nn_rows) * S_ * 3, dtype=torch.float32, device=dev)
         d2_parts = torch.split(d2_all, [S_ * r * 3 for r in nn_rows])
-        for i, (name, (u, k)) in enumerate({"fp3": (2, 3), "fp2": (1, 2), "fp1": (0, 1)}.items()):
-            nu, m = self.xyz[u].shape[1], self.xyz[k].shape[1]
-            d2 = d2_parts[i].view(S_, nu, 3)
-            idx = nn_idx[i].view(S_, nu, 3)
-            _native.three_nn_wrapper(S_, nu, m, self.xyz[u], self.xyz[k], d2, idx)
-            self.nn[name] = (d2, idx, m)
+        B = knn_frames
+        self.knn = [torch.empty(B, n, 16, dtype=torch.int64, device=dev) for _ in range(2)] if B else None
+        big = n > 2048
+        temp = torch.full((S_, n), 1e10, dtype=torch.float32, device=dev) if big else None
+
+        main = torch.cuda.current_stream()
+        if side is not None:
+            side.wait_stream(main)
+        ctx = torch.cuda.stream(side) if side is not None else _NullCtx()
+        with ctx:
+            for lvl in range(3):
+                src = self.xyz[-1]
+                if lvl > 0 and fps_identity_holds(src.shape[1], npoint):
+                    # FPS over a cloud that is itself an FPS ordering, selecting all of it: the identity (see
+                    # fps_identity_holds).  Centroids = source cloud, no kernel.
+                    if CHECK_FPS_IDENTITY:
+                        _check_fps_identity(src, npoint, self.nuniq[-1])
+                    self.xyz.append(src)
+                    self.nuniq.append(self.nuniq[-1])
+                    continue
+                if src.shape[1] <= 2048:
+                    _lib.call("rtk_fps_centroids", S_, src.shape[1], npoint, src.data_ptr(), fps_idx[lvl].data_ptr(),
+                              new_xyz[lvl].data_ptr(), cnt[lvl].data_ptr(), _stream())
+                else:   # large clouds: generic FPS + gather
+                    idx = fps_idx[lvl].view(S_, npoint)
+                    _native.furthest_point_sampling_wrapper(S_, src.shape[1], npoint, src, temp, idx)
+                    new_xyz[lvl].copy_(torch.gather(src, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)))
+                self.xyz.append(new_xyz[lvl])
+                self.nuniq.append(cnt[lvl])
+            self.ball = []
+            for lvl in range(3):
+                row = []
+                for s in range(2):
+                    ns, r = _PNHeadWeights.NSAMPLES[lvl][s], _PNHeadWeights.RADII[lvl][s]
+                    bidx = ball[lvl * 2 + s].view(S_, npoint, ns)
+                    row.append(bidx)
+                self.ball.append(row)
+            # order on the side stream = order of first use: level-l tables right after level-l centroids
+            # (the three FPS calls are a dependent chain, so they were enqueued first)
+            for lvl in range(3):
+                for s in range(2):
+                    ns, r = _PNHeadWeights.NSAMPLES[lvl][s], _PNHeadWeights.RADII[lvl][s]
+                    _native.ball_query_wrapper(S_, self.xyz[lvl].shape[1], npoint, float(r), ns, self.xyz[lvl + 1], self.xyz[lvl],
+                                               self.ball[lvl][s])
+                self._record(lvl, side)
+            self.nn = {}
+            for i, (name, (u, k)) in enumerate({"fp3": (2, 3), "fp2": (1, 2), "fp1": (0, 1)}.items()):
+                nu, m = self.xyz[u].shape[1], self.xyz[k].shape[1]
+                d2 = d2_parts[i].view(S_, nu, 3)
+                idx = nn_idx[i].view(S_, nu, 3)
+                _native.three_nn_wrapper(S_, nu, m, self.xyz[u], self.xyz[k], d2, idx)
+                self.nn[name] = (d2, idx, m)
+            self._record("nn", side)
+            if B:
+                x1, x2 = xyz[:B], xyz[B:]
+                _native.knn_point_wrapper(B, n, n, 16, x1, x2, self.knn[0])
+                _native.knn_point_wrapper(B, n, n, 16, x1, x1, self.knn[1])
+                self._record("knn", side)
+
+    def _record(self, key, side):
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record(side)
+            self.events[key] = ev
+
+    def wait(self, key):
+        """Make the current stream wait for geometry stage `key` (0,1,2 = levels, 'nn', 'knn')."""
+        ev = self.events.get(key)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     def head(self, count):
         """View on the first `count` samples (the pc1 half)."""
@@ -277,6 +362,7 @@ class Geometry:
         g.xyz = [x[:count] for x in self.xyz]
         g.ball = [[b[:count] for b in row] for row in self.ball]
         g.nuniq = [c[:count] for c in self.nuniq]
+        g.events, g.knn = self.events, self.knn
         g.nn = {k: (d2[:count], idx[:count], m) for k, (d2, idx, m) in self.nn.items()}
         return g
 
@@ -298,17 +384,21 @@ def run_pnhead(W, geo, q1):
     dev = q1.device
     new = lambda rows, c: torch.empty(rows, c, dtype=torch.float32, device=dev)
     sa1 = new(S_ * S, 64)
+    geo.wait(0)
     sa_scale(geo, W, 0, 0, q1, 0, sa1, 0)
     sa_scale(geo, W, 0, 1, q1, 16, sa1, 32)
     t1 = pointwise(S_ * S, S, [(sa1, 64, False)], W.trans[0], new(S_ * S, 96))        # l1_points | q2_s0 | q2_s1
     sa2 = new(S_ * S, 96)
+    geo.wait(1)
     sa_scale(geo, W, 1, 0, t1, 32, sa2, 0)
     sa_scale(geo, W, 1, 1, t1, 64, sa2, 32)
     t2 = pointwise(S_ * S, S, [(sa2, 96, False)], W.trans[1], new(S_ * S, 192))       # l2_points | q3_s0 | q3_s1
     sa3 = new(S_ * S, 128)
+    geo.wait(2)
     sa_scale(geo, W, 2, 0, t2, 64, sa3, 0)
     sa_scale(geo, W, 2, 1, t2, 128, sa3, 64)
     l3 = pointwise(S_ * S, S, [(sa3, 128, False)], W.lin3, new(S_ * S, 64))
+    geo.wait("nn")
     d2, idx, m = geo.nn["fp3"]
     f3 = pointwise(S_ * S, S, [(t2[:, 0:64], 64, False)], W.fp["fp3"], new(S_ * S, 128),
                    interp=(l3, 64, m, idx.reshape(-1, 3), d2.reshape(-1, 3)))
@@ -333,6 +423,7 @@ class FusedBackbone:
         self.gru_whh = g("weight_hh").transpose(1, 2).contiguous()
         self.gru_bih, self.gru_bhh = g("bias_ih").contiguous(), g("bias_hh").contiguous()
         self.kernel_events = None      # set to a list to record (start, stop) events around the dominant kernel
+        self.side, self.use_side_stream = None, True    # geometry kernels run on a forked stream
         self._last_cv = None
         self.enc = _PNHeadWeights(sd, "pn_head.", dev)
         self.dec = _PNHeadWeights(sd, "fd_layer.mse.", dev)
@@ -388,7 +479,9 @@ class FusedBackbone:
         ins = [t.contiguous() for t in (pc1, pc2, feature1, feature2)]
         _lib.call("rtk_prepare_inputs", B, N, ins[0].data_ptr(), ins[1].data_ptr(), ins[2].data_ptr(), ins[3].data_ptr(),
                   xyz.data_ptr(), raw.data_ptr(), _stream())
-        geo = Geometry(xyz, self.npoint)
+        if self.side is None and self.use_side_stream:
+            self.side = torch.cuda.Stream(device=dev)
+        geo = Geometry(xyz, self.npoint, side=self.side if self.use_side_stream else None, knn_frames=B)
         # ---- encoder over both frames at once (same weights; eval-mode BN is per-element) --------------
         q1 = pointwise(2 * B * N, N, [(raw, 2, False)], self.enc_q1, new(2 * B * N, 32))
         loc = run_pnhead(self.enc, geo, q1)                                              # (2B*N, 128)
@@ -400,10 +493,8 @@ class FusedBackbone:
         p1 = pointwise(B * N, N, [(f1, 128, False)], self.p1_loc, new(B * N, 256), sample_bias=sb1)
         p2 = pointwise(B * N, N, [(f2, 128, False)], self.p2_loc, new(B * N, 256), sample_bias=sb2)
         x1, x2 = xyz[:B], xyz[B:]
-        knn1 = torch.empty(B, N, 16, dtype=torch.int64, device=dev)
-        _native.knn_point_wrapper(B, N, N, 16, x1, x2, knn1)
-        knn2 = torch.empty(B, N, 16, dtype=torch.int64, device=dev)
-        _native.knn_point_wrapper(B, N, N, 16, x1, x1, knn2)
+        geo.wait("knn")
+        knn1, knn2 = geo.knn
         cor1 = new(B * N, 256)
         self._last_cv = (B, N, x1, x2, knn1, p1, p2, cor1)
         ev = self.kernel_events

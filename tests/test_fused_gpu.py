@@ -146,6 +146,7 @@ def test_fused_pnhead_matches_modules(name):
         raw[:, :, :2] = f1.permute(0, 2, 1)
         raw = raw.reshape(B * N, 4)
         geo = F.Geometry(xyz, 512)
+        torch.cuda.synchronize()
         q1 = F.pointwise(B * N, N, [(raw, 2, False)], eng.enc_q1, torch.empty(B * N, 32, device=DEV))
         got = F.run_pnhead(eng.enc, geo, q1).view(B, N, 128).permute(0, 2, 1)
     assert rel_err(got.cpu(), ref.cpu()) < 2e-5
@@ -264,3 +265,26 @@ def test_misc_kernels():
     g = torch.randn(B, 128, device=DEV)
     _lib.call("rtk_to_channel_major", B, N, 128, g.data_ptr(), 128, 1, dst.data_ptr(), 200, 0, F._stream())
     assert torch.equal(dst[:, :128], g.unsqueeze(2).expand(-1, -1, N))
+
+
+def test_fps_identity():
+    """Levels 2/3 elide FPS (n == npoint == 512 over an FPS-ordered cloud): assert against the full kernel on every
+    fixture cloud, on duplicate-heavy clouds and on clouds with exact distance ties."""
+    from _util import EVAL_CASES, inputs_of, load_case
+    from ratrack_amd import _lib
+    clouds = []
+    for name in EVAL_CASES:
+        pc1, pc2, _, _ = inputs_of(load_case(name), DEV)
+        clouds += [pc1.permute(0, 2, 1).contiguous(), pc2.permute(0, 2, 1).contiguous()]
+    g = torch.Generator().manual_seed(5)
+    lattice = torch.randint(0, 6, (3, 700, 3), generator=g).float().to(DEV)      # integer lattice: many exact ties + duplicates
+    clouds += [lattice, lattice[:, :300].contiguous(), torch.zeros(2, 64, 3, device=DEV)]
+    for xyz in clouds:
+        S_, n, _ = xyz.shape
+        l1 = torch.empty(S_, 512, 3, device=DEV)
+        idx = torch.empty(S_, 512, dtype=torch.int32, device=DEV)
+        c1 = torch.empty(S_, dtype=torch.int32, device=DEV)
+        _lib.call("rtk_fps_centroids", S_, n, 512, xyz.data_ptr(), idx.data_ptr(), l1.data_ptr(), c1.data_ptr(), F._stream())
+        assert F.fps_identity_holds(512, 512)
+        F._check_fps_identity(l1, 512, c1)        # asserts new_xyz == l1 and equal counters
+    assert not F.fps_identity_holds(500, 512) and not F.fps_identity_holds(2048, 2048) and not F.fps_identity_holds(384, 384)
