@@ -52,27 +52,34 @@ typedef struct {
     int pitch, channels, m;
     const int *idx;       /* (rows, 3) int32, indices into the sample's m known points */
     const float *dist2;   /* (rows, 3) squared distances from rtk_three_nn */
+    const int *nuniq;     /* optional (samples): known rows >= nuniq[b] are duplicates of row 0 and read as row 0 */
 } rtk_interp_t;
 
 /* rows = total points (samples * rows_per_sample).  Input vector = [interp segment (optional)] ||
  * srcs[0] || srcs[1] ...; each segment padded to a multiple of 16 channels.  sample_bias (optional,
  * (samples, 16*layers[0].cout16)) is added to layer 0's pre-activation.  Output: point-major
  * (rows, out_pitch) at channel offset 0, or channel-major (samples, out_channels, rows_per_sample)
- * when out_channel_major != 0; only out_channels channels are written. */
+ * when out_channel_major != 0; only out_channels channels are written.
+ * row_nuniq (optional, (samples)): rows r >= row_nuniq[b] of sample b are duplicates of the sample's row 0
+ * (centroids picked after furthest-point sampling exhausted the cloud, see rtk_fps_centroids); they are
+ * neither read nor written -- consumers alias them to row 0. */
 RTK_EXPORT int rtk_pointwise_mlp(int rows, int rows_per_sample, const rtk_interp_t *interp, int nsrc,
                                  const rtk_src_t *srcs, const float *sample_bias, int nlayers,
                                  const rtk_layer_t *layers, float *out, int out_pitch, int out_channels,
-                                 int out_channel_major, rtk_stream_t stream);
+                                 int out_channel_major, const int *row_nuniq, rtk_stream_t stream);
 
 /* One scale of a set-abstraction level.  q (samples*n, q_pitch): per-point layer-1 projection of the
  * features (BN scale folded); layer 1 = relu(q[idx] + Wx.(xyz[idx] - centroid) + b1) with
  * w1xyz_packed the [1][c1_16][64][4] image of [Wx | b1]; then nlayers more packed layers; the last
  * one's bias+ReLU is applied after the max over the nsample neighbours.  idx from rtk_ball_query.
- * out (samples*npoint, out_pitch) receives 16*last.cout16 channels at out_offset. */
+ * out (samples*npoint, out_pitch) receives 16*last.cout16 channels at out_offset.
+ * src_nuniq / dst_nuniq (optional, (samples)): duplicate-row counters of the source level (q rows >= src_nuniq[b]
+ * are read as row 0) and of the centroid level (centroids >= dst_nuniq[b] are skipped). */
 RTK_EXPORT int rtk_sa_scale(int samples, int n, int npoint, int nsample, const float *xyz,
                             const float *new_xyz, const int *idx, const float *q, int q_pitch, int c1_16,
                             const float *w1xyz_packed, int nlayers, const rtk_layer_t *layers, float *out,
-                            int out_pitch, int out_offset, rtk_stream_t stream);
+                            int out_pitch, int out_offset, const int *src_nuniq, const int *dst_nuniq,
+                            rtk_stream_t stream);
 
 /* Point-to-patch cost volume for k = 16 neighbours.  p1 (samples*n1, 256) / p2 (samples*n2, 256):
  * first-layer projections of the query / neighbour features (bias folded into p1);

@@ -37,6 +37,7 @@ struct SaParams {
     const float *bias2, *bias3;
     float *out;
     int out_pitch, out_offset;
+    const int *src_nuniq, *dst_nuniq;
 };
 
 // NS = neighbours per centroid; V1/V2/V3 = layer widths / 16 (V3 = 0: two-layer MLP).
@@ -59,11 +60,26 @@ __global__ __launch_bounds__(256) void sa_scale_kernel(const SaParams P) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int slot0 = j % NS;                         // neighbour slot of this lane within the first tile
-    for (long unit = wave; unit < units; unit += nwaves) {
+    // Work order: sample-minor (consecutive waves take the same centroid group of different samples) so that the
+    // duplicate-centroid tail of every sample is spread evenly over the waves instead of landing on the same ones.
+    const long groups_per_sample = P.npoint / CPT;
+    const bool remap = (P.npoint % CPT) == 0;
+    for (long w_i = wave; w_i < units; w_i += nwaves) {
+        const long unit = remap ? (w_i % P.samples) * groups_per_sample + w_i / P.samples : w_i;
         long c = unit * CPT + (NS >= 16 ? 0 : j / NS);        // centroid of this lane (global index)
         const bool valid = c < total_centroids;
         if (!valid) c = total_centroids - 1;
         const int b = (int)(c / P.npoint);
+        if (P.dst_nuniq) {
+            // centroids >= nuniq[b] are copies of the sample's centroid 0 (FPS exhausted the cloud): skip the unit when all
+            // of its centroids are duplicates (lane 0 holds the unit's first centroid: wave-uniform decision)
+            const long cf = unit * CPT;
+            const int bf = (int)(cf / P.npoint);
+            const long cl = min(cf + CPT, total_centroids) - 1;
+            const int ef = __builtin_amdgcn_readfirstlane(P.dst_nuniq[bf]);
+            if (bf == (int)(cl / P.npoint) && cf - (long)bf * P.npoint >= ef) continue;
+        }
+        const int src_e = P.src_nuniq ? P.src_nuniq[b] : 0x7fffffff;
         const float cg = g < 3 ? P.new_xyz[c * 3 + g] : 0.f;
         f4 best[VL];
 #pragma unroll
@@ -74,7 +90,7 @@ __global__ __launch_bounds__(256) void sa_scale_kernel(const SaParams P) {
             // offset operand: (neighbour - centroid) component g, or 1 for the bias column
             const float bop = g < 3 ? __fsub_rn(P.xyz[src * 3 + g], cg) : 1.0f;
             f4 a1[V1];
-            const float *qrow = P.q + src * P.q_pitch + 4 * g;
+            const float *qrow = P.q + ((long)b * P.n + (id < src_e ? id : 0)) * P.q_pitch + 4 * g;   // duplicate source rows alias row 0
 #pragma unroll
             for (int v = 0; v < V1; ++v) a1[v] = *reinterpret_cast<const f4 *>(qrow + 16 * v);
 #pragma unroll
@@ -124,7 +140,7 @@ __global__ __launch_bounds__(256) void sa_scale_kernel(const SaParams P) {
 extern "C" int rtk_sa_scale(int samples, int n, int npoint, int nsample, const float *xyz, const float *new_xyz,
                             const int *idx, const float *q, int q_pitch, int c1_16, const float *w1xyz_packed,
                             int nlayers, const rtk_layer_t *layers, float *out, int out_pitch, int out_offset,
-                            rtk_stream_t stream) {
+                            const int *src_nuniq, const int *dst_nuniq, rtk_stream_t stream) {
     RTK_REQUIRE(samples > 0 && n > 0 && npoint > 0 && xyz && new_xyz && idx && q && w1xyz_packed && layers && out,
                 "sa_scale: bad arguments");
     RTK_REQUIRE(nlayers == 1 || nlayers == 2, "sa_scale: nlayers=%d (1 or 2 layers after the offset layer)", nlayers);
@@ -140,6 +156,7 @@ extern "C" int rtk_sa_scale(int samples, int n, int npoint, int nsample, const f
     P.bias2 = layers[0].bias;
     P.bias3 = nlayers == 2 ? layers[1].bias : nullptr;
     P.out = out; P.out_pitch = out_pitch; P.out_offset = out_offset;
+    P.src_nuniq = src_nuniq; P.dst_nuniq = dst_nuniq;
     const int v1 = c1_16, v2 = layers[0].cout16, v3 = nlayers == 2 ? layers[1].cout16 : 0;
     hipStream_t s = (hipStream_t)stream;
     const long centroids = (long)samples * npoint;

@@ -23,6 +23,7 @@ struct PwParams {
     rtk_layer_t layer[RTK_MAX_LAYERS];
     float *out;
     int out_pitch, out_channels, out_cm;
+    const int *row_nuniq;
 };
 
 template <int V>
@@ -85,16 +86,40 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void pointwise_mlp_kernel(const PwPa
 
     for (int it = 0; it < iters; ++it) {
         asm volatile("" ::: "memory");   // keep loop-invariant loads/addresses inside the loop (registers are the scarce resource)
-        const int t = (it * gridDim.x + blockIdx.x) * PW_NW + wave_in_wg;
-        const int p_raw = t * 16 + j;
-        const bool valid = p_raw < P.rows;
-        const int p = valid ? p_raw : P.rows - 1;
+        // Workgroup iteration G covers 64 consecutive rows.  Order them sample-minor when a sample is a whole number of
+        // 64-row groups: the duplicate-row tails (row_nuniq) are then spread evenly over the workgroups.
+        const int G = it * gridDim.x + blockIdx.x;
+        const int samples = P.rows / P.rows_per_sample;
+        const int gps = P.rows_per_sample / (PW_NW * 16);
+        const bool remap = P.rows_per_sample % (PW_NW * 16) == 0;
+        const int r0 = remap ? (G % samples) * P.rows_per_sample + (G / samples) * (PW_NW * 16) : G * (PW_NW * 16);
+        const int p_raw = r0 + wave_in_wg * 16 + j;
+        bool valid = p_raw < P.rows && (!remap || G < samples * gps);
+        const int p = p_raw < P.rows ? p_raw : P.rows - 1;
         const int b = p / P.rows_per_sample;
+        if (P.row_nuniq) {
+            // duplicate rows (>= nuniq of their sample) are skipped.  The decision must be uniform over the workgroup
+            // because the weight stream has barriers: skip only when all 64 rows of this iteration are duplicates.
+            const int r1 = min(r0 + PW_NW * 16, P.rows) - 1;
+            int skip = 0;
+            if (r0 < P.rows) {
+                const int b0 = r0 / P.rows_per_sample;
+                skip = (b0 == r1 / P.rows_per_sample) && (r0 - b0 * P.rows_per_sample >= P.row_nuniq[b0]);
+            }
+            // readfirstlane: the decision is wave- (and workgroup-) uniform by construction; say so, the branch must be scalar
+            if (__builtin_amdgcn_readfirstlane(skip)) continue;
+            valid = valid && (p - b * P.rows_per_sample) < P.row_nuniq[b];
+        }
 
         f4 h[U];
         // ---- segment 0 (optional): three-NN interpolation, lib/pointnet2_modules.py:141-146 -------------
         if (INTERP) {
-            const int *id = P.interp.idx + (size_t)p * 3;
+            const int *idp = P.interp.idx + (size_t)p * 3;
+            int id[3] = {idp[0], idp[1], idp[2]};
+            if (P.interp.nuniq) {       // known rows beyond the sample's unique count are copies of its row 0
+                const int e = P.interp.nuniq[b];
+                id[0] = id[0] < e ? id[0] : 0; id[1] = id[1] < e ? id[1] : 0; id[2] = id[2] < e ? id[2] : 0;
+            }
             const float *d2 = P.interp.dist2 + (size_t)p * 3;
             const float r0 = __fdiv_rn(1.0f, __fadd_rn(__fsqrt_rn(d2[0]), 1e-8f));
             const float r1 = __fdiv_rn(1.0f, __fadd_rn(__fsqrt_rn(d2[1]), 1e-8f));
@@ -198,7 +223,7 @@ static int launch_pw(const PwParams &P, bool interp, hipStream_t s) {
 extern "C" int rtk_pointwise_mlp(int rows, int rows_per_sample, const rtk_interp_t *interp, int nsrc,
                                  const rtk_src_t *srcs, const float *sample_bias, int nlayers,
                                  const rtk_layer_t *layers, float *out, int out_pitch, int out_channels,
-                                 int out_channel_major, rtk_stream_t stream) {
+                                 int out_channel_major, const int *row_nuniq, rtk_stream_t stream) {
     RTK_REQUIRE(rows > 0 && rows_per_sample > 0 && rows % rows_per_sample == 0, "pointwise_mlp: bad row counts (%d, %d)", rows, rows_per_sample);
     RTK_REQUIRE(nsrc >= 0 && nsrc <= RTK_MAX_SRC && (nsrc == 0 || srcs), "pointwise_mlp: nsrc=%d", nsrc);
     RTK_REQUIRE(nlayers >= 1 && nlayers <= RTK_MAX_LAYERS && layers && out, "pointwise_mlp: nlayers=%d", nlayers);
@@ -236,6 +261,7 @@ extern "C" int rtk_pointwise_mlp(int rows, int rows_per_sample, const rtk_interp
     P.out_pitch = out_pitch;
     P.out_channels = out_channels;
     P.out_cm = out_channel_major;
+    P.row_nuniq = row_nuniq;
     RTK_REQUIRE(out_channels > 0 && out_channels <= 16 * cin, "pointwise_mlp: out_channels=%d", out_channels);
     RTK_REQUIRE(out_channel_major || (out_pitch % 4 == 0 && out_pitch >= out_channels), "pointwise_mlp: bad out_pitch %d", out_pitch);
     hipStream_t s = (hipStream_t)stream;

@@ -33,14 +33,14 @@ class _Layer(ctypes.Structure):
 
 class _Interp(ctypes.Structure):
     _fields_ = [("known_feats", ctypes.c_void_p), ("pitch", ctypes.c_int), ("channels", ctypes.c_int), ("m", ctypes.c_int),
-                ("idx", ctypes.c_void_p), ("dist2", ctypes.c_void_p)]
+                ("idx", ctypes.c_void_p), ("dist2", ctypes.c_void_p), ("nuniq", ctypes.c_void_p)]
 
 
 _vp, _ci = ctypes.c_void_p, ctypes.c_int
 _lib.SIGNATURES.update({
     "rtk_pointwise_mlp": [_ci, _ci, ctypes.POINTER(_Interp), _ci, ctypes.POINTER(_Src), _vp, _ci, ctypes.POINTER(_Layer), _vp,
-                          _ci, _ci, _ci, _vp],
-    "rtk_sa_scale": [_ci] * 4 + [_vp] * 4 + [_ci, _ci, _vp, _ci, ctypes.POINTER(_Layer), _vp, _ci, _ci, _vp],
+                          _ci, _ci, _ci, _vp, _vp],
+    "rtk_sa_scale": [_ci] * 4 + [_vp] * 4 + [_ci, _ci, _vp, _ci, ctypes.POINTER(_Layer), _vp, _ci, _ci, _vp, _vp, _vp],
     "rtk_cost_volume": [_ci] * 3 + [_vp] * 6 + [ctypes.POINTER(_Layer), ctypes.POINTER(_Layer), _vp, _ci, _vp],
     "rtk_patch_cost": [_ci] * 2 + [_vp] * 3 + [_ci, ctypes.POINTER(_Layer), _vp, _ci, _ci, _vp],
     "rtk_prepare_inputs": [_ci] * 2 + [_vp] * 6 + [_vp],
@@ -118,19 +118,21 @@ def _colptr(t, col=0):
     return t.data_ptr() + 4 * col, t.stride(0)
 
 
-def pointwise(rows, rows_per_sample, srcs, chain, out, out_channels=None, sample_bias=None, interp=None, channel_major=False):
-    """Like pointwise_mlp but sources are (2-D tensor or column-sliced view, channels, per_sample)."""
+def pointwise(rows, rows_per_sample, srcs, chain, out, out_channels=None, sample_bias=None, interp=None, channel_major=False,
+              row_nuniq=None):
+    """srcs: list of (2-D tensor or column-sliced view, channels, per_sample).  out: (rows, pitch) point-major (may be a
+    column-sliced view) or (samples, C, n) channel-major.  interp: (known_feats (samples*m, pitch), channels, m,
+    idx (rows,3) int32, dist2 (rows,3)[, nuniq (samples) int32]).  row_nuniq: per-sample count of non-duplicate rows."""
     arr = (_Src * max(len(srcs), 1))()
-    keep = []
     for i, (t, ch, per) in enumerate(srcs):
         ptr, pitch = _colptr(t)
         arr[i].ptr, arr[i].pitch, arr[i].channels, arr[i].per_sample = ptr, pitch, ch, int(per)
-        keep.append(t)
     ip = None
     if interp is not None:
-        kf, ch, m, idx, d2 = interp
+        kf, ch, m, idx, d2 = interp[:5]
+        nu = interp[5] if len(interp) > 5 else None
         ptr, pitch = _colptr(kf)
-        ip = ctypes.pointer(_Interp(ptr, pitch, ch, m, idx.data_ptr(), d2.data_ptr()))
+        ip = ctypes.pointer(_Interp(ptr, pitch, ch, m, idx.data_ptr(), d2.data_ptr(), nu.data_ptr() if nu is not None else None))
     oc = out_channels if out_channels is not None else chain.cout
     if channel_major:
         optr, opitch = out.data_ptr(), 0
@@ -138,7 +140,7 @@ def pointwise(rows, rows_per_sample, srcs, chain, out, out_channels=None, sample
         optr, opitch = _colptr(out)
     _lib.call("rtk_pointwise_mlp", rows, rows_per_sample, ip, len(srcs), arr,
               sample_bias.data_ptr() if sample_bias is not None else None, chain.n, chain.arr, optr, opitch, oc,
-              int(channel_major), _stream())
+              int(channel_major), row_nuniq.data_ptr() if row_nuniq is not None else None, _stream())
     return out
 
 
@@ -311,6 +313,7 @@ class Geometry:
                     idx = fps_idx[lvl].view(S_, npoint)
                     _native.furthest_point_sampling_wrapper(S_, src.shape[1], npoint, src, temp, idx)
                     new_xyz[lvl].copy_(torch.gather(src, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)))
+                    cnt[lvl].fill_(npoint)      # no exhausted-cloud information on this path: every centroid is computed
                 self.xyz.append(new_xyz[lvl])
                 self.nuniq.append(cnt[lvl])
             self.ball = []
@@ -368,45 +371,50 @@ class Geometry:
 
 
 def sa_scale(geo, W, lvl, s, q, qcol, out, out_offset):
-    """One MSG scale (level lvl, scale s) of PNHead weights W on geometry geo; q[:, qcol:] holds its layer-1 projection."""
+    """One MSG scale (level lvl, scale s) of PNHead weights W on geometry geo; q[:, qcol:] holds its layer-1 projection.
+    Duplicate centroids (geo.nuniq) are skipped; gathers from duplicate source rows alias row 0."""
     sc = W.scales[lvl][s]
     qptr, qpitch = _colptr(q, qcol)
     optr, opitch = _colptr(out)
     src, dst = geo.xyz[lvl], geo.xyz[lvl + 1]
+    src_nu = geo.nuniq[lvl - 1].data_ptr() if lvl > 0 else None     # level-0 source rows are the original points
     _lib.call("rtk_sa_scale", geo.samples, src.shape[1], geo.npoint, sc.nsample, src.data_ptr(), dst.data_ptr(),
               geo.ball[lvl][s].data_ptr(), qptr, qpitch, ceil16(sc.c1) // 16, sc.w1img.data_ptr(),
-              sc.chain.n, sc.chain.arr, optr, opitch, out_offset, _stream())
+              sc.chain.n, sc.chain.arr, optr, opitch, out_offset, src_nu, geo.nuniq[lvl].data_ptr(), _stream())
 
 
 def run_pnhead(W, geo, q1):
-    """q1 (samples*n, 32): per-point sa1 layer-1 projections (scale 0 | scale 1).  Returns l0_points (samples*n, 128)."""
+    """q1 (samples*n, 32): per-point sa1 layer-1 projections (scale 0 | scale 1).  Returns l0_points (samples*n, 128).
+    All centroid-level tensors hold valid data only in rows < geo.nuniq[level][sample]; the rest are duplicates of the
+    sample's row 0 and are never read (consumers alias them)."""
     S_, n, S = geo.samples, geo.n, geo.npoint
     dev = q1.device
     new = lambda rows, c: torch.empty(rows, c, dtype=torch.float32, device=dev)
+    nu = geo.nuniq
     sa1 = new(S_ * S, 64)
     geo.wait(0)
     sa_scale(geo, W, 0, 0, q1, 0, sa1, 0)
     sa_scale(geo, W, 0, 1, q1, 16, sa1, 32)
-    t1 = pointwise(S_ * S, S, [(sa1, 64, False)], W.trans[0], new(S_ * S, 96))        # l1_points | q2_s0 | q2_s1
+    t1 = pointwise(S_ * S, S, [(sa1, 64, False)], W.trans[0], new(S_ * S, 96), row_nuniq=nu[0])      # l1_points | q2_s0 | q2_s1
     sa2 = new(S_ * S, 96)
     geo.wait(1)
     sa_scale(geo, W, 1, 0, t1, 32, sa2, 0)
     sa_scale(geo, W, 1, 1, t1, 64, sa2, 32)
-    t2 = pointwise(S_ * S, S, [(sa2, 96, False)], W.trans[1], new(S_ * S, 192))       # l2_points | q3_s0 | q3_s1
+    t2 = pointwise(S_ * S, S, [(sa2, 96, False)], W.trans[1], new(S_ * S, 192), row_nuniq=nu[1])     # l2_points | q3_s0 | q3_s1
     sa3 = new(S_ * S, 128)
     geo.wait(2)
     sa_scale(geo, W, 2, 0, t2, 64, sa3, 0)
     sa_scale(geo, W, 2, 1, t2, 128, sa3, 64)
-    l3 = pointwise(S_ * S, S, [(sa3, 128, False)], W.lin3, new(S_ * S, 64))
+    l3 = pointwise(S_ * S, S, [(sa3, 128, False)], W.lin3, new(S_ * S, 64), row_nuniq=nu[2])
     geo.wait("nn")
     d2, idx, m = geo.nn["fp3"]
-    f3 = pointwise(S_ * S, S, [(t2[:, 0:64], 64, False)], W.fp["fp3"], new(S_ * S, 128),
-                   interp=(l3, 64, m, idx.reshape(-1, 3), d2.reshape(-1, 3)))
+    f3 = pointwise(S_ * S, S, [(t2[:, 0:64], 64, False)], W.fp["fp3"], new(S_ * S, 128), row_nuniq=nu[1],
+                   interp=(l3, 64, m, idx.reshape(-1, 3), d2.reshape(-1, 3), nu[2]))
     d2, idx, m = geo.nn["fp2"]
-    f2 = pointwise(S_ * S, S, [(t1[:, 0:32], 32, False)], W.fp["fp2"], new(S_ * S, 128),
-                   interp=(f3, 128, m, idx.reshape(-1, 3), d2.reshape(-1, 3)))
+    f2 = pointwise(S_ * S, S, [(t1[:, 0:32], 32, False)], W.fp["fp2"], new(S_ * S, 128), row_nuniq=nu[0],
+                   interp=(f3, 128, m, idx.reshape(-1, 3), d2.reshape(-1, 3), nu[1]))
     d2, idx, m = geo.nn["fp1"]
-    return pointwise(S_ * n, n, [], W.fp["fp1"], new(S_ * n, 128), interp=(f2, 128, m, idx.reshape(-1, 3), d2.reshape(-1, 3)))
+    return pointwise(S_ * n, n, [], W.fp["fp1"], new(S_ * n, 128), interp=(f2, 128, m, idx.reshape(-1, 3), d2.reshape(-1, 3), nu[0]))
 
 
 class FusedBackbone:
