@@ -219,40 +219,42 @@ __device__ __forceinline__ f4 bias_frag(const float *__restrict__ bias, int v, i
 }
 
 // ---- reductions over the 16 positions of a tile (the 16 lanes of a DPP row) ---------------------
-// row_ror rotates within a 16-lane row, so 4 steps leave the full-row result in every lane.
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+// One instruction per step: v_max_f32 / v_add_f32 with a DPP-permuted first operand (row_ror rotates within a
+// 16-lane row, so 4 steps leave the full-row result in every lane).  Written as inline asm on a whole f4:
+// hipcc otherwise emits v_mov_b32_dpp + s_nop + canonicalising v_max per step (5x the instructions), which made
+// the epilogue, not the MFMAs, the cost of the small set-abstraction scales.  Hazard: a VGPR written by VALU needs
+// 2 wait states before a DPP read -- the leading s_nop 1 covers the producer of v, and inside the block each
+// register is re-read only after the 3 other components were issued.
+#define RTK_DPP4(op, ctrl)                                                 \
+    op " %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n"                 \
+    op " %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n"                 \
+    op " %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n"                 \
+    op " %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf\n"
+
+__device__ __forceinline__ void row_max16_f4(f4 &v) {
+    asm volatile("s_nop 1\n" RTK_DPP4("v_max_f32_dpp", "row_ror:8") RTK_DPP4("v_max_f32_dpp", "row_ror:4")
+                 RTK_DPP4("v_max_f32_dpp", "row_ror:2") RTK_DPP4("v_max_f32_dpp", "row_ror:1")
+                 : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
 }
 
-__device__ __forceinline__ float row_max16(float v) {
-    v = fmaxf(v, dpp_f<0x128>(v));  // row_ror:8
-    v = fmaxf(v, dpp_f<0x124>(v));  // row_ror:4
-    v = fmaxf(v, dpp_f<0x122>(v));  // row_ror:2
-    v = fmaxf(v, dpp_f<0x121>(v));  // row_ror:1
-    return v;
+__device__ __forceinline__ void row_sum16_f4(f4 &v) {
+    asm volatile("s_nop 1\n" RTK_DPP4("v_add_f32_dpp", "row_ror:8") RTK_DPP4("v_add_f32_dpp", "row_ror:4")
+                 RTK_DPP4("v_add_f32_dpp", "row_ror:2") RTK_DPP4("v_add_f32_dpp", "row_ror:1")
+                 : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
 }
 
-__device__ __forceinline__ float row_sum16(float v) {
-    v += dpp_f<0x128>(v);
-    v += dpp_f<0x124>(v);
-    v += dpp_f<0x122>(v);
-    v += dpp_f<0x121>(v);
-    return v;
-}
-
-// max over aligned sub-groups of GROUP (4 or 8) lanes within the row
+// max over aligned sub-groups of GROUP (4, 8 or 16) lanes within the row
 template <int GROUP>
-__device__ __forceinline__ float row_max_group(float v) {
-    if (GROUP >= 16) return row_max16(v);
-    // quad_perm / row_ror do not respect sub-group boundaries for 8; use xor-style swaps via ds_swizzle-free DPP:
-    // row_ror would mix groups, so use quad_perm for 1,2 and row_half_mirror-free shuffles for 4.
-    v = fmaxf(v, dpp_f<0xB1>(v));   // quad_perm:[1,0,3,2]  (xor 1)
-    v = fmaxf(v, dpp_f<0x4E>(v));   // quad_perm:[2,3,0,1]  (xor 2)
-    if (GROUP >= 8) {
-        // xor 4 inside each 8-lane half: row_half_mirror (0x141) maps lane i -> 7 - i within each half;
-        // after the quad reductions every quad is uniform, so mirroring reaches the other quad.
-        v = fmaxf(v, dpp_f<0x141>(v));
+__device__ __forceinline__ void row_max_group_f4(f4 &v) {
+    if constexpr (GROUP >= 16) {
+        row_max16_f4(v);
+    } else if constexpr (GROUP == 8) {
+        // quad xor-1, quad xor-2, then row_half_mirror (lane i <-> 7-i inside each 8-lane half reaches the other quad)
+        asm volatile("s_nop 1\n" RTK_DPP4("v_max_f32_dpp", "quad_perm:[1,0,3,2]") RTK_DPP4("v_max_f32_dpp", "quad_perm:[2,3,0,1]")
+                     RTK_DPP4("v_max_f32_dpp", "row_half_mirror")
+                     : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+    } else {
+        asm volatile("s_nop 1\n" RTK_DPP4("v_max_f32_dpp", "quad_perm:[1,0,3,2]") RTK_DPP4("v_max_f32_dpp", "quad_perm:[2,3,0,1]")
+                     : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
     }
-    return v;
 }

@@ -122,11 +122,8 @@ __global__ __launch_bounds__(256) void sa_scale_kernel(const SaParams P) {
         const float *bl = V3 ? P.bias3 : P.bias2;
 #pragma unroll
         for (int v = 0; v < VL; ++v) {
-            f4 m;
-            m.x = row_max_group<(NS > 16 ? 16 : NS)>(best[v].x);
-            m.y = row_max_group<(NS > 16 ? 16 : NS)>(best[v].y);
-            m.z = row_max_group<(NS > 16 ? 16 : NS)>(best[v].z);
-            m.w = row_max_group<(NS > 16 ? 16 : NS)>(best[v].w);
+            f4 m = best[v];
+            row_max_group_f4<(NS > 16 ? 16 : NS)>(m);
             best[v] = f4_relu(m + bias_frag(bl, v, g));
         }
         if (valid && slot0 == 0) {
@@ -285,11 +282,8 @@ __global__ __launch_bounds__(64 * CV_NW, 2) void cost_volume_kernel(const CvPara
 #pragma unroll
         for (int v = 0; v < CV_V; ++v) {
             const f4 w = weightnet_out(P.wn, lane, g, v, t2);
-            f4 r;
-            r.x = row_sum16(w.x * h[v].x);
-            r.y = row_sum16(w.y * h[v].y);
-            r.z = row_sum16(w.z * h[v].z);
-            r.w = row_sum16(w.w * h[v].w);
+            f4 r = w * h[v];
+            row_sum16_f4(r);
             if (valid && j == 0) *reinterpret_cast<f4 *>(o + 16 * v) = r;
         }
     }
@@ -364,11 +358,8 @@ __global__ __launch_bounds__(256) void patch_cost_kernel(const PcParams P) {
         for (int v = 0; v < CV_V; ++v) {
             const f4 w = weightnet_out(P.wn, lane, g, v, t2);
             const f4 f = *reinterpret_cast<const f4 *>(fr + 16 * v);
-            f4 r;
-            r.x = row_sum16(w.x * f.x);
-            r.y = row_sum16(w.y * f.y);
-            r.z = row_sum16(w.z * f.z);
-            r.w = row_sum16(w.w * f.w);
+            f4 r = w * f;
+            row_sum16_f4(r);
             if (j == 0) {
                 if (!P.out_cm) {
                     *reinterpret_cast<f4 *>(P.out + i * P.out_pitch + 16 * v + 4 * g) = r;
