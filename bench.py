@@ -67,6 +67,48 @@ def cpu_baseline(batch, n, budget_s=20.0):
             "sample": "%d forward passes of the CPU oracle at B=%d, N=%d (%.1f s)" % (runs, batch, n, el)}
 
 
+def bench_train(a, net, d, dev, dist, world, rank):
+    """Train step per rank on B frame-pairs: train-mode forward (HIP ops + PyTorch-ROCm dense layers, autograd),
+    multi-task loss, backward, ONE flat gradient all-reduce over RCCL, Adam.  Weak scaling (B per GPU fixed)."""
+    from ratrack_amd.ddp import broadcast_parameters
+    from ratrack_amd.train import Trainer
+    broadcast_parameters(net)
+    tr = Trainer(net)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in d.items()}
+    h = torch.zeros(5, a.batch, 128, device=dev)
+    step = lambda: tr.step(t["pc1"], t["pc2"], t["feature1"], t["feature2"], t["gt_warp"], t["gt_cls"], h)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    el = float(el.item())
+    if rank == 0:
+        pairs = a.batch * world * a.steps / el
+        print(json.dumps({
+            "metric": "radar frame-pairs/sec (train step) at B=%d,N=%d per GPU" % (a.batch, a.npoints), "value": round(pairs, 1),
+            "unit": "frame-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Track4D.backbone train step (fwd+loss+bwd+grad all-reduce+Adam), B=%d x N=%d per GPU, module path"
+                                   % (a.batch, a.npoints), "global_batch": a.batch * world,
+                       "parallelism": "dp%d, one flat RCCL all-reduce of %d bytes per step" % (world, tr.reducer.payload_bytes)},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,6 +118,9 @@ def main():
     ap.add_argument("--npoints", type=int, default=256, help="radar points per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--mode", choices=["forward", "train"], default="forward",
+                    help="forward = the headline metric (eval backbone, fused kernels); train = forward+loss+backward+"
+                         "gradient all-reduce+Adam on the module path (BASELINE config 3/4), reported with the same fields")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,6 +146,9 @@ def main():
     pc1, pc2 = torch.from_numpy(d["pc1"]).to(dev), torch.from_numpy(d["pc2"]).to(dev)
     f1, f2 = torch.from_numpy(d["feature1"]).to(dev), torch.from_numpy(d["feature2"]).to(dev)
     h = torch.zeros(5, a.batch, 128, device=dev)
+
+    if a.mode == "train":
+        return bench_train(a, net, d, dev, dist, world, rank)
 
     eng = None
     with torch.no_grad():

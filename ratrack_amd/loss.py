@@ -22,14 +22,18 @@ def flow_loss(pc1_warp, gt_flow):
 
 
 def motion_seg_loss(pred_cls, gt_cls):
-    """pred (B,N) probabilities, gt (B,N) or (N,) bool -> (B,) 0.4*BCE_pos + 0.6*BCE_neg (NaN if a class is empty)."""
+    """pred (B,N) probabilities, gt (B,N) or (N,) bool -> ((B,) 0.4*BCE_pos + 0.6*BCE_neg, (B,) bool defined).
+    A sample without positives (or without negatives) has an undefined term -- the reference gets NaN from a mean over
+    an empty selection and then zeroes the WHOLE segmentation loss (losses/loss.py:19-20).  The division is masked
+    (x / max(count,1) selected by count > 0) so that the zeroed samples also have exactly zero -- not NaN -- gradient."""
     if gt_cls.dim() == 1:
         gt_cls = gt_cls.unsqueeze(0).expand_as(pred_cls)
     g = gt_cls.to(pred_cls.dtype)
     bce = F.binary_cross_entropy(pred_cls, g, reduction="none")
-    pos = (bce * g).sum(1) / g.sum(1)
-    neg = (bce * (1 - g)).sum(1) / (1 - g).sum(1)
-    return 0.4 * pos + 0.6 * neg
+    npos, nneg = g.sum(1), (1 - g).sum(1)
+    pos = (bce * g).sum(1) / npos.clamp_min(1)
+    neg = (bce * (1 - g)).sum(1) / nneg.clamp_min(1)
+    return 0.4 * pos + 0.6 * neg, (npos > 0) & (nneg > 0)
 
 
 def affinity_loss(mappings_prev, mappings_curr, aff_mat):
@@ -48,7 +52,8 @@ def _nan_to_zero(x):
 def backbone_loss(pc1_warp, cls, gt_flow, gt_cls, pretrain=False, trk_loss=None):
     """Batch mean of the per-sample reference loss.  Returns (total, items) with the reference's keys."""
     sf = _nan_to_zero(flow_loss(pc1_warp, gt_flow)).mean()
-    seg = _nan_to_zero(motion_seg_loss(cls, gt_cls)).mean()
+    seg_i, defined = motion_seg_loss(cls, gt_cls)
+    seg = torch.where(defined, seg_i, torch.zeros_like(seg_i)).mean()
     trk = trk_loss if trk_loss is not None else torch.zeros((), device=pc1_warp.device)
     total = seg if pretrain else 0.5 * sf + 0.5 * trk + seg
     return total, {"Loss": total, "SceneFlowLoss": sf, "TrackingLoss": trk, "SegLoss": seg}

@@ -56,3 +56,7 @@ def test_batched_loss_is_mean_of_per_sample():
     assert abs(float(it["SegLoss"]) - np.mean([float(p["SegLoss"]) for p in per])) < 1e-6
     assert abs(float(it["SceneFlowLoss"]) - np.mean([float(p["SceneFlowLoss"]) for p in per])) < 1e-6
     assert float(per[2]["SegLoss"]) == 0.0
+    # the zeroed sample must contribute a ZERO gradient, not NaN (0/0 under a nan->0 select poisons the weights)
+    cls2 = cls.clone().requires_grad_(True)
+    L.backbone_loss(warp, cls2, gt, g)[0].backward()
+    assert torch.isfinite(cls2.grad).all() and float(cls2.grad[2].abs().sum()) == 0.0
