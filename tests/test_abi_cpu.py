@@ -37,7 +37,8 @@ def test_library_builds_loads_and_exports_everything():
         assert hasattr(lib, name), "librtk_hip.so does not export %s" % name
     lib.rtk_version.restype = ctypes.c_int
     assert lib.rtk_version() >= 1
-    # the Python binding knows every compute entry point the header declares
+    # the Python binding knows every compute entry point the headers declare (fused.py registers rtk_fused.h's)
+    import ratrack_amd.fused  # noqa: F401
     bound = set(_lib.SIGNATURES) | {"rtk_last_error", "rtk_version"}
     assert set(declared_symbols()) <= bound, set(declared_symbols()) - bound
 
