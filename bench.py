@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 # algorithmic work per frame-pair forward (fp32, weights excluded)
 ALG_BYTES_PER_PAIR = {256: 14154240, 1024: 25293312}
 ALG_FLOPS_PER_PAIR = {256: 4.003e9, 1024: 10.790e9}
+EXEC_FLOPS_PER_PAIR = {256: 1.78e9}
 FP32_PEAK_TFLOPS = 157.3      # MI355X fp32 vector == fp32-input MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 
@@ -118,6 +119,7 @@ def main():
     ap.add_argument("--npoints", type=int, default=256, help="radar points per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--pipeline", type=int, default=2, help="captured graphs in flight (batch-level pipelining on streams)")
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
                     help="forward = the headline metric (eval backbone, fused kernels); train = forward+loss+backward+"
                          "gradient all-reduce+Adam on the module path (BASELINE config 3/4), reported with the same fields")
@@ -156,11 +158,15 @@ def main():
         eng = net._fused
         assert eng, "fused engine not active"
         step = lambda: net.backbone(pc1, pc2, f1, f2, h)
-        if not a.no_graph and hasattr(eng, "capture"):
-            gstep = eng.capture(pc1, pc2, f1, f2, h)
-            step = lambda: gstep(pc1, pc2, f1, f2, h)
+        pipe = None
+        if not a.no_graph:
+            from ratrack_amd.fused import GraphPipeline
+            pipe = GraphPipeline(eng, (pc1, pc2, f1, f2, h), depth=max(1, a.pipeline))
+            step = lambda: pipe.submit(pc1, pc2, f1, f2, h)        # inputs are copied into the slot's static buffers
 
         def barrier():
+            if pipe is not None:
+                pipe.drain()                                       # every submitted batch finishes inside the timed region
             if dist is not None:
                 dist.barrier()
             torch.cuda.synchronize()
@@ -197,13 +203,18 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Track4D.backbone forward, B=%d frame-pairs x N=%d points per GPU, S=512 centroids, "
-                                   "eval-mode BN, random-init weights, hipGraph=%s" % (a.batch, a.npoints, not a.no_graph),
+                                   "eval-mode BN, random-init weights, hipGraph=%s, batches in flight=%d"
+                                   % (a.batch, a.npoints, not a.no_graph, 1 if a.no_graph else max(1, a.pipeline)),
                        "global_batch": a.batch * world, "parallelism": "replicas x%d (no collective on the forward path)" % world},
             "roofline": {"kernel": "cost_volume_kernel", "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None,
                          "kernel_ms": round(kern_ms, 4), "flops_per_launch": cv_flops},
+            # whole path per GPU against both rooflines (SURVEY.md H1 asks for both).  "algorithmic" = the reference
+            # formulation's 14.15 MB / 4.003 GFLOP per pair; "executed" = the multiply-adds this design actually issues
+            # (per-point layer-1 projections, duplicate centroids skipped): 1.78 GFLOP per pair at N=256.
             "whole_path": {"hbm_frac_algorithmic": round(pairs_per_s / world * ALG_BYTES_PER_PAIR.get(a.npoints, 0) / (HBM_PEAK_GBS * 1e9), 5),
-                           "fp32_frac_algorithmic": round(pairs_per_s / world * ALG_FLOPS_PER_PAIR.get(a.npoints, 0) / (FP32_PEAK_TFLOPS * 1e12), 5)},
+                           "fp32_frac_algorithmic": round(pairs_per_s / world * ALG_FLOPS_PER_PAIR.get(a.npoints, 0) / (FP32_PEAK_TFLOPS * 1e12), 5),
+                           "fp32_frac_executed": round(pairs_per_s / world * EXEC_FLOPS_PER_PAIR.get(a.npoints, 0) / (FP32_PEAK_TFLOPS * 1e12), 5)},
         }
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(8, a.npoints)

@@ -596,3 +596,45 @@ class FusedBackbone:
             return outs
         step.graph = graph
         return step
+
+
+class GraphPipeline:
+    """Batch-level software pipeline for throughput: `depth` captured backbone graphs, each with its own static
+    buffers and geometry side stream, replayed round-robin on `depth` streams.  While one batch sits in its
+    latency-bound phases (FPS chain, small gathers) the MFMA stages of the previous/next batch keep the CUs busy
+    (measured on MI355X at B=64, N=256: 1.85 -> 1.57 ms per batch with depth 2; depth 3 gives nothing more).
+    Weights are shared between the engines.  Usage:  p = GraphPipeline(net, example_inputs); outs = p.submit(*inputs)
+    ... p.drain().  Outputs of a submit stay valid until the same slot is reused, `depth` submits later."""
+
+    def __init__(self, model_or_engine, example_inputs, depth=2):
+        import copy
+        eng = model_or_engine if isinstance(model_or_engine, FusedBackbone) else FusedBackbone(model_or_engine)
+        self.engines = [eng]
+        for _ in range(depth - 1):
+            e = copy.copy(eng)          # shallow: packed weights are shared, per-engine state is reset below
+            e.side, e._last_cv, e.kernel_events = None, None, None
+            self.engines.append(e)
+        self.depth = depth
+        with torch.no_grad():
+            self.steps = [e.capture(*example_inputs) for e in self.engines]
+        self.streams = [torch.cuda.Stream() for _ in range(depth)]
+        self.i = 0
+        self._forked = False
+
+    def submit(self, *inputs):
+        cur = torch.cuda.current_stream()
+        if not self._forked:
+            for s in self.streams:
+                s.wait_stream(cur)
+            self._forked = True
+        k = self.i % self.depth
+        self.i += 1
+        with torch.cuda.stream(self.streams[k]):
+            return self.steps[k](*inputs)
+
+    def drain(self):
+        """Join all in-flight batches into the current stream."""
+        cur = torch.cuda.current_stream()
+        for s in self.streams:
+            cur.wait_stream(s)
+        self._forked = False
