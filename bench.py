@@ -194,6 +194,13 @@ def main():
         pairs_per_s = a.batch * world * a.steps / elapsed
         cv_flops = cost_volume_flops_per_pair(a.npoints) * a.batch
         achieved = cv_flops / (kern_ms * 1e-3) / 1e12
+        traffic = None
+        try:   # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (same workload only)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_cost_volume.json")))
+            if a.batch == 64 and a.npoints == 256:
+                traffic = pm["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         res = {
             "metric": "radar frame-pairs/sec (backbone forward, eval) at B=%d,N=%d per GPU" % (a.batch, a.npoints),
             "value": round(pairs_per_s, 1),
@@ -207,7 +214,7 @@ def main():
                                    % (a.batch, a.npoints, not a.no_graph, 1 if a.no_graph else max(1, a.pipeline)),
                        "global_batch": a.batch * world, "parallelism": "replicas x%d (no collective on the forward path)" % world},
             "roofline": {"kernel": "cost_volume_kernel", "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
                          "kernel_ms": round(kern_ms, 4), "flops_per_launch": cv_flops},
             # whole path per GPU against both rooflines (SURVEY.md H1 asks for both).  "algorithmic" = the reference
             # formulation's 14.15 MB / 4.003 GFLOP per pair; "executed" = the multiply-adds this design actually issues
