@@ -121,6 +121,18 @@ RTK_EXPORT int rtk_gru_step(int b, int layers, int hidden, const float *x, const
 RTK_EXPORT int rtk_to_channel_major(int samples, int n, int channels, const float *src, int src_pitch, int per_sample,
                                     float *dst, int dst_channels, int dst_channel_offset, rtk_stream_t stream);
 
+/* Both ball queries of one MSG level in a single scan of the source cloud (lib/pointnet2_modules.py:37-38 issues
+ * one ball_query per scale over the same centroids): identical results to two rtk_ball_query calls with
+ * (radius1, nsample1) and (radius2, nsample2), radius1 <= radius2.  idx1/idx2 zero-initialised by the caller.
+ * nuniq (optional, (B)): centroids >= nuniq[b] (duplicates of centroid 0, see rtk_fps_centroids) are skipped. */
+RTK_EXPORT int rtk_ball_query_pair(int b, int n, int npoint, float radius1, int nsample1, float radius2, int nsample2,
+                                   const float *new_xyz, const float *xyz, int *idx1, int *idx2, const int *nuniq,
+                                   rtk_stream_t stream);
+
+/* rtk_three_nn restricted to the non-duplicate unknown rows: rows >= unknown_nuniq[b] are not computed. */
+RTK_EXPORT int rtk_three_nn_masked(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
+                                   const int *unknown_nuniq, rtk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

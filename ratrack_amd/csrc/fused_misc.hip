@@ -39,6 +39,7 @@ extern "C" int rtk_prepare_inputs(int b, int n, const float *pc1, const float *p
 // TRANSPOSED (L, H, 3H) so that the 3H threads read consecutive addresses (L2-resident: 1.9 MB shared by all
 // workgroups); the H-vectors live in LDS.
 // ------------------------------------------------------------------------------------------------
+#define GRU_MAXL 8
 __global__ __launch_bounds__(384) void gru_step_kernel(int b, int layers, int hidden, const float *__restrict__ x,
                                                        const float *__restrict__ h_in, const float *__restrict__ w_ih,
                                                        const float *__restrict__ w_hh, const float *__restrict__ b_ih,
@@ -80,8 +81,8 @@ __global__ __launch_bounds__(384) void gru_step_kernel(int b, int layers, int hi
 extern "C" int rtk_gru_step(int b, int layers, int hidden, const float *x, const float *h_in, const float *w_ih,
                             const float *w_hh, const float *b_ih, const float *b_hh, float *h_out, float *y,
                             rtk_stream_t stream) {
-    RTK_REQUIRE(b > 0 && layers > 0 && hidden > 0 && hidden <= 128 && hidden % 4 == 0 && x && h_in && w_ih && w_hh && b_ih &&
-                b_hh && h_out && y, "gru_step: bad arguments (hidden=%d)", hidden);
+    RTK_REQUIRE(b > 0 && layers > 0 && layers <= GRU_MAXL && hidden > 0 && hidden <= 128 && hidden % 4 == 0 && x && h_in && w_ih &&
+                w_hh && b_ih && b_hh && h_out && y, "gru_step: bad arguments (hidden=%d, layers=%d)", hidden, layers);
     gru_step_kernel<<<b, 384, 0, (hipStream_t)stream>>>(b, layers, hidden, x, h_in, w_ih, w_hh, b_ih, b_hh, h_out, y);
     RTK_CHECK_LAUNCH("gru_step");
     return RTK_OK;

@@ -362,6 +362,75 @@ extern "C" int rtk_ball_query(int b, int n, int npoint, float radius, int nsampl
     return RTK_OK;
 }
 
+// Both scales of an MSG level in one scan (radius1 <= radius2, so every scale-1 hit is a scale-2 hit).
+__global__ __launch_bounds__(64 * BQ_WAVES) void ball_query_pair_kernel(int n, int m, float r2a, int nsa, float r2b, int nsb,
+                                                                         const float *__restrict__ new_xyz,
+                                                                         const float *__restrict__ xyz, int *__restrict__ idxa,
+                                                                         int *__restrict__ idxb, const int *__restrict__ nuniq) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bs = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    xyz += (size_t)bs * n * 3;
+    float *sx = smem, *sy = smem + n, *sz = smem + 2 * n;
+    const int c0 = (blockIdx.x * BQ_WAVES + wave) * BQ_CENTROIDS_PER_WAVE;
+    const int climit = nuniq ? min(m, nuniq[bs]) : m;
+    if (blockIdx.x * BQ_WAVES * BQ_CENTROIDS_PER_WAVE >= climit) return;      // whole workgroup beyond the unique centroids
+    for (int k = tid; k < n; k += 64 * BQ_WAVES) {
+        sx[k] = xyz[k * 3 + 0];
+        sy[k] = xyz[k * 3 + 1];
+        sz[k] = xyz[k * 3 + 2];
+    }
+    __syncthreads();
+    for (int ci = 0; ci < BQ_CENTROIDS_PER_WAVE; ++ci) {
+        const int pt = c0 + ci;
+        if (pt >= climit) break;
+        const float *q = new_xyz + ((size_t)bs * m + pt) * 3;
+        const float qx = q[0], qy = q[1], qz = q[2];
+        int *oa = idxa + ((size_t)bs * m + pt) * nsa;
+        int *ob = idxb + ((size_t)bs * m + pt) * nsb;
+        int ca = 0, cb = 0, fa = -1, fb = -1;
+        for (int base = 0; base < n && (ca < nsa || cb < nsb); base += 64) {
+            const int k = base + lane;
+            float d2 = INFINITY;
+            if (k < n) d2 = rtk_sqdist(qx, qy, qz, sx[k], sy[k], sz[k]);
+            const bool hb = d2 < r2b, ha = d2 < r2a;
+            const unsigned long long mb = __ballot(hb);
+            if (mb) {
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (cb < nsb) {
+                    if (fb < 0) fb = base + __builtin_ctzll(mb);
+                    const int rank = cb + __builtin_popcountll(mb & below);
+                    if (hb && rank < nsb) ob[rank] = k;
+                    cb += __builtin_popcountll(mb);
+                }
+                const unsigned long long ma = __ballot(ha);
+                if (ma && ca < nsa) {
+                    if (fa < 0) fa = base + __builtin_ctzll(ma);
+                    const int rank = ca + __builtin_popcountll(ma & below);
+                    if (ha && rank < nsa) oa[rank] = k;
+                    ca += __builtin_popcountll(ma);
+                }
+            }
+        }
+        if (fa >= 0 && ca < nsa) for (int l = ca + lane; l < nsa; l += 64) oa[l] = fa;
+        if (fb >= 0 && cb < nsb) for (int l = cb + lane; l < nsb; l += 64) ob[l] = fb;
+    }
+}
+
+extern "C" int rtk_ball_query_pair(int b, int n, int npoint, float radius1, int nsample1, float radius2, int nsample2,
+                                   const float *new_xyz, const float *xyz, int *idx1, int *idx2, const int *nuniq,
+                                   rtk_stream_t stream) {
+    RTK_REQUIRE(b > 0 && n > 0 && npoint > 0 && nsample1 > 0 && nsample2 > 0 && new_xyz && xyz && idx1 && idx2, "ball_query_pair: bad arguments");
+    RTK_REQUIRE(radius1 <= radius2, "ball_query_pair: radius1 (%g) must not exceed radius2 (%g)", radius1, radius2);
+    RTK_REQUIRE(b <= 65535 && (size_t)n * 12 <= 64 * 1024, "ball_query_pair: b or n too large (n=%d)", n);
+    dim3 grid(rtk_divup(npoint, BQ_WAVES * BQ_CENTROIDS_PER_WAVE), b);
+    ball_query_pair_kernel<<<grid, 64 * BQ_WAVES, (size_t)n * 12, (hipStream_t)stream>>>(n, npoint, radius1 * radius1, nsample1,
+                                                                                         radius2 * radius2, nsample2, new_xyz, xyz,
+                                                                                         idx1, idx2, nuniq);
+    RTK_CHECK_LAUNCH("ball_query_pair");
+    return RTK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // group_points / grad   (group_points_gpu.cu:47-66, 8-25)
 // ------------------------------------------------------------------------------------------------
@@ -494,9 +563,10 @@ __device__ __forceinline__ void kv_row_merge(unsigned (&d)[K], int (&i)[K]) {
 template <bool USE_LDS>
 __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float *__restrict__ unknown,
                                                        const float *__restrict__ known, float *__restrict__ dist2,
-                                                       int *__restrict__ idx) {
+                                                       int *__restrict__ idx, const int *__restrict__ unknown_nuniq) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bs = blockIdx.y, tid = threadIdx.x;
+    if (unknown_nuniq && blockIdx.x * 16 >= unknown_nuniq[bs]) return;    // all 16 queries of this workgroup are duplicate rows
     known += (size_t)bs * m * 3;
     float *sx = smem, *sy = smem + m, *sz = smem + 2 * m;
     if (USE_LDS) {
@@ -546,10 +616,24 @@ extern "C" int rtk_three_nn(int b, int n, int m, const float *unknown, const flo
     dim3 grid(rtk_divup(n, 16), b);
     const size_t lds = (size_t)m * 3 * sizeof(float);
     if (lds <= 64 * 1024)
-        three_nn_kernel<true><<<grid, 256, lds, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx);
+        three_nn_kernel<true><<<grid, 256, lds, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx, nullptr);
     else
-        three_nn_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx);
+        three_nn_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx, nullptr);
     RTK_CHECK_LAUNCH("three_nn");
+    return RTK_OK;
+}
+
+extern "C" int rtk_three_nn_masked(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
+                                   const int *unknown_nuniq, rtk_stream_t stream) {
+    RTK_REQUIRE(b > 0 && n > 0 && m > 0 && unknown && known && dist2 && idx, "three_nn_masked: bad arguments");
+    RTK_REQUIRE(b <= 65535, "three_nn_masked: b exceeds grid limits");
+    dim3 grid(rtk_divup(n, 16), b);
+    const size_t lds = (size_t)m * 3 * sizeof(float);
+    if (lds <= 64 * 1024)
+        three_nn_kernel<true><<<grid, 256, lds, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx, unknown_nuniq);
+    else
+        three_nn_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx, unknown_nuniq);
+    RTK_CHECK_LAUNCH("three_nn_masked");
     return RTK_OK;
 }
 

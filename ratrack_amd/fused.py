@@ -47,6 +47,8 @@ _lib.SIGNATURES.update({
     "rtk_fps_centroids": [_ci] * 3 + [_vp] * 4 + [_vp],
     "rtk_gru_step": [_ci] * 3 + [_vp] * 8 + [_vp],
     "rtk_to_channel_major": [_ci] * 3 + [_vp, _ci, _ci, _vp, _ci, _ci, _vp],
+    "rtk_ball_query_pair": [_ci] * 3 + [ctypes.c_float, _ci, ctypes.c_float, _ci] + [_vp] * 5 + [_vp],
+    "rtk_three_nn_masked": [_ci] * 3 + [_vp] * 5 + [_vp],
 })
 
 
@@ -327,17 +329,26 @@ class Geometry:
             # order on the side stream = order of first use: level-l tables right after level-l centroids
             # (the three FPS calls are a dependent chain, so they were enqueued first)
             for lvl in range(3):
-                for s in range(2):
-                    ns, r = _PNHeadWeights.NSAMPLES[lvl][s], _PNHeadWeights.RADII[lvl][s]
-                    _native.ball_query_wrapper(S_, self.xyz[lvl].shape[1], npoint, float(r), ns, self.xyz[lvl + 1], self.xyz[lvl],
-                                               self.ball[lvl][s])
+                (r1, r2), (n1, n2) = _PNHeadWeights.RADII[lvl], _PNHeadWeights.NSAMPLES[lvl]
+                nsrc = self.xyz[lvl].shape[1]
+                if nsrc * 12 <= 64 * 1024:      # both scales in one scan, duplicate centroids skipped
+                    _lib.call("rtk_ball_query_pair", S_, nsrc, npoint, float(r1), n1, float(r2), n2, self.xyz[lvl + 1].data_ptr(),
+                              self.xyz[lvl].data_ptr(), self.ball[lvl][0].data_ptr(), self.ball[lvl][1].data_ptr(),
+                              self.nuniq[lvl].data_ptr(), _stream())
+                else:
+                    for s in range(2):
+                        _native.ball_query_wrapper(S_, nsrc, npoint, float(_PNHeadWeights.RADII[lvl][s]), _PNHeadWeights.NSAMPLES[lvl][s],
+                                                   self.xyz[lvl + 1], self.xyz[lvl], self.ball[lvl][s])
                 self._record(lvl, side)
             self.nn = {}
             for i, (name, (u, k)) in enumerate({"fp3": (2, 3), "fp2": (1, 2), "fp1": (0, 1)}.items()):
                 nu, m = self.xyz[u].shape[1], self.xyz[k].shape[1]
                 d2 = d2_parts[i].view(S_, nu, 3)
                 idx = nn_idx[i].view(S_, nu, 3)
-                _native.three_nn_wrapper(S_, nu, m, self.xyz[u], self.xyz[k], d2, idx)
+                # unknown rows of fp3 / fp2 are level centroids: duplicates are never read downstream
+                mask = self.nuniq[u - 1].data_ptr() if u > 0 else None
+                _lib.call("rtk_three_nn_masked", S_, nu, m, self.xyz[u].data_ptr(), self.xyz[k].data_ptr(), d2.data_ptr(), idx.data_ptr(),
+                          mask, _stream())
                 self.nn[name] = (d2, idx, m)
             self._record("nn", side)
             if B:

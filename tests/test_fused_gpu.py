@@ -288,3 +288,33 @@ def test_fps_identity():
         assert F.fps_identity_holds(512, 512)
         F._check_fps_identity(l1, 512, c1)        # asserts new_xyz == l1 and equal counters
     assert not F.fps_identity_holds(500, 512) and not F.fps_identity_holds(2048, 2048) and not F.fps_identity_holds(384, 384)
+
+
+def test_ball_query_pair_and_masked_three_nn():
+    from oracle import pointnet2_ref as P
+    from ratrack_amd import _lib, synth
+    d = synth.make_frame_pairs(3, 300, 21)
+    xyz = torch.from_numpy(d["pc1"]).permute(0, 2, 1).contiguous()
+    q = torch.from_numpy(d["pc2"]).permute(0, 2, 1).contiguous()[:, :200].contiguous()
+    q[:, 0] = 900.0                                           # empty balls
+    nuniq = torch.tensor([200, 150, 7], dtype=torch.int32)
+    for (r1, n1, r2, n2) in [(2.0, 4, 4.0, 8), (4.0, 8, 8.0, 16), (8.0, 16, 16.0, 32)]:
+        i1 = torch.zeros(3, 200, n1, dtype=torch.int32, device=DEV)
+        i2 = torch.zeros(3, 200, n2, dtype=torch.int32, device=DEV)
+        xd, qd, nd = xyz.to(DEV), q.to(DEV), nuniq.to(DEV)
+        _lib.call("rtk_ball_query_pair", 3, 300, 200, r1, n1, r2, n2, qd.data_ptr(), xd.data_ptr(), i1.data_ptr(), i2.data_ptr(),
+                  nd.data_ptr(), F._stream())
+        ra, rb = P.ball_query(r1, n1, xyz, q), P.ball_query(r2, n2, xyz, q)
+        for b in range(3):
+            e = int(nuniq[b])
+            assert torch.equal(i1[b, :e].cpu(), ra[b, :e]) and torch.equal(i2[b, :e].cpu(), rb[b, :e])
+            assert (i1[b, e:] == 0).all() and (i2[b, e:] == 0).all()         # skipped rows keep the caller's zeros
+    d2 = torch.full((3, 200, 3), -1.0, device=DEV)
+    idx = torch.full((3, 200, 3), -1, dtype=torch.int32, device=DEV)
+    _lib.call("rtk_three_nn_masked", 3, 200, 300, qd.data_ptr(), xd.data_ptr(), d2.data_ptr(), idx.data_ptr(), nd.data_ptr(), F._stream())
+    rd, ri = P.three_nn(q, xyz)
+    for b in range(3):
+        e = int(nuniq[b])
+        assert torch.equal(idx[b, :e].cpu(), ri[b, :e]) and torch.equal(d2[b, :e].cpu(), rd[b, :e])
+        lim = (e + 15) // 16 * 16
+        assert (idx[b, lim:] == -1).all()
