@@ -49,48 +49,37 @@ __global__ __launch_bounds__(256) void sa_scale_kernel(const SaParams P) {
     constexpr int CPT = NS >= 16 ? 1 : 16 / NS;      // centroids per tile
     __shared__ __attribute__((aligned(16))) f4 s_w[NF * 64];
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    // 2-D grid: blockIdx.y = sample, blockIdx.x strides over the sample's centroid groups -- all index arithmetic is
+    // 32-bit and division-free (a 64-bit divide per tile cost more issue slots than the MFMAs of the small scales).
+    // Workgroups whose groups are all duplicates (>= nuniq[b], copies of centroid 0) exit at once; the dispatcher
+    // back-fills them, which spreads the live work evenly.
+    const int b = blockIdx.y;
+    const int dst_e = P.dst_nuniq ? __builtin_amdgcn_readfirstlane(P.dst_nuniq[b]) : P.npoint;
+    const int live_groups = (min(dst_e, P.npoint) + CPT - 1) / CPT;
+    if ((int)blockIdx.x * 4 >= live_groups) return;
     for (int i = threadIdx.x; i < NF * 64; i += blockDim.x) s_w[i] = P.blob[i];
     float w1[V1];
 #pragma unroll
     for (int v = 0; v < V1; ++v) w1[v] = P.w1[v * 64 + lane];
     __syncthreads();
-
-    const long total_centroids = (long)P.samples * P.npoint;
-    const long units = (total_centroids + CPT - 1) / CPT;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const int slot0 = j % NS;                         // neighbour slot of this lane within the first tile
-    // Work order: sample-minor (consecutive waves take the same centroid group of different samples) so that the
-    // duplicate-centroid tail of every sample is spread evenly over the waves instead of landing on the same ones.
-    const long groups_per_sample = P.npoint / CPT;
-    const bool remap = (P.npoint % CPT) == 0;
-    for (long w_i = wave; w_i < units; w_i += nwaves) {
-        const long unit = remap ? (w_i % P.samples) * groups_per_sample + w_i / P.samples : w_i;
-        long c = unit * CPT + (NS >= 16 ? 0 : j / NS);        // centroid of this lane (global index)
-        const bool valid = c < total_centroids;
-        if (!valid) c = total_centroids - 1;
-        const int b = (int)(c / P.npoint);
-        if (P.dst_nuniq) {
-            // centroids >= nuniq[b] are copies of the sample's centroid 0 (FPS exhausted the cloud): skip the unit when all
-            // of its centroids are duplicates (lane 0 holds the unit's first centroid: wave-uniform decision)
-            const long cf = unit * CPT;
-            const int bf = (int)(cf / P.npoint);
-            const long cl = min(cf + CPT, total_centroids) - 1;
-            const int ef = __builtin_amdgcn_readfirstlane(P.dst_nuniq[bf]);
-            if (bf == (int)(cl / P.npoint) && cf - (long)bf * P.npoint >= ef) continue;
-        }
+    for (int unit = blockIdx.x * 4 + (threadIdx.x >> 6); unit < live_groups; unit += gridDim.x * 4) {
+        int cl = unit * CPT + (NS >= 16 ? 0 : j / NS);        // centroid of this lane within the sample
+        const bool valid = cl < P.npoint;
+        if (!valid) cl = P.npoint - 1;
+        const int c = b * P.npoint + cl;                      // global centroid index (fits 32 bits: asserted by the launcher)
         const int src_e = P.src_nuniq ? P.src_nuniq[b] : 0x7fffffff;
-        const float cg = g < 3 ? P.new_xyz[c * 3 + g] : 0.f;
+        const float cg = g < 3 ? P.new_xyz[(long)c * 3 + g] : 0.f;
         f4 best[VL];
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
             const int slot = slot0 + 16 * t;
-            const int id = P.idx[c * NS + slot];
-            const long src = (long)b * P.n + id;
+            const int id = P.idx[(long)c * NS + slot];
+            const int src = b * P.n + id;
             // offset operand: (neighbour - centroid) component g, or 1 for the bias column
-            const float bop = g < 3 ? __fsub_rn(P.xyz[src * 3 + g], cg) : 1.0f;
+            const float bop = g < 3 ? __fsub_rn(P.xyz[(long)src * 3 + g], cg) : 1.0f;
             f4 a1[V1];
-            const float *qrow = P.q + ((long)b * P.n + (id < src_e ? id : 0)) * P.q_pitch + 4 * g;   // duplicate source rows alias row 0
+            const float *qrow = P.q + (long)(b * P.n + (id < src_e ? id : 0)) * P.q_pitch + 4 * g;   // duplicate source rows alias row 0
 #pragma unroll
             for (int v = 0; v < V1; ++v) a1[v] = *reinterpret_cast<const f4 *>(qrow + 16 * v);
 #pragma unroll
@@ -127,7 +116,7 @@ __global__ __launch_bounds__(256) void sa_scale_kernel(const SaParams P) {
             best[v] = f4_relu(m + bias_frag(bl, v, g));
         }
         if (valid && slot0 == 0) {
-            float *o = P.out + c * P.out_pitch + P.out_offset + 4 * g;
+            float *o = P.out + (long)c * P.out_pitch + P.out_offset + 4 * g;
 #pragma unroll
             for (int v = 0; v < VL; ++v) *reinterpret_cast<f4 *>(o + 16 * v) = best[v];
         }
@@ -156,11 +145,13 @@ extern "C" int rtk_sa_scale(int samples, int n, int npoint, int nsample, const f
     P.src_nuniq = src_nuniq; P.dst_nuniq = dst_nuniq;
     const int v1 = c1_16, v2 = layers[0].cout16, v3 = nlayers == 2 ? layers[1].cout16 : 0;
     hipStream_t s = (hipStream_t)stream;
-    const long centroids = (long)samples * npoint;
+    RTK_REQUIRE((long)samples * npoint * nsample < 0x7fffffffL && (long)samples * n < 0x7fffffffL && samples <= 65535,
+                "sa_scale: problem too large for 32-bit indexing");
     const int cpt = nsample >= 16 ? 1 : 16 / nsample;
-    const long units = (centroids + cpt - 1) / cpt;
-    int blocks = (int)((units + 3) / 4);
-    if (blocks > 2048) blocks = 2048;
+    const int groups = (npoint + cpt - 1) / cpt;
+    int bx = (groups + 3) / 4;                 // one unit per wave per pass ...
+    while ((long)bx * samples > 4096 && bx > 1) bx = (bx + 1) / 2;      // ... unless that makes an absurd number of workgroups
+    const dim3 blocks(bx, samples);
     const long key = (((long)nsample * 32 + v1) * 32 + v2) * 32 + v3;
 #define SA_CASE(ns, a, b, c)                                              \
     case (((long)(ns) * 32 + (a)) * 32 + (b)) * 32 + (c):                 \
@@ -241,18 +232,18 @@ __global__ __launch_bounds__(64 * CV_NW, 2) void cost_volume_kernel(const CvPara
     __shared__ __attribute__((aligned(16))) f4 s_w[2 * CV_F * 64];
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     const int wave_in_wg = threadIdx.x >> 6;
-    const long npts = (long)P.samples * P.n1;
-    const long per_iter = (long)gridDim.x * CV_NW;
-    const int iters = (int)((npts + per_iter - 1) / per_iter);
+    // 2-D grid: blockIdx.y = sample, blockIdx.x strides over the sample's points, CV_NW points (one per wave) per
+    // iteration.  The trip count is the same for every wave of the workgroup (barriers in the weight stream).
+    const int b = blockIdx.y;
+    const int groups = (P.n1 + CV_NW - 1) / CV_NW;
     constexpr int NF = 2 * CV_V * CV_V;
     WStream<CV_NW, CV_F, NF> ws;
     ws.start(P.blob, s_w, wave_in_wg, lane);
-    for (int it = 0; it < iters; ++it) {
+    for (int G = blockIdx.x; G < groups; G += gridDim.x) {
         asm volatile("" ::: "memory");   // keep loop-invariant weight/bias loads inside the loop (registers are the scarce resource)
-        long i = ((long)it * gridDim.x + blockIdx.x) * CV_NW + wave_in_wg;      // query point (global index)
-        const bool valid = i < npts;
-        if (!valid) i = npts - 1;
-        const int b = (int)(i / P.n1);
+        const int pt = G * CV_NW + wave_in_wg;                                  // query point within the sample
+        const bool valid = pt < P.n1;
+        const long i = (long)b * P.n1 + (valid ? pt : P.n1 - 1);               // global query index
         const long nb = (long)b * P.n2 + (long)P.knn[i * 16 + j];               // neighbour j in pc2
         const float bop = g < 3 ? __fsub_rn(P.xyz2[nb * 3 + g], P.xyz1[i * 3 + g]) : 1.0f;
         // layer 1: leaky(p1[i] + p2[nb] + Wd.d)     (bias folded into p1)
@@ -321,10 +312,12 @@ extern "C" int rtk_cost_volume(int samples, int n1, int n2, const float *xyz1, c
     if (fill_wn(P.wn, wn, "cost_volume") != RTK_OK) return RTK_ERR_INVALID;
     RTK_REQUIRE(wn[2].cout16 == 16, "cost_volume: WeightNet must produce 256 channels");
     P.out = out; P.out_pitch = out_pitch;
-    const long npts = (long)samples * n1;
-    int blocks = (int)((npts + CV_NW - 1) / CV_NW);
-    if (blocks > 512) blocks = 512;
-    cost_volume_kernel<<<blocks, 64 * CV_NW, 0, (hipStream_t)stream>>>(P);
+    RTK_REQUIRE(samples <= 65535, "cost_volume: too many samples");
+    const int groups = (n1 + CV_NW - 1) / CV_NW;
+    int gx = 512 / samples;           // 2 workgroups per CU (64 KiB LDS each); the rest is looped
+    if (gx < 1) gx = 1;
+    if (gx > groups) gx = groups;
+    cost_volume_kernel<<<dim3(gx, samples), 64 * CV_NW, 0, (hipStream_t)stream>>>(P);
     RTK_CHECK_LAUNCH("cost_volume");
     return RTK_OK;
 }
@@ -345,11 +338,9 @@ struct PcParams {
 
 __global__ __launch_bounds__(256) void patch_cost_kernel(const PcParams P) {
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const long npts = (long)P.samples * P.n;
-    for (long i = wave; i < npts; i += nwaves) {
-        const int b = (int)(i / P.n);
+    const int b = blockIdx.y;                                       // 2-D grid: sample on y, points strided on x
+    for (int pt = blockIdx.x * 4 + (threadIdx.x >> 6); pt < P.n; pt += gridDim.x * 4) {
+        const long i = (long)b * P.n + pt;
         const long nb = (long)b * P.n + (long)P.knn[i * 16 + j];
         const float bop = g < 3 ? __fsub_rn(P.xyz[nb * 3 + g], P.xyz[i * 3 + g]) : 1.0f;
         const f4 t2 = weightnet_hidden(P.wn, lane, g, bop);
@@ -383,10 +374,10 @@ extern "C" int rtk_patch_cost(int samples, int n, const float *xyz, const int64_
     if (fill_wn(P.wn, wn, "patch_cost") != RTK_OK) return RTK_ERR_INVALID;
     RTK_REQUIRE(wn[2].cout16 == 16, "patch_cost: WeightNet must produce 256 channels");
     P.out = out; P.out_pitch = out_pitch; P.out_cm = out_channel_major;
-    const long npts = (long)samples * n;
-    int blocks = (int)((npts + 3) / 4);
-    if (blocks > 2048) blocks = 2048;
-    patch_cost_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(P);
+    RTK_REQUIRE(samples <= 65535, "patch_cost: too many samples");
+    int gx = (n + 3) / 4;
+    while ((long)gx * samples > 4096 && gx > 1) gx = (gx + 1) / 2;
+    patch_cost_kernel<<<dim3(gx, samples), 256, 0, (hipStream_t)stream>>>(P);
     RTK_CHECK_LAUNCH("patch_cost");
     return RTK_OK;
 }

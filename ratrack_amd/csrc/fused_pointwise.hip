@@ -70,9 +70,15 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void pointwise_mlp_kernel(const PwPa
     __shared__ __attribute__((aligned(16))) f4 s_w[2 * PW_F * 64];
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     const int wave_in_wg = threadIdx.x >> 6;
-    const int ntiles = (P.rows + 15) >> 4;
-    const int tiles_per_iter = gridDim.x * PW_NW;
-    const int iters = (ntiles + tiles_per_iter - 1) / tiles_per_iter;   // identical for every workgroup (barriers inside)
+    // 2-D grid: blockIdx.y = sample, blockIdx.x strides over the sample's 64-row groups (one 16-row tile per wave).
+    // No division anywhere; a tile never straddles two samples; workgroups whose groups are all duplicate rows
+    // (>= row_nuniq[b]) exit before touching the weight stream.  The trip count is uniform over the workgroup, which
+    // the barriers inside the weight stream require.
+    const int b = blockIdx.y;
+    const int rps = P.rows_per_sample;
+    const int live_rows = P.row_nuniq ? min(rps, __builtin_amdgcn_readfirstlane(P.row_nuniq[b])) : rps;
+    const int live_groups = (live_rows + PW_NW * 16 - 1) / (PW_NW * 16);
+    if ((int)blockIdx.x >= live_groups) return;
     constexpr int NF = U * V1 + V1 * V2 + V2 * V3 + V3 * V4;
     WStream<PW_NW, PW_F, NF> ws;
     ws.start(reinterpret_cast<const f4 *>(P.layer[0].w_packed), s_w, wave_in_wg, lane);
@@ -84,32 +90,11 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void pointwise_mlp_kernel(const PwPa
     for (int s = 0; s < RTK_MAX_SRC; ++s) ustart[s + 1] = ustart[s] + (s < P.nsrc ? (P.src[s].channels + 15) >> 4 : 0);
     const int uend = ustart[RTK_MAX_SRC];
 
-    for (int it = 0; it < iters; ++it) {
+    for (int G = blockIdx.x; G < live_groups; G += gridDim.x) {
         asm volatile("" ::: "memory");   // keep loop-invariant loads/addresses inside the loop (registers are the scarce resource)
-        // Workgroup iteration G covers 64 consecutive rows.  Order them sample-minor when a sample is a whole number of
-        // 64-row groups: the duplicate-row tails (row_nuniq) are then spread evenly over the workgroups.
-        const int G = it * gridDim.x + blockIdx.x;
-        const int samples = P.rows / P.rows_per_sample;
-        const int gps = P.rows_per_sample / (PW_NW * 16);
-        const bool remap = P.rows_per_sample % (PW_NW * 16) == 0;
-        const int r0 = remap ? (G % samples) * P.rows_per_sample + (G / samples) * (PW_NW * 16) : G * (PW_NW * 16);
-        const int p_raw = r0 + wave_in_wg * 16 + j;
-        bool valid = p_raw < P.rows && (!remap || G < samples * gps);
-        const int p = p_raw < P.rows ? p_raw : P.rows - 1;
-        const int b = p / P.rows_per_sample;
-        if (P.row_nuniq) {
-            // duplicate rows (>= nuniq of their sample) are skipped.  The decision must be uniform over the workgroup
-            // because the weight stream has barriers: skip only when all 64 rows of this iteration are duplicates.
-            const int r1 = min(r0 + PW_NW * 16, P.rows) - 1;
-            int skip = 0;
-            if (r0 < P.rows) {
-                const int b0 = r0 / P.rows_per_sample;
-                skip = (b0 == r1 / P.rows_per_sample) && (r0 - b0 * P.rows_per_sample >= P.row_nuniq[b0]);
-            }
-            // readfirstlane: the decision is wave- (and workgroup-) uniform by construction; say so, the branch must be scalar
-            if (__builtin_amdgcn_readfirstlane(skip)) continue;
-            valid = valid && (p - b * P.rows_per_sample) < P.row_nuniq[b];
-        }
+        const int r = G * (PW_NW * 16) + wave_in_wg * 16 + j;           // row within the sample
+        const bool valid = r < live_rows;
+        const int p = b * rps + (r < rps ? r : rps - 1);                  // global row (clamped: out-of-range lanes compute garbage, never stored)
 
         f4 h[U];
         // ---- segment 0 (optional): three-NN interpolation, lib/pointnet2_modules.py:141-146 -------------
@@ -210,9 +195,12 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void pointwise_mlp_kernel(const PwPa
 
 template <int U, int V1, int V2, int V3, int V4>
 static int launch_pw(const PwParams &P, bool interp, hipStream_t s) {
-    const int ntiles = (P.rows + 15) / 16;
-    int blocks = (ntiles + PW_NW - 1) / PW_NW;
-    if (blocks > 512) blocks = 512;   // 2 workgroups per CU (64 KiB LDS each); the rest is looped
+    const int samples = P.rows / P.rows_per_sample;
+    const int groups = (P.rows_per_sample + PW_NW * 16 - 1) / (PW_NW * 16);
+    int gx = 512 / samples;           // 2 workgroups per CU (64 KiB LDS each); the rest is looped (measured: 1024 is 5% slower end to end)
+    if (gx < 1) gx = 1;
+    if (gx > groups) gx = groups;
+    const dim3 blocks(gx, samples);
     if (interp)
         pointwise_mlp_kernel<U, V1, V2, V3, V4, true><<<blocks, 256, 0, s>>>(P);
     else
@@ -224,7 +212,8 @@ extern "C" int rtk_pointwise_mlp(int rows, int rows_per_sample, const rtk_interp
                                  const rtk_src_t *srcs, const float *sample_bias, int nlayers,
                                  const rtk_layer_t *layers, float *out, int out_pitch, int out_channels,
                                  int out_channel_major, const int *row_nuniq, rtk_stream_t stream) {
-    RTK_REQUIRE(rows > 0 && rows_per_sample > 0 && rows % rows_per_sample == 0, "pointwise_mlp: bad row counts (%d, %d)", rows, rows_per_sample);
+    RTK_REQUIRE(rows > 0 && rows_per_sample > 0 && rows % rows_per_sample == 0 && rows / rows_per_sample <= 65535,
+                "pointwise_mlp: bad row counts (%d, %d)", rows, rows_per_sample);
     RTK_REQUIRE(nsrc >= 0 && nsrc <= RTK_MAX_SRC && (nsrc == 0 || srcs), "pointwise_mlp: nsrc=%d", nsrc);
     RTK_REQUIRE(nlayers >= 1 && nlayers <= RTK_MAX_LAYERS && layers && out, "pointwise_mlp: nlayers=%d", nlayers);
     PwParams P;

@@ -507,8 +507,8 @@ class FusedBackbone:
         glob = loc.view(2 * B, N, 128).amax(1)                                             # (2B,128)
         f1, f2, g1, g2 = loc[:B * N], loc[B * N:], glob[:B].contiguous(), glob[B:].contiguous()
         # ---- cost volume ---------------------------------------------------------------------------------
-        sb1 = pointwise(B, 1, [(g1, 128, False)], self.p1_glob, new(B, 256))
-        sb2 = pointwise(B, 1, [(g2, 128, False)], self.p2_glob, new(B, 256))
+        sb1 = pointwise(B, B, [(g1, 128, False)], self.p1_glob, new(B, 256))
+        sb2 = pointwise(B, B, [(g2, 128, False)], self.p2_glob, new(B, 256))
         p1 = pointwise(B * N, N, [(f1, 128, False)], self.p1_loc, new(B * N, 256), sample_bias=sb1)
         p2 = pointwise(B * N, N, [(f2, 128, False)], self.p2_loc, new(B * N, 256), sample_bias=sb2)
         x1, x2 = xyz[:B], xyz[B:]
@@ -530,7 +530,7 @@ class FusedBackbone:
         # ---- decoder -------------------------------------------------------------------------------------
         cls = torch.empty(B, N, dtype=torch.float32, device=dev)
         pointwise(B * N, N, [(cor, 256, False)], self.cls_head, cls, out_channels=1, channel_major=True)
-        sbq = pointwise(B, 1, [(g1, 128, False)], self.dec_q1_glob, new(B, 32))
+        sbq = pointwise(B, B, [(g1, 128, False)], self.dec_q1_glob, new(B, 32))
         q1d = pointwise(B * N, N, [(raw[:B * N], 2, False), (f1, 128, False), (cor, 256, False)], self.dec_q1, new(B * N, 32),
                         sample_bias=sbq)
         prop = run_pnhead(self.dec, geo.head(B), q1d)                                     # (B*N,128)
@@ -538,7 +538,7 @@ class FusedBackbone:
         if h is None:
             h = torch.zeros(5, B, 128, device=dev, dtype=torch.float32)
         gout, h_out = self._gru_step(gfeat, h)
-        sbf = pointwise(B, 1, [(gout, 128, False)], self.flow_glob, new(B, 128))
+        sbf = pointwise(B, B, [(gout, 128, False)], self.flow_glob, new(B, 128))
         flow = torch.empty(B, 3, N, dtype=torch.float32, device=dev)
         pointwise(B * N, N, [(prop, 128, False)], self.flow_head, flow, out_channels=3, sample_bias=sbf, channel_major=True)
         # ---- API layouts (B,C,N) -------------------------------------------------------------------------
