@@ -38,8 +38,13 @@ def load():
     if _lib is not None:
         return _lib
     if not os.path.exists(SO_PATH):
-        raise RtkError("librtk_hip.so not found at %s -- build it with `python -m ratrack_amd.build` "
-                       "(there is no CPU fallback)" % SO_PATH)
+        # not a fallback: build the product itself (hipcc for gfx950) if this checkout has never been built
+        try:
+            from . import build as _build
+            _build.build(verbose=False)
+        except Exception as e:
+            raise RtkError("librtk_hip.so not found at %s and building it failed (%s) -- run `python -m ratrack_amd.build` "
+                           "(there is no CPU fallback)" % (SO_PATH, e))
     try:
         lib = ctypes.CDLL(SO_PATH)
     except OSError as e:  # e.g. libamdhip64 missing

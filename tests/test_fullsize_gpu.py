@@ -1,0 +1,88 @@
+"""GPU: size-independent properties at BASELINE.json's full sizes (the oracle is too slow to run there):
+batch consistency (a sample's result does not depend on its batch neighbours), determinism, the module path
+as a second implementation, the pipelined graph path, and the N=1024 stress configuration."""
+import numpy as np
+import pytest
+import torch
+
+from ratrack_amd import fused as F
+from ratrack_amd import synth
+from ratrack_amd.track4d import Args, Track4D
+
+from _util import RTOL, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+NAMES = ["flow", "h", "cls", "cor", "pc1_features", "pc2_features", "prop"]
+
+
+def make(b, n, case):
+    net = Track4D(Args()).to(DEV).eval()
+    synth.fill_state_dict(net.state_dict())
+    net.invalidate_fused()
+    d = synth.make_frame_pairs(b, n, case)
+    t = [torch.from_numpy(d[k]).to(DEV) for k in ("pc1", "pc2", "feature1", "feature2")]
+    return net, t
+
+
+def test_b64_n256_batch_consistency_and_determinism():
+    net, t = make(64, 256, 1000)
+    h = torch.randn(5, 64, 128, device=DEV) * 0.1
+    with torch.no_grad():
+        full = net.backbone(*t, h)
+        again = net.backbone(*t, h)
+        for a, b in zip(full, again):
+            assert torch.equal(a, b)                       # no atomics / races on the fused path: bit-reproducible
+        for i in (0, 17, 63):
+            one = net.backbone(*[x[i:i + 1].contiguous() for x in t], h[:, i:i + 1].contiguous())
+            for name, a, b in zip(NAMES, full, one):
+                a_i = a[:, i:i + 1] if name == "h" else a[i:i + 1]
+                assert torch.equal(a_i, b), "sample %d: %s depends on the batch" % (i, name)
+        assert all(torch.isfinite(x).all() for x in full)
+
+
+def test_b64_fused_matches_module_path():
+    net, t = make(64, 256, 1001)
+    with torch.no_grad():
+        fused = net.backbone(*t, None)
+        net.use_fused = False
+        ref = net.backbone(*t, None)
+    for name, a, b in zip(NAMES, fused, ref):
+        assert rel_err(a.cpu(), b.cpu()) <= RTOL, name
+
+
+def test_graph_pipeline_matches_eager():
+    net, t = make(8, 256, 1002)
+    h = torch.zeros(5, 8, 128, device=DEV)
+    with torch.no_grad():
+        ref = [x.clone() for x in net.backbone(*t, h)]
+        pipe = F.GraphPipeline(net._fused, (*t, h), depth=2)
+        outs = [pipe.submit(*t, h) for _ in range(5)]      # slots are reused round-robin
+        pipe.drain()
+        torch.cuda.synchronize()
+        for a, b in zip(outs[-1], ref):
+            assert torch.equal(a, b)
+        # new inputs go through the static buffers
+        net2, t2 = make(8, 256, 1003)
+        ref2 = [x.clone() for x in net.backbone(*t2, h)]
+        out2 = pipe.submit(*t2, h)
+        pipe.drain()
+        torch.cuda.synchronize()
+        for a, b in zip(out2, ref2):
+            assert torch.equal(a, b)
+
+
+def test_n1024_stress_config():
+    """BASELINE config 5: N=1024 (radar_5frames clouds): FPS genuinely down-samples, FP1 genuinely interpolates."""
+    net, t = make(4, 1024, 1004)
+    with torch.no_grad():
+        fused = net.backbone(*t, None)
+        net.use_fused = False
+        ref = net.backbone(*t, None)
+    for name, a, b in zip(NAMES, fused, ref):
+        assert rel_err(a.cpu(), b.cpu()) <= RTOL, name
+    net.use_fused = True
+    net32, t32 = make(32, 1024, 1005)
+    with torch.no_grad():
+        out = net32.backbone(*t32, None)
+    assert all(torch.isfinite(x).all() for x in out) and out[0].shape == (32, 3, 1024)
