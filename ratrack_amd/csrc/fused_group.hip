@@ -211,8 +211,15 @@ __device__ __forceinline__ f4 weightnet_out(const WnWeights &W, int lane, int g,
 // =================================================================================================
 // rtk_cost_volume
 // =================================================================================================
-#define CV_NW 4
-#define CV_F 32
+#ifndef CV_NW
+#define CV_NW 4          // waves per workgroup (all share one weight stream)
+#endif
+#ifndef CV_F
+#define CV_F 32          // fragments (KiB) per half of the LDS double buffer
+#endif
+#ifndef CV_WGS_PER_CU
+#define CV_WGS_PER_CU 2
+#endif
 #define CV_V 16          // 256 channels
 
 struct CvParams {
@@ -228,7 +235,7 @@ struct CvParams {
     int out_pitch;
 };
 
-__global__ __launch_bounds__(64 * CV_NW, 2) void cost_volume_kernel(const CvParams P) {
+__global__ __launch_bounds__(64 * CV_NW, (CV_NW * CV_WGS_PER_CU) / 4) void cost_volume_kernel(const CvParams P) {
     __shared__ __attribute__((aligned(16))) f4 s_w[2 * CV_F * 64];
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     const int wave_in_wg = threadIdx.x >> 6;
@@ -314,7 +321,7 @@ extern "C" int rtk_cost_volume(int samples, int n1, int n2, const float *xyz1, c
     P.out = out; P.out_pitch = out_pitch;
     RTK_REQUIRE(samples <= 65535, "cost_volume: too many samples");
     const int groups = (n1 + CV_NW - 1) / CV_NW;
-    int gx = 512 / samples;           // 2 workgroups per CU (64 KiB LDS each); the rest is looped
+    int gx = 256 * CV_WGS_PER_CU / samples;           // resident workgroups; the rest is looped
     if (gx < 1) gx = 1;
     if (gx > groups) gx = groups;
     cost_volume_kernel<<<dim3(gx, samples), 64 * CV_NW, 0, (hipStream_t)stream>>>(P);
