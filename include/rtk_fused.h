@@ -62,11 +62,14 @@ typedef struct {
  * when out_channel_major != 0; only out_channels channels are written.
  * row_nuniq (optional, (samples)): rows r >= row_nuniq[b] of sample b are duplicates of the sample's row 0
  * (centroids picked after furthest-point sampling exhausted the cloud, see rtk_fps_centroids); they are
- * neither read nor written -- consumers alias them to row 0. */
+ * neither read nor written -- consumers alias them to row 0.
+ * colmax (optional, (samples, 16*last.cout16), ZERO-INITIALISED by the caller): per-sample maximum over the rows of
+ * every output channel (torch.max(features, -1), models/track4d.py:89-92), accumulated with atomic max on the float
+ * bits -- only valid when the last activation is non-negative (ReLU / sigmoid). */
 RTK_EXPORT int rtk_pointwise_mlp(int rows, int rows_per_sample, const rtk_interp_t *interp, int nsrc,
                                  const rtk_src_t *srcs, const float *sample_bias, int nlayers,
                                  const rtk_layer_t *layers, float *out, int out_pitch, int out_channels,
-                                 int out_channel_major, const int *row_nuniq, rtk_stream_t stream);
+                                 int out_channel_major, const int *row_nuniq, float *colmax, rtk_stream_t stream);
 
 /* One scale of a set-abstraction level.  q (samples*n, q_pitch): per-point layer-1 projection of the
  * features (BN scale folded); layer 1 = relu(q[idx] + Wx.(xyz[idx] - centroid) + b1) with
@@ -129,9 +132,18 @@ RTK_EXPORT int rtk_ball_query_pair(int b, int n, int npoint, float radius1, int 
                                    const float *new_xyz, const float *xyz, int *idx1, int *idx2, const int *nuniq,
                                    rtk_stream_t stream);
 
-/* rtk_three_nn restricted to the non-duplicate unknown rows: rows >= unknown_nuniq[b] are not computed. */
+/* rtk_three_nn restricted to the non-duplicate unknown rows (rows >= unknown_nuniq[b] are not computed) and aware of
+ * duplicate known rows (known rows >= known_nuniq[b] are copies of known row 0: only the unique prefix is scanned,
+ * the result is identical to the full scan).  Either counter may be NULL. */
 RTK_EXPORT int rtk_three_nn_masked(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
-                                   const int *unknown_nuniq, rtk_stream_t stream);
+                                   const int *unknown_nuniq, const int *known_nuniq, rtk_stream_t stream);
+
+/* Several rtk_to_channel_major jobs in one launch. */
+typedef struct {
+    const float *src; float *dst;
+    int channels, src_pitch, per_sample, dst_channels, dst_channel_offset;
+} rtk_layout_job_t;
+RTK_EXPORT int rtk_to_channel_major_multi(int samples, int n, int njobs, const rtk_layout_job_t *jobs, rtk_stream_t stream);
 
 #ifdef __cplusplus
 }

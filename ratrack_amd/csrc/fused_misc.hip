@@ -121,3 +121,50 @@ extern "C" int rtk_to_channel_major(int samples, int n, int channels, const floa
     RTK_CHECK_LAUNCH("to_channel_major");
     return RTK_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// rtk_to_channel_major_multi: the six layout conversions of one backbone() in a single launch (job = blockIdx.z / samples)
+// ------------------------------------------------------------------------------------------------
+#define LAYOUT_MAX_JOBS 8
+struct LayoutJobs {
+    rtk_layout_job_t job[LAYOUT_MAX_JOBS];
+    int samples, n;
+};
+
+__global__ __launch_bounds__(256) void to_channel_major_multi_kernel(const LayoutJobs J) {
+    __shared__ float tile[32][33];
+    const int jid = blockIdx.z / J.samples, s = blockIdx.z % J.samples;
+    const rtk_layout_job_t job = J.job[jid];
+    const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32, n = J.n;
+    if (c0 >= job.channels) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        float v = 0.f;
+        if (p < n && c < job.channels) v = job.src[(job.per_sample ? (long)s : (long)s * n + p) * job.src_pitch + c];
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        if (p < n && c < job.channels) job.dst[((long)s * job.dst_channels + job.dst_channel_offset + c) * n + p] = tile[tx][r];
+    }
+}
+
+extern "C" int rtk_to_channel_major_multi(int samples, int n, int njobs, const rtk_layout_job_t *jobs, rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && n > 0 && njobs > 0 && njobs <= LAYOUT_MAX_JOBS && jobs && (long)samples * njobs <= 65535,
+                "to_channel_major_multi: bad arguments (njobs=%d)", njobs);
+    LayoutJobs J;
+    int cmax = 0;
+    for (int i = 0; i < njobs; ++i) {
+        RTK_REQUIRE(jobs[i].src && jobs[i].dst && jobs[i].channels > 0 && jobs[i].src_pitch >= jobs[i].channels &&
+                    jobs[i].dst_channel_offset + jobs[i].channels <= jobs[i].dst_channels, "to_channel_major_multi: bad job %d", i);
+        J.job[i] = jobs[i];
+        if (jobs[i].channels > cmax) cmax = jobs[i].channels;
+    }
+    J.samples = samples; J.n = n;
+    dim3 grid(rtk_divup(n, 32), rtk_divup(cmax, 32), samples * njobs);
+    to_channel_major_multi_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(J);
+    RTK_CHECK_LAUNCH("to_channel_major_multi");
+    return RTK_OK;
+}

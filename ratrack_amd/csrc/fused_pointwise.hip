@@ -24,6 +24,7 @@ struct PwParams {
     float *out;
     int out_pitch, out_channels, out_cm;
     const int *row_nuniq;
+    float *colmax;
 };
 
 template <int V>
@@ -34,6 +35,23 @@ __device__ __forceinline__ void init_bias(f4 (&acc)[V], const float *__restrict_
 
 template <int V>
 __device__ __forceinline__ void store_tile(const PwParams &P, const f4 (&acc)[V], int p, int b, int g, bool valid) {
+    if (P.colmax) {
+        // per-sample column maximum: DPP max over the tile's 16 rows, then one atomic max per channel on the float bits
+        // (outputs are >= 0 after ReLU, so unsigned order == float order and the zero-initialised buffer is the identity)
+        unsigned *cm = reinterpret_cast<unsigned *>(P.colmax) + (size_t)b * 16 * V + 4 * g;
+        const bool lead = (threadIdx.x & 15) == 0;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            f4 m = valid ? acc[v] : f4_zero();
+            row_max16_f4(m);
+            if (lead) {
+                atomicMax(cm + 16 * v + 0, __float_as_uint(m.x));
+                atomicMax(cm + 16 * v + 1, __float_as_uint(m.y));
+                atomicMax(cm + 16 * v + 2, __float_as_uint(m.z));
+                atomicMax(cm + 16 * v + 3, __float_as_uint(m.w));
+            }
+        }
+    }
     if (!valid) return;
     if (!P.out_cm) {
         float *o = P.out + (size_t)p * P.out_pitch;
@@ -211,7 +229,7 @@ static int launch_pw(const PwParams &P, bool interp, hipStream_t s) {
 extern "C" int rtk_pointwise_mlp(int rows, int rows_per_sample, const rtk_interp_t *interp, int nsrc,
                                  const rtk_src_t *srcs, const float *sample_bias, int nlayers,
                                  const rtk_layer_t *layers, float *out, int out_pitch, int out_channels,
-                                 int out_channel_major, const int *row_nuniq, rtk_stream_t stream) {
+                                 int out_channel_major, const int *row_nuniq, float *colmax, rtk_stream_t stream) {
     RTK_REQUIRE(rows > 0 && rows_per_sample > 0 && rows % rows_per_sample == 0 && rows / rows_per_sample <= 65535,
                 "pointwise_mlp: bad row counts (%d, %d)", rows, rows_per_sample);
     RTK_REQUIRE(nsrc >= 0 && nsrc <= RTK_MAX_SRC && (nsrc == 0 || srcs), "pointwise_mlp: nsrc=%d", nsrc);
@@ -251,6 +269,7 @@ extern "C" int rtk_pointwise_mlp(int rows, int rows_per_sample, const rtk_interp
     P.out_channels = out_channels;
     P.out_cm = out_channel_major;
     P.row_nuniq = row_nuniq;
+    P.colmax = colmax;
     RTK_REQUIRE(out_channels > 0 && out_channels <= 16 * cin, "pointwise_mlp: out_channels=%d", out_channels);
     RTK_REQUIRE(out_channel_major || (out_pitch % 4 == 0 && out_pitch >= out_channels), "pointwise_mlp: bad out_pitch %d", out_pitch);
     hipStream_t s = (hipStream_t)stream;

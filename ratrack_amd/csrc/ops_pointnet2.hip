@@ -563,11 +563,17 @@ __device__ __forceinline__ void kv_row_merge(unsigned (&d)[K], int (&i)[K]) {
 template <bool USE_LDS>
 __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float *__restrict__ unknown,
                                                        const float *__restrict__ known, float *__restrict__ dist2,
-                                                       int *__restrict__ idx, const int *__restrict__ unknown_nuniq) {
+                                                       int *__restrict__ idx, const int *__restrict__ unknown_nuniq,
+                                                       const int *__restrict__ known_nuniq) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bs = blockIdx.y, tid = threadIdx.x;
     if (unknown_nuniq && blockIdx.x * 16 >= unknown_nuniq[bs]) return;    // all 16 queries of this workgroup are duplicate rows
+    // known rows >= known_nuniq[b] are copies of known row 0: of those only the first two (lowest indices) can reach the
+    // top 3, at the distance of row 0 -- scan the unique prefix and add these two candidates: identical result, half the scan
+    const int m_full = m;
+    const int ke = known_nuniq ? min(m, known_nuniq[bs]) : m;
     known += (size_t)bs * m * 3;
+    m = ke;
     float *sx = smem, *sy = smem + m, *sz = smem + 2 * m;
     if (USE_LDS) {
         for (int k = tid; k < m; k += 256) {
@@ -596,6 +602,16 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float
             kv_cex(d[0], i[0], d[1], i[1]);
         }
     }
+    if (li >= 1 && li <= 2 && ke + li - 1 < m_full) {          // the two possible duplicate-of-row-0 candidates: indices ke, ke+1
+        const float kx = USE_LDS ? sx[0] : known[0], ky = USE_LDS ? sy[0] : known[1], kz = USE_LDS ? sz[0] : known[2];
+        const float dd = rtk_sqdist(ux, uy, uz, kx, ky, kz);
+        if (dd < INFINITY) {
+            d[3] = __float_as_uint(dd); i[3] = ke + li - 1;
+            kv_cex(d[2], i[2], d[3], i[3]);
+            kv_cex(d[1], i[1], d[2], i[2]);
+            kv_cex(d[0], i[0], d[1], i[1]);
+        }
+    }
     d[3] = KEY_INF_D; i[3] = KEY_INF_I;
     kv_row_merge<4>(d, i);
     if (li == 0 && pt_raw < n) {
@@ -616,23 +632,23 @@ extern "C" int rtk_three_nn(int b, int n, int m, const float *unknown, const flo
     dim3 grid(rtk_divup(n, 16), b);
     const size_t lds = (size_t)m * 3 * sizeof(float);
     if (lds <= 64 * 1024)
-        three_nn_kernel<true><<<grid, 256, lds, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx, nullptr);
+        three_nn_kernel<true><<<grid, 256, lds, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx, nullptr, nullptr);
     else
-        three_nn_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx, nullptr);
+        three_nn_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx, nullptr, nullptr);
     RTK_CHECK_LAUNCH("three_nn");
     return RTK_OK;
 }
 
 extern "C" int rtk_three_nn_masked(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
-                                   const int *unknown_nuniq, rtk_stream_t stream) {
+                                   const int *unknown_nuniq, const int *known_nuniq, rtk_stream_t stream) {
     RTK_REQUIRE(b > 0 && n > 0 && m > 0 && unknown && known && dist2 && idx, "three_nn_masked: bad arguments");
     RTK_REQUIRE(b <= 65535, "three_nn_masked: b exceeds grid limits");
     dim3 grid(rtk_divup(n, 16), b);
     const size_t lds = (size_t)m * 3 * sizeof(float);
     if (lds <= 64 * 1024)
-        three_nn_kernel<true><<<grid, 256, lds, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx, unknown_nuniq);
+        three_nn_kernel<true><<<grid, 256, lds, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx, unknown_nuniq, known_nuniq);
     else
-        three_nn_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx, unknown_nuniq);
+        three_nn_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx, unknown_nuniq, known_nuniq);
     RTK_CHECK_LAUNCH("three_nn_masked");
     return RTK_OK;
 }

@@ -39,7 +39,7 @@ class _Interp(ctypes.Structure):
 _vp, _ci = ctypes.c_void_p, ctypes.c_int
 _lib.SIGNATURES.update({
     "rtk_pointwise_mlp": [_ci, _ci, ctypes.POINTER(_Interp), _ci, ctypes.POINTER(_Src), _vp, _ci, ctypes.POINTER(_Layer), _vp,
-                          _ci, _ci, _ci, _vp, _vp],
+                          _ci, _ci, _ci, _vp, _vp, _vp],
     "rtk_sa_scale": [_ci] * 4 + [_vp] * 4 + [_ci, _ci, _vp, _ci, ctypes.POINTER(_Layer), _vp, _ci, _ci, _vp, _vp, _vp],
     "rtk_cost_volume": [_ci] * 3 + [_vp] * 6 + [ctypes.POINTER(_Layer), ctypes.POINTER(_Layer), _vp, _ci, _vp],
     "rtk_patch_cost": [_ci] * 2 + [_vp] * 3 + [_ci, ctypes.POINTER(_Layer), _vp, _ci, _ci, _vp],
@@ -48,8 +48,14 @@ _lib.SIGNATURES.update({
     "rtk_gru_step": [_ci] * 3 + [_vp] * 8 + [_vp],
     "rtk_to_channel_major": [_ci] * 3 + [_vp, _ci, _ci, _vp, _ci, _ci, _vp],
     "rtk_ball_query_pair": [_ci] * 3 + [ctypes.c_float, _ci, ctypes.c_float, _ci] + [_vp] * 5 + [_vp],
-    "rtk_three_nn_masked": [_ci] * 3 + [_vp] * 5 + [_vp],
+    "rtk_three_nn_masked": [_ci] * 3 + [_vp] * 6 + [_vp],
+    "rtk_to_channel_major_multi": [_ci] * 3 + [_vp, _vp],
 })
+
+
+class _LayoutJob(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("channels", ctypes.c_int), ("src_pitch", ctypes.c_int),
+                ("per_sample", ctypes.c_int), ("dst_channels", ctypes.c_int), ("dst_channel_offset", ctypes.c_int)]
 
 
 def _stream():
@@ -121,7 +127,7 @@ def _colptr(t, col=0):
 
 
 def pointwise(rows, rows_per_sample, srcs, chain, out, out_channels=None, sample_bias=None, interp=None, channel_major=False,
-              row_nuniq=None):
+              row_nuniq=None, colmax=None):
     """srcs: list of (2-D tensor or column-sliced view, channels, per_sample).  out: (rows, pitch) point-major (may be a
     column-sliced view) or (samples, C, n) channel-major.  interp: (known_feats (samples*m, pitch), channels, m,
     idx (rows,3) int32, dist2 (rows,3)[, nuniq (samples) int32]).  row_nuniq: per-sample count of non-duplicate rows."""
@@ -142,7 +148,8 @@ def pointwise(rows, rows_per_sample, srcs, chain, out, out_channels=None, sample
         optr, opitch = _colptr(out)
     _lib.call("rtk_pointwise_mlp", rows, rows_per_sample, ip, len(srcs), arr,
               sample_bias.data_ptr() if sample_bias is not None else None, chain.n, chain.arr, optr, opitch, oc,
-              int(channel_major), row_nuniq.data_ptr() if row_nuniq is not None else None, _stream())
+              int(channel_major), row_nuniq.data_ptr() if row_nuniq is not None else None,
+              colmax.data_ptr() if colmax is not None else None, _stream())
     return out
 
 
@@ -348,7 +355,7 @@ class Geometry:
                 # unknown rows of fp3 / fp2 are level centroids: duplicates are never read downstream
                 mask = self.nuniq[u - 1].data_ptr() if u > 0 else None
                 _lib.call("rtk_three_nn_masked", S_, nu, m, self.xyz[u].data_ptr(), self.xyz[k].data_ptr(), d2.data_ptr(), idx.data_ptr(),
-                          mask, _stream())
+                          mask, self.nuniq[k - 1].data_ptr(), _stream())      # known level k: duplicate centroids beyond nuniq
                 self.nn[name] = (d2, idx, m)
             self._record("nn", side)
             if B:
@@ -425,7 +432,10 @@ def run_pnhead(W, geo, q1):
     f2 = pointwise(S_ * S, S, [(t1[:, 0:32], 32, False)], W.fp["fp2"], new(S_ * S, 128), row_nuniq=nu[0],
                    interp=(f3, 128, m, idx.reshape(-1, 3), d2.reshape(-1, 3), nu[1]))
     d2, idx, m = geo.nn["fp1"]
-    return pointwise(S_ * n, n, [], W.fp["fp1"], new(S_ * n, 128), interp=(f2, 128, m, idx.reshape(-1, 3), d2.reshape(-1, 3), nu[0]))
+    gmax = torch.zeros(S_, 128, dtype=torch.float32, device=dev)          # global max-pool, fused into fp1's epilogue
+    out = pointwise(S_ * n, n, [], W.fp["fp1"], new(S_ * n, 128), interp=(f2, 128, m, idx.reshape(-1, 3), d2.reshape(-1, 3), nu[0]),
+                    colmax=gmax)
+    return out, gmax
 
 
 class FusedBackbone:
@@ -503,9 +513,8 @@ class FusedBackbone:
         geo = Geometry(xyz, self.npoint, side=self.side if self.use_side_stream else None, knn_frames=B)
         # ---- encoder over both frames at once (same weights; eval-mode BN is per-element) --------------
         q1 = pointwise(2 * B * N, N, [(raw, 2, False)], self.enc_q1, new(2 * B * N, 32))
-        loc = run_pnhead(self.enc, geo, q1)                                              # (2B*N, 128)
-        glob = loc.view(2 * B, N, 128).amax(1)                                             # (2B,128)
-        f1, f2, g1, g2 = loc[:B * N], loc[B * N:], glob[:B].contiguous(), glob[B:].contiguous()
+        loc, glob = run_pnhead(self.enc, geo, q1)                                        # (2B*N, 128), (2B, 128)
+        f1, f2, g1, g2 = loc[:B * N], loc[B * N:], glob[:B], glob[B:]
         # ---- cost volume ---------------------------------------------------------------------------------
         sb1 = pointwise(B, B, [(g1, 128, False)], self.p1_glob, new(B, 256))
         sb2 = pointwise(B, B, [(g2, 128, False)], self.p2_glob, new(B, 256))
@@ -533,8 +542,7 @@ class FusedBackbone:
         sbq = pointwise(B, B, [(g1, 128, False)], self.dec_q1_glob, new(B, 32))
         q1d = pointwise(B * N, N, [(raw[:B * N], 2, False), (f1, 128, False), (cor, 256, False)], self.dec_q1, new(B * N, 32),
                         sample_bias=sbq)
-        prop = run_pnhead(self.dec, geo.head(B), q1d)                                     # (B*N,128)
-        gfeat = prop.view(B, N, 128).amax(1)
+        prop, gfeat = run_pnhead(self.dec, geo.head(B), q1d)                              # (B*N,128), (B,128)
         if h is None:
             h = torch.zeros(5, B, 128, device=dev, dtype=torch.float32)
         gout, h_out = self._gru_step(gfeat, h)
@@ -542,17 +550,17 @@ class FusedBackbone:
         flow = torch.empty(B, 3, N, dtype=torch.float32, device=dev)
         pointwise(B * N, N, [(prop, 128, False)], self.flow_head, flow, out_channels=3, sample_bias=sbf, channel_major=True)
         # ---- API layouts (B,C,N) -------------------------------------------------------------------------
-        def cm(dst, off, src, ch, per_sample=False):
-            _lib.call("rtk_to_channel_major", B, N, ch, src.data_ptr(), src.stride(0), int(per_sample), dst.data_ptr(), dst.shape[1], off,
-                      _stream())
         pc1_features = torch.empty(B, 256, N, dtype=torch.float32, device=dev)
         pc2_features = torch.empty(B, 256, N, dtype=torch.float32, device=dev)
         cor_cm = torch.empty(B, 256, N, dtype=torch.float32, device=dev)
         prop_cm = torch.empty(B, 128, N, dtype=torch.float32, device=dev)
-        cm(pc1_features, 0, f1, 128); cm(pc1_features, 128, g1, 128, True)
-        cm(pc2_features, 0, f2, 128); cm(pc2_features, 128, g2, 128, True)
-        cm(cor_cm, 0, cor, 256)
-        cm(prop_cm, 0, prop, 128)
+        jobs = [(pc1_features, 0, f1, 128, 0), (pc1_features, 128, g1, 128, 1), (pc2_features, 0, f2, 128, 0),
+                (pc2_features, 128, g2, 128, 1), (cor_cm, 0, cor, 256, 0), (prop_cm, 0, prop, 128, 0)]
+        arr = (_LayoutJob * len(jobs))()
+        for i, (dst, off, src, ch, per) in enumerate(jobs):
+            arr[i].src, arr[i].dst, arr[i].channels, arr[i].src_pitch = src.data_ptr(), dst.data_ptr(), ch, src.stride(0)
+            arr[i].per_sample, arr[i].dst_channels, arr[i].dst_channel_offset = per, dst.shape[1], off
+        _lib.call("rtk_to_channel_major_multi", B, N, len(jobs), arr, _stream())
         return flow, h_out, cls, cor_cm, pc1_features, pc2_features, prop_cm
 
     # --------------------------------------------------------------------------------------------------

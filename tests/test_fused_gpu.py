@@ -148,8 +148,10 @@ def test_fused_pnhead_matches_modules(name):
         geo = F.Geometry(xyz, 512)
         torch.cuda.synchronize()
         q1 = F.pointwise(B * N, N, [(raw, 2, False)], eng.enc_q1, torch.empty(B * N, 32, device=DEV))
-        got = F.run_pnhead(eng.enc, geo, q1).view(B, N, 128).permute(0, 2, 1)
+        loc, gmax = F.run_pnhead(eng.enc, geo, q1)
+        got = loc.view(B, N, 128).permute(0, 2, 1)
     assert rel_err(got.cpu(), ref.cpu()) < 2e-5
+    assert torch.equal(gmax, loc.view(B, N, 128).amax(1))          # fused global max-pool == max over points
 
 
 @pytest.mark.parametrize("name", ["eval_b2_n256", "eval_b1_n242", "eval_b1_n1024"])
@@ -311,10 +313,33 @@ def test_ball_query_pair_and_masked_three_nn():
             assert (i1[b, e:] == 0).all() and (i2[b, e:] == 0).all()         # skipped rows keep the caller's zeros
     d2 = torch.full((3, 200, 3), -1.0, device=DEV)
     idx = torch.full((3, 200, 3), -1, dtype=torch.int32, device=DEV)
-    _lib.call("rtk_three_nn_masked", 3, 200, 300, qd.data_ptr(), xd.data_ptr(), d2.data_ptr(), idx.data_ptr(), nd.data_ptr(), F._stream())
+    _lib.call("rtk_three_nn_masked", 3, 200, 300, qd.data_ptr(), xd.data_ptr(), d2.data_ptr(), idx.data_ptr(), nd.data_ptr(), None,
+              F._stream())
     rd, ri = P.three_nn(q, xyz)
     for b in range(3):
         e = int(nuniq[b])
         assert torch.equal(idx[b, :e].cpu(), ri[b, :e]) and torch.equal(d2[b, :e].cpu(), rd[b, :e])
         lim = (e + 15) // 16 * 16
         assert (idx[b, lim:] == -1).all()
+
+
+def test_three_nn_duplicate_aware_scan_is_exact():
+    """Known clouds whose tail rows are copies of row 0 (over-sampled FPS levels): scanning only the unique prefix plus the two
+    lowest duplicate indices reproduces the full scan bit for bit, including the tie order (0, E, E+1)."""
+    from oracle import pointnet2_ref as P
+    from ratrack_amd import _lib
+    torch.manual_seed(9)
+    B, m, n = 3, 512, 300
+    known = torch.randn(B, m, 3) * 4
+    ke = torch.tensor([256, 511, 40], dtype=torch.int32)
+    for b in range(B):
+        known[b, int(ke[b]):] = known[b, 0]
+    unknown = torch.randn(B, n, 3) * 4
+    unknown[:, :64] = known[:, :64]                # zero distances incl. to row 0 and its copies
+    unknown[:, 64] = known[:, 0] + 1e-3
+    rd, ri = P.three_nn(unknown, known)
+    d2 = torch.empty(B, n, 3, device=DEV)
+    idx = torch.empty(B, n, 3, dtype=torch.int32, device=DEV)
+    ud, kd, ked = unknown.to(DEV), known.to(DEV), ke.to(DEV)
+    _lib.call("rtk_three_nn_masked", B, n, m, ud.data_ptr(), kd.data_ptr(), d2.data_ptr(), idx.data_ptr(), None, ked.data_ptr(), F._stream())
+    assert torch.equal(idx.cpu(), ri) and torch.equal(d2.cpu(), rd)
