@@ -1,0 +1,175 @@
+"""Post-backbone half of Track4D.forward: moving-point clustering and frame-to-frame object association
+(reference: models/track4d.py:53-65,108-223; helpers models/utils/track4d_utils.py:19-23,405-438).
+SURVEY.md 8(f) ranks 1-2 -- the first consumers of the backbone's cls / flow / prop outputs.  B = 1 logic, as in
+the reference (mov_mask = (cls > 0.5).squeeze(0)).
+
+The reference clusters with sklearn.cluster.DBSCAN on the host; `dbscan` below restates that algorithm (same core
+definition, same expansion order, hence the same labels -- tests/test_association_cpu.py checks it against sklearn
+itself) so the product does not depend on scikit-learn.  Everything else is PyTorch and device agnostic.
+"""
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+
+def dbscan(x, eps, min_samples):
+    """Labels of sklearn.cluster.DBSCAN(eps, min_samples).fit_predict(x) (Euclidean, brute force): x (n, d) array.
+    A point is core when its closed eps-ball holds >= min_samples points (itself included); clusters grow by a
+    depth-first expansion from the core points in index order; -1 = noise."""
+    x = np.asarray(x, dtype=np.float64)
+    n = x.shape[0]
+    labels = np.full(n, -1, dtype=np.int64)
+    if n == 0:
+        return labels
+    d2 = ((x[:, None, :] - x[None, :, :]) ** 2).sum(-1)
+    neigh = [np.nonzero(np.sqrt(d2[i]) <= eps)[0] for i in range(n)]
+    core = np.array([len(v) >= min_samples for v in neigh])
+    label = 0
+    for i in range(n):
+        if labels[i] != -1 or not core[i]:
+            continue
+        stack, cur = [], i
+        while True:
+            if labels[cur] == -1:
+                labels[cur] = label
+                if core[cur]:
+                    for v in neigh[cur]:
+                        if labels[v] == -1:
+                            stack.append(v)
+            if not stack:
+                break
+            cur = stack.pop()
+        label += 1
+    return labels
+
+
+def obj_centre(obj):
+    """(1,3,n) -> (1,3) mean position (track4d_utils.py:19-23)."""
+    return torch.mean(obj, dim=2)
+
+
+def cluster_objects(point_features, eps=1.5, min_samples=2):
+    """models/track4d.py:108-126.  point_features (1,139,n) = [warped xyz | xyz | flow | (RCS, v_r) | prop(128)] of the
+    moving points; clustered on channels 3:9 and 10:12 (xyz, flow, v_r, first prop channel).  Returns the objects as a
+    list of (1,139,n_i) tensors, in order of their first point."""
+    if point_features.shape[2] == 0:
+        return []
+    f = torch.cat((point_features[0, 3:9, :], point_features[0, 10:12, :]), dim=0).detach().cpu().numpy().T
+    labels = dbscan(f, eps, min_samples)
+    groups = defaultdict(list)
+    for i, l in enumerate(labels):
+        if l != -1:
+            groups[int(l)].append(i)
+    return [point_features[:, :, torch.as_tensor(ix, device=point_features.device)] for ix in groups.values()]
+
+
+def object_descriptor(obj, prop_channels):
+    """141-d descriptor of an object (models/track4d.py:200-214): [centre(3) | var xyz(3) | max prop(128) | mean flow(3) |
+    mean (RCS,v_r)(2) | var (RCS,v_r)(2)], shape (1,1,141)."""
+    feat = torch.max(obj[:, 11:11 + prop_channels, :], dim=2)[0].unsqueeze(1)
+    flow = torch.mean(obj[:, 6:9, :], dim=2).unsqueeze(1)
+    pos = obj_centre(obj[:, 3:6, :]).unsqueeze(1)
+    rrv = torch.mean(obj[:, 9:11, :], dim=2).unsqueeze(1)
+    rrv_var = torch.var(obj[:, 9:11, :], dim=2, unbiased=False).unsqueeze(1)
+    var = torch.var(obj[:, 3:6, :], dim=2, unbiased=False).unsqueeze(1)
+    return torch.cat((pos, var, feat, flow, rrv, rrv_var), dim=2)
+
+
+def affinity_matrix(affinity_net, objects_curr, objects_prev):
+    """M (previous) x N (current) affinities (models/track4d.py:182-223).  Returns (aff_list, aff_mat (1,M,N), M, N)."""
+    m, n = len(objects_prev), len(objects_curr)
+    keys = list(objects_prev.keys())
+    dev = objects_curr[0].device if n else (objects_prev[keys[0]].device if m else torch.device("cpu"))
+    aff_list = []
+    for i in range(m):
+        prev = objects_prev[keys[i]]
+        d_prev = object_descriptor(prev, 256)       # the reference slices 11:267 of a 139-channel tensor = its 128 prop channels
+        for j in range(n):
+            aff_list.append(affinity_net(object_descriptor(objects_curr[j], 128), d_prev).squeeze(0))
+    if m != 0 and n != 0:
+        aff_list = torch.cat(aff_list, dim=0)
+        aff_mat = torch.reshape(aff_list, (m, n)).unsqueeze(0)
+    else:       # nothing to associate (the reference ends up with an empty tensor and starts new tracks)
+        aff_mat = torch.zeros(1, m, n, device=dev)
+    return aff_list, aff_mat, m, n
+
+
+def log_sinkhorn_iterations(Z, log_mu, log_nu, iters):
+    """track4d_utils.py:405-411."""
+    u, v = torch.zeros_like(log_mu), torch.zeros_like(log_nu)
+    for _ in range(iters):
+        u = log_mu - torch.logsumexp(Z + v.unsqueeze(1), dim=2)
+        v = log_nu - torch.logsumexp(Z + u.unsqueeze(2), dim=1)
+    return Z + u.unsqueeze(2) + v.unsqueeze(1)
+
+
+def log_optimal_transport(scores, alpha, iters):
+    """Differentiable optimal transport in log space with a dustbin row/column (track4d_utils.py:414-434)."""
+    b, m, n = scores.shape
+    one = scores.new_tensor(1)
+    ms, ns = (m * one).to(scores), (n * one).to(scores)
+    bins0 = alpha.expand(b, m, 1)
+    bins1 = alpha.expand(b, 1, n)
+    alpha = alpha.expand(b, 1, 1)
+    couplings = torch.cat([torch.cat([scores, bins0], -1), torch.cat([bins1, alpha], -1)], 1)
+    norm = -(ms + ns).log()
+    log_mu = torch.cat([norm.expand(m), ns.log()[None] + norm])
+    log_nu = torch.cat([norm.expand(n), ms.log()[None] + norm])
+    log_mu, log_nu = log_mu[None].expand(b, -1), log_nu[None].expand(b, -1)
+    Z = log_sinkhorn_iterations(couplings, log_mu, log_nu, iters)
+    return Z - norm
+
+
+def sinkhorn_assignment(aff_mat, iters=500):
+    """Mutual-best assignment after Sinkhorn normalisation (models/track4d.py:166-180): for every current object the
+    index of the matched previous object, or -1.  Returns indices1 (1,N) int64."""
+    scores = log_optimal_transport(aff_mat, torch.tensor(0.9, device=aff_mat.device), iters)
+    max0, max1 = scores[:, :-1, :-1].max(2), scores[:, :-1, :-1].max(1)
+    indices0, indices1 = max0.indices, max1.indices
+    ar = lambda t: t.new_ones(t.shape[1]).cumsum(0) - 1
+    mutual0 = ar(indices0)[None] == indices1.gather(1, indices0)
+    mutual1 = ar(indices1)[None] == indices0.gather(1, indices1)
+    zero = scores.new_tensor(0)
+    mscores0 = torch.where(mutual0, max0.values.exp(), zero)
+    valid0 = mutual0 & (mscores0 > 0)
+    valid1 = mutual1 & valid0.gather(1, indices1)
+    return torch.where(valid1, indices1, indices1.new_tensor(-1))
+
+
+class Associator:
+    """ID bookkeeping across frames (models/track4d.py:135-164): holds `max_id`."""
+
+    def __init__(self, affinity_net):
+        self.affinity_net = affinity_net
+        self.max_id = 0
+
+    def __call__(self, objects_curr, objects_prev):
+        objects, confs = dict(), []
+        aff_list, aff_mat, m, n = affinity_matrix(self.affinity_net, objects_curr, objects_prev)
+        indices1 = None
+
+        def fresh(obj):
+            objects[self.max_id] = obj
+            self.max_id += 1
+            confs.append(0)
+
+        if aff_mat.size(1) > 0 and aff_mat.size(2) > 0:
+            try:
+                indices1 = sinkhorn_assignment(aff_mat)
+                prev_keys = list(objects_prev.keys())
+                for i in range(n):
+                    k = int(indices1[0, i])
+                    conf = aff_mat[0, k, i]
+                    if k == -1 or k >= m or conf < 0.01:
+                        fresh(objects_curr[i])
+                    else:
+                        objects[prev_keys[k]] = objects_curr[i]
+                        confs.append(conf)
+            except Exception:      # the reference swallows association failures and starts new tracks (track4d.py:154-158)
+                for obj in objects_curr:
+                    fresh(obj)
+        else:
+            for obj in objects_curr:
+                fresh(obj)
+        return aff_list, aff_mat, indices1, confs, objects

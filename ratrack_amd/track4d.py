@@ -2,14 +2,14 @@
 `Track4D(args)`, `backbone(pc1, pc2, feature1, feature2, h)` -> 7-tuple, `forward(...)` -> 10-tuple,
 reference state-dict keys -- on top of the gfx950 kernels.
 
-Scope: `backbone()` is the hot path and is batch-general.  The post-backbone half of
-the reference's forward (CPU DBSCAN clustering, Affinity MLP, log-Sinkhorn association,
-models/track4d.py:56-63,108-223) is B=1 host-side logic ranked "next" in SURVEY.md 8(f); forward()
-returns the backbone results with empty association structures until that row is built.
+Scope: `backbone()` is the hot path and is batch-general.  The post-backbone half of the
+reference's forward (moving-point clustering, Affinity MLP, log-Sinkhorn association, models/track4d.py:56-63,
+108-223) lives in ratrack_amd/association.py and is B = 1 logic, as in the reference.
 """
 import torch
 import torch.nn as nn
 
+from . import association as A
 from .model_utils import FeatureCorrelator, FlowDecoder, PNHead
 
 
@@ -40,7 +40,8 @@ class Track4D(nn.Module):
         self.fd_layer = FlowDecoder(fc_inch=fc_inch, args=args)
         self.affinity = Affinity(141)
         self.register_parameter("bin_score", nn.Parameter(torch.tensor(1.)))
-        self.max_id = 0
+        self.min_obj_points = args.min_obj_points
+        self.associator = A.Associator(self.affinity)
         self._fused = None     # lazily built fused inference engine (ratrack_amd.fused)
         self.use_fused = True
 
@@ -87,14 +88,32 @@ class Track4D(nn.Module):
             self._fused = None      # folded BN constants go stale once training resumes
         return super().train(mode)
 
+    @property
+    def max_id(self):
+        return self.associator.max_id
+
+    @max_id.setter
+    def max_id(self, v):
+        self.associator.max_id = v
+
+    def detect_and_associate(self, pc1, feature1, flow, cls, prop_features, objects_prev):
+        """models/track4d.py:53-63: select the moving points, cluster them into objects, associate with the previous
+        frame's objects.  B = 1.  Returns (pc1_warp, aff_list, aff_mat, indices1, confs, objects, objects_curr)."""
+        assert pc1.shape[0] == 1, "detection / association is single-frame logic (B = 1), as in the reference"
+        pc1_warp = pc1 + flow
+        point_features = torch.cat((pc1_warp, pc1, flow, feature1, prop_features), dim=1)      # (1,139,N)
+        mov_mask = (cls > 0.5).squeeze(0)
+        objects_curr = A.cluster_objects(point_features[:, :, mov_mask], eps=1.5, min_samples=self.min_obj_points)
+        aff_list, aff_mat, indices1, confs, objects = self.associator(objects_curr, objects_prev or dict())
+        return pc1_warp, aff_list, aff_mat, indices1, confs, objects, objects_curr
+
     def forward(self, pc1, pc2, feature1, feature2, h, objects_prev=None):
-        """Reference 10-tuple (models/track4d.py:49-65).  Detection/association is not built yet
-        (SURVEY.md 8(f) ranks 1-2): the association members come back empty."""
+        """The reference's 10-tuple (models/track4d.py:49-65):
+        (h, pc1_warp, cls, aff_list, aff_mat, indices1, confs, objects, timeout_obj_curr, objects_curr)."""
         output, h, cls, cor, pc1_features, pc2_features, prop = self.backbone(pc1, pc2, feature1, feature2, h)
-        pc1_warp = pc1 + output
-        aff_list, aff_mat, indices1, confs = [], torch.zeros(1, 0, 0, device=pc1.device), None, []
-        objects, timeout_obj_curr, objects_curr = dict(), dict(), []
-        return h, pc1_warp, cls, aff_list, aff_mat, indices1, confs, objects, timeout_obj_curr, objects_curr
+        pc1_warp, aff_list, aff_mat, indices1, confs, objects, objects_curr = self.detect_and_associate(
+            pc1, feature1, output, cls, prop, objects_prev)
+        return h, pc1_warp, cls, aff_list, aff_mat, indices1, confs, objects, dict(), objects_curr
 
 
 class Args(dict):

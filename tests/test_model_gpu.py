@@ -106,3 +106,30 @@ def test_train_step_matches_golden():
     for k in case:
         if k.startswith("bn/") and not k.endswith("num_batches_tracked"):
             assert_close(sd[k[3:]].cpu().numpy(), case[k], 1e-4, k)
+
+
+def test_full_forward_matches_reference_two_frames():
+    """Track4D.forward (fused backbone + clustering + association) on the GPU over two consecutive frames against the
+    reference's own forward(): movers, objects, affinities, assignments, track IDs."""
+    case = load_case("forward_b1_n256")
+    sd = reference_state_dict(DEV)
+    sd["fd_layer.cp.linear.bias"] = sd["fd_layer.cp.linear.bias"] + 0.09          # tools/make_golden.py FORWARD_CLS_BIAS_SHIFT
+    net = Track4D(Args()).to(DEV)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    objects_prev, h = dict(), torch.zeros(5, 1, 128, device=DEV)
+    with torch.no_grad():
+        for fi in range(2):
+            g = lambda k: torch.from_numpy(case["f%d_in_%s" % (fi, k)]).to(DEV)
+            h, pc1_warp, cls, aff_list, aff_mat, indices1, confs, objects, timeout, objects_curr = net(
+                g("pc1"), g("pc2"), g("feature1"), g("feature2"), h, objects_prev)
+            p = "f%d_" % fi
+            assert_close(pc1_warp.cpu().numpy(), case[p + "pc1_warp"], RTOL, "pc1_warp")
+            assert np.abs(cls.cpu().numpy() - case[p + "cls"]).max() < 1e-5
+            assert [o.shape[2] for o in objects_curr] == case[p + "object_sizes_curr"].tolist()
+            assert list(objects.keys()) == case[p + "object_ids"].tolist()
+            if case[p + "aff_mat"].size:
+                assert np.abs(aff_mat.cpu().numpy() - case[p + "aff_mat"]).max() < 1e-4
+                assert np.array_equal(indices1.cpu().numpy(), case[p + "indices1"])
+            assert np.allclose([float(c) for c in confs], case[p + "confs"], atol=1e-4)
+            objects_prev = {k: v.clone().detach() for k, v in objects.items()}

@@ -309,6 +309,48 @@ def train_case(name, d, Track4D, args, rec, mu, ref_loss, outdir):
     save(os.path.join(outdir, name + ".npz"), d, out)
 
 
+def forward_case(name, Track4D, args, rec, outdir):
+    """Two consecutive B=1 frames through the reference's full forward() (models/track4d.py:49-65): backbone ->
+    mover selection -> sklearn DBSCAN -> Affinity MLP + log-Sinkhorn association with the previous frame's objects.
+    The cls bias is raised so that a realistic share of points is classified as moving."""
+    net = build_net(Track4D, args, train=False)
+    sd = net.state_dict()
+    sd["fd_layer.cp.linear.bias"] += FORWARD_CLS_BIAS_SHIFT
+    frames = [synth.make_frame_pairs(1, 256, 20), synth.make_frame_pairs(1, 256, 21)]
+    out = {}
+    objects_prev, h = dict(), None
+    with torch.no_grad():
+        for fi, d in enumerate(frames):
+            t = {k: torch.from_numpy(v) for k, v in d.items() if k != "gt_cls"}
+            for k, v in d.items():
+                out["f%d_in_%s" % (fi, k)] = v
+            if h is None:
+                h = torch.zeros(5, 1, 128)
+            h, pc1_warp, cls, aff_list, aff_mat, indices1, confs, objects, timeout, objects_curr = net(
+                t["pc1"], t["pc2"], t["feature1"], t["feature2"], h, objects_prev)
+            p = "f%d_" % fi
+            out[p + "pc1_warp"], out[p + "cls"], out[p + "h"] = npf(pc1_warp), npf(cls), npf(h)
+            out[p + "n_objects_curr"] = np.int64(len(objects_curr))
+            out[p + "object_sizes_curr"] = np.array([o.shape[2] for o in objects_curr], dtype=np.int64)
+            out[p + "object_first_xyz"] = np.array([npf(o[0, 3:6, 0]) for o in objects_curr], dtype=np.float32).reshape(-1, 3)
+            out[p + "aff_mat"] = npf(aff_mat) if torch.is_tensor(aff_mat) else np.zeros((1, 0, 0), np.float32)
+            out[p + "indices1"] = indices1.numpy().astype(np.int64) if indices1 is not None else np.zeros((0,), np.int64)
+            out[p + "confs"] = np.array([float(c) for c in confs], dtype=np.float64)
+            out[p + "object_ids"] = np.array(list(objects.keys()), dtype=np.int64)
+            out[p + "object_sizes"] = np.array([objects[k].shape[2] for k in objects], dtype=np.int64)
+            out[p + "max_id"] = np.int64(net.max_id)
+            objects_prev = {k: v.clone().detach() for k, v in objects.items()}
+            margin = float((cls - 0.5).abs().min())
+            assert margin > 2e-5, "a point sits on the mover threshold (margin %.2e): pick another FORWARD_CLS_BIAS_SHIFT" % margin
+            print("  frame %d: movers %d (threshold margin %.1e), clusters %d, ids %s, confs %s" % (fi, int((cls > 0.5).sum()), margin, len(objects_curr),
+                                                                         list(objects.keys()), [round(float(c), 4) for c in confs]))
+    np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
+    print("wrote %s (%d arrays)" % (name, len(out)))
+
+
+FORWARD_CLS_BIAS_SHIFT = 0.09
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
@@ -334,6 +376,7 @@ def main():
         "eval_b1_n1024": lambda: eval_case("eval_b1_n1024", synth.make_frame_pairs(1, 1024, 3), Track4D, args, rec, mu, ref_main_utils, a.out),
         "eval_b1_n256_dups": lambda: eval_case("eval_b1_n256_dups", special_cloud(256), Track4D, args, rec, mu, ref_main_utils, a.out),
         "train_b1_n256": lambda: train_case("train_b1_n256", synth.make_frame_pairs(1, 256, 1), Track4D, args, rec, mu, ref_loss, a.out),
+        "forward_b1_n256": lambda: forward_case("forward_b1_n256", Track4D, args, rec, a.out),
     }
     for name, fn in cases.items():
         if a.only and a.only != name:
