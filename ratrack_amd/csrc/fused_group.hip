@@ -26,6 +26,9 @@ __device__ __forceinline__ f4 f4_relu(f4 a) { return (f4){fmaxf(a.x, 0.f), fmaxf
 // =================================================================================================
 // rtk_sa_scale
 // =================================================================================================
+#ifndef SA_MAX_WGS
+#define SA_MAX_WGS 1024
+#endif
 struct SaParams {
     int samples, n, npoint;
     const float *xyz, *new_xyz;
@@ -150,7 +153,7 @@ extern "C" int rtk_sa_scale(int samples, int n, int npoint, int nsample, const f
     const int cpt = nsample >= 16 ? 1 : 16 / nsample;
     const int groups = (npoint + cpt - 1) / cpt;
     int bx = (groups + 3) / 4;                 // one unit per wave per pass ...
-    while ((long)bx * samples > 4096 && bx > 1) bx = (bx + 1) / 2;      // ... unless that makes an absurd number of workgroups
+    while ((long)bx * samples > SA_MAX_WGS && bx > 1) bx = (bx + 1) / 2;   // few, fat workgroups: the LDS weight fill is paid per workgroup
     const dim3 blocks(bx, samples);
     const long key = (((long)nsample * 32 + v1) * 32 + v2) * 32 + v3;
 #define SA_CASE(ns, a, b, c)                                              \

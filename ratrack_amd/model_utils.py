@@ -50,6 +50,8 @@ class FeatureCorrelator(nn.Module):
     """kNN cost volume: point-to-patch (pc1 -> pc2) then patch-to-patch (pc1 -> pc1).
     model_utils.py:166-250.  pc (B,3,N), features (B,D,N) -> (B, mlp[-1], N1)."""
 
+    project_first = True
+
     def __init__(self, nsample, in_channel, mlp, bn=False, use_leaky=True):
         super().__init__()
         self.nsample = nsample
@@ -78,10 +80,26 @@ class FeatureCorrelator(nn.Module):
 
         knn_idx = knn_point(self.nsample, pc2, pc1)                         # (B,N1,k)
         direction = index_points(pc2, knn_idx) - pc1.reshape(B, N1, 1, C)   # neighbour - query
-        grouped2 = index_points(feature2, knn_idx)
-        grouped1 = feature1.reshape(B, N1, 1, D1).expand(-1, -1, self.nsample, -1)
-        x = torch.cat([grouped1, grouped2, direction], dim=-1).permute(0, 3, 2, 1)   # (B, D1+D2+3, k, N1)
-        for i, conv in enumerate(self.mlp_convs):
+        D2 = feature2.shape[2]
+        if self.project_first:
+            # conv0([f1 || f2[idx] || d]) = W1.f1 + (W2.f2)[idx] + Wd.d + b: project per point, then gather -- the reference's
+            # (B, 515, k, N) input tensor (540 MB at B=64) and the 515->256 conv over N*k positions never exist
+            conv0 = self.mlp_convs[0]
+            w = conv0.weight[:, :, 0, 0]                                     # (Cout, D1+D2+3)
+            p1 = F.linear(feature1, w[:, :D1], conv0.bias)                   # (B,N1,Cout)
+            p2 = F.linear(feature2, w[:, D1:D1 + D2])                        # (B,N2,Cout)
+            x = p1.unsqueeze(2) + index_points(p2, knn_idx) + F.linear(direction, w[:, D1 + D2:])     # (B,N1,k,Cout)
+            x = x.permute(0, 3, 2, 1)                                        # (B,Cout,k,N1)
+            if self.bn:
+                x = self.mlp_bns[0](x)
+            x = F.leaky_relu(x, self.slope)
+            rest = list(enumerate(self.mlp_convs))[1:]
+        else:
+            grouped2 = index_points(feature2, knn_idx)
+            grouped1 = feature1.reshape(B, N1, 1, D1).expand(-1, -1, self.nsample, -1)
+            x = torch.cat([grouped1, grouped2, direction], dim=-1).permute(0, 3, 2, 1)   # (B, D1+D2+3, k, N1)
+            rest = list(enumerate(self.mlp_convs))
+        for i, conv in rest:
             x = conv(x)
             if self.bn:
                 x = self.mlp_bns[i](x)

@@ -24,6 +24,32 @@ class PointnetSAModuleMSG(nn.Module):
             for r, ns in zip(radii, nsamples))
         self.mlps = nn.ModuleList(SharedMLP(list(spec), bn=bn) for spec in mlps)
 
+    project_first = True
+
+    @staticmethod
+    def _project_then_group(grouper, mlp, xyz, new_xyz, features):
+        """Same value as mlp(grouper(xyz, new_xyz, features)) with the first 1x1 conv moved in front of the gather:
+        conv([d_xyz || feats[idx]]) = Wx.d_xyz + (Wf.feats)[idx]  (a 1x1 conv and a gather commute).  The reference
+        materialises the grouped (B, 3+C, npoint, nsample) tensor -- 813 MB for the decoder's 514-channel level at B=64 --
+        convolves it and back-propagates through it; here only the C1-channel projection is gathered (and scattered in
+        the backward).  Parameters, BatchNorm statistics and results are unchanged up to fp32 summation order."""
+        layer0 = mlp.layer0
+        w = layer0.conv.weight                                                    # (C1, 3+C, 1, 1), no bias (bn=True)
+        c1 = w.shape[0]
+        idx = PU.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
+        grouped_xyz = PU.grouping_operation(xyz.transpose(1, 2).contiguous(), idx) - new_xyz.transpose(1, 2).unsqueeze(-1)
+        proj = F.conv1d(features, w[:, 3:, 0, :])                                 # (B, C1, n): per-POINT projection
+        x = F.conv2d(grouped_xyz, w[:, :3]) + PU.grouping_operation(proj.contiguous(), idx)
+        if layer0.conv.bias is not None:
+            x = x + layer0.conv.bias.view(1, c1, 1, 1)
+        for name, mod in layer0.named_children():                                 # bn / activation of layer 0
+            if name != "conv":
+                x = mod(x)
+        for name, layer in mlp.named_children():
+            if name != "layer0":
+                x = layer(x)
+        return x
+
     def forward(self, xyz, features=None, new_xyz=None):
         """xyz (B,N,3), features (B,C,N) -> new_xyz (B,npoint,3), (B, sum_k mlps[k][-1], npoint)."""
         if new_xyz is None and self.npoint is not None:
@@ -32,7 +58,10 @@ class PointnetSAModuleMSG(nn.Module):
             new_xyz = PU.gather_operation(flipped, idx).transpose(1, 2).contiguous()
         outs = []
         for grouper, mlp in zip(self.groupers, self.mlps):
-            x = mlp(grouper(xyz, new_xyz, features))          # (B, C', npoint, nsample)
+            if self.project_first and isinstance(grouper, PU.QueryAndGroup) and grouper.use_xyz and features is not None:
+                x = self._project_then_group(grouper, mlp, xyz, new_xyz, features)
+            else:
+                x = mlp(grouper(xyz, new_xyz, features))      # (B, C', npoint, nsample)
             if self.pool_method == "max_pool":
                 x = F.max_pool2d(x, kernel_size=[1, x.size(3)])
             elif self.pool_method == "avg_pool":
