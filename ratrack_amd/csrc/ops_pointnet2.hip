@@ -750,12 +750,37 @@ extern "C" int rtk_three_interpolate(int b, int c, int m, int n, const float *po
     return RTK_OK;
 }
 
+// As group_points_grad_lds_kernel: one workgroup per (batch, channel) row, LDS accumulation, no global atomics.
+__global__ __launch_bounds__(256) void three_interpolate_grad_lds_kernel(int c, int n, int m, const float *__restrict__ grad_out,
+                                                                         const int *__restrict__ idx, const float *__restrict__ weight,
+                                                                         float *__restrict__ grad_points) {
+    extern __shared__ float s_acc[];
+    const int bs = blockIdx.y, ci = blockIdx.x, tid = threadIdx.x;
+    for (int k = tid; k < m; k += 256) s_acc[k] = 0.f;
+    __syncthreads();
+    const float *go = grad_out + ((size_t)bs * c + ci) * n;
+    for (int pt = tid; pt < n; pt += 256) {
+        const float g = go[pt];
+        const float *w = weight + ((size_t)bs * n + pt) * 3;
+        const int *id = idx + ((size_t)bs * n + pt) * 3;
+        atomicAdd(&s_acc[id[0]], __fmul_rn(g, w[0]));
+        atomicAdd(&s_acc[id[1]], __fmul_rn(g, w[1]));
+        atomicAdd(&s_acc[id[2]], __fmul_rn(g, w[2]));
+    }
+    __syncthreads();
+    float *gp = grad_points + ((size_t)bs * c + ci) * m;
+    for (int k = tid; k < m; k += 256) gp[k] += s_acc[k];
+}
+
 extern "C" int rtk_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int *idx,
                                           const float *weight, float *grad_points, rtk_stream_t stream) {
     RTK_REQUIRE(b > 0 && c > 0 && m > 0 && n > 0 && grad_out && idx && weight && grad_points,
                 "three_interpolate_grad: bad arguments");
     RTK_REQUIRE(c <= 65535 && b <= 65535, "three_interpolate_grad: c/b exceed grid limits");
-    three_interpolate_grad_kernel<<<dim3(rtk_divup(n, 256), c, b), 256, 0, (hipStream_t)stream>>>(c, n, m, grad_out, idx, weight, grad_points);
+    if ((size_t)m * sizeof(float) <= 64 * 1024)
+        three_interpolate_grad_lds_kernel<<<dim3(c, b), 256, (size_t)m * sizeof(float), (hipStream_t)stream>>>(c, n, m, grad_out, idx, weight, grad_points);
+    else
+        three_interpolate_grad_kernel<<<dim3(rtk_divup(n, 256), c, b), 256, 0, (hipStream_t)stream>>>(c, n, m, grad_out, idx, weight, grad_points);
     RTK_CHECK_LAUNCH("three_interpolate_grad");
     return RTK_OK;
 }
