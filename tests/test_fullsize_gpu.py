@@ -86,3 +86,16 @@ def test_n1024_stress_config():
     with torch.no_grad():
         out = net32.backbone(*t32, None)
     assert all(torch.isfinite(x).all() for x in out) and out[0].shape == (32, 3, 1024)
+
+
+@pytest.mark.parametrize("b,n", [(3, 100), (1, 2500), (2, 6000)])
+def test_odd_shapes_fused_matches_module_path(b, n):
+    """Shapes off the tuned path: B not a power of two, N < 256, N > 2048 (generic FPS kernel + gather, ball query without the
+    LDS-staged pair kernel beyond 5461 points)."""
+    net, t = make(b, n, 1100 + n)
+    with torch.no_grad():
+        fused = net.backbone(*t, None)
+        net.use_fused = False
+        ref = net.backbone(*t, None)
+    for name, a, r in zip(NAMES, fused, ref):
+        assert rel_err(a.cpu(), r.cpu()) <= RTOL, name
