@@ -95,6 +95,8 @@ __device__ __forceinline__ int fps_pos_to_index(int p, int block, int q, int rem
     return r + jj * block;
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 template <int PPL>
 __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, const float *__restrict__ xyz,
                                                       float *__restrict__ temp, int *__restrict__ idxs,
@@ -108,18 +110,21 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, c
     if (new_xyz) new_xyz += (size_t)b * m * 3;
     const int q = n / block, rem = n % block;
 
-    float x[PPL], y[PPL], z[PPL];
-    unsigned t[PPL];   // min-distance bits; 0 for padding (can never equal a positive maximum)
+    // LANE-MAJOR layout: lane l owns positions PPL*l .. PPL*l + PPL-1 (positions enumerate the points in the reference's
+    // tie order), so "smallest position among the maxima" = lowest lane with the maximum, then its lowest slot.
+    // Slots are processed in pairs with packed fp32 math (v_pk_add/mul/fma: same roundings as the scalar chain).
+    constexpr int H = PPL / 2;
+    f2 x[H], y[H], z[H];
+    unsigned t[PPL];   // min-distance bits; padding slots hold 0 and coordinates of point 0 (distance stays 0)
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
-        const int p = lane + 64 * i;
+        const int p = lane * PPL + i;
         const bool ok = p < n;
         const int k = ok ? fps_pos_to_index(p, block, q, rem) : 0;
-        x[i] = ok ? xyz[k * 3 + 0] : 0.f;
-        y[i] = ok ? xyz[k * 3 + 1] : 0.f;
-        z[i] = ok ? xyz[k * 3 + 2] : 0.f;
+        const float px = xyz[k * 3 + 0], py = xyz[k * 3 + 1], pz = xyz[k * 3 + 2];
+        x[i / 2][i % 2] = px; y[i / 2][i % 2] = py; z[i / 2][i % 2] = pz;
         t[i] = ok ? __float_as_uint(temp ? temp[k] : 1e10f) : 0u;
-        if (ok) s_pt[p] = make_float4(x[i], y[i], z[i], __int_as_float(k));
+        if (ok) s_pt[p] = make_float4(px, py, pz, __int_as_float(k));
     }
     __syncthreads();
     float4 o = s_pt[0];   // position 0 is always point 0
@@ -130,25 +135,34 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, c
     const float4 p0 = o;
     int j = 1;
     for (; j < m; ++j) {
+        const f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
         unsigned mloc = 0u;
 #pragma unroll
-        for (int i = 0; i < PPL; ++i) {
-            const bool ok = lane + 64 * i < n;
-            const float d = rtk_sqdist(x[i], y[i], z[i], o.x, o.y, o.z);
-            const float d2 = fminf(d, __uint_as_float(t[i]));
-            t[i] = ok ? __float_as_uint(d2) : 0u;
-            mloc = t[i] > mloc ? t[i] : mloc;
+        for (int hh = 0; hh < H; ++hh) {
+            const f2 dx = x[hh] - ox, dy = y[hh] - oy, dz = z[hh] - oz;
+            f2 d = dx * dx;                                    // fp-contract is off: mul, then two explicit fmas
+            d = __builtin_elementwise_fma(dy, dy, d);
+            d = __builtin_elementwise_fma(dz, dz, d);
+            // d >= +0 (or NaN, whose bits exceed every finite value), so the unsigned minimum of the bit patterns is
+            // fminf(d, t) without the canonicalising v_max; padding slots hold t = 0 and stay 0
+            const unsigned d0 = __float_as_uint(d[0]), d1 = __float_as_uint(d[1]);
+            t[2 * hh] = d0 < t[2 * hh] ? d0 : t[2 * hh];
+            t[2 * hh + 1] = d1 < t[2 * hh + 1] ? d1 : t[2 * hh + 1];
+            const unsigned mm = t[2 * hh] > t[2 * hh + 1] ? t[2 * hh] : t[2 * hh + 1];
+            mloc = mm > mloc ? mm : mloc;
         }
+        // lowest slot holding the lane's own maximum: independent of the wave reduction, fills its DPP wait states
+        int sl = 0;
+#pragma unroll
+        for (int i = PPL - 1; i >= 0; --i) sl = t[i] == mloc ? i : sl;
+        asm volatile("" : "+v"(sl));              // keep it above the reduction (the compiler would sink it below)
         const unsigned M = wave_max_u32(mloc);
         if (M == 0u) break;                       // exhausted: every remaining pick is index 0
-        int pos = 0;
-        bool found = false;
-#pragma unroll
-        for (int i = 0; i < PPL; ++i) {
-            const unsigned long long mask = __ballot(t[i] == M);
-            if (!found && mask) { pos = 64 * i + __builtin_ctzll(mask); found = true; }
-        }
-        o = s_pt[pos];
+        const unsigned long long mask = __ballot(mloc == M);
+        const int wl = __builtin_ctzll(mask);     // lowest lane holding the maximum
+        const int pos = wl * PPL + __builtin_amdgcn_readlane(sl, wl);
+        o = s_pt[pos];                            // one uniform-address b128 read; lane 0 stores from registers
+        asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(o.w));
         if (lane == 0) {
             idxs[j] = __float_as_int(o.w);
             if (new_xyz) { new_xyz[j * 3 + 0] = o.x; new_xyz[j * 3 + 1] = o.y; new_xyz[j * 3 + 2] = o.z; }
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, c
     if (temp) {
 #pragma unroll
         for (int i = 0; i < PPL; ++i) {
-            const int p = lane + 64 * i;
+            const int p = lane * PPL + i;
             if (p < n) temp[__float_as_int(s_pt[p].w)] = __uint_as_float(t[i]);
         }
     }
