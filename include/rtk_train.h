@@ -1,0 +1,65 @@
+/*
+ * rtk_train.h -- C ABI of the training-mode kernels of librtk_hip.so.
+ *
+ * Training-mode BatchNorm2d + ReLU (+ max-pool over the neighbourhood axis) of a SharedMLP layer
+ * (lib/pytorch_utils.py:20-32,104-123 = Conv2d(1x1, no bias) -> nn.BatchNorm2d -> ReLU, followed in a
+ * set-abstraction scale by F.max_pool2d over nsample, lib/pointnet2_modules.py:44-47) as ONE weighted
+ * operator on the DE-DUPLICATED activation tensor:
+ *
+ *   z (samples, C, rows, ns) fp32, NCHW-contiguous, holds one row per UNIQUE centroid.  The reference tensor
+ *   has npoint rows of which rows >= nuniq[b] are exact copies of row 0 (over-sampling FPS, see
+ *   rtk_fps_centroids); their contribution to the batch statistics is carried by a per-row weight
+ *   row_weight (samples, rows):  w[b][0] = 1 + npoint - nuniq[b],  w[b][r] = 1 for 0 < r < nuniq[b],  0 beyond.
+ *   With count = samples/groups * npoint * ns (the reference element count per channel):
+ *       mean = sum w z / count,   var = sum w (z - mean)^2 / count   (biased; running_var gets count/(count-1))
+ *       y = relu(gamma (z - mean) rstd + beta)
+ *       dz_i = gamma rstd (dy_i [y_i > 0] - w_i (sum_j dy_j [y_j>0]) / count - w_i xhat_i (sum_j dy_j [y_j>0] xhat_j) / count)
+ *   which is the exact gradient of the reference computation w.r.t. the de-duplicated rows (dy_i already holds
+ *   the sum of the gradients of all copies of row i).
+ *
+ * groups: the reference runs the same module on frame 1 and then on frame 2 (models/track4d.py:88-92), i.e. two
+ * BatchNorm calls with separate batch statistics and two running-stat updates; with groups = 2 both halves
+ * of a stacked batch (samples/2 each) go through one launch with per-group statistics, and the running statistics
+ * are updated group 0 first, then group 1 -- identical to the two sequential calls.
+ *
+ * Same conventions as rtk_pointnet2.h: caller-allocated device buffers, explicit stream, 0 / negative status.
+ */
+#ifndef RTK_TRAIN_H
+#define RTK_TRAIN_H
+
+#include "rtk_pointnet2.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Weighted per-(group, channel) sums.  sums (groups, C, 2) float64, ZERO-INITIALISED by the caller:
+ * [..,0] += sum w z, [..,1] += sum w z^2.  ns must be a power of two; row_weight may be NULL (all ones). */
+RTK_EXPORT int rtk_bn_train_stats(int samples, int channels, int rows, int ns, int groups, const float *z,
+                                  const float *row_weight, double *sums, rtk_stream_t stream);
+
+/* sums -> par (4, groups, C) fp32 = [mean | rstd | scale = gamma rstd | shift = beta - mean scale]; updates
+ * running_mean / running_var (momentum, unbiased variance) group by group and adds `groups` to
+ * num_batches_tracked (int64, may be NULL).  count = reference elements per channel and group. */
+RTK_EXPORT int rtk_bn_train_finalize(int channels, int groups, const double *sums, double count, const float *gamma,
+                                     const float *beta, float eps, float momentum, float *running_mean,
+                                     float *running_var, int64_t *num_batches_tracked, float *par, rtk_stream_t stream);
+
+/* y = relu(z scale + shift).  pool == 0: y has the shape of z.  pool != 0: y (samples, C, rows) = max over ns. */
+RTK_EXPORT int rtk_bn_relu_fwd(int samples, int channels, int rows, int ns, int groups, const float *z, const float *par,
+                               int pool, float *y, rtk_stream_t stream);
+
+/* Backward, pass 1.  dy has the shape of y.  sums2 (groups, C, 2) float64 zero-initialised:
+ * [..,0] += sum dy [y>0], [..,1] += sum dy [y>0] xhat   (pool: only the first arg-max position of each row counts). */
+RTK_EXPORT int rtk_bn_relu_bwd_stats(int samples, int channels, int rows, int ns, int groups, const float *z,
+                                     const float *dy, const float *par, int pool, double *sums2, rtk_stream_t stream);
+
+/* Backward, pass 2: dz (shape of z); dgamma_dbeta (2, C) fp32 = [sum_g sums2[g][c][1] | sum_g sums2[g][c][0]]. */
+RTK_EXPORT int rtk_bn_relu_bwd_apply(int samples, int channels, int rows, int ns, int groups, const float *z,
+                                     const float *dy, const float *par, const float *row_weight, const double *sums2,
+                                     double count, int pool, float *dz, float *dgamma_dbeta, rtk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTK_TRAIN_H */

@@ -1,0 +1,436 @@
+// Training-mode BatchNorm2d + ReLU (+ max-pool over nsample) on de-duplicated, row-weighted activations
+// (include/rtk_train.h).  Reference: lib/pytorch_utils.py:20-32,104-123 (Conv2d -> BatchNorm2d -> ReLU) and
+// lib/pointnet2_modules.py:44-47 (F.max_pool2d over the neighbourhood axis).
+//
+// All kernels are HBM-bound streaming passes over z (samples, C, rows, ns): one workgroup per (channel, sample)
+// plane (rows*ns contiguous floats), 16-byte loads, per-thread float64 partial sums, one float64 atomic pair per
+// workgroup.  In the pooled variants the ns/4 lanes that hold one row's float4 chunks are adjacent, so the max /
+// arg-max over the neighbourhood is a 0..3-step xor-shuffle inside the wave -- no second pass, no index tensor.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "rtk_common.h"
+#include "rtk_train.h"
+
+namespace {
+
+constexpr int BN_T = 256;
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// block-wide sum of two doubles; result valid in thread 0
+__device__ __forceinline__ void block_sum2(double &a, double &b) {
+    __shared__ double s_red[2][BN_T / 64];
+    a = wave_sum_f64(a);
+    b = wave_sum_f64(b);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_red[0][w] = a; s_red[1][w] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = s_red[0][0]; b = s_red[1][0];
+#pragma unroll
+        for (int i = 1; i < BN_T / 64; ++i) { a += s_red[0][i]; b += s_red[1][i]; }
+    }
+}
+
+struct Plane {
+    size_t base;   // element offset of the (b, c) plane
+    int g;         // statistics group of sample b
+};
+
+__device__ __forceinline__ Plane plane_of(int samples, int channels, int rows, int ns, int groups) {
+    const int c = blockIdx.x, b = blockIdx.y;
+    Plane p;
+    p.base = ((size_t)b * channels + c) * (size_t)rows * ns;
+    p.g = b / (samples / groups);
+    return p;
+}
+
+// ---- forward: weighted sums --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BN_T) void bn_stats_kernel(int samples, int channels, int rows, int lg_ns, int groups,
+                                                        const float *__restrict__ z, const float *__restrict__ rw,
+                                                        double *__restrict__ sums) {
+    const Plane p = plane_of(samples, channels, rows, 1 << lg_ns, groups);
+    const int E = rows << lg_ns;
+    const float *zp = z + p.base;
+    const float *w = rw ? rw + (size_t)blockIdx.y * rows : nullptr;
+    double s = 0.0, ss = 0.0;
+    if ((E & 3) == 0) {
+        for (int e4 = threadIdx.x; e4 < (E >> 2); e4 += BN_T) {
+            const float4 v = *reinterpret_cast<const float4 *>(zp + 4 * e4);
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double wi = w ? (double)w[(4 * e4 + i) >> lg_ns] : 1.0;
+                const double x = vv[i];
+                s += wi * x;
+                ss += wi * x * x;
+            }
+        }
+    } else {
+        for (int e = threadIdx.x; e < E; e += BN_T) {
+            const double wi = w ? (double)w[e >> lg_ns] : 1.0;
+            const double x = zp[e];
+            s += wi * x;
+            ss += wi * x * x;
+        }
+    }
+    block_sum2(s, ss);
+    if (threadIdx.x == 0) {
+        double *dst = sums + ((size_t)p.g * channels + blockIdx.x) * 2;
+        atomicAdd(dst, s);
+        atomicAdd(dst + 1, ss);
+    }
+}
+
+__global__ void bn_finalize_kernel(int channels, int groups, const double *__restrict__ sums, double count,
+                                   const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
+                                   float *__restrict__ running_mean, float *__restrict__ running_var,
+                                   int64_t *__restrict__ nbt, float *__restrict__ par) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += groups;
+    if (c >= channels) return;
+    const size_t GC = (size_t)groups * channels;
+    float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+    for (int g = 0; g < groups; ++g) {
+        const double s = sums[((size_t)g * channels + c) * 2], ss = sums[((size_t)g * channels + c) * 2 + 1];
+        const double mean = s / count;
+        double var = ss / count - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * rstd;
+        const size_t o = (size_t)g * channels + c;
+        par[o] = (float)mean;
+        par[GC + o] = rstd;
+        par[2 * GC + o] = sc;
+        par[3 * GC + o] = beta[c] - (float)mean * sc;
+        // nn.BatchNorm2d: running = (1 - momentum) running + momentum batch; the variance unbiased
+        rm = (1.f - momentum) * rm + momentum * (float)mean;
+        rv = (1.f - momentum) * rv + momentum * (float)(var * (count / (count - 1.0)));
+    }
+    if (running_mean) running_mean[c] = rm;
+    if (running_var) running_var[c] = rv;
+}
+
+// ---- forward: normalise + ReLU --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BN_T) void bn_relu_fwd_kernel(int samples, int channels, int rows, int ns, int groups,
+                                                           const float *__restrict__ z, const float *__restrict__ par,
+                                                           float *__restrict__ y) {
+    const Plane p = plane_of(samples, channels, rows, ns, groups);
+    const size_t GC = (size_t)groups * channels, o = (size_t)p.g * channels + blockIdx.x;
+    const float sc = par[2 * GC + o], sh = par[3 * GC + o];
+    const int E = rows * ns;
+    const float *zp = z + p.base;
+    float *yp = y + p.base;
+    if ((E & 3) == 0) {
+        for (int e4 = threadIdx.x; e4 < (E >> 2); e4 += BN_T) {
+            float4 v = *reinterpret_cast<const float4 *>(zp + 4 * e4);
+            v.x = fmaxf(__fmaf_rn(v.x, sc, sh), 0.f);
+            v.y = fmaxf(__fmaf_rn(v.y, sc, sh), 0.f);
+            v.z = fmaxf(__fmaf_rn(v.z, sc, sh), 0.f);
+            v.w = fmaxf(__fmaf_rn(v.w, sc, sh), 0.f);
+            *reinterpret_cast<float4 *>(yp + 4 * e4) = v;
+        }
+    } else {
+        for (int e = threadIdx.x; e < E; e += BN_T) yp[e] = fmaxf(__fmaf_rn(zp[e], sc, sh), 0.f);
+    }
+}
+
+// One row = G = ns/4 adjacent lanes, each holding a float4 chunk.  Returns (in every lane of the group) the row's maximum
+// of y = relu(z sc + sh), and the z value and element index (within the row) of its FIRST arg-max.
+template <int G>
+__device__ __forceinline__ void row_argmax(const float4 v, float sc, float sh, int sub, float &ymax, float &zarg, int &karg) {
+    const float zz[4] = {v.x, v.y, v.z, v.w};
+    ymax = -1.f;
+    zarg = 0.f;
+    karg = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float yi = fmaxf(__fmaf_rn(zz[i], sc, sh), 0.f);
+        if (yi > ymax) { ymax = yi; zarg = zz[i]; karg = 4 * sub + i; }
+    }
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) {
+        const float y2 = __shfl_xor(ymax, o, 64), z2 = __shfl_xor(zarg, o, 64);
+        const int k2 = __shfl_xor(karg, o, 64);
+        const bool take = y2 > ymax || (y2 == ymax && k2 < karg);
+        ymax = take ? y2 : ymax;
+        zarg = take ? z2 : zarg;
+        karg = take ? k2 : karg;
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(BN_T) void bn_relu_pool_fwd_kernel(int samples, int channels, int rows, int groups,
+                                                                const float *__restrict__ z, const float *__restrict__ par,
+                                                                float *__restrict__ y) {
+    constexpr int NS = 4 * G;
+    const Plane p = plane_of(samples, channels, rows, NS, groups);
+    const size_t GC = (size_t)groups * channels, o = (size_t)p.g * channels + blockIdx.x;
+    const float sc = par[2 * GC + o], sh = par[3 * GC + o];
+    const float *zp = z + p.base;
+    float *yp = y + ((size_t)blockIdx.y * channels + blockIdx.x) * rows;
+    const int E4 = rows * G;
+    for (int base = 0; base < E4; base += BN_T) {
+        const int e4 = base + threadIdx.x;
+        const bool ok = e4 < E4;
+        const float4 v = ok ? *reinterpret_cast<const float4 *>(zp + 4 * e4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float ymax, zarg;
+        int karg;
+        row_argmax<G>(v, sc, sh, e4 % G, ymax, zarg, karg);
+        if (ok && (e4 % G) == 0) yp[e4 / G] = ymax;
+    }
+}
+
+// ---- backward, pass 1 -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BN_T) void bn_relu_bwd_stats_kernel(int samples, int channels, int rows, int ns, int groups,
+                                                                 const float *__restrict__ z, const float *__restrict__ dy,
+                                                                 const float *__restrict__ par, double *__restrict__ sums2) {
+    const Plane p = plane_of(samples, channels, rows, ns, groups);
+    const size_t GC = (size_t)groups * channels, o = (size_t)p.g * channels + blockIdx.x;
+    const float mean = par[o], rstd = par[GC + o], sc = par[2 * GC + o], sh = par[3 * GC + o];
+    const int E = rows * ns;
+    const float *zp = z + p.base, *dp = dy + p.base;
+    double s = 0.0, sx = 0.0;
+    auto acc = [&](float zi, float di) {
+        const bool on = __fmaf_rn(zi, sc, sh) > 0.f;
+        const float d = on ? di : 0.f;
+        s += (double)d;
+        sx += (double)d * (double)((zi - mean) * rstd);
+    };
+    if ((E & 3) == 0) {
+        for (int e4 = threadIdx.x; e4 < (E >> 2); e4 += BN_T) {
+            const float4 v = *reinterpret_cast<const float4 *>(zp + 4 * e4);
+            const float4 d = *reinterpret_cast<const float4 *>(dp + 4 * e4);
+            acc(v.x, d.x); acc(v.y, d.y); acc(v.z, d.z); acc(v.w, d.w);
+        }
+    } else {
+        for (int e = threadIdx.x; e < E; e += BN_T) acc(zp[e], dp[e]);
+    }
+    block_sum2(s, sx);
+    if (threadIdx.x == 0) {
+        double *dst = sums2 + o * 2;
+        atomicAdd(dst, s);
+        atomicAdd(dst + 1, sx);
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(BN_T) void bn_relu_pool_bwd_stats_kernel(int samples, int channels, int rows, int groups,
+                                                                      const float *__restrict__ z, const float *__restrict__ dy,
+                                                                      const float *__restrict__ par, double *__restrict__ sums2) {
+    constexpr int NS = 4 * G;
+    const Plane p = plane_of(samples, channels, rows, NS, groups);
+    const size_t GC = (size_t)groups * channels, o = (size_t)p.g * channels + blockIdx.x;
+    const float mean = par[o], rstd = par[GC + o], sc = par[2 * GC + o], sh = par[3 * GC + o];
+    const float *zp = z + p.base;
+    const float *dp = dy + ((size_t)blockIdx.y * channels + blockIdx.x) * rows;
+    const int E4 = rows * G;
+    double s = 0.0, sx = 0.0;
+    for (int base = 0; base < E4; base += BN_T) {
+        const int e4 = base + threadIdx.x;
+        const bool ok = e4 < E4;
+        const float4 v = ok ? *reinterpret_cast<const float4 *>(zp + 4 * e4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float ymax, zarg;
+        int karg;
+        row_argmax<G>(v, sc, sh, e4 % G, ymax, zarg, karg);
+        if (ok && (e4 % G) == 0 && ymax > 0.f) {
+            const float d = dp[e4 / G];
+            s += (double)d;
+            sx += (double)d * (double)((zarg - mean) * rstd);
+        }
+    }
+    block_sum2(s, sx);
+    if (threadIdx.x == 0) {
+        double *dst = sums2 + o * 2;
+        atomicAdd(dst, s);
+        atomicAdd(dst + 1, sx);
+    }
+}
+
+// ---- backward, pass 2 -------------------------------------------------------------------------------------------------
+struct BwdCoef {
+    float mean, rstd, sc, sh, c1, c2;
+};
+
+__device__ __forceinline__ BwdCoef bwd_coef(int channels, int groups, int g, const float *par, const double *sums2, double count,
+                                            float *dgb) {
+    const int c = blockIdx.x;
+    const size_t GC = (size_t)groups * channels, o = (size_t)g * channels + c;
+    BwdCoef k;
+    k.mean = par[o]; k.rstd = par[GC + o]; k.sc = par[2 * GC + o]; k.sh = par[3 * GC + o];
+    k.c1 = (float)(sums2[o * 2] / count);
+    k.c2 = (float)(sums2[o * 2 + 1] / count);
+    if (dgb && blockIdx.y == 0 && threadIdx.x == 0) {     // parameter gradients: sum over the groups
+        double db = 0.0, dg = 0.0;
+        for (int gg = 0; gg < groups; ++gg) {
+            db += sums2[((size_t)gg * channels + c) * 2];
+            dg += sums2[((size_t)gg * channels + c) * 2 + 1];
+        }
+        dgb[c] = (float)dg;
+        dgb[channels + c] = (float)db;
+    }
+    return k;
+}
+
+__global__ __launch_bounds__(BN_T) void bn_relu_bwd_apply_kernel(int samples, int channels, int rows, int lg_ns, int groups,
+                                                                 const float *__restrict__ z, const float *__restrict__ dy,
+                                                                 const float *__restrict__ par, const float *__restrict__ rw,
+                                                                 const double *__restrict__ sums2, double count,
+                                                                 float *__restrict__ dz, float *__restrict__ dgb) {
+    const Plane p = plane_of(samples, channels, rows, 1 << lg_ns, groups);
+    const BwdCoef k = bwd_coef(channels, groups, p.g, par, sums2, count, dgb);
+    const int E = rows << lg_ns;
+    const float *zp = z + p.base, *dp = dy + p.base;
+    float *op = dz + p.base;
+    const float *w = rw ? rw + (size_t)blockIdx.y * rows : nullptr;
+    auto one = [&](float zi, float di, int e) -> float {
+        const bool on = __fmaf_rn(zi, k.sc, k.sh) > 0.f;
+        const float wi = w ? w[e >> lg_ns] : 1.f;
+        const float xh = (zi - k.mean) * k.rstd;
+        return k.sc * ((on ? di : 0.f) - wi * (k.c1 + xh * k.c2));
+    };
+    if ((E & 3) == 0) {
+        for (int e4 = threadIdx.x; e4 < (E >> 2); e4 += BN_T) {
+            const float4 v = *reinterpret_cast<const float4 *>(zp + 4 * e4);
+            const float4 d = *reinterpret_cast<const float4 *>(dp + 4 * e4);
+            float4 r;
+            r.x = one(v.x, d.x, 4 * e4); r.y = one(v.y, d.y, 4 * e4 + 1);
+            r.z = one(v.z, d.z, 4 * e4 + 2); r.w = one(v.w, d.w, 4 * e4 + 3);
+            *reinterpret_cast<float4 *>(op + 4 * e4) = r;
+        }
+    } else {
+        for (int e = threadIdx.x; e < E; e += BN_T) op[e] = one(zp[e], dp[e], e);
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(BN_T) void bn_relu_pool_bwd_apply_kernel(int samples, int channels, int rows, int groups,
+                                                                      const float *__restrict__ z, const float *__restrict__ dy,
+                                                                      const float *__restrict__ par, const float *__restrict__ rw,
+                                                                      const double *__restrict__ sums2, double count,
+                                                                      float *__restrict__ dz, float *__restrict__ dgb) {
+    constexpr int NS = 4 * G;
+    const Plane p = plane_of(samples, channels, rows, NS, groups);
+    const BwdCoef k = bwd_coef(channels, groups, p.g, par, sums2, count, dgb);
+    const float *zp = z + p.base;
+    const float *dp = dy + ((size_t)blockIdx.y * channels + blockIdx.x) * rows;
+    float *op = dz + p.base;
+    const float *w = rw ? rw + (size_t)blockIdx.y * rows : nullptr;
+    const int E4 = rows * G;
+    for (int base = 0; base < E4; base += BN_T) {
+        const int e4 = base + threadIdx.x;
+        const bool ok = e4 < E4;
+        const float4 v = ok ? *reinterpret_cast<const float4 *>(zp + 4 * e4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float ymax, zarg;
+        int karg;
+        const int sub = e4 % G;
+        row_argmax<G>(v, k.sc, k.sh, sub, ymax, zarg, karg);
+        if (ok) {
+            const int row = e4 / G;
+            const float d = ymax > 0.f ? dp[row] : 0.f;
+            const float wi = w ? w[row] : 1.f;
+            const float zz[4] = {v.x, v.y, v.z, v.w};
+            float r[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float xh = (zz[i] - k.mean) * k.rstd;
+                r[i] = k.sc * ((karg == 4 * sub + i ? d : 0.f) - wi * (k.c1 + xh * k.c2));
+            }
+            *reinterpret_cast<float4 *>(op + 4 * e4) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+    }
+}
+
+int ilog2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+
+#define RTK_BN_COMMON_CHECKS(name)                                                                                    \
+    RTK_REQUIRE(samples > 0 && channels > 0 && rows > 0 && ns > 0, name ": empty tensor");                          \
+    RTK_REQUIRE(groups > 0 && samples % groups == 0, name ": samples (%d) not divisible by groups (%d)", samples, groups); \
+    RTK_REQUIRE(ilog2_exact(ns) >= 0, name ": ns (%d) must be a power of two", ns);                                 \
+    RTK_REQUIRE(samples <= 65535, name ": too many samples (%d)", samples)
+
+#define RTK_BN_POOL_DISPATCH(KERNEL, ...)                                                   \
+    switch (ns) {                                                                           \
+    case 4: KERNEL<1><<<grid, BN_T, 0, s>>>(__VA_ARGS__); break;                            \
+    case 8: KERNEL<2><<<grid, BN_T, 0, s>>>(__VA_ARGS__); break;                            \
+    case 16: KERNEL<4><<<grid, BN_T, 0, s>>>(__VA_ARGS__); break;                           \
+    case 32: KERNEL<8><<<grid, BN_T, 0, s>>>(__VA_ARGS__); break;                           \
+    default: rtk_set_error("pooled BatchNorm: ns (%d) must be 4, 8, 16 or 32", ns); return RTK_ERR_INVALID; \
+    }
+
+}  // namespace
+
+extern "C" int rtk_bn_train_stats(int samples, int channels, int rows, int ns, int groups, const float *z, const float *row_weight,
+                                  double *sums, rtk_stream_t stream) {
+    RTK_BN_COMMON_CHECKS("rtk_bn_train_stats");
+    hipStream_t s = (hipStream_t)stream;
+    bn_stats_kernel<<<dim3(channels, samples), BN_T, 0, s>>>(samples, channels, rows, ilog2_exact(ns), groups, z, row_weight, sums);
+    RTK_CHECK_LAUNCH("rtk_bn_train_stats");
+    return RTK_OK;
+}
+
+extern "C" int rtk_bn_train_finalize(int channels, int groups, const double *sums, double count, const float *gamma,
+                                     const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                                     int64_t *num_batches_tracked, float *par, rtk_stream_t stream) {
+    RTK_REQUIRE(channels > 0 && groups > 0 && count > 1.0, "rtk_bn_train_finalize: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    bn_finalize_kernel<<<rtk_divup(channels, 128), 128, 0, s>>>(channels, groups, sums, count, gamma, beta, eps, momentum,
+                                                               running_mean, running_var, num_batches_tracked, par);
+    RTK_CHECK_LAUNCH("rtk_bn_train_finalize");
+    return RTK_OK;
+}
+
+extern "C" int rtk_bn_relu_fwd(int samples, int channels, int rows, int ns, int groups, const float *z, const float *par, int pool,
+                               float *y, rtk_stream_t stream) {
+    RTK_BN_COMMON_CHECKS("rtk_bn_relu_fwd");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(channels, samples);
+    if (pool) {
+        RTK_BN_POOL_DISPATCH(bn_relu_pool_fwd_kernel, samples, channels, rows, groups, z, par, y)
+    } else {
+        bn_relu_fwd_kernel<<<grid, BN_T, 0, s>>>(samples, channels, rows, ns, groups, z, par, y);
+    }
+    RTK_CHECK_LAUNCH("rtk_bn_relu_fwd");
+    return RTK_OK;
+}
+
+extern "C" int rtk_bn_relu_bwd_stats(int samples, int channels, int rows, int ns, int groups, const float *z, const float *dy,
+                                     const float *par, int pool, double *sums2, rtk_stream_t stream) {
+    RTK_BN_COMMON_CHECKS("rtk_bn_relu_bwd_stats");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(channels, samples);
+    if (pool) {
+        RTK_BN_POOL_DISPATCH(bn_relu_pool_bwd_stats_kernel, samples, channels, rows, groups, z, dy, par, sums2)
+    } else {
+        bn_relu_bwd_stats_kernel<<<grid, BN_T, 0, s>>>(samples, channels, rows, ns, groups, z, dy, par, sums2);
+    }
+    RTK_CHECK_LAUNCH("rtk_bn_relu_bwd_stats");
+    return RTK_OK;
+}
+
+extern "C" int rtk_bn_relu_bwd_apply(int samples, int channels, int rows, int ns, int groups, const float *z, const float *dy,
+                                     const float *par, const float *row_weight, const double *sums2, double count, int pool,
+                                     float *dz, float *dgamma_dbeta, rtk_stream_t stream) {
+    RTK_BN_COMMON_CHECKS("rtk_bn_relu_bwd_apply");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(channels, samples);
+    if (pool) {
+        RTK_BN_POOL_DISPATCH(bn_relu_pool_bwd_apply_kernel, samples, channels, rows, groups, z, dy, par, row_weight, sums2, count, dz,
+                             dgamma_dbeta)
+    } else {
+        bn_relu_bwd_apply_kernel<<<grid, BN_T, 0, s>>>(samples, channels, rows, ilog2_exact(ns), groups, z, dy, par, row_weight, sums2,
+                                                       count, dz, dgamma_dbeta);
+    }
+    RTK_CHECK_LAUNCH("rtk_bn_relu_bwd_apply");
+    return RTK_OK;
+}

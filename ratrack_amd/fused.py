@@ -272,10 +272,12 @@ class Geometry:
     """FPS centroids, ball-query indices and three-NN tables of one batch of clouds (feature independent,
     so the decoder's PNHead over pc1 reuses the encoder's)."""
 
-    def __init__(self, xyz, npoint, side=None, knn_frames=0):
+    def __init__(self, xyz, npoint, side=None, knn_frames=0, finite=False):
         """xyz (S_,n,3).  With `side` (a torch.cuda.Stream) every geometry kernel is enqueued on that stream, forked from
         the current one, and consumers call wait(stage) -- the feature kernels overlap the latency-bound FPS chain.
-        knn_frames = B > 0: also the two kNN tables of the cost volume, frame 1 = xyz[:B], frame 2 = xyz[B:]."""
+        knn_frames = B > 0: also the two kNN tables of the cost volume, frame 1 = xyz[:B], frame 2 = xyz[B:].
+        finite: zero-fill the three-NN distances of the skipped (duplicate) rows instead of leaving them unwritten
+        (the training path computes -- and ignores -- those rows, so they must hold finite numbers)."""
         S_, n, _ = xyz.shape
         dev = xyz.device
         self.n, self.samples, self.npoint = n, S_, npoint
@@ -293,7 +295,7 @@ class Geometry:
         parts = list(torch.split(ws, sizes))
         fps_idx, cnt, ball, nn_idx = parts[0:3], parts[3:6], parts[6:12], parts[12:15]
         new_xyz = [torch.empty(S_, npoint, 3, dtype=torch.float32, device=dev) for _ in range(3)]
-        d2_all = torch.empty(sum(nn_rows) * S_ * 3, dtype=torch.float32, device=dev)
+        d2_all = (torch.zeros if finite else torch.empty)(sum(nn_rows) * S_ * 3, dtype=torch.float32, device=dev)
         d2_parts = torch.split(d2_all, [S_ * r * 3 for r in nn_rows])
         B = knn_frames
         self.knn = [torch.empty(B, n, 16, dtype=torch.int64, device=dev) for _ in range(2)] if B else None

@@ -221,13 +221,19 @@ class FlowDecoder(nn.Module):
         self.pnnGru = _UnusedPointGRU(fc_inch // 2, fc_inch // 2)             # unused (:278)
         self.torchGRU = nn.GRU(fc_inch // 2, fc_inch // 2, 5)
 
-    def forward(self, pc1, feature1, pc1_features, cor_features, h):
+    def forward(self, pc1, feature1, pc1_features, cor_features, h, train_geo=None):
+        """train_geo: optional train_path.TrainGeometry of pc1 (training mode): the 514-channel PNHead then runs on
+        the de-duplicated levels."""
         cls = self.cp(cor_features)
         if feature1 is not None:
             embeddings = torch.cat((feature1, pc1_features, cor_features), dim=1)
         else:
             embeddings = torch.cat((pc1_features, cor_features), dim=1)
-        _, prop = self.mse(pc1.permute(0, 2, 1).contiguous(), embeddings)
+        if train_geo is not None:
+            from .train_path import pnhead_train
+            prop = pnhead_train(self.mse, train_geo, embeddings)
+        else:
+            _, prop = self.mse(pc1.permute(0, 2, 1).contiguous(), embeddings)
         gfeat = torch.max(prop, -1)[0].unsqueeze(2)
         if h is None:   # the reference hard-wires (5,1,128) (model_utils.py:294-295); batch-general here
             h = torch.zeros(5, prop.size(0), 128, device=prop.device, dtype=prop.dtype)

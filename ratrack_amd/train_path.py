@@ -1,0 +1,140 @@
+"""Training-mode PNHead on de-duplicated levels.
+
+The reference samples npoint = 512 centroids from clouds of N = 256 points (configs.yaml: num_points 256, npoints 512),
+so at every set-abstraction level at least half of the centroid rows are exact copies of centroid 0
+(SURVEY.md A.5).  Its training step convolves, batch-normalises and back-propagates through all of them
+(lib/pointnet2_modules.py:10-56).  Here every level tensor keeps ONE row per unique centroid:
+
+  * geometry (FPS / ball query / three-NN, no gradient) comes from the same `Geometry` tables the inference engine
+    uses; indices that point at a duplicate row are redirected to row 0 (identical values);
+  * BatchNorm statistics count the missing copies through a per-row weight (w[b][0] = 1 + npoint - nuniq[b]), and the
+    backward of the weighted operator is the exact gradient of the reference computation (include/rtk_train.h);
+  * BatchNorm + ReLU (+ the max over the neighbourhood) is one HIP operator per layer (train_ops.bn_relu) instead of
+    MIOpen batch-norm + ReLU + max_pool2d kernels, forward and backward;
+  * the two per-frame encoder calls (models/track4d.py:88-92) run as one stacked batch with per-frame statistics
+    (groups = 2), running statistics updated frame 1 first, then frame 2.
+
+Parameters, state-dict keys, running statistics and results are those of the module path (pointnet2_modules.py /
+model_utils.PNHead) up to fp32 summation order; tests/test_train_gpu.py checks both against the golden train step.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import pointnet2_utils as PU
+from .train_ops import bn_relu
+
+
+class TrainGeometry:
+    """De-duplicated view of fused.Geometry for one stacked batch of clouds xyz (S_, n, 3)."""
+
+    def __init__(self, xyz, npoint):
+        from . import fused
+        geo = fused.Geometry(xyz, npoint, side=None, knn_frames=0, finite=True)
+        S_, n, _ = xyz.shape
+        self.samples, self.n, self.npoint = S_, n, npoint
+        U = self.U = min(n, npoint)
+        dev = xyz.device
+        nu = geo.nuniq                                            # per level: (S_,) int32 unique-centroid counts
+        ar = torch.arange(U, device=dev, dtype=torch.int32).view(1, U)
+        self.row_w = []
+        for lvl in range(3):
+            c = nu[lvl].view(S_, 1)
+            w = (ar < c).float()
+            w[:, 0] += (npoint - c.view(S_)).float()
+            self.row_w.append(w.contiguous())
+        self.ball, self.dxyz = [], []
+        for lvl in range(3):
+            src = geo.xyz[lvl][:, : (n if lvl == 0 else U)]
+            dst = geo.xyz[lvl + 1][:, :U]
+            src_t = src.transpose(1, 2).contiguous()
+            dst_t = dst.transpose(1, 2).unsqueeze(-1)
+            rows_b, rows_d = [], []
+            for s in range(2):
+                idx = geo.ball[lvl][s][:, :U]
+                if lvl > 0:      # source rows >= nuniq are copies of row 0
+                    idx = torch.where(idx >= nu[lvl - 1].view(S_, 1, 1), torch.zeros_like(idx), idx)
+                idx = idx.contiguous()
+                rows_b.append(idx)
+                rows_d.append(PU.grouping_operation(src_t, idx) - dst_t)      # (S_,3,U,ns), no gradient
+            self.ball.append(rows_b)
+            self.dxyz.append(rows_d)
+        self.interp = {}
+        for name, (u, k) in {"fp3": (2, 3), "fp2": (1, 2), "fp1": (0, 1)}.items():
+            d2, idx, _ = geo.nn[name]
+            rows = n if u == 0 else U
+            d2, idx = d2[:, :rows], idx[:, :rows]
+            idx = torch.where(idx >= nu[k - 1].view(S_, 1, 1), torch.zeros_like(idx), idx).contiguous()
+            recip = 1.0 / (torch.sqrt(d2) + 1e-8)                 # lib/pointnet2_modules.py:143-146
+            self.interp[name] = (idx, (recip / torch.sum(recip, dim=2, keepdim=True)).contiguous())
+        self.l3_xyz = geo.xyz[3]
+
+    def head(self, count):
+        """View on the first `count` samples (the pc1 half of a stacked batch)."""
+        g = object.__new__(TrainGeometry)
+        g.samples, g.n, g.npoint, g.U = count, self.n, self.npoint, self.U
+        g.row_w = [w[:count] for w in self.row_w]
+        g.ball = [[b[:count] for b in row] for row in self.ball]
+        g.dxyz = [[d[:count] for d in row] for row in self.dxyz]
+        g.interp = {k: (i[:count], w[:count]) for k, (i, w) in self.interp.items()}
+        g.l3_xyz = self.l3_xyz[:count]
+        return g
+
+
+def supported(head):
+    """The de-duplicated path covers the configuration RaTrack instantiates: max-pooled MSG levels whose SharedMLP
+    layers are Conv2d(no bias) + BatchNorm2d + ReLU."""
+    for sa in (head.sa1, head.sa2, head.sa3):
+        if sa.pool_method != "max_pool" or sa.npoint is None:
+            return False
+        for mlp in sa.mlps:
+            for layer in mlp.children():
+                if not hasattr(layer, "bn") or not hasattr(layer, "activation") or layer.conv.bias is not None:
+                    return False
+    return True
+
+
+def _sa_scale(mlp, tg, lvl, s, feats, groups):
+    """One MSG scale: (project -> gather) + offset conv -> [BN+ReLU -> conv]* -> BN+ReLU+max.  feats (S_,C,n_src)."""
+    layers = list(mlp.children())
+    w = layers[0].conv.weight                                     # (C1, 3+C, 1, 1): [d_xyz | features]
+    idx = tg.ball[lvl][s]
+    ns = idx.shape[2]
+    count = (tg.samples // groups) * tg.npoint * ns
+    proj = F.conv1d(feats, w[:, 3:, 0, :])                        # per-POINT projection (a 1x1 conv and a gather commute)
+    z = F.conv2d(tg.dxyz[lvl][s], w[:, :3]) + PU.grouping_operation(proj.contiguous(), idx)
+    x = None
+    for i, layer in enumerate(layers):
+        if i > 0:
+            z = F.conv2d(x, layer.conv.weight)
+        x = bn_relu(z, layer.bn.bn, tg.row_w[lvl], count, groups, pool=(i == len(layers) - 1))
+    return x                                                      # (S_, C_out, U)
+
+
+def _fp(fp, tg, name, skip, known_feats, row_w, count_rows, groups):
+    idx, weight = tg.interp[name]
+    x = PU.three_interpolate(known_feats.contiguous(), idx, weight)
+    if skip is not None:
+        x = torch.cat([x, skip], dim=1)
+    layers = list(fp.mlp.children())
+    x = x.unsqueeze(-1)
+    for layer in layers:
+        z = F.conv2d(x, layer.conv.weight)
+        x = bn_relu(z, layer.bn.bn, row_w, (tg.samples // groups) * count_rows, groups)
+    return x.squeeze(-1)
+
+
+def pnhead_train(head, tg, features, groups=1):
+    """PNHead.forward (model_utils.py:393-424) in training mode on geometry tg.  features (S_,Cf,n) -> l0_points
+    (S_,128,n).  groups: number of consecutive batch slices with their own BatchNorm statistics."""
+    lin = lambda layer, x: layer(x.permute(0, 2, 1)).permute(0, 2, 1).contiguous()
+    feats = features.contiguous()
+    levels = []
+    for lvl, (sa, linear) in enumerate(((head.sa1, head.linear1), (head.sa2, head.linear2), (head.sa3, head.linear3))):
+        outs = [_sa_scale(mlp, tg, lvl, s, feats, groups) for s, mlp in enumerate(sa.mlps)]
+        feats = lin(linear, torch.cat(outs, dim=1))               # (S_, C, U)
+        levels.append(feats)
+    l1, l2, l3 = levels
+    S, n = tg.npoint, tg.n
+    l2 = _fp(head.fp3, tg, "fp3", l2, l3, tg.row_w[1], S, groups)
+    l1 = _fp(head.fp2, tg, "fp2", l1, l2, tg.row_w[0], S, groups)
+    return _fp(head.fp1, tg, "fp1", None, l1, None, n, groups)

@@ -1,0 +1,155 @@
+"""GPU: training-mode kernels (include/rtk_train.h) and the de-duplicated training path (ratrack_amd/train_path.py).
+
+* bn_relu against nn.BatchNorm2d(train) + ReLU (+ max_pool2d) in float64 on the EXPANDED tensor (duplicate rows
+  materialised as the reference has them): outputs, running statistics, dz (copies summed), dgamma, dbeta.
+* one training step of Track4D through the de-duplicated path against the same step through the module path
+  (reference structure: every duplicate row computed, MIOpen BatchNorm) -- and, in test_model_gpu.py, against the
+  golden train step captured from the reference.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ratrack_amd import synth
+from ratrack_amd.track4d import Args, Track4D
+from ratrack_amd.train_ops import bn_relu
+
+from _util import reference_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _expand_rows(t, nuniq, npoint):
+    """(S,C,U,ns) -> (S,C,npoint,ns): rows >= nuniq[b] are copies of row 0."""
+    S_, C, U, ns = t.shape
+    idx = torch.arange(npoint, device=t.device).view(1, npoint).repeat(S_, 1)
+    idx = torch.where(idx >= nuniq.view(S_, 1), torch.zeros_like(idx), idx)
+    return torch.gather(t, 2, idx.view(S_, 1, npoint, 1).expand(S_, C, npoint, ns)), idx
+
+
+@pytest.mark.parametrize("ns,pool,groups,dedup", [(1, False, 1, True), (4, True, 2, True), (8, False, 2, True), (16, True, 1, True),
+                                                  (32, True, 2, False), (1, False, 2, False), (32, False, 1, True)])
+def test_bn_relu_matches_expanded_batchnorm(ns, pool, groups, dedup):
+    torch.manual_seed(ns * 7 + pool + groups)
+    S_, C, npoint = 4, 19, 40
+    U = 24 if dedup else npoint
+    nuniq = torch.tensor([24, 17, 24, 9] if dedup else [npoint] * 4, device=DEV)
+    z = (torch.randn(S_, C, U, ns, device=DEV) * 1.7 + 0.3).requires_grad_(True)
+    bn = nn.BatchNorm2d(C).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(-1.0, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 2.0)
+    ref = nn.BatchNorm2d(C).to(DEV).double()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v.clone() for k, v in bn.state_dict().items()})
+    ar = torch.arange(U, device=DEV).view(1, U)
+    w = (ar < nuniq.view(S_, 1)).float()
+    w[:, 0] += (npoint - nuniq).float()
+    y = bn_relu(z, bn, w.contiguous() if dedup else None, (S_ // groups) * npoint * ns, groups, pool)
+
+    zd = z.detach().double().requires_grad_(True)
+    full, idx = _expand_rows(zd, nuniq, npoint)
+    outs = []
+    for g in range(groups):                                        # sequential calls, as the reference's per-frame passes
+        sl = slice(g * S_ // groups, (g + 1) * S_ // groups)
+        o = F.relu(ref(full[sl]))
+        outs.append(F.max_pool2d(o, kernel_size=[1, ns]).squeeze(-1) if pool else o)
+    yref_full = torch.cat(outs, 0)
+    live = (ar < nuniq.view(S_, 1))                                # rows that consumers read
+    yref = yref_full[:, :, :U]
+    m = live.view(S_, 1, U, *([1] if not pool else [])).expand_as(y)
+    assert torch.allclose(y[m].double(), yref[m], rtol=1e-5, atol=1e-5)
+    for k in ("running_mean", "running_var"):
+        assert torch.allclose(getattr(bn, k).double(), getattr(ref, k), rtol=1e-5, atol=1e-6), k
+    assert int(bn.num_batches_tracked) == groups
+
+    # gradient: random cotangent on the live de-duplicated rows; the expanded graph receives it on the first copy only
+    # (consumers of a duplicate are redirected to row 0, so the copies have no consumers of their own)
+    ct = torch.randn_like(y) * m.float()
+    y.backward(ct)
+    ct_full = torch.zeros_like(yref_full)
+    ct_full[:, :, :U] = ct.double()
+    yref_full.backward(ct_full)
+    scale = float(zd.grad.abs().max())
+    assert torch.allclose(z.grad.double()[:, :, :][live.view(S_, 1, U, 1).expand_as(z)],
+                          zd.grad[live.view(S_, 1, U, 1).expand_as(z)], rtol=1e-4, atol=2e-5 * scale)
+    assert torch.allclose(bn.weight.grad.double(), ref.weight.grad, rtol=1e-4, atol=1e-5 * float(ref.weight.grad.abs().max()))
+    assert torch.allclose(bn.bias.grad.double(), ref.bias.grad, rtol=1e-4, atol=1e-5 * float(ref.bias.grad.abs().max()))
+
+
+def _train_once(dedup, B, N, pretrain=False):
+    from ratrack_amd import loss as L
+    net = Track4D(Args()).to(DEV)
+    net.load_state_dict(reference_state_dict(DEV), strict=True)
+    net.train()
+    net.dedup_train = dedup
+    d = synth.make_frame_pairs(B, N, 5)
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in d.items()}
+    flow, h, cls, cor, f1, f2, prop = net.backbone(t["pc1"], t["pc2"], t["feature1"], t["feature2"], None)
+    total, items = L.backbone_loss(t["pc1"] + flow, cls, t["gt_warp"], t["gt_cls"], pretrain=pretrain)
+    total.backward()
+    grads = {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in net.named_parameters()}
+    stats = {k: v.detach().clone() for k, v in net.state_dict().items() if "running_" in k or "num_batches" in k}
+    return dict(flow=flow.detach(), cls=cls.detach(), prop=prop.detach(), h=h.detach(), f1=f1.detach(), f2=f2.detach(),
+                total=float(total.detach())), grads, stats
+
+
+@pytest.mark.parametrize("B,N", [(2, 256), (3, 200), (2, 640)])
+def test_dedup_train_step_matches_module_path(B, N):
+    """Same weights, same batch: forward outputs, every parameter gradient and every BatchNorm running statistic of the
+    de-duplicated path agree with the module path that computes all 512 centroid rows."""
+    out_d, g_d, s_d = _train_once(True, B, N)
+    out_m, g_m, s_m = _train_once(False, B, N)
+    for k in ("flow", "cls", "prop", "h", "f1", "f2"):
+        a, b = out_d[k], out_m[k]
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-6, k
+    assert abs(out_d["total"] - out_m["total"]) <= 1e-4 * abs(out_m["total"])
+    gmax = max(float(g.norm()) for g in g_m.values() if g is not None)
+    for k, gm in g_m.items():
+        gd = g_d[k]
+        if gm is None:
+            assert gd is None or float(gd.norm()) == 0.0, k
+            continue
+        err = float((gd - gm).norm())
+        # two fp32 evaluations of a batch-statistic network: the 514-channel first decoder layer amplifies rounding
+        # differences to a few 1e-3 at small batch; a wrong weight or count shows up at O(1)
+        assert err <= 1.5e-2 * float(gm.norm()) + 1e-5 * gmax, (k, err, float(gm.norm()))
+    for k, v in s_m.items():
+        if v.is_floating_point():
+            assert float((s_d[k] - v).abs().max()) <= 1e-4 * float(v.abs().max()) + 1e-7, k
+        else:
+            assert int(s_d[k]) == int(v), k
+
+
+def test_dedup_train_handles_duplicate_input_points():
+    """Clouds with repeated points (padded frames): FPS exhausts before n picks, so some of the min(n, npoint) rows are
+    dead (weight 0).  Forward and gradients still match the module path."""
+    from ratrack_amd import loss as L
+    B, N = 2, 256
+    d = synth.make_frame_pairs(B, N, 9)
+    for k in ("pc1", "pc2"):
+        d[k][:, :, 200:] = d[k][:, :, :56]                         # 56 exact duplicates per cloud
+    d["feature1"][:, :, 200:] = d["feature1"][:, :, :56]
+    d["feature2"][:, :, 200:] = d["feature2"][:, :, :56]
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in d.items()}
+    res = []
+    for dedup in (True, False):
+        net = Track4D(Args()).to(DEV)
+        net.load_state_dict(reference_state_dict(DEV), strict=True)
+        net.train()
+        net.dedup_train = dedup
+        flow, h, cls, *_ = net.backbone(t["pc1"], t["pc2"], t["feature1"], t["feature2"], None)
+        total, _ = L.backbone_loss(t["pc1"] + flow, cls, t["gt_warp"], t["gt_cls"], pretrain=False)
+        total.backward()
+        res.append((flow.detach(), {k: p.grad for k, p in net.named_parameters() if p.grad is not None}))
+    (fa, ga), (fb, gb) = res
+    assert torch.isfinite(fa).all()
+    assert float((fa - fb).abs().max()) <= 2e-4 * float(fb.abs().max())
+    gmax = max(float(g.norm()) for g in gb.values())
+    for k in gb:
+        assert torch.isfinite(ga[k]).all(), k
+        assert float((ga[k] - gb[k]).norm()) <= 1.5e-2 * float(gb[k].norm()) + 1e-5 * gmax, k
