@@ -27,7 +27,7 @@
 #ifndef RTK_TRAIN_H
 #define RTK_TRAIN_H
 
-#include "rtk_pointnet2.h"
+#include "rtk_fused.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -58,6 +58,28 @@ RTK_EXPORT int rtk_bn_relu_bwd_stats(int samples, int channels, int rows, int ns
 RTK_EXPORT int rtk_bn_relu_bwd_apply(int samples, int channels, int rows, int ns, int groups, const float *z,
                                      const float *dy, const float *par, const float *row_weight, const double *sums2,
                                      double count, int pool, float *dz, float *dgamma_dbeta, rtk_stream_t stream);
+
+/* ---- cost volume (utils/model_utils/model_utils.py:216-236) ------------------------------------------------------
+ * Backward of rtk_cost_volume (rtk_fused.h; same forward arguments).  layers[0..3] = the packed 256x256 layers
+ * W2, W3, W3^T, W2^T, contiguous in memory (biases of W2, W3 in layers[0], layers[1]).  dout (samples*n1, dout_pitch)
+ * is the gradient of the forward output.  Outputs, all caller-allocated, M = samples*n1*16 positions (query-major,
+ * neighbour minor):
+ *   a1, a2 (M,256)   recomputed activations of layers 1 and 2            (operands of dW2 = dz2^T a1, dW3 = dz3^T a2)
+ *   dz1, dz2, dz3 (M,256)  gradients of the three pre-activations        (db = column sums; dWd = dz1^T d4[:, :3])
+ *   dq3 (M,256)      gradient of the WeightNet's last pre-activation
+ *   d4 (M,4)         (neighbour - query, 1) of every position
+ *   dp1 (samples*n1, 256)  gradient of p1 (= sum of dz1 over the 16 neighbours).
+ * The gradient of p2 is rtk_scatter_add_rows(knn_idx, dz1). */
+RTK_EXPORT int rtk_cost_volume_bwd(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
+                                   const float *p1, const float *p2, const float *wd_packed, const rtk_layer_t *layers,
+                                   const rtk_layer_t *wn, const float *dout, int dout_pitch, float *a1, float *a2, float *dz1,
+                                   float *dz2, float *dz3, float *dq3, float *d4, float *dp1, rtk_stream_t stream);
+
+/* dst[b][idx[b][r]][:] += src[b][r][:] for r < m, dst (samples, n, channels) fully written (no zero-fill needed):
+ * the scatter half of the backward of a row gather.  idx (samples, m) int64 in [0, n); channels % 32 == 0;
+ * n * 128 bytes of LDS per workgroup (n <= 1024). */
+RTK_EXPORT int rtk_scatter_add_rows(int samples, int m, int n, int channels, const int64_t *idx, const float *src, float *dst,
+                                    rtk_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,7 @@
 #include "rtk_common.h"
 #include "fused_common.h"
 #include "rtk_fused.h"
+#include "rtk_train.h"
 
 // The single k-step "offset" layer: A operand image [V][64] floats, lane (g, i) holds W4[16v + i][g] with
 // W4 = [Wx | b] (Cout x 4); B operand: lane (g, j) holds (dx, dy, dz, 1)[g] of pair j.
@@ -329,6 +330,197 @@ extern "C" int rtk_cost_volume(int samples, int n1, int n2, const float *xyz1, c
     if (gx > groups) gx = groups;
     cost_volume_kernel<<<dim3(gx, samples), 64 * CV_NW, 0, (hipStream_t)stream>>>(P);
     RTK_CHECK_LAUNCH("cost_volume");
+    return RTK_OK;
+}
+
+// =================================================================================================
+// rtk_cost_volume_bwd: backward of rtk_cost_volume (include/rtk_train.h).
+//
+// Same tiling as the forward (one wave = one query point x its 16 neighbours, activations stationary in registers):
+// the forward is recomputed, then the gradient walks back through the two 256x256 layers with the TRANSPOSED packed
+// weights streamed through the same LDS double buffer (blob order W2, W3, W3^T, W2^T = one pass per tile).
+// Weight gradients are contractions over all B*N*16 positions -- plain GEMMs -- so the kernel materialises exactly
+// their operands, point-major (position, 256): the recomputed activations a1, a2 and the pre-activation gradients
+// dz1, dz2, dz3 (+ dq3 for the WeightNet and the 4-vector (dx, dy, dz, 1) of every position); the host multiplies.
+// dp1 (gradient of the per-query projection) is the sum of dz1 over the 16 neighbours, reduced in registers.
+// =================================================================================================
+struct CvBwdParams {
+    CvParams f;                   // forward arguments; f.blob holds 4 layers: W2, W3, W3^T, W2^T
+    const float *dout;
+    int dout_pitch;
+    float *a1, *a2, *dz1, *dz2, *dz3, *dq3, *d4, *dp1;
+};
+
+__device__ __forceinline__ f4 leaky_grad(f4 d, f4 a) {     // d * leaky'(z), the sign of z read off a = leaky(z)
+    f4 r;
+    r.x = a.x > 0.f ? d.x : 0.1f * d.x;
+    r.y = a.y > 0.f ? d.y : 0.1f * d.y;
+    r.z = a.z > 0.f ? d.z : 0.1f * d.z;
+    r.w = a.w > 0.f ? d.w : 0.1f * d.w;
+    return r;
+}
+
+__global__ __launch_bounds__(64 * CV_NW, (CV_NW * CV_WGS_PER_CU) / 4) void cost_volume_bwd_kernel(const CvBwdParams Q) {
+    __shared__ __attribute__((aligned(16))) f4 s_w[2 * CV_F * 64];
+    const CvParams &P = Q.f;
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    const int wave_in_wg = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int groups = (P.n1 + CV_NW - 1) / CV_NW;
+    constexpr int NF = 4 * CV_V * CV_V;
+    constexpr int L = CV_V * CV_V;
+    WStream<CV_NW, CV_F, NF> ws;
+    ws.start(P.blob, s_w, wave_in_wg, lane);
+    for (int G = blockIdx.x; G < groups; G += gridDim.x) {
+        asm volatile("" ::: "memory");
+        const int pt = G * CV_NW + wave_in_wg;
+        const bool valid = pt < P.n1;
+        const long i = (long)b * P.n1 + (valid ? pt : P.n1 - 1);
+        const long nb = (long)b * P.n2 + (long)P.knn[i * 16 + j];
+        const float bop = g < 3 ? __fsub_rn(P.xyz2[nb * 3 + g], P.xyz1[i * 3 + g]) : 1.0f;
+        const long pos = i * 16 + j;                                     // row of the materialised (position, 256) tensors
+        const long ro = pos * 256 + 4 * g;
+        if (valid) Q.d4[pos * 4 + g] = bop;
+        // ---- forward recompute ---------------------------------------------------------------------------------------
+        f4 h[CV_V];
+        {
+            const float *r1 = P.p1 + i * 256 + 4 * g, *r2 = P.p2 + nb * 256 + 4 * g;
+#pragma unroll
+            for (int v = 0; v < CV_V; ++v)
+                h[v] = *reinterpret_cast<const f4 *>(r1 + 16 * v) + *reinterpret_cast<const f4 *>(r2 + 16 * v);
+#pragma unroll
+            for (int v = 0; v < CV_V; ++v) h[v] = mfma4(P.wd[v * 64 + lane], bop, h[v]);
+            apply_act<CV_V>(h, RTK_ACT_LEAKY);
+        }
+        if (valid) {
+#pragma unroll
+            for (int v = 0; v < CV_V; ++v) *reinterpret_cast<f4 *>(Q.a1 + ro + 16 * v) = h[v];
+        }
+        f4 a[CV_V];
+#pragma unroll
+        for (int v = 0; v < CV_V; ++v) a[v] = bias_frag(P.bias2, v, g);
+        mlp_layer_ws<CV_V, CV_V, 0>(ws, h, a);
+        apply_act<CV_V>(a, RTK_ACT_LEAKY);
+        if (valid) {
+#pragma unroll
+            for (int v = 0; v < CV_V; ++v) *reinterpret_cast<f4 *>(Q.a2 + ro + 16 * v) = a[v];
+        }
+#pragma unroll
+        for (int v = 0; v < CV_V; ++v) h[v] = bias_frag(P.bias3, v, g);
+        mlp_layer_ws<CV_V, CV_V, L>(ws, a, h);
+        apply_act<CV_V>(h, RTK_ACT_LEAKY);                               // h = a3
+        // ---- out = sum_k wn * a3:  dz3 = dout wn leaky'(z3),  dq3 = dout a3 [wn > 0] ---------------------------------
+        const f4 t2 = weightnet_hidden(P.wn, lane, g, bop);
+        const float *dor = Q.dout + i * Q.dout_pitch + 4 * g;
+#pragma unroll
+        for (int v = 0; v < CV_V; ++v) {
+            const f4 w = weightnet_out(P.wn, lane, g, v, t2);
+            const f4 d = *reinterpret_cast<const f4 *>(dor + 16 * v);
+            f4 q;
+            q.x = w.x > 0.f ? d.x * h[v].x : 0.f;
+            q.y = w.y > 0.f ? d.y * h[v].y : 0.f;
+            q.z = w.z > 0.f ? d.z * h[v].z : 0.f;
+            q.w = w.w > 0.f ? d.w * h[v].w : 0.f;
+            h[v] = leaky_grad(d * w, h[v]);
+            if (valid) {
+                *reinterpret_cast<f4 *>(Q.dq3 + ro + 16 * v) = q;
+                *reinterpret_cast<f4 *>(Q.dz3 + ro + 16 * v) = h[v];
+            }
+        }
+        // ---- da2 = W3^T dz3;  dz2 = da2 leaky'(z2) ---------------------------------------------------------------------
+#pragma unroll
+        for (int v = 0; v < CV_V; ++v) a[v] = f4_zero();
+        mlp_layer_ws<CV_V, CV_V, 2 * L>(ws, h, a);
+#pragma unroll
+        for (int v = 0; v < CV_V; ++v) {
+            const f4 act = *reinterpret_cast<const f4 *>(Q.a2 + ro + 16 * v);     // this lane's own store, above
+            a[v] = leaky_grad(a[v], act);
+            if (valid) *reinterpret_cast<f4 *>(Q.dz2 + ro + 16 * v) = a[v];
+        }
+        // ---- da1 = W2^T dz2;  dz1 = da1 leaky'(z1);  dp1 = sum over the 16 neighbours ----------------------------------
+#pragma unroll
+        for (int v = 0; v < CV_V; ++v) h[v] = f4_zero();
+        mlp_layer_ws<CV_V, CV_V, 3 * L>(ws, a, h);
+        ws.next();   // wrap the stream to chunk 0
+        float *dpr = Q.dp1 + i * 256 + 4 * g;
+#pragma unroll
+        for (int v = 0; v < CV_V; ++v) {
+            const f4 act = *reinterpret_cast<const f4 *>(Q.a1 + ro + 16 * v);
+            f4 r = leaky_grad(h[v], act);
+            if (valid) *reinterpret_cast<f4 *>(Q.dz1 + ro + 16 * v) = r;
+            row_sum16_f4(r);
+            if (valid && j == 0) *reinterpret_cast<f4 *>(dpr + 16 * v) = r;
+        }
+    }
+    ws.finish();
+}
+
+extern "C" int rtk_cost_volume_bwd(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
+                                   const float *p1, const float *p2, const float *wd_packed, const rtk_layer_t *layers,
+                                   const rtk_layer_t *wn, const float *dout, int dout_pitch, float *a1, float *a2, float *dz1,
+                                   float *dz2, float *dz3, float *dq3, float *d4, float *dp1, rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && n1 > 0 && n2 >= 16 && xyz1 && xyz2 && knn_idx && p1 && p2 && wd_packed && layers && dout && a1 &&
+                a2 && dz1 && dz2 && dz3 && dq3 && d4 && dp1, "cost_volume_bwd: bad arguments");
+    for (int l = 0; l < 4; ++l)
+        RTK_REQUIRE(layers[l].cin16 == 16 && layers[l].cout16 == 16 && layers[l].w_packed == layers[0].w_packed + (size_t)l * 256 * 256,
+                    "cost_volume_bwd: expects four contiguous 256x256 layers (W2, W3, W3^T, W2^T)");
+    RTK_REQUIRE(dout_pitch % 4 == 0 && dout_pitch >= 256, "cost_volume_bwd: bad dout_pitch");
+    RTK_REQUIRE(samples <= 65535, "cost_volume_bwd: too many samples");
+    CvBwdParams Q;
+    CvParams &P = Q.f;
+    P.samples = samples; P.n1 = n1; P.n2 = n2;
+    P.xyz1 = xyz1; P.xyz2 = xyz2; P.knn = knn_idx; P.p1 = p1; P.p2 = p2; P.wd = wd_packed;
+    P.blob = reinterpret_cast<const f4 *>(layers[0].w_packed);
+    P.bias2 = layers[0].bias; P.bias3 = layers[1].bias;
+    if (fill_wn(P.wn, wn, "cost_volume_bwd") != RTK_OK) return RTK_ERR_INVALID;
+    RTK_REQUIRE(wn[2].cout16 == 16, "cost_volume_bwd: WeightNet must produce 256 channels");
+    P.out = nullptr; P.out_pitch = 0;
+    Q.dout = dout; Q.dout_pitch = dout_pitch;
+    Q.a1 = a1; Q.a2 = a2; Q.dz1 = dz1; Q.dz2 = dz2; Q.dz3 = dz3; Q.dq3 = dq3; Q.d4 = d4; Q.dp1 = dp1;
+    const int groups = (n1 + CV_NW - 1) / CV_NW;
+    int gx = 256 * CV_WGS_PER_CU / samples;
+    if (gx < 1) gx = 1;
+    if (gx > groups) gx = groups;
+    cost_volume_bwd_kernel<<<dim3(gx, samples), 64 * CV_NW, 0, (hipStream_t)stream>>>(Q);
+    RTK_CHECK_LAUNCH("cost_volume_bwd");
+    return RTK_OK;
+}
+
+// dst[b][idx[b][m]][:] += src[b][m][:]  -- the scatter half of a gather's backward (dp2 of the cost volume: every
+// neighbour row collects the dz1 of the positions that gathered it).  One workgroup owns (sample, 32-channel slab):
+// the slab of dst is accumulated in LDS with ds_add_f32 and written once -- no global atomics, dst needs no zero-fill.
+#define SC_CH 32
+__global__ __launch_bounds__(256) void scatter_rows_kernel(int m, int n, int channels, const int64_t *__restrict__ idx,
+                                                           const float *__restrict__ src, float *__restrict__ dst) {
+    extern __shared__ float s_acc[];                  // [n][SC_CH]
+    const int b = blockIdx.y, c0 = blockIdx.x * SC_CH;
+    for (int e = threadIdx.x; e < n * SC_CH; e += 256) s_acc[e] = 0.f;
+    __syncthreads();
+    const int cl = threadIdx.x & (SC_CH - 1), rsub = threadIdx.x / SC_CH;      // 8 rows per pass
+    const int64_t *ib = idx + (size_t)b * m;
+    const float *sb = src + (size_t)b * m * channels + c0 + cl;
+    for (int r = rsub; r < m; r += 256 / SC_CH) {
+        const int t = (int)ib[r];
+        atomicAdd(&s_acc[t * SC_CH + cl], sb[(size_t)r * channels]);
+    }
+    __syncthreads();
+    float *db = dst + (size_t)b * n * channels + c0;
+    for (int e = threadIdx.x; e < n * SC_CH; e += 256) db[(size_t)(e / SC_CH) * channels + (e % SC_CH)] = s_acc[e];
+}
+
+extern "C" int rtk_scatter_add_rows(int samples, int m, int n, int channels, const int64_t *idx, const float *src, float *dst,
+                                    rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && m > 0 && n > 0 && channels > 0 && channels % SC_CH == 0 && idx && src && dst,
+                "scatter_add_rows: bad arguments (channels must be a multiple of %d)", SC_CH);
+    RTK_REQUIRE((size_t)n * SC_CH * 4 <= 128 * 1024, "scatter_add_rows: n (%d) too large for the LDS slab", n);
+    RTK_REQUIRE(samples <= 65535, "scatter_add_rows: too many samples");
+    const size_t lds = (size_t)n * SC_CH * 4;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        RTK_REQUIRE(e == hipSuccess, "scatter_add_rows: cannot raise the LDS limit: %s", hipGetErrorString(e));
+    }
+    scatter_rows_kernel<<<dim3(channels / SC_CH, samples), 256, lds, (hipStream_t)stream>>>(m, n, channels, idx, src, dst);
+    RTK_CHECK_LAUNCH("scatter_add_rows");
     return RTK_OK;
 }
 

@@ -72,7 +72,10 @@ class Track4D(nn.Module):
         g2 = torch.max(f2, -1)[0].unsqueeze(2).expand(-1, -1, pc2.size(2))
         pc1_features = torch.cat((f1, g1), dim=1)
         pc2_features = torch.cat((f2, g2), dim=1)
-        cor_features = self.fc_layer(pc1, pc2, pc1_features, pc2_features)
+        if tg1 is not None and TP.correlator_supported(self.fc_layer):
+            cor_features = TP.correlator_train(self.fc_layer, pc1, pc2, pc1_features, pc2_features)
+        else:
+            cor_features = self.fc_layer(pc1, pc2, pc1_features, pc2_features)
         output, h, prop_features, cls = self.fd_layer(pc1, feature1, pc1_features, cor_features, h, train_geo=tg1)
         return output, h, cls, cor_features, pc1_features, pc2_features, prop_features
 

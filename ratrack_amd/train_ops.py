@@ -8,10 +8,13 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, fused
 
 _i, _f, _d, _p = ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
+_LayerP = ctypes.POINTER(fused._Layer)
 _lib.SIGNATURES.update({
+    "rtk_cost_volume_bwd": [_i] * 3 + [_p] * 6 + [_LayerP, _LayerP, _p, _i] + [_p] * 8 + [_p],
+    "rtk_scatter_add_rows": [_i] * 4 + [_p] * 3 + [_p],
     "rtk_bn_train_stats": [_i] * 5 + [_p] * 3 + [_p],
     "rtk_bn_train_finalize": [_i, _i, _p, _d, _p, _p, _f, _f, _p, _p, _p, _p, _p],
     "rtk_bn_relu_fwd": [_i] * 5 + [_p, _p, _i, _p, _p],
@@ -81,3 +84,89 @@ def bn_relu(z, bn, row_weight=None, count=None, groups=1, pool=False):
     return _BNReLU.apply(z, bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None,
                          bn.num_batches_tracked if track else None, row_weight, float(count), int(groups), bn.eps, momentum,
                          bool(pool))
+
+
+# ---- cost volume -------------------------------------------------------------------------------------------------------
+
+class _CvWeights:
+    """Packed kernel images of the live cost-volume weights (re-packed every step: the weights are being trained)."""
+
+    def __init__(self, wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, backward):
+        dev = w2.device
+        L = fused._Layer
+        mats = [w2, w3] + ([w3.t(), w2.t()] if backward else [])
+        self.blob = torch.cat([fused.pack_layer(m) for m in mats]).contiguous()
+        self.bias = torch.cat([b2.float(), b3.float()]).contiguous()
+        self.layers = (L * len(mats))()
+        for i in range(len(mats)):
+            self.layers[i].w_packed = self.blob.data_ptr() + 4 * i * 256 * 256
+            self.layers[i].bias = self.bias.data_ptr() + 4 * 256 * min(i, 1)
+            self.layers[i].cin16, self.layers[i].cout16, self.layers[i].act = 16, 16, fused.ACT_LEAKY
+        self.wd = fused.offset_image(torch.cat([wd, torch.zeros(256, 1, device=dev, dtype=wd.dtype)], 1), dev)
+        self.wa = fused.offset_image(torch.cat([wa, ba[:, None]], 1), dev)
+        self.wb, self.bb = fused.pack_layer(wb), fused.pad_bias(bb, 8)
+        self.wc, self.bc = fused.pack_layer(wc), fused.pad_bias(bc, 256)
+        wn = (L * 3)()
+        wn[0].w_packed, wn[0].cin16, wn[0].cout16 = self.wa.data_ptr(), 1, 1
+        wn[1].w_packed, wn[1].bias, wn[1].cin16, wn[1].cout16 = self.wb.data_ptr(), self.bb.data_ptr(), 1, 1
+        wn[2].w_packed, wn[2].bias, wn[2].cin16, wn[2].cout16 = self.wc.data_ptr(), self.bc.data_ptr(), 1, 16
+        self.wn = wn
+
+
+class _CostVolume(torch.autograd.Function):
+    """out[i] = sum_k WeightNet(d_ik) * mlp(p1[i] + p2[knn[i,k]] + Wd d_ik),  d_ik = xyz2[knn[i,k]] - xyz1[i]
+    (utils/model_utils/model_utils.py:216-236 with the first conv split by input segment).  Forward = the inference
+    kernel rtk_cost_volume; backward = rtk_cost_volume_bwd + GEMMs for the weight gradients."""
+
+    @staticmethod
+    def forward(ctx, p1, p2, wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, xyz1, xyz2, knn):
+        B, n1, _ = xyz1.shape
+        n2 = xyz2.shape[1]
+        p1, p2 = p1.contiguous(), p2.contiguous()
+        W = _CvWeights(wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, backward=False)
+        out = torch.empty(B * n1, 256, dtype=torch.float32, device=p1.device)
+        _lib.call("rtk_cost_volume", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
+                  W.wd.data_ptr(), W.layers, W.wn, out.data_ptr(), 256, _stream())
+        ctx.save_for_backward(p1, p2, wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, xyz1, xyz2, knn)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        p1, p2, wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, xyz1, xyz2, knn = ctx.saved_tensors
+        B, n1, _ = xyz1.shape
+        n2 = xyz2.shape[1]
+        dev = p1.device
+        M = B * n1 * 16
+        dout = dout.contiguous()
+        W = _CvWeights(wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, backward=True)
+        big = torch.empty(6, M, 256, dtype=torch.float32, device=dev)
+        a1, a2, dz1, dz2, dz3, dq3 = big.unbind(0)
+        d4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
+        dp1 = torch.empty(B * n1, 256, dtype=torch.float32, device=dev)
+        _lib.call("rtk_cost_volume_bwd", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
+                  W.wd.data_ptr(), W.layers, W.wn, dout.data_ptr(), 256, a1.data_ptr(), a2.data_ptr(), dz1.data_ptr(),
+                  dz2.data_ptr(), dz3.data_ptr(), dq3.data_ptr(), d4.data_ptr(), dp1.data_ptr(), _stream())
+        dp2 = torch.empty(B * n2, 256, dtype=torch.float32, device=dev)
+        _lib.call("rtk_scatter_add_rows", B, n1 * 16, n2, 256, knn.data_ptr(), dz1.data_ptr(), dp2.data_ptr(), _stream())
+        # weight gradients: contractions over the M positions
+        dw3, db3 = torch.mm(dz3.t(), a2), dz3.sum(0)
+        dw2, db2 = torch.mm(dz2.t(), a1), dz2.sum(0)
+        dwd = torch.mm(dz1.t(), d4)[:, :3]
+        # WeightNet 3 -> 8 -> 8 -> 256 (ReLU after every conv): the hidden layers are (M,8) tensors, recomputed here
+        d3 = d4[:, :3]
+        t1 = torch.relu(torch.addmm(ba, d3, wa.t()))
+        t2 = torch.relu(torch.addmm(bb, t1, wb.t()))
+        dwc, dbc = torch.mm(dq3.t(), t2), dq3.sum(0)
+        dt2 = torch.mm(dq3, wc) * (t2 > 0)
+        dwb, dbb = torch.mm(dt2.t(), t1), dt2.sum(0)
+        dt1 = torch.mm(dt2, wb) * (t1 > 0)
+        dwa, dba = torch.mm(dt1.t(), d3), dt1.sum(0)
+        return dp1, dp2, dwd, dw2, db2, dw3, db3, dwa, dba, dwb, dbb, dwc, dbc, None, None, None
+
+
+def cost_volume(p1, p2, wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, xyz1, xyz2, knn):
+    """p1 (B*n1,256) (first-layer bias included), p2 (B*n2,256), wd (256,3), w2/w3 (256,256), b2/b3 (256),
+    WeightNet wa (8,3) ba (8) wb (8,8) bb (8) wc (256,8) bc (256), xyz1 (B,n1,3), xyz2 (B,n2,3), knn (B,n1,16) int64
+    -> (B*n1, 256)."""
+    assert xyz1.is_contiguous() and xyz2.is_contiguous() and knn.is_contiguous() and knn.dtype == torch.int64
+    return _CostVolume.apply(p1, p2, wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, xyz1, xyz2, knn)

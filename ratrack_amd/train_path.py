@@ -21,7 +21,7 @@ import torch
 import torch.nn.functional as F
 
 from . import pointnet2_utils as PU
-from .train_ops import bn_relu
+from .train_ops import bn_relu, cost_volume
 
 
 class TrainGeometry:
@@ -138,3 +138,33 @@ def pnhead_train(head, tg, features, groups=1):
     l2 = _fp(head.fp3, tg, "fp3", l2, l3, tg.row_w[1], S, groups)
     l1 = _fp(head.fp2, tg, "fp2", l1, l2, tg.row_w[0], S, groups)
     return _fp(head.fp1, tg, "fp1", None, l1, None, n, groups)
+
+
+def correlator_supported(fc):
+    return (not fc.bn and fc.nsample == 16 and abs(fc.slope - 0.1) < 1e-12 and len(fc.mlp_convs) == 3
+            and all(c.out_channels == 256 for c in fc.mlp_convs) and not fc.weightnet1.bn)
+
+
+def correlator_train(fc, pc1, pc2, feature1, feature2):
+    """FeatureCorrelator.forward (model_utils.py:166-250) in training mode: the point-to-patch cost volume is one
+    fused operator (forward kernel of the inference engine + its backward kernel); the light patch-to-patch
+    aggregation stays on framework ops.  pc (B,3,N), features (B,D,N) -> (B,256,N1)."""
+    from .model_utils import index_points, knn_point
+    B, C, N1 = pc1.shape
+    x1, x2 = pc1.permute(0, 2, 1).contiguous(), pc2.permute(0, 2, 1).contiguous()
+    f1, f2 = feature1.permute(0, 2, 1), feature2.permute(0, 2, 1)
+    D1, D2 = f1.shape[2], f2.shape[2]
+    knn = knn_point(16, x2, x1).contiguous()
+    conv0, conv1, conv2 = fc.mlp_convs
+    w0 = conv0.weight[:, :, 0, 0]
+    p1 = F.linear(f1, w0[:, :D1], conv0.bias).reshape(B * N1, 256)
+    p2 = F.linear(f2, w0[:, D1:D1 + D2]).reshape(-1, 256)
+    wn = fc.weightnet1.mlp_convs
+    x = cost_volume(p1, p2, w0[:, D1 + D2:], conv1.weight[:, :, 0, 0], conv1.bias, conv2.weight[:, :, 0, 0], conv2.bias,
+                    wn[0].weight[:, :, 0, 0], wn[0].bias, wn[1].weight[:, :, 0, 0], wn[1].bias, wn[2].weight[:, :, 0, 0],
+                    wn[2].bias, x1, x2, knn).view(B, N1, 256)
+    knn = knn_point(16, x1, x1)
+    direction = index_points(x1, knn) - x1.reshape(B, N1, 1, C)
+    w = fc.weightnet2(direction.permute(0, 3, 2, 1))
+    x = index_points(x, knn).permute(0, 3, 2, 1)
+    return torch.sum(w * x, dim=2)

@@ -153,3 +153,47 @@ def test_dedup_train_handles_duplicate_input_points():
     for k in gb:
         assert torch.isfinite(ga[k]).all(), k
         assert float((ga[k] - gb[k]).norm()) <= 1.5e-2 * float(gb[k].norm()) + 1e-5 * gmax, k
+
+
+@pytest.mark.parametrize("B,N", [(2, 256), (3, 77), (1, 1024)])
+def test_cost_volume_operator_matches_module_autograd(B, N):
+    """Fused cost-volume forward + backward kernels against FeatureCorrelator.forward under framework autograd: output,
+    gradients of both feature tensors and of every fc_layer parameter on the path."""
+    from ratrack_amd import train_path as TP
+    torch.manual_seed(3)
+    net = Track4D(Args()).to(DEV)
+    net.load_state_dict(reference_state_dict(DEV), strict=True)
+    fc = net.fc_layer
+    d = synth.make_frame_pairs(B, N, 11)
+    pc1, pc2 = torch.from_numpy(d["pc1"]).to(DEV), torch.from_numpy(d["pc2"]).to(DEV)
+    res = []
+    for fused_op in (True, False):
+        torch.manual_seed(5)
+        f1 = (torch.randn(B, 256, N, device=DEV) * 0.5).requires_grad_(True)
+        f2 = (torch.randn(B, 256, N, device=DEV) * 0.5).requires_grad_(True)
+        fc.zero_grad(set_to_none=True)
+        out = TP.correlator_train(fc, pc1, pc2, f1, f2) if fused_op else fc(pc1, pc2, f1, f2)
+        ct = torch.randn(out.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(7))
+        out.backward(ct)
+        grads = {k: p.grad.detach().clone() for k, p in fc.named_parameters() if p.grad is not None}
+        grads["f1"], grads["f2"] = f1.grad.clone(), f2.grad.clone()
+        res.append((out.detach(), grads))
+    (oa, ga), (ob, gb) = res
+    assert float((oa - ob).abs().max()) <= 1e-4 * float(ob.abs().max())
+    assert set(ga) == set(gb)
+    for k in gb:
+        err, ref = float((ga[k] - gb[k]).norm()), float(gb[k].norm())
+        assert err <= 2e-4 * ref + 1e-7, (k, err, ref)
+
+
+def test_scatter_add_rows_matches_index_add():
+    from ratrack_amd import _lib, train_ops  # noqa: F401
+    B, m, n, C = 3, 1000, 77, 64
+    g = torch.Generator(DEV).manual_seed(1)
+    idx = torch.randint(0, n, (B, m), device=DEV, generator=g)
+    src = torch.randn(B, m, C, device=DEV, generator=g)
+    dst = torch.full((B, n, C), float("nan"), device=DEV)
+    _lib.call("rtk_scatter_add_rows", B, m, n, C, idx.data_ptr(), src.data_ptr(), dst.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    ref = torch.zeros(B, n, C, device=DEV, dtype=torch.float64)
+    ref.scatter_add_(1, idx.unsqueeze(-1).expand(-1, -1, C), src.double())
+    assert torch.allclose(dst.double(), ref, rtol=1e-5, atol=1e-5)
