@@ -74,7 +74,7 @@ def bench_train(a, net, d, dev, dist, world, rank):
     from ratrack_amd.ddp import broadcast_parameters
     from ratrack_amd.train import Trainer
     broadcast_parameters(net)
-    tr = Trainer(net)
+    tr = Trainer(net, graph=not a.no_graph)
     t = {k: torch.from_numpy(v).to(dev) for k, v in d.items()}
     h = torch.zeros(5, a.batch, 128, device=dev)
     step = lambda: tr.step(t["pc1"], t["pc2"], t["feature1"], t["feature2"], t["gt_warp"], t["gt_cls"], h)
@@ -101,8 +101,8 @@ def bench_train(a, net, d, dev, dist, world, rank):
             "metric": "radar frame-pairs/sec (train step) at B=%d,N=%d per GPU" % (a.batch, a.npoints), "value": round(pairs, 1),
             "unit": "frame-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Track4D.backbone train step (fwd+loss+bwd+grad all-reduce+Adam), B=%d x N=%d per GPU, module path"
-                                   % (a.batch, a.npoints), "global_batch": a.batch * world,
+            "config": {"workload": "Track4D.backbone train step (fwd+loss+bwd+grad all-reduce+Adam), B=%d x N=%d per GPU, hipGraph=%s"
+                                   % (a.batch, a.npoints, not a.no_graph), "global_batch": a.batch * world,
                        "parallelism": "dp%d, one flat RCCL all-reduce of %d bytes per step" % (world, tr.reducer.payload_bytes)},
             "roofline": None, "cpu_baseline": None}), flush=True)
     if dist is not None:

@@ -28,6 +28,8 @@ class FlatGradAllReducer:
         self.names = None
         self.params = None
         self.flat = None
+        self.views = None
+        self.always_pack = False      # tests: exercise the packing path in a single process
 
     def _build(self):
         named = [(n, p) for n, p in self.module.named_parameters() if p.requires_grad and p.grad is not None]
@@ -36,6 +38,10 @@ class FlatGradAllReducer:
         total = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
         if self.world > 1:
             # every rank must have built the same bucket: compare a digest of (name, numel) lists
             digest = hashlib.sha1(repr([(n, p.numel()) for n, p in named]).encode()).digest()[:8]
@@ -51,29 +57,24 @@ class FlatGradAllReducer:
         return 0 if self.flat is None else self.flat.numel() * 4
 
     def reduce(self):
-        """Average the gradients over the ranks in place.  Call after backward(), before optimizer.step()."""
+        """Average the gradients over the ranks in place.  Call after backward(), before optimizer.step().
+        Single process: nothing to exchange, the gradients stay where autograd put them.  Otherwise the live gradients
+        are packed into the flat bucket with one multi-tensor copy, all-reduced once, and the parameters' .grad are
+        re-pointed at the bucket's slices (no copy back)."""
+        if self.world == 1 and not self.always_pack:
+            return
         if self.flat is None:
             self._build()
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            g = p.grad
-            if g is None:       # parameter lost its gradient this step (e.g. pre-training without the flow term): zeros
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(g.reshape(-1))
-            off += n
+        missing = [i for i, p in enumerate(self.params) if p.grad is None]
+        for i in missing:      # parameter lost its gradient this step (e.g. pre-training without the flow term): zeros
+            self.views[i].zero_()
+        live = [i for i, p in enumerate(self.params) if p.grad is not None]
+        torch._foreach_copy_([self.views[i] for i in live], [self.params[i].grad for i in live])
         if self.world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.div_(self.world)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                p.grad = self.flat[off:off + n].view_as(p).clone()
-            else:
-                p.grad.copy_(self.flat[off:off + n].view_as(p))
-            off += n
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
 
 def broadcast_parameters(module, src=0, process_group=None):

@@ -8,27 +8,64 @@ from . import loss as L
 from .ddp import FlatGradAllReducer
 
 
-def make_optimizer(model, lr=1e-3):
+def make_optimizer(model, lr=1e-3, capturable=False):
     """Adam(lr=1e-3, weight_decay=1e-10) + StepLR(step=1, gamma=0.97) as main.py:61-62."""
-    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=1e-10)
+    if capturable:      # a device-resident learning rate: the scheduler updates it in place, the captured graph reads it
+        lr = torch.tensor(float(lr), device=next(model.parameters()).device)
+    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=1e-10, capturable=capturable)
     sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.97)
     return opt, sched
 
 
 class Trainer:
-    def __init__(self, model, lr=1e-3, process_group=None):
-        self.model = model
-        self.opt, self.sched = make_optimizer(model, lr)
-        self.reducer = FlatGradAllReducer(model, process_group)
+    """graph=True: after `graph_warmup` eager steps the whole step (forward, loss, backward, gradient all-reduce, Adam) is
+    captured into ONE hipGraph and replayed; the batch is copied into static input buffers.  The step issues ~2500
+    kernels whose CPU launch cost rivals their GPU time at B=64; a replay is a single launch.  Shapes must then stay
+    fixed (the reference trains on fixed-size clouds, configs.yaml num_points) -- a different shape re-captures."""
 
-    def step(self, pc1, pc2, feature1, feature2, gt_warp, gt_cls, h=None, pretrain=False):
-        """One optimisation step on this rank's shard.  Returns the loss items (python floats are NOT taken here:
-        no device->host sync inside the step)."""
-        self.model.train()
+    def __init__(self, model, lr=1e-3, process_group=None, graph=False, graph_warmup=3):
+        self.model = model
+        self.opt, self.sched = make_optimizer(model, lr, capturable=graph)
+        self.reducer = FlatGradAllReducer(model, process_group)
+        self.graph = graph
+        self._warm = graph_warmup
+        self._g = None
+        self._static = None
+        self._key = None
+
+    def _step(self, pc1, pc2, feature1, feature2, gt_warp, gt_cls, h, pretrain):
         flow, h_out, cls, *_ = self.model.backbone(pc1, pc2, feature1, feature2, h)
         total, items = L.backbone_loss(pc1 + flow, cls, gt_warp, gt_cls, pretrain=pretrain)
         self.opt.zero_grad(set_to_none=True)
         total.backward()
         self.reducer.reduce()
         self.opt.step()
-        return items, h_out.detach()
+        # detached: a caller holding last step's loss must not keep its autograd graph (and the parameters' gradient
+        # accumulators, bound to the stream of that step) alive into the next step / into the graph capture
+        return {k: v.detach() for k, v in items.items()}, h_out.detach()
+
+    def step(self, pc1, pc2, feature1, feature2, gt_warp, gt_cls, h=None, pretrain=False):
+        """One optimisation step on this rank's shard.  Returns the loss items (python floats are NOT taken here:
+        no device->host sync inside the step)."""
+        self.model.train()
+        args = [pc1, pc2, feature1, feature2, gt_warp, gt_cls, h]
+        if not self.graph:
+            return self._step(*args, pretrain)
+        key = tuple((tuple(t.shape), t.dtype) if t is not None else None for t in args) + (bool(pretrain),)
+        if key != self._key:
+            self._key, self._g, self._count = key, None, 0
+        if self._g is None and self._count < self._warm:      # eager warm-up (MIOpen finds its kernels, the bucket is built)
+            self._count += 1
+            return self._step(*args, pretrain)
+        if self._g is None:
+            self._static = [t.clone() if t is not None else None for t in args]
+            torch.cuda.synchronize()
+            self._g = torch.cuda.CUDAGraph()
+            self.opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(self._g):
+                self._out = self._step(*self._static, pretrain)
+        for dst, src in zip(self._static, args):
+            if dst is not None:
+                dst.copy_(src)
+        self._g.replay()
+        return self._out

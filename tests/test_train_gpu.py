@@ -197,3 +197,44 @@ def test_scatter_add_rows_matches_index_add():
     ref = torch.zeros(B, n, C, device=DEV, dtype=torch.float64)
     ref.scatter_add_(1, idx.unsqueeze(-1).expand(-1, -1, C), src.double())
     assert torch.allclose(dst.double(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_graphed_trainer_matches_eager():
+    """Trainer(graph=True): 3 eager warm-up steps, capture, replays.  With lr = 0 (parameters frozen, everything else live)
+    the captured step must reproduce the eager losses and BatchNorm running statistics on every batch -- the static input
+    buffers, the geometry and every kernel are replayed correctly.  With lr = 1e-3 the replayed optimizer moves the
+    parameters as far as the eager one (the trajectories themselves are chaotic: Adam's first steps are sign-like, and
+    float atomics make even two eager runs differ by 1e-3 after a few steps)."""
+    from ratrack_amd.train import Trainer
+    B, N = 2, 256
+    batches = []
+    for i in range(6):
+        d = synth.make_frame_pairs(B, N, 20 + i)
+        batches.append({k: torch.from_numpy(v).to(DEV) for k, v in d.items()})
+
+    def run(graph, lr):
+        net = Track4D(Args()).to(DEV)
+        net.load_state_dict(reference_state_dict(DEV), strict=True)
+        init = {k: v.detach().clone() for k, v in net.named_parameters()}
+        tr = Trainer(net, graph=graph, lr=lr)
+        h = torch.zeros(5, B, 128, device=DEV)
+        losses = []
+        for t in batches:
+            items, _ = tr.step(t["pc1"], t["pc2"], t["feature1"], t["feature2"], t["gt_warp"], t["gt_cls"], h)
+            losses.append(float(items["Loss"]))
+        moved = float(torch.sqrt(sum(((p.detach() - init[k]) ** 2).sum() for k, p in net.named_parameters())))
+        return losses, {k: v.detach().clone() for k, v in net.state_dict().items()}, moved
+
+    la, sa, _ = run(False, 0.0)
+    lb, sb, _ = run(True, 0.0)
+    np.testing.assert_allclose(lb, la, rtol=1e-5)
+    for k, v in sa.items():
+        if "running_" in k:
+            assert float((sb[k] - v).abs().max()) <= 1e-5 * float(v.abs().max()) + 1e-7, k
+        elif "num_batches" in k:
+            assert torch.equal(sb[k], v), k
+    lc, _, moved_e = run(False, 1e-3)
+    ld, _, moved_g = run(True, 1e-3)
+    assert np.isfinite(ld).all() and moved_g > 0
+    assert abs(moved_g - moved_e) <= 0.05 * moved_e, (moved_g, moved_e)
+    np.testing.assert_allclose(ld[:3], lc[:3], rtol=1e-3)          # the eager warm-up steps
