@@ -61,19 +61,25 @@ RTK_EXPORT int rtk_bn_relu_bwd_apply(int samples, int channels, int rows, int ns
 
 /* ---- cost volume (utils/model_utils/model_utils.py:216-236) ------------------------------------------------------
  * Backward of rtk_cost_volume (rtk_fused.h; same forward arguments).  layers[0..3] = the packed 256x256 layers
- * W2, W3, W3^T, W2^T, contiguous in memory (biases of W2, W3 in layers[0], layers[1]).  dout (samples*n1, dout_pitch)
- * is the gradient of the forward output.  Outputs, all caller-allocated, M = samples*n1*16 positions (query-major,
+ * W2, W3, W3^T, W2^T, contiguous in memory (biases of W2, W3 in layers[0], layers[1]); wct_packed = the packed
+ * transpose of the WeightNet's last layer (8 x 256 -> [16][1] fragments).  dout (samples*n1, dout_pitch) is the
+ * gradient of the forward output.  Outputs, all caller-allocated, M = samples*n1*16 positions (query-major,
  * neighbour minor):
- *   a1, a2 (M,256)   recomputed activations of layers 1 and 2            (operands of dW2 = dz2^T a1, dW3 = dz3^T a2)
- *   dz1, dz2, dz3 (M,256)  gradients of the three pre-activations        (db = column sums; dWd = dz1^T d4[:, :3])
- *   dq3 (M,256)      gradient of the WeightNet's last pre-activation
+ *   a1, a2 (M, act_pitch)  recomputed activations of layers 1 and 2; with act_pitch > 256 column 256 is set to 1 and
+ *                    columns 257..259 to 0 (the rest of the padding is not written), so that ONE product
+ *                    dz^T [a | 1] yields the weight and the bias gradient (dW2|db2 = dz2^T a1, dW3|db3 = dz3^T a2)
+ *   dz1, dz2, dz3 (M,256)  gradients of the three pre-activations
+ *   dq3 (M,256)      gradient of the WeightNet's last pre-activation  (dWc|dbc = dq3^T [t2 | 1])
+ *   dt2 (M,8)        Wc^T dq3: gradient of the WeightNet's second hidden activation (before its ReLU mask)
  *   d4 (M,4)         (neighbour - query, 1) of every position
- *   dp1 (samples*n1, 256)  gradient of p1 (= sum of dz1 over the 16 neighbours).
+ *   dp1 (samples*n1, 256)     gradient of p1 = sum of dz1 over the 16 neighbours
+ *   dpd (samples*n1, 3, 256)  per-query partial sums of dz1 x direction; dWd[c][k] = sum over queries of dpd[q][k][c].
  * The gradient of p2 is rtk_scatter_add_rows(knn_idx, dz1). */
 RTK_EXPORT int rtk_cost_volume_bwd(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
                                    const float *p1, const float *p2, const float *wd_packed, const rtk_layer_t *layers,
-                                   const rtk_layer_t *wn, const float *dout, int dout_pitch, float *a1, float *a2, float *dz1,
-                                   float *dz2, float *dz3, float *dq3, float *d4, float *dp1, rtk_stream_t stream);
+                                   const rtk_layer_t *wn, const float *wct_packed, const float *dout, int dout_pitch,
+                                   int act_pitch, float *a1, float *a2, float *dz1, float *dz2, float *dz3, float *dq3,
+                                   float *d4, float *dp1, float *dpd, float *dt2, rtk_stream_t stream);
 
 /* dst[b][idx[b][r]][:] += src[b][r][:] for r < m, dst (samples, n, channels) fully written (no zero-fill needed):
  * the scatter half of the backward of a row gather.  idx (samples, m) int64 in [0, n); channels % 32 == 0;

@@ -348,7 +348,9 @@ struct CvBwdParams {
     CvParams f;                   // forward arguments; f.blob holds 4 layers: W2, W3, W3^T, W2^T
     const float *dout;
     int dout_pitch;
-    float *a1, *a2, *dz1, *dz2, *dz3, *dq3, *d4, *dp1;
+    int act_pitch;                // row pitch of a1 / a2 (>= 256; column 256 receives 1.0 when act_pitch > 256)
+    const f4 *wct;                // packed Wc^T (WeightNet last layer transposed): [16][1] fragments
+    float *a1, *a2, *dz1, *dz2, *dz3, *dq3, *d4, *dp1, *dpd, *dt2;
 };
 
 __device__ __forceinline__ f4 leaky_grad(f4 d, f4 a) {     // d * leaky'(z), the sign of z read off a = leaky(z)
@@ -358,6 +360,10 @@ __device__ __forceinline__ f4 leaky_grad(f4 d, f4 a) {     // d * leaky'(z), the
     r.z = a.z > 0.f ? d.z : 0.1f * d.z;
     r.w = a.w > 0.f ? d.w : 0.1f * d.w;
     return r;
+}
+
+__device__ __forceinline__ f4 *cv_at(float *base, unsigned byte_off) {
+    return reinterpret_cast<f4 *>(reinterpret_cast<char *>(base) + byte_off);
 }
 
 __global__ __launch_bounds__(64 * CV_NW, (CV_NW * CV_WGS_PER_CU) / 4) void cost_volume_bwd_kernel(const CvBwdParams Q) {
@@ -379,8 +385,18 @@ __global__ __launch_bounds__(64 * CV_NW, (CV_NW * CV_WGS_PER_CU) / 4) void cost_
         const long nb = (long)b * P.n2 + (long)P.knn[i * 16 + j];
         const float bop = g < 3 ? __fsub_rn(P.xyz2[nb * 3 + g], P.xyz1[i * 3 + g]) : 1.0f;
         const long pos = i * 16 + j;                                     // row of the materialised (position, 256) tensors
-        const long ro = pos * 256 + 4 * g;
-        if (valid) Q.d4[pos * 4 + g] = bop;
+        // byte offsets of this lane's 16-byte slot in a (position, 256) / (position, act_pitch) row: one 32-bit VGPR each,
+        // added to the tensors' uniform base pointers (SGPR-base addressing; 64-bit per-tensor addresses would spill)
+        const unsigned ro = (unsigned)pos * 1024u + 16u * g;
+        const unsigned ra = (unsigned)pos * (4u * Q.act_pitch) + 16u * g;   // a1 / a2 rows carry a trailing ones column
+        if (valid) {
+            Q.d4[pos * 4 + g] = bop;
+            if (Q.act_pitch > 256 && g == 0) {
+                const f4 one = {1.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f4 *>(Q.a1 + pos * Q.act_pitch + 256) = one;
+                *reinterpret_cast<f4 *>(Q.a2 + pos * Q.act_pitch + 256) = one;
+            }
+        }
         // ---- forward recompute ---------------------------------------------------------------------------------------
         f4 h[CV_V];
         {
@@ -394,7 +410,7 @@ __global__ __launch_bounds__(64 * CV_NW, (CV_NW * CV_WGS_PER_CU) / 4) void cost_
         }
         if (valid) {
 #pragma unroll
-            for (int v = 0; v < CV_V; ++v) *reinterpret_cast<f4 *>(Q.a1 + ro + 16 * v) = h[v];
+            for (int v = 0; v < CV_V; ++v) *cv_at(Q.a1, ra + 64u * v) = h[v];
         }
         f4 a[CV_V];
 #pragma unroll
@@ -403,7 +419,7 @@ __global__ __launch_bounds__(64 * CV_NW, (CV_NW * CV_WGS_PER_CU) / 4) void cost_
         apply_act<CV_V>(a, RTK_ACT_LEAKY);
         if (valid) {
 #pragma unroll
-            for (int v = 0; v < CV_V; ++v) *reinterpret_cast<f4 *>(Q.a2 + ro + 16 * v) = a[v];
+            for (int v = 0; v < CV_V; ++v) *cv_at(Q.a2, ra + 64u * v) = a[v];
         }
 #pragma unroll
         for (int v = 0; v < CV_V; ++v) h[v] = bias_frag(P.bias3, v, g);
@@ -412,6 +428,7 @@ __global__ __launch_bounds__(64 * CV_NW, (CV_NW * CV_WGS_PER_CU) / 4) void cost_
         // ---- out = sum_k wn * a3:  dz3 = dout wn leaky'(z3),  dq3 = dout a3 [wn > 0] ---------------------------------
         const f4 t2 = weightnet_hidden(P.wn, lane, g, bop);
         const float *dor = Q.dout + i * Q.dout_pitch + 4 * g;
+        f4 dt2 = f4_zero();                                              // Wc^T dq3: gradient of the WeightNet's hidden layer
 #pragma unroll
         for (int v = 0; v < CV_V; ++v) {
             const f4 w = weightnet_out(P.wn, lane, g, v, t2);
@@ -422,20 +439,27 @@ __global__ __launch_bounds__(64 * CV_NW, (CV_NW * CV_WGS_PER_CU) / 4) void cost_
             q.z = w.z > 0.f ? d.z * h[v].z : 0.f;
             q.w = w.w > 0.f ? d.w * h[v].w : 0.f;
             h[v] = leaky_grad(d * w, h[v]);
+            const f4 ft = Q.wct[v * 64 + lane];
+            dt2 = mfma4(ft.x, q.x, dt2);
+            dt2 = mfma4(ft.y, q.y, dt2);
+            dt2 = mfma4(ft.z, q.z, dt2);
+            dt2 = mfma4(ft.w, q.w, dt2);
             if (valid) {
-                *reinterpret_cast<f4 *>(Q.dq3 + ro + 16 * v) = q;
-                *reinterpret_cast<f4 *>(Q.dz3 + ro + 16 * v) = h[v];
+                *cv_at(Q.dq3, ro + 64u * v) = q;
+                *cv_at(Q.dz3, ro + 64u * v) = h[v];
             }
+            __builtin_amdgcn_sched_barrier(0);      // keep the 16 iterations' global loads from being hoisted together (spills)
         }
+        if (valid && g < 2) *reinterpret_cast<f4 *>(Q.dt2 + pos * 8 + 4 * g) = dt2;     // 8 hidden units
         // ---- da2 = W3^T dz3;  dz2 = da2 leaky'(z2) ---------------------------------------------------------------------
 #pragma unroll
         for (int v = 0; v < CV_V; ++v) a[v] = f4_zero();
         mlp_layer_ws<CV_V, CV_V, 2 * L>(ws, h, a);
 #pragma unroll
         for (int v = 0; v < CV_V; ++v) {
-            const f4 act = *reinterpret_cast<const f4 *>(Q.a2 + ro + 16 * v);     // this lane's own store, above
+            const f4 act = *cv_at(Q.a2, ra + 64u * v);     // this lane's own store, above
             a[v] = leaky_grad(a[v], act);
-            if (valid) *reinterpret_cast<f4 *>(Q.dz2 + ro + 16 * v) = a[v];
+            if (valid) *cv_at(Q.dz2, ro + 64u * v) = a[v];
         }
         // ---- da1 = W2^T dz2;  dz1 = da1 leaky'(z1);  dp1 = sum over the 16 neighbours ----------------------------------
 #pragma unroll
@@ -445,11 +469,31 @@ __global__ __launch_bounds__(64 * CV_NW, (CV_NW * CV_WGS_PER_CU) / 4) void cost_
         float *dpr = Q.dp1 + i * 256 + 4 * g;
 #pragma unroll
         for (int v = 0; v < CV_V; ++v) {
-            const f4 act = *reinterpret_cast<const f4 *>(Q.a1 + ro + 16 * v);
+            const f4 act = *cv_at(Q.a1, ra + 64u * v);
             f4 r = leaky_grad(h[v], act);
-            if (valid) *reinterpret_cast<f4 *>(Q.dz1 + ro + 16 * v) = r;
+            if (valid) *cv_at(Q.dz1, ro + 64u * v) = r;
             row_sum16_f4(r);
             if (valid && j == 0) *reinterpret_cast<f4 *>(dpr + 16 * v) = r;
+        }
+        // per-query partials of dWd = dz1^T d, in a second sweep over this lane's own dz1 stores (the activation registers
+        // are dead by now; doing it in the loop above spills).  Direction components of position j are held by lanes
+        // (0,j), (1,j), (2,j) as their MFMA B operand.
+        if (valid) {
+            float *dpd = Q.dpd + i * 768 + 4 * g;
+            const float dx = __shfl(bop, j, 64), dy = __shfl(bop, 16 + j, 64), dzc = __shfl(bop, 32 + j, 64);
+#pragma unroll 4
+            for (int v = 0; v < CV_V; ++v) {
+                const f4 r = *cv_at(Q.dz1, ro + 64u * v);
+                f4 rx = r * dx, ry = r * dy, rz = r * dzc;
+                row_sum16_f4(rx);
+                row_sum16_f4(ry);
+                row_sum16_f4(rz);
+                if (j == 0) {
+                    *reinterpret_cast<f4 *>(dpd + 16 * v) = rx;
+                    *reinterpret_cast<f4 *>(dpd + 256 + 16 * v) = ry;
+                    *reinterpret_cast<f4 *>(dpd + 512 + 16 * v) = rz;
+                }
+            }
         }
     }
     ws.finish();
@@ -457,10 +501,14 @@ __global__ __launch_bounds__(64 * CV_NW, (CV_NW * CV_WGS_PER_CU) / 4) void cost_
 
 extern "C" int rtk_cost_volume_bwd(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
                                    const float *p1, const float *p2, const float *wd_packed, const rtk_layer_t *layers,
-                                   const rtk_layer_t *wn, const float *dout, int dout_pitch, float *a1, float *a2, float *dz1,
-                                   float *dz2, float *dz3, float *dq3, float *d4, float *dp1, rtk_stream_t stream) {
+                                   const rtk_layer_t *wn, const float *wct_packed, const float *dout, int dout_pitch,
+                                   int act_pitch, float *a1, float *a2, float *dz1, float *dz2, float *dz3, float *dq3,
+                                   float *d4, float *dp1, float *dpd, float *dt2, rtk_stream_t stream) {
     RTK_REQUIRE(samples > 0 && n1 > 0 && n2 >= 16 && xyz1 && xyz2 && knn_idx && p1 && p2 && wd_packed && layers && dout && a1 &&
-                a2 && dz1 && dz2 && dz3 && dq3 && d4 && dp1, "cost_volume_bwd: bad arguments");
+                a2 && dz1 && dz2 && dz3 && dq3 && d4 && dp1 && dpd && dt2 && wct_packed, "cost_volume_bwd: bad arguments");
+    RTK_REQUIRE(act_pitch == 256 || (act_pitch >= 260 && act_pitch % 4 == 0), "cost_volume_bwd: bad act_pitch %d", act_pitch);
+    RTK_REQUIRE((double)samples * n1 * 16.0 * 4.0 * act_pitch < 4294967296.0, "cost_volume_bwd: more than 4 GiB per materialised tensor "
+                "(32-bit row offsets): split the batch");
     for (int l = 0; l < 4; ++l)
         RTK_REQUIRE(layers[l].cin16 == 16 && layers[l].cout16 == 16 && layers[l].w_packed == layers[0].w_packed + (size_t)l * 256 * 256,
                     "cost_volume_bwd: expects four contiguous 256x256 layers (W2, W3, W3^T, W2^T)");
@@ -476,7 +524,8 @@ extern "C" int rtk_cost_volume_bwd(int samples, int n1, int n2, const float *xyz
     RTK_REQUIRE(wn[2].cout16 == 16, "cost_volume_bwd: WeightNet must produce 256 channels");
     P.out = nullptr; P.out_pitch = 0;
     Q.dout = dout; Q.dout_pitch = dout_pitch;
-    Q.a1 = a1; Q.a2 = a2; Q.dz1 = dz1; Q.dz2 = dz2; Q.dz3 = dz3; Q.dq3 = dq3; Q.d4 = d4; Q.dp1 = dp1;
+    Q.act_pitch = act_pitch; Q.wct = reinterpret_cast<const f4 *>(wct_packed);
+    Q.a1 = a1; Q.a2 = a2; Q.dz1 = dz1; Q.dz2 = dz2; Q.dz3 = dz3; Q.dq3 = dq3; Q.d4 = d4; Q.dp1 = dp1; Q.dpd = dpd; Q.dt2 = dt2;
     const int groups = (n1 + CV_NW - 1) / CV_NW;
     int gx = 256 * CV_WGS_PER_CU / samples;
     if (gx < 1) gx = 1;

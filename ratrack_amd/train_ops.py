@@ -13,7 +13,7 @@ from . import _lib, fused
 _i, _f, _d, _p = ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 _LayerP = ctypes.POINTER(fused._Layer)
 _lib.SIGNATURES.update({
-    "rtk_cost_volume_bwd": [_i] * 3 + [_p] * 6 + [_LayerP, _LayerP, _p, _i] + [_p] * 8 + [_p],
+    "rtk_cost_volume_bwd": [_i] * 3 + [_p] * 6 + [_LayerP, _LayerP, _p, _p, _i, _i] + [_p] * 10 + [_p],
     "rtk_scatter_add_rows": [_i] * 4 + [_p] * 3 + [_p],
     "rtk_bn_train_stats": [_i] * 5 + [_p] * 3 + [_p],
     "rtk_bn_train_finalize": [_i, _i, _p, _d, _p, _p, _f, _f, _p, _p, _p, _p, _p],
@@ -113,6 +113,18 @@ class _CvWeights:
         self.wn = wn
 
 
+def _tall_tn(a, b):
+    """a^T b for tall-skinny a (M,p), b (M,q) with M >> p, q: the (p,q) output is a handful of GEMM tiles, so a plain mm
+    walks the M dimension in one or two workgroups.  Split M into up to 256 slabs (batched GEMM), then add the slabs."""
+    M = a.shape[0]
+    c = 256
+    while M % c:
+        c //= 2
+    if c == 1:
+        return torch.mm(a.t(), b)
+    return torch.bmm(a.view(c, M // c, -1).transpose(1, 2), b.view(c, M // c, -1)).sum(0)
+
+
 class _CostVolume(torch.autograd.Function):
     """out[i] = sum_k WeightNet(d_ik) * mlp(p1[i] + p2[knn[i,k]] + Wd d_ik),  d_ik = xyz2[knn[i,k]] - xyz1[i]
     (utils/model_utils/model_utils.py:216-236 with the first conv split by input segment).  Forward = the inference
@@ -139,28 +151,40 @@ class _CostVolume(torch.autograd.Function):
         M = B * n1 * 16
         dout = dout.contiguous()
         W = _CvWeights(wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, backward=True)
-        big = torch.empty(6, M, 256, dtype=torch.float32, device=dev)
-        a1, a2, dz1, dz2, dz3, dq3 = big.unbind(0)
+        AP = 272                                                   # a1 / a2 rows: 256 activations + a ones column (+ padding)
+        acts = torch.empty(2, M, AP, dtype=torch.float32, device=dev)
+        acts[:, :, 256:].zero_()
+        a1, a2 = acts.unbind(0)
+        big = torch.empty(4, M, 256, dtype=torch.float32, device=dev)
+        dz1, dz2, dz3, dq3 = big.unbind(0)
         d4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
+        dt2 = torch.empty(M, 8, dtype=torch.float32, device=dev)
         dp1 = torch.empty(B * n1, 256, dtype=torch.float32, device=dev)
+        dpd = torch.empty(B * n1, 3, 256, dtype=torch.float32, device=dev)
+        wct = fused.pack_layer(wc.t())
         _lib.call("rtk_cost_volume_bwd", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
-                  W.wd.data_ptr(), W.layers, W.wn, dout.data_ptr(), 256, a1.data_ptr(), a2.data_ptr(), dz1.data_ptr(),
-                  dz2.data_ptr(), dz3.data_ptr(), dq3.data_ptr(), d4.data_ptr(), dp1.data_ptr(), _stream())
+                  W.wd.data_ptr(), W.layers, W.wn, wct.data_ptr(), dout.data_ptr(), 256, AP, a1.data_ptr(), a2.data_ptr(),
+                  dz1.data_ptr(), dz2.data_ptr(), dz3.data_ptr(), dq3.data_ptr(), d4.data_ptr(), dp1.data_ptr(), dpd.data_ptr(),
+                  dt2.data_ptr(), _stream())
         dp2 = torch.empty(B * n2, 256, dtype=torch.float32, device=dev)
         _lib.call("rtk_scatter_add_rows", B, n1 * 16, n2, 256, knn.data_ptr(), dz1.data_ptr(), dp2.data_ptr(), _stream())
-        # weight gradients: contractions over the M positions
-        dw3, db3 = torch.mm(dz3.t(), a2), dz3.sum(0)
-        dw2, db2 = torch.mm(dz2.t(), a1), dz2.sum(0)
-        dwd = torch.mm(dz1.t(), d4)[:, :3]
+        # weight gradients: contractions over the M positions; the ones column of a1 / a2 yields the bias gradients
+        g3 = torch.mm(dz3.t(), a2)
+        dw3, db3 = g3[:, :256], g3[:, 256]
+        g2 = torch.mm(dz2.t(), a1)
+        dw2, db2 = g2[:, :256], g2[:, 256]
+        dwd = dpd.sum(0).t()
         # WeightNet 3 -> 8 -> 8 -> 256 (ReLU after every conv): the hidden layers are (M,8) tensors, recomputed here
         d3 = d4[:, :3]
         t1 = torch.relu(torch.addmm(ba, d3, wa.t()))
         t2 = torch.relu(torch.addmm(bb, t1, wb.t()))
-        dwc, dbc = torch.mm(dq3.t(), t2), dq3.sum(0)
-        dt2 = torch.mm(dq3, wc) * (t2 > 0)
-        dwb, dbb = torch.mm(dt2.t(), t1), dt2.sum(0)
+        t2p = torch.cat([t2, torch.ones(M, 1, dtype=torch.float32, device=dev), torch.zeros(M, 7, dtype=torch.float32, device=dev)], 1)
+        gc = _tall_tn(dq3, t2p)
+        dwc, dbc = gc[:, :8], gc[:, 8]
+        dt2 = dt2 * (t2 > 0)
+        dwb, dbb = _tall_tn(dt2, t1), dt2.sum(0)
         dt1 = torch.mm(dt2, wb) * (t1 > 0)
-        dwa, dba = torch.mm(dt1.t(), d3), dt1.sum(0)
+        dwa, dba = _tall_tn(dt1, d3), dt1.sum(0)
         return dp1, dp2, dwd, dw2, db2, dw3, db3, dwa, dba, dwb, dbb, dwc, dbc, None, None, None
 
 
@@ -170,3 +194,34 @@ def cost_volume(p1, p2, wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, xyz1, xyz2, 
     -> (B*n1, 256)."""
     assert xyz1.is_contiguous() and xyz2.is_contiguous() and knn.is_contiguous() and knn.dtype == torch.int64
     return _CostVolume.apply(p1, p2, wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, xyz1, xyz2, knn)
+
+
+# ---- 1x1 convolution with a GEMM weight gradient ----------------------------------------------------------------------
+
+class _Conv1x1(torch.autograd.Function):
+    """z = W x for x (S,Cin,rows,ns) NCHW, W (Cout,Cin,1,1).  Forward and input gradient are the framework's convolution;
+    the WEIGHT gradient dW = sum_b dz_b x_b^T contracts over the positions, which are the contiguous axis of both NCHW
+    operands -- a batched NT GEMM as is.  (MIOpen's backward-weights path first transposes both tensors to NHWC, which
+    costs more than the contraction for these narrow layers.)"""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return torch.nn.functional.conv2d(x, w)
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w = ctx.saved_tensors
+        dz = dz.contiguous()
+        S_, Co = dz.shape[:2]
+        Ci = x.shape[1]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.nn.grad.conv2d_input(x.shape, w, dz)      # (a broadcast GEMM W^T dz_b was measured slower)
+        if ctx.needs_input_grad[1]:
+            dw = torch.bmm(dz.view(S_, Co, -1), x.reshape(S_, Ci, -1).transpose(1, 2)).sum(0).view_as(w)
+        return dx, dw
+
+
+def conv1x1(x, w):
+    return _Conv1x1.apply(x, w)

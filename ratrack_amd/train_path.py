@@ -21,7 +21,7 @@ import torch
 import torch.nn.functional as F
 
 from . import pointnet2_utils as PU
-from .train_ops import bn_relu, cost_volume
+from .train_ops import bn_relu, conv1x1, cost_volume
 
 
 class TrainGeometry:
@@ -100,12 +100,12 @@ def _sa_scale(mlp, tg, lvl, s, feats, groups):
     idx = tg.ball[lvl][s]
     ns = idx.shape[2]
     count = (tg.samples // groups) * tg.npoint * ns
-    proj = F.conv1d(feats, w[:, 3:, 0, :])                        # per-POINT projection (a 1x1 conv and a gather commute)
-    z = F.conv2d(tg.dxyz[lvl][s], w[:, :3]) + PU.grouping_operation(proj.contiguous(), idx)
+    proj = conv1x1(feats.unsqueeze(-1), w[:, 3:]).squeeze(-1)     # per-POINT projection (a 1x1 conv and a gather commute)
+    z = conv1x1(tg.dxyz[lvl][s], w[:, :3]) + PU.grouping_operation(proj, idx)
     x = None
     for i, layer in enumerate(layers):
         if i > 0:
-            z = F.conv2d(x, layer.conv.weight)
+            z = conv1x1(x, layer.conv.weight)
         x = bn_relu(z, layer.bn.bn, tg.row_w[lvl], count, groups, pool=(i == len(layers) - 1))
     return x                                                      # (S_, C_out, U)
 
@@ -118,7 +118,7 @@ def _fp(fp, tg, name, skip, known_feats, row_w, count_rows, groups):
     layers = list(fp.mlp.children())
     x = x.unsqueeze(-1)
     for layer in layers:
-        z = F.conv2d(x, layer.conv.weight)
+        z = conv1x1(x, layer.conv.weight)
         x = bn_relu(z, layer.bn.bn, row_w, (tg.samples // groups) * count_rows, groups)
     return x.squeeze(-1)
 
@@ -126,7 +126,8 @@ def _fp(fp, tg, name, skip, known_feats, row_w, count_rows, groups):
 def pnhead_train(head, tg, features, groups=1):
     """PNHead.forward (model_utils.py:393-424) in training mode on geometry tg.  features (S_,Cf,n) -> l0_points
     (S_,128,n).  groups: number of consecutive batch slices with their own BatchNorm statistics."""
-    lin = lambda layer, x: layer(x.permute(0, 2, 1)).permute(0, 2, 1).contiguous()
+    # nn.Linear over the channel axis of a (S_,C,U) tensor = a 1x1 convolution (no permute copies)
+    lin = lambda layer, x: (conv1x1(x.unsqueeze(-1), layer.weight[:, :, None, None]) + layer.bias.view(1, -1, 1, 1)).squeeze(-1)
     feats = features.contiguous()
     levels = []
     for lvl, (sa, linear) in enumerate(((head.sa1, head.linear1), (head.sa2, head.linear2), (head.sa3, head.linear3))):
