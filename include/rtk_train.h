@@ -81,6 +81,13 @@ RTK_EXPORT int rtk_cost_volume_bwd(int samples, int n1, int n2, const float *xyz
                                    int act_pitch, float *a1, float *a2, float *dz1, float *dz2, float *dz3, float *dq3,
                                    float *d4, float *dp1, float *dpd, float *dt2, rtk_stream_t stream);
 
+/* Backward of rtk_patch_cost (rtk_fused.h; same forward arguments; feat point-major).  dout (samples*n, dout_pitch).
+ * Outputs over the M = samples*n*16 positions: dxg (M,256) = dout * wn (scatter it onto feat's rows with
+ * rtk_scatter_add_rows(knn_idx, dxg)), dq3 (M,256), dt2 (M,8), d4 (M,4) as in rtk_cost_volume_bwd. */
+RTK_EXPORT int rtk_patch_cost_bwd(int samples, int n, const float *xyz, const int64_t *knn_idx, const float *feat, int feat_pitch,
+                                  const rtk_layer_t *wn, const float *wct_packed, const float *dout, int dout_pitch, float *dxg,
+                                  float *dq3, float *dt2, float *d4, rtk_stream_t stream);
+
 /* dst[b][idx[b][r]][:] += src[b][r][:] for r < m, dst (samples, n, channels) fully written (no zero-fill needed):
  * the scatter half of the backward of a row gather.  idx (samples, m) int64 in [0, n); channels % 32 == 0;
  * n * 128 bytes of LDS per workgroup (n <= 1024). */

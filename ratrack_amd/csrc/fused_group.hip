@@ -632,3 +632,72 @@ extern "C" int rtk_patch_cost(int samples, int n, const float *xyz, const int64_
     RTK_CHECK_LAUNCH("patch_cost");
     return RTK_OK;
 }
+
+// Backward of rtk_patch_cost: out[i] = sum_k wn(d_ik) * feat[knn[i,k]].  Per position (i,k), point-major (M,256):
+//   dxg = dout[i] * wn          -> scattered onto feat's rows by the caller (rtk_scatter_add_rows)
+//   dq3 = dout[i] * feat[nb] * [wn > 0]   (gradient of the WeightNet's last pre-activation), dt2 = Wc^T dq3, d4 = (d, 1).
+struct PcBwdParams {
+    PcParams f;
+    const float *dout;
+    int dout_pitch;
+    const f4 *wct;
+    float *dxg, *dq3, *dt2, *d4;
+};
+
+__global__ __launch_bounds__(256) void patch_cost_bwd_kernel(const PcBwdParams Q) {
+    const PcParams &P = Q.f;
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    const int b = blockIdx.y;
+    for (int pt = blockIdx.x * 4 + (threadIdx.x >> 6); pt < P.n; pt += gridDim.x * 4) {
+        const long i = (long)b * P.n + pt;
+        const long nb = (long)b * P.n + (long)P.knn[i * 16 + j];
+        const float bop = g < 3 ? __fsub_rn(P.xyz[nb * 3 + g], P.xyz[i * 3 + g]) : 1.0f;
+        const long pos = i * 16 + j;
+        Q.d4[pos * 4 + g] = bop;
+        const f4 t2 = weightnet_hidden(P.wn, lane, g, bop);
+        const float *fr = P.feat + nb * P.feat_pitch + 4 * g;
+        const float *dor = Q.dout + i * Q.dout_pitch + 4 * g;
+        f4 dt2 = f4_zero();
+#pragma unroll
+        for (int v = 0; v < CV_V; ++v) {
+            const f4 w = weightnet_out(P.wn, lane, g, v, t2);
+            const f4 f = *reinterpret_cast<const f4 *>(fr + 16 * v);
+            const f4 d = *reinterpret_cast<const f4 *>(dor + 16 * v);
+            f4 q;
+            q.x = w.x > 0.f ? d.x * f.x : 0.f;
+            q.y = w.y > 0.f ? d.y * f.y : 0.f;
+            q.z = w.z > 0.f ? d.z * f.z : 0.f;
+            q.w = w.w > 0.f ? d.w * f.w : 0.f;
+            const f4 ft = Q.wct[v * 64 + lane];
+            dt2 = mfma4(ft.x, q.x, dt2);
+            dt2 = mfma4(ft.y, q.y, dt2);
+            dt2 = mfma4(ft.z, q.z, dt2);
+            dt2 = mfma4(ft.w, q.w, dt2);
+            *reinterpret_cast<f4 *>(Q.dq3 + pos * 256 + 16 * v + 4 * g) = q;
+            *reinterpret_cast<f4 *>(Q.dxg + pos * 256 + 16 * v + 4 * g) = d * w;
+        }
+        if (g < 2) *reinterpret_cast<f4 *>(Q.dt2 + pos * 8 + 4 * g) = dt2;
+    }
+}
+
+extern "C" int rtk_patch_cost_bwd(int samples, int n, const float *xyz, const int64_t *knn_idx, const float *feat, int feat_pitch,
+                                  const rtk_layer_t *wn, const float *wct_packed, const float *dout, int dout_pitch, float *dxg,
+                                  float *dq3, float *dt2, float *d4, rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && n >= 16 && xyz && knn_idx && feat && dout && dxg && dq3 && dt2 && d4 && wct_packed &&
+                feat_pitch % 4 == 0 && feat_pitch >= 256 && dout_pitch % 4 == 0 && dout_pitch >= 256, "patch_cost_bwd: bad arguments");
+    PcBwdParams Q;
+    PcParams &P = Q.f;
+    P.samples = samples; P.n = n; P.xyz = xyz; P.knn = knn_idx; P.feat = feat; P.feat_pitch = feat_pitch;
+    if (fill_wn(P.wn, wn, "patch_cost_bwd") != RTK_OK) return RTK_ERR_INVALID;
+    RTK_REQUIRE(wn[2].cout16 == 16, "patch_cost_bwd: WeightNet must produce 256 channels");
+    P.out = nullptr; P.out_pitch = 0; P.out_cm = 0;
+    Q.dout = dout; Q.dout_pitch = dout_pitch; Q.wct = reinterpret_cast<const f4 *>(wct_packed);
+    Q.dxg = dxg; Q.dq3 = dq3; Q.dt2 = dt2; Q.d4 = d4;
+    RTK_REQUIRE(samples <= 65535, "patch_cost_bwd: too many samples");
+    int gx = (n + 3) / 4;
+    while ((long)gx * samples > 4096 && gx > 1) gx = (gx + 1) / 2;
+    patch_cost_bwd_kernel<<<dim3(gx, samples), 256, 0, (hipStream_t)stream>>>(Q);
+    RTK_CHECK_LAUNCH("patch_cost_bwd");
+    return RTK_OK;
+}
+

@@ -15,6 +15,7 @@ _LayerP = ctypes.POINTER(fused._Layer)
 _lib.SIGNATURES.update({
     "rtk_cost_volume_bwd": [_i] * 3 + [_p] * 6 + [_LayerP, _LayerP, _p, _p, _i, _i] + [_p] * 10 + [_p],
     "rtk_scatter_add_rows": [_i] * 4 + [_p] * 3 + [_p],
+    "rtk_patch_cost_bwd": [_i, _i, _p, _p, _p, _i, _LayerP, _p, _p, _i, _p, _p, _p, _p, _p],
     "rtk_bn_train_stats": [_i] * 5 + [_p] * 3 + [_p],
     "rtk_bn_train_finalize": [_i, _i, _p, _d, _p, _p, _f, _f, _p, _p, _p, _p, _p],
     "rtk_bn_relu_fwd": [_i] * 5 + [_p, _p, _i, _p, _p],
@@ -169,17 +170,7 @@ class _CostVolume(torch.autograd.Function):
         dw3, db3 = _tall_tn(dz3, a2), dz3.sum(0)
         dw2, db2 = _tall_tn(dz2, a1), dz2.sum(0)
         dwd = dpd.sum(0).t()
-        # WeightNet 3 -> 8 -> 8 -> 256 (ReLU after every conv): the hidden layers are (M,8) tensors, recomputed here
-        d3 = d4[:, :3]
-        t1 = torch.relu(torch.addmm(ba, d3, wa.t()))
-        t2 = torch.relu(torch.addmm(bb, t1, wb.t()))
-        t2p = torch.cat([t2, torch.ones(M, 1, dtype=torch.float32, device=dev), torch.zeros(M, 7, dtype=torch.float32, device=dev)], 1)
-        gc = _tall_tn(dq3, t2p)
-        dwc, dbc = gc[:, :8], gc[:, 8]
-        dt2 = dt2 * (t2 > 0)
-        dwb, dbb = _tall_tn(dt2, t1), dt2.sum(0)
-        dt1 = torch.mm(dt2, wb) * (t1 > 0)
-        dwa, dba = _tall_tn(dt1, d3), dt1.sum(0)
+        dwa, dba, dwb, dbb, dwc, dbc = _weightnet_backward(d4, dq3, dt2, wa, ba, wb, bb, wc)
         return dp1, dp2, dwd, dw2, db2, dw3, db3, dwa, dba, dwb, dbb, dwc, dbc, None, None, None
 
 
@@ -189,6 +180,77 @@ def cost_volume(p1, p2, wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, xyz1, xyz2, 
     -> (B*n1, 256)."""
     assert xyz1.is_contiguous() and xyz2.is_contiguous() and knn.is_contiguous() and knn.dtype == torch.int64
     return _CostVolume.apply(p1, p2, wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, xyz1, xyz2, knn)
+
+
+def _weightnet_images(wa, ba, wb, bb, wc, bc):
+    """Kernel images of a WeightNet 3 -> 8 -> 8 -> 256 (see fused._WeightNet) from live parameters."""
+    L = fused._Layer
+    dev = wa.device
+    keep = [fused.offset_image(torch.cat([wa, ba[:, None]], 1), dev), fused.pack_layer(wb), fused.pad_bias(bb, 8),
+            fused.pack_layer(wc), fused.pad_bias(bc, 256)]
+    wn = (L * 3)()
+    wn[0].w_packed, wn[0].cin16, wn[0].cout16 = keep[0].data_ptr(), 1, 1
+    wn[1].w_packed, wn[1].bias, wn[1].cin16, wn[1].cout16 = keep[1].data_ptr(), keep[2].data_ptr(), 1, 1
+    wn[2].w_packed, wn[2].bias, wn[2].cin16, wn[2].cout16 = keep[3].data_ptr(), keep[4].data_ptr(), 1, 16
+    return wn, keep
+
+
+def _weightnet_backward(d4, dq3, dt2, wa, ba, wb, bb, wc):
+    """Gradients of the WeightNet parameters from dq3 (M,256) (last pre-activation), dt2 = dq3 Wc (M,8) and the
+    direction vectors d4[:, :3]; the (M,8) hidden activations are recomputed."""
+    M = d4.shape[0]
+    dev = d4.device
+    d3 = d4[:, :3]
+    t1 = torch.relu(torch.addmm(ba, d3, wa.t()))
+    t2 = torch.relu(torch.addmm(bb, t1, wb.t()))
+    t2p = torch.cat([t2, torch.ones(M, 1, dtype=torch.float32, device=dev), torch.zeros(M, 7, dtype=torch.float32, device=dev)], 1)
+    gc = _tall_tn(dq3, t2p)
+    dwc, dbc = gc[:, :8], gc[:, 8]
+    dt2 = dt2 * (t2 > 0)
+    dwb, dbb = _tall_tn(dt2, t1), dt2.sum(0)
+    dt1 = torch.mm(dt2, wb) * (t1 > 0)
+    dwa, dba = _tall_tn(dt1, d3), dt1.sum(0)
+    return dwa, dba, dwb, dbb, dwc, dbc
+
+
+class _PatchCost(torch.autograd.Function):
+    """out[i] = sum_k WeightNet(xyz[knn[i,k]] - xyz[i]) * feat[knn[i,k]]  (model_utils.py:238-248): forward = the inference
+    kernel rtk_patch_cost, backward = rtk_patch_cost_bwd + the LDS scatter + the WeightNet's small GEMMs."""
+
+    @staticmethod
+    def forward(ctx, feat, wa, ba, wb, bb, wc, bc, xyz, knn):
+        B, n, _ = xyz.shape
+        feat = feat.contiguous()
+        wn, keep = _weightnet_images(wa, ba, wb, bb, wc, bc)
+        out = torch.empty(B * n, 256, dtype=torch.float32, device=feat.device)
+        _lib.call("rtk_patch_cost", B, n, xyz.data_ptr(), knn.data_ptr(), feat.data_ptr(), 256, wn, out.data_ptr(), 256, 0, _stream())
+        ctx.save_for_backward(feat, wa, ba, wb, bb, wc, bc, xyz, knn)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feat, wa, ba, wb, bb, wc, bc, xyz, knn = ctx.saved_tensors
+        B, n, _ = xyz.shape
+        M = B * n * 16
+        dev = feat.device
+        dout = dout.contiguous()
+        wn, keep = _weightnet_images(wa, ba, wb, bb, wc, bc)
+        wct = fused.pack_layer(wc.t())
+        big = torch.empty(2, M, 256, dtype=torch.float32, device=dev)
+        dxg, dq3 = big.unbind(0)
+        dt2 = torch.empty(M, 8, dtype=torch.float32, device=dev)
+        d4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
+        _lib.call("rtk_patch_cost_bwd", B, n, xyz.data_ptr(), knn.data_ptr(), feat.data_ptr(), 256, wn, wct.data_ptr(), dout.data_ptr(),
+                  256, dxg.data_ptr(), dq3.data_ptr(), dt2.data_ptr(), d4.data_ptr(), _stream())
+        dfeat = torch.empty(B * n, 256, dtype=torch.float32, device=dev)
+        _lib.call("rtk_scatter_add_rows", B, n * 16, n, 256, knn.data_ptr(), dxg.data_ptr(), dfeat.data_ptr(), _stream())
+        return (dfeat,) + _weightnet_backward(d4, dq3, dt2, wa, ba, wb, bb, wc) + (None, None)
+
+
+def patch_cost(feat, wa, ba, wb, bb, wc, bc, xyz, knn):
+    """feat (B*n,256) point-major, WeightNet parameters as in cost_volume, xyz (B,n,3), knn (B,n,16) int64 -> (B*n,256)."""
+    assert xyz.is_contiguous() and knn.is_contiguous() and knn.dtype == torch.int64
+    return _PatchCost.apply(feat, wa, ba, wb, bb, wc, bc, xyz, knn)
 
 
 # ---- 1x1 convolution with a GEMM weight gradient ----------------------------------------------------------------------

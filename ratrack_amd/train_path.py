@@ -21,7 +21,7 @@ import torch
 import torch.nn.functional as F
 
 from . import pointnet2_utils as PU
-from .train_ops import bn_relu, conv1x1, cost_volume
+from .train_ops import bn_relu, conv1x1, cost_volume, patch_cost
 
 
 class TrainGeometry:
@@ -143,14 +143,14 @@ def pnhead_train(head, tg, features, groups=1):
 
 def correlator_supported(fc):
     return (not fc.bn and fc.nsample == 16 and abs(fc.slope - 0.1) < 1e-12 and len(fc.mlp_convs) == 3
-            and all(c.out_channels == 256 for c in fc.mlp_convs) and not fc.weightnet1.bn)
+            and all(c.out_channels == 256 for c in fc.mlp_convs) and not fc.weightnet1.bn and not fc.weightnet2.bn)
 
 
 def correlator_train(fc, pc1, pc2, feature1, feature2):
     """FeatureCorrelator.forward (model_utils.py:166-250) in training mode: the point-to-patch cost volume is one
-    fused operator (forward kernel of the inference engine + its backward kernel); the light patch-to-patch
-    aggregation stays on framework ops.  pc (B,3,N), features (B,D,N) -> (B,256,N1)."""
-    from .model_utils import index_points, knn_point
+    fused operator (forward kernel of the inference engine + its backward kernel), and so is the patch-to-patch
+    aggregation.  pc (B,3,N), features (B,D,N) -> (B,256,N1)."""
+    from .model_utils import knn_point
     B, C, N1 = pc1.shape
     x1, x2 = pc1.permute(0, 2, 1).contiguous(), pc2.permute(0, 2, 1).contiguous()
     f1, f2 = feature1.permute(0, 2, 1), feature2.permute(0, 2, 1)
@@ -163,9 +163,9 @@ def correlator_train(fc, pc1, pc2, feature1, feature2):
     wn = fc.weightnet1.mlp_convs
     x = cost_volume(p1, p2, w0[:, D1 + D2:], conv1.weight[:, :, 0, 0], conv1.bias, conv2.weight[:, :, 0, 0], conv2.bias,
                     wn[0].weight[:, :, 0, 0], wn[0].bias, wn[1].weight[:, :, 0, 0], wn[1].bias, wn[2].weight[:, :, 0, 0],
-                    wn[2].bias, x1, x2, knn).view(B, N1, 256)
-    knn = knn_point(16, x1, x1)
-    direction = index_points(x1, knn) - x1.reshape(B, N1, 1, C)
-    w = fc.weightnet2(direction.permute(0, 3, 2, 1))
-    x = index_points(x, knn).permute(0, 3, 2, 1)
-    return torch.sum(w * x, dim=2)
+                    wn[2].bias, x1, x2, knn)                                   # (B*N1, 256) point-major
+    knn = knn_point(16, x1, x1).contiguous()
+    wn = fc.weightnet2.mlp_convs
+    x = patch_cost(x, wn[0].weight[:, :, 0, 0], wn[0].bias, wn[1].weight[:, :, 0, 0], wn[1].bias, wn[2].weight[:, :, 0, 0],
+                   wn[2].bias, x1, knn)
+    return x.view(B, N1, 256).permute(0, 2, 1)
