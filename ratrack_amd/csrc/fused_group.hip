@@ -548,10 +548,20 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(int m, int n, int cha
     const int cl = threadIdx.x & (SC_CH - 1), rsub = threadIdx.x / SC_CH;      // 8 rows per pass
     const int64_t *ib = idx + (size_t)b * m;
     const float *sb = src + (size_t)b * m * channels + c0 + cl;
-    for (int r = rsub; r < m; r += 256 / SC_CH) {
-        const int t = (int)ib[r];
-        atomicAdd(&s_acc[t * SC_CH + cl], sb[(size_t)r * channels]);
+    constexpr int RP = 256 / SC_CH, UN = 8;                                     // UN independent loads in flight per thread
+    int r = rsub;
+    for (; r + (UN - 1) * RP < m; r += UN * RP) {
+        int t[UN];
+        float v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            t[u] = (int)ib[r + u * RP];
+            v[u] = sb[(size_t)(r + u * RP) * channels];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) atomicAdd(&s_acc[t[u] * SC_CH + cl], v[u]);
     }
+    for (; r < m; r += RP) atomicAdd(&s_acc[(int)ib[r] * SC_CH + cl], sb[(size_t)r * channels]);
     __syncthreads();
     float *db = dst + (size_t)b * n * channels + c0;
     for (int e = threadIdx.x; e < n * SC_CH; e += 256) db[(size_t)(e / SC_CH) * channels + (e % SC_CH)] = s_acc[e];

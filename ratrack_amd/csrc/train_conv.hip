@@ -1,0 +1,265 @@
+// Training-mode 1x1 convolution fused with the BatchNorm work around it (include/rtk_train.h), for the set-abstraction
+// SharedMLPs (lib/pytorch_utils.py:20-32: Conv2d(1x1, no bias) -> BatchNorm2d(batch statistics) -> ReLU).
+//
+//   forward  (rtk_conv_bn_fwd):  a = relu(scale_prev x + shift_prev)   [the previous layer's BatchNorm + ReLU, on load]
+//                                z = W a                               [fp32 MFMA, activation-stationary]
+//                                sums += (sum w z, sum w z^2)           [this layer's batch statistics, in the epilogue]
+//                                optionally stores a (the weight gradient of this layer needs it)
+//   backward (rtk_conv_bn_bwd):  dy = W^T dz ;  m = [scale_prev zprev + shift_prev > 0]
+//        pass 0:  sums2 += (sum dy m, sum dy m xhat)                    [BatchNorm backward statistics of the previous layer]
+//        pass 1:  dzprev = scale_prev (dy m - w (c1 + xhat c2))          [recomputes dy: 2 reads + 1 write instead of 4 + 2]
+//
+// Tensors are NCHW planes (samples, C, P = rows*ns).  A wave owns 64 consecutive positions of one sample as FOUR
+// interleaved MFMA tiles (tile t = positions 4j + t, j = lane & 15): every global access is a 16-byte load/store of 4
+// consecutive positions of one channel, 256 contiguous bytes per 16 lanes, and the D layout of the MFMA
+// (channel 16v + 4g + r, position j) re-assembles into the same float4s without any shuffle.  Weights (<= 16 KiB packed)
+// sit in LDS for the whole kernel.  The kernels are HBM-bound by design: 2 reads + 2 writes (forward), 2 + 0 and 2 + 1
+// (backward) of the activation planes, against conv + 2 BatchNorm passes + ReLU-free apply of the unfused path.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fused_common.h"
+#include "rtk_common.h"
+#include "rtk_train.h"
+
+namespace {
+
+constexpr int TC_T = 256;            // 4 waves
+constexpr int TC_CHUNK = 64;         // positions per wave iteration
+
+struct TcParams {
+    int samples, rows, lg_ns, groups, P;
+    const float *in;        // (S, 16U, P): x (forward) or dz (backward)
+    const float *w_packed;  // [U][V][64][4]
+    const float *pre;       // (4, groups, Cpre) mean | rstd | scale | shift of the previous layer's BatchNorm; NULL = identity (forward only)
+    const float *zprev;     // backward: (S, 16V, P)
+    const float *rw;        // (S, rows) row weights or NULL
+    float *out;             // forward: z (S, 16V, P); backward pass 1: dzprev
+    float *act_out;         // forward: a (S, 16U, P) or NULL
+    double *sums;           // (groups, 16V, 2)
+    double count;
+    float *dgb;             // backward pass 1: (2, 16V) dgamma | dbeta
+};
+
+__device__ __forceinline__ double wave_row_sum(double v) {      // sum over the 16 lanes that share g
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// MODE 0: forward.  MODE 1: backward statistics.  MODE 2: backward apply.
+template <int U, int V, int MODE>
+__global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
+    __shared__ __attribute__((aligned(16))) f4 s_w[U * V * 64];
+    __shared__ double s_red[TC_T / 64][V * 16][2];
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int grp = b / (Q.samples / Q.groups);
+    for (int i = threadIdx.x; i < U * V * 64; i += TC_T) s_w[i] = reinterpret_cast<const f4 *>(Q.w_packed)[i];
+    __syncthreads();
+    const int P = Q.P;
+    // BatchNorm constants of the channels on the affine side (inputs in the forward, outputs in the backward), in LDS:
+    // lanes that share g read the same word (broadcast), and 6 x 16V registers per lane would spill
+    constexpr int CA = 16 * (MODE == 0 ? U : V);
+    __shared__ float s_sc[CA], s_sh[CA], s_mu[CA], s_rs[CA], s_c1[CA], s_c2[CA];
+    const bool has_pre = Q.pre != nullptr;
+    {
+        const size_t GC = (size_t)Q.groups * CA, o = (size_t)grp * CA;
+        for (int c = threadIdx.x; c < CA; c += TC_T) {
+            s_mu[c] = has_pre ? Q.pre[o + c] : 0.f;
+            s_rs[c] = has_pre ? Q.pre[GC + o + c] : 1.f;
+            s_sc[c] = has_pre ? Q.pre[2 * GC + o + c] : 1.f;
+            s_sh[c] = has_pre ? Q.pre[3 * GC + o + c] : 0.f;
+            if (MODE == 2) {
+                s_c1[c] = (float)(Q.sums[(o + c) * 2] / Q.count);
+                s_c2[c] = (float)(Q.sums[(o + c) * 2 + 1] / Q.count);
+            }
+        }
+    }
+    __syncthreads();
+    if (MODE == 2 && Q.dgb && b == 0 && blockIdx.x == 0 && threadIdx.x < 16 * V) {      // parameter gradients: sum over the groups
+        const int c = threadIdx.x;
+        double db = 0.0, dg = 0.0;
+        for (int gg = 0; gg < Q.groups; ++gg) {
+            db += Q.sums[((size_t)gg * 16 * V + c) * 2];
+            dg += Q.sums[((size_t)gg * 16 * V + c) * 2 + 1];
+        }
+        Q.dgb[c] = (float)dg;
+        Q.dgb[16 * V + c] = (float)db;
+    }
+    f4 st0[V], st1[V];      // per-lane partial statistics (float within the wave's chunks, float64 across waves)
+#pragma unroll
+    for (int v = 0; v < V; ++v) { st0[v] = f4_zero(); st1[v] = f4_zero(); }
+
+    // uniform (SGPR) plane bases + 32-bit per-lane byte offsets: 64-bit per-channel addresses would cost 2 VGPRs each
+    const char *inb = reinterpret_cast<const char *>(Q.in + (size_t)b * 16 * U * P);
+    const char *zpb = MODE != 0 ? reinterpret_cast<const char *>(Q.zprev + (size_t)b * 16 * V * P) : nullptr;
+    char *outb = Q.out ? reinterpret_cast<char *>(Q.out + (size_t)b * 16 * V * P) : nullptr;
+    char *actb = (MODE == 0 && Q.act_out) ? reinterpret_cast<char *>(Q.act_out + (size_t)b * 16 * U * P) : nullptr;
+    const unsigned pitch = 4u * (unsigned)P;                      // bytes per channel plane
+    const int nchunks = (P + TC_CHUNK - 1) / TC_CHUNK;
+    for (int ch = blockIdx.x * (TC_T / 64) + wave; ch < nchunks; ch += gridDim.x * (TC_T / 64)) {
+        const int p = ch * TC_CHUNK + 4 * j;                       // this lane's 4 positions
+        const bool ok = p < P;                                     // P % 4 == 0: all four or none
+        const float wl = ok ? (Q.rw ? Q.rw[(size_t)b * Q.rows + (p >> Q.lg_ns)] : 1.f) : 0.f;
+        // ---- load: h[t][u][r] = in[channel 16u + 4g + r][position p + t] ------------------------------------------------
+        f4 h[4][U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned ioff = (unsigned)(16 * u + 4 * g + r) * pitch + 4u * (unsigned)p;
+                f4 x = ok ? *reinterpret_cast<const f4 *>(inb + ioff) : f4_zero();
+                if (MODE == 0) {
+                    if (has_pre) {
+                        const float sc = s_sc[16 * u + 4 * g + r], sh = s_sh[16 * u + 4 * g + r];
+                        x.x = fmaxf(__fmaf_rn(x.x, sc, sh), 0.f);
+                        x.y = fmaxf(__fmaf_rn(x.y, sc, sh), 0.f);
+                        x.z = fmaxf(__fmaf_rn(x.z, sc, sh), 0.f);
+                        x.w = fmaxf(__fmaf_rn(x.w, sc, sh), 0.f);
+                    }
+                    if (actb && ok) *reinterpret_cast<f4 *>(actb + ioff) = x;
+                }
+                h[0][u][r] = x.x; h[1][u][r] = x.y; h[2][u][r] = x.z; h[3][u][r] = x.w;
+            }
+        }
+        // ---- 4 tiles x (16V x 16U) MFMA ----------------------------------------------------------------------------------
+        f4 acc[4][V];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[t][v] = f4_zero();
+            mlp_layer<U, V>(s_w, lane, h[t], acc[t]);
+        }
+        // ---- epilogue: out[channel 16v + 4g + r][p .. p+3] = (acc[0..3][v][r]) ---------------------------------------------
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f4 y = {acc[0][v][r], acc[1][v][r], acc[2][v][r], acc[3][v][r]};
+                const unsigned off = (unsigned)(16 * v + 4 * g + r) * pitch + 4u * (unsigned)p;
+                if (MODE == 0) {
+                    if (ok) *reinterpret_cast<f4 *>(outb + off) = y;
+                    st0[v][r] += wl * ((y.x + y.y) + (y.z + y.w));
+                    st1[v][r] += wl * ((y.x * y.x + y.y * y.y) + (y.z * y.z + y.w * y.w));
+                } else {
+                    const f4 zp = ok ? *reinterpret_cast<const f4 *>(zpb + off) : f4_zero();
+                    const int cc = 16 * v + 4 * g + r;
+                    const float sc = s_sc[cc], sh = s_sh[cc], mu = s_mu[cc], rs = s_rs[cc];
+                    f4 d, xh;
+                    d.x = __fmaf_rn(zp.x, sc, sh) > 0.f ? y.x : 0.f;
+                    d.y = __fmaf_rn(zp.y, sc, sh) > 0.f ? y.y : 0.f;
+                    d.z = __fmaf_rn(zp.z, sc, sh) > 0.f ? y.z : 0.f;
+                    d.w = __fmaf_rn(zp.w, sc, sh) > 0.f ? y.w : 0.f;
+                    xh.x = (zp.x - mu) * rs; xh.y = (zp.y - mu) * rs; xh.z = (zp.z - mu) * rs; xh.w = (zp.w - mu) * rs;
+                    if (MODE == 1) {
+                        st0[v][r] += (d.x + d.y) + (d.z + d.w);
+                        st1[v][r] += (d.x * xh.x + d.y * xh.y) + (d.z * xh.z + d.w * xh.w);
+                    } else if (ok) {
+                        const float k1 = s_c1[cc], k2 = s_c2[cc];
+                        f4 o;
+                        o.x = sc * (d.x - wl * (k1 + xh.x * k2));
+                        o.y = sc * (d.y - wl * (k1 + xh.y * k2));
+                        o.z = sc * (d.z - wl * (k1 + xh.z * k2));
+                        o.w = sc * (d.w - wl * (k1 + xh.w * k2));
+                        *reinterpret_cast<f4 *>(outb + off) = o;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one output block at a time: hoisting all 16V zprev loads spills
+        }
+    }
+    if (MODE == 2) return;
+    // ---- statistics: lanes -> wave (xor shuffles over j) -> workgroup (LDS) -> one float64 atomic pair per channel ------
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double a0 = wave_row_sum((double)st0[v][r]), a1 = wave_row_sum((double)st1[v][r]);
+            if (j == 0) { s_red[wave][16 * v + 4 * g + r][0] = a0; s_red[wave][16 * v + 4 * g + r][1] = a1; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 * V) {
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int w = 0; w < TC_T / 64; ++w) { a0 += s_red[w][threadIdx.x][0]; a1 += s_red[w][threadIdx.x][1]; }
+        double *dst = Q.sums + ((size_t)grp * 16 * V + threadIdx.x) * 2;
+        atomicAdd(dst, a0);
+        atomicAdd(dst + 1, a1);
+    }
+}
+
+int ilog2x(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+
+template <int MODE>
+int launch(const TcParams &Q, int cin, int cout, hipStream_t s) {
+    const int U = cin / 16, V = cout / 16;
+    const int nchunks = (Q.P + TC_CHUNK - 1) / TC_CHUNK;
+    int gx = (nchunks + 3) / 4;                       // one chunk per wave per pass ...
+    while ((long)gx * Q.samples > 2048 && gx > 1) gx = (gx + 1) / 2;   // ... but few, fat workgroups: LDS fill + atomics are paid per workgroup
+    const dim3 grid(gx, Q.samples);
+#define TC_CASE(u, v)                                                    \
+    if (U == u && V == v) {                                              \
+        conv_bn_kernel<u, v, MODE><<<grid, TC_T, 0, s>>>(Q);             \
+        return 0;                                                        \
+    }
+    TC_CASE(1, 1) TC_CASE(1, 2) TC_CASE(1, 4) TC_CASE(2, 1) TC_CASE(2, 2) TC_CASE(2, 4) TC_CASE(4, 1) TC_CASE(4, 2) TC_CASE(4, 4)
+#undef TC_CASE
+    return 1;
+}
+
+int check(const char *who, int samples, int cin, int cout, int rows, int ns, int groups) {
+    if ((double)rows * ns * 64.0 * 4.0 >= 4294967296.0) {
+        rtk_set_error("%s: sample planes larger than 4 GiB (32-bit offsets)", who);
+        return RTK_ERR_INVALID;
+    }
+    if (samples <= 0 || rows <= 0 || groups <= 0 || samples % groups || samples > 65535) {
+        rtk_set_error("%s: bad batch (%d samples, %d groups)", who, samples, groups);
+        return RTK_ERR_INVALID;
+    }
+    if (ilog2x(ns) < 2) {
+        rtk_set_error("%s: ns (%d) must be a power of two >= 4", who, ns);
+        return RTK_ERR_INVALID;
+    }
+    auto okc = [](int c) { return c == 16 || c == 32 || c == 64; };
+    if (!okc(cin) || !okc(cout)) {
+        rtk_set_error("%s: channel counts (%d -> %d) must be 16, 32 or 64", who, cin, cout);
+        return RTK_ERR_UNSUPPORTED;
+    }
+    return RTK_OK;
+}
+
+}  // namespace
+
+extern "C" int rtk_conv_bn_fwd(int samples, int cin, int cout, int rows, int ns, int groups, const float *x, const float *pre_par,
+                               const float *w_packed, float *z, float *act_out, const float *row_weight, double *sums,
+                               rtk_stream_t stream) {
+    if (int rc = check("rtk_conv_bn_fwd", samples, cin, cout, rows, ns, groups)) return rc;
+    RTK_REQUIRE(x && w_packed && z && sums, "rtk_conv_bn_fwd: null argument");
+    TcParams Q = {};
+    Q.samples = samples; Q.rows = rows; Q.lg_ns = ilog2x(ns); Q.groups = groups; Q.P = rows * ns;
+    Q.in = x; Q.w_packed = w_packed; Q.pre = pre_par; Q.rw = row_weight; Q.out = z; Q.act_out = act_out; Q.sums = sums;
+    launch<0>(Q, cin, cout, (hipStream_t)stream);
+    RTK_CHECK_LAUNCH("rtk_conv_bn_fwd");
+    return RTK_OK;
+}
+
+extern "C" int rtk_conv_bn_bwd(int samples, int cprev, int cout, int rows, int ns, int groups, const float *dz, const float *wt_packed,
+                               const float *zprev, const float *pre_par, const float *row_weight, double *sums2, double count, int apply,
+                               float *dzprev, float *dgamma_dbeta, rtk_stream_t stream) {
+    if (int rc = check("rtk_conv_bn_bwd", samples, cout, cprev, rows, ns, groups)) return rc;
+    RTK_REQUIRE(dz && wt_packed && zprev && pre_par && sums2 && (!apply || dzprev), "rtk_conv_bn_bwd: null argument");
+    TcParams Q = {};
+    Q.samples = samples; Q.rows = rows; Q.lg_ns = ilog2x(ns); Q.groups = groups; Q.P = rows * ns;
+    Q.in = dz; Q.w_packed = wt_packed; Q.pre = pre_par; Q.zprev = zprev; Q.rw = row_weight; Q.out = dzprev; Q.sums = sums2;
+    Q.count = count; Q.dgb = dgamma_dbeta;
+    if (apply) launch<2>(Q, cout, cprev, (hipStream_t)stream);
+    else launch<1>(Q, cout, cprev, (hipStream_t)stream);
+    RTK_CHECK_LAUNCH("rtk_conv_bn_bwd");
+    return RTK_OK;
+}

@@ -15,6 +15,8 @@ _LayerP = ctypes.POINTER(fused._Layer)
 _lib.SIGNATURES.update({
     "rtk_cost_volume_bwd": [_i] * 3 + [_p] * 6 + [_LayerP, _LayerP, _p, _p, _i, _i] + [_p] * 10 + [_p],
     "rtk_scatter_add_rows": [_i] * 4 + [_p] * 3 + [_p],
+    "rtk_conv_bn_fwd": [_i] * 6 + [_p] * 7 + [_p],
+    "rtk_conv_bn_bwd": [_i] * 6 + [_p] * 6 + [_d, _i, _p, _p, _p],
     "rtk_patch_cost_bwd": [_i, _i, _p, _p, _p, _i, _LayerP, _p, _p, _i, _p, _p, _p, _p, _p],
     "rtk_bn_train_stats": [_i] * 5 + [_p] * 3 + [_p],
     "rtk_bn_train_finalize": [_i, _i, _p, _d, _p, _p, _f, _f, _p, _p, _p, _p, _p],
@@ -85,6 +87,113 @@ def bn_relu(z, bn, row_weight=None, count=None, groups=1, pool=False):
     return _BNReLU.apply(z, bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None,
                          bn.num_batches_tracked if track else None, row_weight, float(count), int(groups), bn.eps, momentum,
                          bool(pool))
+
+
+# ---- SharedMLP chain of one set-abstraction scale ------------------------------------------------------------------------
+
+def _bn_finalize(bn, sums, count, groups):
+    C = bn.num_features
+    par = torch.empty(4, groups, C, dtype=torch.float32, device=sums.device)
+    momentum = bn.momentum if bn.momentum is not None else 0.1
+    track = bn.track_running_stats
+    _lib.call("rtk_bn_train_finalize", C, groups, sums.data_ptr(), float(count), bn.weight.detach().data_ptr(), bn.bias.detach().data_ptr(),
+              float(bn.eps), float(momentum), _ptr(bn.running_mean if track else None), _ptr(bn.running_var if track else None),
+              _ptr(bn.num_batches_tracked if track else None), par.data_ptr(), _stream())
+    return par
+
+
+class _SAChain(torch.autograd.Function):
+    """[BN + ReLU -> 1x1 conv]* -> BN + ReLU -> max over the neighbourhood, starting from the first layer's
+    pre-activation z1 (S,C1,rows,ns).  Each inner layer is ONE kernel forward (previous BatchNorm + ReLU on load, MFMA,
+    this layer's batch sums in the epilogue) and TWO backward (statistics, apply; both recompute W^T dz) + a batched GEMM
+    for the weight gradient; the normalised activations are stored once for that GEMM, nothing else is materialised."""
+
+    @staticmethod
+    def forward(ctx, z1, row_w, count, groups, bns, *tensors):
+        z1 = z1.contiguous()
+        S_, C1, rows, ns = z1.shape
+        dev = z1.device
+        L = len(bns)
+        weights = [None] + [tensors[3 * i - 1] for i in range(1, L)]        # tensors = g0, b0, W1, g1, b1, W2, g2, b2
+        f64 = lambda c: torch.zeros(groups, c, 2, dtype=torch.float64, device=dev)
+        sums = f64(C1)
+        _lib.call("rtk_bn_train_stats", S_, C1, rows, ns, groups, z1.data_ptr(), _ptr(row_w), sums.data_ptr(), _stream())
+        zs, ys, pars = [z1], [], [_bn_finalize(bns[0], sums, count, groups)]
+        for i in range(1, L):
+            W = weights[i]
+            Co, Ci = W.shape[0], W.shape[1]
+            wp = fused.pack_layer(W.detach().reshape(Co, Ci))
+            z = torch.empty(S_, Co, rows, ns, dtype=torch.float32, device=dev)
+            y = torch.empty(S_, Ci, rows, ns, dtype=torch.float32, device=dev)
+            sums = f64(Co)
+            _lib.call("rtk_conv_bn_fwd", S_, Ci, Co, rows, ns, groups, zs[-1].data_ptr(), pars[-1].data_ptr(), wp.data_ptr(), z.data_ptr(),
+                      y.data_ptr(), _ptr(row_w), sums.data_ptr(), _stream())
+            pars.append(_bn_finalize(bns[i], sums, count, groups))
+            zs.append(z)
+            ys.append(y)
+        C = zs[-1].shape[1]
+        out = torch.empty(S_, C, rows, dtype=torch.float32, device=dev)
+        _lib.call("rtk_bn_relu_fwd", S_, C, rows, ns, groups, zs[-1].data_ptr(), pars[-1].data_ptr(), 1, out.data_ptr(), _stream())
+        ctx.save_for_backward(row_w, *zs, *ys, *pars, *[w for w in weights[1:]])
+        ctx.cfg = (count, groups, L)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        count, groups, L = ctx.cfg
+        saved = list(ctx.saved_tensors)
+        row_w = saved[0]
+        zs, ys = saved[1:1 + L], saved[1 + L:2 * L]
+        pars, weights = saved[2 * L:3 * L], [None] + saved[3 * L:]
+        S_, _, rows, ns = zs[0].shape
+        dev = dout.device
+        dout = dout.contiguous()
+        f64 = lambda c: torch.zeros(groups, c, 2, dtype=torch.float64, device=dev)
+        # last layer: BN + ReLU + max-pool
+        C = zs[-1].shape[1]
+        sums2 = f64(C)
+        _lib.call("rtk_bn_relu_bwd_stats", S_, C, rows, ns, groups, zs[-1].data_ptr(), dout.data_ptr(), pars[-1].data_ptr(), 1,
+                  sums2.data_ptr(), _stream())
+        dz = torch.empty_like(zs[-1])
+        dgb = torch.empty(2, C, dtype=torch.float32, device=dev)
+        _lib.call("rtk_bn_relu_bwd_apply", S_, C, rows, ns, groups, zs[-1].data_ptr(), dout.data_ptr(), pars[-1].data_ptr(), _ptr(row_w),
+                  sums2.data_ptr(), float(count), 1, dz.data_ptr(), dgb.data_ptr(), _stream())
+        grads = {L - 1: (None, dgb[0], dgb[1])}
+        for i in range(L - 1, 0, -1):
+            W = weights[i]
+            Co, Ci = W.shape[0], W.shape[1]
+            dW = torch.bmm(dz.view(S_, Co, -1), ys[i - 1].view(S_, Ci, -1).transpose(1, 2)).sum(0).view_as(W)
+            wt = fused.pack_layer(W.reshape(Co, Ci).t())
+            sums2 = f64(Ci)
+            args = (S_, Ci, Co, rows, ns, groups, dz.data_ptr(), wt.data_ptr(), zs[i - 1].data_ptr(), pars[i - 1].data_ptr(), _ptr(row_w),
+                    sums2.data_ptr(), float(count))
+            _lib.call("rtk_conv_bn_bwd", *args, 0, None, None, _stream())
+            dzp = torch.empty_like(zs[i - 1])
+            dgb = torch.empty(2, Ci, dtype=torch.float32, device=dev)
+            _lib.call("rtk_conv_bn_bwd", *args, 1, dzp.data_ptr(), dgb.data_ptr(), _stream())
+            grads[i] = (dW, grads[i][1], grads[i][2])
+            grads[i - 1] = (None, dgb[0], dgb[1])
+            dz = dzp
+        flat = [grads[0][1], grads[0][2]]
+        for i in range(1, L):
+            flat += [grads[i][0], grads[i][1], grads[i][2]]
+        return (dz, None, None, None, None) + tuple(flat)
+
+
+def sa_chain_supported(layers):
+    chans = [layers[0].conv.out_channels] + [l.conv.out_channels for l in layers[1:]]
+    return len(layers) >= 2 and all(c in (16, 32, 64) for c in chans) and all(l.conv.bias is None for l in layers)
+
+
+def sa_chain(z1, layers, row_w, count, groups):
+    """z1 (S,C1,rows,ns): first layer's pre-activation; layers: the SharedMLP's Conv2d blocks (conv, bn.bn); returns the
+    max-pooled (S,C_last,rows) output of the chain.  Updates every BatchNorm's running statistics."""
+    tensors = []
+    for i, l in enumerate(layers):
+        if i > 0:
+            tensors.append(l.conv.weight)
+        tensors += [l.bn.bn.weight, l.bn.bn.bias]
+    return _SAChain.apply(z1, row_w, float(count), int(groups), tuple(l.bn.bn for l in layers), *tensors)
 
 
 # ---- cost volume -------------------------------------------------------------------------------------------------------

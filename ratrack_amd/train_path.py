@@ -21,7 +21,10 @@ import torch
 import torch.nn.functional as F
 
 from . import pointnet2_utils as PU
-from .train_ops import bn_relu, conv1x1, cost_volume, patch_cost
+from .train_ops import bn_relu, conv1x1, cost_volume, patch_cost, sa_chain, sa_chain_supported
+
+
+FUSED_SA_CHAIN = True      # False: one bn_relu + framework convolution per layer (reference structure, kept for tests)
 
 
 class TrainGeometry:
@@ -102,6 +105,8 @@ def _sa_scale(mlp, tg, lvl, s, feats, groups):
     count = (tg.samples // groups) * tg.npoint * ns
     proj = conv1x1(feats.unsqueeze(-1), w[:, 3:]).squeeze(-1)     # per-POINT projection (a 1x1 conv and a gather commute)
     z = conv1x1(tg.dxyz[lvl][s], w[:, :3]) + PU.grouping_operation(proj, idx)
+    if FUSED_SA_CHAIN and sa_chain_supported(layers) and ns >= 4:
+        return sa_chain(z, layers, tg.row_w[lvl], count, groups)
     x = None
     for i, layer in enumerate(layers):
         if i > 0:
