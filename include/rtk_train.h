@@ -63,19 +63,19 @@ RTK_EXPORT int rtk_bn_relu_bwd_apply(int samples, int channels, int rows, int ns
  * Tensors are NCHW planes (samples, C, rows*ns), ns a power of two >= 4, channel counts 16, 32 or 64.
  *
  * rtk_conv_bn_fwd:  a = relu(scale x + shift) with (scale, shift) of the PREVIOUS layer's BatchNorm read from pre_par
- * ((4, groups, cin) as written by rtk_bn_train_finalize; NULL: a = x), z = W a with w_packed the fragment-major image
- * of W (cout, cin) (rtk_fused.h), and this layer's weighted batch sums accumulated into sums (groups, cout, 2) float64,
+ * ((4, groups, cin) as written by rtk_bn_train_finalize; NULL: a = x), z = W a with w the plain row-major (cout, cin)
+ * weight of the convolution, and this layer's weighted batch sums accumulated into sums (groups, cout, 2) float64,
  * zero-initialised by the caller (same meaning as rtk_bn_train_stats).  act_out (optional, shape of x) receives a. */
 RTK_EXPORT int rtk_conv_bn_fwd(int samples, int cin, int cout, int rows, int ns, int groups, const float *x, const float *pre_par,
-                               const float *w_packed, float *z, float *act_out, const float *row_weight, double *sums,
+                               const float *w, float *z, float *act_out, const float *row_weight, double *sums,
                                rtk_stream_t stream);
 
 /* rtk_conv_bn_bwd: backward through z = W relu(BatchNorm(zprev)) down to zprev.  dz (samples, cout, P) is the gradient of z,
- * wt_packed the packed image of W^T (cprev, cout), pre_par the (4, groups, cprev) constants of the BatchNorm applied to
+ * w the SAME row-major (cout, cprev) weight as in the forward, pre_par the (4, groups, cprev) constants of the BatchNorm applied to
  * zprev.  apply == 0: sums2 (groups, cprev, 2) float64 (zero-initialised) += (sum dy m, sum dy m xhat) with dy = W^T dz and
  * m the ReLU mask.  apply != 0: dzprev = scale (dy m - w (sums2[0] + xhat sums2[1]) / count) is written, and
  * dgamma_dbeta (2, cprev) (optional) = (sum_g sums2[g][c][1] | sum_g sums2[g][c][0]). */
-RTK_EXPORT int rtk_conv_bn_bwd(int samples, int cprev, int cout, int rows, int ns, int groups, const float *dz, const float *wt_packed,
+RTK_EXPORT int rtk_conv_bn_bwd(int samples, int cprev, int cout, int rows, int ns, int groups, const float *dz, const float *w,
                                const float *zprev, const float *pre_par, const float *row_weight, double *sums2, double count, int apply,
                                float *dzprev, float *dgamma_dbeta, rtk_stream_t stream);
 

@@ -30,7 +30,7 @@ constexpr int TC_CHUNK = 64;         // positions per wave iteration
 struct TcParams {
     int samples, rows, lg_ns, groups, P;
     const float *in;        // (S, 16U, P): x (forward) or dz (backward)
-    const float *w_packed;  // [U][V][64][4]
+    const float *w_packed;  // the layer's weight W, row-major (cout, cin) of the FORWARD convolution (fragments are built on load)
     const float *pre;       // (4, groups, Cpre) mean | rstd | scale | shift of the previous layer's BatchNorm; NULL = identity (forward only)
     const float *zprev;     // backward: (S, 16V, P)
     const float *rw;        // (S, rows) row weights or NULL
@@ -55,7 +55,19 @@ __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int grp = b / (Q.samples / Q.groups);
-    for (int i = threadIdx.x; i < U * V * 64; i += TC_T) s_w[i] = reinterpret_cast<const f4 *>(Q.w_packed)[i];
+    // A-operand fragments straight from the row-major weight (no host-side packing): fragment (u,v), lane (g,i) holds
+    // Wm[16v+i][16u+4g .. +3] where Wm = W (forward, (16V,16U)) or W^T (backward, W is (16U,16V))
+    for (int e = threadIdx.x; e < U * V * 64; e += TC_T) {
+        const int f = e >> 6, l = e & 63, fu = f / V, fv = f % V, fg = l >> 4, fi = l & 15;
+        f4 w;
+        if (MODE == 0) {
+            w = *reinterpret_cast<const f4 *>(Q.w_packed + (size_t)(16 * fv + fi) * (16 * U) + 16 * fu + 4 * fg);
+        } else {
+            const float *src = Q.w_packed + (size_t)(16 * fu + 4 * fg) * (16 * V) + 16 * fv + fi;
+            w = (f4){src[0], src[16 * V], src[2 * 16 * V], src[3 * 16 * V]};
+        }
+        s_w[e] = w;
+    }
     __syncthreads();
     const int P = Q.P;
     // BatchNorm constants of the channels on the affine side (inputs in the forward, outputs in the backward), in LDS:
@@ -237,26 +249,26 @@ int check(const char *who, int samples, int cin, int cout, int rows, int ns, int
 }  // namespace
 
 extern "C" int rtk_conv_bn_fwd(int samples, int cin, int cout, int rows, int ns, int groups, const float *x, const float *pre_par,
-                               const float *w_packed, float *z, float *act_out, const float *row_weight, double *sums,
+                               const float *w, float *z, float *act_out, const float *row_weight, double *sums,
                                rtk_stream_t stream) {
     if (int rc = check("rtk_conv_bn_fwd", samples, cin, cout, rows, ns, groups)) return rc;
-    RTK_REQUIRE(x && w_packed && z && sums, "rtk_conv_bn_fwd: null argument");
+    RTK_REQUIRE(x && w && z && sums, "rtk_conv_bn_fwd: null argument");
     TcParams Q = {};
     Q.samples = samples; Q.rows = rows; Q.lg_ns = ilog2x(ns); Q.groups = groups; Q.P = rows * ns;
-    Q.in = x; Q.w_packed = w_packed; Q.pre = pre_par; Q.rw = row_weight; Q.out = z; Q.act_out = act_out; Q.sums = sums;
+    Q.in = x; Q.w_packed = w; Q.pre = pre_par; Q.rw = row_weight; Q.out = z; Q.act_out = act_out; Q.sums = sums;
     launch<0>(Q, cin, cout, (hipStream_t)stream);
     RTK_CHECK_LAUNCH("rtk_conv_bn_fwd");
     return RTK_OK;
 }
 
-extern "C" int rtk_conv_bn_bwd(int samples, int cprev, int cout, int rows, int ns, int groups, const float *dz, const float *wt_packed,
+extern "C" int rtk_conv_bn_bwd(int samples, int cprev, int cout, int rows, int ns, int groups, const float *dz, const float *w,
                                const float *zprev, const float *pre_par, const float *row_weight, double *sums2, double count, int apply,
                                float *dzprev, float *dgamma_dbeta, rtk_stream_t stream) {
     if (int rc = check("rtk_conv_bn_bwd", samples, cout, cprev, rows, ns, groups)) return rc;
-    RTK_REQUIRE(dz && wt_packed && zprev && pre_par && sums2 && (!apply || dzprev), "rtk_conv_bn_bwd: null argument");
+    RTK_REQUIRE(dz && w && zprev && pre_par && sums2 && (!apply || dzprev), "rtk_conv_bn_bwd: null argument");
     TcParams Q = {};
     Q.samples = samples; Q.rows = rows; Q.lg_ns = ilog2x(ns); Q.groups = groups; Q.P = rows * ns;
-    Q.in = dz; Q.w_packed = wt_packed; Q.pre = pre_par; Q.zprev = zprev; Q.rw = row_weight; Q.out = dzprev; Q.sums = sums2;
+    Q.in = dz; Q.w_packed = w; Q.pre = pre_par; Q.zprev = zprev; Q.rw = row_weight; Q.out = dzprev; Q.sums = sums2;
     Q.count = count; Q.dgb = dgamma_dbeta;
     if (apply) launch<2>(Q, cout, cprev, (hipStream_t)stream);
     else launch<1>(Q, cout, cprev, (hipStream_t)stream);

@@ -82,8 +82,11 @@ def pack_layer(w):
     (zero padded to multiples of 16).  One (u, v) fragment = the A operands of 4 consecutive MFMA k-steps."""
     cout, cin = w.shape
     V, U = ceil16(cout) // 16, ceil16(cin) // 16
-    wp = torch.zeros(V * 16, U * 16, dtype=torch.float32, device=w.device)
-    wp[:cout, :cin] = w.float()
+    if cout % 16 == 0 and cin % 16 == 0:      # no padding: one permuting copy (the training path re-packs every step)
+        wp = w.float()
+    else:
+        wp = torch.zeros(V * 16, U * 16, dtype=torch.float32, device=w.device)
+        wp[:cout, :cin] = w.float()
     return wp.reshape(V, 16, U, 4, 4).permute(2, 0, 3, 1, 4).contiguous().reshape(-1)   # (U, V, g, i, r)
 
 

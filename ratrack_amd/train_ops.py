@@ -102,6 +102,22 @@ def _bn_finalize(bn, sums, count, groups):
     return par
 
 
+class _SumsPool:
+    """The float64 statistics buffers of one chain pass, zeroed with ONE fill: call with a channel count to get the next
+    (groups, C, 2) slice."""
+
+    def __init__(self, groups, channels, device):
+        self.groups = groups
+        self.buf = torch.zeros(groups * 2 * sum(channels), dtype=torch.float64, device=device)
+        self.off = 0
+
+    def __call__(self, c):
+        n = self.groups * c * 2
+        t = self.buf[self.off:self.off + n].view(self.groups, c, 2)
+        self.off += n
+        return t
+
+
 class _SAChain(torch.autograd.Function):
     """[BN + ReLU -> 1x1 conv]* -> BN + ReLU -> max over the neighbourhood, starting from the first layer's
     pre-activation z1 (S,C1,rows,ns).  Each inner layer is ONE kernel forward (previous BatchNorm + ReLU on load, MFMA,
@@ -115,18 +131,18 @@ class _SAChain(torch.autograd.Function):
         dev = z1.device
         L = len(bns)
         weights = [None] + [tensors[3 * i - 1] for i in range(1, L)]        # tensors = g0, b0, W1, g1, b1, W2, g2, b2
-        f64 = lambda c: torch.zeros(groups, c, 2, dtype=torch.float64, device=dev)
+        f64 = _SumsPool(groups, [C1] + [w.shape[0] for w in weights[1:]], dev)
         sums = f64(C1)
         _lib.call("rtk_bn_train_stats", S_, C1, rows, ns, groups, z1.data_ptr(), _ptr(row_w), sums.data_ptr(), _stream())
         zs, ys, pars = [z1], [], [_bn_finalize(bns[0], sums, count, groups)]
         for i in range(1, L):
             W = weights[i]
             Co, Ci = W.shape[0], W.shape[1]
-            wp = fused.pack_layer(W.detach().reshape(Co, Ci))
+            wc = W.detach().contiguous()
             z = torch.empty(S_, Co, rows, ns, dtype=torch.float32, device=dev)
             y = torch.empty(S_, Ci, rows, ns, dtype=torch.float32, device=dev)
             sums = f64(Co)
-            _lib.call("rtk_conv_bn_fwd", S_, Ci, Co, rows, ns, groups, zs[-1].data_ptr(), pars[-1].data_ptr(), wp.data_ptr(), z.data_ptr(),
+            _lib.call("rtk_conv_bn_fwd", S_, Ci, Co, rows, ns, groups, zs[-1].data_ptr(), pars[-1].data_ptr(), wc.data_ptr(), z.data_ptr(),
                       y.data_ptr(), _ptr(row_w), sums.data_ptr(), _stream())
             pars.append(_bn_finalize(bns[i], sums, count, groups))
             zs.append(z)
@@ -148,7 +164,7 @@ class _SAChain(torch.autograd.Function):
         S_, _, rows, ns = zs[0].shape
         dev = dout.device
         dout = dout.contiguous()
-        f64 = lambda c: torch.zeros(groups, c, 2, dtype=torch.float64, device=dev)
+        f64 = _SumsPool(groups, [z.shape[1] for z in zs], dev)
         # last layer: BN + ReLU + max-pool
         C = zs[-1].shape[1]
         sums2 = f64(C)
@@ -163,9 +179,9 @@ class _SAChain(torch.autograd.Function):
             W = weights[i]
             Co, Ci = W.shape[0], W.shape[1]
             dW = torch.bmm(dz.view(S_, Co, -1), ys[i - 1].view(S_, Ci, -1).transpose(1, 2)).sum(0).view_as(W)
-            wt = fused.pack_layer(W.reshape(Co, Ci).t())
+            wc = W.contiguous()
             sums2 = f64(Ci)
-            args = (S_, Ci, Co, rows, ns, groups, dz.data_ptr(), wt.data_ptr(), zs[i - 1].data_ptr(), pars[i - 1].data_ptr(), _ptr(row_w),
+            args = (S_, Ci, Co, rows, ns, groups, dz.data_ptr(), wc.data_ptr(), zs[i - 1].data_ptr(), pars[i - 1].data_ptr(), _ptr(row_w),
                     sums2.data_ptr(), float(count))
             _lib.call("rtk_conv_bn_bwd", *args, 0, None, None, _stream())
             dzp = torch.empty_like(zs[i - 1])
