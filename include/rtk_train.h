@@ -59,6 +59,15 @@ RTK_EXPORT int rtk_bn_relu_bwd_apply(int samples, int channels, int rows, int ns
                                      const float *dy, const float *par, const float *row_weight, const double *sums2,
                                      double count, int pool, float *dz, float *dgamma_dbeta, rtk_stream_t stream);
 
+/* First layer of a set-abstraction SharedMLP from the per-point projection (conv([d_xyz || feats[idx]]) =
+ * Wx.d_xyz + (Wf.feats)[idx]):  z[b][c][row][k] = proj[b][c][idx[b][row][k]] + wx[c] . dxyz[b][:, row, k], and the weighted
+ * batch sums of z accumulated into sums (groups, C, 2) float64 (zero-initialised; as rtk_bn_train_stats).
+ * proj (samples, C, n_src), idx (samples, rows, ns) int32 in [0, n_src), dxyz (samples, 3, rows, ns), wx (C, 3) row-major,
+ * z (samples, C, rows, ns); ns a power of two >= 4. */
+RTK_EXPORT int rtk_sa_first_layer(int samples, int channels, int rows, int ns, int groups, int n_src, const float *proj, const int *idx,
+                                  const float *dxyz, const float *wx, const float *row_weight, float *z, double *sums,
+                                  rtk_stream_t stream);
+
 /* ---- 1x1 convolution fused with the BatchNorm work around it (set-abstraction SharedMLP layers 2, 3) ----------------
  * Tensors are NCHW planes (samples, C, rows*ns), ns a power of two >= 4, channel counts 16, 32 or 64.
  *

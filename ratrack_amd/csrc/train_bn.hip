@@ -88,6 +88,54 @@ __global__ __launch_bounds__(BN_T) void bn_stats_kernel(int samples, int channel
     }
 }
 
+// First layer of a set-abstraction SharedMLP in training mode, straight from the per-point projection:
+//   z1[b][c][row][k] = proj[b][c][idx[b][row][k]] + Wx[c] . dxyz[b][:, row, k]
+// (conv([d_xyz || feats[idx]]) = Wx.d_xyz + (Wf.feats)[idx], lib/pointnet2_utils.py:269-292 + lib/pytorch_utils.py:20-32)
+// written once, with the layer's weighted batch sums accumulated on the way -- instead of a gather kernel, a 3-channel
+// convolution, an addition and a statistics pass.  One workgroup per (channel, sample) plane; the plane's projection row
+// sits in LDS, so the gather never leaves the CU.
+__global__ __launch_bounds__(BN_T) void sa_first_layer_kernel(int samples, int channels, int rows, int lg_ns, int groups, int n_src,
+                                                              const float *__restrict__ proj, const int *__restrict__ idx,
+                                                              const float *__restrict__ dxyz, const float *__restrict__ wx,
+                                                              const float *__restrict__ rw, float *__restrict__ z,
+                                                              double *__restrict__ sums) {
+    extern __shared__ float s_proj[];
+    const Plane p = plane_of(samples, channels, rows, 1 << lg_ns, groups);
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int E = rows << lg_ns;                                   // multiple of 4 (ns >= 4)
+    const float *pr = proj + ((size_t)b * channels + c) * n_src;
+    for (int i = threadIdx.x; i < n_src; i += BN_T) s_proj[i] = pr[i];
+    __syncthreads();
+    const float w0 = wx[c * 3 + 0], w1 = wx[c * 3 + 1], w2 = wx[c * 3 + 2];
+    const int *ib = idx + (size_t)b * E;
+    const float *dx = dxyz + (size_t)b * 3 * E, *dy = dx + E, *dz = dy + E;
+    const float *w = rw ? rw + (size_t)b * rows : nullptr;
+    float *zp = z + p.base;
+    double s = 0.0, ss = 0.0;
+    for (int e4 = threadIdx.x; e4 < (E >> 2); e4 += BN_T) {
+        const int4 t = *reinterpret_cast<const int4 *>(ib + 4 * e4);
+        const float4 x = *reinterpret_cast<const float4 *>(dx + 4 * e4);
+        const float4 y = *reinterpret_cast<const float4 *>(dy + 4 * e4);
+        const float4 q = *reinterpret_cast<const float4 *>(dz + 4 * e4);
+        float4 v;
+        v.x = s_proj[t.x] + __fmaf_rn(w2, q.x, __fmaf_rn(w1, y.x, w0 * x.x));
+        v.y = s_proj[t.y] + __fmaf_rn(w2, q.y, __fmaf_rn(w1, y.y, w0 * x.y));
+        v.z = s_proj[t.z] + __fmaf_rn(w2, q.z, __fmaf_rn(w1, y.z, w0 * x.z));
+        v.w = s_proj[t.w] + __fmaf_rn(w2, q.w, __fmaf_rn(w1, y.w, w0 * x.w));
+        *reinterpret_cast<float4 *>(zp + 4 * e4) = v;
+        const double wi = w ? (double)w[(4 * e4) >> lg_ns] : 1.0;     // ns >= 4: the four positions share a row
+        const double a = v.x, bb = v.y, cc = v.z, d = v.w;
+        s += wi * ((a + bb) + (cc + d));
+        ss += wi * ((a * a + bb * bb) + (cc * cc + d * d));
+    }
+    block_sum2(s, ss);
+    if (threadIdx.x == 0) {
+        double *dst = sums + ((size_t)p.g * channels + c) * 2;
+        atomicAdd(dst, s);
+        atomicAdd(dst + 1, ss);
+    }
+}
+
 __global__ void bn_finalize_kernel(int channels, int groups, const double *__restrict__ sums, double count,
                                    const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
                                    float *__restrict__ running_mean, float *__restrict__ running_var,
@@ -432,5 +480,18 @@ extern "C" int rtk_bn_relu_bwd_apply(int samples, int channels, int rows, int ns
                                                        count, dz, dgamma_dbeta);
     }
     RTK_CHECK_LAUNCH("rtk_bn_relu_bwd_apply");
+    return RTK_OK;
+}
+
+extern "C" int rtk_sa_first_layer(int samples, int channels, int rows, int ns, int groups, int n_src, const float *proj, const int *idx,
+                                  const float *dxyz, const float *wx, const float *row_weight, float *z, double *sums,
+                                  rtk_stream_t stream) {
+    RTK_BN_COMMON_CHECKS("rtk_sa_first_layer");
+    RTK_REQUIRE(ns >= 4 && n_src > 0 && n_src <= 16384, "rtk_sa_first_layer: ns (%d) must be >= 4, n_src (%d) <= 16384", ns, n_src);
+    RTK_REQUIRE(proj && idx && dxyz && wx && z && sums, "rtk_sa_first_layer: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    sa_first_layer_kernel<<<dim3(channels, samples), BN_T, (size_t)n_src * 4, s>>>(samples, channels, rows, ilog2_exact(ns), groups, n_src,
+                                                                                proj, idx, dxyz, wx, row_weight, z, sums);
+    RTK_CHECK_LAUNCH("rtk_sa_first_layer");
     return RTK_OK;
 }

@@ -15,6 +15,7 @@ _LayerP = ctypes.POINTER(fused._Layer)
 _lib.SIGNATURES.update({
     "rtk_cost_volume_bwd": [_i] * 3 + [_p] * 6 + [_LayerP, _LayerP, _p, _p, _i, _i] + [_p] * 10 + [_p],
     "rtk_scatter_add_rows": [_i] * 4 + [_p] * 3 + [_p],
+    "rtk_sa_first_layer": [_i] * 6 + [_p] * 7 + [_p],
     "rtk_conv_bn_fwd": [_i] * 6 + [_p] * 7 + [_p],
     "rtk_conv_bn_bwd": [_i] * 6 + [_p] * 6 + [_d, _i, _p, _p, _p],
     "rtk_patch_cost_bwd": [_i, _i, _p, _p, _p, _i, _LayerP, _p, _p, _i, _p, _p, _p, _p, _p],
@@ -125,15 +126,19 @@ class _SAChain(torch.autograd.Function):
     for the weight gradient; the normalised activations are stored once for that GEMM, nothing else is materialised."""
 
     @staticmethod
-    def forward(ctx, z1, row_w, count, groups, bns, *tensors):
-        z1 = z1.contiguous()
-        S_, C1, rows, ns = z1.shape
-        dev = z1.device
+    def forward(ctx, proj, wx, idx, dxyz, row_w, count, groups, bns, *tensors):
+        proj = proj.contiguous()                                          # (S, C1, n_src)
+        S_, C1, n_src = proj.shape
+        _, rows, ns = idx.shape
+        dev = proj.device
         L = len(bns)
         weights = [None] + [tensors[3 * i - 1] for i in range(1, L)]        # tensors = g0, b0, W1, g1, b1, W2, g2, b2
         f64 = _SumsPool(groups, [C1] + [w.shape[0] for w in weights[1:]], dev)
         sums = f64(C1)
-        _lib.call("rtk_bn_train_stats", S_, C1, rows, ns, groups, z1.data_ptr(), _ptr(row_w), sums.data_ptr(), _stream())
+        z1 = torch.empty(S_, C1, rows, ns, dtype=torch.float32, device=dev)
+        wxc = wx.detach().reshape(C1, 3).contiguous()
+        _lib.call("rtk_sa_first_layer", S_, C1, rows, ns, groups, n_src, proj.data_ptr(), idx.data_ptr(), dxyz.data_ptr(), wxc.data_ptr(),
+                  _ptr(row_w), z1.data_ptr(), sums.data_ptr(), _stream())
         zs, ys, pars = [z1], [], [_bn_finalize(bns[0], sums, count, groups)]
         for i in range(1, L):
             W = weights[i]
@@ -150,15 +155,16 @@ class _SAChain(torch.autograd.Function):
         C = zs[-1].shape[1]
         out = torch.empty(S_, C, rows, dtype=torch.float32, device=dev)
         _lib.call("rtk_bn_relu_fwd", S_, C, rows, ns, groups, zs[-1].data_ptr(), pars[-1].data_ptr(), 1, out.data_ptr(), _stream())
-        ctx.save_for_backward(row_w, *zs, *ys, *pars, *[w for w in weights[1:]])
-        ctx.cfg = (count, groups, L)
+        ctx.save_for_backward(row_w, idx, dxyz, *zs, *ys, *pars, *[w for w in weights[1:]])
+        ctx.cfg = (count, groups, L, n_src)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        count, groups, L = ctx.cfg
+        count, groups, L, n_src = ctx.cfg
         saved = list(ctx.saved_tensors)
-        row_w = saved[0]
+        row_w, idx, dxyz = saved[0:3]
+        saved = saved[2:]
         zs, ys = saved[1:1 + L], saved[1 + L:2 * L]
         pars, weights = saved[2 * L:3 * L], [None] + saved[3 * L:]
         S_, _, rows, ns = zs[0].shape
@@ -193,7 +199,13 @@ class _SAChain(torch.autograd.Function):
         flat = [grads[0][1], grads[0][2]]
         for i in range(1, L):
             flat += [grads[i][0], grads[i][1], grads[i][2]]
-        return (dz, None, None, None, None) + tuple(flat)
+        # first layer: z1 = proj[idx] + Wx.dxyz  ->  dproj = scatter of dz over idx (LDS kernel), dWx = sum_b dz_b dxyz_b^T
+        C1 = dz.shape[1]
+        dproj = torch.zeros(S_, C1, n_src, dtype=torch.float32, device=dev)
+        from . import pointnet2_hip as _native
+        _native.group_points_grad_wrapper(S_, C1, n_src, rows, ns, dz, idx, dproj)
+        dwx = torch.bmm(dz.view(S_, C1, -1), dxyz.view(S_, 3, -1).transpose(1, 2)).sum(0).view(C1, 3, 1, 1)
+        return (dproj, dwx, None, None, None, None, None, None) + tuple(flat)
 
 
 def sa_chain_supported(layers):
@@ -201,15 +213,17 @@ def sa_chain_supported(layers):
     return len(layers) >= 2 and all(c in (16, 32, 64) for c in chans) and all(l.conv.bias is None for l in layers)
 
 
-def sa_chain(z1, layers, row_w, count, groups):
-    """z1 (S,C1,rows,ns): first layer's pre-activation; layers: the SharedMLP's Conv2d blocks (conv, bn.bn); returns the
-    max-pooled (S,C_last,rows) output of the chain.  Updates every BatchNorm's running statistics."""
+def sa_chain(proj, wx, idx, dxyz, layers, row_w, count, groups):
+    """proj (S,C1,n_src): per-point projection of the features by the first layer's feature columns; wx (C1,3,1,1): its
+    offset columns; idx (S,rows,ns) int32 ball-query indices; dxyz (S,3,rows,ns) neighbour offsets; layers: the SharedMLP's
+    Conv2d blocks (conv, bn.bn).  Returns the max-pooled (S,C_last,rows) output.  Updates every BatchNorm's running
+    statistics."""
     tensors = []
     for i, l in enumerate(layers):
         if i > 0:
             tensors.append(l.conv.weight)
         tensors += [l.bn.bn.weight, l.bn.bn.bias]
-    return _SAChain.apply(z1, row_w, float(count), int(groups), tuple(l.bn.bn for l in layers), *tensors)
+    return _SAChain.apply(proj, wx, idx, dxyz, row_w, float(count), int(groups), tuple(l.bn.bn for l in layers), *tensors)
 
 
 # ---- cost volume -------------------------------------------------------------------------------------------------------

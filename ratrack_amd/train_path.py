@@ -104,9 +104,9 @@ def _sa_scale(mlp, tg, lvl, s, feats, groups):
     ns = idx.shape[2]
     count = (tg.samples // groups) * tg.npoint * ns
     proj = conv1x1(feats.unsqueeze(-1), w[:, 3:]).squeeze(-1)     # per-POINT projection (a 1x1 conv and a gather commute)
-    z = conv1x1(tg.dxyz[lvl][s], w[:, :3]) + PU.grouping_operation(proj, idx)
     if FUSED_SA_CHAIN and sa_chain_supported(layers) and ns >= 4:
-        return sa_chain(z, layers, tg.row_w[lvl], count, groups)
+        return sa_chain(proj, w[:, :3], idx, tg.dxyz[lvl][s], layers, tg.row_w[lvl], count, groups)
+    z = conv1x1(tg.dxyz[lvl][s], w[:, :3]) + PU.grouping_operation(proj, idx)
     x = None
     for i, layer in enumerate(layers):
         if i > 0:
