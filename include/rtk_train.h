@@ -118,8 +118,9 @@ RTK_EXPORT int rtk_patch_cost_bwd(int samples, int n, const float *xyz, const in
                                   float *dq3, float *dt2, float *d4, rtk_stream_t stream);
 
 /* dst[b][idx[b][r]][:] += src[b][r][:] for r < m, dst (samples, n, channels) fully written (no zero-fill needed):
- * the scatter half of the backward of a row gather.  idx (samples, m) int64 in [0, n); channels % 32 == 0;
- * n * 128 bytes of LDS per workgroup (n <= 1024). */
+ * the scatter half of the backward of a row gather.  idx (samples, m) int64 in [0, n); channels % 32 == 0.
+ * channels == 256: partitioned by destination rows, deterministic, any n.  Otherwise: 32-channel slabs accumulated with
+ * LDS atomics, n * 128 bytes of LDS per workgroup (n <= 1024). */
 RTK_EXPORT int rtk_scatter_add_rows(int samples, int m, int n, int channels, const int64_t *idx, const float *src, float *dst,
                                     rtk_stream_t stream);
 

@@ -567,12 +567,69 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(int m, int n, int cha
     for (int e = threadIdx.x; e < n * SC_CH; e += 256) db[(size_t)(e / SC_CH) * channels + (e % SC_CH)] = s_acc[e];
 }
 
+// 256-channel variant, partitioned by DESTINATION: one workgroup owns 32 destination rows of one sample (32 KiB of LDS
+// accumulators, thread = channel, so no atomics at all) and walks the index list once; matching source rows are compacted
+// per 256-entry chunk (ballot + prefix, position order) and fetched as full coalesced 1 KiB rows, four in flight.
+// Deterministic: every destination element is accumulated by one thread in position order.
+#define SC_RB 32
+__global__ __launch_bounds__(256) void scatter_rows256_kernel(int m, int n, const int64_t *__restrict__ idx,
+                                                              const float *__restrict__ src, float *__restrict__ dst) {
+    __shared__ float s_acc[SC_RB][256];
+    __shared__ int s_list[256];
+    __shared__ int s_cnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, r0 = blockIdx.x * SC_RB;
+#pragma unroll
+    for (int r = 0; r < SC_RB; ++r) s_acc[r][tid] = 0.f;
+    const int64_t *ib = idx + (size_t)b * m;
+    const float *sb = src + (size_t)b * m * 256 + tid;
+    for (int base = 0; base < m; base += 256) {
+        const int p = base + tid;
+        const int t = p < m ? (int)ib[p] - r0 : -1;
+        const bool hit = t >= 0 && t < SC_RB;
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) s_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int c = s_cnt[w];
+            off += w < wave ? c : 0;
+            total += c;
+        }
+        if (hit) s_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = tid | (t << 8);
+        __syncthreads();
+        int q = 0;
+        for (; q + 4 <= total; q += 4) {
+            const int e0 = s_list[q], e1 = s_list[q + 1], e2 = s_list[q + 2], e3 = s_list[q + 3];
+            const float v0 = sb[(size_t)(base + (e0 & 255)) * 256], v1 = sb[(size_t)(base + (e1 & 255)) * 256];
+            const float v2 = sb[(size_t)(base + (e2 & 255)) * 256], v3 = sb[(size_t)(base + (e3 & 255)) * 256];
+            s_acc[e0 >> 8][tid] += v0;
+            s_acc[e1 >> 8][tid] += v1;
+            s_acc[e2 >> 8][tid] += v2;
+            s_acc[e3 >> 8][tid] += v3;
+        }
+        for (; q < total; ++q) {
+            const int e = s_list[q];
+            s_acc[e >> 8][tid] += sb[(size_t)(base + (e & 255)) * 256];
+        }
+        __syncthreads();
+    }
+    float *db = dst + ((size_t)b * n + r0) * 256 + tid;
+    for (int r = 0; r < SC_RB && r0 + r < n; ++r) db[(size_t)r * 256] = s_acc[r][tid];
+}
+
 extern "C" int rtk_scatter_add_rows(int samples, int m, int n, int channels, const int64_t *idx, const float *src, float *dst,
                                     rtk_stream_t stream) {
     RTK_REQUIRE(samples > 0 && m > 0 && n > 0 && channels > 0 && channels % SC_CH == 0 && idx && src && dst,
                 "scatter_add_rows: bad arguments (channels must be a multiple of %d)", SC_CH);
-    RTK_REQUIRE((size_t)n * SC_CH * 4 <= 128 * 1024, "scatter_add_rows: n (%d) too large for the LDS slab", n);
+    RTK_REQUIRE(channels == 256 || (size_t)n * SC_CH * 4 <= 128 * 1024, "scatter_add_rows: n (%d) too large for the LDS slab", n);
     RTK_REQUIRE(samples <= 65535, "scatter_add_rows: too many samples");
+    if (channels == 256) {
+        scatter_rows256_kernel<<<dim3((n + SC_RB - 1) / SC_RB, samples), 256, 0, (hipStream_t)stream>>>(m, n, idx, src, dst);
+        RTK_CHECK_LAUNCH("scatter_add_rows");
+        return RTK_OK;
+    }
     const size_t lds = (size_t)n * SC_CH * 4;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

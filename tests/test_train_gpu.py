@@ -186,9 +186,10 @@ def test_cost_volume_operator_matches_module_autograd(B, N):
         assert err <= 2e-4 * ref + 1e-7, (k, err, ref)
 
 
-def test_scatter_add_rows_matches_index_add():
+@pytest.mark.parametrize("m,n,C", [(1000, 77, 64), (4096, 256, 256), (1111, 300, 256), (16384, 1024, 256)])
+def test_scatter_add_rows_matches_index_add(m, n, C):
     from ratrack_amd import _lib, train_ops  # noqa: F401
-    B, m, n, C = 3, 1000, 77, 64
+    B = 3
     g = torch.Generator(DEV).manual_seed(1)
     idx = torch.randint(0, n, (B, m), device=DEV, generator=g)
     src = torch.randn(B, m, C, device=DEV, generator=g)
