@@ -88,6 +88,12 @@ RTK_EXPORT int rtk_conv_bn_bwd(int samples, int cprev, int cout, int rows, int n
                                const float *zprev, const float *pre_par, const float *row_weight, double *sums2, double count, int apply,
                                float *dzprev, float *dgamma_dbeta, rtk_stream_t stream);
 
+/* Weight gradient of the same layer: dw (cout, cprev) row-major fp32, ZERO-INITIALISED by the caller,
+ * += sum over samples and positions of dz (x) relu(BatchNorm(zprev)); the normalised activation is recomputed from zprev
+ * and pre_par on load.  Accumulated with float atomics (order-dependent in the last bits). */
+RTK_EXPORT int rtk_conv_wgrad(int samples, int cprev, int cout, int rows, int ns, int groups, const float *dz, const float *zprev,
+                              const float *pre_par, float *dw, rtk_stream_t stream);
+
 /* ---- cost volume (utils/model_utils/model_utils.py:216-236) ------------------------------------------------------
  * Backward of rtk_cost_volume (rtk_fused.h; same forward arguments).  layers[0..3] = the packed 256x256 layers
  * W2, W3, W3^T, W2^T, contiguous in memory (biases of W2, W3 in layers[0], layers[1]); wct_packed = the packed

@@ -202,6 +202,84 @@ __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
     }
 }
 
+// Weight gradient of z = W relu(BatchNorm(zprev)):  dW[co][ci] += sum_{b,p} dz[b][co][p] * a[b][ci][p],  a recomputed from
+// zprev on load (the forward does not have to store it).  Both operands are contiguous along the contraction axis p, so
+// a lane's float4 along p IS four MFMA k-steps:  k-step s of lane group g contracts position p0 + 4g + s, for the A operand
+// (lane (g,i) <- dz row 16v+i) and the B operand (lane (g,j) <- a row 16u+j) alike.  The 16V x 16U accumulator block stays
+// in registers over the wave's whole position range; waves are reduced through LDS, workgroups with float atomics.
+template <int U, int V>
+__global__ __launch_bounds__(TC_T, 2) void conv_wgrad_kernel(const TcParams Q) {
+    __shared__ float s_red[16 * V][16 * U + 1];
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int grp = b / (Q.samples / Q.groups);
+    const int P = Q.P;
+    const unsigned pitch = 4u * (unsigned)P;
+    const char *dzb = reinterpret_cast<const char *>(Q.in + (size_t)b * 16 * V * P);        // dz (S, 16V, P)
+    const char *zpb = reinterpret_cast<const char *>(Q.zprev + (size_t)b * 16 * U * P);     // zprev (S, 16U, P)
+    float sc[U], sh[U];
+    {
+        const size_t GC = (size_t)Q.groups * 16 * U, o = (size_t)grp * 16 * U;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            sc[u] = Q.pre[2 * GC + o + 16 * u + j];
+            sh[u] = Q.pre[3 * GC + o + 16 * u + j];
+        }
+    }
+    f4 acc[V][U];
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[v][u] = f4_zero();
+    const int ntiles = (P + 15) / 16;
+    for (int t = blockIdx.x * (TC_T / 64) + wave; t < ntiles; t += gridDim.x * (TC_T / 64)) {
+        const int p = 16 * t + 4 * g;
+        const bool ok = p < P;
+        f4 a[V], bq[U];
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+            a[v] = ok ? *reinterpret_cast<const f4 *>(dzb + (unsigned)(16 * v + j) * pitch + 4u * (unsigned)p) : f4_zero();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            f4 x = ok ? *reinterpret_cast<const f4 *>(zpb + (unsigned)(16 * u + j) * pitch + 4u * (unsigned)p) : f4_zero();
+            x.x = fmaxf(__fmaf_rn(x.x, sc[u], sh[u]), 0.f);
+            x.y = fmaxf(__fmaf_rn(x.y, sc[u], sh[u]), 0.f);
+            x.z = fmaxf(__fmaf_rn(x.z, sc[u], sh[u]), 0.f);
+            x.w = fmaxf(__fmaf_rn(x.w, sc[u], sh[u]), 0.f);
+            bq[u] = ok ? x : f4_zero();
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc[v][u] = mfma4(a[v].x, bq[u].x, acc[v][u]);
+                acc[v][u] = mfma4(a[v].y, bq[u].y, acc[v][u]);
+                acc[v][u] = mfma4(a[v].z, bq[u].z, acc[v][u]);
+                acc[v][u] = mfma4(a[v].w, bq[u].w, acc[v][u]);
+            }
+    }
+    // D layout: acc[v][u][r] = dW[16v + 4g + r][16u + j]; the four waves add into one LDS image in turn
+    for (int w = 0; w < TC_T / 64; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float &d = s_red[16 * v + 4 * g + r][16 * u + j];
+                        d = w == 0 ? acc[v][u][r] : d + acc[v][u][r];
+                    }
+        }
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < 16 * V * 16 * U; e += TC_T) {
+        const int co = e / (16 * U), ci = e % (16 * U);
+        const float sum = s_red[co][ci];
+        atomicAdd(Q.out + (size_t)co * 16 * U + ci, sum);
+    }
+}
+
 int ilog2x(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
@@ -273,5 +351,26 @@ extern "C" int rtk_conv_bn_bwd(int samples, int cprev, int cout, int rows, int n
     if (apply) launch<2>(Q, cout, cprev, (hipStream_t)stream);
     else launch<1>(Q, cout, cprev, (hipStream_t)stream);
     RTK_CHECK_LAUNCH("rtk_conv_bn_bwd");
+    return RTK_OK;
+}
+
+extern "C" int rtk_conv_wgrad(int samples, int cprev, int cout, int rows, int ns, int groups, const float *dz, const float *zprev,
+                              const float *pre_par, float *dw, rtk_stream_t stream) {
+    if (int rc = check("rtk_conv_wgrad", samples, cprev, cout, rows, ns, groups)) return rc;
+    RTK_REQUIRE(dz && zprev && pre_par && dw, "rtk_conv_wgrad: null argument");
+    TcParams Q = {};
+    Q.samples = samples; Q.rows = rows; Q.lg_ns = ilog2x(ns); Q.groups = groups; Q.P = rows * ns;
+    Q.in = dz; Q.zprev = zprev; Q.pre = pre_par; Q.out = dw;
+    const int U = cprev / 16, V = cout / 16;
+    const int ntiles = (Q.P + 15) / 16;
+    int gx = (ntiles + 3) / 4;
+    while ((long)gx * samples > 512 && gx > 1) gx = (gx + 1) / 2;      // every workgroup ends with 256 U V atomics: keep them few
+    const dim3 grid(gx, samples);
+    hipStream_t s = (hipStream_t)stream;
+#define TW_CASE(u, v)                                        \
+    if (U == u && V == v) conv_wgrad_kernel<u, v><<<grid, TC_T, 0, s>>>(Q);
+    TW_CASE(1, 1) TW_CASE(1, 2) TW_CASE(1, 4) TW_CASE(2, 1) TW_CASE(2, 2) TW_CASE(2, 4) TW_CASE(4, 1) TW_CASE(4, 2) TW_CASE(4, 4)
+#undef TW_CASE
+    RTK_CHECK_LAUNCH("rtk_conv_wgrad");
     return RTK_OK;
 }

@@ -17,6 +17,7 @@ _lib.SIGNATURES.update({
     "rtk_scatter_add_rows": [_i] * 4 + [_p] * 3 + [_p],
     "rtk_sa_first_layer": [_i] * 6 + [_p] * 7 + [_p],
     "rtk_conv_bn_fwd": [_i] * 6 + [_p] * 7 + [_p],
+    "rtk_conv_wgrad": [_i] * 6 + [_p] * 4 + [_p],
     "rtk_conv_bn_bwd": [_i] * 6 + [_p] * 6 + [_d, _i, _p, _p, _p],
     "rtk_patch_cost_bwd": [_i, _i, _p, _p, _p, _i, _LayerP, _p, _p, _i, _p, _p, _p, _p, _p],
     "rtk_bn_train_stats": [_i] * 5 + [_p] * 3 + [_p],
@@ -145,17 +146,15 @@ class _SAChain(torch.autograd.Function):
             Co, Ci = W.shape[0], W.shape[1]
             wc = W.detach().contiguous()
             z = torch.empty(S_, Co, rows, ns, dtype=torch.float32, device=dev)
-            y = torch.empty(S_, Ci, rows, ns, dtype=torch.float32, device=dev)
             sums = f64(Co)
             _lib.call("rtk_conv_bn_fwd", S_, Ci, Co, rows, ns, groups, zs[-1].data_ptr(), pars[-1].data_ptr(), wc.data_ptr(), z.data_ptr(),
-                      y.data_ptr(), _ptr(row_w), sums.data_ptr(), _stream())
+                      None, _ptr(row_w), sums.data_ptr(), _stream())      # the normalised input is NOT stored (rtk_conv_wgrad recomputes it)
             pars.append(_bn_finalize(bns[i], sums, count, groups))
             zs.append(z)
-            ys.append(y)
         C = zs[-1].shape[1]
         out = torch.empty(S_, C, rows, dtype=torch.float32, device=dev)
         _lib.call("rtk_bn_relu_fwd", S_, C, rows, ns, groups, zs[-1].data_ptr(), pars[-1].data_ptr(), 1, out.data_ptr(), _stream())
-        ctx.save_for_backward(row_w, idx, dxyz, *zs, *ys, *pars, *[w for w in weights[1:]])
+        ctx.save_for_backward(row_w, idx, dxyz, *zs, *pars, *[w for w in weights[1:]])
         ctx.cfg = (count, groups, L, n_src)
         return out
 
@@ -165,8 +164,8 @@ class _SAChain(torch.autograd.Function):
         saved = list(ctx.saved_tensors)
         row_w, idx, dxyz = saved[0:3]
         saved = saved[2:]
-        zs, ys = saved[1:1 + L], saved[1 + L:2 * L]
-        pars, weights = saved[2 * L:3 * L], [None] + saved[3 * L:]
+        zs = saved[1:1 + L]
+        pars, weights = saved[1 + L:1 + 2 * L], [None] + saved[1 + 2 * L:]
         S_, _, rows, ns = zs[0].shape
         dev = dout.device
         dout = dout.contiguous()
@@ -181,10 +180,15 @@ class _SAChain(torch.autograd.Function):
         _lib.call("rtk_bn_relu_bwd_apply", S_, C, rows, ns, groups, zs[-1].data_ptr(), dout.data_ptr(), pars[-1].data_ptr(), _ptr(row_w),
                   sums2.data_ptr(), float(count), 1, dz.data_ptr(), dgb.data_ptr(), _stream())
         grads = {L - 1: (None, dgb[0], dgb[1])}
+        dwbuf = torch.zeros(sum(w.numel() for w in weights[1:]), dtype=torch.float32, device=dev)      # all dW of the chain, one fill
+        dwoff = 0
         for i in range(L - 1, 0, -1):
             W = weights[i]
             Co, Ci = W.shape[0], W.shape[1]
-            dW = torch.bmm(dz.view(S_, Co, -1), ys[i - 1].view(S_, Ci, -1).transpose(1, 2)).sum(0).view_as(W)
+            dW = dwbuf[dwoff:dwoff + W.numel()].view_as(W)
+            dwoff += W.numel()
+            _lib.call("rtk_conv_wgrad", S_, Ci, Co, rows, ns, groups, dz.data_ptr(), zs[i - 1].data_ptr(), pars[i - 1].data_ptr(),
+                      dW.data_ptr(), _stream())
             wc = W.contiguous()
             sums2 = f64(Ci)
             args = (S_, Ci, Co, rows, ns, groups, dz.data_ptr(), wc.data_ptr(), zs[i - 1].data_ptr(), pars[i - 1].data_ptr(), _ptr(row_w),

@@ -17,4 +17,4 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
     for _ in range(3): step()
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=70))
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=400, max_name_column_width=70))
