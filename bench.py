@@ -68,6 +68,67 @@ def cpu_baseline(batch, n, budget_s=20.0):
             "sample": "%d forward passes of the CPU oracle at B=%d, N=%d (%.1f s)" % (runs, batch, n, el)}
 
 
+def time_cost_volume_bwd(batch, n, dev, iters=10):
+    """Dominant kernel of the train step (cost_volume_bwd_kernel: forward recompute + both 256x256 input gradients of the
+    cost volume, 4 x 2 x 256 x 256 MACs per (point, neighbour) pair) timed live with HIP events at the bench shape."""
+    from ratrack_amd import _lib, train_ops
+    from ratrack_amd.fused import pack_layer
+    g = torch.Generator(dev).manual_seed(0)
+    r = lambda *sh: torch.randn(*sh, device=dev, generator=g)
+    B, M = batch, batch * n * 16
+    xyz1, xyz2 = r(B, n, 3).contiguous(), r(B, n, 3).contiguous()
+    knn = torch.randint(0, n, (B, n, 16), device=dev, generator=g)
+    p1, p2, dout = r(B * n, 256), r(B * n, 256), r(B * n, 256)
+    w2, w3 = r(256, 256) * 0.06, r(256, 256) * 0.06
+    W = train_ops._CvWeights(r(256, 3), w2, r(256), w3, r(256), r(8, 3), r(8), r(8, 8), r(8), r(256, 8), r(256), backward=True)
+    wct = pack_layer(r(8, 256))
+    big = torch.empty(6, M, 256, device=dev)
+    d4, dt2 = torch.empty(M, 4, device=dev), torch.empty(M, 8, device=dev)
+    dp1, dpd = torch.empty(B * n, 256, device=dev), torch.empty(B * n, 3, 256, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def launch():
+        _lib.call("rtk_cost_volume_bwd", B, n, n, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
+                  W.wd.data_ptr(), W.layers, W.wn, wct.data_ptr(), dout.data_ptr(), 256, 256, big[0].data_ptr(), big[1].data_ptr(),
+                  big[2].data_ptr(), big[3].data_ptr(), big[4].data_ptr(), big[5].data_ptr(), d4.data_ptr(), dp1.data_ptr(),
+                  dpd.data_ptr(), dt2.data_ptr(), st)
+    for _ in range(3):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * M * (4 * 256 * 256 + 3 * 256 + 2136 + 256 + 8 * 256)
+    return ms, flops
+
+
+def cpu_train_baseline(batch, n, budget_s=20.0):
+    """The CPU oracle's train step (train-mode forward + multi-task loss + backward, torch-CPU autograd over the C ops)."""
+    from oracle import track4d_ref as R
+    from ratrack_amd import loss as L
+    from ratrack_amd import synth
+    from ratrack_amd.track4d import Args, Track4D
+    net = Track4D(Args())
+    synth.fill_state_dict(net.state_dict())
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in net.state_dict().items()}
+    d = synth.make_frame_pairs(batch, n, case_id=98)
+    t = {k: torch.from_numpy(v) for k, v in d.items()}
+    runs, t0 = 0, time.perf_counter()
+    while True:
+        flow, h, cls, *_ = R.backbone(sd, t["pc1"], t["pc2"], t["feature1"], t["feature2"], None, training=True)
+        total, _ = L.backbone_loss(t["pc1"] + flow, cls, t["gt_warp"], t["gt_cls"])      # a few reductions, device-agnostic
+        total.backward()
+        runs += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or runs >= 10:
+            break
+    return {"value": round(batch * runs / el, 3), "unit": "frame-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d train steps (forward + loss + backward) of the CPU oracle at B=%d, N=%d (%.1f s)" % (runs, batch, n, el)}
+
+
 def bench_train(a, net, d, dev, dist, world, rank):
     """Train step per rank on B frame-pairs: train-mode forward (HIP ops + PyTorch-ROCm dense layers, autograd),
     multi-task loss, backward, ONE flat gradient all-reduce over RCCL, Adam.  Weak scaling (B per GPU fixed)."""
@@ -97,14 +158,26 @@ def bench_train(a, net, d, dev, dist, world, rank):
     el = float(el.item())
     if rank == 0:
         pairs = a.batch * world * a.steps / el
+        kms, kflops = time_cost_volume_bwd(a.batch, a.npoints, dev)
+        ach = kflops / (kms * 1e-3) / 1e12
+        roof = {"kernel": "cost_volume_bwd_kernel", "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": None, "kernel_ms": round(kms, 4), "flops_per_launch": kflops,
+                "share_of_step": round(kms / (el / a.steps * 1e3), 3)}
+        cpu = None
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                cpu = cpu_train_baseline(min(a.batch, 4), a.npoints)
+            except Exception as e:          # the baseline is a reported extra, never a reason to lose the measurement
+                cpu = {"error": repr(e)[:200]}
         print(json.dumps({
             "metric": "radar frame-pairs/sec (train step) at B=%d,N=%d per GPU" % (a.batch, a.npoints), "value": round(pairs, 1),
             "unit": "frame-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Track4D.backbone train step (fwd+loss+bwd+grad all-reduce+Adam), B=%d x N=%d per GPU, hipGraph=%s"
                                    % (a.batch, a.npoints, not a.no_graph), "global_batch": a.batch * world,
-                       "parallelism": "dp%d, one flat RCCL all-reduce of %d bytes per step" % (world, tr.reducer.payload_bytes)},
-            "roofline": None, "cpu_baseline": None}), flush=True)
+                       "parallelism": "dp%d, one flat RCCL all-reduce of %d bytes per step" % (
+                           world, tr.reducer.payload_bytes or 4 * sum(p.numel() for p in net.parameters() if p.grad is not None))},
+            "roofline": roof, "cpu_baseline": cpu}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
