@@ -239,3 +239,50 @@ def test_graphed_trainer_matches_eager():
     assert np.isfinite(ld).all() and moved_g > 0
     assert abs(moved_g - moved_e) <= 0.05 * moved_e, (moved_g, moved_e)
     np.testing.assert_allclose(ld[:3], lc[:3], rtol=1e-3)          # the eager warm-up steps
+
+
+@pytest.mark.parametrize("chans,ns,U,n_src,groups", [([16, 16, 32], 4, 200, 200, 2), ([32, 32], 8, 57, 100, 1), ([32, 64], 16, 242, 242, 2),
+                                                      ([64, 64], 32, 100, 256, 1)])
+def test_fused_sa_chain_matches_unfused_operators(chans, ns, U, n_src, groups):
+    """The fused set-abstraction chain (first-layer kernel, conv+BN kernels, MFMA weight gradient, two-pass backward) against
+    the same chain built from bn_relu + framework convolutions, on odd sizes (positions not a multiple of 64, dead rows,
+    two statistics groups): output, gradients of the projection input and of every parameter, running statistics."""
+    import copy
+    import types
+    from ratrack_amd import train_path as TP
+    from ratrack_amd.pytorch_utils import SharedMLP
+    torch.manual_seed(sum(chans) + ns)
+    S_, npoint, Cf = 4, 512, 24
+    mlp0 = SharedMLP([3 + Cf] + chans, bn=True).to(DEV)
+    with torch.no_grad():
+        for p in mlp0.parameters():
+            p.mul_(1.5).add_(torch.randn_like(p) * 0.05)
+    nuniq = torch.tensor([U, max(U - 13, 1), U, max(U // 2, 1)], device=DEV)
+    ar = torch.arange(U, device=DEV).view(1, U)
+    row_w = (ar < nuniq.view(S_, 1)).float()
+    row_w[:, 0] += (npoint - nuniq).float()
+    g = torch.Generator(DEV).manual_seed(3)
+    tg = types.SimpleNamespace(samples=S_, npoint=npoint, row_w=[row_w.contiguous()],
+                               ball=[[torch.randint(0, n_src, (S_, U, ns), device=DEV, generator=g, dtype=torch.int32)]],
+                               dxyz=[[torch.randn(S_, 3, U, ns, device=DEV, generator=g)]])
+    res = []
+    for fused_chain in (True, False):
+        mlp = copy.deepcopy(mlp0)
+        feats = torch.randn(S_, Cf, n_src, device=DEV, generator=torch.Generator(DEV).manual_seed(5)).requires_grad_(True)
+        TP.FUSED_SA_CHAIN = fused_chain
+        try:
+            out = TP._sa_scale(mlp, tg, 0, 0, feats, groups)
+        finally:
+            TP.FUSED_SA_CHAIN = True
+        live = (ar < nuniq.view(S_, 1)).view(S_, 1, U).expand_as(out)
+        ct = torch.randn(out.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(9)) * live
+        out.backward(ct)
+        res.append((out.detach()[live], feats.grad.clone(), {k: p.grad.clone() for k, p in mlp.named_parameters()},
+                    {k: v.clone() for k, v in mlp.state_dict().items() if "running" in k}))
+    (oa, fa, ga, sa), (ob, fb, gb, sb) = res
+    assert float((oa - ob).abs().max()) <= 1e-4 * float(ob.abs().max())
+    assert float((fa - fb).norm()) <= 2e-4 * float(fb.norm())
+    for k in gb:
+        assert float((ga[k] - gb[k]).norm()) <= 2e-4 * float(gb[k].norm()) + 1e-6, k
+    for k in sb:
+        assert float((sa[k] - sb[k]).abs().max()) <= 1e-5 * float(sb[k].abs().max()) + 1e-7, k
