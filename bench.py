@@ -135,7 +135,10 @@ def bench_train(a, net, d, dev, dist, world, rank):
     from ratrack_amd.ddp import broadcast_parameters
     from ratrack_amd.train import Trainer
     broadcast_parameters(net)
-    tr = Trainer(net, graph=not a.no_graph)
+    # whole-step capture is validated on one GPU; with a collective inside (RCCL all-reduce under stream capture) it is opt-in
+    # until it has been run on a multi-GPU node
+    use_graph = (not a.no_graph) and (world == 1 or os.environ.get("RTK_TRAIN_GRAPH_DDP") == "1")
+    tr = Trainer(net, graph=use_graph)
     t = {k: torch.from_numpy(v).to(dev) for k, v in d.items()}
     h = torch.zeros(5, a.batch, 128, device=dev)
     step = lambda: tr.step(t["pc1"], t["pc2"], t["feature1"], t["feature2"], t["gt_warp"], t["gt_cls"], h)
@@ -174,7 +177,7 @@ def bench_train(a, net, d, dev, dist, world, rank):
             "unit": "frame-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Track4D.backbone train step (fwd+loss+bwd+grad all-reduce+Adam), B=%d x N=%d per GPU, hipGraph=%s"
-                                   % (a.batch, a.npoints, not a.no_graph), "global_batch": a.batch * world,
+                                   % (a.batch, a.npoints, use_graph), "global_batch": a.batch * world,
                        "parallelism": "dp%d, one flat RCCL all-reduce of %d bytes per step" % (
                            world, tr.reducer.payload_bytes or 4 * sum(p.numel() for p in net.parameters() if p.grad is not None))},
             "roofline": roof, "cpu_baseline": cpu}), flush=True)

@@ -126,6 +126,13 @@ class _Predictor(nn.Module):
 
     def _trunk(self, feat):
         x = feat.unsqueeze(3)
+        if self.training and x.is_cuda and torch.is_grad_enabled():
+            # training on the GPU: 1x1 conv with a GEMM weight gradient + the fused BatchNorm/ReLU operator (train_ops.py);
+            # same parameters, statistics and running-stat updates as the nn.Sequential blocks below
+            from .train_ops import bn_relu, conv1x1
+            for block in self.sf_mlp:
+                x = bn_relu(conv1x1(x, block[0].weight), block[1])
+            return conv1x1(x, self.conv2.weight).squeeze(3)
         for block in self.sf_mlp:
             x = block(x)
         return self.conv2(x).squeeze(3)
