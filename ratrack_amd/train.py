@@ -12,7 +12,10 @@ def make_optimizer(model, lr=1e-3, capturable=False):
     """Adam(lr=1e-3, weight_decay=1e-10) + StepLR(step=1, gamma=0.97) as main.py:61-62."""
     if capturable:      # a device-resident learning rate: the scheduler updates it in place, the captured graph reads it
         lr = torch.tensor(float(lr), device=next(model.parameters()).device)
-    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=1e-10, capturable=capturable)
+    # fused: ONE multi-tensor kernel per step; the foreach implementation in capturable mode issues ~200 tiny kernels for the
+    # per-parameter step counters and bias corrections
+    on_gpu = next(model.parameters()).is_cuda
+    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=1e-10, capturable=capturable, fused=on_gpu)
     sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.97)
     return opt, sched
 
