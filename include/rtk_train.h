@@ -123,6 +123,17 @@ RTK_EXPORT int rtk_patch_cost_bwd(int samples, int n, const float *xyz, const in
                                   const rtk_layer_t *wn, const float *wct_packed, const float *dout, int dout_pitch, float *dxg,
                                   float *dq3, float *dt2, float *d4, rtk_stream_t stream);
 
+/* ---- GRU step (fd_layer.torchGRU on a length-1 sequence, utils/model_utils/model_utils.py:279,296) -------------------
+ * Backward of rtk_gru_step (rtk_fused.h).  x (B,H), h_in / h_out (L,B,H) as in the forward; w_ih_t, w_hh_t the TRANSPOSED
+ * weights (L,H,3H) of the forward, w_ih, w_hh the original (L,3H,H), b_ih, b_hh (L,3H); dy (B,H) gradient of y = h_out[L-1],
+ * dh_out (L,B,H) gradient of h_out (may be NULL).  Outputs: dx (B,H), dh_in (L,B,H), and the gate gradients dgi, dgh
+ * (L,B,3H) from which the caller forms dW_ih[l] = dgi[l]^T x_l, dW_hh[l] = dgh[l]^T h_in[l], db = column sums
+ * (x_0 = x, x_l = h_out[l-1]).  H = 128. */
+RTK_EXPORT int rtk_gru_step_bwd(int b, int layers, int hidden, const float *x, const float *h_in, const float *h_out,
+                                const float *w_ih_t, const float *w_hh_t, const float *w_ih, const float *w_hh, const float *b_ih,
+                                const float *b_hh, const float *dy, const float *dh_out, float *dx, float *dh_in, float *dgi, float *dgh,
+                                rtk_stream_t stream);
+
 /* dst[b][idx[b][r]][:] += src[b][r][:] for r < m, dst (samples, n, channels) fully written (no zero-fill needed):
  * the scatter half of the backward of a row gather.  idx (samples, m) int64 in [0, n); channels % 32 == 0.
  * channels == 256: partitioned by destination rows, deterministic, any n.  Otherwise: 32-channel slabs accumulated with

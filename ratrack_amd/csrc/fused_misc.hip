@@ -5,6 +5,7 @@
 
 #include "rtk_common.h"
 #include "rtk_fused.h"
+#include "rtk_train.h"
 
 // ------------------------------------------------------------------------------------------------
 // rtk_prepare_inputs
@@ -85,6 +86,103 @@ extern "C" int rtk_gru_step(int b, int layers, int hidden, const float *x, const
                 w_hh && b_ih && b_hh && h_out && y, "gru_step: bad arguments (hidden=%d, layers=%d)", hidden, layers);
     gru_step_kernel<<<b, 384, 0, (hipStream_t)stream>>>(b, layers, hidden, x, h_in, w_ih, w_hh, b_ih, b_hh, h_out, y);
     RTK_CHECK_LAUNCH("gru_step");
+    return RTK_OK;
+}
+
+// Backward of rtk_gru_step.  Samples are independent, so one workgroup walks one sample down the layer stack: gates are
+// recomputed from (x_l, h_in_l) exactly as in the forward, the gate gradients dgi / dgh (L,B,3H) are stored for the weight
+// gradients (two batched GEMMs on the host side: dW_ih[l] = dgi[l]^T x_l, dW_hh[l] = dgh[l]^T h_in[l]) and propagated through
+// W_ih^T / W_hh^T (original (L,3H,H) layout: consecutive threads read consecutive addresses).
+//   r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r gh_n), h' = (1 - z) n + z h
+__global__ __launch_bounds__(384) void gru_step_bwd_kernel(int b, int layers, int hidden, const float *__restrict__ x,
+                                                           const float *__restrict__ h_in, const float *__restrict__ h_out,
+                                                           const float *__restrict__ w_ih_t, const float *__restrict__ w_hh_t,
+                                                           const float *__restrict__ w_ih, const float *__restrict__ w_hh,
+                                                           const float *__restrict__ b_ih, const float *__restrict__ b_hh,
+                                                           const float *__restrict__ dy, const float *__restrict__ dh_out,
+                                                           float *__restrict__ dx, float *__restrict__ dh_in, float *__restrict__ dgi,
+                                                           float *__restrict__ dgh) {
+    __shared__ float s_x[128], s_h[128], s_gi[384], s_gh[384], s_dx[3][128], s_dh[3][128], s_carry[128], s_direct[128];
+    const int s = blockIdx.x, t = threadIdx.x, H = hidden;
+    if (t < H) s_carry[t] = dy[(long)s * H + t];
+    for (int l = layers - 1; l >= 0; --l) {
+        if (t < H) {
+            s_x[t] = l == 0 ? x[(long)s * H + t] : h_out[((long)(l - 1) * b + s) * H + t];
+            s_h[t] = h_in[((long)l * b + s) * H + t];
+        }
+        __syncthreads();
+        if (t < 3 * H) {
+            const float *wi = w_ih_t + (long)l * H * 3 * H + t;
+            const float *wh = w_hh_t + (long)l * H * 3 * H + t;
+            float ai = b_ih[l * 3 * H + t], ah = b_hh[l * 3 * H + t];
+#pragma unroll 8
+            for (int k = 0; k < H; ++k) {
+                ai = fmaf(wi[(long)k * 3 * H], s_x[k], ai);
+                ah = fmaf(wh[(long)k * 3 * H], s_h[k], ah);
+            }
+            s_gi[t] = ai;
+            s_gh[t] = ah;
+        }
+        __syncthreads();
+        float g_r = 0.f, g_z = 0.f, g_n = 0.f, g_nr = 0.f;
+        if (t < H) {
+            const float r = 1.f / (1.f + expf(-(s_gi[t] + s_gh[t])));
+            const float z = 1.f / (1.f + expf(-(s_gi[H + t] + s_gh[H + t])));
+            const float hn = s_gh[2 * H + t];
+            const float nn = tanhf(s_gi[2 * H + t] + r * hn);
+            const float dhp = s_carry[t] + (dh_out ? dh_out[((long)l * b + s) * H + t] : 0.f);
+            const float dn = dhp * (1.f - z) * (1.f - nn * nn);
+            g_n = dn;
+            g_nr = dn * r;
+            g_r = dn * hn * r * (1.f - r);
+            g_z = dhp * (s_h[t] - nn) * z * (1.f - z);
+            s_direct[t] = dhp * z;
+        }
+        __syncthreads();        // every thread has read s_gi / s_gh
+        if (t < H) {
+            s_gi[t] = g_r; s_gi[H + t] = g_z; s_gi[2 * H + t] = g_n;
+            s_gh[t] = g_r; s_gh[H + t] = g_z; s_gh[2 * H + t] = g_nr;
+        }
+        __syncthreads();
+        if (t < 3 * H) {
+            dgi[((long)l * b + s) * 3 * H + t] = s_gi[t];
+            dgh[((long)l * b + s) * 3 * H + t] = s_gh[t];
+        }
+        {   // dx = W_ih^T dgi, dh = W_hh^T dgh: thread (part, j) sums a third of the 3H rows
+            const int part = t / H, j = t % H;
+            if (part < 3) {
+                const float *wi = w_ih + ((long)l * 3 * H + (long)part * H) * H + j;
+                const float *wh = w_hh + ((long)l * 3 * H + (long)part * H) * H + j;
+                float ax = 0.f, ah = 0.f;
+#pragma unroll 8
+                for (int i = 0; i < H; ++i) {
+                    ax = fmaf(wi[(long)i * H], s_gi[part * H + i], ax);
+                    ah = fmaf(wh[(long)i * H], s_gh[part * H + i], ah);
+                }
+                s_dx[part][j] = ax;
+                s_dh[part][j] = ah;
+            }
+        }
+        __syncthreads();
+        if (t < H) {
+            const float gx = s_dx[0][t] + s_dx[1][t] + s_dx[2][t];
+            dh_in[((long)l * b + s) * H + t] = s_direct[t] + (s_dh[0][t] + s_dh[1][t] + s_dh[2][t]);
+            s_carry[t] = gx;
+            if (l == 0) dx[(long)s * H + t] = gx;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int rtk_gru_step_bwd(int b, int layers, int hidden, const float *x, const float *h_in, const float *h_out,
+                                const float *w_ih_t, const float *w_hh_t, const float *w_ih, const float *w_hh, const float *b_ih,
+                                const float *b_hh, const float *dy, const float *dh_out, float *dx, float *dh_in, float *dgi, float *dgh,
+                                rtk_stream_t stream) {
+    RTK_REQUIRE(b > 0 && layers > 0 && layers <= GRU_MAXL && hidden == 128 && x && h_in && h_out && w_ih_t && w_hh_t && w_ih && w_hh &&
+                b_ih && b_hh && dy && dx && dh_in && dgi && dgh, "gru_step_bwd: bad arguments (hidden=%d must be 128, layers=%d)", hidden, layers);
+    gru_step_bwd_kernel<<<b, 384, 0, (hipStream_t)stream>>>(b, layers, hidden, x, h_in, h_out, w_ih_t, w_hh_t, w_ih, w_hh, b_ih, b_hh, dy,
+                                                            dh_out, dx, dh_in, dgi, dgh);
+    RTK_CHECK_LAUNCH("gru_step_bwd");
     return RTK_OK;
 }
 

@@ -244,7 +244,12 @@ class FlowDecoder(nn.Module):
         gfeat = torch.max(prop, -1)[0].unsqueeze(2)
         if h is None:   # the reference hard-wires (5,1,128) (model_utils.py:294-295); batch-general here
             h = torch.zeros(5, prop.size(0), 128, device=prop.device, dtype=prop.dtype)
-        gfeat, h = self.torchGRU(gfeat.permute(2, 0, 1), h)
-        gfeat = gfeat.permute(1, 2, 0).expand(prop.size(0), prop.size(1), pc1.size(2))
+        if self.training and prop.is_cuda and torch.is_grad_enabled():
+            from .train_ops import gru_step                      # one forward + one backward kernel instead of MIOpen's RNN
+            y, h = gru_step(gfeat.squeeze(2), h, self.torchGRU)
+            gfeat = y.unsqueeze(2).expand(prop.size(0), prop.size(1), pc1.size(2))
+        else:
+            gfeat, h = self.torchGRU(gfeat.permute(2, 0, 1), h)
+            gfeat = gfeat.permute(1, 2, 0).expand(prop.size(0), prop.size(1), pc1.size(2))
         output = self.fp(torch.cat((prop, gfeat), dim=1))
         return output, h, prop, cls

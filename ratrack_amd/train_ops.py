@@ -19,6 +19,7 @@ _lib.SIGNATURES.update({
     "rtk_conv_bn_fwd": [_i] * 6 + [_p] * 7 + [_p],
     "rtk_conv_wgrad": [_i] * 6 + [_p] * 4 + [_p],
     "rtk_conv_bn_bwd": [_i] * 6 + [_p] * 6 + [_d, _i, _p, _p, _p],
+    "rtk_gru_step_bwd": [_i] * 3 + [_p] * 15 + [_p],
     "rtk_patch_cost_bwd": [_i, _i, _p, _p, _p, _i, _LayerP, _p, _p, _i, _p, _p, _p, _p, _p],
     "rtk_bn_train_stats": [_i] * 5 + [_p] * 3 + [_p],
     "rtk_bn_train_finalize": [_i, _i, _p, _d, _p, _p, _f, _f, _p, _p, _p, _p, _p],
@@ -425,3 +426,61 @@ class _Conv1x1(torch.autograd.Function):
 
 def conv1x1(x, w):
     return _Conv1x1.apply(x, w)
+
+
+# ---- GRU step -------------------------------------------------------------------------------------------------------------
+
+class _GRUStep(torch.autograd.Function):
+    """nn.GRU(H, H, L) on a length-1 sequence (model_utils.py:279,296): forward = the inference kernel rtk_gru_step, backward
+    = rtk_gru_step_bwd + two batched GEMMs for the weight gradients (MIOpen's RNN issues ~150 kernels for this 64 x 128
+    problem).  params = (w_ih_l0, w_hh_l0, b_ih_l0, b_hh_l0, w_ih_l1, ...)."""
+
+    @staticmethod
+    def forward(ctx, x, h_in, *params):
+        L = len(params) // 4
+        B, H = x.shape
+        x, h_in = x.contiguous(), h_in.contiguous()
+        w_ih = torch.stack([params[4 * l] for l in range(L)])              # (L,3H,H)
+        w_hh = torch.stack([params[4 * l + 1] for l in range(L)])
+        b_ih = torch.stack([params[4 * l + 2] for l in range(L)])
+        b_hh = torch.stack([params[4 * l + 3] for l in range(L)])
+        w_ih_t, w_hh_t = w_ih.transpose(1, 2).contiguous(), w_hh.transpose(1, 2).contiguous()
+        h_out = torch.empty(L, B, H, dtype=torch.float32, device=x.device)
+        y = torch.empty(B, H, dtype=torch.float32, device=x.device)
+        _lib.call("rtk_gru_step", B, L, H, x.data_ptr(), h_in.data_ptr(), w_ih_t.data_ptr(), w_hh_t.data_ptr(), b_ih.data_ptr(),
+                  b_hh.data_ptr(), h_out.data_ptr(), y.data_ptr(), _stream())
+        ctx.save_for_backward(x, h_in, h_out, w_ih, w_hh, w_ih_t, w_hh_t, b_ih, b_hh)
+        return y, h_out
+
+    @staticmethod
+    def backward(ctx, dy, dh_out):
+        x, h_in, h_out, w_ih, w_hh, w_ih_t, w_hh_t, b_ih, b_hh = ctx.saved_tensors
+        L, B, H = h_out.shape
+        dev = x.device
+        dy = dy.contiguous() if dy is not None else torch.zeros(B, H, dtype=torch.float32, device=dev)
+        dho = dh_out.contiguous() if dh_out is not None else None
+        dx = torch.empty(B, H, dtype=torch.float32, device=dev)
+        dh_in = torch.empty(L, B, H, dtype=torch.float32, device=dev)
+        dg = torch.empty(2, L, B, 3 * H, dtype=torch.float32, device=dev)
+        _lib.call("rtk_gru_step_bwd", B, L, H, x.data_ptr(), h_in.data_ptr(), h_out.data_ptr(), w_ih_t.data_ptr(), w_hh_t.data_ptr(),
+                  w_ih.data_ptr(), w_hh.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr(), dy.data_ptr(), _ptr(dho), dx.data_ptr(),
+                  dh_in.data_ptr(), dg[0].data_ptr(), dg[1].data_ptr(), _stream())
+        xs = torch.cat([x.unsqueeze(0), h_out[:-1]], 0)                                   # layer inputs (L,B,H)
+        dw_ih = torch.bmm(dg[0].transpose(1, 2), xs)                                      # (L,3H,H)
+        dw_hh = torch.bmm(dg[1].transpose(1, 2), h_in)
+        db = dg.sum(2)                                                                    # (2,L,3H)
+        grads = []
+        for l in range(L):
+            grads += [dw_ih[l], dw_hh[l], db[0, l], db[1, l]]
+        return (dx, dh_in) + tuple(grads)
+
+
+def gru_step(x, h_in, gru):
+    """x (B,H), h_in (L,B,H), gru: nn.GRU(H, H, L) -> (y (B,H), h_out (L,B,H))."""
+    L = gru.num_layers
+    assert gru.input_size == gru.hidden_size == 128 and not gru.bidirectional and gru.bias and not gru.batch_first
+    params = []
+    for l in range(L):
+        params += [getattr(gru, "weight_ih_l%d" % l), getattr(gru, "weight_hh_l%d" % l), getattr(gru, "bias_ih_l%d" % l),
+                   getattr(gru, "bias_hh_l%d" % l)]
+    return _GRUStep.apply(x, h_in, *params)

@@ -286,3 +286,31 @@ def test_fused_sa_chain_matches_unfused_operators(chans, ns, U, n_src, groups):
         assert float((ga[k] - gb[k]).norm()) <= 2e-4 * float(gb[k].norm()) + 1e-6, k
     for k in sb:
         assert float((sa[k] - sb[k]).abs().max()) <= 1e-5 * float(sb[k].abs().max()) + 1e-7, k
+
+
+@pytest.mark.parametrize("B", [1, 5, 64])
+def test_gru_step_operator_matches_nn_gru(B):
+    """rtk_gru_step + rtk_gru_step_bwd against nn.GRU(128,128,5) on a length-1 sequence: outputs, input / state gradients and
+    all 20 parameter gradients, with cotangents on both outputs."""
+    from ratrack_amd.train_ops import gru_step
+    torch.manual_seed(B)
+    gru = nn.GRU(128, 128, 5).to(DEV)
+    res = []
+    for custom in (True, False):
+        gru.zero_grad(set_to_none=True)
+        g = torch.Generator(DEV).manual_seed(2)
+        x = torch.randn(B, 128, device=DEV, generator=g).requires_grad_(True)
+        h0 = (torch.randn(5, B, 128, device=DEV, generator=g) * 0.5).requires_grad_(True)
+        if custom:
+            y, h1 = gru_step(x, h0, gru)
+        else:
+            o, h1 = gru(x.unsqueeze(0), h0)
+            y = o[0]
+        cy, ch = torch.randn(B, 128, device=DEV, generator=g), torch.randn(5, B, 128, device=DEV, generator=g) * 0.3
+        (y * cy).sum().add((h1 * ch).sum()).backward()
+        res.append((y.detach(), h1.detach(), x.grad.clone(), h0.grad.clone(), {k: p.grad.clone() for k, p in gru.named_parameters()}))
+    a, b = res
+    for i in range(4):
+        assert float((a[i] - b[i]).abs().max()) <= 2e-5 * float(b[i].abs().max()) + 1e-6, i
+    for k in b[4]:
+        assert float((a[4][k] - b[4][k]).norm()) <= 1e-4 * float(b[4][k].norm()) + 1e-6, k
