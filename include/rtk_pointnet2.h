@@ -71,6 +71,9 @@ RTK_EXPORT int rtk_group_points(int b, int c, int n, int npoint, int nsample, co
                      float *out, rtk_stream_t stream);
 RTK_EXPORT int rtk_group_points_grad(int b, int c, int n, int npoint, int nsample, const float *grad_out,
                           const int *idx, float *grad_points, rtk_stream_t stream);
+/* same result written (not accumulated) into an UNINITIALISED grad_points: saves the caller's zero-fill */
+RTK_EXPORT int rtk_group_points_grad_set(int b, int c, int n, int npoint, int nsample, const float *grad_out,
+                          const int *idx, float *grad_points, rtk_stream_t stream);
 
 /* replaces three_nn_wrapper   interpolate.cpp:16-25 / interpolate_gpu.cu:81-124
  * unknown (B,n,3), known (B,m,3) -> dist2 (B,n,3) SQUARED distances ascending, idx int32 (B,n,3);
@@ -88,6 +91,9 @@ RTK_EXPORT int rtk_knn(int b, int n, int m, int k, const float *unknown, const f
 RTK_EXPORT int rtk_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
                           const float *weight, float *out, rtk_stream_t stream);
 RTK_EXPORT int rtk_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                               const float *weight, float *grad_points, rtk_stream_t stream);
+/* same result written (not accumulated) into an UNINITIALISED grad_points */
+RTK_EXPORT int rtk_three_interpolate_grad_set(int b, int c, int n, int m, const float *grad_out, const int *idx,
                                const float *weight, float *grad_points, rtk_stream_t stream);
 
 /* replaces knn_point()   utils/model_utils/model_utils.py:17-39,85-99  (square_distance + torch.topk)

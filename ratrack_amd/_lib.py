@@ -18,10 +18,12 @@ SIGNATURES = {
     "rtk_ball_query": [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 3 + [_c_void_p],
     "rtk_group_points": [_c_int] * 5 + [_c_void_p] * 3 + [_c_void_p],
     "rtk_group_points_grad": [_c_int] * 5 + [_c_void_p] * 3 + [_c_void_p],
+    "rtk_group_points_grad_set": [_c_int] * 5 + [_c_void_p] * 3 + [_c_void_p],
     "rtk_three_nn": [_c_int] * 3 + [_c_void_p] * 4 + [_c_void_p],
     "rtk_knn": [_c_int] * 4 + [_c_void_p] * 4 + [_c_void_p],
     "rtk_three_interpolate": [_c_int] * 4 + [_c_void_p] * 4 + [_c_void_p],
     "rtk_three_interpolate_grad": [_c_int] * 4 + [_c_void_p] * 4 + [_c_void_p],
+    "rtk_three_interpolate_grad_set": [_c_int] * 4 + [_c_void_p] * 4 + [_c_void_p],
     "rtk_knn_point": [_c_int] * 4 + [_c_void_p] * 3 + [_c_void_p],
 }
 

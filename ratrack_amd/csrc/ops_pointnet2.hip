@@ -477,6 +477,7 @@ extern "C" int rtk_group_points(int b, int c, int n, int npoint, int nsample, co
 // not an L2 round trip) and writes the row back with plain stores.  The reference's per-element atomicAdd
 // (group_points_gpu.cu:24) collapses when many neighbourhoods share points -- e.g. the 256 duplicate centroids of an
 // over-sampled level hit the same 4-32 addresses 256 times per channel: 21 ms of a 92 ms train step at B=64.
+template <bool SET>
 __global__ __launch_bounds__(256) void group_points_grad_lds_kernel(int c, int n, int sn, const float *__restrict__ grad_out,
                                                                     const int *__restrict__ idx, float *__restrict__ grad_points) {
     extern __shared__ float s_acc[];
@@ -488,21 +489,35 @@ __global__ __launch_bounds__(256) void group_points_grad_lds_kernel(int c, int n
     for (int t = tid; t < sn; t += 256) atomicAdd(&s_acc[id[t]], go[t]);
     __syncthreads();
     float *gp = grad_points + ((size_t)bs * c + ci) * n;
-    for (int k = tid; k < n; k += 256) gp[k] += s_acc[k];
+    for (int k = tid; k < n; k += 256) gp[k] = SET ? s_acc[k] : gp[k] + s_acc[k];
 }
 
-extern "C" int rtk_group_points_grad(int b, int c, int n, int npoint, int nsample, const float *grad_out,
-                                     const int *idx, float *grad_points, rtk_stream_t stream) {
+static int group_points_grad_impl(bool set, int b, int c, int n, int npoint, int nsample, const float *grad_out, const int *idx,
+                                  float *grad_points, rtk_stream_t stream) {
     RTK_REQUIRE(b > 0 && c > 0 && n > 0 && npoint > 0 && nsample > 0 && grad_out && idx && grad_points,
                 "group_points_grad: bad arguments");
     RTK_REQUIRE(c <= 65535 && b <= 65535, "group_points_grad: c/b exceed grid limits");
     const int sn = npoint * nsample;
-    if ((size_t)n * sizeof(float) <= 64 * 1024)
-        group_points_grad_lds_kernel<<<dim3(c, b), 256, (size_t)n * sizeof(float), (hipStream_t)stream>>>(c, n, sn, grad_out, idx, grad_points);
-    else
-        group_points_grad_kernel<<<dim3(rtk_divup(sn, 256), c, b), 256, 0, (hipStream_t)stream>>>(c, n, sn, grad_out, idx, grad_points);
+    hipStream_t s = (hipStream_t)stream;
+    if ((size_t)n * sizeof(float) <= 64 * 1024) {
+        if (set) group_points_grad_lds_kernel<true><<<dim3(c, b), 256, (size_t)n * sizeof(float), s>>>(c, n, sn, grad_out, idx, grad_points);
+        else group_points_grad_lds_kernel<false><<<dim3(c, b), 256, (size_t)n * sizeof(float), s>>>(c, n, sn, grad_out, idx, grad_points);
+    } else {
+        if (set) (void)hipMemsetAsync(grad_points, 0, (size_t)b * c * n * sizeof(float), s);
+        group_points_grad_kernel<<<dim3(rtk_divup(sn, 256), c, b), 256, 0, s>>>(c, n, sn, grad_out, idx, grad_points);
+    }
     RTK_CHECK_LAUNCH("group_points_grad");
     return RTK_OK;
+}
+
+extern "C" int rtk_group_points_grad(int b, int c, int n, int npoint, int nsample, const float *grad_out,
+                                     const int *idx, float *grad_points, rtk_stream_t stream) {
+    return group_points_grad_impl(false, b, c, n, npoint, nsample, grad_out, idx, grad_points, stream);
+}
+
+extern "C" int rtk_group_points_grad_set(int b, int c, int n, int npoint, int nsample, const float *grad_out,
+                                         const int *idx, float *grad_points, rtk_stream_t stream) {
+    return group_points_grad_impl(true, b, c, n, npoint, nsample, grad_out, idx, grad_points, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -765,6 +780,7 @@ extern "C" int rtk_three_interpolate(int b, int c, int m, int n, const float *po
 }
 
 // As group_points_grad_lds_kernel: one workgroup per (batch, channel) row, LDS accumulation, no global atomics.
+template <bool SET>
 __global__ __launch_bounds__(256) void three_interpolate_grad_lds_kernel(int c, int n, int m, const float *__restrict__ grad_out,
                                                                          const int *__restrict__ idx, const float *__restrict__ weight,
                                                                          float *__restrict__ grad_points) {
@@ -783,20 +799,34 @@ __global__ __launch_bounds__(256) void three_interpolate_grad_lds_kernel(int c, 
     }
     __syncthreads();
     float *gp = grad_points + ((size_t)bs * c + ci) * m;
-    for (int k = tid; k < m; k += 256) gp[k] += s_acc[k];
+    for (int k = tid; k < m; k += 256) gp[k] = SET ? s_acc[k] : gp[k] + s_acc[k];
+}
+
+static int three_interpolate_grad_impl(bool set, int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight,
+                                       float *grad_points, rtk_stream_t stream) {
+    RTK_REQUIRE(b > 0 && c > 0 && m > 0 && n > 0 && grad_out && idx && weight && grad_points,
+                "three_interpolate_grad: bad arguments");
+    RTK_REQUIRE(c <= 65535 && b <= 65535, "three_interpolate_grad: c/b exceed grid limits");
+    hipStream_t s = (hipStream_t)stream;
+    if ((size_t)m * sizeof(float) <= 64 * 1024) {
+        if (set) three_interpolate_grad_lds_kernel<true><<<dim3(c, b), 256, (size_t)m * sizeof(float), s>>>(c, n, m, grad_out, idx, weight, grad_points);
+        else three_interpolate_grad_lds_kernel<false><<<dim3(c, b), 256, (size_t)m * sizeof(float), s>>>(c, n, m, grad_out, idx, weight, grad_points);
+    } else {
+        if (set) (void)hipMemsetAsync(grad_points, 0, (size_t)b * c * m * sizeof(float), s);
+        three_interpolate_grad_kernel<<<dim3(rtk_divup(n, 256), c, b), 256, 0, s>>>(c, n, m, grad_out, idx, weight, grad_points);
+    }
+    RTK_CHECK_LAUNCH("three_interpolate_grad");
+    return RTK_OK;
 }
 
 extern "C" int rtk_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int *idx,
                                           const float *weight, float *grad_points, rtk_stream_t stream) {
-    RTK_REQUIRE(b > 0 && c > 0 && m > 0 && n > 0 && grad_out && idx && weight && grad_points,
-                "three_interpolate_grad: bad arguments");
-    RTK_REQUIRE(c <= 65535 && b <= 65535, "three_interpolate_grad: c/b exceed grid limits");
-    if ((size_t)m * sizeof(float) <= 64 * 1024)
-        three_interpolate_grad_lds_kernel<<<dim3(c, b), 256, (size_t)m * sizeof(float), (hipStream_t)stream>>>(c, n, m, grad_out, idx, weight, grad_points);
-    else
-        three_interpolate_grad_kernel<<<dim3(rtk_divup(n, 256), c, b), 256, 0, (hipStream_t)stream>>>(c, n, m, grad_out, idx, weight, grad_points);
-    RTK_CHECK_LAUNCH("three_interpolate_grad");
-    return RTK_OK;
+    return three_interpolate_grad_impl(false, b, c, n, m, grad_out, idx, weight, grad_points, stream);
+}
+
+extern "C" int rtk_three_interpolate_grad_set(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                              const float *weight, float *grad_points, rtk_stream_t stream) {
+    return three_interpolate_grad_impl(true, b, c, n, m, grad_out, idx, weight, grad_points, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 from torch.autograd import Function
 
+from . import _lib
 from . import pointnet2_hip as _native
 
 
@@ -128,8 +129,11 @@ class ThreeInterpolate(Function):
     def backward(ctx, grad_out):
         idx, weight = ctx.saved_tensors
         B, c, n = grad_out.shape
-        grad = torch.zeros((B, c, ctx.m), dtype=torch.float32, device=grad_out.device)
-        _native.three_interpolate_grad_wrapper(B, c, n, ctx.m, grad_out.contiguous(), idx, weight, grad)
+        # the reference zero-fills and lets the kernel accumulate (lib/pointnet2_utils.py:176-177); the *_set entry point
+        # writes the same values into an uninitialised buffer
+        grad = torch.empty((B, c, ctx.m), dtype=torch.float32, device=grad_out.device)
+        _lib.call("rtk_three_interpolate_grad_set", B, c, n, ctx.m, grad_out.contiguous().data_ptr(), idx.data_ptr(), weight.data_ptr(),
+                  grad.data_ptr(), torch.cuda.current_stream().cuda_stream)
         return grad, None, None
 
 
@@ -155,8 +159,9 @@ class GroupingOperation(Function):
     def backward(ctx, grad_out):
         (idx,) = ctx.saved_tensors
         B, C, npoint, nsample = grad_out.shape
-        grad = torch.zeros((B, C, ctx.N), dtype=torch.float32, device=grad_out.device)
-        _native.group_points_grad_wrapper(B, C, ctx.N, npoint, nsample, grad_out.contiguous(), idx, grad)
+        grad = torch.empty((B, C, ctx.N), dtype=torch.float32, device=grad_out.device)      # see ThreeInterpolate.backward
+        _lib.call("rtk_group_points_grad_set", B, C, ctx.N, npoint, nsample, grad_out.contiguous().data_ptr(), idx.data_ptr(),
+                  grad.data_ptr(), torch.cuda.current_stream().cuda_stream)
         return grad, None
 
 

@@ -206,9 +206,8 @@ class _SAChain(torch.autograd.Function):
             flat += [grads[i][0], grads[i][1], grads[i][2]]
         # first layer: z1 = proj[idx] + Wx.dxyz  ->  dproj = scatter of dz over idx (LDS kernel), dWx = sum_b dz_b dxyz_b^T
         C1 = dz.shape[1]
-        dproj = torch.zeros(S_, C1, n_src, dtype=torch.float32, device=dev)
-        from . import pointnet2_hip as _native
-        _native.group_points_grad_wrapper(S_, C1, n_src, rows, ns, dz, idx, dproj)
+        dproj = torch.empty(S_, C1, n_src, dtype=torch.float32, device=dev)
+        _lib.call("rtk_group_points_grad_set", S_, C1, n_src, rows, ns, dz.data_ptr(), idx.data_ptr(), dproj.data_ptr(), _stream())
         dwx = torch.bmm(dz.view(S_, C1, -1), dxyz.view(S_, 3, -1).transpose(1, 2)).sum(0).view(C1, 3, 1, 1)
         return (dproj, dwx, None, None, None, None, None, None) + tuple(flat)
 

@@ -103,10 +103,12 @@ def _sa_scale(mlp, tg, lvl, s, feats, groups):
     idx = tg.ball[lvl][s]
     ns = idx.shape[2]
     count = (tg.samples // groups) * tg.npoint * ns
-    proj = conv1x1(feats.unsqueeze(-1), w[:, 3:]).squeeze(-1)     # per-POINT projection (a 1x1 conv and a gather commute)
+    # split (not two slices): the backward is one concatenation instead of two zero-fills, two copies and an addition
+    wx, wf = torch.split(w, [3, w.shape[1] - 3], dim=1)
+    proj = conv1x1(feats.unsqueeze(-1), wf).squeeze(-1)           # per-POINT projection (a 1x1 conv and a gather commute)
     if FUSED_SA_CHAIN and sa_chain_supported(layers) and ns >= 4:
-        return sa_chain(proj, w[:, :3], idx, tg.dxyz[lvl][s], layers, tg.row_w[lvl], count, groups)
-    z = conv1x1(tg.dxyz[lvl][s], w[:, :3]) + PU.grouping_operation(proj, idx)
+        return sa_chain(proj, wx, idx, tg.dxyz[lvl][s], layers, tg.row_w[lvl], count, groups)
+    z = conv1x1(tg.dxyz[lvl][s], wx) + PU.grouping_operation(proj, idx)
     x = None
     for i, layer in enumerate(layers):
         if i > 0:
