@@ -123,6 +123,21 @@ RTK_EXPORT int rtk_patch_cost_bwd(int samples, int n, const float *xyz, const in
                                   const rtk_layer_t *wn, const float *wct_packed, const float *dout, int dout_pitch, float *dxg,
                                   float *dq3, float *dt2, float *d4, rtk_stream_t stream);
 
+/* ---- de-duplicated geometry tables (ratrack_amd/train_path.py) ---------------------------------------------------------
+ * rtk_train_group_geometry: for the first `rows` centroids of every sample, idx_out (samples, rows, ns) = ball_idx
+ * (samples, npoint, ns) with entries >= src_nuniq[b] redirected to 0 (src_nuniq may be NULL), and
+ * dxyz (samples, 3, rows, ns) = src_xyz[idx_out] - dst_xyz (neighbour - centroid, lib/pointnet2_utils.py:279-285);
+ * src_xyz (samples, n_src_rows, 3), dst_xyz (samples, npoint, 3). */
+RTK_EXPORT int rtk_train_group_geometry(int samples, int n_src_rows, int npoint, int rows, int ns, const float *src_xyz,
+                                        const float *dst_xyz, const int *ball_idx, const int *src_nuniq, int *idx_out, float *dxyz,
+                                        rtk_stream_t stream);
+/* three-NN tables -> interpolation weights (lib/pointnet2_modules.py:143-146: 1/(sqrt(d2)+1e-8), normalised) and indices with
+ * entries >= known_nuniq[b] redirected to 0, for the first `rows` of `rows_total` unknown rows. */
+RTK_EXPORT int rtk_train_interp_weights(int samples, int rows_total, int rows, const float *dist2, const int *idx, const int *known_nuniq,
+                                        int *idx_out, float *weight_out, rtk_stream_t stream);
+/* BatchNorm row weights of a level: w[b][r] = [r < nuniq[b]] + [r == 0] (npoint - nuniq[b]). */
+RTK_EXPORT int rtk_train_row_weights(int samples, int rows, int npoint, const int *nuniq, float *weights, rtk_stream_t stream);
+
 /* ---- GRU step (fd_layer.torchGRU on a length-1 sequence, utils/model_utils/model_utils.py:279,296) -------------------
  * Backward of rtk_gru_step (rtk_fused.h).  x (B,H), h_in / h_out (L,B,H) as in the forward; w_ih_t, w_hh_t the TRANSPOSED
  * weights (L,H,3H) of the forward, w_ih, w_hh the original (L,3H,H), b_ih, b_hh (L,3H); dy (B,H) gradient of y = h_out[L-1],

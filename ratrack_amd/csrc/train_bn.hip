@@ -495,3 +495,79 @@ extern "C" int rtk_sa_first_layer(int samples, int channels, int rows, int ns, i
     RTK_CHECK_LAUNCH("rtk_sa_first_layer");
     return RTK_OK;
 }
+
+// ---- de-duplicated geometry tables of the training path (ratrack_amd/train_path.py) ----------------------------------------
+// One launch each instead of a dozen framework kernels (slice copies, comparisons, where, gather, subtract, sqrt, divide).
+namespace {
+
+__global__ void train_group_geometry_kernel(int n_src_rows, int npoint, int rows, int ns, const float *__restrict__ src_xyz,
+                                            const float *__restrict__ dst_xyz, const int *__restrict__ ball,
+                                            const int *__restrict__ src_nuniq, int *__restrict__ idx_out, float *__restrict__ dxyz) {
+    const int b = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;      // (row, k)
+    if (e >= rows * ns) return;
+    const int row = e / ns, k = e % ns;
+    int t = ball[((size_t)b * npoint + row) * ns + k];
+    if (src_nuniq && t >= src_nuniq[b]) t = 0;                // source rows >= nuniq are copies of row 0
+    idx_out[(size_t)b * rows * ns + e] = t;
+    const float *p = src_xyz + ((size_t)b * n_src_rows + t) * 3, *c = dst_xyz + ((size_t)b * npoint + row) * 3;
+    float *o = dxyz + (size_t)b * 3 * rows * ns + e;
+    o[0] = __fsub_rn(p[0], c[0]);
+    o[(size_t)rows * ns] = __fsub_rn(p[1], c[1]);
+    o[2 * (size_t)rows * ns] = __fsub_rn(p[2], c[2]);
+}
+
+__global__ void train_interp_kernel(int rows_total, int rows, const float *__restrict__ d2, const int *__restrict__ idx,
+                                    const int *__restrict__ known_nuniq, int *__restrict__ idx_out, float *__restrict__ w_out) {
+    const int b = blockIdx.y, r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float *d = d2 + ((size_t)b * rows_total + r) * 3;
+    const int *id = idx + ((size_t)b * rows_total + r) * 3;
+    const int nu = known_nuniq ? known_nuniq[b] : 0x7fffffff;
+    // lib/pointnet2_modules.py:143-146: dist_recip = 1 / (dist + 1e-8), weight = dist_recip / sum(dist_recip); dist = sqrt(d2)
+    const float r0 = __fdiv_rn(1.0f, __fadd_rn(__fsqrt_rn(d[0]), 1e-8f));
+    const float r1 = __fdiv_rn(1.0f, __fadd_rn(__fsqrt_rn(d[1]), 1e-8f));
+    const float r2 = __fdiv_rn(1.0f, __fadd_rn(__fsqrt_rn(d[2]), 1e-8f));
+    const float norm = __fadd_rn(__fadd_rn(r0, r1), r2);
+    float *w = w_out + ((size_t)b * rows + r) * 3;
+    int *io = idx_out + ((size_t)b * rows + r) * 3;
+    w[0] = __fdiv_rn(r0, norm); w[1] = __fdiv_rn(r1, norm); w[2] = __fdiv_rn(r2, norm);
+    io[0] = id[0] >= nu ? 0 : id[0]; io[1] = id[1] >= nu ? 0 : id[1]; io[2] = id[2] >= nu ? 0 : id[2];
+}
+
+__global__ void train_row_weights_kernel(int rows, int npoint, const int *__restrict__ nuniq, float *__restrict__ w) {
+    const int b = blockIdx.y, r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const int nu = nuniq[b];
+    w[(size_t)b * rows + r] = (r < nu ? 1.f : 0.f) + (r == 0 ? (float)(npoint - nu) : 0.f);
+}
+
+}  // namespace
+
+extern "C" int rtk_train_group_geometry(int samples, int n_src_rows, int npoint, int rows, int ns, const float *src_xyz,
+                                        const float *dst_xyz, const int *ball_idx, const int *src_nuniq, int *idx_out, float *dxyz,
+                                        rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && samples <= 65535 && n_src_rows > 0 && npoint > 0 && rows > 0 && rows <= npoint && ns > 0 && src_xyz &&
+                dst_xyz && ball_idx && idx_out && dxyz, "rtk_train_group_geometry: bad arguments");
+    train_group_geometry_kernel<<<dim3(rtk_divup((long)rows * ns, 256), samples), 256, 0, (hipStream_t)stream>>>(
+        n_src_rows, npoint, rows, ns, src_xyz, dst_xyz, ball_idx, src_nuniq, idx_out, dxyz);
+    RTK_CHECK_LAUNCH("rtk_train_group_geometry");
+    return RTK_OK;
+}
+
+extern "C" int rtk_train_interp_weights(int samples, int rows_total, int rows, const float *dist2, const int *idx, const int *known_nuniq,
+                                        int *idx_out, float *weight_out, rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && samples <= 65535 && rows > 0 && rows <= rows_total && dist2 && idx && idx_out && weight_out,
+                "rtk_train_interp_weights: bad arguments");
+    train_interp_kernel<<<dim3(rtk_divup(rows, 256), samples), 256, 0, (hipStream_t)stream>>>(rows_total, rows, dist2, idx, known_nuniq,
+                                                                                        idx_out, weight_out);
+    RTK_CHECK_LAUNCH("rtk_train_interp_weights");
+    return RTK_OK;
+}
+
+extern "C" int rtk_train_row_weights(int samples, int rows, int npoint, const int *nuniq, float *weights, rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && samples <= 65535 && rows > 0 && npoint >= rows && nuniq && weights, "rtk_train_row_weights: bad arguments");
+    train_row_weights_kernel<<<dim3(rtk_divup(rows, 256), samples), 256, 0, (hipStream_t)stream>>>(rows, npoint, nuniq, weights);
+    RTK_CHECK_LAUNCH("rtk_train_row_weights");
+    return RTK_OK;
+}

@@ -20,6 +20,7 @@ model_utils.PNHead) up to fp32 summation order; tests/test_train_gpu.py checks b
 import torch
 import torch.nn.functional as F
 
+from . import _lib
 from . import pointnet2_utils as PU
 from .train_ops import bn_relu, conv1x1, cost_volume, patch_cost, sa_chain, sa_chain_supported
 
@@ -38,37 +39,37 @@ class TrainGeometry:
         U = self.U = min(n, npoint)
         dev = xyz.device
         nu = geo.nuniq                                            # per level: (S_,) int32 unique-centroid counts
-        ar = torch.arange(U, device=dev, dtype=torch.int32).view(1, U)
+        st = torch.cuda.current_stream().cuda_stream
+        f32 = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        i32 = lambda *sh: torch.empty(*sh, dtype=torch.int32, device=dev)
         self.row_w = []
         for lvl in range(3):
-            c = nu[lvl].view(S_, 1)
-            w = (ar < c).float()
-            w[:, 0] += (npoint - c.view(S_)).float()
-            self.row_w.append(w.contiguous())
+            w = f32(S_, U)
+            _lib.call("rtk_train_row_weights", S_, U, npoint, nu[lvl].data_ptr(), w.data_ptr(), st)
+            self.row_w.append(w)
         self.ball, self.dxyz = [], []
         for lvl in range(3):
-            src = geo.xyz[lvl][:, : (n if lvl == 0 else U)]
-            dst = geo.xyz[lvl + 1][:, :U]
-            src_t = src.transpose(1, 2).contiguous()
-            dst_t = dst.transpose(1, 2).unsqueeze(-1)
+            src, dst = geo.xyz[lvl], geo.xyz[lvl + 1]             # (S_, n or npoint, 3), (S_, npoint, 3)
             rows_b, rows_d = [], []
             for s in range(2):
-                idx = geo.ball[lvl][s][:, :U]
-                if lvl > 0:      # source rows >= nuniq are copies of row 0
-                    idx = torch.where(idx >= nu[lvl - 1].view(S_, 1, 1), torch.zeros_like(idx), idx)
-                idx = idx.contiguous()
+                ball = geo.ball[lvl][s]
+                ns = ball.shape[2]
+                idx, d = i32(S_, U, ns), f32(S_, 3, U, ns)
+                # source rows >= nuniq are copies of row 0: redirect; neighbour - centroid offsets (no gradient)
+                _lib.call("rtk_train_group_geometry", S_, src.shape[1], npoint, U, ns, src.data_ptr(), dst.data_ptr(), ball.data_ptr(),
+                          nu[lvl - 1].data_ptr() if lvl > 0 else None, idx.data_ptr(), d.data_ptr(), st)
                 rows_b.append(idx)
-                rows_d.append(PU.grouping_operation(src_t, idx) - dst_t)      # (S_,3,U,ns), no gradient
+                rows_d.append(d)
             self.ball.append(rows_b)
             self.dxyz.append(rows_d)
         self.interp = {}
         for name, (u, k) in {"fp3": (2, 3), "fp2": (1, 2), "fp1": (0, 1)}.items():
             d2, idx, _ = geo.nn[name]
             rows = n if u == 0 else U
-            d2, idx = d2[:, :rows], idx[:, :rows]
-            idx = torch.where(idx >= nu[k - 1].view(S_, 1, 1), torch.zeros_like(idx), idx).contiguous()
-            recip = 1.0 / (torch.sqrt(d2) + 1e-8)                 # lib/pointnet2_modules.py:143-146
-            self.interp[name] = (idx, (recip / torch.sum(recip, dim=2, keepdim=True)).contiguous())
+            io, wo = i32(S_, rows, 3), f32(S_, rows, 3)
+            _lib.call("rtk_train_interp_weights", S_, d2.shape[1], rows, d2.data_ptr(), idx.data_ptr(), nu[k - 1].data_ptr(), io.data_ptr(),
+                      wo.data_ptr(), st)
+            self.interp[name] = (io, wo)
         self.l3_xyz = geo.xyz[3]
 
     def head(self, count):
