@@ -282,7 +282,10 @@ class _CostVolume(torch.autograd.Function):
         B, n1, _ = xyz1.shape
         n2 = xyz2.shape[1]
         p1, p2 = p1.contiguous(), p2.contiguous()
-        W = _CvWeights(wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, backward=False)
+        # all kernel images are built once per step, here: the backward reuses them (ctx.images)
+        W = _CvWeights(wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, backward=True)
+        W.wct = fused.pack_layer(wc.t())
+        ctx.images = W
         out = torch.empty(B * n1, 256, dtype=torch.float32, device=p1.device)
         _lib.call("rtk_cost_volume", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
                   W.wd.data_ptr(), W.layers, W.wn, out.data_ptr(), 256, _stream())
@@ -297,7 +300,7 @@ class _CostVolume(torch.autograd.Function):
         dev = p1.device
         M = B * n1 * 16
         dout = dout.contiguous()
-        W = _CvWeights(wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, backward=True)
+        W = ctx.images
         AP = 256      # a ones column (AP = 272) would fold the bias sums into the GEMMs, but N = 272 runs 2.2x slower than N = 256
         big = torch.empty(6, M, 256, dtype=torch.float32, device=dev)
         a1, a2, dz1, dz2, dz3, dq3 = big.unbind(0)
@@ -305,7 +308,7 @@ class _CostVolume(torch.autograd.Function):
         dt2 = torch.empty(M, 8, dtype=torch.float32, device=dev)
         dp1 = torch.empty(B * n1, 256, dtype=torch.float32, device=dev)
         dpd = torch.empty(B * n1, 3, 256, dtype=torch.float32, device=dev)
-        wct = fused.pack_layer(wc.t())
+        wct = W.wct
         _lib.call("rtk_cost_volume_bwd", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
                   W.wd.data_ptr(), W.layers, W.wn, wct.data_ptr(), dout.data_ptr(), 256, AP, a1.data_ptr(), a2.data_ptr(),
                   dz1.data_ptr(), dz2.data_ptr(), dz3.data_ptr(), dq3.data_ptr(), d4.data_ptr(), dp1.data_ptr(), dpd.data_ptr(),
@@ -368,6 +371,7 @@ class _PatchCost(torch.autograd.Function):
         B, n, _ = xyz.shape
         feat = feat.contiguous()
         wn, keep = _weightnet_images(wa, ba, wb, bb, wc, bc)
+        ctx.images = (wn, keep, fused.pack_layer(wc.t()))           # reused by the backward
         out = torch.empty(B * n, 256, dtype=torch.float32, device=feat.device)
         _lib.call("rtk_patch_cost", B, n, xyz.data_ptr(), knn.data_ptr(), feat.data_ptr(), 256, wn, out.data_ptr(), 256, 0, _stream())
         ctx.save_for_backward(feat, wa, ba, wb, bb, wc, bc, xyz, knn)
@@ -380,8 +384,7 @@ class _PatchCost(torch.autograd.Function):
         M = B * n * 16
         dev = feat.device
         dout = dout.contiguous()
-        wn, keep = _weightnet_images(wa, ba, wb, bb, wc, bc)
-        wct = fused.pack_layer(wc.t())
+        wn, keep, wct = ctx.images
         big = torch.empty(2, M, 256, dtype=torch.float32, device=dev)
         dxg, dq3 = big.unbind(0)
         dt2 = torch.empty(M, 8, dtype=torch.float32, device=dev)
