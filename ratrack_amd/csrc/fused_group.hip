@@ -380,7 +380,11 @@ __global__ __launch_bounds__(64 * CV_NW, (CV_NW * CV_WGS_PER_CU) / 4) void cost_
     for (int G = blockIdx.x; G < groups; G += gridDim.x) {
         asm volatile("" ::: "memory");
         const int pt = G * CV_NW + wave_in_wg;
+#ifdef CVB_NOSTORE      // ablation: no materialisation at all (results are wrong)
+        const bool valid = false;
+#else
         const bool valid = pt < P.n1;
+#endif
         const long i = (long)b * P.n1 + (valid ? pt : P.n1 - 1);
         const long nb = (long)b * P.n2 + (long)P.knn[i * 16 + j];
         const float bop = g < 3 ? __fsub_rn(P.xyz2[nb * 3 + g], P.xyz1[i * 3 + g]) : 1.0f;
