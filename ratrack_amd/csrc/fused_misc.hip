@@ -56,11 +56,21 @@ __global__ __launch_bounds__(384) void gru_step_kernel(int b, int layers, int hi
             // transposed weights (L, H, 3H): consecutive threads read consecutive addresses
             const float *wi = w_ih + (long)l * H * 3 * H + t;
             const float *wh = w_hh + (long)l * H * 3 * H + t;
+            // 16 weight loads of each matrix in flight per thread (the loop is L2-latency bound otherwise); the summation
+            // order is still k ascending per accumulator pair, combined once at the end
             float ai = b_ih[l * 3 * H + t], ah = b_hh[l * 3 * H + t];
-#pragma unroll 8
-            for (int k = 0; k < H; ++k) {
-                ai = fmaf(wi[(long)k * 3 * H], s_x[k], ai);
-                ah = fmaf(wh[(long)k * 3 * H], s_h[k], ah);
+            for (int k0 = 0; k0 < H; k0 += 16) {
+                float wv[16], uv[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    wv[q] = wi[(long)(k0 + q) * 3 * H];
+                    uv[q] = wh[(long)(k0 + q) * 3 * H];
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    ai = fmaf(wv[q], s_x[k0 + q], ai);
+                    ah = fmaf(uv[q], s_h[k0 + q], ah);
+                }
             }
             s_gi[t] = ai;
             s_gh[t] = ah;
@@ -114,11 +124,21 @@ __global__ __launch_bounds__(384) void gru_step_bwd_kernel(int b, int layers, in
         if (t < 3 * H) {
             const float *wi = w_ih_t + (long)l * H * 3 * H + t;
             const float *wh = w_hh_t + (long)l * H * 3 * H + t;
+            // 16 weight loads of each matrix in flight per thread (the loop is L2-latency bound otherwise); the summation
+            // order is still k ascending per accumulator pair, combined once at the end
             float ai = b_ih[l * 3 * H + t], ah = b_hh[l * 3 * H + t];
-#pragma unroll 8
-            for (int k = 0; k < H; ++k) {
-                ai = fmaf(wi[(long)k * 3 * H], s_x[k], ai);
-                ah = fmaf(wh[(long)k * 3 * H], s_h[k], ah);
+            for (int k0 = 0; k0 < H; k0 += 16) {
+                float wv[16], uv[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    wv[q] = wi[(long)(k0 + q) * 3 * H];
+                    uv[q] = wh[(long)(k0 + q) * 3 * H];
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    ai = fmaf(wv[q], s_x[k0 + q], ai);
+                    ah = fmaf(uv[q], s_h[k0 + q], ah);
+                }
             }
             s_gi[t] = ai;
             s_gh[t] = ah;
@@ -154,10 +174,18 @@ __global__ __launch_bounds__(384) void gru_step_bwd_kernel(int b, int layers, in
                 const float *wi = w_ih + ((long)l * 3 * H + (long)part * H) * H + j;
                 const float *wh = w_hh + ((long)l * 3 * H + (long)part * H) * H + j;
                 float ax = 0.f, ah = 0.f;
-#pragma unroll 8
-                for (int i = 0; i < H; ++i) {
-                    ax = fmaf(wi[(long)i * H], s_gi[part * H + i], ax);
-                    ah = fmaf(wh[(long)i * H], s_gh[part * H + i], ah);
+                for (int i0 = 0; i0 < H; i0 += 16) {
+                    float wv[16], uv[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        wv[q] = wi[(long)(i0 + q) * H];
+                        uv[q] = wh[(long)(i0 + q) * H];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        ax = fmaf(wv[q], s_gi[part * H + i0 + q], ax);
+                        ah = fmaf(uv[q], s_gh[part * H + i0 + q], ah);
+                    }
                 }
                 s_dx[part][j] = ax;
                 s_dh[part][j] = ah;
