@@ -478,15 +478,45 @@ extern "C" int rtk_group_points(int b, int c, int n, int npoint, int nsample, co
 // (group_points_gpu.cu:24) collapses when many neighbourhoods share points -- e.g. the 256 duplicate centroids of an
 // over-sampled level hit the same 4-32 addresses 256 times per channel: 21 ms of a 92 ms train step at B=64.
 template <bool SET>
-__global__ __launch_bounds__(256) void group_points_grad_lds_kernel(int c, int n, int sn, const float *__restrict__ grad_out,
+__global__ __launch_bounds__(256) void group_points_grad_lds_kernel(int c, int n, int npoint, int nsample, const float *__restrict__ grad_out,
                                                                     const int *__restrict__ idx, float *__restrict__ grad_points) {
     extern __shared__ float s_acc[];
     const int bs = blockIdx.y, ci = blockIdx.x, tid = threadIdx.x;
+    const int sn = npoint * nsample;
     for (int k = tid; k < n; k += 256) s_acc[k] = 0.f;
     __syncthreads();
     const float *go = grad_out + ((size_t)bs * c + ci) * sn;
     const int *id = idx + (size_t)bs * sn;
-    for (int t = tid; t < sn; t += 256) atomicAdd(&s_acc[id[t]], go[t]);
+    if ((nsample & 3) == 0) {
+        // One thread per neighbourhood: a ball query pads a short neighbourhood with copies of its first hit, so runs of equal
+        // indices are the rule -- they are summed in a register and hit the LDS once, instead of serialising as same-address
+        // atomics inside a wave.
+        for (int row = tid; row < npoint; row += 256) {
+            const int4 *ip = reinterpret_cast<const int4 *>(id + (size_t)row * nsample);
+            const float4 *gp = reinterpret_cast<const float4 *>(go + (size_t)row * nsample);
+            int cur = -1;
+            float acc = 0.f;
+            for (int q = 0; q < nsample / 4; ++q) {
+                const int4 t = ip[q];
+                const float4 g = gp[q];
+                const int tt[4] = {t.x, t.y, t.z, t.w};
+                const float gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (tt[e] == cur) {
+                        acc += gg[e];
+                    } else {
+                        if (cur >= 0) atomicAdd(&s_acc[cur], acc);
+                        cur = tt[e];
+                        acc = gg[e];
+                    }
+                }
+            }
+            if (cur >= 0) atomicAdd(&s_acc[cur], acc);
+        }
+    } else {
+        for (int t = tid; t < sn; t += 256) atomicAdd(&s_acc[id[t]], go[t]);
+    }
     __syncthreads();
     float *gp = grad_points + ((size_t)bs * c + ci) * n;
     for (int k = tid; k < n; k += 256) gp[k] = SET ? s_acc[k] : gp[k] + s_acc[k];
@@ -500,8 +530,8 @@ static int group_points_grad_impl(bool set, int b, int c, int n, int npoint, int
     const int sn = npoint * nsample;
     hipStream_t s = (hipStream_t)stream;
     if ((size_t)n * sizeof(float) <= 64 * 1024) {
-        if (set) group_points_grad_lds_kernel<true><<<dim3(c, b), 256, (size_t)n * sizeof(float), s>>>(c, n, sn, grad_out, idx, grad_points);
-        else group_points_grad_lds_kernel<false><<<dim3(c, b), 256, (size_t)n * sizeof(float), s>>>(c, n, sn, grad_out, idx, grad_points);
+        if (set) group_points_grad_lds_kernel<true><<<dim3(c, b), 256, (size_t)n * sizeof(float), s>>>(c, n, npoint, nsample, grad_out, idx, grad_points);
+        else group_points_grad_lds_kernel<false><<<dim3(c, b), 256, (size_t)n * sizeof(float), s>>>(c, n, npoint, nsample, grad_out, idx, grad_points);
     } else {
         if (set) (void)hipMemsetAsync(grad_points, 0, (size_t)b * c * n * sizeof(float), s);
         group_points_grad_kernel<<<dim3(rtk_divup(sn, 256), c, b), 256, 0, s>>>(c, n, sn, grad_out, idx, grad_points);
