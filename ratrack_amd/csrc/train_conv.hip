@@ -41,17 +41,10 @@ struct TcParams {
     float *dgb;             // backward pass 1: (2, 16V) dgamma | dbeta
 };
 
-__device__ __forceinline__ double wave_row_sum(double v) {      // sum over the 16 lanes that share g
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 // MODE 0: forward.  MODE 1: backward statistics.  MODE 2: backward apply.
 template <int U, int V, int MODE>
 __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
     __shared__ __attribute__((aligned(16))) f4 s_w[U * V * 64];
-    __shared__ double s_red[TC_T / 64][V * 16][2];
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int grp = b / (Q.samples / Q.groups);
@@ -110,18 +103,42 @@ __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
     char *actb = (MODE == 0 && Q.act_out) ? reinterpret_cast<char *>(Q.act_out + (size_t)b * 16 * U * P) : nullptr;
     const unsigned pitch = 4u * (unsigned)P;                      // bytes per channel plane
     const int nchunks = (P + TC_CHUNK - 1) / TC_CHUNK;
-    for (int ch = blockIdx.x * (TC_T / 64) + wave; ch < nchunks; ch += gridDim.x * (TC_T / 64)) {
+    const int stride = gridDim.x * (TC_T / 64);
+    // Register plan (U = V = 4): input tiles 64 + zprev of half the output blocks 32 (backward) + accumulators of HALF the
+    // output blocks 32 + statistics 32.  The backward requests a pass's zprev rows before that pass's MFMAs and every mode
+    // requests the next chunk's input at the end of the current one -- nothing is waited for right after issue.
+    constexpr int VH = V >= 4 ? (MODE == 1 ? V / 4 : V / 2) : V;   // output blocks per MFMA pass (the statistics pass carries 32 more registers)
+    f4 xin[U][4];
+    auto load_in = [&](int chunk, f4 (&dst)[U][4]) {
+        const int pp = chunk * TC_CHUNK + 4 * j;
+        const bool okk = pp < P;
+        // ONE per-lane byte offset (lane's channel group + position), opaque to the optimiser, added to uniform row pointers:
+        // otherwise every one of the 16U + 32V row addresses is hoisted as a loop-invariant 64-bit VGPR pair and spills
+        unsigned lo = (unsigned)(4 * g) * pitch + 4u * (unsigned)pp;
+        asm volatile("" : "+v"(lo));
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                dst[u][r] = okk ? *reinterpret_cast<const f4 *>(inb + (size_t)((unsigned)(16 * u + r) * pitch) + lo) : f4_zero();
+    };
+    int ch = blockIdx.x * (TC_T / 64) + wave;
+    if (ch < nchunks) load_in(ch, xin);
+    for (; ch < nchunks; ch += stride) {
         const int p = ch * TC_CHUNK + 4 * j;                       // this lane's 4 positions
         const bool ok = p < P;                                     // P % 4 == 0: all four or none
+        unsigned lane_off = (unsigned)(4 * g) * pitch + 4u * (unsigned)p;      // see load_in
+        asm volatile("" : "+v"(lane_off));
         const float wl = ok ? (Q.rw ? Q.rw[(size_t)b * Q.rows + (p >> Q.lg_ns)] : 1.f) : 0.f;
-        // ---- load: h[t][u][r] = in[channel 16u + 4g + r][position p + t] ------------------------------------------------
+        asm volatile("" ::: "memory");      // re-read the BatchNorm constants from LDS every chunk: hoisted, they pin 4 x 16V registers
+
+        // ---- tiles: h[t][u][r] = in[channel 16u + 4g + r][position p + t] (previous BatchNorm + ReLU applied in the forward) ----
         f4 h[4][U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const unsigned ioff = (unsigned)(16 * u + 4 * g + r) * pitch + 4u * (unsigned)p;
-                f4 x = ok ? *reinterpret_cast<const f4 *>(inb + ioff) : f4_zero();
+                f4 x = xin[u][r];
                 if (MODE == 0) {
                     if (has_pre) {
                         const float sc = s_sc[16 * u + 4 * g + r], sh = s_sh[16 * u + 4 * g + r];
@@ -130,64 +147,97 @@ __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
                         x.z = fmaxf(__fmaf_rn(x.z, sc, sh), 0.f);
                         x.w = fmaxf(__fmaf_rn(x.w, sc, sh), 0.f);
                     }
-                    if (actb && ok) *reinterpret_cast<f4 *>(actb + ioff) = x;
+                    if (actb && ok) *reinterpret_cast<f4 *>(actb + (size_t)((unsigned)(16 * u + r) * pitch) + lane_off) = x;
                 }
                 h[0][u][r] = x.x; h[1][u][r] = x.y; h[2][u][r] = x.z; h[3][u][r] = x.w;
             }
         }
-        // ---- 4 tiles x (16V x 16U) MFMA ----------------------------------------------------------------------------------
-        f4 acc[4][V];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int v0 = 0; v0 < V; v0 += VH) {
+            // backward: this pass's zprev rows are requested now and consumed after the pass's MFMAs
+            f4 zp[MODE == 0 ? 1 : VH][4];
+            if constexpr (MODE != 0) {
 #pragma unroll
-            for (int v = 0; v < V; ++v) acc[t][v] = f4_zero();
-            mlp_layer<U, V>(s_w, lane, h[t], acc[t]);
-        }
-        // ---- epilogue: out[channel 16v + 4g + r][p .. p+3] = (acc[0..3][v][r]) ---------------------------------------------
+                for (int q = 0; q < VH; ++q)
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
+                    for (int r = 0; r < 4; ++r)
+                        zp[q][r] = ok ? *reinterpret_cast<const f4 *>(zpb + (size_t)((unsigned)(16 * (v0 + q) + r) * pitch) + lane_off) : f4_zero();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- 4 tiles x (16 VH x 16U) MFMA --------------------------------------------------------------------------------
+            f4 acc[4][VH];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const f4 y = {acc[0][v][r], acc[1][v][r], acc[2][v][r], acc[3][v][r]};
-                const unsigned off = (unsigned)(16 * v + 4 * g + r) * pitch + 4u * (unsigned)p;
-                if (MODE == 0) {
-                    if (ok) *reinterpret_cast<f4 *>(outb + off) = y;
-                    st0[v][r] += wl * ((y.x + y.y) + (y.z + y.w));
-                    st1[v][r] += wl * ((y.x * y.x + y.y * y.y) + (y.z * y.z + y.w * y.w));
-                } else {
-                    const f4 zp = ok ? *reinterpret_cast<const f4 *>(zpb + off) : f4_zero();
-                    const int cc = 16 * v + 4 * g + r;
-                    const float sc = s_sc[cc], sh = s_sh[cc], mu = s_mu[cc], rs = s_rs[cc];
-                    f4 d, xh;
-                    d.x = __fmaf_rn(zp.x, sc, sh) > 0.f ? y.x : 0.f;
-                    d.y = __fmaf_rn(zp.y, sc, sh) > 0.f ? y.y : 0.f;
-                    d.z = __fmaf_rn(zp.z, sc, sh) > 0.f ? y.z : 0.f;
-                    d.w = __fmaf_rn(zp.w, sc, sh) > 0.f ? y.w : 0.f;
-                    xh.x = (zp.x - mu) * rs; xh.y = (zp.y - mu) * rs; xh.z = (zp.z - mu) * rs; xh.w = (zp.w - mu) * rs;
-                    if (MODE == 1) {
-                        st0[v][r] += (d.x + d.y) + (d.z + d.w);
-                        st1[v][r] += (d.x * xh.x + d.y * xh.y) + (d.z * xh.z + d.w * xh.w);
-                    } else if (ok) {
-                        const float k1 = s_c1[cc], k2 = s_c2[cc];
-                        f4 o;
-                        o.x = sc * (d.x - wl * (k1 + xh.x * k2));
-                        o.y = sc * (d.y - wl * (k1 + xh.y * k2));
-                        o.z = sc * (d.z - wl * (k1 + xh.z * k2));
-                        o.w = sc * (d.w - wl * (k1 + xh.w * k2));
-                        *reinterpret_cast<f4 *>(outb + off) = o;
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int q = 0; q < VH; ++q) acc[t][q] = f4_zero();
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                f4 wf[VH];
+#pragma unroll
+                for (int q = 0; q < VH; ++q) wf[q] = s_w[(u * V + v0 + q) * 64 + lane];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int q = 0; q < VH; ++q) {
+                        acc[t][q] = mfma4(wf[q].x, h[t][u].x, acc[t][q]);
+                        acc[t][q] = mfma4(wf[q].y, h[t][u].y, acc[t][q]);
+                        acc[t][q] = mfma4(wf[q].z, h[t][u].z, acc[t][q]);
+                        acc[t][q] = mfma4(wf[q].w, h[t][u].w, acc[t][q]);
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- epilogue: out[channel 16v + 4g + r][p .. p+3] = (acc[0..3][v][r]) -------------------------------------------
+#pragma unroll
+            for (int q = 0; q < VH; ++q) {
+                const int v = v0 + q;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const f4 y = {acc[0][q][r], acc[1][q][r], acc[2][q][r], acc[3][q][r]};
+                    char *orow = outb + (size_t)((unsigned)(16 * v + r) * pitch);
+                    if constexpr (MODE == 0) {
+                        if (ok) *reinterpret_cast<f4 *>(orow + lane_off) = y;
+                        st0[v][r] += wl * ((y.x + y.y) + (y.z + y.w));
+                        st1[v][r] += wl * ((y.x * y.x + y.y * y.y) + (y.z * y.z + y.w * y.w));
+                    } else {
+                        const f4 zq = zp[q][r];
+                        const int cc = 16 * v + 4 * g + r;
+                        const float sc = s_sc[cc], sh = s_sh[cc], mu = s_mu[cc], rs = s_rs[cc];
+                        f4 d, xh;
+                        d.x = __fmaf_rn(zq.x, sc, sh) > 0.f ? y.x : 0.f;
+                        d.y = __fmaf_rn(zq.y, sc, sh) > 0.f ? y.y : 0.f;
+                        d.z = __fmaf_rn(zq.z, sc, sh) > 0.f ? y.z : 0.f;
+                        d.w = __fmaf_rn(zq.w, sc, sh) > 0.f ? y.w : 0.f;
+                        xh.x = (zq.x - mu) * rs; xh.y = (zq.y - mu) * rs; xh.z = (zq.z - mu) * rs; xh.w = (zq.w - mu) * rs;
+                        if (MODE == 1) {
+                            st0[v][r] += (d.x + d.y) + (d.z + d.w);
+                            st1[v][r] += (d.x * xh.x + d.y * xh.y) + (d.z * xh.z + d.w * xh.w);
+                        } else if (ok) {
+                            const float k1 = s_c1[cc], k2 = s_c2[cc];
+                            f4 o;
+                            o.x = sc * (d.x - wl * (k1 + xh.x * k2));
+                            o.y = sc * (d.y - wl * (k1 + xh.y * k2));
+                            o.z = sc * (d.z - wl * (k1 + xh.z * k2));
+                            o.w = sc * (d.w - wl * (k1 + xh.w * k2));
+                            *reinterpret_cast<f4 *>(orow + lane_off) = o;
+                        }
                     }
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);      // one output block at a time: hoisting all 16V zprev loads spills
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ch + stride < nchunks) load_in(ch + stride, xin);      // the next chunk's input is in flight across the loop back-edge
     }
     if (MODE == 2) return;
     // ---- statistics: lanes -> wave (xor shuffles over j) -> workgroup (LDS) -> one float64 atomic pair per channel ------
+    __shared__ double s_red[TC_T / 64][V * 16][2];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const double a0 = wave_row_sum((double)st0[v][r]), a1 = wave_row_sum((double)st1[v][r]);
+            double a0 = (double)st0[v][r], a1 = (double)st1[v][r];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); }
             if (j == 0) { s_red[wave][16 * v + 4 * g + r][0] = a0; s_red[wave][16 * v + 4 * g + r][1] = a1; }
         }
     }
