@@ -107,11 +107,13 @@ __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
     // Register plan (U = V = 4): input tiles 64 + zprev of half the output blocks 32 (backward) + accumulators of HALF the
     // output blocks 32 + statistics 32.  The backward requests a pass's zprev rows before that pass's MFMAs and every mode
     // requests the next chunk's input at the end of the current one -- nothing is waited for right after issue.
-    constexpr int VH = V >= 4 ? (MODE == 1 ? V / 4 : V / 2) : V;   // output blocks per MFMA pass (the statistics pass carries 32 more registers)
+    // output blocks per MFMA pass; the statistics pass (32 accumulator registers more) takes quarter passes and stays at 3 waves/SIMD
+    constexpr int VH = V >= 4 ? (MODE == 1 ? V / 4 : V / 2) : V;
     f4 xin[U][4];
     auto load_in = [&](int chunk, f4 (&dst)[U][4]) {
-        const int pp = chunk * TC_CHUNK + 4 * j;
-        const bool okk = pp < P;
+        int pp = chunk * TC_CHUNK + 4 * j;
+        pp = pp < P ? pp : P - 4;         // tail lanes re-read the last valid float4 (unconditional loads: no branch per row);
+                                          // their results are never stored and enter no sum
         // ONE per-lane byte offset (lane's channel group + position), opaque to the optimiser, added to uniform row pointers:
         // otherwise every one of the 16U + 32V row addresses is hoisted as a loop-invariant 64-bit VGPR pair and spills
         unsigned lo = (unsigned)(4 * g) * pitch + 4u * (unsigned)pp;
@@ -120,14 +122,14 @@ __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                dst[u][r] = okk ? *reinterpret_cast<const f4 *>(inb + (size_t)((unsigned)(16 * u + r) * pitch) + lo) : f4_zero();
+                dst[u][r] = *reinterpret_cast<const f4 *>(inb + (size_t)((unsigned)(16 * u + r) * pitch) + lo);
     };
     int ch = blockIdx.x * (TC_T / 64) + wave;
     if (ch < nchunks) load_in(ch, xin);
     for (; ch < nchunks; ch += stride) {
         const int p = ch * TC_CHUNK + 4 * j;                       // this lane's 4 positions
         const bool ok = p < P;                                     // P % 4 == 0: all four or none
-        unsigned lane_off = (unsigned)(4 * g) * pitch + 4u * (unsigned)p;      // see load_in
+        unsigned lane_off = (unsigned)(4 * g) * pitch + 4u * (unsigned)(ok ? p : P - 4);      // see load_in
         asm volatile("" : "+v"(lane_off));
         const float wl = ok ? (Q.rw ? Q.rw[(size_t)b * Q.rows + (p >> Q.lg_ns)] : 1.f) : 0.f;
         asm volatile("" ::: "memory");      // re-read the BatchNorm constants from LDS every chunk: hoisted, they pin 4 x 16V registers
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
                 for (int q = 0; q < VH; ++q)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        zp[q][r] = ok ? *reinterpret_cast<const f4 *>(zpb + (size_t)((unsigned)(16 * (v0 + q) + r) * pitch) + lane_off) : f4_zero();
+                        zp[q][r] = *reinterpret_cast<const f4 *>(zpb + (size_t)((unsigned)(16 * (v0 + q) + r) * pitch) + lane_off);
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- 4 tiles x (16 VH x 16U) MFMA --------------------------------------------------------------------------------
@@ -204,10 +206,10 @@ __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
                         const int cc = 16 * v + 4 * g + r;
                         const float sc = s_sc[cc], sh = s_sh[cc], mu = s_mu[cc], rs = s_rs[cc];
                         f4 d, xh;
-                        d.x = __fmaf_rn(zq.x, sc, sh) > 0.f ? y.x : 0.f;
-                        d.y = __fmaf_rn(zq.y, sc, sh) > 0.f ? y.y : 0.f;
-                        d.z = __fmaf_rn(zq.z, sc, sh) > 0.f ? y.z : 0.f;
-                        d.w = __fmaf_rn(zq.w, sc, sh) > 0.f ? y.w : 0.f;
+                        d.x = (ok && __fmaf_rn(zq.x, sc, sh) > 0.f) ? y.x : 0.f;      // tail lanes contribute nothing
+                        d.y = (ok && __fmaf_rn(zq.y, sc, sh) > 0.f) ? y.y : 0.f;
+                        d.z = (ok && __fmaf_rn(zq.z, sc, sh) > 0.f) ? y.z : 0.f;
+                        d.w = (ok && __fmaf_rn(zq.w, sc, sh) > 0.f) ? y.w : 0.f;
                         xh.x = (zq.x - mu) * rs; xh.y = (zq.y - mu) * rs; xh.z = (zq.z - mu) * rs; xh.w = (zq.w - mu) * rs;
                         if (MODE == 1) {
                             st0[v][r] += (d.x + d.y) + (d.z + d.w);
