@@ -477,49 +477,65 @@ extern "C" int rtk_group_points(int b, int c, int n, int npoint, int nsample, co
 // not an L2 round trip) and writes the row back with plain stores.  The reference's per-element atomicAdd
 // (group_points_gpu.cu:24) collapses when many neighbourhoods share points -- e.g. the 256 duplicate centroids of an
 // over-sampled level hit the same 4-32 addresses 256 times per channel: 21 ms of a 92 ms train step at B=64.
-template <bool SET>
+template <bool SET, int CPB>      // CPB channels per workgroup: the index table is read once per CPB gradient planes
 __global__ __launch_bounds__(256) void group_points_grad_lds_kernel(int c, int n, int npoint, int nsample, const float *__restrict__ grad_out,
                                                                     const int *__restrict__ idx, float *__restrict__ grad_points) {
-    extern __shared__ float s_acc[];
-    const int bs = blockIdx.y, ci = blockIdx.x, tid = threadIdx.x;
+    extern __shared__ float s_acc[];                               // [CPB][n]
+    const int bs = blockIdx.y, c0 = blockIdx.x * CPB, tid = threadIdx.x;
     const int sn = npoint * nsample;
-    for (int k = tid; k < n; k += 256) s_acc[k] = 0.f;
+    for (int k = tid; k < CPB * n; k += 256) s_acc[k] = 0.f;
     __syncthreads();
-    const float *go = grad_out + ((size_t)bs * c + ci) * sn;
+    const float *go = grad_out + ((size_t)bs * c + c0) * sn;
     const int *id = idx + (size_t)bs * sn;
-    if ((nsample & 3) == 0) {
-        // One thread per neighbourhood: a ball query pads a short neighbourhood with copies of its first hit, so runs of equal
-        // indices are the rule -- they are summed in a register and hit the LDS once, instead of serialising as same-address
-        // atomics inside a wave.
-        for (int row = tid; row < npoint; row += 256) {
-            const int4 *ip = reinterpret_cast<const int4 *>(id + (size_t)row * nsample);
-            const float4 *gp = reinterpret_cast<const float4 *>(go + (size_t)row * nsample);
-            int cur = -1;
-            float acc = 0.f;
-            for (int q = 0; q < nsample / 4; ++q) {
-                const int4 t = ip[q];
-                const float4 g = gp[q];
-                const int tt[4] = {t.x, t.y, t.z, t.w};
-                const float gg[4] = {g.x, g.y, g.z, g.w};
+    if ((sn & 3) == 0) {
+        // Coalesced: a thread takes one float4 of every plane (consecutive threads, consecutive 16 bytes), four chunks in flight.
+        // A ball query pads a short neighbourhood with copies of its first hit, so equal neighbours inside a float4 are the
+        // rule: they are summed in registers and hit the LDS once.
+        const int4 *ip = reinterpret_cast<const int4 *>(id);
+        const int n4 = sn >> 2;
+        for (int base = 0; base < n4; base += 256 * 4) {
+            int4 t[4];
+            float4 g[4][CPB];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (tt[e] == cur) {
-                        acc += gg[e];
-                    } else {
-                        if (cur >= 0) atomicAdd(&s_acc[cur], acc);
-                        cur = tt[e];
-                        acc = gg[e];
-                    }
+            for (int u = 0; u < 4; ++u) {
+                const int e4 = base + u * 256 + tid;
+                if (e4 < n4) {
+                    t[u] = ip[e4];
+#pragma unroll
+                    for (int q = 0; q < CPB; ++q) g[u][q] = *reinterpret_cast<const float4 *>(go + (size_t)q * sn + 4 * (size_t)e4);
                 }
             }
-            if (cur >= 0) atomicAdd(&s_acc[cur], acc);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (base + u * 256 + tid >= n4) continue;
+                const int tt[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
+#pragma unroll
+                for (int q = 0; q < CPB; ++q) {
+                    const float gg[4] = {g[u][q].x, g[u][q].y, g[u][q].z, g[u][q].w};
+                    float acc = gg[0];
+#pragma unroll
+                    for (int e = 1; e < 4; ++e) {
+                        if (tt[e] == tt[e - 1]) {
+                            acc += gg[e];
+                        } else {
+                            atomicAdd(&s_acc[q * n + tt[e - 1]], acc);
+                            acc = gg[e];
+                        }
+                    }
+                    atomicAdd(&s_acc[q * n + tt[3]], acc);
+                }
+            }
         }
     } else {
-        for (int t = tid; t < sn; t += 256) atomicAdd(&s_acc[id[t]], go[t]);
+        for (int t = tid; t < sn; t += 256) {
+            const int k = id[t];
+#pragma unroll
+            for (int q = 0; q < CPB; ++q) atomicAdd(&s_acc[q * n + k], go[(size_t)q * sn + t]);
+        }
     }
     __syncthreads();
-    float *gp = grad_points + ((size_t)bs * c + ci) * n;
-    for (int k = tid; k < n; k += 256) gp[k] = SET ? s_acc[k] : gp[k] + s_acc[k];
+    float *gp = grad_points + ((size_t)bs * c + c0) * n;
+    for (int k = tid; k < CPB * n; k += 256) gp[k] = SET ? s_acc[k] : gp[k] + s_acc[k];
 }
 
 static int group_points_grad_impl(bool set, int b, int c, int n, int npoint, int nsample, const float *grad_out, const int *idx,
@@ -530,8 +546,13 @@ static int group_points_grad_impl(bool set, int b, int c, int n, int npoint, int
     const int sn = npoint * nsample;
     hipStream_t s = (hipStream_t)stream;
     if ((size_t)n * sizeof(float) <= 64 * 1024) {
-        if (set) group_points_grad_lds_kernel<true><<<dim3(c, b), 256, (size_t)n * sizeof(float), s>>>(c, n, npoint, nsample, grad_out, idx, grad_points);
-        else group_points_grad_lds_kernel<false><<<dim3(c, b), 256, (size_t)n * sizeof(float), s>>>(c, n, npoint, nsample, grad_out, idx, grad_points);
+        const bool four = (c % 4 == 0) && (size_t)n * 4 * sizeof(float) <= 64 * 1024;
+        const size_t lds = (size_t)n * sizeof(float) * (four ? 4 : 1);
+        const dim3 grid(four ? c / 4 : c, b);
+        if (set && four) group_points_grad_lds_kernel<true, 4><<<grid, 256, lds, s>>>(c, n, npoint, nsample, grad_out, idx, grad_points);
+        else if (set) group_points_grad_lds_kernel<true, 1><<<grid, 256, lds, s>>>(c, n, npoint, nsample, grad_out, idx, grad_points);
+        else if (four) group_points_grad_lds_kernel<false, 4><<<grid, 256, lds, s>>>(c, n, npoint, nsample, grad_out, idx, grad_points);
+        else group_points_grad_lds_kernel<false, 1><<<grid, 256, lds, s>>>(c, n, npoint, nsample, grad_out, idx, grad_points);
     } else {
         if (set) (void)hipMemsetAsync(grad_points, 0, (size_t)b * c * n * sizeof(float), s);
         group_points_grad_kernel<<<dim3(rtk_divup(sn, 256), c, b), 256, 0, s>>>(c, n, sn, grad_out, idx, grad_points);

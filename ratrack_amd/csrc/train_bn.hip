@@ -94,45 +94,58 @@ __global__ __launch_bounds__(BN_T) void bn_stats_kernel(int samples, int channel
 // written once, with the layer's weighted batch sums accumulated on the way -- instead of a gather kernel, a 3-channel
 // convolution, an addition and a statistics pass.  One workgroup per (channel, sample) plane; the plane's projection row
 // sits in LDS, so the gather never leaves the CU.
+template <int CPB>      // channels per workgroup: idx and d_xyz are read once per CPB output planes
 __global__ __launch_bounds__(BN_T) void sa_first_layer_kernel(int samples, int channels, int rows, int lg_ns, int groups, int n_src,
                                                               const float *__restrict__ proj, const int *__restrict__ idx,
                                                               const float *__restrict__ dxyz, const float *__restrict__ wx,
                                                               const float *__restrict__ rw, float *__restrict__ z,
                                                               double *__restrict__ sums) {
-    extern __shared__ float s_proj[];
-    const Plane p = plane_of(samples, channels, rows, 1 << lg_ns, groups);
-    const int c = blockIdx.x, b = blockIdx.y;
+    extern __shared__ float s_proj[];                              // [CPB][n_src]
+    const int c0 = blockIdx.x * CPB, b = blockIdx.y;
+    const int grp = b / (samples / groups);
     const int E = rows << lg_ns;                                   // multiple of 4 (ns >= 4)
-    const float *pr = proj + ((size_t)b * channels + c) * n_src;
-    for (int i = threadIdx.x; i < n_src; i += BN_T) s_proj[i] = pr[i];
+    for (int i = threadIdx.x; i < CPB * n_src; i += BN_T) s_proj[i] = proj[((size_t)b * channels + c0) * n_src + i];
     __syncthreads();
-    const float w0 = wx[c * 3 + 0], w1 = wx[c * 3 + 1], w2 = wx[c * 3 + 2];
+    float w0[CPB], w1[CPB], w2[CPB];
+#pragma unroll
+    for (int q = 0; q < CPB; ++q) { w0[q] = wx[(c0 + q) * 3 + 0]; w1[q] = wx[(c0 + q) * 3 + 1]; w2[q] = wx[(c0 + q) * 3 + 2]; }
     const int *ib = idx + (size_t)b * E;
     const float *dx = dxyz + (size_t)b * 3 * E, *dy = dx + E, *dz = dy + E;
     const float *w = rw ? rw + (size_t)b * rows : nullptr;
-    float *zp = z + p.base;
-    double s = 0.0, ss = 0.0;
+    float *zp = z + ((size_t)b * channels + c0) * E;
+    double s[CPB], ss[CPB];
+#pragma unroll
+    for (int q = 0; q < CPB; ++q) { s[q] = 0.0; ss[q] = 0.0; }
     for (int e4 = threadIdx.x; e4 < (E >> 2); e4 += BN_T) {
         const int4 t = *reinterpret_cast<const int4 *>(ib + 4 * e4);
         const float4 x = *reinterpret_cast<const float4 *>(dx + 4 * e4);
         const float4 y = *reinterpret_cast<const float4 *>(dy + 4 * e4);
-        const float4 q = *reinterpret_cast<const float4 *>(dz + 4 * e4);
-        float4 v;
-        v.x = s_proj[t.x] + __fmaf_rn(w2, q.x, __fmaf_rn(w1, y.x, w0 * x.x));
-        v.y = s_proj[t.y] + __fmaf_rn(w2, q.y, __fmaf_rn(w1, y.y, w0 * x.y));
-        v.z = s_proj[t.z] + __fmaf_rn(w2, q.z, __fmaf_rn(w1, y.z, w0 * x.z));
-        v.w = s_proj[t.w] + __fmaf_rn(w2, q.w, __fmaf_rn(w1, y.w, w0 * x.w));
-        *reinterpret_cast<float4 *>(zp + 4 * e4) = v;
+        const float4 u = *reinterpret_cast<const float4 *>(dz + 4 * e4);
         const double wi = w ? (double)w[(4 * e4) >> lg_ns] : 1.0;     // ns >= 4: the four positions share a row
-        const double a = v.x, bb = v.y, cc = v.z, d = v.w;
-        s += wi * ((a + bb) + (cc + d));
-        ss += wi * ((a * a + bb * bb) + (cc * cc + d * d));
+#pragma unroll
+        for (int q = 0; q < CPB; ++q) {
+            const float *pr = s_proj + q * n_src;
+            float4 v;
+            v.x = pr[t.x] + __fmaf_rn(w2[q], u.x, __fmaf_rn(w1[q], y.x, w0[q] * x.x));
+            v.y = pr[t.y] + __fmaf_rn(w2[q], u.y, __fmaf_rn(w1[q], y.y, w0[q] * x.y));
+            v.z = pr[t.z] + __fmaf_rn(w2[q], u.z, __fmaf_rn(w1[q], y.z, w0[q] * x.z));
+            v.w = pr[t.w] + __fmaf_rn(w2[q], u.w, __fmaf_rn(w1[q], y.w, w0[q] * x.w));
+            *reinterpret_cast<float4 *>(zp + (size_t)q * E + 4 * e4) = v;
+            const double a = v.x, bb = v.y, cc = v.z, d = v.w;
+            s[q] += wi * ((a + bb) + (cc + d));
+            ss[q] += wi * ((a * a + bb * bb) + (cc * cc + d * d));
+        }
     }
-    block_sum2(s, ss);
-    if (threadIdx.x == 0) {
-        double *dst = sums + ((size_t)p.g * channels + c) * 2;
-        atomicAdd(dst, s);
-        atomicAdd(dst + 1, ss);
+#pragma unroll
+    for (int q = 0; q < CPB; ++q) {
+        double a = s[q], c = ss[q];
+        block_sum2(a, c);
+        if (threadIdx.x == 0) {
+            double *dst = sums + ((size_t)grp * channels + c0 + q) * 2;
+            atomicAdd(dst, a);
+            atomicAdd(dst + 1, c);
+        }
+        __syncthreads();      // block_sum2's LDS scratch is reused by the next channel
     }
 }
 
@@ -490,8 +503,12 @@ extern "C" int rtk_sa_first_layer(int samples, int channels, int rows, int ns, i
     RTK_REQUIRE(ns >= 4 && n_src > 0 && n_src <= 16384, "rtk_sa_first_layer: ns (%d) must be >= 4, n_src (%d) <= 16384", ns, n_src);
     RTK_REQUIRE(proj && idx && dxyz && wx && z && sums, "rtk_sa_first_layer: null argument");
     hipStream_t s = (hipStream_t)stream;
-    sa_first_layer_kernel<<<dim3(channels, samples), BN_T, (size_t)n_src * 4, s>>>(samples, channels, rows, ilog2_exact(ns), groups, n_src,
-                                                                                proj, idx, dxyz, wx, row_weight, z, sums);
+    if (channels % 4 == 0 && (size_t)n_src * 16 <= 64 * 1024)
+        sa_first_layer_kernel<4><<<dim3(channels / 4, samples), BN_T, (size_t)n_src * 16, s>>>(samples, channels, rows, ilog2_exact(ns), groups,
+                                                                                            n_src, proj, idx, dxyz, wx, row_weight, z, sums);
+    else
+        sa_first_layer_kernel<1><<<dim3(channels, samples), BN_T, (size_t)n_src * 4, s>>>(samples, channels, rows, ilog2_exact(ns), groups, n_src,
+                                                                                       proj, idx, dxyz, wx, row_weight, z, sums);
     RTK_CHECK_LAUNCH("rtk_sa_first_layer");
     return RTK_OK;
 }
