@@ -11,6 +11,9 @@ already resident in HBM.  One process per GPU; frame-pairs are independent, so r
 batches with no data-path collective (weak scaling); the timed region is bracketed by a barrier +
 synchronize on both sides and the maximum over ranks is reported.
 
+`--mode train` times the training step instead (BASELINE configs 3/4: forward + multi-task loss + backward + gradient
+all-reduce + Adam); its roofline entry is the cost-volume backward kernel, its CPU baseline the oracle's train step.
+
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      the dominant kernel (cost_volume_kernel) against the fp32 MFMA peak, duration measured
                 live with HIP events on the launch stream during the timed region;
@@ -198,7 +201,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=2, help="captured graphs in flight (batch-level pipelining on streams)")
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
                     help="forward = the headline metric (eval backbone, fused kernels); train = forward+loss+backward+"
-                         "gradient all-reduce+Adam on the module path (BASELINE config 3/4), reported with the same fields")
+                         "gradient all-reduce+Adam on the training path, captured in one hipGraph (BASELINE config 3/4), same fields")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -1,7 +1,7 @@
 """Training step of the backbone (counterpart of the inner loop of main_utils.epoch, main_utils.py:122-156,
-248-251, minus the host-side label/GT machinery): forward in train mode (batch-statistic BatchNorm, the
-module path with HIP ops + PyTorch-ROCm dense layers and autograd), multi-task loss, backward, gradient
-all-reduce across ranks, optimizer step."""
+248-251, minus the host-side label/GT machinery): forward in train mode (batch-statistic BatchNorm; the training
+path of ratrack_amd/train_path.py: fused HIP operators with hand-written backward kernels under autograd), multi-task
+loss, backward, gradient all-reduce across ranks, optimizer step -- optionally the whole step as one hipGraph."""
 import torch
 
 from . import loss as L
