@@ -88,6 +88,26 @@ __device__ __forceinline__ void mlp_layer(const f4 *__restrict__ w, int lane, co
     }
 }
 
+// ---- workgroup -> (sample, slice) decode, XCD-aware ---------------------------------------------------------------------
+// Consecutive workgroup ids are dispatched round-robin over the 8 XCDs (observed: block b runs on XCD b % 8) and each XCD
+// has its own L2.  With a plain 2-D grid (x = slice, y = sample) the slices of one sample land on different XCDs and every
+// one of those L2s fetches the sample's gathered rows again (measured on the cost volume: 2.9x the algorithmic bytes, on the
+// patch aggregation 6.6x).  When samples % 8 == 0 the launchers use a 1-D grid of nbx * samples workgroups instead, decoded
+// so that ALL workgroups of sample s run on XCD s % 8:  id -> (xcd = id % 8, slot = id / 8), s = 8 (slot / nbx) + xcd.
+// gx <= 0 selects the plain 2-D grid.
+__device__ __forceinline__ void rtk_decode_block(int gx, int &b, int &bx, int &nbx) {
+    if (gx > 0) {
+        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        b = (slot / gx) * 8 + xcd;
+        bx = slot - (slot / gx) * gx;
+        nbx = gx;
+    } else {
+        b = blockIdx.y;
+        bx = blockIdx.x;
+        nbx = gridDim.x;
+    }
+}
+
 // ---- LDS weight stream ----------------------------------------------------------------------------
 // The packed weights of a whole layer chain form one blob of NF fragments (1 fragment = one (u, v)
 // A-operand image = 64 lanes x 16 B = 1 KiB).  The workgroup streams the blob cyclically through a

@@ -42,6 +42,7 @@ struct SaParams {
     float *out;
     int out_pitch, out_offset;
     const int *src_nuniq, *dst_nuniq;
+    int gx;                 // > 0: XCD-aware 1-D grid (rtk_decode_block)
 };
 
 // NS = neighbours per centroid; V1/V2/V3 = layer widths / 16 (V3 = 0: two-layer MLP).
@@ -53,21 +54,22 @@ __global__ __launch_bounds__(256) void sa_scale_kernel(const SaParams P) {
     constexpr int CPT = NS >= 16 ? 1 : 16 / NS;      // centroids per tile
     __shared__ __attribute__((aligned(16))) f4 s_w[NF * 64];
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
-    // 2-D grid: blockIdx.y = sample, blockIdx.x strides over the sample's centroid groups -- all index arithmetic is
-    // 32-bit and division-free (a 64-bit divide per tile cost more issue slots than the MFMAs of the small scales).
+    // A workgroup owns one sample and strides over its centroid groups -- the index arithmetic inside the loop is 32-bit and
+    // division-free (a 64-bit divide per tile cost more issue slots than the MFMAs of the small scales).
     // Workgroups whose groups are all duplicates (>= nuniq[b], copies of centroid 0) exit at once; the dispatcher
     // back-fills them, which spreads the live work evenly.
-    const int b = blockIdx.y;
+    int b, bx, nbx;
+    rtk_decode_block(P.gx, b, bx, nbx);
     const int dst_e = P.dst_nuniq ? __builtin_amdgcn_readfirstlane(P.dst_nuniq[b]) : P.npoint;
     const int live_groups = (min(dst_e, P.npoint) + CPT - 1) / CPT;
-    if ((int)blockIdx.x * 4 >= live_groups) return;
+    if (bx * 4 >= live_groups) return;
     for (int i = threadIdx.x; i < NF * 64; i += blockDim.x) s_w[i] = P.blob[i];
     float w1[V1];
 #pragma unroll
     for (int v = 0; v < V1; ++v) w1[v] = P.w1[v * 64 + lane];
     __syncthreads();
     const int slot0 = j % NS;                         // neighbour slot of this lane within the first tile
-    for (int unit = blockIdx.x * 4 + (threadIdx.x >> 6); unit < live_groups; unit += gridDim.x * 4) {
+    for (int unit = bx * 4 + (threadIdx.x >> 6); unit < live_groups; unit += nbx * 4) {
         int cl = unit * CPT + (NS >= 16 ? 0 : j / NS);        // centroid of this lane within the sample
         const bool valid = cl < P.npoint;
         if (!valid) cl = P.npoint - 1;
@@ -155,7 +157,8 @@ extern "C" int rtk_sa_scale(int samples, int n, int npoint, int nsample, const f
     const int groups = (npoint + cpt - 1) / cpt;
     int bx = (groups + 3) / 4;                 // one unit per wave per pass ...
     while ((long)bx * samples > SA_MAX_WGS && bx > 1) bx = (bx + 1) / 2;   // few, fat workgroups: the LDS weight fill is paid per workgroup
-    const dim3 blocks(bx, samples);
+    P.gx = samples % 8 == 0 ? bx : 0;
+    const dim3 blocks = P.gx ? dim3(bx * samples) : dim3(bx, samples);
     const long key = (((long)nsample * 32 + v1) * 32 + v2) * 32 + v3;
 #define SA_CASE(ns, a, b, c)                                              \
     case (((long)(ns) * 32 + (a)) * 32 + (b)) * 32 + (c):                 \
@@ -237,20 +240,22 @@ struct CvParams {
     WnWeights wn;
     float *out;
     int out_pitch;
+    int gx;                       // workgroups per sample; > 0 selects the XCD-aware 1-D grid (rtk_decode_block)
 };
 
 __global__ __launch_bounds__(64 * CV_NW, (CV_NW * CV_WGS_PER_CU) / 4) void cost_volume_kernel(const CvParams P) {
     __shared__ __attribute__((aligned(16))) f4 s_w[2 * CV_F * 64];
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     const int wave_in_wg = threadIdx.x >> 6;
-    // 2-D grid: blockIdx.y = sample, blockIdx.x strides over the sample's points, CV_NW points (one per wave) per
-    // iteration.  The trip count is the same for every wave of the workgroup (barriers in the weight stream).
-    const int b = blockIdx.y;
+    // A workgroup owns one sample and strides over its points, CV_NW points (one per wave) per iteration.  The trip count is
+    // the same for every wave of the workgroup (barriers in the weight stream).
+    int b, bx, nbx;
+    rtk_decode_block(P.gx, b, bx, nbx);
     const int groups = (P.n1 + CV_NW - 1) / CV_NW;
     constexpr int NF = 2 * CV_V * CV_V;
     WStream<CV_NW, CV_F, NF> ws;
     ws.start(P.blob, s_w, wave_in_wg, lane);
-    for (int G = blockIdx.x; G < groups; G += gridDim.x) {
+    for (int G = bx; G < groups; G += nbx) {
         asm volatile("" ::: "memory");   // keep loop-invariant weight/bias loads inside the loop (registers are the scarce resource)
         const int pt = G * CV_NW + wave_in_wg;                                  // query point within the sample
         const bool valid = pt < P.n1;
@@ -328,7 +333,13 @@ extern "C" int rtk_cost_volume(int samples, int n1, int n2, const float *xyz1, c
     int gx = 256 * CV_WGS_PER_CU / samples;           // resident workgroups; the rest is looped
     if (gx < 1) gx = 1;
     if (gx > groups) gx = groups;
-    cost_volume_kernel<<<dim3(gx, samples), 64 * CV_NW, 0, (hipStream_t)stream>>>(P);
+    if (samples % 8 == 0) {
+        P.gx = gx;
+        cost_volume_kernel<<<dim3(gx * samples), 64 * CV_NW, 0, (hipStream_t)stream>>>(P);
+    } else {
+        P.gx = 0;
+        cost_volume_kernel<<<dim3(gx, samples), 64 * CV_NW, 0, (hipStream_t)stream>>>(P);
+    }
     RTK_CHECK_LAUNCH("cost_volume");
     return RTK_OK;
 }
@@ -371,13 +382,14 @@ __global__ __launch_bounds__(64 * CV_NW, (CV_NW * CV_WGS_PER_CU) / 4) void cost_
     const CvParams &P = Q.f;
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     const int wave_in_wg = threadIdx.x >> 6;
-    const int b = blockIdx.y;
+    int b, bx, nbx;
+    rtk_decode_block(P.gx, b, bx, nbx);
     const int groups = (P.n1 + CV_NW - 1) / CV_NW;
     constexpr int NF = 4 * CV_V * CV_V;
     constexpr int L = CV_V * CV_V;
     WStream<CV_NW, CV_F, NF> ws;
     ws.start(P.blob, s_w, wave_in_wg, lane);
-    for (int G = blockIdx.x; G < groups; G += gridDim.x) {
+    for (int G = bx; G < groups; G += nbx) {
         asm volatile("" ::: "memory");
         const int pt = G * CV_NW + wave_in_wg;
 #ifdef CVB_NOSTORE      // ablation: no materialisation at all (results are wrong)
@@ -534,7 +546,13 @@ extern "C" int rtk_cost_volume_bwd(int samples, int n1, int n2, const float *xyz
     int gx = 256 * CV_WGS_PER_CU / samples;
     if (gx < 1) gx = 1;
     if (gx > groups) gx = groups;
-    cost_volume_bwd_kernel<<<dim3(gx, samples), 64 * CV_NW, 0, (hipStream_t)stream>>>(Q);
+    if (samples % 8 == 0) {
+        P.gx = gx;
+        cost_volume_bwd_kernel<<<dim3(gx * samples), 64 * CV_NW, 0, (hipStream_t)stream>>>(Q);
+    } else {
+        P.gx = 0;
+        cost_volume_bwd_kernel<<<dim3(gx, samples), 64 * CV_NW, 0, (hipStream_t)stream>>>(Q);
+    }
     RTK_CHECK_LAUNCH("cost_volume_bwd");
     return RTK_OK;
 }
@@ -656,12 +674,14 @@ struct PcParams {
     WnWeights wn;
     float *out;
     int out_pitch, out_cm;
+    int gx;                 // > 0: XCD-aware 1-D grid (rtk_decode_block)
 };
 
 __global__ __launch_bounds__(256) void patch_cost_kernel(const PcParams P) {
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
-    const int b = blockIdx.y;                                       // 2-D grid: sample on y, points strided on x
-    for (int pt = blockIdx.x * 4 + (threadIdx.x >> 6); pt < P.n; pt += gridDim.x * 4) {
+    int b, bx, nbx;                                                 // one sample per workgroup, its points strided
+    rtk_decode_block(P.gx, b, bx, nbx);
+    for (int pt = bx * 4 + (threadIdx.x >> 6); pt < P.n; pt += nbx * 4) {
         const long i = (long)b * P.n + pt;
         const long nb = (long)b * P.n + (long)P.knn[i * 16 + j];
         const float bop = g < 3 ? __fsub_rn(P.xyz[nb * 3 + g], P.xyz[i * 3 + g]) : 1.0f;
@@ -699,7 +719,8 @@ extern "C" int rtk_patch_cost(int samples, int n, const float *xyz, const int64_
     RTK_REQUIRE(samples <= 65535, "patch_cost: too many samples");
     int gx = (n + 3) / 4;
     while ((long)gx * samples > 4096 && gx > 1) gx = (gx + 1) / 2;
-    patch_cost_kernel<<<dim3(gx, samples), 256, 0, (hipStream_t)stream>>>(P);
+    P.gx = samples % 8 == 0 ? gx : 0;
+    patch_cost_kernel<<<P.gx ? dim3(gx * samples) : dim3(gx, samples), 256, 0, (hipStream_t)stream>>>(P);
     RTK_CHECK_LAUNCH("patch_cost");
     return RTK_OK;
 }
@@ -718,8 +739,9 @@ struct PcBwdParams {
 __global__ __launch_bounds__(256) void patch_cost_bwd_kernel(const PcBwdParams Q) {
     const PcParams &P = Q.f;
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
-    const int b = blockIdx.y;
-    for (int pt = blockIdx.x * 4 + (threadIdx.x >> 6); pt < P.n; pt += gridDim.x * 4) {
+    int b, bx, nbx;
+    rtk_decode_block(P.gx, b, bx, nbx);
+    for (int pt = bx * 4 + (threadIdx.x >> 6); pt < P.n; pt += nbx * 4) {
         const long i = (long)b * P.n + pt;
         const long nb = (long)b * P.n + (long)P.knn[i * 16 + j];
         const float bop = g < 3 ? __fsub_rn(P.xyz[nb * 3 + g], P.xyz[i * 3 + g]) : 1.0f;
@@ -767,7 +789,8 @@ extern "C" int rtk_patch_cost_bwd(int samples, int n, const float *xyz, const in
     RTK_REQUIRE(samples <= 65535, "patch_cost_bwd: too many samples");
     int gx = (n + 3) / 4;
     while ((long)gx * samples > 4096 && gx > 1) gx = (gx + 1) / 2;
-    patch_cost_bwd_kernel<<<dim3(gx, samples), 256, 0, (hipStream_t)stream>>>(Q);
+    P.gx = samples % 8 == 0 ? gx : 0;
+    patch_cost_bwd_kernel<<<P.gx ? dim3(gx * samples) : dim3(gx, samples), 256, 0, (hipStream_t)stream>>>(Q);
     RTK_CHECK_LAUNCH("patch_cost_bwd");
     return RTK_OK;
 }

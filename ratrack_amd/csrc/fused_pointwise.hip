@@ -25,6 +25,7 @@ struct PwParams {
     int out_pitch, out_channels, out_cm;
     const int *row_nuniq;
     float *colmax;
+    int gx;                 // > 0: XCD-aware 1-D grid (rtk_decode_block)
 };
 
 template <int V>
@@ -88,15 +89,16 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void pointwise_mlp_kernel(const PwPa
     __shared__ __attribute__((aligned(16))) f4 s_w[2 * PW_F * 64];
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     const int wave_in_wg = threadIdx.x >> 6;
-    // 2-D grid: blockIdx.y = sample, blockIdx.x strides over the sample's 64-row groups (one 16-row tile per wave).
-    // No division anywhere; a tile never straddles two samples; workgroups whose groups are all duplicate rows
-    // (>= row_nuniq[b]) exit before touching the weight stream.  The trip count is uniform over the workgroup, which
-    // the barriers inside the weight stream require.
-    const int b = blockIdx.y;
+    // A workgroup owns one sample and strides over its 64-row groups (one 16-row tile per wave).  No division inside the
+    // loop; a tile never straddles two samples; workgroups whose groups are all duplicate rows (>= row_nuniq[b]) exit
+    // before touching the weight stream.  The trip count is uniform over the workgroup, which the barriers inside the
+    // weight stream require.
+    int b, bx, nbx;
+    rtk_decode_block(P.gx, b, bx, nbx);
     const int rps = P.rows_per_sample;
     const int live_rows = P.row_nuniq ? min(rps, __builtin_amdgcn_readfirstlane(P.row_nuniq[b])) : rps;
     const int live_groups = (live_rows + PW_NW * 16 - 1) / (PW_NW * 16);
-    if ((int)blockIdx.x >= live_groups) return;
+    if (bx >= live_groups) return;
     constexpr int NF = U * V1 + V1 * V2 + V2 * V3 + V3 * V4;
     WStream<PW_NW, PW_F, NF> ws;
     ws.start(reinterpret_cast<const f4 *>(P.layer[0].w_packed), s_w, wave_in_wg, lane);
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void pointwise_mlp_kernel(const PwPa
     for (int s = 0; s < RTK_MAX_SRC; ++s) ustart[s + 1] = ustart[s] + (s < P.nsrc ? (P.src[s].channels + 15) >> 4 : 0);
     const int uend = ustart[RTK_MAX_SRC];
 
-    for (int G = blockIdx.x; G < live_groups; G += gridDim.x) {
+    for (int G = bx; G < live_groups; G += nbx) {
         asm volatile("" ::: "memory");   // keep loop-invariant loads/addresses inside the loop (registers are the scarce resource)
         const int r = G * (PW_NW * 16) + wave_in_wg * 16 + j;           // row within the sample
         const bool valid = r < live_rows;
@@ -212,13 +214,15 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void pointwise_mlp_kernel(const PwPa
 }
 
 template <int U, int V1, int V2, int V3, int V4>
-static int launch_pw(const PwParams &P, bool interp, hipStream_t s) {
+static int launch_pw(const PwParams &P0, bool interp, hipStream_t s) {
+    PwParams P = P0;
     const int samples = P.rows / P.rows_per_sample;
     const int groups = (P.rows_per_sample + PW_NW * 16 - 1) / (PW_NW * 16);
     int gx = 512 / samples;           // 2 workgroups per CU (64 KiB LDS each); the rest is looped (measured: 1024 is 5% slower end to end)
     if (gx < 1) gx = 1;
     if (gx > groups) gx = groups;
-    const dim3 blocks(gx, samples);
+    P.gx = samples % 8 == 0 ? gx : 0;
+    const dim3 blocks = P.gx ? dim3(gx * samples) : dim3(gx, samples);
     if (interp)
         pointwise_mlp_kernel<U, V1, V2, V3, V4, true><<<blocks, 256, 0, s>>>(P);
     else
