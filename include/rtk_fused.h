@@ -145,6 +145,12 @@ typedef struct {
 } rtk_layout_job_t;
 RTK_EXPORT int rtk_to_channel_major_multi(int samples, int n, int njobs, const rtk_layout_job_t *jobs, rtk_stream_t stream);
 
+/* Object association (models/track4d.py:166-180, models/utils/track4d_utils.py:405-434): log-space Sinkhorn normalisation
+ * with a dustbin row and column, all `iters` iterations in one launch.  scores (m,n) fp32 (previous x current object
+ * affinities), alpha the dustbin score; out (m+1, n+1) = log_optimal_transport(scores, alpha, iters).  One workgroup:
+ * (m+1)(n+2) floats must fit 64 KiB of LDS (m, n up to ~120 objects). */
+RTK_EXPORT int rtk_log_sinkhorn(int m, int n, const float *scores, float alpha, int iters, float *out, rtk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

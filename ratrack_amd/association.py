@@ -76,23 +76,31 @@ def object_descriptor(obj, prop_channels):
     return torch.cat((pos, var, feat, flow, rrv, rrv_var), dim=2)
 
 
-def affinity_matrix(affinity_net, objects_curr, objects_prev):
-    """M (previous) x N (current) affinities (models/track4d.py:182-223).  Returns (aff_list, aff_mat (1,M,N), M, N)."""
+def affinity_matrix(affinity_net, objects_curr, objects_prev, descriptors=None):
+    """M (previous) x N (current) affinities (models/track4d.py:182-223).  Returns (aff_list, aff_mat (1,M,N), M, N).
+    The reference evaluates the descriptor pair and the 5-layer Affinity MLP once per (previous, current) pair -- M*N
+    tiny launches sequences, 60-100 ms per frame for 20 x 20 objects.  Here every object's descriptor is computed once
+    (`descriptors`: optional cache keyed by id(object tensor), filled here -- an object keeps its descriptor when it
+    becomes a previous object in the next frame: the reference's 11:267 slice of a 139-channel tensor IS its 128 prop
+    channels) and the MLP runs once on the (M*N, 141) matrix of descriptor differences, in the reference's pair order."""
     m, n = len(objects_prev), len(objects_curr)
     keys = list(objects_prev.keys())
     dev = objects_curr[0].device if n else (objects_prev[keys[0]].device if m else torch.device("cpu"))
-    aff_list = []
-    for i in range(m):
-        prev = objects_prev[keys[i]]
-        d_prev = object_descriptor(prev, 256)       # the reference slices 11:267 of a 139-channel tensor = its 128 prop channels
-        for j in range(n):
-            aff_list.append(affinity_net(object_descriptor(objects_curr[j], 128), d_prev).squeeze(0))
-    if m != 0 and n != 0:
-        aff_list = torch.cat(aff_list, dim=0)
-        aff_mat = torch.reshape(aff_list, (m, n)).unsqueeze(0)
-    else:       # nothing to associate (the reference ends up with an empty tensor and starts new tracks)
-        aff_mat = torch.zeros(1, m, n, device=dev)
-    return aff_list, aff_mat, m, n
+    if m == 0 or n == 0:        # nothing to associate (the reference ends up with an empty tensor and starts new tracks)
+        return [], torch.zeros(1, m, n, device=dev), m, n
+    cache = descriptors if descriptors is not None else {}
+
+    def desc(obj):
+        d = cache.get(id(obj))
+        if d is None:
+            d = cache[id(obj)] = object_descriptor(obj, 128)
+        return d
+
+    d_curr = torch.cat([desc(objects_curr[j]) for j in range(n)], dim=1)           # (1,N,141)
+    d_prev = torch.cat([desc(objects_prev[k]) for k in keys], dim=1)               # (1,M,141)
+    diff = (d_curr.unsqueeze(1) - d_prev.unsqueeze(2)).reshape(m * n, -1)          # pair (i, j) -> row i*N + j: curr_j - prev_i
+    aff_list = affinity_net.affinity(diff).reshape(m * n)
+    return aff_list, aff_list.reshape(m, n).unsqueeze(0), m, n
 
 
 def log_sinkhorn_iterations(Z, log_mu, log_nu, iters):
@@ -121,10 +129,25 @@ def log_optimal_transport(scores, alpha, iters):
     return Z - norm
 
 
+def _log_optimal_transport_hip(aff_mat, alpha, iters):
+    """log_optimal_transport on the GPU as ONE kernel (rtk_log_sinkhorn) instead of ~8 framework kernels per iteration."""
+    from . import _lib, fused  # noqa: F401  (fused registers the signature)
+    _, m, n = aff_mat.shape
+    scores = aff_mat.detach().reshape(m, n).contiguous().float()
+    out = torch.empty(1, m + 1, n + 1, dtype=torch.float32, device=aff_mat.device)
+    _lib.call("rtk_log_sinkhorn", m, n, scores.data_ptr(), float(alpha), int(iters), out.data_ptr(),
+              torch.cuda.current_stream().cuda_stream)
+    return out
+
+
 def sinkhorn_assignment(aff_mat, iters=500):
     """Mutual-best assignment after Sinkhorn normalisation (models/track4d.py:166-180): for every current object the
     index of the matched previous object, or -1.  Returns indices1 (1,N) int64."""
-    scores = log_optimal_transport(aff_mat, torch.tensor(0.9, device=aff_mat.device), iters)
+    _, m, n = aff_mat.shape
+    if aff_mat.is_cuda and (m + 1) * ((n + 1) | 1) + m + n + 2 <= 16 * 1024:
+        scores = _log_optimal_transport_hip(aff_mat, 0.9, iters)
+    else:       # host tensors (CPU tests) or more objects than one workgroup's LDS holds: the framework formulation
+        scores = log_optimal_transport(aff_mat, torch.tensor(0.9, device=aff_mat.device), iters)
     max0, max1 = scores[:, :-1, :-1].max(2), scores[:, :-1, :-1].max(1)
     indices0, indices1 = max0.indices, max1.indices
     ar = lambda t: t.new_ones(t.shape[1]).cumsum(0) - 1
@@ -143,10 +166,14 @@ class Associator:
     def __init__(self, affinity_net):
         self.affinity_net = affinity_net
         self.max_id = 0
+        self._desc = {}          # id(object tensor) -> its 141-d descriptor, for the objects of the last frame
 
     def __call__(self, objects_curr, objects_prev):
         objects, confs = dict(), []
-        aff_list, aff_mat, m, n = affinity_matrix(self.affinity_net, objects_curr, objects_prev)
+        live = {id(o): o for o in list(objects_prev.values()) + list(objects_curr)}
+        self._desc = {k: v for k, v in self._desc.items() if k in live}      # descriptors of objects that still exist
+        aff_list, aff_mat, m, n = affinity_matrix(self.affinity_net, objects_curr, objects_prev, self._desc)
+        self._keep = live        # the cached ids stay valid only while the tensors are alive
         indices1 = None
 
         def fresh(obj):
@@ -158,14 +185,16 @@ class Associator:
             try:
                 indices1 = sinkhorn_assignment(aff_mat)
                 prev_keys = list(objects_prev.keys())
+                idx_host = indices1[0].tolist()                       # ONE device->host transfer each for the decisions
+                aff_host = aff_mat[0].detach().cpu()
                 for i in range(n):
-                    k = int(indices1[0, i])
-                    conf = aff_mat[0, k, i]
-                    if k == -1 or k >= m or conf < 0.01:
+                    k = idx_host[i]
+                    # the reference indexes aff_mat[0, -1, i] when k == -1 (python wrap-around) before testing k
+                    if k == -1 or k >= m or float(aff_host[k, i]) < 0.01:
                         fresh(objects_curr[i])
                     else:
                         objects[prev_keys[k]] = objects_curr[i]
-                        confs.append(conf)
+                        confs.append(aff_mat[0, k, i])
             except Exception:      # the reference swallows association failures and starts new tracks (track4d.py:154-158)
                 for obj in objects_curr:
                     fresh(obj)

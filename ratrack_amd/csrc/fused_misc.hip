@@ -215,6 +215,64 @@ extern "C" int rtk_gru_step_bwd(int b, int layers, int hidden, const float *x, c
 }
 
 // ------------------------------------------------------------------------------------------------
+// rtk_log_sinkhorn: the 500-iteration log-space Sinkhorn normalisation of the object association
+// (log_optimal_transport / log_sinkhorn_iterations, models/utils/track4d_utils.py:405-434) in ONE launch.
+// The reference issues ~8 framework kernels per iteration on an (m+1) x (n+1) matrix of a few hundred entries: 4000
+// launches, 40-90 ms per radar frame -- of a 100 ms frame period.  Here one workgroup keeps the score matrix with its
+// dustbin row / column in LDS and alternates row and column log-sum-exp passes (thread = row, then thread = column).
+//   couplings = [[scores, alpha], [alpha, alpha]],  norm = -log(m + n),
+//   log_mu = (norm, ..., norm, log n + norm),  log_nu = (norm, ..., norm, log m + norm),  u = v = 0
+//   iters x { u = log_mu - lse_j(Z + v);  v = log_nu - lse_i(Z + u) };   out = Z + u + v - norm
+// logsumexp is evaluated as torch does: max + log(sum(exp(x - max))), summed in index order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void log_sinkhorn_kernel(int m, int n, const float *__restrict__ scores, float alpha, int iters,
+                                                           float *__restrict__ out) {
+    extern __shared__ float s_mem[];
+    const int R = m + 1, C = n + 1, ld = C | 1;           // odd row stride: the column pass walks down a column conflict-free
+    float *Z = s_mem, *u = Z + R * ld, *v = u + R;
+    const int t = threadIdx.x;
+    for (int e = t; e < R * C; e += 256) {
+        const int i = e / C, j = e % C;
+        Z[i * ld + j] = (i < m && j < n) ? scores[i * n + j] : alpha;
+    }
+    for (int e = t; e < R; e += 256) u[e] = 0.f;
+    for (int e = t; e < C; e += 256) v[e] = 0.f;
+    const float norm = -logf((float)m + (float)n);
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+        for (int i = t; i < R; i += 256) {
+            float mx = -INFINITY;
+            for (int j = 0; j < C; ++j) mx = fmaxf(mx, Z[i * ld + j] + v[j]);
+            float sum = 0.f;
+            for (int j = 0; j < C; ++j) sum += expf(Z[i * ld + j] + v[j] - mx);
+            u[i] = (i < m ? norm : logf((float)n) + norm) - (logf(sum) + mx);
+        }
+        __syncthreads();
+        for (int j = t; j < C; j += 256) {
+            float mx = -INFINITY;
+            for (int i = 0; i < R; ++i) mx = fmaxf(mx, Z[i * ld + j] + u[i]);
+            float sum = 0.f;
+            for (int i = 0; i < R; ++i) sum += expf(Z[i * ld + j] + u[i] - mx);
+            v[j] = (j < n ? norm : logf((float)m) + norm) - (logf(sum) + mx);
+        }
+        __syncthreads();
+    }
+    for (int e = t; e < R * C; e += 256) {
+        const int i = e / C, j = e % C;
+        out[e] = Z[i * ld + j] + u[i] + v[j] - norm;
+    }
+}
+
+extern "C" int rtk_log_sinkhorn(int m, int n, const float *scores, float alpha, int iters, float *out, rtk_stream_t stream) {
+    RTK_REQUIRE(m > 0 && n > 0 && iters >= 0 && scores && out, "log_sinkhorn: bad arguments");
+    const size_t lds = ((size_t)(m + 1) * ((n + 1) | 1) + (m + 1) + (n + 1)) * sizeof(float);
+    RTK_REQUIRE(lds <= 64 * 1024, "log_sinkhorn: %d x %d objects exceed the single-workgroup LDS budget", m, n);
+    log_sinkhorn_kernel<<<1, 256, lds, (hipStream_t)stream>>>(m, n, scores, alpha, iters, out);
+    RTK_CHECK_LAUNCH("log_sinkhorn");
+    return RTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // rtk_to_channel_major: 32x32 tiles through LDS so that both the point-major reads and the
 // channel-major writes are coalesced.
 // ------------------------------------------------------------------------------------------------

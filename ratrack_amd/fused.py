@@ -50,6 +50,7 @@ _lib.SIGNATURES.update({
     "rtk_ball_query_pair": [_ci] * 3 + [ctypes.c_float, _ci, ctypes.c_float, _ci] + [_vp] * 5 + [_vp],
     "rtk_three_nn_masked": [_ci] * 3 + [_vp] * 6 + [_vp],
     "rtk_to_channel_major_multi": [_ci] * 3 + [_vp, _vp],
+    "rtk_log_sinkhorn": [_ci, _ci, _vp, ctypes.c_float, _ci, _vp, _vp],
 })
 
 
