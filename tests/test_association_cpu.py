@@ -56,3 +56,31 @@ def test_forward_second_half_matches_reference():
             assert np.allclose([float(c) for c in confs], case[p + "confs"], atol=2e-5)
             objects_prev = {k: v.clone().detach() for k, v in objects.items()}
     assert len(case["f1_confs"]) and (case["f1_confs"] > 0).any()      # the fixture really exercises re-identification
+
+
+def test_batched_affinity_matches_per_pair_evaluation():
+    """affinity_matrix evaluates the Affinity MLP once on all (previous, current) pairs; the reference evaluates it pair by
+    pair (models/track4d.py:182-223).  Same values, same aff_list order, descriptors cached by object identity."""
+    import torch
+    from ratrack_amd import association as A
+    from ratrack_amd.track4d import Affinity
+    torch.manual_seed(0)
+    net = Affinity(141)
+    curr = [torch.randn(1, 139, k) for k in (3, 1, 7, 2)]
+    prev = {5: torch.randn(1, 139, 4), 9: torch.randn(1, 139, 2), 11: curr[2]}
+    cache = {}
+    aff_list, aff_mat, m, n = A.affinity_matrix(net, curr, prev, cache)
+    assert (m, n) == (3, 4) and aff_mat.shape == (1, 3, 4) and aff_list.shape == (12,)
+    want = []
+    for key in prev:                                                    # the reference's loop nest and slices
+        for o2 in curr:
+            d2 = A.object_descriptor(o2, 128)
+            d1 = A.object_descriptor(prev[key], 256)
+            want.append(net(d2, d1).squeeze(0))
+    want = torch.cat(want)
+    assert torch.allclose(aff_list, want, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(aff_mat[0], want.reshape(3, 4), rtol=1e-5, atol=1e-6)
+    assert len(cache) == 6 and id(curr[2]) in cache                     # 4 current + 2 distinct previous objects
+    # empty sides
+    l0, m0, a, b = A.affinity_matrix(net, [], prev)
+    assert m0.shape == (1, 3, 0) and (a, b) == (3, 0)

@@ -343,3 +343,25 @@ def test_three_nn_duplicate_aware_scan_is_exact():
     ud, kd, ked = unknown.to(DEV), known.to(DEV), ke.to(DEV)
     _lib.call("rtk_three_nn_masked", B, n, m, ud.data_ptr(), kd.data_ptr(), d2.data_ptr(), idx.data_ptr(), None, ked.data_ptr(), F._stream())
     assert torch.equal(idx.cpu(), ri) and torch.equal(d2.cpu(), rd)
+
+
+@pytest.mark.parametrize("m,n", [(1, 1), (3, 5), (20, 17), (1, 30), (64, 64), (100, 120)])
+def test_log_sinkhorn_kernel_matches_framework_iterations(m, n):
+    """rtk_log_sinkhorn (500 iterations in one launch) against log_optimal_transport (track4d_utils.py:405-434 restated with
+    framework ops), and the mutual-best assignment built on either."""
+    from ratrack_amd import association as A
+    g = torch.Generator(DEV).manual_seed(m * 131 + n)
+    aff = torch.rand(1, m, n, device=DEV, generator=g)
+    ref = A.log_optimal_transport(aff, torch.tensor(0.9, device=DEV), 500)
+    out = A._log_optimal_transport_hip(aff, 0.9, 500)
+    assert out.shape == ref.shape
+    assert float((out - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max()))
+    scores = ref
+    max0, max1 = scores[:, :-1, :-1].max(2), scores[:, :-1, :-1].max(1)
+    idx = A.sinkhorn_assignment(aff)
+    assert idx.shape == (1, n) and int(idx.max()) < m
+    # where the framework result has a clear margin, the kernel path picks the same partner
+    top2 = scores[:, :-1, :-1].topk(min(2, m), dim=1).values
+    clear = (top2[:, 0] - top2[:, -1] > 1e-3) if m > 1 else torch.ones(1, n, dtype=torch.bool, device=DEV)
+    pick = torch.where(idx >= 0, idx, max1.indices)
+    assert torch.equal(pick[clear], max1.indices[clear])
