@@ -153,11 +153,11 @@ def sinkhorn_assignment(aff_mat, iters=500):
     ar = lambda t: t.new_ones(t.shape[1]).cumsum(0) - 1
     mutual0 = ar(indices0)[None] == indices1.gather(1, indices0)
     mutual1 = ar(indices1)[None] == indices0.gather(1, indices1)
-    zero = scores.new_tensor(0)
-    mscores0 = torch.where(mutual0, max0.values.exp(), zero)
+    # python scalars, not new_tensor(): each new_tensor is a synchronous host->device copy (~1 ms)
+    mscores0 = torch.where(mutual0, max0.values.exp(), 0.0)
     valid0 = mutual0 & (mscores0 > 0)
     valid1 = mutual1 & valid0.gather(1, indices1)
-    return torch.where(valid1, indices1, indices1.new_tensor(-1))
+    return torch.where(valid1, indices1, -1)
 
 
 class Associator:

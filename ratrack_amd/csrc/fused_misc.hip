@@ -223,8 +223,28 @@ extern "C" int rtk_gru_step_bwd(int b, int layers, int hidden, const float *x, c
 //   couplings = [[scores, alpha], [alpha, alpha]],  norm = -log(m + n),
 //   log_mu = (norm, ..., norm, log n + norm),  log_nu = (norm, ..., norm, log m + norm),  u = v = 0
 //   iters x { u = log_mu - lse_j(Z + v);  v = log_nu - lse_i(Z + u) };   out = Z + u + v - norm
-// logsumexp is evaluated as torch does: max + log(sum(exp(x - max))), summed in index order.
+// logsumexp is evaluated as torch does: max + log(sum(exp(x - max))) (tree-summed across the lanes of a wave).
 // ------------------------------------------------------------------------------------------------
+// max / sum over the 16 lanes of a DPP row, result in every lane (s_nop 1: a VGPR written by VALU needs 2 wait states
+// before a DPP read)
+__device__ __forceinline__ float row16_max(float v) {
+    asm volatile("s_nop 1\n v_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+                 : "+v"(v));
+    return v;
+}
+
+__device__ __forceinline__ float row16_sum(float v) {
+    asm volatile("s_nop 1\n v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+                 "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+                 "v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+                 "v_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+                 : "+v"(v));
+    return v;
+}
+
 __global__ __launch_bounds__(256) void log_sinkhorn_kernel(int m, int n, const float *__restrict__ scores, float alpha, int iters,
                                                            float *__restrict__ out) {
     extern __shared__ float s_mem[];
@@ -239,21 +259,34 @@ __global__ __launch_bounds__(256) void log_sinkhorn_kernel(int m, int n, const f
     for (int e = t; e < C; e += 256) v[e] = 0.f;
     const float norm = -logf((float)m + (float)n);
     __syncthreads();
+    // One 16-lane DPP row per matrix row (then per column), its lanes across the other axis: max and sum are 4 rotate-and-
+    // combine DPP steps (a ds_bpermute shuffle chain costs ~60 cycles per step; 500 iterations x 2 phases x 12 steps of it
+    // were 3 ms).  16 rows per pass over the workgroup.
+    const int grp = t >> 4, c = t & 15;
+    const float lmu_last = logf((float)n) + norm, lnu_last = logf((float)m) + norm;
     for (int it = 0; it < iters; ++it) {
-        for (int i = t; i < R; i += 256) {
+        for (int i0 = 0; i0 < R; i0 += 16) {
+            const int i = i0 + grp;
+            const bool live = i < R;
             float mx = -INFINITY;
-            for (int j = 0; j < C; ++j) mx = fmaxf(mx, Z[i * ld + j] + v[j]);
+            if (live) for (int j = c; j < C; j += 16) mx = fmaxf(mx, Z[i * ld + j] + v[j]);
+            mx = row16_max(mx);
             float sum = 0.f;
-            for (int j = 0; j < C; ++j) sum += expf(Z[i * ld + j] + v[j] - mx);
-            u[i] = (i < m ? norm : logf((float)n) + norm) - (logf(sum) + mx);
+            if (live) for (int j = c; j < C; j += 16) sum += expf(Z[i * ld + j] + v[j] - mx);
+            sum = row16_sum(sum);
+            if (live && c == 0) u[i] = (i < m ? norm : lmu_last) - (logf(sum) + mx);
         }
         __syncthreads();
-        for (int j = t; j < C; j += 256) {
+        for (int j0 = 0; j0 < C; j0 += 16) {
+            const int j = j0 + grp;
+            const bool live = j < C;
             float mx = -INFINITY;
-            for (int i = 0; i < R; ++i) mx = fmaxf(mx, Z[i * ld + j] + u[i]);
+            if (live) for (int i = c; i < R; i += 16) mx = fmaxf(mx, Z[i * ld + j] + u[i]);
+            mx = row16_max(mx);
             float sum = 0.f;
-            for (int i = 0; i < R; ++i) sum += expf(Z[i * ld + j] + u[i] - mx);
-            v[j] = (j < n ? norm : logf((float)m) + norm) - (logf(sum) + mx);
+            if (live) for (int i = c; i < R; i += 16) sum += expf(Z[i * ld + j] + u[i] - mx);
+            sum = row16_sum(sum);
+            if (live && c == 0) v[j] = (j < n ? norm : lnu_last) - (logf(sum) + mx);
         }
         __syncthreads();
     }
