@@ -76,6 +76,26 @@ def object_descriptor(obj, prop_channels):
     return torch.cat((pos, var, feat, flow, rrv, rrv_var), dim=2)
 
 
+def batched_descriptors(objs):
+    """object_descriptor(o, 128) of every object in `objs` ((1,139,n_i) tensors) with a dozen launches in total instead of a
+    dozen per object: the objects' points are concatenated and reduced per segment (two-pass variance, like torch.var).
+    Returns (len(objs), 141)."""
+    dev = objs[0].device
+    x = torch.cat([o[0] for o in objs], dim=1)                                         # (139, P)
+    sizes = [o.shape[2] for o in objs]
+    seg = torch.repeat_interleave(torch.arange(len(objs), device=dev), torch.tensor(sizes, device=dev), output_size=sum(sizes))
+    cnt = torch.tensor(sizes, device=dev, dtype=x.dtype)
+    k = len(objs)
+    stat = x[3:11]                                                                     # xyz(3) | flow(3) | (RCS, v_r)(2)
+    mean = torch.zeros(8, k, device=dev, dtype=x.dtype).index_add_(1, seg, stat) / cnt
+    dev2 = (stat - mean[:, seg]) ** 2
+    var = torch.zeros(8, k, device=dev, dtype=x.dtype).index_add_(1, seg, dev2) / cnt
+    prop = x[11:139]
+    feat = torch.full((128, k), float("-inf"), device=dev, dtype=x.dtype).scatter_reduce_(1, seg.expand(128, -1), prop, "amax")
+    # [centre(3) | var xyz(3) | max prop(128) | mean flow(3) | mean (RCS,v_r)(2) | var (RCS,v_r)(2)]
+    return torch.cat((mean[0:3], var[0:3], feat, mean[3:6], mean[6:8], var[6:8]), dim=0).t().contiguous()
+
+
 def affinity_matrix(affinity_net, objects_curr, objects_prev, descriptors=None):
     """M (previous) x N (current) affinities (models/track4d.py:182-223).  Returns (aff_list, aff_mat (1,M,N), M, N).
     The reference evaluates the descriptor pair and the 5-layer Affinity MLP once per (previous, current) pair -- M*N
@@ -90,11 +110,17 @@ def affinity_matrix(affinity_net, objects_curr, objects_prev, descriptors=None):
         return [], torch.zeros(1, m, n, device=dev), m, n
     cache = descriptors if descriptors is not None else {}
 
+    todo, seen = [], set()
+    for o in list(objects_curr) + [objects_prev[k] for k in keys]:
+        if id(o) not in cache and id(o) not in seen:
+            seen.add(id(o))
+            todo.append(o)
+    if todo:
+        for o, d in zip(todo, batched_descriptors(todo)):
+            cache[id(o)] = d.view(1, 1, -1)
+
     def desc(obj):
-        d = cache.get(id(obj))
-        if d is None:
-            d = cache[id(obj)] = object_descriptor(obj, 128)
-        return d
+        return cache[id(obj)]
 
     d_curr = torch.cat([desc(objects_curr[j]) for j in range(n)], dim=1)           # (1,N,141)
     d_prev = torch.cat([desc(objects_prev[k]) for k in keys], dim=1)               # (1,M,141)

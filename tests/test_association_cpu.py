@@ -84,3 +84,14 @@ def test_batched_affinity_matches_per_pair_evaluation():
     # empty sides
     l0, m0, a, b = A.affinity_matrix(net, [], prev)
     assert m0.shape == (1, 3, 0) and (a, b) == (3, 0)
+
+
+def test_batched_descriptors_match_per_object_descriptor():
+    import torch
+    from ratrack_amd import association as A
+    torch.manual_seed(1)
+    objs = [torch.randn(1, 139, k) for k in (1, 5, 2, 9, 3)]
+    got = A.batched_descriptors(objs)
+    want = torch.cat([A.object_descriptor(o, 128).reshape(1, 141) for o in objs], 0)
+    assert got.shape == (5, 141)
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6)
