@@ -61,7 +61,12 @@ def cluster_objects(point_features, eps=1.5, min_samples=2):
     for i, l in enumerate(labels):
         if l != -1:
             groups[int(l)].append(i)
-    return [point_features[:, :, torch.as_tensor(ix, device=point_features.device)] for ix in groups.values()]
+    if not groups:
+        return []
+    # one gather for all objects (one host->device index copy), then per-object views of it
+    order = [i for ix in groups.values() for i in ix]
+    gathered = point_features.index_select(2, torch.as_tensor(order, device=point_features.device))
+    return list(torch.split(gathered, [len(ix) for ix in groups.values()], dim=2))
 
 
 def object_descriptor(obj, prop_channels):
