@@ -719,7 +719,11 @@ extern "C" int rtk_patch_cost(int samples, int n, const float *xyz, const int64_
     RTK_REQUIRE(samples <= 65535, "patch_cost: too many samples");
     int gx = (n + 3) / 4;
     while ((long)gx * samples > 4096 && gx > 1) gx = (gx + 1) / 2;
+#ifdef PC_NO_XCD
+    P.gx = 0;
+#else
     P.gx = samples % 8 == 0 ? gx : 0;
+#endif
     patch_cost_kernel<<<P.gx ? dim3(gx * samples) : dim3(gx, samples), 256, 0, (hipStream_t)stream>>>(P);
     RTK_CHECK_LAUNCH("patch_cost");
     return RTK_OK;

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Ad-hoc: standalone time of rtk_patch_cost at B=64, N=256."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ratrack_amd import _lib, train_ops, fused
+dev = "cuda"; B, n = 64, 256
+g = torch.Generator(dev).manual_seed(0)
+r = lambda *s: torch.randn(*s, device=dev, generator=g)
+xyz = r(B, n, 3).contiguous(); knn = torch.randint(0, n, (B, n, 16), device=dev, generator=g); feat = r(B * n, 256)
+wn, keep = train_ops._weightnet_images(r(8, 3), r(8), r(8, 8), r(8), r(256, 8), r(256))
+out = torch.empty(B * n, 256, device=dev); st = torch.cuda.current_stream().cuda_stream
+f = lambda: _lib.call("rtk_patch_cost", B, n, xyz.data_ptr(), knn.data_ptr(), feat.data_ptr(), 256, wn, out.data_ptr(), 256, 0, st)
+for _ in range(5): f()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(50): f()
+e1.record(); torch.cuda.synchronize()
+print("patch_cost %.1f us" % (e0.elapsed_time(e1) * 20))
