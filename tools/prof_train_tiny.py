@@ -21,6 +21,6 @@ rows = []
 for ev in prof.key_averages(group_by_input_shape=True):
     if ev.key.startswith("aten::") and ev.device_time_total > 0 and ev.self_device_time_total > 0:
         rows.append((ev.count, ev.self_device_time_total, ev.key, str(ev.input_shapes)[:150]))
-rows.sort(key=lambda r: -r[1])
+rows.sort(key=lambda r: (-r[0], -r[1]))
 for c, tm, k, sh in rows[:70]:
     print("%4d %8.1f us  %-28s %s" % (c, tm, k, sh))
