@@ -24,7 +24,9 @@ class Trainer:
     """graph=True: after `graph_warmup` eager steps the whole step (forward, loss, backward, gradient all-reduce, Adam) is
     captured into ONE hipGraph and replayed; the batch is copied into static input buffers.  The step issues ~2500
     kernels whose CPU launch cost rivals their GPU time at B=64; a replay is a single launch.  Shapes must then stay
-    fixed (the reference trains on fixed-size clouds, configs.yaml num_points) -- a different shape re-captures."""
+    fixed (the reference trains on fixed-size clouds, configs.yaml num_points) -- a different shape re-captures.  The
+    returned loss items and GRU state are the graph's static output tensors: every replay overwrites them in place, so
+    copy (`.clone()` / `float()`) what must outlive the next step."""
 
     def __init__(self, model, lr=1e-3, process_group=None, graph=False, graph_warmup=3):
         self.model = model
