@@ -316,7 +316,7 @@ class Geometry:
                 if lvl > 0 and fps_identity_holds(src.shape[1], npoint):
                     # FPS over a cloud that is itself an FPS ordering, selecting all of it: the identity (see
                     # fps_identity_holds).  Centroids = source cloud, no kernel.
-                    if CHECK_FPS_IDENTITY:
+                    if CHECK_FPS_IDENTITY and not torch.cuda.is_current_stream_capturing():      # the check synchronises
                         _check_fps_identity(src, npoint, self.nuniq[-1])
                     self.xyz.append(src)
                     self.nuniq.append(self.nuniq[-1])
