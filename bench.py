@@ -166,8 +166,14 @@ def bench_train(a, net, d, dev, dist, world, rank):
         pairs = a.batch * world * a.steps / el
         kms, kflops = time_cost_volume_bwd(a.batch, a.npoints, dev)
         ach = kflops / (kms * 1e-3) / 1e12
+        traffic = None
+        try:   # fabric-side bytes per launch from the committed PMC passes (same workload only)
+            if a.batch == 64 and a.npoints == 256:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_cost_volume_bwd.json")))["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         roof = {"kernel": "cost_volume_bwd_kernel", "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": None, "kernel_ms": round(kms, 4), "flops_per_launch": kflops,
+                "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": traffic, "kernel_ms": round(kms, 4), "flops_per_launch": kflops,
                 "share_of_step": round(kms / (el / a.steps * 1e3), 3)}
         cpu = None
         if world == 1 and not a.no_cpu_baseline:
