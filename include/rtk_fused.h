@@ -107,9 +107,18 @@ RTK_EXPORT int rtk_prepare_inputs(int b, int n, const float *pc1, const float *p
  * (lib/pointnet2_modules.py:30-35): same selection rule as rtk_furthest_point_sampling with the
  * min-distance scratch held on chip (initialised to 1e10).  idx (B,npoint) int32, new_xyz (B,npoint,3);
  * nuniq (B) int32 (optional) = number of picks made before the cloud was exhausted (every later pick is
- * point 0, i.e. a duplicate of centroid 0). */
+ * point 0, i.e. a duplicate of centroid 0).  tie (B) int32 (optional) = 1 if some round had more than one point at a
+ * non-zero maximum (the pick then depended on the reference's tie rule), else 0. */
 RTK_EXPORT int rtk_fps_centroids(int b, int n, int npoint, const float *xyz, int *idx, float *new_xyz, int *nuniq,
-                                 rtk_stream_t stream);
+                                 int *tie, rtk_stream_t stream);
+
+/* Levels 2 .. 1+levels of a PNHead (model_utils.py:415-417): furthest point sampling of npoint out of the npoint
+ * centroids of the previous level, starting from the level-1 centroids xyz1 (B,npoint,3) with their counters
+ * nuniq1 / tie (B) from rtk_fps_centroids.  Samples whose level-1 run had no tie are the identity on the coordinates
+ * (proof at fps_relevel_kernel) and are only copied; tied samples run the full selection level after level.
+ * idx (levels,B,npoint) int32, new_xyz (levels,B,npoint,3), nuniq (levels,B). */
+RTK_EXPORT int rtk_fps_relevel(int b, int npoint, int levels, const float *xyz1, const int *nuniq1, const int *tie,
+                               int *idx, float *new_xyz, int *nuniq, rtk_stream_t stream);
 
 /* One time step of nn.GRU(hidden, hidden, layers) on a length-1 sequence (model_utils.py:279,296).
  * x (B,H); h_in, h_out (L,B,H); w_ih, w_hh TRANSPOSED (L,H,3H) = weight_{ih,hh}_l{l}.T, gate order (r,z,n);

@@ -44,8 +44,10 @@ RTK_EXPORT int rtk_version(void);
 /* replaces furthest_point_sampling_wrapper   sampling.cpp:37-47 / sampling_gpu.cu:94-253
  * xyz (B,N,3); temp (B,N) scratch the caller pre-fills with 1e10 (lib/pointnet2_utils.py:26) --
  * read as the initial min-distance and left holding the final one; idx int32 (B,npoint).
- * Tie rule of the reference block reduction is reproduced: ties -> min (k mod block, k),
- * block = 2^floor(log2 N) capped at 1024 (cuda_utils.h:10-14). */
+ * The selection rule of the reference block reduction is reproduced exactly: each of the
+ * block = 2^floor(log2 N) (capped at 1024, cuda_utils.h:10-14) threads keeps the first maximum of its
+ * strided scan, and the shared-memory halving tree (sampling_gpu.cu:86-91,143-203) keeps slot t over
+ * slot t+s on equal values, so ties go to the smallest (bitrev(k mod block), k div block). */
 RTK_EXPORT int rtk_furthest_point_sampling(int b, int n, int npoint, const float *xyz, float *temp, int *idx,
                                 rtk_stream_t stream);
 

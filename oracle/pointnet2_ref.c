@@ -8,7 +8,8 @@
  * The reference ships these ops as CUDA only (src/lib/src/ *.cu -- needs nvcc, unbuildable here),
  * so there is no reference CPU build to link against ("parity unpinned" by the reference's own
  * tests).  Every function below follows the cited .cu kernel statement by
- * statement; thread/block structure is restated only where it decides the result (FPS tie rule).
+ * statement; thread/block structure is restated only where it decides the result (the FPS block
+ * reduction, run as the literal halving tree).
  *
  * Arithmetic contract (mirrored bit-for-bit by the HIP kernels in ratrack_amd/csrc):
  *   squared distance  d2 = fmaf(dz,dz, fmaf(dy,dy, dx*dx))       -- the contraction nvcc's default
@@ -44,8 +45,12 @@ RTK_API int rtk_ref_fps_block_size(int n) {
 /* sampling_gpu.cu:94-209 furthest_point_sampling_kernel<block_size>
  * dataset (B,N,3), temp (B,N) pre-filled by the caller (1e10, lib/pointnet2_utils.py:26), idxs (B,M).
  * Tie rule: thread tid scans k = tid, tid+block, ... keeping the FIRST maximum (strict >, :136-137);
- * the shared-memory tree keeps the LOWER tid on equal values (__update, :86-91).  So the winner is
- * the maximum of temp with ties broken by (k mod block, then k). */
+ * the per-thread results then go through the shared-memory halving tree of :143-203, run literally
+ * below: at stride s = block/2 ... 1 slot t < s absorbs slot t+s and KEEPS ITS OWN entry on equal values
+ * (__update, :86-91: `v2 > v1 ? i2 : i1`).  Slot 0 therefore ends up with the maximum whose thread has the
+ * smallest BIT-REVERSED tid (the last level prefers even tids over odd ones, the level before tids = 0 mod 4
+ * over 2 mod 4, ...): e.g. tids 1 and 2 tied -> tid 2 wins.  Pinned by the literal SIMT emulation
+ * tools/emulate_cu.py (tests/test_emulator_cpu.py). */
 RTK_API int rtk_ref_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
                                             int *idxs) {
     if (m <= 0) return 0;
@@ -73,13 +78,15 @@ RTK_API int rtk_ref_furthest_point_sampling(int b, int n, int m, const float *da
                 best_v[tid] = best;
                 best_i[tid] = besti;
             }
-            /* tree reduction == left fold with "keep the lower tid on ties" */
-            float bv = best_v[0];
-            int bidx = best_i[0];
-            for (int tid = 1; tid < block; ++tid) {
-                if (best_v[tid] > bv) { bv = best_v[tid]; bidx = best_i[tid]; }
-            }
-            old = bidx;
+            /* :143-203 the halving tree; __update(dists, dists_i, t, t + s) for t < s at every level */
+            for (int s = block >> 1; s >= 1; s >>= 1)
+                for (int t = 0; t < s; ++t) {
+                    const float v1 = best_v[t], v2 = best_v[t + s];
+                    const int i1 = best_i[t], i2 = best_i[t + s];
+                    best_v[t] = v1 > v2 ? v1 : v2;      /* max(v1, v2), :89 (no NaNs: distances of finite points) */
+                    best_i[t] = v2 > v1 ? i2 : i1;      /* :90 -- equal values keep slot t */
+                }
+            old = best_i[0];
             out[j] = old;
         }
     }

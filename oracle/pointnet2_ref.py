@@ -150,6 +150,16 @@ def three_interpolate(features, idx, weight):
     return out
 
 
+def knn(k, unknown, known):
+    """interpolate_gpu.cu:9-57 (the exported, dead-on-the-live-path kernel): -> (dist2 (B,n,k), idx int32 (B,n,k))."""
+    B, n, _ = unknown.shape
+    m = known.shape[1]
+    d2 = torch.empty(B, n, k, dtype=torch.float32)
+    idx = torch.empty(B, n, k, dtype=torch.int32)
+    knn_wrapper(B, n, m, k, unknown.contiguous(), known.contiguous(), d2, idx)
+    return d2, idx
+
+
 def knn_point(nsample, xyz, new_xyz, with_dist=False):
     """model_utils.py:85-99: k nearest of `xyz` (B,N,3) for every `new_xyz` (B,S,3) under the
     expansion-formula distance; indices int64 (B,S,k) ordered by (distance, index)."""

@@ -73,66 +73,86 @@ __device__ __forceinline__ void wave_key_max(unsigned &hi, unsigned &lo) {
 // ------------------------------------------------------------------------------------------------
 // furthest point sampling   (reference: sampling_gpu.cu:94-209)
 //
-// The reference runs one CUDA block per sample with 2^floor(log2 n) threads and 511 block-wide
-// shared-memory tree reductions.  Here one WAVE owns one sample and the 511-round dependent chain
-// contains no barrier:
+// The reference runs one CUDA block per sample with block = 2^floor(log2 n) threads and 511 block-wide
+// shared-memory tree reductions.  Its selection rule, which everything below reproduces bit for bit:
+//   * thread tid scans k = tid, tid+block, ... and keeps the FIRST maximum (strict >, :136-137);
+//   * the halving tree (:143-203) merges slot t+s into slot t for s = block/2 ... 1 and keeps slot t's entry
+//     on equal values (__update, :86-91), so among threads holding the maximum the one with the smallest
+//     BIT-REVERSED tid wins (tids 1 and 2 tied -> tid 2).
+// Hence: winner = maximum of the running min-distance, ties broken by the key (bitrev(k mod block), k div block).
+//
+// Here one WAVE owns one sample and the 511-round dependent chain contains no barrier:
 //   * the n <= 64*PPL points and their running min-distances live in registers, laid out in the
-//     reference's TIE ORDER: position p = 64*slot + lane enumerates the points by (k mod block, k div block),
-//     so "ties -> lower tid, then first k" becomes "ties -> smallest position";
+//     reference's TIE ORDER: position p enumerates the points by ascending (bitrev(k mod block), k div block),
+//     so "ties -> reference winner" becomes "ties -> smallest position";
 //   * the round's maximum is a 6-instruction DPP max of the distance bits (non-negative floats order
-//     like unsigned ints); the winner is the first set bit of the first non-empty ballot(t == max)
-//     over the slots -- no index travels through the reduction;
+//     like unsigned ints); the winner is the first set bit of ballot(t == max) -- no index travels through
+//     the reduction;
 //   * the winner's (x, y, z, k) comes back with one uniform-address LDS read;
-//   * once the maximum is 0 every remaining pick is point 0 (all distances stay 0, position 0 wins
-//     every tie), so over-sampled levels (n < npoint, or duplicated points) stop early -- exact.
+//   * once the maximum is 0 every remaining pick is point 0 (all distances stay 0, position 0 = point 0 wins
+//     every tie), so over-sampled levels (n < npoint, or duplicated points) stop early -- exact;
+//   * `tie` reports whether any round had more than one position at a non-zero maximum: without such a tie the
+//     selection is independent of the tie rule, which is what allows the level-2/3 shortcut of
+//     rtk_fps_relevel below.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int fps_pos_to_index(int p, int block, int q, int rem) {
-    // positions sorted by (k mod block, k div block); residues r < rem own q+1 points, the others q
-    const int lim = rem * (q + 1);
-    int r, jj;
-    if (p < lim) { r = p / (q + 1); jj = p % (q + 1); }
-    else { const int pp = p - lim; r = rem + pp / q; jj = pp % q; }
-    return r + jj * block;
+__device__ __forceinline__ int fps_brev(int r, int bits) { return bits ? (int)(__brev((unsigned)r) >> (32 - bits)) : 0; }
+
+// Number of preference ranks i' < i whose residue bitrev(i') owns an extra point, i.e. bitrev(i') < rem.
+// Digit walk over the set bits of i: the ranks that share i's bits above t and have bit t clear are the numbers
+// bitrev = F * 2^(bits-t) + L with t free high bits F and the fixed low part L.
+__device__ __forceinline__ int fps_extra_before(int i, int bits, int rem) {
+    int cnt = 0;
+    for (int t = bits - 1; t >= 0; --t) {
+        if (!((i >> t) & 1)) continue;
+        const int hi = (i >> (t + 1)) << (t + 1);
+        const int L = fps_brev(hi, bits);
+        int c = rem > L ? (rem - L + (1 << (bits - t)) - 1) >> (bits - t) : 0;
+        c = c < (1 << t) ? c : (1 << t);
+        cnt += c;
+    }
+    return cnt;
+}
+
+// position of point k in the tie order: ranks (= bit-reversed residues) ascending, q or q+1 points per residue
+__device__ __forceinline__ int fps_index_to_pos(int k, int block, int bits, int q, int rem) {
+    const int i = fps_brev(k & (block - 1), bits);
+    return i * q + fps_extra_before(i, bits, rem) + (k >> bits);
 }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// One FPS run by one wave.  s_pt: n float4 of LDS.  Returns the number of picks made before the cloud was exhausted.
 template <int PPL>
-__global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, const float *__restrict__ xyz,
-                                                      float *__restrict__ temp, int *__restrict__ idxs,
-                                                      float *__restrict__ new_xyz, int *__restrict__ nuniq) {
-    extern __shared__ __attribute__((aligned(16))) float4 s_pt[];   // (x, y, z, bits(k)) by position
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x;
-    xyz += (size_t)b * n * 3;
-    if (temp) temp += (size_t)b * n;
-    idxs += (size_t)b * m;
-    if (new_xyz) new_xyz += (size_t)b * m * 3;
-    const int q = n / block, rem = n % block;
+__device__ __forceinline__ int fps_wave_body(int n, int m, int block, const float *__restrict__ xyz, float *__restrict__ temp,
+                                             int *__restrict__ idxs, float *__restrict__ new_xyz, float4 *s_pt, int lane,
+                                             bool &tie_out) {
+    const int bits = 31 - __builtin_clz(block);
+    const int q = n >> bits, rem = n & (block - 1);
+    for (int k = lane; k < n; k += 64)      // coalesced read of the cloud, scattered into tie order
+        s_pt[fps_index_to_pos(k, block, bits, q, rem)] = make_float4(xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2], __int_as_float(k));
+    __syncthreads();
 
-    // LANE-MAJOR layout: lane l owns positions PPL*l .. PPL*l + PPL-1 (positions enumerate the points in the reference's
-    // tie order), so "smallest position among the maxima" = lowest lane with the maximum, then its lowest slot.
-    // Slots are processed in pairs with packed fp32 math (v_pk_add/mul/fma: same roundings as the scalar chain).
+    // LANE-MAJOR layout: lane l owns positions PPL*l .. PPL*l + PPL-1, so "smallest position among the maxima" =
+    // lowest lane with the maximum, then its lowest slot.  Slots are processed in pairs with packed fp32 math
+    // (v_pk_add/mul/fma: same roundings as the scalar chain).
     constexpr int H = PPL / 2;
     f2 x[H], y[H], z[H];
     unsigned t[PPL];   // min-distance bits; padding slots hold 0 and coordinates of point 0 (distance stays 0)
+    const float4 p0 = s_pt[0];   // position 0 is always point 0
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
         const int p = lane * PPL + i;
         const bool ok = p < n;
-        const int k = ok ? fps_pos_to_index(p, block, q, rem) : 0;
-        const float px = xyz[k * 3 + 0], py = xyz[k * 3 + 1], pz = xyz[k * 3 + 2];
-        x[i / 2][i % 2] = px; y[i / 2][i % 2] = py; z[i / 2][i % 2] = pz;
-        t[i] = ok ? __float_as_uint(temp ? temp[k] : 1e10f) : 0u;
-        if (ok) s_pt[p] = make_float4(px, py, pz, __int_as_float(k));
+        const float4 v = ok ? s_pt[p] : p0;
+        x[i / 2][i % 2] = v.x; y[i / 2][i % 2] = v.y; z[i / 2][i % 2] = v.z;
+        t[i] = ok ? __float_as_uint(temp ? temp[__float_as_int(v.w)] : 1e10f) : 0u;
     }
-    __syncthreads();
-    float4 o = s_pt[0];   // position 0 is always point 0
+    float4 o = p0;
     if (lane == 0) {
         idxs[0] = 0;
         if (new_xyz) { new_xyz[0] = o.x; new_xyz[1] = o.y; new_xyz[2] = o.z; }
     }
-    const float4 p0 = o;
+    bool tie = false;
     int j = 1;
     for (; j < m; ++j) {
         const f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
@@ -151,16 +171,22 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, c
             const unsigned mm = t[2 * hh] > t[2 * hh + 1] ? t[2 * hh] : t[2 * hh + 1];
             mloc = mm > mloc ? mm : mloc;
         }
-        // lowest slot holding the lane's own maximum: independent of the wave reduction, fills its DPP wait states
-        int sl = 0;
+        // lowest (bits 0-7) and highest (bits 8-15) slot holding the lane's own maximum: independent of the wave
+        // reduction, fills its DPP wait states
+        int sl = 0, sh = 0;
 #pragma unroll
         for (int i = PPL - 1; i >= 0; --i) sl = t[i] == mloc ? i : sl;
-        asm volatile("" : "+v"(sl));              // keep it above the reduction (the compiler would sink it below)
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) sh = t[i] == mloc ? i : sh;
+        int slh = sl | (sh << 8);
+        asm volatile("" : "+v"(slh));             // keep it above the reduction (the compiler would sink it below)
         const unsigned M = wave_max_u32(mloc);
         if (M == 0u) break;                       // exhausted: every remaining pick is index 0
         const unsigned long long mask = __ballot(mloc == M);
         const int wl = __builtin_ctzll(mask);     // lowest lane holding the maximum
-        const int pos = wl * PPL + __builtin_amdgcn_readlane(sl, wl);
+        const int w = __builtin_amdgcn_readlane(slh, wl);
+        tie |= ((mask & (mask - 1)) != 0ull) | ((w >> 8) != (w & 0xff));
+        const int pos = wl * PPL + (w & 0xff);
         o = s_pt[pos];                            // one uniform-address b128 read; lane 0 stores from registers
         asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(o.w));
         if (lane == 0) {
@@ -168,7 +194,6 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, c
             if (new_xyz) { new_xyz[j * 3 + 0] = o.x; new_xyz[j * 3 + 1] = o.y; new_xyz[j * 3 + 2] = o.z; }
         }
     }
-    if (nuniq && lane == 0) nuniq[b] = j;
     for (int jj = j + lane; jj < m; jj += 64) {
         idxs[jj] = 0;
         if (new_xyz) { new_xyz[jj * 3 + 0] = p0.x; new_xyz[jj * 3 + 1] = p0.y; new_xyz[jj * 3 + 2] = p0.z; }
@@ -180,6 +205,63 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, c
             if (p < n) temp[__float_as_int(s_pt[p].w)] = __uint_as_float(t[i]);
         }
     }
+    tie_out = tie;
+    return j;
+}
+
+template <int PPL>
+__global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, const float *__restrict__ xyz,
+                                                      float *__restrict__ temp, int *__restrict__ idxs,
+                                                      float *__restrict__ new_xyz, int *__restrict__ nuniq,
+                                                      int *__restrict__ tie) {
+    extern __shared__ __attribute__((aligned(16))) float4 s_pt[];   // (x, y, z, bits(k)) by position
+    const int b = blockIdx.x;
+    bool tied;
+    const int j = fps_wave_body<PPL>(n, m, block, xyz + (size_t)b * n * 3, temp ? temp + (size_t)b * n : nullptr,
+                                     idxs + (size_t)b * m, new_xyz ? new_xyz + (size_t)b * m * 3 : nullptr, s_pt,
+                                     (int)threadIdx.x, tied);
+    if (threadIdx.x == 0) {
+        if (nuniq) nuniq[b] = j;
+        if (tie) tie[b] = tied ? 1 : 0;
+    }
+}
+
+// Levels 2.. of a PNHead: furthest point sampling of npoint out of the npoint centroids of the previous level
+// (model_utils.py:415-417).  Without a tie in the level-1 run (tie[b] == 0) every such run is the identity on the
+// coordinates: by induction the selected prefix is P[0..j), the running min-distances are bit-identical to the
+// level-1 run's (same formula on the same coordinates), whose UNIQUE maximum was P[j]; once the cloud is exhausted
+// both runs pick index 0, whose coordinates are those of the copies of P[0] that fill the tail.  So
+// new_xyz = xyz1, idx = (0 .. nuniq-1, 0, 0, ...), nuniq unchanged, and this kernel only copies.  With a tie the
+// reference re-breaks it by the POSITION in the new cloud (bit-reversed), which may differ from level 1's choice:
+// the full selection runs, level after level.
+template <int PPL>
+__global__ __launch_bounds__(64) void fps_relevel_kernel(int samples, int npoint, int block, int levels,
+                                                         const float *__restrict__ xyz1, const int *__restrict__ nuniq1,
+                                                         const int *__restrict__ tie, int *__restrict__ idx,
+                                                         float *__restrict__ new_xyz, int *__restrict__ nuniq) {
+    extern __shared__ __attribute__((aligned(16))) float4 s_pt[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float *src = xyz1 + (size_t)b * npoint * 3;
+    if (!tie[b]) {
+        const int nu = nuniq1[b];
+        for (int l = 0; l < levels; ++l) {
+            int *io = idx + ((size_t)l * samples + b) * npoint;
+            float *xo = new_xyz + ((size_t)l * samples + b) * npoint * 3;
+            for (int jj = lane; jj < npoint; jj += 64) io[jj] = jj < nu ? jj : 0;
+            for (int jj = lane; jj < npoint * 3; jj += 64) xo[jj] = src[jj];
+            if (lane == 0) nuniq[(size_t)l * samples + b] = nu;
+        }
+        return;
+    }
+    for (int l = 0; l < levels; ++l) {
+        int *io = idx + ((size_t)l * samples + b) * npoint;
+        float *xo = new_xyz + ((size_t)l * samples + b) * npoint * 3;
+        bool tied;
+        const int j = fps_wave_body<PPL>(npoint, npoint, block, src, nullptr, io, xo, s_pt, lane, tied);
+        if (lane == 0) nuniq[(size_t)l * samples + b] = j;
+        __syncthreads();      // workgroup-scope fence: this wave's centroid stores are visible to its own next run
+        src = xo;
+    }
 }
 
 // General fallback for n > 2048: one 256-thread workgroup per sample, min-distances in global memory.
@@ -187,6 +269,7 @@ __global__ __launch_bounds__(256) void fps_block_kernel(int n, int m, int block,
                                                         float *__restrict__ temp, int *__restrict__ idxs) {
     __shared__ unsigned s_hi[4], s_lo[4];
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int bits = 31 - __builtin_clz(block);
     xyz += (size_t)b * n * 3;
     temp += (size_t)b * n;
     idxs += (size_t)b * m;
@@ -199,7 +282,8 @@ __global__ __launch_bounds__(256) void fps_block_kernel(int n, int m, int block,
             const float d = rtk_sqdist(xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2], ox, oy, oz);
             const float d2 = fminf(d, temp[k]);
             temp[k] = d2;
-            const unsigned nr = ~(((unsigned)(k % block) << 16) | (unsigned)(k / block));
+            // tie key of the reference: (bitrev(k mod block), k div block) ascending = complement descending
+            const unsigned nr = ~(((unsigned)fps_brev(k & (block - 1), bits) << 16) | (unsigned)(k >> bits));
             const unsigned h = __float_as_uint(d2);
             const bool take = (h > hi) || (h == hi && nr > lo);
             hi = take ? h : hi;
@@ -216,7 +300,7 @@ __global__ __launch_bounds__(256) void fps_block_kernel(int n, int m, int block,
             lo = take ? s_lo[w] : lo;
         }
         const unsigned rank = ~lo;
-        old = (int)((rank & 0xffffu) * (unsigned)block + (rank >> 16));
+        old = (int)((rank & 0xffffu) * (unsigned)block) + fps_brev((int)(rank >> 16), bits);
         if (tid == 0) idxs[j] = old;
         __syncthreads();
     }
@@ -231,14 +315,14 @@ static int fps_block_size(int n) {  // cuda_utils.h:10-14 (host code in the refe
 }
 
 static int fps_launch(int b, int n, int npoint, const float *xyz, float *temp, int *idx, float *new_xyz, int *nuniq,
-                      hipStream_t s) {
+                      int *tie, hipStream_t s) {
     const int block = fps_block_size(n);
     RTK_REQUIRE(n / block < 65536, "furthest_point_sampling: n=%d too large", n);
     const size_t lds = (size_t)n * sizeof(float4);
-    if (n <= 64 * 4) fps_wave_kernel<4><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq);
-    else if (n <= 64 * 8) fps_wave_kernel<8><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq);
-    else if (n <= 64 * 16) fps_wave_kernel<16><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq);
-    else if (n <= 64 * 32) fps_wave_kernel<32><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq);
+    if (n <= 64 * 4) fps_wave_kernel<4><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie);
+    else if (n <= 64 * 8) fps_wave_kernel<8><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie);
+    else if (n <= 64 * 16) fps_wave_kernel<16><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie);
+    else if (n <= 64 * 32) fps_wave_kernel<32><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie);
     else return 1;   // caller falls back to the block kernel
     return 0;
 }
@@ -248,7 +332,7 @@ extern "C" int rtk_furthest_point_sampling(int b, int n, int npoint, const float
     RTK_REQUIRE(b > 0 && n > 0 && xyz && temp && idx, "furthest_point_sampling: bad arguments (b=%d n=%d)", b, n);
     if (npoint <= 0) return RTK_OK;
     hipStream_t s = (hipStream_t)stream;
-    const int rc = fps_launch(b, n, npoint, xyz, temp, idx, nullptr, nullptr, s);
+    const int rc = fps_launch(b, n, npoint, xyz, temp, idx, nullptr, nullptr, nullptr, s);
     if (rc < 0) return rc;
     if (rc == 1) fps_block_kernel<<<b, 256, 0, s>>>(n, npoint, fps_block_size(n), xyz, temp, idx);
     RTK_CHECK_LAUNCH("furthest_point_sampling");
@@ -256,12 +340,28 @@ extern "C" int rtk_furthest_point_sampling(int b, int n, int npoint, const float
 }
 
 extern "C" int rtk_fps_centroids(int b, int n, int npoint, const float *xyz, int *idx, float *new_xyz, int *nuniq,
-                                 rtk_stream_t stream) {
+                                 int *tie, rtk_stream_t stream) {
     RTK_REQUIRE(b > 0 && n > 0 && npoint > 0 && xyz && idx && new_xyz, "fps_centroids: bad arguments (b=%d n=%d)", b, n);
     RTK_REQUIRE(n <= 2048, "fps_centroids: n=%d > 2048 (use rtk_furthest_point_sampling + rtk_gather_points)", n);
-    const int rc = fps_launch(b, n, npoint, xyz, nullptr, idx, new_xyz, nuniq, (hipStream_t)stream);
+    const int rc = fps_launch(b, n, npoint, xyz, nullptr, idx, new_xyz, nuniq, tie, (hipStream_t)stream);
     if (rc < 0) return rc;
     RTK_CHECK_LAUNCH("fps_centroids");
+    return RTK_OK;
+}
+
+extern "C" int rtk_fps_relevel(int b, int npoint, int levels, const float *xyz1, const int *nuniq1, const int *tie, int *idx,
+                               float *new_xyz, int *nuniq, rtk_stream_t stream) {
+    RTK_REQUIRE(b > 0 && npoint > 0 && levels > 0 && xyz1 && nuniq1 && tie && idx && new_xyz && nuniq,
+                "fps_relevel: bad arguments (b=%d npoint=%d levels=%d)", b, npoint, levels);
+    RTK_REQUIRE(npoint <= 2048, "fps_relevel: npoint=%d > 2048", npoint);
+    hipStream_t s = (hipStream_t)stream;
+    const int block = fps_block_size(npoint);
+    const size_t lds = (size_t)npoint * sizeof(float4);
+    if (npoint <= 64 * 4) fps_relevel_kernel<4><<<b, 64, lds, s>>>(b, npoint, block, levels, xyz1, nuniq1, tie, idx, new_xyz, nuniq);
+    else if (npoint <= 64 * 8) fps_relevel_kernel<8><<<b, 64, lds, s>>>(b, npoint, block, levels, xyz1, nuniq1, tie, idx, new_xyz, nuniq);
+    else if (npoint <= 64 * 16) fps_relevel_kernel<16><<<b, 64, lds, s>>>(b, npoint, block, levels, xyz1, nuniq1, tie, idx, new_xyz, nuniq);
+    else fps_relevel_kernel<32><<<b, 64, lds, s>>>(b, npoint, block, levels, xyz1, nuniq1, tie, idx, new_xyz, nuniq);
+    RTK_CHECK_LAUNCH("fps_relevel");
     return RTK_OK;
 }
 

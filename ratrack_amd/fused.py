@@ -44,7 +44,8 @@ _lib.SIGNATURES.update({
     "rtk_cost_volume": [_ci] * 3 + [_vp] * 6 + [ctypes.POINTER(_Layer), ctypes.POINTER(_Layer), _vp, _ci, _vp],
     "rtk_patch_cost": [_ci] * 2 + [_vp] * 3 + [_ci, ctypes.POINTER(_Layer), _vp, _ci, _ci, _vp],
     "rtk_prepare_inputs": [_ci] * 2 + [_vp] * 6 + [_vp],
-    "rtk_fps_centroids": [_ci] * 3 + [_vp] * 4 + [_vp],
+    "rtk_fps_centroids": [_ci] * 3 + [_vp] * 5 + [_vp],
+    "rtk_fps_relevel": [_ci] * 3 + [_vp] * 6 + [_vp],
     "rtk_gru_step": [_ci] * 3 + [_vp] * 8 + [_vp],
     "rtk_to_channel_major": [_ci] * 3 + [_vp, _ci, _ci, _vp, _ci, _ci, _vp],
     "rtk_ball_query_pair": [_ci] * 3 + [ctypes.c_float, _ci, ctypes.c_float, _ci] + [_vp] * 5 + [_vp],
@@ -234,34 +235,23 @@ class _PNHeadWeights:
             self.fp[name] = Chain([(w, b, ACT_RELU)], device)
 
 
-CHECK_FPS_IDENTITY = bool(int(__import__("os").environ.get("RTK_CHECK_FPS_IDENTITY", "0")))
+CHECK_FPS_RELEVEL = bool(int(__import__("os").environ.get("RTK_CHECK_FPS_RELEVEL", "0")))
 
 
-def fps_identity_holds(n, npoint):
-    """True when furthest-point sampling of `npoint` out of `n` points is provably the identity permutation GIVEN
-    that the cloud is itself the output of a previous FPS (levels 2 and 3 of PNHead, model_utils.py:415-417):
-    n == npoint and n a power of two <= 1024.
-
-    Proof sketch.  Let P[0..n) be the centroids of the previous level in selection order.  Run FPS on P.  By
-    induction the selected prefix is P[0..j): the running min-distances are then bit-identical to the previous
-    run's (same formula on the same coordinates, rtk_sqdist), so P[j] -- the previous run's arg-max over a superset
-    of the remaining candidates -- still attains the maximum M.  If M > 0 every already selected position has
-    distance 0 < M, so the lowest tied position is j, and with block = 2^floor(log2 n) = n the reference's tie
-    rule (k mod block, k) IS position order: pick j.  If M = 0 the cloud is exhausted and every later pick is
-    index 0 in both runs, whose coordinates equal P[j] (a copy of P[0]) -- the gathered centroids are again P.
-    Hence new_xyz == xyz bit for bit, and the exhausted-cloud counter carries over.  RTK_CHECK_FPS_IDENTITY=1
-    re-runs the full kernel and asserts it; tests/test_fused_gpu.py::test_fps_identity does so on every fixture."""
-    return n == npoint and n <= 1024 and (n & (n - 1)) == 0
-
-
-def _check_fps_identity(src, npoint, cnt_prev):
-    S_ = src.shape[0]
-    idx = torch.empty(S_, npoint, dtype=torch.int32, device=src.device)
-    out = torch.empty(S_, npoint, 3, dtype=torch.float32, device=src.device)
-    cnt = torch.empty(S_, dtype=torch.int32, device=src.device)
-    _lib.call("rtk_fps_centroids", S_, src.shape[1], npoint, src.data_ptr(), idx.data_ptr(), out.data_ptr(), cnt.data_ptr(), _stream())
-    assert torch.equal(out, src), "FPS identity violated: level centroids differ from the source cloud"
-    assert torch.equal(cnt, cnt_prev.view(-1)), "FPS identity violated: exhausted-cloud counters differ"
+def check_fps_relevel(xyz1, idx, new_xyz, nuniq):
+    """Debug / test helper: levels 2.. as produced by rtk_fps_relevel (idx (L,S_,npoint), new_xyz (L,S_,npoint,3),
+    nuniq (L,S_)) against the full selection kernel run level after level.  Synchronises."""
+    S_, npoint, _ = xyz1.shape
+    src = xyz1
+    for l in range(idx.shape[0]):
+        i = torch.empty(S_, npoint, dtype=torch.int32, device=src.device)
+        out = torch.empty(S_, npoint, 3, dtype=torch.float32, device=src.device)
+        cnt = torch.empty(S_, dtype=torch.int32, device=src.device)
+        _lib.call("rtk_fps_centroids", S_, npoint, npoint, src.data_ptr(), i.data_ptr(), out.data_ptr(), cnt.data_ptr(), None, _stream())
+        assert torch.equal(i, idx[l].view(S_, npoint)), "fps_relevel: level %d indices differ from the full selection" % (l + 2)
+        assert torch.equal(out, new_xyz[l].view(S_, npoint, 3)), "fps_relevel: level %d centroids differ" % (l + 2)
+        assert torch.equal(cnt, nuniq[l].view(-1)), "fps_relevel: level %d exhausted-cloud counters differ" % (l + 2)
+        src = out
 
 
 class _NullCtx:
@@ -294,11 +284,14 @@ class Geometry:
         # and the 3 three-NN index tables
         ns_all = [ns for row in _PNHeadWeights.NSAMPLES for ns in row]
         nn_rows = [npoint, npoint, n]
-        sizes = [S_ * npoint] * 3 + [S_] * 3 + [S_ * npoint * ns for ns in ns_all] + [S_ * r * 3 for r in nn_rows]
+        sizes = [S_ * npoint] * 3 + [S_] * 4 + [S_ * npoint * ns for ns in ns_all] + [S_ * r * 3 for r in nn_rows]
         ws = torch.zeros(sum(sizes), dtype=torch.int32, device=dev)
         parts = list(torch.split(ws, sizes))
-        fps_idx, cnt, ball, nn_idx = parts[0:3], parts[3:6], parts[6:12], parts[12:15]
-        new_xyz = [torch.empty(S_, npoint, 3, dtype=torch.float32, device=dev) for _ in range(3)]
+        fps_idx, cnt, tie, ball, nn_idx = parts[0:3], parts[3:6], parts[6], parts[7:13], parts[13:16]
+        self.fps_idx = [t.view(S_, npoint) for t in fps_idx]
+        self.tie = tie
+        xyz_all = torch.empty(3, S_, npoint, 3, dtype=torch.float32, device=dev)
+        new_xyz = [xyz_all[l] for l in range(3)]
         d2_all = (torch.zeros if finite else torch.empty)(sum(nn_rows) * S_ * 3, dtype=torch.float32, device=dev)
         d2_parts = torch.split(d2_all, [S_ * r * 3 for r in nn_rows])
         B = knn_frames
@@ -311,24 +304,25 @@ class Geometry:
             side.wait_stream(main)
         ctx = torch.cuda.stream(side) if side is not None else _NullCtx()
         with ctx:
+            # ---- level 1: the only full furthest-point selection on the common path ---------------------------
+            if not big:
+                _lib.call("rtk_fps_centroids", S_, n, npoint, xyz.data_ptr(), fps_idx[0].data_ptr(), new_xyz[0].data_ptr(),
+                          cnt[0].data_ptr(), tie.data_ptr(), _stream())
+            else:   # large clouds: generic FPS + gather, no exhausted-cloud / tie information
+                _native.furthest_point_sampling_wrapper(S_, n, npoint, xyz, temp, self.fps_idx[0])
+                new_xyz[0].copy_(torch.gather(xyz, 1, self.fps_idx[0].long().unsqueeze(-1).expand(-1, -1, 3)))
+                cnt[0].fill_(npoint)
+                tie.fill_(1)            # unknown: levels 2, 3 run the full selection
+
+            def relevel():
+                # ---- levels 2, 3: FPS of npoint out of the previous level's npoint centroids (model_utils.py:415-417).
+                # One launch: samples without a level-1 tie are provably the identity on the coordinates and are copied,
+                # tied samples run the full selection (see fps_relevel_kernel) -- decided on the device, no host sync.
+                _lib.call("rtk_fps_relevel", S_, npoint, 2, new_xyz[0].data_ptr(), cnt[0].data_ptr(), tie.data_ptr(),
+                          fps_idx[1].data_ptr(), new_xyz[1].data_ptr(), cnt[1].data_ptr(), _stream())
+                if CHECK_FPS_RELEVEL and not torch.cuda.is_current_stream_capturing():      # the check synchronises
+                    check_fps_relevel(new_xyz[0], torch.stack(self.fps_idx[1:]), xyz_all[1:], torch.stack(list(cnt[1:3])))
             for lvl in range(3):
-                src = self.xyz[-1]
-                if lvl > 0 and fps_identity_holds(src.shape[1], npoint):
-                    # FPS over a cloud that is itself an FPS ordering, selecting all of it: the identity (see
-                    # fps_identity_holds).  Centroids = source cloud, no kernel.
-                    if CHECK_FPS_IDENTITY and not torch.cuda.is_current_stream_capturing():      # the check synchronises
-                        _check_fps_identity(src, npoint, self.nuniq[-1])
-                    self.xyz.append(src)
-                    self.nuniq.append(self.nuniq[-1])
-                    continue
-                if src.shape[1] <= 2048:
-                    _lib.call("rtk_fps_centroids", S_, src.shape[1], npoint, src.data_ptr(), fps_idx[lvl].data_ptr(),
-                              new_xyz[lvl].data_ptr(), cnt[lvl].data_ptr(), _stream())
-                else:   # large clouds: generic FPS + gather
-                    idx = fps_idx[lvl].view(S_, npoint)
-                    _native.furthest_point_sampling_wrapper(S_, src.shape[1], npoint, src, temp, idx)
-                    new_xyz[lvl].copy_(torch.gather(src, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)))
-                    cnt[lvl].fill_(npoint)      # no exhausted-cloud information on this path: every centroid is computed
                 self.xyz.append(new_xyz[lvl])
                 self.nuniq.append(cnt[lvl])
             self.ball = []
@@ -340,7 +334,6 @@ class Geometry:
                     row.append(bidx)
                 self.ball.append(row)
             # order on the side stream = order of first use: level-l tables right after level-l centroids
-            # (the three FPS calls are a dependent chain, so they were enqueued first)
             for lvl in range(3):
                 (r1, r2), (n1, n2) = _PNHeadWeights.RADII[lvl], _PNHeadWeights.NSAMPLES[lvl]
                 nsrc = self.xyz[lvl].shape[1]
@@ -353,6 +346,8 @@ class Geometry:
                         _native.ball_query_wrapper(S_, nsrc, npoint, float(_PNHeadWeights.RADII[lvl][s]), _PNHeadWeights.NSAMPLES[lvl][s],
                                                    self.xyz[lvl + 1], self.xyz[lvl], self.ball[lvl][s])
                 self._record(lvl, side)
+                if lvl == 0:
+                    relevel()
             self.nn = {}
             for i, (name, (u, k)) in enumerate({"fp3": (2, 3), "fp2": (1, 2), "fp1": (0, 1)}.items()):
                 nu, m = self.xyz[u].shape[1], self.xyz[k].shape[1]
@@ -389,6 +384,7 @@ class Geometry:
         g.xyz = [x[:count] for x in self.xyz]
         g.ball = [[b[:count] for b in row] for row in self.ball]
         g.nuniq = [c[:count] for c in self.nuniq]
+        g.fps_idx, g.tie = [i[:count] for i in self.fps_idx], self.tie[:count]
         g.events, g.knn = self.events, self.knn
         g.nn = {k: (d2[:count], idx[:count], m) for k, (d2, idx, m) in self.nn.items()}
         return g

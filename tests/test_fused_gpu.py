@@ -239,7 +239,10 @@ def test_misc_kernels():
     idx = torch.empty(2 * B, 512, dtype=torch.int32, device=DEV)
     nxyz = torch.empty(2 * B, 512, 3, device=DEV)
     cnt = torch.empty(2 * B, dtype=torch.int32, device=DEV)
-    _lib.call("rtk_fps_centroids", 2 * B, N, 512, xyz.data_ptr(), idx.data_ptr(), nxyz.data_ptr(), cnt.data_ptr(), F._stream())
+    tie = torch.empty(2 * B, dtype=torch.int32, device=DEV)
+    _lib.call("rtk_fps_centroids", 2 * B, N, 512, xyz.data_ptr(), idx.data_ptr(), nxyz.data_ptr(), cnt.data_ptr(), tie.data_ptr(),
+              F._stream())
+    assert (tie.cpu() == 0).all()              # generic float cloud: no round had two points at the maximum
     ref = P.fps(xyz.cpu(), 512)
     assert torch.equal(idx.cpu(), ref)
     assert torch.equal(nxyz.cpu(), torch.gather(xyz.cpu(), 1, ref.long().unsqueeze(-1).expand(-1, -1, 3)))
@@ -269,10 +272,13 @@ def test_misc_kernels():
     assert torch.equal(dst[:, :128], g.unsqueeze(2).expand(-1, -1, N))
 
 
-def test_fps_identity():
-    """Levels 2/3 elide FPS (n == npoint == 512 over an FPS-ordered cloud): assert against the full kernel on every
-    fixture cloud, on duplicate-heavy clouds and on clouds with exact distance ties."""
+def test_fps_relevel():
+    """Levels 2/3 (FPS of 512 out of the previous level's 512 centroids): the one-launch rtk_fps_relevel -- copy when the
+    level-1 run had no tie, full selection otherwise -- against (a) the full selection kernel level after level and
+    (b) the CPU oracle, on every fixture cloud, on duplicate-heavy clouds and on lattices with exact distance ties
+    between distinct points (where the reference's bit-reversed tie rule makes level 2 differ from level 1)."""
     from _util import EVAL_CASES, inputs_of, load_case
+    from oracle import pointnet2_ref as P
     from ratrack_amd import _lib
     clouds = []
     for name in EVAL_CASES:
@@ -280,16 +286,33 @@ def test_fps_identity():
         clouds += [pc1.permute(0, 2, 1).contiguous(), pc2.permute(0, 2, 1).contiguous()]
     g = torch.Generator().manual_seed(5)
     lattice = torch.randint(0, 6, (3, 700, 3), generator=g).float().to(DEV)      # integer lattice: many exact ties + duplicates
-    clouds += [lattice, lattice[:, :300].contiguous(), torch.zeros(2, 64, 3, device=DEV)]
+    grid = torch.stack(torch.meshgrid(*[torch.arange(8.)] * 3, indexing="ij"), -1).reshape(1, 512, 3).to(DEV)
+    clouds += [lattice, lattice[:, :300].contiguous(), torch.zeros(2, 64, 3, device=DEV), grid, grid[:, :256].contiguous()]
+    n_tied = n_moved = 0
     for xyz in clouds:
         S_, n, _ = xyz.shape
         l1 = torch.empty(S_, 512, 3, device=DEV)
         idx = torch.empty(S_, 512, dtype=torch.int32, device=DEV)
         c1 = torch.empty(S_, dtype=torch.int32, device=DEV)
-        _lib.call("rtk_fps_centroids", S_, n, 512, xyz.data_ptr(), idx.data_ptr(), l1.data_ptr(), c1.data_ptr(), F._stream())
-        assert F.fps_identity_holds(512, 512)
-        F._check_fps_identity(l1, 512, c1)        # asserts new_xyz == l1 and equal counters
-    assert not F.fps_identity_holds(500, 512) and not F.fps_identity_holds(2048, 2048) and not F.fps_identity_holds(384, 384)
+        tie = torch.empty(S_, dtype=torch.int32, device=DEV)
+        _lib.call("rtk_fps_centroids", S_, n, 512, xyz.data_ptr(), idx.data_ptr(), l1.data_ptr(), c1.data_ptr(), tie.data_ptr(), F._stream())
+        idx23 = torch.empty(2, S_, 512, dtype=torch.int32, device=DEV)
+        xyz23 = torch.empty(2, S_, 512, 3, device=DEV)
+        c23 = torch.empty(2, S_, dtype=torch.int32, device=DEV)
+        _lib.call("rtk_fps_relevel", S_, 512, 2, l1.data_ptr(), c1.data_ptr(), tie.data_ptr(), idx23.data_ptr(), xyz23.data_ptr(),
+                  c23.data_ptr(), F._stream())
+        F.check_fps_relevel(l1, idx23, xyz23, c23)
+        # the CPU oracle, level after level
+        src = l1.cpu()
+        assert torch.equal(idx.cpu(), P.fps(xyz.cpu(), 512))
+        for l in range(2):
+            ref = P.fps(src, 512)
+            assert torch.equal(idx23[l].cpu(), ref), l
+            src = torch.gather(src, 1, ref.long().unsqueeze(-1).expand(-1, -1, 3))
+            assert torch.equal(xyz23[l].cpu(), src), l
+        n_tied += int(tie.sum())
+        n_moved += int((xyz23[0] != l1).any(-1).any(-1).sum())
+    assert n_tied > 0 and n_moved > 0, "the lattice clouds must exercise the tied (non-identity) path"
 
 
 def test_ball_query_pair_and_masked_three_nn():

@@ -38,6 +38,25 @@ def test_fps_duplicates_and_ties():
         assert torch.equal(PU.furthest_point_sample(x.to(DEV), 512).cpu(), P.fps(x, 512))
 
 
+@pytest.mark.parametrize("n,m", [(64, 64), (125, 125), (242, 300), (256, 512), (343, 343), (512, 512), (1000, 512), (1024, 512),
+                                 (2048, 100), (2500, 40), (4096, 33)])
+def test_fps_lattice_ties(n, m):
+    """Integer lattices: almost every round has distinct points at exactly the same distance, so each pick is decided by
+    the reference's block reduction (sampling_gpu.cu:86-91,143-203: smallest bit-reversed thread id wins).  The oracle is
+    pinned to a literal emulation of that reduction in tests/test_emulator_cpu.py."""
+    side = 2
+    while side ** 3 < n:
+        side += 1
+    g = torch.stack(torch.meshgrid(*[torch.arange(float(side))] * 3, indexing="ij"), -1).reshape(-1, 3)
+    perm = torch.randperm(side ** 3, generator=torch.Generator().manual_seed(n))
+    x = torch.stack([g[:n], g[perm][:n]]).contiguous()          # lexicographic and shuffled lattice points
+    ref = P.fps(x, m)
+    out = PU.furthest_point_sample(x.to(DEV), m).cpu()
+    assert torch.equal(out, ref)
+    if n == 64:       # the probe quoted in VERDICT round 1: tids 1,2 tied -> tid 2
+        assert ref[0, :8].tolist() == [0, 63, 56, 14, 35, 28, 49, 7]
+
+
 @pytest.mark.parametrize("n,m,r,ns", [(256, 512, 2.0, 4), (256, 512, 4.0, 8), (512, 512, 8.0, 16), (512, 512, 16.0, 32),
                                       (1024, 512, 2.0, 4), (242, 512, 4.0, 8), (6000, 70, 8.0, 16), (5, 3, 100.0, 7)])
 def test_ball_query(n, m, r, ns):

@@ -116,8 +116,10 @@ def test_train_step_matches_reference():
 def test_kernel_edge_cases():
     """Empty balls stay zero, N < npoint over-sampling, < 3 known points, ties keep the first index."""
     xyz = torch.tensor([[[0., 0, 0], [1, 0, 0], [1, 0, 0], [50, 0, 0]]])
-    # FPS over-sampling: after the 3 distinct points are exhausted index 0 repeats
-    assert P.fps(xyz, 6)[0].tolist() == [0, 3, 1, 0, 0, 0]
+    # FPS over-sampling: after the 3 distinct points are exhausted index 0 repeats.  Points 1 and 2 (threads 1 and 2 of a
+    # 4-thread block) tie in round 2: the halving tree keeps the smaller BIT-REVERSED tid, i.e. thread 2
+    # (sampling_gpu.cu:86-91,143-203; literal emulation in tests/test_emulator_cpu.py)
+    assert P.fps(xyz, 6)[0].tolist() == [0, 3, 2, 0, 0, 0]
     new_xyz = torch.tensor([[[0.5, 0, 0], [200., 0, 0]]])
     idx = P.ball_query(1.0, 4, xyz, new_xyz)
     assert idx[0, 0].tolist() == [0, 1, 2, 0]      # first hit pre-fills all slots, then index order
