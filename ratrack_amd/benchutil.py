@@ -1,0 +1,99 @@
+"""Measurement helpers of bench.py (no product logic): live HIP-event timings of the irregular (geometry / gather / scatter)
+kernels at the bench shape with their algorithmic byte counts -- north_star asks for these ops' GB/s against the 8 TB/s
+HBM roofline ("HBM bandwidth for n1-n6, the kNN and every gather/scatter")."""
+import torch
+
+from . import _lib, fused
+from . import pointnet2_hip as _native
+
+HBM_PEAK_GBS = 8000.0
+
+
+def _time(fn, iters):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters          # ms per launch, on the launch stream
+
+
+def irregular_ops(batch, n, dev, npoint=512, iters=20, pmc=None):
+    """One entry per irregular kernel of a forward / train step at B=batch frame-pairs of n points (2B clouds through the
+    shared encoder): launches per step, ms per launch (HIP events, back-to-back launches on the current stream), the
+    ALGORITHMIC bytes per launch (compulsory reads + writes of the rows the kernel computes; duplicate centroids beyond the
+    exhausted-cloud counter are not computed), GB/s and the fraction of the 8 TB/s HBM peak.  `pmc`: optional
+    {kernel: fabric bytes per launch} from the committed PMC passes (profiles/r02_irregular_hbm.json) -> "traffic"."""
+    from . import synth
+    d = synth.make_frame_pairs(batch, n, case_id=1000)
+    xyz = torch.cat([torch.from_numpy(d["pc1"]), torch.from_numpy(d["pc2"])]).permute(0, 2, 1).contiguous().to(dev)
+    S_ = 2 * batch
+    st = fused._stream
+    geo = fused.Geometry(xyz, npoint, side=None, knn_frames=batch)
+    torch.cuda.synchronize()
+    U = [float(c.double().mean().item()) for c in geo.nuniq]            # live centroid rows per sample and level
+    out = []
+
+    def add(kernel, per_step, ms, nbytes, what):
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        e = {"kernel": kernel, "launches_per_step": per_step, "ms": round(ms, 5), "bytes": int(nbytes), "GB/s": round(gbs, 1),
+             "frac": round(gbs / HBM_PEAK_GBS, 5), "what": what}
+        if pmc and kernel in pmc:
+            e["traffic"] = pmc[kernel]
+        out.append(e)
+
+    i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
+    f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    # ---- furthest point sampling + centroid gather, level 1 (the 511-round dependent chain) ----------------------------
+    idx, nx, cnt, tie = i32(S_, npoint), f32(S_, npoint, 3), i32(S_), i32(S_)
+    ms = _time(lambda: _lib.call("rtk_fps_centroids", S_, n, npoint, xyz.data_ptr(), idx.data_ptr(), nx.data_ptr(), cnt.data_ptr(),
+                                 tie.data_ptr(), st()), iters)
+    add("fps_wave_kernel", 1, ms, S_ * (n * 12 + npoint * 16 + 8), "FPS %d -> %d + centroid gather, %d clouds" % (n, npoint, S_))
+    idx23, nx23, cnt23 = i32(2, S_, npoint), f32(2, S_, npoint, 3), i32(2, S_)
+    ms = _time(lambda: _lib.call("rtk_fps_relevel", S_, npoint, 2, nx.data_ptr(), cnt.data_ptr(), tie.data_ptr(), idx23.data_ptr(),
+                                 nx23.data_ptr(), cnt23.data_ptr(), st()), iters)
+    add("fps_relevel_kernel", 1, ms, S_ * (npoint * 12 + 2 * npoint * 16 + 12), "levels 2, 3 (copy unless a level-1 tie)")
+    # ---- ball queries: both scales of a level in one scan ----------------------------------------------------------------
+    for lvl in range(3):
+        (r1, r2), (n1, n2) = fused._PNHeadWeights.RADII[lvl], fused._PNHeadWeights.NSAMPLES[lvl]
+        src, dst = geo.xyz[lvl], geo.xyz[lvl + 1]
+        b1, b2 = geo.ball[lvl]
+        ms = _time(lambda: _lib.call("rtk_ball_query_pair", S_, src.shape[1], npoint, float(r1), n1, float(r2), n2, dst.data_ptr(),
+                                     src.data_ptr(), b1.data_ptr(), b2.data_ptr(), geo.nuniq[lvl].data_ptr(), st()), iters)
+        nsrc = src.shape[1] if lvl == 0 else U[lvl - 1]
+        add("ball_query_pair_kernel[l%d]" % (lvl + 1), 1, ms, S_ * (nsrc * 12 + U[lvl] * (12 + 4 * (n1 + n2))),
+            "r=(%g,%g) ns=(%d,%d), %d source points" % (r1, r2, n1, n2, src.shape[1]))
+    # ---- three nearest neighbours ----------------------------------------------------------------------------------------
+    for name, (u, k) in {"fp3": (2, 3), "fp2": (1, 2), "fp1": (0, 1)}.items():
+        d2, ix, m = geo.nn[name]
+        nu = geo.xyz[u].shape[1]
+        mask = geo.nuniq[u - 1].data_ptr() if u > 0 else None
+        ms = _time(lambda: _lib.call("rtk_three_nn_masked", S_, nu, m, geo.xyz[u].data_ptr(), geo.xyz[k].data_ptr(), d2.data_ptr(),
+                                     ix.data_ptr(), mask, geo.nuniq[k - 1].data_ptr(), st()), iters)
+        rows = nu if u == 0 else U[u - 1]
+        add("three_nn_kernel[%s]" % name, 1, ms, S_ * (rows * 12 + U[k - 1] * 12 + rows * 24), "%d unknown vs %d known" % (nu, m))
+    # ---- kNN (k = 16) of the cost volume: torch.topk-based knn_point in the reference ---------------------------------------
+    x1, x2 = xyz[:batch], xyz[batch:]
+    knn = torch.empty(batch, n, 16, dtype=torch.int64, device=dev)
+    ms = _time(lambda: _native.knn_point_wrapper(batch, n, n, 16, x1, x2, knn), iters)
+    add("knn_point_kernel", 2, ms, batch * (2 * n * 12 + n * 16 * 8), "k=16, %d x %d per pair, int64 indices" % (n, n))
+    # ---- training-side gather gradients ------------------------------------------------------------------------------------
+    M = batch * n * 16
+    src_rows = torch.randn(M, 256, device=dev)
+    dst_rows = f32(batch * n, 256)
+    from . import train_ops  # noqa: F401  (registers the signatures)
+    ms = _time(lambda: _lib.call("rtk_scatter_add_rows", batch, n * 16, n, 256, knn.data_ptr(), src_rows.data_ptr(), dst_rows.data_ptr(),
+                                 st()), iters)
+    add("scatter_add_rows_kernel", 2, ms, M * 256 * 4 + M * 8 + batch * n * 256 * 4,
+        "gather backward of the cost volume: %d rows x 256 ch -> %d rows, atomic-free" % (M, batch * n))
+    rows, ns, C = int(min(n, npoint)), 32, 64
+    gidx = torch.randint(0, rows, (S_, rows, ns), dtype=torch.int32, device=dev)
+    dz, dq = torch.randn(S_, C, rows, ns, device=dev), f32(S_, C, rows)
+    ms = _time(lambda: _lib.call("rtk_group_points_grad_set", S_, C, rows, rows, ns, dz.data_ptr(), gidx.data_ptr(), dq.data_ptr(), st()),
+               iters)
+    add("group_points_grad_kernel", 12, ms, S_ * (C * rows * ns * 4 + rows * ns * 4 + C * rows * 4),
+        "grouping backward, largest SA shape: %d ch x %d centroids x %d neighbours (LDS float atomics)" % (C, rows, ns))
+    return out

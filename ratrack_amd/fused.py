@@ -68,6 +68,41 @@ def ceil16(c):
     return (c + 15) // 16 * 16
 
 
+# ---- work counter ------------------------------------------------------------------------------------------------
+# The multiply-adds this design EXECUTES differ from the reference formulation's (per-point layer-1 projections instead of
+# per-(centroid, neighbour) ones, duplicate centroids skipped, composed linear maps), and part of the count is data
+# dependent (exhausted-cloud counters).  trace_work() records every fused launch of one backbone() call with its shapes;
+# executed_macs() turns the records into multiply-adds (true channel counts, not the 16-padded MFMA tiles).
+_TRACE = None
+
+
+class trace_work:
+    def __enter__(self):
+        global _TRACE
+        _TRACE = self.records = []
+        return self
+
+    def __exit__(self, *a):
+        global _TRACE
+        _TRACE = None
+        return False
+
+    def executed_macs(self):
+        """-> (total multiply-adds, {kernel family: multiply-adds}).  Synchronises (reads the duplicate-row counters)."""
+        per = {}
+        for kind, rows, macs_per_row in self.records:
+            r = float(rows.sum().item()) if torch.is_tensor(rows) else float(rows)
+            per[kind] = per.get(kind, 0.0) + r * macs_per_row
+        return sum(per.values()), per
+
+
+def _live_rows(nuniq, rows_per_sample, samples):
+    """Rows a kernel computes when rows >= nuniq[b] of every sample are skipped (device tensor: no sync here)."""
+    if nuniq is None:
+        return samples * rows_per_sample
+    return torch.clamp(nuniq[:samples].to(torch.int64), max=rows_per_sample)
+
+
 # ---- weight preparation -----------------------------------------------------------------------------
 
 def fold_bn(w, bn_prefix, sd, eps=1e-5):
@@ -104,6 +139,7 @@ class Chain:
     def __init__(self, layers, device):
         """layers: list of (W (Cout,Cin) float64/32 tensor, bias (Cout,), act)."""
         packs, biases, meta = [], [], []
+        self.dims = [tuple(w.shape) for w, _, _ in layers]          # true (Cout, Cin) per layer, for the work counter
         for w, b, act in layers:
             cout, cin = w.shape
             packs.append(pack_layer(w.to(device)))
@@ -147,6 +183,9 @@ def pointwise(rows, rows_per_sample, srcs, chain, out, out_channels=None, sample
         ptr, pitch = _colptr(kf)
         ip = ctypes.pointer(_Interp(ptr, pitch, ch, m, idx.data_ptr(), d2.data_ptr(), nu.data_ptr() if nu is not None else None))
     oc = out_channels if out_channels is not None else chain.cout
+    if _TRACE is not None:
+        macs = sum(co * ci for co, ci in chain.dims) + (3 * interp[1] if interp is not None else 0)
+        _TRACE.append(("pointwise", _live_rows(row_nuniq, rows_per_sample, rows // rows_per_sample), macs))
     if channel_major:
         optr, opitch = out.data_ptr(), 0
     else:
@@ -398,6 +437,9 @@ def sa_scale(geo, W, lvl, s, q, qcol, out, out_offset):
     optr, opitch = _colptr(out)
     src, dst = geo.xyz[lvl], geo.xyz[lvl + 1]
     src_nu = geo.nuniq[lvl - 1].data_ptr() if lvl > 0 else None     # level-0 source rows are the original points
+    if _TRACE is not None:      # per (centroid, neighbour) pair: offset layer (3 + bias) x C1, then the resident chain
+        macs = sc.nsample * (4 * sc.c1 + sum(co * ci for co, ci in sc.chain.dims))
+        _TRACE.append(("sa_scale", _live_rows(geo.nuniq[lvl], geo.npoint, geo.samples), macs))
     _lib.call("rtk_sa_scale", geo.samples, src.shape[1], geo.npoint, sc.nsample, src.data_ptr(), dst.data_ptr(),
               geo.ball[lvl][s].data_ptr(), qptr, qpitch, ceil16(sc.c1) // 16, sc.w1img.data_ptr(),
               sc.chain.n, sc.chain.arr, optr, opitch, out_offset, src_nu, geo.nuniq[lvl].data_ptr(), _stream())
@@ -454,6 +496,7 @@ class FusedBackbone:
         self.gru_whh = g("weight_hh").transpose(1, 2).contiguous()
         self.gru_bih, self.gru_bhh = g("bias_ih").contiguous(), g("bias_hh").contiguous()
         self.kernel_events = None      # set to a list to record (start, stop) events around the dominant kernel
+        self._split_hook = None
         self.side, self.use_side_stream = None, True    # geometry kernels run on a forked stream
         self._last_cv = None
         self.enc = _PNHeadWeights(sd, "pn_head.", dev)
@@ -527,15 +570,25 @@ class FusedBackbone:
         knn1, knn2 = geo.knn
         cor1 = new(B * N, 256)
         self._last_cv = (B, N, x1, x2, knn1, p1, p2, cor1)
-        ev = self.kernel_events
-        if ev is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        self._cost_volume(*self._last_cv)
-        if ev is not None:
-            e1.record()
-            ev.append((e0, e1))
+        if self._split_hook is not None:
+            # segmented capture (capture(split_cost_volume=True)): the graph ends here, the dominant kernel is launched
+            # eagerly between two HIP events at replay time, a second graph takes over.  Every geometry stage has been
+            # joined (the kNN tables are the last work on the side stream); later wait() calls must not reference events
+            # of the finished capture.
+            geo.events.clear()
+            self._split_hook()
+        else:
+            ev = self.kernel_events
+            if ev is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            self._cost_volume(*self._last_cv)
+            if ev is not None:
+                e1.record()
+                ev.append((e0, e1))
         cor = new(B * N, 256)
+        if _TRACE is not None:
+            _TRACE.append(("patch_cost", B * N * 16, (3 * 8 + 8 * 8 + 8 * 256) + 256))
         _lib.call("rtk_patch_cost", B, N, x1.data_ptr(), knn2.data_ptr(), cor1.data_ptr(), 256, self.wn2.arr, cor.data_ptr(), 256, 0,
                   _stream())
         # ---- decoder -------------------------------------------------------------------------------------
@@ -567,11 +620,15 @@ class FusedBackbone:
 
     # --------------------------------------------------------------------------------------------------
     def _cost_volume(self, B, N, x1, x2, knn1, p1, p2, cor1):
+        if _TRACE is not None:      # per (point, neighbour) pair: direction term, layers 2+3, WeightNet 3-8-8-256, weighted sum
+            _TRACE.append(("cost_volume", B * N * 16, 3 * 256 + 2 * 256 * 256 + (3 * 8 + 8 * 8 + 8 * 256) + 256))
         _lib.call("rtk_cost_volume", B, N, N, x1.data_ptr(), x2.data_ptr(), knn1.data_ptr(), p1.data_ptr(), p2.data_ptr(),
                   self.cv_wd.data_ptr(), self.cv_layers.arr, self.wn1.arr, cor1.data_ptr(), 256, _stream())
 
     def _gru_step(self, x, h):
         L, B, H = h.shape
+        if _TRACE is not None:
+            _TRACE.append(("gru", B * L, 2 * 3 * H * H))
         h_out = torch.empty_like(h)
         y = torch.empty(B, H, dtype=torch.float32, device=h.device)
         h = h.contiguous()
@@ -593,9 +650,12 @@ class FusedBackbone:
         torch.cuda.synchronize()
         return ev
 
-    def capture(self, pc1, pc2, feature1, feature2, h):
+    def capture(self, pc1, pc2, feature1, feature2, h, split_cost_volume=False):
         """Capture one backbone() into a hipGraph (all launches, ours and the glue ops, are on the capture
-        stream).  Returns step(pc1=None, ...) -> outputs: new inputs are copied into the static buffers."""
+        stream).  Returns step(pc1=None, ...) -> outputs: new inputs are copied into the static buffers.
+        split_cost_volume: capture TWO graphs around the dominant kernel and launch it eagerly between them, bracketed by
+        HIP events appended to self.kernel_events -- the kernel's duration measured in situ (same stream, same
+        neighbours in flight) at the cost of two extra launches per step."""
         static = [t.clone() for t in (pc1, pc2, feature1, feature2, h)]
         saved, self.kernel_events = self.kernel_events, None
         side = torch.cuda.Stream()
@@ -604,18 +664,59 @@ class FusedBackbone:
             for _ in range(2):
                 self.backbone(*static)
         torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            outs = self.backbone(*static)
+        if not split_cost_volume:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = self.backbone(*static)
+            self.kernel_events = saved
+
+            def step(*new_inputs):
+                for dst, src in zip(static, new_inputs):
+                    if src is not None:
+                        dst.copy_(src, non_blocking=True)
+                graph.replay()
+                return outs
+            step.graph = graph
+            return step
+
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+
+        def hook():
+            g1.capture_end()
+            g2.capture_begin(pool=g1.pool())
+
+        with torch.cuda.stream(cap):
+            self._split_hook = hook
+            try:
+                g1.capture_begin()
+                outs = self.backbone(*static)
+                g2.capture_end()
+            finally:
+                self._split_hook = None
+        torch.cuda.current_stream().wait_stream(cap)
+        cv_args = self._last_cv
         self.kernel_events = saved
+        eng = self
 
         def step(*new_inputs):
             for dst, src in zip(static, new_inputs):
                 if src is not None:
                     dst.copy_(src, non_blocking=True)
-            graph.replay()
+            g1.replay()
+            ev = eng.kernel_events
+            if ev is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            eng._cost_volume(*cv_args)
+            if ev is not None:
+                e1.record()
+                ev.append((e0, e1))
+            g2.replay()
             return outs
-        step.graph = graph
+        step.graph = (g1, g2)
         return step
 
 
@@ -627,7 +728,7 @@ class GraphPipeline:
     Weights are shared between the engines.  Usage:  p = GraphPipeline(net, example_inputs); outs = p.submit(*inputs)
     ... p.drain().  Outputs of a submit stay valid until the same slot is reused, `depth` submits later."""
 
-    def __init__(self, model_or_engine, example_inputs, depth=2):
+    def __init__(self, model_or_engine, example_inputs, depth=2, split_cost_volume=False):
         import copy
         eng = model_or_engine if isinstance(model_or_engine, FusedBackbone) else FusedBackbone(model_or_engine)
         self.engines = [eng]
@@ -637,7 +738,7 @@ class GraphPipeline:
             self.engines.append(e)
         self.depth = depth
         with torch.no_grad():
-            self.steps = [e.capture(*example_inputs) for e in self.engines]
+            self.steps = [e.capture(*example_inputs, split_cost_volume=split_cost_volume) for e in self.engines]
         self.streams = [torch.cuda.Stream() for _ in range(depth)]
         self.i = 0
         self._forked = False
@@ -652,6 +753,11 @@ class GraphPipeline:
         self.i += 1
         with torch.cuda.stream(self.streams[k]):
             return self.steps[k](*inputs)
+
+    def set_kernel_events(self, events):
+        """Every engine appends its (start, stop) event pairs around the dominant kernel to `events` (None: stop)."""
+        for e in self.engines:
+            e.kernel_events = events
 
     def drain(self):
         """Join all in-flight batches into the current stream."""

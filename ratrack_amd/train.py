@@ -21,33 +21,61 @@ def make_optimizer(model, lr=1e-3, capturable=False):
 
 
 class Trainer:
-    """graph=True: after `graph_warmup` eager steps the whole step (forward, loss, backward, gradient all-reduce, Adam) is
-    captured into ONE hipGraph and replayed; the batch is copied into static input buffers.  The step issues ~2500
-    kernels whose CPU launch cost rivals their GPU time at B=64; a replay is a single launch.  Shapes must then stay
-    fixed (the reference trains on fixed-size clouds, configs.yaml num_points) -- a different shape re-captures.  The
-    returned loss items and GRU state are the graph's static output tensors: every replay overwrites them in place, so
-    copy (`.clone()` / `float()`) what must outlive the next step."""
+    """graph=True: after `graph_warmup` eager steps the step is captured into hipGraphs and replayed; the batch is copied
+    into static input buffers.  The step issues hundreds of kernels whose CPU launch cost rivals their GPU time at B=64; a
+    replay is a single launch.
+      * one process (world 1): ONE graph = forward, loss, backward, Adam;
+      * data parallel (world > 1): graph A = forward, loss, backward, pack of the gradients into the flat bucket; the RCCL
+        all-reduce of the bucket issued eagerly on the same stream (stream ordered, no host synchronisation); graph B = Adam
+        on gradients that alias the bucket.  `graph_collective=True` captures the all-reduce as well (one graph) -- RCCL
+        supports stream capture, but this build has only been run on one GPU, so it is opt-in.
+    Shapes must stay fixed (the reference trains on fixed-size clouds, configs.yaml num_points) -- a different shape or
+    loss configuration re-captures.  The returned loss items and GRU state are the graph's static output tensors: every
+    replay overwrites them in place, so copy (`.clone()` / `float()`) what must outlive the next step."""
 
-    def __init__(self, model, lr=1e-3, process_group=None, graph=False, graph_warmup=3):
+    def __init__(self, model, lr=1e-3, process_group=None, graph=False, graph_warmup=3, graph_collective=False, split_graph=None):
         self.model = model
         self.opt, self.sched = make_optimizer(model, lr, capturable=graph)
         self.reducer = FlatGradAllReducer(model, process_group)
         self.graph = graph
+        # split_graph: None = automatic (split when there is a collective that is not to be captured)
+        self.split = (self.reducer.world > 1 and not graph_collective) if split_graph is None else bool(split_graph)
         self._warm = graph_warmup
         self._g = None
+        self._g_opt = None
         self._static = None
         self._key = None
 
-    def _step(self, pc1, pc2, feature1, feature2, gt_warp, gt_cls, h, pretrain):
+    def _forward_backward(self, pc1, pc2, feature1, feature2, gt_warp, gt_cls, h, pretrain):
         flow, h_out, cls, *_ = self.model.backbone(pc1, pc2, feature1, feature2, h)
         total, items = L.backbone_loss(pc1 + flow, cls, gt_warp, gt_cls, pretrain=pretrain)
         self.opt.zero_grad(set_to_none=True)
         total.backward()
-        self.reducer.reduce()
-        self.opt.step()
+        self.reducer.pack()
         # detached: a caller holding last step's loss must not keep its autograd graph (and the parameters' gradient
         # accumulators, bound to the stream of that step) alive into the next step / into the graph capture
         return {k: v.detach() for k, v in items.items()}, h_out.detach()
+
+    def _optimize(self):
+        self.reducer.unpack()
+        self.opt.step()
+
+    def _step(self, *args):
+        out = self._forward_backward(*args)
+        self.reducer.all_reduce()
+        self._optimize()
+        return out
+
+    @staticmethod
+    def _capture(fn):
+        g = torch.cuda.CUDAGraph()
+        import torch.distributed as dist
+        # with a process group alive, its watchdog thread polls events while we capture: only this thread's calls may
+        # invalidate the capture
+        mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+        with torch.cuda.graph(g, capture_error_mode=mode):
+            out = fn()
+        return g, out
 
     def step(self, pc1, pc2, feature1, feature2, gt_warp, gt_cls, h=None, pretrain=False):
         """One optimisation step on this rank's shard.  Returns the loss items (python floats are NOT taken here:
@@ -58,19 +86,24 @@ class Trainer:
             return self._step(*args, pretrain)
         key = tuple((tuple(t.shape), t.dtype) if t is not None else None for t in args) + (bool(pretrain),)
         if key != self._key:
-            self._key, self._g, self._count = key, None, 0
+            self._key, self._g, self._g_opt, self._count = key, None, None, 0
         if self._g is None and self._count < self._warm:      # eager warm-up (MIOpen finds its kernels, the bucket is built)
             self._count += 1
             return self._step(*args, pretrain)
         if self._g is None:
             self._static = [t.clone() if t is not None else None for t in args]
             torch.cuda.synchronize()
-            self._g = torch.cuda.CUDAGraph()
             self.opt.zero_grad(set_to_none=True)
-            with torch.cuda.graph(self._g):
-                self._out = self._step(*self._static, pretrain)
+            if self.split:
+                self._g, self._out = self._capture(lambda: self._forward_backward(*self._static, pretrain))
+                self._g_opt, _ = self._capture(self._optimize)
+            else:
+                self._g, self._out = self._capture(lambda: self._step(*self._static, pretrain))
         for dst, src in zip(self._static, args):
             if dst is not None:
                 dst.copy_(src)
         self._g.replay()
+        if self._g_opt is not None:
+            self.reducer.all_reduce()
+            self._g_opt.replay()
         return self._out

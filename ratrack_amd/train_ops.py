@@ -331,6 +331,42 @@ def cost_volume(p1, p2, wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, xyz1, xyz2, 
     return _CostVolume.apply(p1, p2, wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, xyz1, xyz2, knn)
 
 
+def time_cost_volume_bwd(batch, n, dev, iters=10):
+    """Measurement helper (bench.py): rtk_cost_volume_bwd at the bench shape on random operands, `iters` back-to-back launches
+    between two HIP events on the current stream.  Returns (ms per launch, FLOPs per launch): per (point, neighbour) pair the
+    forward recompute (2 x 256x256 + direction term + WeightNet + weighted sum) and the two 256x256 input gradients + Wc^T dq3."""
+    g = torch.Generator(dev).manual_seed(0)
+    r = lambda *sh: torch.randn(*sh, device=dev, generator=g)
+    B, M = batch, batch * n * 16
+    xyz1, xyz2 = r(B, n, 3).contiguous(), r(B, n, 3).contiguous()
+    knn = torch.randint(0, n, (B, n, 16), device=dev, generator=g)
+    p1, p2, dout = r(B * n, 256), r(B * n, 256), r(B * n, 256)
+    w2, w3 = r(256, 256) * 0.06, r(256, 256) * 0.06
+    W = _CvWeights(r(256, 3), w2, r(256), w3, r(256), r(8, 3), r(8), r(8, 8), r(8), r(256, 8), r(256), backward=True)
+    wct = fused.pack_layer(r(8, 256))
+    big = torch.empty(6, M, 256, device=dev)
+    d4, dt2 = torch.empty(M, 4, device=dev), torch.empty(M, 8, device=dev)
+    dp1, dpd = torch.empty(B * n, 256, device=dev), torch.empty(B * n, 3, 256, device=dev)
+    st = _stream()
+
+    def launch():
+        _lib.call("rtk_cost_volume_bwd", B, n, n, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
+                  W.wd.data_ptr(), W.layers, W.wn, wct.data_ptr(), dout.data_ptr(), 256, 256, big[0].data_ptr(), big[1].data_ptr(),
+                  big[2].data_ptr(), big[3].data_ptr(), big[4].data_ptr(), big[5].data_ptr(), d4.data_ptr(), dp1.data_ptr(),
+                  dpd.data_ptr(), dt2.data_ptr(), st)
+    for _ in range(3):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * M * (4 * 256 * 256 + 3 * 256 + 2136 + 256 + 8 * 256)
+    return ms, flops
+
+
 def _weightnet_images(wa, ba, wb, bb, wc, bc):
     """Kernel images of a WeightNet 3 -> 8 -> 8 -> 256 (see fused._WeightNet) from live parameters."""
     L = fused._Layer

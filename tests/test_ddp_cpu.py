@@ -108,3 +108,113 @@ def test_single_process_reducer_is_identity():
             assert torch.equal(p.grad, before[n])
         else:
             assert p.grad is None
+
+
+# ---- the Trainer itself (ratrack_amd/train.py) over gloo --------------------------------------------------------------
+
+class TinyBackbone(nn.Module):
+    """CPU stand-in exposing Track4D.backbone()'s signature and 7-tuple: a segmentation branch, a flow branch (no gradient
+    under the pre-training loss, main_utils.py:148) and parameters that never receive one."""
+
+    def __init__(self):
+        super().__init__()
+        self.seg = nn.Conv1d(5, 8, 1)
+        self.bn = nn.BatchNorm1d(8)
+        self.seg_out = nn.Conv1d(8, 1, 1)
+        self.flow = nn.Conv1d(5, 3, 1)
+        self.dead = nn.Linear(4, 4)
+
+    def backbone(self, pc1, pc2, feature1, feature2, h):
+        x = torch.cat([pc1, feature1], 1)
+        cls = torch.sigmoid(self.seg_out(torch.relu(self.bn(self.seg(x))))).squeeze(1)
+        return 0.1 * self.flow(x), h, cls, None, None, None, None
+
+
+def _tiny_batches(n_steps, b):
+    g = torch.Generator().manual_seed(5)
+    out = []
+    for _ in range(n_steps):
+        pc1 = torch.randn(b, 3, 12, generator=g)
+        out.append({"pc1": pc1, "pc2": torch.randn(b, 3, 12, generator=g), "feature1": torch.randn(b, 2, 12, generator=g),
+                    "feature2": torch.randn(b, 2, 12, generator=g), "gt_warp": pc1 + 0.1 * torch.randn(b, 3, 12, generator=g),
+                    "gt_cls": torch.rand(b, 12, generator=g) > 0.5})
+    return out
+
+
+PRETRAIN = [True, True, False, False, True, False]       # bucket grows at step 3; the flow branch loses its gradient at step 5
+
+
+def _trainer_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ratrack_amd.train import Trainer
+        torch.manual_seed(200 + rank)
+        net = TinyBackbone()
+        broadcast_parameters(net, 0)
+        tr = Trainer(net, lr=1e-2)
+        payloads = []
+        for full, pre in zip(_tiny_batches(len(PRETRAIN), 4), PRETRAIN):
+            t = shard_batch(full, rank, world)
+            tr.step(t["pc1"], t["pc2"], t["feature1"], t["feature2"], t["gt_warp"], t["gt_cls"], torch.zeros(5, 2, 4), pretrain=pre)
+            payloads.append(tr.reducer.payload_bytes)
+            assert (net.flow.weight.grad is None) == pre          # no gradient under the pre-training loss: Adam skips it
+            assert net.dead.weight.grad is None
+        assert "flow.weight" in tr.reducer.names and "dead.weight" not in tr.reducer.names
+        q.put((rank, {k: v.detach().cpu().numpy().copy() for k, v in net.state_dict().items()}, payloads))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_over_gloo_matches_manual_gradient_averaging():
+    """Trainer + FlatGradAllReducer with world_size 2: identical replicas after every loss configuration (incl. a bucket that
+    GROWS when the flow branch starts receiving gradients and a parameter that LOSES its gradient again), equal to a
+    single process that averages the two shards' gradients by hand.  BatchNorm statistics stay per replica, as under the
+    reference's nn.DataParallel: every rank sees its own shard."""
+    import numpy as np
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, sd, payloads = q.get(timeout=120)
+        res[r] = (sd, payloads)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    seg_bytes = 4 * (5 * 8 + 8 + 8 + 8 + 8 + 1)
+    assert res[0][1] == [seg_bytes] * 2 + [seg_bytes + 4 * 18] * 4, res[0][1]
+    for k in res[0][0]:
+        if "running" in k:
+            continue                                              # per-replica BatchNorm statistics
+        assert np.array_equal(res[0][0][k], res[1][0][k]), k
+    # manual reference: two replicas in one process, gradients averaged by hand, one Adam
+    from ratrack_amd import loss as L
+    from ratrack_amd.train import make_optimizer
+    torch.manual_seed(200)
+    nets = [TinyBackbone(), TinyBackbone()]
+    nets[1].load_state_dict(nets[0].state_dict())
+    opt, _ = make_optimizer(nets[0], 1e-2)
+    for full, pre in zip(_tiny_batches(len(PRETRAIN), 4), PRETRAIN):
+        grads = []
+        for r, net in enumerate(nets):
+            net.train()
+            net.zero_grad(set_to_none=True)
+            t = shard_batch(full, r, world)
+            flow, _, cls, *_ = net.backbone(t["pc1"], t["pc2"], t["feature1"], t["feature2"], None)
+            L.backbone_loss(t["pc1"] + flow, cls, t["gt_warp"], t["gt_cls"], pretrain=pre)[0].backward()
+            grads.append([p.grad for p in net.parameters()])
+        for p, g0, g1 in zip(nets[0].parameters(), *grads):
+            p.grad = None if g0 is None else (g0 + g1) / 2
+        opt.step()
+        with torch.no_grad():
+            for p0, p1 in zip(nets[0].parameters(), nets[1].parameters()):
+                p1.copy_(p0)
+    for k, v in nets[0].state_dict().items():
+        if "running" in k or "num_batches" in k:
+            continue
+        assert np.allclose(v.numpy(), res[0][0][k], rtol=1e-5, atol=1e-6), k

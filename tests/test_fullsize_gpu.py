@@ -41,6 +41,52 @@ def test_b64_n256_batch_consistency_and_determinism():
         assert all(torch.isfinite(x).all() for x in full)
 
 
+def test_b32_n256_config2_forward():
+    """BASELINE config 2 at its exact size (B=32, N=256, full backbone + scene-flow forward): fused path vs module path within
+    the north-star tolerance, batch consistency bit for bit, EPE of the two paths against the synthetic ground truth equal."""
+    from ratrack_amd.metrics import eval_scene_flow
+    net, t = make(32, 256, 1010)
+    d = synth.make_frame_pairs(32, 256, 1010)
+    with torch.no_grad():
+        full = net.backbone(*t, None)
+        for i in (0, 9, 31):
+            one = net.backbone(*[x[i:i + 1].contiguous() for x in t], None)
+            for name, a, b in zip(NAMES, full, one):
+                a_i = a[:, i:i + 1] if name == "h" else a[i:i + 1]
+                assert torch.equal(a_i, b), "sample %d: %s depends on the batch" % (i, name)
+        net.use_fused = False
+        ref = net.backbone(*t, None)
+    for name, a, b in zip(NAMES, full, ref):
+        assert rel_err(a.cpu(), b.cpu()) <= RTOL, name
+    gt_warp, static = torch.from_numpy(d["gt_warp"]), torch.from_numpy(~d["gt_cls"][0]).int()
+    epe = [eval_scene_flow(t[0].cpu(), (t[0] + o[0]).cpu(), gt_warp, static)["epe"] for o in (full, ref)]
+    assert abs(epe[0] - epe[1]) <= 1e-4 * max(epe[1], 1.0), epe
+
+
+def test_b64_graphed_train_step_config3():
+    """BASELINE config 3 at its full size: the captured train step (forward + loss + backward + Adam, one hipGraph) at
+    B=64, N=256 reproduces the eager step's losses batch by batch (lr = 0: parameters frozen, BatchNorm statistics live)."""
+    from ratrack_amd.train import Trainer
+    from _util import reference_state_dict
+    batches = []
+    for i in range(5):
+        d = synth.make_frame_pairs(64, 256, 1020 + i)
+        batches.append({k: torch.from_numpy(v).to(DEV) for k, v in d.items()})
+    res = []
+    for graph in (False, True):
+        net = Track4D(Args()).to(DEV)
+        net.load_state_dict(reference_state_dict(DEV), strict=True)
+        tr = Trainer(net, graph=graph, lr=0.0)
+        h = torch.zeros(5, 64, 128, device=DEV)
+        losses = []
+        for t in batches:
+            items, _ = tr.step(t["pc1"], t["pc2"], t["feature1"], t["feature2"], t["gt_warp"], t["gt_cls"], h)
+            losses.append([float(items[k]) for k in ("Loss", "SceneFlowLoss", "SegLoss")])
+        res.append(np.array(losses))
+    assert np.isfinite(res[1]).all()
+    np.testing.assert_allclose(res[1], res[0], rtol=1e-5)
+
+
 def test_b64_fused_matches_module_path():
     net, t = make(64, 256, 1001)
     with torch.no_grad():

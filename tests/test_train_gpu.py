@@ -98,10 +98,11 @@ def _train_once(dedup, B, N, pretrain=False):
                 total=float(total.detach())), grads, stats
 
 
-@pytest.mark.parametrize("B,N", [(2, 256), (3, 200), (2, 640)])
+@pytest.mark.parametrize("B,N", [(2, 256), (3, 200), (2, 640), (64, 256)])
 def test_dedup_train_step_matches_module_path(B, N):
     """Same weights, same batch: forward outputs, every parameter gradient and every BatchNorm running statistic of the
-    de-duplicated path agree with the module path that computes all 512 centroid rows."""
+    de-duplicated path agree with the module path that computes all 512 centroid rows.  (64, 256) is BASELINE config 3 at
+    its full size."""
     out_d, g_d, s_d = _train_once(True, B, N)
     out_m, g_m, s_m = _train_once(False, B, N)
     for k in ("flow", "cls", "prop", "h", "f1", "f2"):
@@ -239,6 +240,60 @@ def test_graphed_trainer_matches_eager():
     assert np.isfinite(ld).all() and moved_g > 0
     assert abs(moved_g - moved_e) <= 0.05 * moved_e, (moved_g, moved_e)
     np.testing.assert_allclose(ld[:3], lc[:3], rtol=1e-3)          # the eager warm-up steps
+
+
+def test_data_parallel_step_structure_on_one_gpu():
+    """The world > 1 step structure, exercised on ONE GPU through a 1-rank RCCL process group: gradients packed into the flat
+    bucket, a real RCCL all-reduce, Adam on gradients aliasing the bucket --
+      (a) eager, (b) graph A / eager all-reduce / graph B (the default for world > 1), (c) one graph with the collective
+    captured (opt-in).  With lr = 0 all three must reproduce the plain single-process losses batch by batch; with
+    lr = 1e-3 the optimizer must move the parameters as far as the plain trainer does."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from ratrack_amd.train import Trainer
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        B, N = 2, 256
+        batches = []
+        for i in range(7):
+            d = synth.make_frame_pairs(B, N, 40 + i)
+            batches.append({k: torch.from_numpy(v).to(DEV) for k, v in d.items()})
+
+        def run(lr, **kw):
+            net = Track4D(Args()).to(DEV)
+            net.load_state_dict(reference_state_dict(DEV), strict=True)
+            init = {k: v.detach().clone() for k, v in net.named_parameters()}
+            tr = Trainer(net, lr=lr, **kw)
+            if kw:
+                tr.reducer.always_pack = tr.reducer.always_reduce = True
+            h = torch.zeros(5, B, 128, device=DEV)
+            losses = []
+            for t in batches:
+                items, _ = tr.step(t["pc1"], t["pc2"], t["feature1"], t["feature2"], t["gt_warp"], t["gt_cls"], h)
+                losses.append(float(items["Loss"]))
+            moved = float(torch.sqrt(sum(((p.detach() - init[k]) ** 2).sum() for k, p in net.named_parameters())))
+            if kw:
+                assert tr.reducer.payload_bytes == 4 * 1058196      # the live set of SURVEY fact 8
+                if kw.get("graph"):
+                    assert (tr._g_opt is not None) == bool(kw.get("split_graph"))
+            return losses, moved
+
+        ref, _ = run(0.0)
+        for kw in (dict(graph=False, split_graph=False), dict(graph=True, split_graph=True), dict(graph=True, split_graph=False)):
+            got, _ = run(0.0, **kw)
+            np.testing.assert_allclose(got, ref, rtol=1e-5, err_msg=str(kw))
+        _, moved_ref = run(1e-3)
+        for kw in (dict(graph=True, split_graph=True), dict(graph=True, split_graph=False)):
+            got, moved = run(1e-3, **kw)
+            assert np.isfinite(got).all() and abs(moved - moved_ref) <= 0.05 * moved_ref, (kw, moved, moved_ref)
+    finally:
+        dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("chans,ns,U,n_src,groups", [([16, 16, 32], 4, 200, 200, 2), ([32, 32], 8, 57, 100, 1), ([32, 64], 16, 242, 242, 2),
