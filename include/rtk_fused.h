@@ -109,8 +109,14 @@ RTK_EXPORT int rtk_prepare_inputs(int b, int n, const float *pc1, const float *p
  * nuniq (B) int32 (optional) = number of picks made before the cloud was exhausted (every later pick is
  * point 0, i.e. a duplicate of centroid 0).  tie (B) int32 (optional) = 1 if some round had more than one point at a
  * non-zero maximum (the pick then depended on the reference's tie rule), else 0. */
+/* n_valid (B) int32 (optional): padded batch -- sample b's cloud is its first n_valid[b] <= n points (row pitch n); the
+ * selection, INCLUDING the size-dependent tie rule (block = 2^floor(log2 n_valid[b])), is that of the unpadded cloud. */
 RTK_EXPORT int rtk_fps_centroids(int b, int n, int npoint, const float *xyz, int *idx, float *new_xyz, int *nuniq,
-                                 int *tie, rtk_stream_t stream);
+                                 int *tie, const int *n_valid, rtk_stream_t stream);
+
+/* rtk_knn_point over padded batches: only points[b][0 .. n_valid[b]) are candidates (n_valid (B) int32, >= k). */
+RTK_EXPORT int rtk_knn_point_masked(int b, int s, int n, int k, const float *query, const float *points, int64_t *idx,
+                                    const int *n_valid, rtk_stream_t stream);
 
 /* Levels 2 .. 1+levels of a PNHead (model_utils.py:415-417): furthest point sampling of npoint out of the npoint
  * centroids of the previous level, starting from the level-1 centroids xyz1 (B,npoint,3) with their counters

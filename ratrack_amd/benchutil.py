@@ -50,7 +50,7 @@ def irregular_ops(batch, n, dev, npoint=512, iters=20, pmc=None):
     # ---- furthest point sampling + centroid gather, level 1 (the 511-round dependent chain) ----------------------------
     idx, nx, cnt, tie = i32(S_, npoint), f32(S_, npoint, 3), i32(S_), i32(S_)
     ms = _time(lambda: _lib.call("rtk_fps_centroids", S_, n, npoint, xyz.data_ptr(), idx.data_ptr(), nx.data_ptr(), cnt.data_ptr(),
-                                 tie.data_ptr(), st()), iters)
+                                 tie.data_ptr(), None, st()), iters)
     add("fps_wave_kernel", 1, ms, S_ * (n * 12 + npoint * 16 + 8), "FPS %d -> %d + centroid gather, %d clouds" % (n, npoint, S_))
     idx23, nx23, cnt23 = i32(2, S_, npoint), f32(2, S_, npoint, 3), i32(2, S_)
     ms = _time(lambda: _lib.call("rtk_fps_relevel", S_, npoint, 2, nx.data_ptr(), cnt.data_ptr(), tie.data_ptr(), idx23.data_ptr(),

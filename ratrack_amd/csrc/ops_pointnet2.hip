@@ -213,11 +213,18 @@ template <int PPL>
 __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, const float *__restrict__ xyz,
                                                       float *__restrict__ temp, int *__restrict__ idxs,
                                                       float *__restrict__ new_xyz, int *__restrict__ nuniq,
-                                                      int *__restrict__ tie) {
+                                                      int *__restrict__ tie, const int *__restrict__ nvalid) {
     extern __shared__ __attribute__((aligned(16))) float4 s_pt[];   // (x, y, z, bits(k)) by position
     const int b = blockIdx.x;
     bool tied;
-    const int j = fps_wave_body<PPL>(n, m, block, xyz + (size_t)b * n * 3, temp ? temp + (size_t)b * n : nullptr,
+    const int pitch = n;
+    if (nvalid) {     // padded batch: this sample's cloud is its first nvalid[b] points; the tie rule follows ITS size
+        n = nvalid[b] < n ? nvalid[b] : n;
+        n = n < 1 ? 1 : n;
+        block = 1 << (31 - __builtin_clz(n));      // == cuda_utils.h:10-14 for every n < 2^21 (checked exhaustively)
+        block = block > 1024 ? 1024 : block;
+    }
+    const int j = fps_wave_body<PPL>(n, m, block, xyz + (size_t)b * pitch * 3, temp ? temp + (size_t)b * pitch : nullptr,
                                      idxs + (size_t)b * m, new_xyz ? new_xyz + (size_t)b * m * 3 : nullptr, s_pt,
                                      (int)threadIdx.x, tied);
     if (threadIdx.x == 0) {
@@ -315,14 +322,14 @@ static int fps_block_size(int n) {  // cuda_utils.h:10-14 (host code in the refe
 }
 
 static int fps_launch(int b, int n, int npoint, const float *xyz, float *temp, int *idx, float *new_xyz, int *nuniq,
-                      int *tie, hipStream_t s) {
+                      int *tie, const int *nvalid, hipStream_t s) {
     const int block = fps_block_size(n);
     RTK_REQUIRE(n / block < 65536, "furthest_point_sampling: n=%d too large", n);
     const size_t lds = (size_t)n * sizeof(float4);
-    if (n <= 64 * 4) fps_wave_kernel<4><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie);
-    else if (n <= 64 * 8) fps_wave_kernel<8><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie);
-    else if (n <= 64 * 16) fps_wave_kernel<16><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie);
-    else if (n <= 64 * 32) fps_wave_kernel<32><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie);
+    if (n <= 64 * 4) fps_wave_kernel<4><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid);
+    else if (n <= 64 * 8) fps_wave_kernel<8><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid);
+    else if (n <= 64 * 16) fps_wave_kernel<16><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid);
+    else if (n <= 64 * 32) fps_wave_kernel<32><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid);
     else return 1;   // caller falls back to the block kernel
     return 0;
 }
@@ -332,7 +339,7 @@ extern "C" int rtk_furthest_point_sampling(int b, int n, int npoint, const float
     RTK_REQUIRE(b > 0 && n > 0 && xyz && temp && idx, "furthest_point_sampling: bad arguments (b=%d n=%d)", b, n);
     if (npoint <= 0) return RTK_OK;
     hipStream_t s = (hipStream_t)stream;
-    const int rc = fps_launch(b, n, npoint, xyz, temp, idx, nullptr, nullptr, nullptr, s);
+    const int rc = fps_launch(b, n, npoint, xyz, temp, idx, nullptr, nullptr, nullptr, nullptr, s);
     if (rc < 0) return rc;
     if (rc == 1) fps_block_kernel<<<b, 256, 0, s>>>(n, npoint, fps_block_size(n), xyz, temp, idx);
     RTK_CHECK_LAUNCH("furthest_point_sampling");
@@ -340,10 +347,10 @@ extern "C" int rtk_furthest_point_sampling(int b, int n, int npoint, const float
 }
 
 extern "C" int rtk_fps_centroids(int b, int n, int npoint, const float *xyz, int *idx, float *new_xyz, int *nuniq,
-                                 int *tie, rtk_stream_t stream) {
+                                 int *tie, const int *n_valid, rtk_stream_t stream) {
     RTK_REQUIRE(b > 0 && n > 0 && npoint > 0 && xyz && idx && new_xyz, "fps_centroids: bad arguments (b=%d n=%d)", b, n);
     RTK_REQUIRE(n <= 2048, "fps_centroids: n=%d > 2048 (use rtk_furthest_point_sampling + rtk_gather_points)", n);
-    const int rc = fps_launch(b, n, npoint, xyz, nullptr, idx, new_xyz, nuniq, tie, (hipStream_t)stream);
+    const int rc = fps_launch(b, n, npoint, xyz, nullptr, idx, new_xyz, nuniq, tie, n_valid, (hipStream_t)stream);
     if (rc < 0) return rc;
     RTK_CHECK_LAUNCH("fps_centroids");
     return RTK_OK;
@@ -991,10 +998,15 @@ extern "C" int rtk_three_interpolate_grad_set(int b, int c, int n, int m, const 
 // ------------------------------------------------------------------------------------------------
 template <int K, bool USE_LDS>
 __global__ __launch_bounds__(256) void knn_point_kernel(int s, int n, int k, const float *__restrict__ query,
-                                                        const float *__restrict__ points, int64_t *__restrict__ idx) {
+                                                        const float *__restrict__ points, int64_t *__restrict__ idx,
+                                                        const int *__restrict__ nvalid) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bs = blockIdx.y, tid = threadIdx.x;
     points += (size_t)bs * n * 3;
+    if (nvalid) {     // padded batch: only the sample's own first nvalid[bs] points are candidates (the row pitch stays n)
+        const int nv = nvalid[bs];
+        n = nv < n ? (nv < k ? k : nv) : n;
+    }
     float *sx = smem, *sy = smem + n, *sz = smem + 2 * n, *sn = smem + 3 * n;
     if (USE_LDS) {
         for (int j = tid; j < n; j += 256) {
@@ -1046,8 +1058,8 @@ __global__ __launch_bounds__(256) void knn_point_kernel(int s, int n, int k, con
     }
 }
 
-extern "C" int rtk_knn_point(int b, int s, int n, int k, const float *query, const float *points, int64_t *idx,
-                             rtk_stream_t stream) {
+static int knn_point_impl(int b, int s, int n, int k, const float *query, const float *points, int64_t *idx, const int *nvalid,
+                          rtk_stream_t stream) {
     RTK_REQUIRE(b > 0 && s > 0 && n > 0 && query && points && idx, "knn_point: bad arguments");
     RTK_REQUIRE(k >= 1 && k <= 32 && k <= n, "knn_point: k=%d outside [1, min(32, n=%d)]", k, n);
     RTK_REQUIRE(b <= 65535, "knn_point: b exceeds grid limits");
@@ -1056,12 +1068,22 @@ extern "C" int rtk_knn_point(int b, int s, int n, int k, const float *query, con
     hipStream_t st = (hipStream_t)stream;
     const bool use_lds = lds <= 64 * 1024;
     if (k <= 16) {
-        if (use_lds) knn_point_kernel<16, true><<<grid, 256, lds, st>>>(s, n, k, query, points, idx);
-        else knn_point_kernel<16, false><<<grid, 256, 0, st>>>(s, n, k, query, points, idx);
+        if (use_lds) knn_point_kernel<16, true><<<grid, 256, lds, st>>>(s, n, k, query, points, idx, nvalid);
+        else knn_point_kernel<16, false><<<grid, 256, 0, st>>>(s, n, k, query, points, idx, nvalid);
     } else {
-        if (use_lds) knn_point_kernel<32, true><<<grid, 256, lds, st>>>(s, n, k, query, points, idx);
-        else knn_point_kernel<32, false><<<grid, 256, 0, st>>>(s, n, k, query, points, idx);
+        if (use_lds) knn_point_kernel<32, true><<<grid, 256, lds, st>>>(s, n, k, query, points, idx, nvalid);
+        else knn_point_kernel<32, false><<<grid, 256, 0, st>>>(s, n, k, query, points, idx, nvalid);
     }
     RTK_CHECK_LAUNCH("knn_point");
     return RTK_OK;
+}
+
+extern "C" int rtk_knn_point(int b, int s, int n, int k, const float *query, const float *points, int64_t *idx,
+                             rtk_stream_t stream) {
+    return knn_point_impl(b, s, n, k, query, points, idx, nullptr, stream);
+}
+
+extern "C" int rtk_knn_point_masked(int b, int s, int n, int k, const float *query, const float *points, int64_t *idx,
+                                    const int *n_valid, rtk_stream_t stream) {
+    return knn_point_impl(b, s, n, k, query, points, idx, n_valid, stream);
 }

@@ -44,7 +44,8 @@ _lib.SIGNATURES.update({
     "rtk_cost_volume": [_ci] * 3 + [_vp] * 6 + [ctypes.POINTER(_Layer), ctypes.POINTER(_Layer), _vp, _ci, _vp],
     "rtk_patch_cost": [_ci] * 2 + [_vp] * 3 + [_ci, ctypes.POINTER(_Layer), _vp, _ci, _ci, _vp],
     "rtk_prepare_inputs": [_ci] * 2 + [_vp] * 6 + [_vp],
-    "rtk_fps_centroids": [_ci] * 3 + [_vp] * 5 + [_vp],
+    "rtk_fps_centroids": [_ci] * 3 + [_vp] * 6 + [_vp],
+    "rtk_knn_point_masked": [_ci] * 4 + [_vp] * 4 + [_vp],
     "rtk_fps_relevel": [_ci] * 3 + [_vp] * 6 + [_vp],
     "rtk_gru_step": [_ci] * 3 + [_vp] * 8 + [_vp],
     "rtk_to_channel_major": [_ci] * 3 + [_vp, _ci, _ci, _vp, _ci, _ci, _vp],
@@ -286,7 +287,7 @@ def check_fps_relevel(xyz1, idx, new_xyz, nuniq):
         i = torch.empty(S_, npoint, dtype=torch.int32, device=src.device)
         out = torch.empty(S_, npoint, 3, dtype=torch.float32, device=src.device)
         cnt = torch.empty(S_, dtype=torch.int32, device=src.device)
-        _lib.call("rtk_fps_centroids", S_, npoint, npoint, src.data_ptr(), i.data_ptr(), out.data_ptr(), cnt.data_ptr(), None, _stream())
+        _lib.call("rtk_fps_centroids", S_, npoint, npoint, src.data_ptr(), i.data_ptr(), out.data_ptr(), cnt.data_ptr(), None, None, _stream())
         assert torch.equal(i, idx[l].view(S_, npoint)), "fps_relevel: level %d indices differ from the full selection" % (l + 2)
         assert torch.equal(out, new_xyz[l].view(S_, npoint, 3)), "fps_relevel: level %d centroids differ" % (l + 2)
         assert torch.equal(cnt, nuniq[l].view(-1)), "fps_relevel: level %d exhausted-cloud counters differ" % (l + 2)
@@ -305,13 +306,19 @@ class Geometry:
     """FPS centroids, ball-query indices and three-NN tables of one batch of clouds (feature independent,
     so the decoder's PNHead over pc1 reuses the encoder's)."""
 
-    def __init__(self, xyz, npoint, side=None, knn_frames=0, finite=False):
+    def __init__(self, xyz, npoint, side=None, knn_frames=0, finite=False, n_valid=None):
         """xyz (S_,n,3).  With `side` (a torch.cuda.Stream) every geometry kernel is enqueued on that stream, forked from
         the current one, and consumers call wait(stage) -- the feature kernels overlap the latency-bound FPS chain.
         knn_frames = B > 0: also the two kNN tables of the cost volume, frame 1 = xyz[:B], frame 2 = xyz[B:].
         finite: zero-fill the three-NN distances of the skipped (duplicate) rows instead of leaving them unwritten
-        (the training path computes -- and ignores -- those rows, so they must hold finite numbers)."""
+        (the training path computes -- and ignores -- those rows, so they must hold finite numbers).
+        n_valid (S_,) int32: padded batch (ratrack_amd/vod_gt.pad_frame_pairs) -- cloud s consists of its first n_valid[s]
+        points, the rest are copies of its point 0; FPS applies the unpadded cloud's tie rule and the kNN tables only
+        hold valid candidates, everything else is exact through the duplicate-of-point-0 property."""
         S_, n, _ = xyz.shape
+        if n_valid is not None:
+            assert n_valid.shape == (S_,) and n_valid.dtype == torch.int32 and n_valid.is_contiguous() and n <= 2048
+        nv = n_valid.data_ptr() if n_valid is not None else None
         dev = xyz.device
         self.n, self.samples, self.npoint = n, S_, npoint
         self.xyz = [xyz]
@@ -346,7 +353,7 @@ class Geometry:
             # ---- level 1: the only full furthest-point selection on the common path ---------------------------
             if not big:
                 _lib.call("rtk_fps_centroids", S_, n, npoint, xyz.data_ptr(), fps_idx[0].data_ptr(), new_xyz[0].data_ptr(),
-                          cnt[0].data_ptr(), tie.data_ptr(), _stream())
+                          cnt[0].data_ptr(), tie.data_ptr(), nv, _stream())
             else:   # large clouds: generic FPS + gather, no exhausted-cloud / tie information
                 _native.furthest_point_sampling_wrapper(S_, n, npoint, xyz, temp, self.fps_idx[0])
                 new_xyz[0].copy_(torch.gather(xyz, 1, self.fps_idx[0].long().unsqueeze(-1).expand(-1, -1, 3)))
@@ -400,8 +407,14 @@ class Geometry:
             self._record("nn", side)
             if B:
                 x1, x2 = xyz[:B], xyz[B:]
-                _native.knn_point_wrapper(B, n, n, 16, x1, x2, self.knn[0])
-                _native.knn_point_wrapper(B, n, n, 16, x1, x1, self.knn[1])
+                if n_valid is None:
+                    _native.knn_point_wrapper(B, n, n, 16, x1, x2, self.knn[0])
+                    _native.knn_point_wrapper(B, n, n, 16, x1, x1, self.knn[1])
+                else:       # candidates = the valid points of frame 2 / frame 1
+                    _lib.call("rtk_knn_point_masked", B, n, n, 16, x1.data_ptr(), x2.data_ptr(), self.knn[0].data_ptr(),
+                              n_valid[B:].data_ptr(), _stream())
+                    _lib.call("rtk_knn_point_masked", B, n, n, 16, x1.data_ptr(), x1.data_ptr(), self.knn[1].data_ptr(),
+                              n_valid[:B].data_ptr(), _stream())
                 self._record("knn", side)
 
     def _record(self, key, side):
@@ -542,7 +555,9 @@ class FusedBackbone:
         self.dec_q1_glob = Chain([(wq[:, 130:258], z(32), ACT_NONE)], dev)
 
     # --------------------------------------------------------------------------------------------------
-    def backbone(self, pc1, pc2, feature1, feature2, h):
+    def backbone(self, pc1, pc2, feature1, feature2, h, n_valid=None):
+        """n_valid (2,B) int32: point counts of a padded variable-N batch (row 0: frame 1, row 1: frame 2), see
+        vod_gt.pad_frame_pairs; outputs at padded positions are those of the sample's point 0 / unspecified."""
         B, _, N = pc1.shape
         dev = pc1.device
         new = lambda rows, c: torch.empty(rows, c, dtype=torch.float32, device=dev)
@@ -555,7 +570,9 @@ class FusedBackbone:
                   xyz.data_ptr(), raw.data_ptr(), _stream())
         if self.side is None and self.use_side_stream:
             self.side = torch.cuda.Stream(device=dev)
-        geo = Geometry(xyz, self.npoint, side=self.side if self.use_side_stream else None, knn_frames=B)
+        if n_valid is not None:
+            n_valid = n_valid.to(device=dev, dtype=torch.int32).reshape(2 * B).contiguous()
+        geo = Geometry(xyz, self.npoint, side=self.side if self.use_side_stream else None, knn_frames=B, n_valid=n_valid)
         # ---- encoder over both frames at once (same weights; eval-mode BN is per-element) --------------
         q1 = pointwise(2 * B * N, N, [(raw, 2, False)], self.enc_q1, new(2 * B * N, 32))
         loc, glob = run_pnhead(self.enc, geo, q1)                                        # (2B*N, 128), (2B, 128)

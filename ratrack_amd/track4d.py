@@ -47,14 +47,29 @@ class Track4D(nn.Module):
         self.dedup_train = True   # training mode: PNHead on de-duplicated levels with the HIP BatchNorm operators (train_path.py)
 
     # ---- hot path ---------------------------------------------------------------------------------
-    def backbone(self, pc1, pc2, feature1, feature2, h):
+    def backbone(self, pc1, pc2, feature1, feature2, h, n_valid=None):
         """pc (B,3,N), feature (B,2,N) = (RCS, v_r), h (5,B,128) or None ->
         (flow (B,3,N), h, cls (B,N), cor_features (B,256,N), pc1_features (B,256,N),
-         pc2_features (B,256,N), prop_features (B,128,N)).  models/track4d.py:67-106."""
+         pc2_features (B,256,N), prop_features (B,128,N)).  models/track4d.py:67-106.
+        n_valid (2,B) int32 (optional): a padded batch of clouds of different sizes (vod_gt.pad_frame_pairs; the reference
+        itself only runs B = 1): every sample's valid columns equal its own unpadded B = 1 result."""
         if self.use_fused and not self.training and not torch.is_grad_enabled():
             eng = self._fused_engine()
             if eng is not None:
-                return eng.backbone(pc1, pc2, feature1, feature2, h)
+                N1, N2 = pc1.shape[2], pc2.shape[2]
+                if N1 == N2:
+                    return eng.backbone(pc1, pc2, feature1, feature2, h, n_valid=n_valid)
+                # consecutive real frames differ in size: pad the smaller cloud with copies of its point 0 (exact, see
+                # vod_gt.pad_frame_pairs) and cut the outputs back
+                assert n_valid is None, "n_valid batches are already padded to a common size"
+                B, Nm = pc1.shape[0], max(N1, N2)
+                pad = lambda t: t if t.shape[2] == Nm else torch.cat([t, t[:, :, :1].expand(-1, -1, Nm - t.shape[2])], dim=2)
+                nv = torch.tensor([[N1] * B, [N2] * B], dtype=torch.int32, device=pc1.device)
+                flow, h, cls, cor, f1, f2, prop = eng.backbone(pad(pc1), pad(pc2), pad(feature1), pad(feature2), h, n_valid=nv)
+                return (flow[:, :, :N1].contiguous(), h, cls[:, :N1].contiguous(), cor[:, :, :N1].contiguous(),
+                        f1[:, :, :N1].contiguous(), f2[:, :, :N2].contiguous(), prop[:, :, :N1].contiguous())
+        if n_valid is not None:
+            return self._backbone_per_sample(pc1, pc2, feature1, feature2, h, n_valid)
         tg1 = None
         if self.training and self.dedup_train and pc1.is_cuda and pc1.shape == pc2.shape:
             from . import train_path as TP
@@ -78,6 +93,22 @@ class Track4D(nn.Module):
             cor_features = self.fc_layer(pc1, pc2, pc1_features, pc2_features)
         output, h, prop_features, cls = self.fd_layer(pc1, feature1, pc1_features, cor_features, h, train_geo=tg1)
         return output, h, cls, cor_features, pc1_features, pc2_features, prop_features
+
+    def _backbone_per_sample(self, pc1, pc2, feature1, feature2, h, n_valid):
+        """The literal meaning of a padded batch: every sample run on its own unpadded clouds (B = 1, as the reference does),
+        results re-padded with zeros.  Used by the module / training paths and as the cross-check of the fused path."""
+        B, _, N = pc1.shape
+        nv = n_valid.cpu().tolist()
+        outs = []
+        for b in range(B):
+            n1, n2 = nv[0][b], nv[1][b]
+            hb = None if h is None else h[:, b:b + 1].contiguous()
+            o = self.backbone(pc1[b:b + 1, :, :n1].contiguous(), pc2[b:b + 1, :, :n2].contiguous(), feature1[b:b + 1, :, :n1].contiguous(),
+                              feature2[b:b + 1, :, :n2].contiguous(), hb)
+            outs.append([o[1]] + [torch.nn.functional.pad(t, (0, N - t.shape[-1])) for i, t in enumerate(o) if i != 1])
+        hs = torch.cat([o[0] for o in outs], dim=1)
+        rest = [torch.cat([o[i] for o in outs], dim=0) for i in range(1, 7)]
+        return (rest[0], hs) + tuple(rest[1:])
 
     def _fused_engine(self):
         if self._fused is None:

@@ -240,7 +240,7 @@ def test_misc_kernels():
     nxyz = torch.empty(2 * B, 512, 3, device=DEV)
     cnt = torch.empty(2 * B, dtype=torch.int32, device=DEV)
     tie = torch.empty(2 * B, dtype=torch.int32, device=DEV)
-    _lib.call("rtk_fps_centroids", 2 * B, N, 512, xyz.data_ptr(), idx.data_ptr(), nxyz.data_ptr(), cnt.data_ptr(), tie.data_ptr(),
+    _lib.call("rtk_fps_centroids", 2 * B, N, 512, xyz.data_ptr(), idx.data_ptr(), nxyz.data_ptr(), cnt.data_ptr(), tie.data_ptr(), None,
               F._stream())
     assert (tie.cpu() == 0).all()              # generic float cloud: no round had two points at the maximum
     ref = P.fps(xyz.cpu(), 512)
@@ -295,7 +295,7 @@ def test_fps_relevel():
         idx = torch.empty(S_, 512, dtype=torch.int32, device=DEV)
         c1 = torch.empty(S_, dtype=torch.int32, device=DEV)
         tie = torch.empty(S_, dtype=torch.int32, device=DEV)
-        _lib.call("rtk_fps_centroids", S_, n, 512, xyz.data_ptr(), idx.data_ptr(), l1.data_ptr(), c1.data_ptr(), tie.data_ptr(), F._stream())
+        _lib.call("rtk_fps_centroids", S_, n, 512, xyz.data_ptr(), idx.data_ptr(), l1.data_ptr(), c1.data_ptr(), tie.data_ptr(), None, F._stream())
         idx23 = torch.empty(2, S_, 512, dtype=torch.int32, device=DEV)
         xyz23 = torch.empty(2, S_, 512, 3, device=DEV)
         c23 = torch.empty(2, S_, dtype=torch.int32, device=DEV)
@@ -388,3 +388,43 @@ def test_log_sinkhorn_kernel_matches_framework_iterations(m, n):
     clear = (top2[:, 0] - top2[:, -1] > 1e-3) if m > 1 else torch.ones(1, n, dtype=torch.bool, device=DEV)
     pick = torch.where(idx >= 0, idx, max1.indices)
     assert torch.equal(pick[clear], max1.indices[clear])
+
+
+def test_padded_variable_n_batch():
+    """the three real View-of-Delft example frames (N = 322 / 352 / 242) as ONE padded batch of frame-pairs through
+    the fused path (clouds padded with copies of their point 0, true counts in n_valid) against every pair run on its own,
+    unpadded, at B = 1 through the module path (what the reference does): valid columns agree within the north-star tolerance;
+    and B = 1 pairs whose two frames differ in size go through the fused path directly (internal padding)."""
+    import os
+    from _util import GOLDEN, RTOL, reference_state_dict, rel_err
+    from ratrack_amd import vod_gt, vod_io
+    from ratrack_amd.track4d import Args, Track4D
+    ex = os.path.join(GOLDEN, "vod_example")
+    scans = [vod_io.load_radar_bin(os.path.join(ex, "radar_%s.bin" % f)) for f in ("00549", "01047", "01201")]
+    pairs = [vod_io.frame_pair_tensors(scans[i], scans[(i + 1) % 3], device=DEV) for i in range(3)]
+    pc1, pc2, f1, f2, nv = vod_gt.pad_frame_pairs(pairs, device=DEV)
+    net = Track4D(Args()).to(DEV).eval()
+    net.load_state_dict(reference_state_dict(DEV), strict=True)
+    names = ["flow", "h", "cls", "cor", "pc1_features", "pc2_features", "prop"]
+    with torch.no_grad():
+        h0 = torch.randn(5, 3, 128, device=DEV) * 0.1
+        out = net.backbone(pc1, pc2, f1, f2, h0, n_valid=nv)
+        net.use_fused = False
+        ref = net.backbone(pc1, pc2, f1, f2, h0, n_valid=nv)                  # per-sample, unpadded, module path
+        singles = [net.backbone(*p, h0[:, b:b + 1].contiguous()) for b, p in enumerate(pairs)]
+        net.use_fused = True
+        fused_singles = [net.backbone(*p, h0[:, b:b + 1].contiguous()) for b, p in enumerate(pairs)]
+    for b in range(3):
+        n1, n2 = int(nv[0, b]), int(nv[1, b])
+        for name, a, r, s_, fs in zip(names, out, ref, singles[b], fused_singles[b]):
+            if name == "h":
+                a, r = a[:, b], r[:, b]
+                s_, fs = s_[:, 0], fs[:, 0]
+            else:
+                n = n2 if name == "pc2_features" else n1
+                a, r = a[b, ..., :n], r[b, ..., :n]
+                s_, fs = s_[0], fs[0]
+            assert s_.shape == a.shape == fs.shape, (name, s_.shape, a.shape, fs.shape)
+            assert torch.equal(r, s_), name                                    # the per-sample fallback IS the B = 1 run
+            assert rel_err(a.cpu(), s_.cpu()) <= RTOL, (b, name, rel_err(a.cpu(), s_.cpu()))
+            assert rel_err(fs.cpu(), s_.cpu()) <= RTOL, (b, name, "B=1 fused with internal padding")
