@@ -166,6 +166,14 @@ RTK_EXPORT int rtk_to_channel_major_multi(int samples, int n, int njobs, const r
  * (m+1)(n+2) floats must fit 64 KiB of LDS (m, n up to ~120 objects). */
 RTK_EXPORT int rtk_log_sinkhorn(int m, int n, const float *scores, float alpha, int iters, float *out, rtk_stream_t stream);
 
+/* Moving-point clustering (models/track4d.py:108-126; sklearn.cluster.DBSCAN(eps, min_samples) in the reference, on the host).
+ * feat: channel-major (C, pitch) per-point tensor of ONE frame; channels (8) int32 DEVICE array = the feature channels
+ * entering the distance; score (n): a point takes part iff score > threshold (the motion-segmentation probability).
+ * labels (n) int32: sklearn's cluster ids restricted to the participating points (numbered by first core point), -1 = noise or
+ * not participating.  One workgroup; n <= ~2900 points. */
+RTK_EXPORT int rtk_dbscan(int n, const float *feat, int pitch, const int *channels, const float *score, float threshold, float eps,
+                          int min_samples, int *labels, rtk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,36 @@ def cluster_objects(point_features, eps=1.5, min_samples=2):
     return list(torch.split(gathered, [len(ix) for ix in groups.values()], dim=2))
 
 
+_CHANNELS = {}
+
+
+def cluster_objects_device(point_features, cls, eps=1.5, min_samples=2, threshold=0.5):
+    """cluster_objects(point_features[:, :, cls > threshold]) without the boolean-mask gather, the feature download and the
+    host-side clustering: ONE kernel (rtk_dbscan: mover selection + DBSCAN, labels identical to `dbscan`) and ONE small
+    device->host copy of the per-point labels (the object list is host-structured: a dict of per-object tensors).
+    point_features (1,139,N) CUDA fp32, cls (1,N) motion-segmentation probabilities."""
+    from . import _lib, fused  # noqa: F401  (fused registers the signatures)
+    pf = point_features.contiguous()
+    n = pf.shape[2]
+    dev = pf.device
+    chan = _CHANNELS.get(dev)
+    if chan is None:
+        chan = _CHANNELS[dev] = torch.tensor([3, 4, 5, 6, 7, 8, 10, 11], dtype=torch.int32, device=dev)
+    score = cls.detach().reshape(-1).contiguous().float()
+    labels = torch.empty(n, dtype=torch.int32, device=dev)
+    _lib.call("rtk_dbscan", n, pf.detach().data_ptr(), n, chan.data_ptr(), score.data_ptr(), float(threshold), float(eps), int(min_samples),
+              labels.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    lab = labels.cpu().numpy()
+    k = int(lab.max()) + 1 if n else 0
+    if k <= 0:
+        return []
+    order = np.argsort(lab, kind="stable")                    # clusters in id order, points in index order inside
+    order = order[lab[order] >= 0]
+    sizes = np.bincount(lab[lab >= 0], minlength=k).tolist()
+    gathered = pf.index_select(2, torch.from_numpy(order).to(dev))
+    return list(torch.split(gathered, sizes, dim=2))
+
+
 def object_descriptor(obj, prop_channels):
     """141-d descriptor of an object (models/track4d.py:200-214): [centre(3) | var xyz(3) | max prop(128) | mean flow(3) |
     mean (RCS,v_r)(2) | var (RCS,v_r)(2)], shape (1,1,141)."""
@@ -113,7 +143,9 @@ def affinity_matrix(affinity_net, objects_curr, objects_prev, descriptors=None):
     dev = objects_curr[0].device if n else (objects_prev[keys[0]].device if m else torch.device("cpu"))
     if m == 0 or n == 0:        # nothing to associate (the reference ends up with an empty tensor and starts new tracks)
         return [], torch.zeros(1, m, n, device=dev), m, n
-    cache = descriptors if descriptors is not None else {}
+    # the cross-frame cache holds tensors: under autograd they would drag the previous frame's (freed) graph into this
+    # frame's affinity loss, so training recomputes every descriptor from the tensors it is handed, as the reference does
+    cache = descriptors if (descriptors is not None and not torch.is_grad_enabled()) else {}
 
     todo, seen = [], set()
     for o in list(objects_curr) + [objects_prev[k] for k in keys]:

@@ -306,6 +306,130 @@ extern "C" int rtk_log_sinkhorn(int m, int n, const float *scores, float alpha, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// rtk_dbscan: clustering of the moving points (models/track4d.py:108-126: sklearn.cluster.DBSCAN(eps, min_samples) on the
+// host, behind a device->host copy of the features and a boolean-mask gather).  One workgroup:
+//   1. ordered compaction of the movers (score > threshold) and their D feature channels into LDS;
+//   2. core points: closed eps-ball (itself included) holds >= min_samples movers.  Distances in float64 with numpy's
+//      pairwise summation order, sqrt(d2) <= eps -- the arithmetic of ratrack_amd/association.dbscan;
+//   3. connected components of the core points under the eps-graph by min-label propagation with pointer jumping;
+//   4. sklearn numbers clusters in order of their first core point and fully expands one cluster before starting the next,
+//      so: cluster id = rank of the component's smallest core index; a border point (non-core, within eps of a core
+//      point; only possible for min_samples > 2) joins the lowest-numbered cluster among its core neighbours; the rest is
+//      noise (-1).
+// labels (n) int32: cluster id of every INPUT point, -1 for noise and for non-movers.
+// ------------------------------------------------------------------------------------------------
+#define DB_D 8
+
+__device__ __forceinline__ bool db_adjacent(const float *f, int i, int j, double eps) {
+    double q[DB_D];
+#pragma unroll
+    for (int c = 0; c < DB_D; ++c) {
+        const double d = (double)f[i * DB_D + c] - (double)f[j * DB_D + c];
+        q[c] = d * d;
+    }
+    const double d2 = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));      // numpy's 8-wide pairwise sum
+    return __dsqrt_rn(d2) <= eps;
+}
+
+__global__ __launch_bounds__(256) void dbscan_kernel(int n, const float *__restrict__ feat, int pitch, const int *__restrict__ chan,
+                                                     const float *__restrict__ score, float thr, double eps, int min_samples,
+                                                     int *__restrict__ labels) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char db_smem[];
+    float *f = reinterpret_cast<float *>(db_smem);                 // (m, 8) compacted features
+    int *src = reinterpret_cast<int *>(f + (size_t)n * DB_D);      // mover -> input index
+    int *lab = src + n;                                            // component label (smallest core index) or INT_MAX
+    int *aux = lab + n;                                            // core flag, then cluster number of a representative
+    __shared__ int s_m, s_changed, s_wave[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // ---- 1. ordered compaction ----------------------------------------------------------------------------------------
+    if (t == 0) s_m = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + t;
+        const bool mv = i < n && score[i] > thr;
+        const unsigned long long bal = __ballot(mv);
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int off = s_m;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        if (mv) {
+            const int k = off + __popcll(bal & ((1ull << lane) - 1ull));
+            src[k] = i;
+#pragma unroll
+            for (int c = 0; c < DB_D; ++c) f[k * DB_D + c] = feat[(size_t)chan[c] * pitch + i];
+        }
+        __syncthreads();
+        if (t == 0) s_m += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    const int m = s_m;
+    for (int i = t; i < n; i += 256) labels[i] = -1;
+    // ---- 2. core points -----------------------------------------------------------------------------------------------
+    for (int i = t; i < m; i += 256) {
+        int cnt = 0;
+        for (int j = 0; j < m; ++j) cnt += db_adjacent(f, i, j, eps) ? 1 : 0;
+        aux[i] = cnt >= min_samples;
+        lab[i] = cnt >= min_samples ? i : 0x7fffffff;
+    }
+    __syncthreads();
+    // ---- 3. components of the core graph ----------------------------------------------------------------------------------
+    for (;;) {
+        if (t == 0) s_changed = 0;
+        __syncthreads();
+        for (int i = t; i < m; i += 256) {
+            if (!aux[i]) continue;
+            int best = lab[i];
+            for (int j = 0; j < m; ++j)
+                if (aux[j] && lab[j] < best && db_adjacent(f, i, j, eps)) best = lab[j];
+            if (best < lab[i]) { lab[i] = best; s_changed = 1; }       // racy reads of lab[j] only ever see smaller, valid labels
+        }
+        __syncthreads();
+        for (int i = t; i < m; i += 256)                               // pointer jumping: label of my label
+            if (aux[i]) { const int l = lab[lab[i]]; if (l < lab[i]) lab[i] = l; }
+        __syncthreads();
+        if (!s_changed) break;
+        __syncthreads();
+    }
+    // ---- 4. cluster numbers, border points, output -------------------------------------------------------------------------
+    for (int i = t; i < m; i += 256) {           // representative i (lab[i] == i): its number = representatives before it
+        if (aux[i] && lab[i] == i) {
+            int r = 0;
+            for (int j = 0; j < i; ++j) r += (aux[j] && lab[j] == j) ? 1 : 0;
+            aux[i] = 2 + r;                      // >= 2 marks "core + number"; plain core points keep 1
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < m; i += 256) {
+        int out = -1;
+        if (aux[i]) {
+            out = aux[lab[i]] - 2;
+        } else if (min_samples > 2) {
+            for (int j = 0; j < m; ++j)
+                if (aux[j] && db_adjacent(f, i, j, eps)) {
+                    const int c = aux[lab[j]] - 2;
+                    out = (out < 0 || c < out) ? c : out;
+                }
+        }
+        labels[src[i]] = out;
+    }
+}
+
+extern "C" int rtk_dbscan(int n, const float *feat, int pitch, const int *channels, const float *score, float threshold, float eps,
+                          int min_samples, int *labels, rtk_stream_t stream) {
+    RTK_REQUIRE(n > 0 && feat && channels && score && labels && pitch >= n && min_samples >= 1, "dbscan: bad arguments");
+    const size_t lds = (size_t)n * (DB_D * sizeof(float) + 3 * sizeof(int));
+    RTK_REQUIRE(lds <= 128 * 1024, "dbscan: %d points exceed the single-workgroup LDS budget", n);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)dbscan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr_set = true;
+    }
+    dbscan_kernel<<<1, 256, lds, (hipStream_t)stream>>>(n, feat, pitch, channels, score, threshold, (double)eps, min_samples, labels);
+    RTK_CHECK_LAUNCH("dbscan");
+    return RTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // rtk_to_channel_major: 32x32 tiles through LDS so that both the point-major reads and the
 // channel-major writes are coalesced.
 // ------------------------------------------------------------------------------------------------

@@ -428,3 +428,32 @@ def test_padded_variable_n_batch():
             assert torch.equal(r, s_), name                                    # the per-sample fallback IS the B = 1 run
             assert rel_err(a.cpu(), s_.cpu()) <= RTOL, (b, name, rel_err(a.cpu(), s_.cpu()))
             assert rel_err(fs.cpu(), s_.cpu()) <= RTOL, (b, name, "B=1 fused with internal padding")
+
+
+@pytest.mark.parametrize("n,eps,ms,seed", [(256, 1.5, 2, 0), (300, 1.5, 2, 1), (1000, 1.2, 4, 2), (2048, 0.9, 3, 3), (64, 0.5, 2, 4),
+                                           (500, 1.5, 6, 5), (10, 1.5, 2, 6)])
+def test_dbscan_kernel_matches_host_restatement(n, eps, ms, seed):
+    """rtk_dbscan (mover selection + DBSCAN in one launch) against association.dbscan -- the host restatement that
+    tests/test_association_cpu.py pins to scikit-learn -- on clustered clouds, incl. min_samples > 2 (border points, which
+    join the lowest-numbered cluster among their core neighbours) and chains of points (many propagation rounds)."""
+    from ratrack_amd import association as A
+    g = torch.Generator().manual_seed(seed)
+    centres = torch.randn(12, 8, generator=g) * 6
+    feats8 = centres[torch.randint(0, 12, (n,), generator=g)] + torch.randn(n, 8, generator=g) * 0.45
+    feats8[: n // 8] = torch.randn(n // 8, 8, generator=g) * 12                    # scattered noise points
+    k = min(40, n // 2)
+    feats8[n - k:] = torch.arange(k).float().unsqueeze(1) * torch.tensor([0.6 * eps, 0, 0, 0, 0, 0, 0, 0]) + 50.0      # a chain: one long component
+    pf = torch.randn(1, 139, n, generator=g)
+    pf[0, [3, 4, 5, 6, 7, 8, 10, 11]] = feats8.t()
+    cls = torch.rand(1, n, generator=g)
+    objs = A.cluster_objects_device(pf.to(DEV), cls.to(DEV), eps=eps, min_samples=ms)
+    mov = (cls > 0.5).squeeze(0)
+    ref = A.cluster_objects(pf[:, :, mov], eps=eps, min_samples=ms)
+    assert len(objs) == len(ref) and (len(ref) > 1 or n < 64)
+    for a, b in zip(objs, ref):
+        assert torch.equal(a.cpu(), b)
+    # all-noise and no-mover inputs
+    assert A.cluster_objects_device(pf.to(DEV), torch.zeros(1, n, device=DEV), eps=eps, min_samples=ms) == []
+    far = pf.clone()
+    far[0, 3] = torch.arange(n).float() * 100
+    assert A.cluster_objects_device(far.to(DEV), torch.ones(1, n, device=DEV), eps=eps, min_samples=2) == []

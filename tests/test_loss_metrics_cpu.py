@@ -60,3 +60,29 @@ def test_batched_loss_is_mean_of_per_sample():
     cls2 = cls.clone().requires_grad_(True)
     L.backbone_loss(warp, cls2, gt, g)[0].backward()
     assert torch.isfinite(cls2.grad).all() and float(cls2.grad[2].abs().sum()) == 0.0
+
+
+def test_affinity_loss_matches_reference():
+    """losses/loss.py:48-72: BCE between the flattened affinity list and the identity-match matrix of the GT mappings
+    (values captured from the reference by tools/make_golden_gt.py --affinity), incl. the empty-mapping case."""
+    import os
+    from _util import GOLDEN
+    from ratrack_amd import loss as L
+    g = dict(np.load(os.path.join(GOLDEN, "affinity_loss.npz")))
+    for ci in range(3):
+        prev, curr = g["aff%d/prev" % ci].tolist(), g["aff%d/curr" % ci].tolist()
+        mp = {k: 100 + i for i, k in enumerate(prev)}
+        mc = {k: 200 + i for i, k in enumerate(curr)}
+        v = L.affinity_loss(mp, mc, torch.from_numpy(g["aff%d/aff" % ci]))
+        assert abs(float(v) - float(g["aff%d/val" % ci])) <= 1e-6 * max(1.0, float(g["aff%d/val" % ci])), ci
+    assert float(L.affinity_loss({}, {1: 2}, torch.rand(0))) == float(g["aff_empty"]) == 0.0
+    # the tracking term enters the total with weight 0.5 (losses/loss.py:22-24) through the 19-argument entry point
+    pc1 = torch.randn(1, 3, 16)
+    cls = torch.rand(1, 16) * 0.9 + 0.05
+    gt_cls = torch.arange(16) % 3 == 0
+    mp, mc = {5: 1, 7: 2}, {7: 3, 5: 4}
+    aff = torch.tensor([0.2, 0.7, 0.9, 0.1])
+    total, items = L.track_4d_loss(None, None, mp, mc, None, None, None, pc1, pc1, pc1 + 0.1, cls, pc1, aff, None, gt_cls, None, None, None)
+    trk = float(L.affinity_loss(mp, mc, aff))
+    assert abs(float(items["TrackingLoss"]) - trk) < 1e-7
+    assert abs(float(total) - (0.5 * float(items["SceneFlowLoss"]) + 0.5 * trk + float(items["SegLoss"]))) < 1e-6

@@ -57,3 +57,27 @@ def test_track_result_lines_match_reference_format(tmp_path):
     assert [b[0] for b in back] == [7, 12] and back[0][2].shape == (3, 3) and back[1][2].shape == (1, 3)
     assert np.allclose(back[0][2], objects[7][0, 3:6].T.double().numpy())
     assert abs(back[1][1] - float(confs[1])) < 1e-12
+
+
+def test_read_reference_result_files_round_trip():
+    """Three of the tracking-result files the reference ships (src/result/4dmot_runthis/delft_1/, copied as data into
+    tests/golden/result_files/): parsed by read_track_results and written back by write_track_results BYTE FOR BYTE."""
+    import os
+    import tempfile
+    import torch
+    from _util import GOLDEN
+    from ratrack_amd import vod_io
+    d = os.path.join(GOLDEN, "result_files")
+    for name in sorted(os.listdir(d)):
+        src = os.path.join(d, name)
+        rows = vod_io.read_track_results(src)
+        assert rows and all(pts.shape[1] == 3 and pts.shape[0] >= 1 for _, _, pts in rows)
+        objects, confs = {}, []
+        for obj_id, conf, pts in rows:
+            t = torch.zeros(1, 6, pts.shape[0], dtype=torch.float32)
+            t[0, 3:6] = torch.from_numpy(pts.T).float()
+            objects[obj_id] = t
+            confs.append(conf)
+        with tempfile.TemporaryDirectory() as tmp:
+            out = vod_io.write_track_results(tmp, "delft_1", int(name.split("_")[-1][:5]), objects, confs)
+            assert open(out).read() == open(src).read(), name

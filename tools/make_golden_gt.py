@@ -101,5 +101,24 @@ def main():
         f, len(my_labels), int(res1[1].sum()), pc1.shape[2]))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--affinity" not in sys.argv:
     main()
+
+
+def affinity_loss_golden():
+    """tests/golden/affinity_loss.npz: losses/loss.py:48-72 affinity_loss on three mapping configurations + the empty case."""
+    _, _, _, _, ref_loss, _ = MG.import_reference()
+    g = torch.Generator().manual_seed(3)
+    out = {}
+    for ci, (prev, curr) in enumerate([([5, 7, 9], [7, 5, 11, 9]), ([1], [2, 3]), ([4, 4.5, 6], [6, 4])]):
+        mp = {k: 100 + i for i, k in enumerate(prev)}
+        mc = {k: 200 + i for i, k in enumerate(curr)}
+        aff = torch.rand(len(prev) * len(curr), generator=g) * 0.98 + 0.01
+        out["aff%d/prev" % ci], out["aff%d/curr" % ci] = np.array(prev, dtype=np.float64), np.array(curr, dtype=np.float64)
+        out["aff%d/aff" % ci], out["aff%d/val" % ci] = aff.numpy(), np.float64(float(ref_loss.affinity_loss(mp, mc, aff)))
+    out["aff_empty"] = np.float64(float(ref_loss.affinity_loss({}, {1: 2}, torch.rand(0))))
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "affinity_loss.npz"), **out)
+
+
+if __name__ == "__main__" and "--affinity" in sys.argv:
+    affinity_loss_golden()
