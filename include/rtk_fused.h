@@ -171,7 +171,7 @@ RTK_EXPORT int rtk_log_sinkhorn(int m, int n, const float *scores, float alpha, 
  * entering the distance; score (n): a point takes part iff score > threshold (the motion-segmentation probability).
  * labels (n) int32: sklearn's cluster ids restricted to the participating points (numbered by first core point), -1 = noise or
  * not participating.  One workgroup; n <= ~2900 points. */
-RTK_EXPORT int rtk_dbscan(int n, const float *feat, int pitch, const int *channels, const float *score, float threshold, float eps,
+RTK_EXPORT int rtk_dbscan(int n, const float *feat, int pitch, const int *channels, const float *score, float threshold, double eps,
                           int min_samples, int *labels, rtk_stream_t stream);
 
 #ifdef __cplusplus

@@ -89,12 +89,17 @@ def cluster_objects_device(point_features, cls, eps=1.5, min_samples=2, threshol
     _lib.call("rtk_dbscan", n, pf.detach().data_ptr(), n, chan.data_ptr(), score.data_ptr(), float(threshold), float(eps), int(min_samples),
               labels.data_ptr(), torch.cuda.current_stream().cuda_stream)
     lab = labels.cpu().numpy()
-    k = int(lab.max()) + 1 if n else 0
-    if k <= 0:
+    pts = np.nonzero(lab >= 0)[0]
+    if pts.size == 0:
         return []
-    order = np.argsort(lab, kind="stable")                    # clusters in id order, points in index order inside
-    order = order[lab[order] >= 0]
-    sizes = np.bincount(lab[lab >= 0], minlength=k).tolist()
+    # the reference collects the objects in a dict while scanning the points in index order (models/track4d.py:119-125):
+    # objects are ordered by their FIRST MEMBER POINT (= cluster-id order unless a border point precedes its cluster's cores)
+    ids, first = np.unique(lab[pts], return_index=True)
+    rank = np.empty(int(ids.max()) + 1, dtype=np.int64)
+    rank[ids[np.argsort(first, kind="stable")]] = np.arange(ids.size)
+    key = rank[lab[pts]]
+    order = pts[np.argsort(key, kind="stable")]               # objects in reference order, points in index order inside
+    sizes = np.bincount(key, minlength=ids.size).tolist()
     gathered = pf.index_select(2, torch.from_numpy(order).to(dev))
     return list(torch.split(gathered, sizes, dim=2))
 

@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void dbscan_kernel(int n, const float *__restr
     }
 }
 
-extern "C" int rtk_dbscan(int n, const float *feat, int pitch, const int *channels, const float *score, float threshold, float eps,
+extern "C" int rtk_dbscan(int n, const float *feat, int pitch, const int *channels, const float *score, float threshold, double eps,
                           int min_samples, int *labels, rtk_stream_t stream) {
     RTK_REQUIRE(n > 0 && feat && channels && score && labels && pitch >= n && min_samples >= 1, "dbscan: bad arguments");
     const size_t lds = (size_t)n * (DB_D * sizeof(float) + 3 * sizeof(int));
@@ -424,7 +424,7 @@ extern "C" int rtk_dbscan(int n, const float *feat, int pitch, const int *channe
         (void)hipFuncSetAttribute((const void *)dbscan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         attr_set = true;
     }
-    dbscan_kernel<<<1, 256, lds, (hipStream_t)stream>>>(n, feat, pitch, channels, score, threshold, (double)eps, min_samples, labels);
+    dbscan_kernel<<<1, 256, lds, (hipStream_t)stream>>>(n, feat, pitch, channels, score, threshold, eps, min_samples, labels);
     RTK_CHECK_LAUNCH("dbscan");
     return RTK_OK;
 }

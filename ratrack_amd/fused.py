@@ -53,7 +53,7 @@ _lib.SIGNATURES.update({
     "rtk_three_nn_masked": [_ci] * 3 + [_vp] * 6 + [_vp],
     "rtk_to_channel_major_multi": [_ci] * 3 + [_vp, _vp],
     "rtk_log_sinkhorn": [_ci, _ci, _vp, ctypes.c_float, _ci, _vp, _vp],
-    "rtk_dbscan": [_ci, _vp, _ci, _vp, _vp, ctypes.c_float, ctypes.c_float, _ci, _vp, _vp],
+    "rtk_dbscan": [_ci, _vp, _ci, _vp, _vp, ctypes.c_float, ctypes.c_double, _ci, _vp, _vp],
 })
 
 
