@@ -94,6 +94,35 @@ RTK_EXPORT int rtk_conv_bn_bwd(int samples, int cprev, int cout, int rows, int n
 RTK_EXPORT int rtk_conv_wgrad(int samples, int cprev, int cout, int rows, int ns, int groups, const float *dz, const float *zprev,
                               const float *pre_par, float *dw, rtk_stream_t stream);
 
+/* ---- per-point layers: 1x1 convolutions on one row per point / centroid (feature propagation, nn.Linear bottlenecks, layer-1
+ * feature projections, predictor heads: lib/pointnet2_modules.py:140-158, utils/model_utils/model_utils.py:308-357,393-424) -----
+ * An operand of a VIRTUAL channel concatenation: element (sample s, channel c, position p) lives at
+ *   layout 0 (channel-major planes):  ptr[s*sample_stride + c*pitch + p]
+ *   layout 1 (point-major rows):      ptr[s*sample_stride + p*pitch + c]
+ * col0 = the operand's first column (input side) or row (output side) in the weight matrix. */
+typedef struct {
+    const float *ptr;
+    long sample_stride;
+    int pitch;
+    int channels;
+    int layout;
+    int col0;
+} rtk_pw_operand_t;
+
+/* [dst_0 ; dst_1 ; ...] = W . [src_0 ; src_1 ; ...] (+ bias): weight element (o, k) = w[o*w_pitch + k], or w[k*w_pitch + o] with
+ * transpose_w (the input gradient W^T dz of the same layer, written into each source's gradient tensor; accumulate != 0 adds
+ * to the destinations).  bias (optional) and sums (optional; (groups, stat_channels, 2) float64, zero-initialised:
+ * += (sum w z, sum w z^2) over the positions, w = row_weight (samples, positions) or 1) are indexed by the weight row of the
+ * output channel.  Up to 4 sources and 4 destinations; any channel and position counts. */
+RTK_EXPORT int rtk_pw_conv(int samples, int positions, int nsrc, const rtk_pw_operand_t *srcs, int ndst, const rtk_pw_operand_t *dsts,
+                           const float *w, int w_pitch, int transpose_w, const float *bias, int accumulate, const float *row_weight,
+                           int groups, double *sums, int stat_channels, rtk_stream_t stream);
+
+/* dw[o][src_i.col0 + k] += sum over samples and positions of dz[o] * src_i[k]; dbias[o] += sum dz[o] (optional).  dw (and dbias)
+ * are ZERO-INITIALISED by the caller; workgroup partials are added with float atomics. */
+RTK_EXPORT int rtk_pw_wgrad(int samples, int positions, const rtk_pw_operand_t *dz, int nsrc, const rtk_pw_operand_t *srcs, float *dw,
+                            int w_pitch, float *dbias, rtk_stream_t stream);
+
 /* ---- cost volume (utils/model_utils/model_utils.py:216-236) ------------------------------------------------------
  * Backward of rtk_cost_volume (rtk_fused.h; same forward arguments).  layers[0..3] = the packed 256x256 layers
  * W2, W3, W3^T, W2^T, contiguous in memory (biases of W2, W3 in layers[0], layers[1]); wct_packed = the packed

@@ -126,13 +126,14 @@ class _Predictor(nn.Module):
 
     def _trunk(self, feat):
         x = feat.unsqueeze(3)
-        if self.training and x.is_cuda and torch.is_grad_enabled():
-            # training on the GPU: 1x1 conv with a GEMM weight gradient + the fused BatchNorm/ReLU operator (train_ops.py);
-            # same parameters, statistics and running-stat updates as the nn.Sequential blocks below
-            from .train_ops import bn_relu, conv1x1
+        if self.training and feat.is_cuda and torch.is_grad_enabled():
+            # training on the GPU: the per-point layer operators (train_ops.pw_bn_relu / pw_linear: conv + batch statistics in one
+            # kernel, hand-written backward); same parameters, statistics and running-stat updates as the nn.Sequential blocks
+            from .train_ops import pw_bn_relu, pw_linear
+            x = feat
             for block in self.sf_mlp:
-                x = bn_relu(conv1x1(x, block[0].weight), block[1])
-            return conv1x1(x, self.conv2.weight).squeeze(3)
+                x = pw_bn_relu([x], block[0].weight, block[1])
+            return pw_linear([x], self.conv2.weight)
         for block in self.sf_mlp:
             x = block(x)
         return self.conv2(x).squeeze(3)
@@ -153,7 +154,11 @@ class ClsPredictor(_Predictor):
         self.linear = nn.Linear(3, 1)
 
     def forward(self, feat):
-        x = self.linear(self._trunk(feat).permute(0, 2, 1))
+        t = self._trunk(feat)
+        if self.training and t.is_cuda and torch.is_grad_enabled():
+            from .train_ops import pw_linear
+            return torch.sigmoid(pw_linear([t], self.linear.weight, self.linear.bias)).squeeze(1)     # Linear(3,1) over the channel axis
+        x = self.linear(t.permute(0, 2, 1))
         return torch.sigmoid(x).squeeze(2)
 
 
@@ -232,15 +237,12 @@ class FlowDecoder(nn.Module):
         """train_geo: optional train_path.TrainGeometry of pc1 (training mode): the 514-channel PNHead then runs on
         the de-duplicated levels."""
         cls = self.cp(cor_features)
-        if feature1 is not None:
-            embeddings = torch.cat((feature1, pc1_features, cor_features), dim=1)
-        else:
-            embeddings = torch.cat((pc1_features, cor_features), dim=1)
+        parts = (feature1, pc1_features, cor_features) if feature1 is not None else (pc1_features, cor_features)
         if train_geo is not None:
             from .train_path import pnhead_train
-            prop = pnhead_train(self.mse, train_geo, embeddings)
+            prop = pnhead_train(self.mse, train_geo, list(parts))          # the 514-channel concatenation stays virtual
         else:
-            _, prop = self.mse(pc1.permute(0, 2, 1).contiguous(), embeddings)
+            _, prop = self.mse(pc1.permute(0, 2, 1).contiguous(), torch.cat(parts, dim=1))
         gfeat = torch.max(prop, -1)[0].unsqueeze(2)
         if h is None:   # the reference hard-wires (5,1,128) (model_utils.py:294-295); batch-general here
             h = torch.zeros(5, prop.size(0), 128, device=prop.device, dtype=prop.dtype)

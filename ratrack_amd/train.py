@@ -35,6 +35,10 @@ class Trainer:
 
     def __init__(self, model, lr=1e-3, process_group=None, graph=False, graph_warmup=3, graph_collective=False, split_graph=None):
         self.model = model
+        self._dev = next(model.parameters()).device
+        if self._dev.type == "cuda":
+            from . import train_ops
+            train_ops.enable_zero_arena(self._dev)      # the step's ~200 small zero-initialised buffers: one fill
         self.opt, self.sched = make_optimizer(model, lr, capturable=graph)
         self.reducer = FlatGradAllReducer(model, process_group)
         self.graph = graph
@@ -47,10 +51,16 @@ class Trainer:
         self._key = None
 
     def _forward_backward(self, pc1, pc2, feature1, feature2, gt_warp, gt_cls, h, pretrain):
+        if self._dev.type == "cuda":
+            from . import train_ops
+            self.opt.zero_grad(set_to_none=True)        # last step's gradients may be views of the arena that is cleared now
+            train_ops.arena_begin_step(self._dev)
         flow, h_out, cls, *_ = self.model.backbone(pc1, pc2, feature1, feature2, h)
         total, items = L.backbone_loss(pc1 + flow, cls, gt_warp, gt_cls, pretrain=pretrain)
         self.opt.zero_grad(set_to_none=True)
         total.backward()
+        if self._dev.type == "cuda":
+            train_ops.arena_end_step(self._dev)
         self.reducer.pack()
         # detached: a caller holding last step's loss must not keep its autograd graph (and the parameters' gradient
         # accumulators, bound to the stream of that step) alive into the next step / into the graph capture

@@ -32,8 +32,62 @@ _lib.SIGNATURES.update({
 })
 
 
+class _PwOperand(ctypes.Structure):      # rtk_pw_operand_t (include/rtk_train.h)
+    _fields_ = [("ptr", ctypes.c_void_p), ("sample_stride", ctypes.c_long), ("pitch", ctypes.c_int), ("channels", ctypes.c_int),
+                ("layout", ctypes.c_int), ("col0", ctypes.c_int)]
+
+
+_PwP = ctypes.POINTER(_PwOperand)
+_lib.SIGNATURES.update({
+    "rtk_pw_conv": [_i, _i, _i, _PwP, _i, _PwP, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p],
+    "rtk_pw_wgrad": [_i, _i, _PwP, _i, _PwP, _p, _i, _p, _p],
+})
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+# ---- zero arena ----------------------------------------------------------------------------------------------------------------
+# The training operators need ~200 small zero-initialised buffers per step (float64 batch sums, atomically accumulated weight
+# gradients).  As separate torch.zeros() calls that is ~200 fill kernels of a few microseconds each -- a tenth of the B = 1
+# step.  With an arena (Trainer enables it) they are slices of ONE buffer that is cleared ONCE at the start of the step.
+# Slices live until the next arena_begin_step(): long enough for the step's backward and optimizer (weight gradients handed to
+# autograd may be arena views).  Without an arena (plain autograd use, tests) every request is a torch.zeros().
+_ARENA = {}
+
+
+def enable_zero_arena(device, nbytes=48 << 20):
+    dev = torch.device(device)
+    if dev.type == "cuda" and dev not in _ARENA:
+        _ARENA[dev] = [torch.zeros(nbytes // 8, dtype=torch.float64, device=dev), 0, False]
+
+
+def arena_begin_step(device):
+    a = _ARENA.get(torch.device(device))
+    if a is not None:
+        a[0].zero_()
+        a[1], a[2] = 0, True
+
+
+def arena_end_step(device):
+    a = _ARENA.get(torch.device(device))
+    if a is not None:
+        a[2] = False
+
+
+def _zeros(shape, dtype, device):
+    a = _ARENA.get(device)
+    n = 1
+    for d in (shape if isinstance(shape, (tuple, list)) else (shape,)):
+        n *= int(d)
+    if a is not None and a[2]:
+        words = (n * (8 if dtype == torch.float64 else 4) + 15) // 16 * 2          # float64 words, 16-byte granules
+        if a[1] + words <= a[0].numel():
+            sl = a[0][a[1]:a[1] + words]
+            a[1] += words
+            return (sl if dtype == torch.float64 else sl.view(torch.float32))[:n].view(shape)
+    return torch.zeros(shape, dtype=dtype, device=device)
 
 
 def _ptr(t):
@@ -49,7 +103,7 @@ class _BNReLU(torch.autograd.Function):
         if row_weight is not None:
             assert row_weight.shape == (S_, rows) and row_weight.dtype == torch.float32 and row_weight.is_contiguous()
         dev = z.device
-        sums = torch.zeros(groups, C, 2, dtype=torch.float64, device=dev)
+        sums = _zeros((groups, C, 2), torch.float64, dev)
         _lib.call("rtk_bn_train_stats", S_, C, rows, ns, groups, z.data_ptr(), _ptr(row_weight), sums.data_ptr(), _stream())
         par = torch.empty(4, groups, C, dtype=torch.float32, device=dev)
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
@@ -68,7 +122,7 @@ class _BNReLU(torch.autograd.Function):
         S_, C, rows, ns = z.shape
         dy = dy.contiguous()
         dev = z.device
-        sums2 = torch.zeros(groups, C, 2, dtype=torch.float64, device=dev)
+        sums2 = _zeros((groups, C, 2), torch.float64, dev)
         _lib.call("rtk_bn_relu_bwd_stats", S_, C, rows, ns, groups, z.data_ptr(), dy.data_ptr(), par.data_ptr(), int(pool),
                   sums2.data_ptr(), _stream())
         dz = torch.empty_like(z)
@@ -95,6 +149,160 @@ def bn_relu(z, bn, row_weight=None, count=None, groups=1, pool=False):
                          bool(pool))
 
 
+# ---- per-point layers (virtual concatenation, both layouts) -------------------------------------------------------------------
+
+def _pw_layout(t):
+    """(S,C,P) tensor -> 0 (channel-major planes, positions contiguous) / 1 (point-major rows, channels contiguous) / None."""
+    if t.stride(2) == 1 or t.shape[2] == 1:
+        return 0
+    if t.stride(1) == 1 or t.shape[1] == 1:
+        return 1
+    return None
+
+
+def _pw_tensor(t):
+    """A (S,C,P) fp32 CUDA tensor the kernels can address directly (either layout, any pitch); copies only exotic strides."""
+    assert t.dim() == 3 and t.is_cuda and t.dtype == torch.float32, "per-point layers take (S,C,P) CUDA fp32 tensors"
+    return t if _pw_layout(t) is not None else t.contiguous()
+
+
+def _pw_operands(tensors, cols):
+    arr = (_PwOperand * len(tensors))()
+    for i, (t, c0) in enumerate(zip(tensors, cols)):
+        lay = _pw_layout(t)
+        pitch = (t.stride(1) if t.shape[1] > 1 else t.shape[2]) if lay == 0 else (t.stride(2) if t.shape[2] > 1 else t.shape[1])
+        arr[i].ptr, arr[i].sample_stride, arr[i].pitch = t.data_ptr(), t.stride(0), pitch
+        arr[i].channels, arr[i].layout, arr[i].col0 = t.shape[1], lay, c0
+    return arr
+
+
+def _pw_like(t, channels=None, point_major=None):
+    """Uninitialised (S,C,P) tensor in t's layout (or the requested one)."""
+    S_, C, P = t.shape
+    C = channels if channels is not None else C
+    pm = (_pw_layout(t) == 1) if point_major is None else point_major
+    if pm:
+        return torch.empty(S_, P, C, dtype=torch.float32, device=t.device).permute(0, 2, 1)
+    return torch.empty(S_, C, P, dtype=torch.float32, device=t.device)
+
+
+def _pw_forward(srcs, cols, W, bias, out, row_w=None, groups=1, sums=None):
+    S_, _, P = srcs[0].shape
+    _lib.call("rtk_pw_conv", S_, P, len(srcs), _pw_operands(srcs, cols), 1, _pw_operands([out], [0]), W.data_ptr(), W.stride(0), 0,
+              _ptr(bias), 0, _ptr(row_w), groups, _ptr(sums), out.shape[1], _stream())
+
+
+def _pw_backward(ctx_needs, srcs, cols, W, dz, want_bias):
+    """-> (dW (full shape of W, zero outside the used columns), dbias or None, [dsrc_i or None])."""
+    S_, Co, P = dz.shape
+    dz = _pw_tensor(dz)
+    buf = _zeros((W.shape[0] * W.shape[1] + (Co if want_bias else 0),), torch.float32, dz.device)      # dW | dbias
+    dW = buf[:W.shape[0] * W.shape[1]].view(W.shape[0], W.shape[1])
+    dbias = buf[W.shape[0] * W.shape[1]:] if want_bias else None
+    _lib.call("rtk_pw_wgrad", S_, P, _pw_operands([dz], [0]), len(srcs), _pw_operands(srcs, cols), dW.data_ptr(), dW.stride(0), _ptr(dbias),
+              _stream())
+    dsrcs = [None] * len(srcs)
+    todo = [i for i in range(len(srcs)) if ctx_needs[i]]
+    if todo:
+        outs = [_pw_like(srcs[i]) for i in todo]
+        _lib.call("rtk_pw_conv", S_, P, 1, _pw_operands([dz], [0]), len(outs), _pw_operands(outs, [cols[i] for i in todo]), W.data_ptr(),
+                  W.stride(0), 1, None, 0, None, 1, None, 0, _stream())
+        for i, o in zip(todo, outs):
+            dsrcs[i] = o
+    return dW, dbias, dsrcs
+
+
+class _PwLinear(torch.autograd.Function):
+    """z = W[:, cols] . [src_0 ; src_1 ; ...] (+ bias): a 1x1 convolution / nn.Linear over the channel axis of per-point tensors,
+    the concatenation virtual (rtk_pw_conv); backward = rtk_pw_wgrad (weight + bias gradient, one launch) + rtk_pw_conv with the
+    transposed weight (all input gradients, one launch)."""
+
+    @staticmethod
+    def forward(ctx, W, bias, cfg, *srcs):
+        cols, out_pm = cfg
+        srcs = [_pw_tensor(t) for t in srcs]
+        W2 = W.detach().reshape(W.shape[0], -1)
+        assert W2.stride(1) == 1
+        out = _pw_like(srcs[0], W2.shape[0], point_major=out_pm)
+        _pw_forward(srcs, cols, W2, bias.detach().contiguous() if bias is not None else None, out)
+        ctx.save_for_backward(W, *srcs)
+        ctx.cfg = (cols, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dz):
+        W, *srcs = ctx.saved_tensors
+        cols, has_bias = ctx.cfg
+        W2 = W.detach().reshape(W.shape[0], -1)
+        dW, dbias, dsrcs = _pw_backward(ctx.needs_input_grad[3:], srcs, cols, W2, dz, has_bias and ctx.needs_input_grad[1])
+        return (dW.view_as(W) if ctx.needs_input_grad[0] else None, dbias, None) + tuple(dsrcs)
+
+
+def _pw_cols(srcs, cols):
+    if cols is not None:
+        return list(cols)
+    out, c = [], 0
+    for t in srcs:
+        out.append(c)
+        c += t.shape[1]
+    return out
+
+
+def pw_linear(srcs, weight, bias=None, cols=None, out_point_major=False):
+    """srcs: (S,Ci,P) tensors, channel-major or point-major views; weight (Co, K[,1,1]) with the sources' columns starting at `cols`
+    (default: consecutive from 0); -> (S,Co,P) (a permuted view of an (S,P,Co) tensor with out_point_major)."""
+    return _PwLinear.apply(weight, bias, (_pw_cols(srcs, cols), bool(out_point_major)), *srcs)
+
+
+class _PwBnRelu(torch.autograd.Function):
+    """relu(BatchNorm_train(W . [src_0 ; src_1 ; ...])) for per-point tensors: conv + batch sums in one kernel (rtk_pw_conv),
+    finalize, normalise + ReLU (rtk_bn_relu_fwd); backward: the two BatchNorm passes, then as _PwLinear."""
+
+    @staticmethod
+    def forward(ctx, W, gamma, beta, cfg, *srcs):
+        bn, row_w, count, groups, cols = cfg
+        srcs = [_pw_tensor(t) for t in srcs]
+        W2 = W.detach().reshape(W.shape[0], -1)
+        S_, _, P = srcs[0].shape
+        Co = W2.shape[0]
+        dev = srcs[0].device
+        sums = _zeros((groups, Co, 2), torch.float64, dev)
+        z = torch.empty(S_, Co, P, dtype=torch.float32, device=dev)
+        _pw_forward(srcs, cols, W2, None, z, row_w, groups, sums)
+        par = _bn_finalize(bn, sums, count, groups)
+        y = torch.empty_like(z)
+        _lib.call("rtk_bn_relu_fwd", S_, Co, P, 1, groups, z.data_ptr(), par.data_ptr(), 0, y.data_ptr(), _stream())
+        ctx.save_for_backward(W, z, par, row_w, *srcs)
+        ctx.cfg = (count, groups, cols)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        W, z, par, row_w, *srcs = ctx.saved_tensors
+        count, groups, cols = ctx.cfg
+        S_, Co, P = z.shape
+        dev = z.device
+        dy = dy.contiguous()
+        sums2 = _zeros((groups, Co, 2), torch.float64, dev)
+        _lib.call("rtk_bn_relu_bwd_stats", S_, Co, P, 1, groups, z.data_ptr(), dy.data_ptr(), par.data_ptr(), 0, sums2.data_ptr(), _stream())
+        dz = torch.empty_like(z)
+        dgb = torch.empty(2, Co, dtype=torch.float32, device=dev)
+        _lib.call("rtk_bn_relu_bwd_apply", S_, Co, P, 1, groups, z.data_ptr(), dy.data_ptr(), par.data_ptr(), _ptr(row_w), sums2.data_ptr(),
+                  float(count), 0, dz.data_ptr(), dgb.data_ptr(), _stream())
+        W2 = W.detach().reshape(W.shape[0], -1)
+        dW, _, dsrcs = _pw_backward(ctx.needs_input_grad[4:], srcs, cols, W2, dz, False)
+        return (dW.view_as(W), dgb[0], dgb[1], None) + tuple(dsrcs)
+
+
+def pw_bn_relu(srcs, weight, bn, row_weight=None, count=None, groups=1, cols=None):
+    """relu(bn(conv1x1(cat(srcs)))) in training mode; bn: the nn.BatchNorm2d whose parameters / running statistics are used and
+    updated; row_weight (S,P), count: as bn_relu.  -> (S,Co,P) channel-major."""
+    S_, _, P = srcs[0].shape
+    if count is None:
+        count = (S_ // groups) * P
+    return _PwBnRelu.apply(weight, bn.weight, bn.bias, (bn, row_weight, float(count), int(groups), _pw_cols(srcs, cols)), *srcs)
+
+
 # ---- SharedMLP chain of one set-abstraction scale ------------------------------------------------------------------------
 
 def _bn_finalize(bn, sums, count, groups):
@@ -114,7 +322,7 @@ class _SumsPool:
 
     def __init__(self, groups, channels, device):
         self.groups = groups
-        self.buf = torch.zeros(groups * 2 * sum(channels), dtype=torch.float64, device=device)
+        self.buf = _zeros((groups * 2 * sum(channels),), torch.float64, device)
         self.off = 0
 
     def __call__(self, c):
@@ -184,7 +392,7 @@ class _SAChain(torch.autograd.Function):
         _lib.call("rtk_bn_relu_bwd_apply", S_, C, rows, ns, groups, zs[-1].data_ptr(), dout.data_ptr(), pars[-1].data_ptr(), _ptr(row_w),
                   sums2.data_ptr(), float(count), 1, dz.data_ptr(), dgb.data_ptr(), _stream())
         grads = {L - 1: (None, dgb[0], dgb[1])}
-        dwbuf = torch.zeros(sum(w.numel() for w in weights[1:]), dtype=torch.float32, device=dev)      # all dW of the chain, one fill
+        dwbuf = _zeros((sum(w.numel() for w in weights[1:]),), torch.float32, dev)      # all dW of the chain
         dwoff = 0
         for i in range(L - 1, 0, -1):
             W = weights[i]

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from . import pointnet2_utils as PU
-from .train_ops import bn_relu, conv1x1, cost_volume, patch_cost, sa_chain, sa_chain_supported
+from .train_ops import bn_relu, conv1x1, cost_volume, patch_cost, pw_bn_relu, pw_linear, sa_chain, sa_chain_supported
 
 
 FUSED_SA_CHAIN = True      # False: one bn_relu + framework convolution per layer (reference structure, kept for tests)
@@ -98,15 +98,21 @@ def supported(head):
 
 
 def _sa_scale(mlp, tg, lvl, s, feats, groups):
-    """One MSG scale: (project -> gather) + offset conv -> [BN+ReLU -> conv]* -> BN+ReLU+max.  feats (S_,C,n_src)."""
+    """One MSG scale: (project -> gather) + offset conv -> [BN+ReLU -> conv]* -> BN+ReLU+max.  feats: list of (S_,C_i,n_src)
+    tensors whose channel concatenation is the level's feature tensor (never materialised)."""
     layers = list(mlp.children())
     w = layers[0].conv.weight                                     # (C1, 3+C, 1, 1): [d_xyz | features]
     idx = tg.ball[lvl][s]
     ns = idx.shape[2]
     count = (tg.samples // groups) * tg.npoint * ns
-    # split (not two slices): the backward is one concatenation instead of two zero-fills, two copies and an addition
-    wx, wf = torch.split(w, [3, w.shape[1] - 3], dim=1)
-    proj = conv1x1(feats.unsqueeze(-1), wf).squeeze(-1)           # per-POINT projection (a 1x1 conv and a gather commute)
+    # per-POINT projection of the features by the layer's feature columns (a 1x1 conv and a gather commute); the weight
+    # gradient comes back full-size with zeros in the three offset columns, which belong to wx below
+    cols, c = [], 3
+    for f in feats:
+        cols.append(c)
+        c += f.shape[1]
+    proj = pw_linear(feats, w, cols=cols)
+    wx = w[:, :3]
     if FUSED_SA_CHAIN and sa_chain_supported(layers) and ns >= 4:
         return sa_chain(proj, wx, idx, tg.dxyz[lvl][s], layers, tg.row_w[lvl], count, groups)
     z = conv1x1(tg.dxyz[lvl][s], wx) + PU.grouping_operation(proj, idx)
@@ -121,27 +127,24 @@ def _sa_scale(mlp, tg, lvl, s, feats, groups):
 def _fp(fp, tg, name, skip, known_feats, row_w, count_rows, groups):
     idx, weight = tg.interp[name]
     x = PU.three_interpolate(known_feats.contiguous(), idx, weight)
-    if skip is not None:
-        x = torch.cat([x, skip], dim=1)
-    layers = list(fp.mlp.children())
-    x = x.unsqueeze(-1)
-    for layer in layers:
-        z = conv1x1(x, layer.conv.weight)
-        x = bn_relu(z, layer.bn.bn, row_w, (tg.samples // groups) * count_rows, groups)
-    return x.squeeze(-1)
+    srcs = [x] if skip is None else [x, skip]                      # lib/pointnet2_modules.py:150-153: cat([interpolated, skip])
+    for layer in fp.mlp.children():
+        x = pw_bn_relu(srcs, layer.conv.weight, layer.bn.bn, row_w, (tg.samples // groups) * count_rows, groups)
+        srcs = [x]
+    return x
 
 
 def pnhead_train(head, tg, features, groups=1):
-    """PNHead.forward (model_utils.py:393-424) in training mode on geometry tg.  features (S_,Cf,n) -> l0_points
-    (S_,128,n).  groups: number of consecutive batch slices with their own BatchNorm statistics."""
-    # nn.Linear over the channel axis of a (S_,C,U) tensor = a 1x1 convolution (no permute copies)
-    lin = lambda layer, x: (conv1x1(x.unsqueeze(-1), layer.weight[:, :, None, None]) + layer.bias.view(1, -1, 1, 1)).squeeze(-1)
-    feats = features.contiguous()
+    """PNHead.forward (model_utils.py:393-424) in training mode on geometry tg.  features (S_,Cf,n), or a list of tensors whose
+    channel concatenation it is -> l0_points (S_,128,n).  groups: number of consecutive batch slices with their own BatchNorm
+    statistics."""
+    feats = list(features) if isinstance(features, (list, tuple)) else [features]
     levels = []
     for lvl, (sa, linear) in enumerate(((head.sa1, head.linear1), (head.sa2, head.linear2), (head.sa3, head.linear3))):
         outs = [_sa_scale(mlp, tg, lvl, s, feats, groups) for s, mlp in enumerate(sa.mlps)]
-        feats = lin(linear, torch.cat(outs, dim=1))               # (S_, C, U)
-        levels.append(feats)
+        # nn.Linear over the channel axis of the two scales' (virtually concatenated) outputs
+        feats = [pw_linear(outs, linear.weight, linear.bias)]     # (S_, C, U)
+        levels.append(feats[0])
     l1, l2, l3 = levels
     S, n = tg.npoint, tg.n
     l2 = _fp(head.fp3, tg, "fp3", l2, l3, tg.row_w[1], S, groups)
@@ -161,13 +164,13 @@ def correlator_train(fc, pc1, pc2, feature1, feature2):
     from .model_utils import knn_point
     B, C, N1 = pc1.shape
     x1, x2 = pc1.permute(0, 2, 1).contiguous(), pc2.permute(0, 2, 1).contiguous()
-    f1, f2 = feature1.permute(0, 2, 1), feature2.permute(0, 2, 1)
-    D1, D2 = f1.shape[2], f2.shape[2]
+    D1, D2 = feature1.shape[1], feature2.shape[1]
     knn = knn_point(16, x2, x1).contiguous()
     conv0, conv1, conv2 = fc.mlp_convs
     w0 = conv0.weight[:, :, 0, 0]
-    p1 = F.linear(f1, w0[:, :D1], conv0.bias).reshape(B * N1, 256)
-    p2 = F.linear(f2, w0[:, D1:D1 + D2]).reshape(-1, 256)
+    # layer 1 of the cost-volume MLP split by input segment: per-point projections of both frames' features, written point-major
+    p1 = pw_linear([feature1], conv0.weight, conv0.bias, cols=[0], out_point_major=True).permute(0, 2, 1).reshape(B * N1, 256)
+    p2 = pw_linear([feature2], conv0.weight, None, cols=[D1], out_point_major=True).permute(0, 2, 1).reshape(-1, 256)
     wn = fc.weightnet1.mlp_convs
     x = cost_volume(p1, p2, w0[:, D1 + D2:], conv1.weight[:, :, 0, 0], conv1.bias, conv2.weight[:, :, 0, 0], conv2.bias,
                     wn[0].weight[:, :, 0, 0], wn[0].bias, wn[1].weight[:, :, 0, 0], wn[1].bias, wn[2].weight[:, :, 0, 0],

@@ -118,7 +118,8 @@ def test_dedup_train_step_matches_module_path(B, N):
         err = float((gd - gm).norm())
         # two fp32 evaluations of a batch-statistic network: the 514-channel first decoder layer amplifies rounding
         # differences to a few 1e-3 at small batch; a wrong weight or count shows up at O(1)
-        assert err <= 1.5e-2 * float(gm.norm()) + 1e-5 * gmax, (k, err, float(gm.norm()))
+        # ... and at B = 64 the first layers' BatchNorm gradients (norm ~1e-2 of the largest) sum 32x more rounding noise
+        assert err <= (1.5e-2 if B < 32 else 2.5e-2) * float(gm.norm()) + (1e-5 if B < 32 else 2e-5) * gmax, (k, err, float(gm.norm()))
     for k, v in s_m.items():
         if v.is_floating_point():
             assert float((s_d[k] - v).abs().max()) <= 1e-4 * float(v.abs().max()) + 1e-7, k
@@ -389,3 +390,130 @@ def test_training_reduces_the_loss_on_a_fixed_batch():
     assert all(np.isfinite(losses)), losses
     assert losses[-1] < 0.7 * losses[0], losses
     assert all(torch.isfinite(p).all() for p in net.parameters())
+
+
+def _pm(t):
+    """Same values as the (S,C,P) tensor t, stored point-major (a permuted view of an (S,P,C) tensor)."""
+    return t.permute(0, 2, 1).contiguous().permute(0, 2, 1)
+
+
+@pytest.mark.parametrize("S,P,cins,cout,layouts,bias,out_pm", [
+    (4, 256, [128], 128, "c", False, False), (3, 242, [64, 64], 128, "cc", False, False), (2, 77, [2, 256, 256], 16, "ccp", False, False),
+    (4, 256, [64, 32], 32, "cp", True, False), (2, 300, [256], 256, "p", True, True), (5, 64, [32], 3, "c", False, False),
+    (2, 1024, [128, 32], 128, "pc", False, False), (3, 50, [3], 1, "p", True, False), (2, 256, [96], 64, "c", True, True)])
+def test_pw_linear_matches_torch(S, P, cins, cout, layouts, bias, out_pm):
+    """rtk_pw_conv / rtk_pw_wgrad behind pw_linear (virtual concatenation, channel- and point-major operands, odd channel and
+    position counts, column-sliced weights) against cat + einsum under autograd: output, weight / bias / input gradients."""
+    from ratrack_amd.train_ops import pw_linear
+    g = torch.Generator(DEV).manual_seed(S * 1000 + P)
+    K = sum(cins)
+    Wfull = (torch.randn(cout, K + 5, device=DEV, generator=g) / K ** 0.5).requires_grad_(True)      # the layer uses columns 3 .. 3+K of a wider matrix
+    b = torch.randn(cout, device=DEV, generator=g).requires_grad_(True) if bias else None
+    base = [torch.randn(S, c, P, device=DEV, generator=g) for c in cins]
+    cot = torch.randn(S, cout, P, device=DEV, generator=g)
+    res = []
+    for ours in (True, False):
+        Wfull.grad = None
+        if b is not None:
+            b.grad = None
+        srcs = [(_pm(t) if l == "p" else t.clone()).requires_grad_(True) for t, l in zip(base, layouts)]
+        if ours:
+            cols, c = [], 3
+            for ci in cins:
+                cols.append(c)
+                c += ci
+            z = pw_linear(srcs, Wfull, b, cols=cols, out_point_major=out_pm)
+            assert z.shape == (S, cout, P) and (cout == 1 or (z.stride(1) == 1) == out_pm)
+        else:
+            z = torch.einsum("ok,skp->sop", Wfull[:, 3:3 + K].double(), torch.cat(srcs, 1).double())
+            if b is not None:
+                z = z + b.double().view(1, -1, 1)
+        (z * cot).sum().backward()
+        res.append((z.detach().double(), Wfull.grad.clone().double(), None if b is None else b.grad.clone().double(), [t.grad.double() for t in srcs]))
+    (za, wa, ba, xa), (zb, wb, bb, xb) = res
+    tol = lambda r: 2e-5 * float(r.abs().max()) + 1e-6
+    assert float((za - zb).abs().max()) <= tol(zb)
+    assert float((wa - wb).abs().max()) <= 5e-5 * float(wb.abs().max()) + 1e-5
+    assert float(wa[:, :3].abs().max()) == 0 and float(wa[:, 3 + K:].abs().max()) == 0      # columns outside the layer stay zero
+    if b is not None:
+        assert float((ba - bb).abs().max()) <= 5e-5 * float(bb.abs().max()) + 1e-5
+    for a, r in zip(xa, xb):
+        assert float((a - r).abs().max()) <= tol(r)
+
+
+@pytest.mark.parametrize("S,P,cins,cout,groups,weighted", [(4, 256, [64, 64], 128, 2, True), (2, 242, [128, 32], 128, 1, True),
+                                                           (4, 256, [256], 128, 1, False), (6, 100, [128], 64, 2, False),
+                                                           (2, 256, [64], 32, 1, False)])
+def test_pw_bn_relu_matches_torch(S, P, cins, cout, groups, weighted):
+    """pw_bn_relu = conv1x1(cat) -> BatchNorm2d(train, per-group statistics, row weights) -> ReLU against the float64 framework
+    formulation on the EXPANDED tensor (rows repeated by their integer weight): outputs, running statistics, all gradients."""
+    from ratrack_amd.train_ops import pw_bn_relu
+    g = torch.Generator(DEV).manual_seed(P + cout)
+    K = sum(cins)
+    base = [torch.randn(S, c, P, device=DEV, generator=g) for c in cins]
+    W0 = torch.randn(cout, K, 1, 1, device=DEV, generator=g) / K ** 0.5
+    rw = None
+    if weighted:
+        rw = torch.ones(S, P, device=DEV)
+        rw[:, 0] = 5.0                                   # row 0 stands for 5 identical rows
+        rw[:, P - 7:] = 0.0                              # dead rows
+    cot = torch.randn(S, cout, P, device=DEV, generator=g)
+    count = (S // groups) * (P if rw is None else int(rw[0].sum()))
+    res = []
+    for ours in (True, False):
+        bn = nn.BatchNorm2d(cout).to(DEV)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5, generator=g) if False else bn.weight.copy_(torch.linspace(0.5, 1.5, cout))
+            bn.bias.copy_(torch.linspace(-0.3, 0.3, cout))
+        W = W0.clone().requires_grad_(True)
+        srcs = [t.clone().requires_grad_(True) for t in base]
+        if ours:
+            y = pw_bn_relu(srcs, W, bn, rw, count, groups)
+            live = torch.ones(S, P, dtype=torch.bool, device=DEV) if rw is None else rw > 0
+            (y * cot * live.unsqueeze(1)).sum().backward()
+            res.append((y.detach().double(), W.grad.double(), bn.weight.grad.double(), bn.bias.grad.double(), [t.grad.double() for t in srcs],
+                        bn.running_mean.clone().double(), bn.running_var.clone().double(), live))
+        else:
+            bn = bn.double()
+            x = torch.cat([t.double() for t in srcs], 1)
+            Wd = W.double()
+            outs = []
+            for gi in range(groups):
+                sl = slice(gi * (S // groups), (gi + 1) * (S // groups))
+                z = torch.einsum("ok,skp->sop", Wd[:, :, 0, 0], x[sl])
+                if rw is None:
+                    outs.append(torch.relu(bn(z.unsqueeze(-1))).squeeze(-1))
+                else:       # expand: row r repeated rw[r] times
+                    rep = rw[0].long()
+                    ze = torch.repeat_interleave(z, rep, dim=2)
+                    ye = torch.relu(bn(ze.unsqueeze(-1))).squeeze(-1)
+                    first = torch.cumsum(rep, 0) - rep
+                    yfull = torch.zeros_like(z)
+                    live0 = rep > 0
+                    yfull[:, :, live0] = ye[:, :, first[live0]]
+                    # the gradient of the de-duplicated row is the SUM over its copies: give every copy the same cotangent
+                    outs.append((yfull, ye, first, rep))
+            if rw is None:
+                y = torch.cat(outs, 0)
+                (y * cot.double()).sum().backward()
+            else:
+                tot = 0
+                ys = []
+                for gi, (yfull, ye, first, rep) in enumerate(outs):
+                    sl = slice(gi * (S // groups), (gi + 1) * (S // groups))
+                    live0 = rep > 0
+                    c = torch.zeros_like(ye)
+                    c[:, :, first[live0]] = cot[sl].double()[:, :, live0]          # cotangent on the first copy only == on the row
+                    tot = tot + (ye * c).sum()
+                    ys.append(yfull)
+                tot.backward()
+                y = torch.cat(ys, 0)
+            res.append((y.detach(), W.grad.double(), bn.weight.grad, bn.bias.grad, [t.grad.double() for t in srcs], bn.running_mean.clone(),
+                        bn.running_var.clone(), None))
+    a, r = res
+    live = a[7].unsqueeze(1)
+    assert float(((a[0] - r[0]) * live).abs().max()) <= 1e-4 * float(r[0].abs().max())
+    for i in (1, 2, 3, 5, 6):
+        assert float((a[i] - r[i]).abs().max()) <= 2e-4 * float(r[i].abs().max()) + 1e-6, i
+    for x, y in zip(a[4], r[4]):
+        assert float(((x - y) * live).abs().max()) <= 2e-4 * float(y.abs().max()) + 1e-6
