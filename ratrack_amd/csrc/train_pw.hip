@@ -148,21 +148,26 @@ __global__ __launch_bounds__(PW_T, 2) void pw_conv_kernel(const PwParams Q) {
                     }
                 }
             }
-            __syncthreads();
+            // the tile's four input blocks are requested up front (all in flight across the barrier and the first MFMAs)
             const int nu = min(4, (S.channels - k0 + 15) >> 4);
-            for (int u = 0; u < nu; ++u) {
-                f4 x[4];
-                pw_load_block(S, sb, k0 + 16 * u, g, p, P, pfull, x);
+            f4 x[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < nu) pw_load_block(S, sb, k0 + 16 * u, g, p, P, pfull, x[u]);
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u >= nu) break;
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     if (16 * v >= nout) continue;                     // workgroup-uniform: narrow layers skip the empty blocks
                     const f4 wf = sw[(u * 4 + v) * 64 + lane];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        acc[t][v] = mfma4(wf.x, x[t].x, acc[t][v]);
-                        acc[t][v] = mfma4(wf.y, x[t].y, acc[t][v]);
-                        acc[t][v] = mfma4(wf.z, x[t].z, acc[t][v]);
-                        acc[t][v] = mfma4(wf.w, x[t].w, acc[t][v]);
+                        acc[t][v] = mfma4(wf.x, x[u][t].x, acc[t][v]);
+                        acc[t][v] = mfma4(wf.y, x[u][t].y, acc[t][v]);
+                        acc[t][v] = mfma4(wf.z, x[u][t].z, acc[t][v]);
+                        acc[t][v] = mfma4(wf.w, x[u][t].w, acc[t][v]);
                     }
                 }
             }
@@ -299,13 +304,21 @@ __global__ __launch_bounds__(PW_T, 2) void pw_wgrad_kernel(const PwWgParams Q) {
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[a][c] = f4_zero();
-    for (long t = t_begin + wave; t < t_end; t += PW_T / 64) {
+    const float *sbase = S.layout == 2 ? nullptr : S.ptr;
+    auto fetch = [&](long t, f4 (&A)[4], f4 (&B)[4]) {
         const int b = (int)(t / tps), pt = (int)(t - (long)b * tps) * 16;
         const int pq = pt + 4 * g;
         const bool pfull = pt + 16 <= P;
-        f4 A[4], B[4];
         pw_load_frags(Q.dz, Q.dz.ptr + (size_t)b * Q.dz.sample_stride, o0, j, pq, P, pfull, A);
-        pw_load_frags(S, S.layout == 2 ? nullptr : S.ptr + (size_t)b * S.sample_stride, k0, j, pq, P, pfull, B);
+        pw_load_frags(S, sbase ? sbase + (size_t)b * S.sample_stride : nullptr, k0, j, pq, P, pfull, B);
+    };
+    f4 A[4], B[4];
+    long t = t_begin + wave;
+    if (t < t_end) fetch(t, A, B);
+    for (; t < t_end; t += PW_T / 64) {
+        f4 An[4], Bn[4];
+        const bool more = t + PW_T / 64 < t_end;
+        if (more) fetch(t + PW_T / 64, An, Bn);       // the next tile's operands are in flight during this tile's 64 MFMAs
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -315,6 +328,10 @@ __global__ __launch_bounds__(PW_T, 2) void pw_wgrad_kernel(const PwWgParams Q) {
                 acc[a][c] = mfma4(A[a].z, B[c].z, acc[a][c]);
                 acc[a][c] = mfma4(A[a].w, B[c].w, acc[a][c]);
             }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { A[q] = An[q]; B[q] = Bn[q]; }
+        }
     }
     // D layout: acc[a][c][r] = dW[o0 + chanA(a, 4g + r)][k0 + chanB(c, j)]; the four waves add into one LDS image in turn
     for (int w = 0; w < PW_T / 64; ++w) {
