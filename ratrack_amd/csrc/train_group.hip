@@ -1,0 +1,161 @@
+// Backward of the first layer of a set-abstraction SharedMLP (include/rtk_train.h):
+//     z1[s][c][row][k] = proj[s][c][idx[s][row][k]] + wx[c] . dxyz[s][:, row, k]          (rtk_sa_first_layer)
+//     dproj[s][c][q]   = sum over the positions p = (row, k) with idx[s][p] == q of dz1[s][c][p]
+//     dwx[c][a]        = sum over samples and positions of dz1[s][c][p] dxyz[s][a][p]
+// The reference scatters with one atomicAdd per element (group_points_gpu.cu:8-25) and gets dwx from the framework's
+// convolution backward; round 1 scattered through LDS float atomics (ds_add_f32 sustains well under one lane per clock: 1 ms
+// per step, LDS-atomic bound) and ran a batched GEMM + a reduction over dz1 for dwx (a second full read of dz1).
+//
+// Here the scatter is turned into a GATHER.  rtk_group_inverse_index sorts every sample's positions by the source point they
+// reference -- once per (level, scale) and step, the table does not depend on the features -- and rtk_sa_first_layer_bwd
+// streams each dz1 plane through LDS exactly once: while a plane is being staged every thread multiplies its elements with
+// the (register-resident) offsets for dwx, then thread q sums the plane at its own positions.  No float atomics on the data
+// path, deterministic dproj, one read of dz1.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rtk_common.h"
+#include "rtk_train.h"
+
+namespace {
+
+// off (samples, n_src + 1) int32: positions referencing source point q are inv[s][off[q] .. off[q+1]), ascending.
+__global__ __launch_bounds__(256) void inverse_index_kernel(int n_src, int P, const int *__restrict__ idx, int *__restrict__ off,
+                                                            unsigned short *__restrict__ inv) {
+    extern __shared__ int s_cnt[];                 // [n_src + 1] counts -> offsets, [n_src] cursors
+    int *s_cur = s_cnt + n_src + 1;
+    const int s = blockIdx.x, t = threadIdx.x;
+    const int *id = idx + (size_t)s * P;
+    for (int q = t; q <= n_src; q += 256) s_cnt[q] = 0;
+    __syncthreads();
+    for (int p = t; p < P; p += 256) atomicAdd(&s_cnt[id[p]], 1);
+    __syncthreads();
+    if (t < 64) {                                  // exclusive scan by one wave
+        int carry = 0;
+        for (int base = 0; base <= n_src; base += 64) {
+            const int q = base + t;
+            const int v = q <= n_src ? s_cnt[q] : 0;
+            int inc = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int u = __shfl_up(inc, o, 64);
+                if (t >= o) inc += u;
+            }
+            if (q <= n_src) s_cnt[q] = carry + inc - v;
+            carry += __shfl(inc, 63, 64);
+        }
+    }
+    __syncthreads();
+    for (int q = t; q < n_src; q += 256) s_cur[q] = s_cnt[q];
+    for (int q = t; q <= n_src; q += 256) off[(size_t)s * (n_src + 1) + q] = s_cnt[q];
+    __syncthreads();
+    unsigned short *iv = inv + (size_t)s * P;
+    for (int p = t; p < P; p += 256) iv[atomicAdd(&s_cur[id[p]], 1)] = (unsigned short)p;
+    __syncthreads();
+    // the atomic cursors filled every list in arbitrary order: sort each (short) list so that the sums are reproducible
+    for (int q = t; q < n_src; q += 256) {
+        const int a = s_cnt[q], b = s_cnt[q + 1];
+        for (int i = a + 1; i < b; ++i) {
+            const unsigned short v = iv[i];
+            int j = i - 1;
+            while (j >= a && iv[j] > v) { iv[j + 1] = iv[j]; --j; }
+            iv[j + 1] = v;
+        }
+    }
+}
+
+constexpr int FB_CG = 4;        // channel planes per workgroup
+constexpr int FB_MAXQ = 8;      // float4 per thread and plane: planes up to 8192 positions keep their offsets in registers
+
+__global__ __launch_bounds__(256) void sa_first_layer_bwd_kernel(int channels, int n_src, int P, const float *__restrict__ dz,
+                                                                 const float *__restrict__ dxyz, const int *__restrict__ off,
+                                                                 const unsigned short *__restrict__ inv, float *__restrict__ dproj,
+                                                                 float *__restrict__ dwx) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem[];
+    float *s_plane = reinterpret_cast<float *>(fb_smem);                                  // [P]
+    int *s_off = reinterpret_cast<int *>(s_plane + ((P + 3) & ~3));                       // [n_src + 1]
+    unsigned short *s_inv = reinterpret_cast<unsigned short *>(s_off + n_src + 1);        // [P]
+    __shared__ float s_red[4][3];
+    const int s = blockIdx.y, c0 = blockIdx.x * FB_CG, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int q = t; q <= n_src; q += 256) s_off[q] = off[(size_t)s * (n_src + 1) + q];
+    for (int p = t; p < P; p += 256) s_inv[p] = inv[(size_t)s * P + p];
+    const int n4 = P >> 2;                        // P % 4 == 0 (ns >= 4)
+    const float4 *dx4 = reinterpret_cast<const float4 *>(dxyz + (size_t)s * 3 * P);
+    float4 ox[FB_MAXQ], oy[FB_MAXQ], oz[FB_MAXQ];
+    const bool in_regs = n4 <= 256 * FB_MAXQ;
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < FB_MAXQ; ++i) {
+            const int e = t + 256 * i;
+            if (e < n4) { ox[i] = dx4[e]; oy[i] = dx4[n4 + e]; oz[i] = dx4[2 * n4 + e]; }
+        }
+    }
+    for (int cc = 0; cc < FB_CG && c0 + cc < channels; ++cc) {
+        const int c = c0 + cc;
+        const float4 *pl = reinterpret_cast<const float4 *>(dz + ((size_t)s * channels + c) * P);
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        __syncthreads();                           // the previous plane has been consumed
+        if (in_regs) {
+#pragma unroll
+            for (int i = 0; i < FB_MAXQ; ++i) {
+                const int e = t + 256 * i;
+                if (e < n4) {
+                    const float4 v = pl[e];
+                    reinterpret_cast<float4 *>(s_plane)[e] = v;
+                    ax += (v.x * ox[i].x + v.y * ox[i].y) + (v.z * ox[i].z + v.w * ox[i].w);
+                    ay += (v.x * oy[i].x + v.y * oy[i].y) + (v.z * oy[i].z + v.w * oy[i].w);
+                    az += (v.x * oz[i].x + v.y * oz[i].y) + (v.z * oz[i].z + v.w * oz[i].w);
+                }
+            }
+        } else {
+            for (int e = t; e < n4; e += 256) {
+                const float4 v = pl[e], a = dx4[e], b = dx4[n4 + e], d = dx4[2 * n4 + e];
+                reinterpret_cast<float4 *>(s_plane)[e] = v;
+                ax += (v.x * a.x + v.y * a.y) + (v.z * a.z + v.w * a.w);
+                ay += (v.x * b.x + v.y * b.y) + (v.z * b.z + v.w * b.w);
+                az += (v.x * d.x + v.y * d.y) + (v.z * d.z + v.w * d.w);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { ax += __shfl_xor(ax, o, 64); ay += __shfl_xor(ay, o, 64); az += __shfl_xor(az, o, 64); }
+        if (lane == 0) { s_red[wave][0] = ax; s_red[wave][1] = ay; s_red[wave][2] = az; }
+        __syncthreads();                           // plane staged, partials visible
+        if (t < 3) atomicAdd(dwx + c * 3 + t, (s_red[0][t] + s_red[1][t]) + (s_red[2][t] + s_red[3][t]));
+        float *out = dproj + ((size_t)s * channels + c) * n_src;
+        for (int q = t; q < n_src; q += 256) {
+            float acc = 0.f;
+            for (int e = s_off[q]; e < s_off[q + 1]; ++e) acc += s_plane[s_inv[e]];
+            out[q] = acc;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int rtk_group_inverse_index(int samples, int n_src, int positions, const int *idx, int *off, unsigned short *inv,
+                                       rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && n_src > 0 && positions > 0 && idx && off && inv, "group_inverse_index: bad arguments");
+    RTK_REQUIRE(positions <= 65536 && n_src <= 8192, "group_inverse_index: %d positions / %d source points exceed the 16-bit table",
+                positions, n_src);
+    inverse_index_kernel<<<samples, 256, (2 * (size_t)n_src + 1) * sizeof(int), (hipStream_t)stream>>>(n_src, positions, idx, off, inv);
+    RTK_CHECK_LAUNCH("group_inverse_index");
+    return RTK_OK;
+}
+
+extern "C" int rtk_sa_first_layer_bwd(int samples, int channels, int rows, int ns, int n_src, const float *dz, const float *dxyz,
+                                      const int *off, const unsigned short *inv, float *dproj, float *dwx, rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && channels > 0 && rows > 0 && ns >= 4 && (ns & 3) == 0 && n_src > 0 && dz && dxyz && off && inv && dproj &&
+                dwx, "sa_first_layer_bwd: bad arguments");
+    const int P = rows * ns;
+    const size_t lds = (size_t)((P + 3) & ~3) * sizeof(float) + (size_t)(n_src + 1) * sizeof(int) + (size_t)P * sizeof(unsigned short);
+    RTK_REQUIRE(P <= 65536 && lds <= 150 * 1024 && samples <= 65535, "sa_first_layer_bwd: %d positions exceed the LDS budget", P);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)sa_first_layer_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    const dim3 grid((channels + FB_CG - 1) / FB_CG, samples);
+    sa_first_layer_bwd_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(channels, n_src, P, dz, dxyz, off, inv, dproj, dwx);
+    RTK_CHECK_LAUNCH("sa_first_layer_bwd");
+    return RTK_OK;
+}

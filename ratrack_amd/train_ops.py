@@ -16,6 +16,8 @@ _lib.SIGNATURES.update({
     "rtk_cost_volume_bwd": [_i] * 3 + [_p] * 6 + [_LayerP, _LayerP, _p, _p, _i, _i] + [_p] * 10 + [_p],
     "rtk_scatter_add_rows": [_i] * 4 + [_p] * 3 + [_p],
     "rtk_sa_first_layer": [_i] * 6 + [_p] * 7 + [_p],
+    "rtk_group_inverse_index": [_i] * 3 + [_p] * 3 + [_p],
+    "rtk_sa_first_layer_bwd": [_i] * 5 + [_p] * 6 + [_p],
     "rtk_conv_bn_fwd": [_i] * 6 + [_p] * 7 + [_p],
     "rtk_conv_wgrad": [_i] * 6 + [_p] * 4 + [_p],
     "rtk_conv_bn_bwd": [_i] * 6 + [_p] * 6 + [_d, _i, _p, _p, _p],
@@ -339,7 +341,7 @@ class _SAChain(torch.autograd.Function):
     for the weight gradient; the normalised activations are stored once for that GEMM, nothing else is materialised."""
 
     @staticmethod
-    def forward(ctx, proj, wx, idx, dxyz, row_w, count, groups, bns, *tensors):
+    def forward(ctx, proj, wx, idx, dxyz, row_w, count, groups, bns, inv, *tensors):
         proj = proj.contiguous()                                          # (S, C1, n_src)
         S_, C1, n_src = proj.shape
         _, rows, ns = idx.shape
@@ -368,6 +370,7 @@ class _SAChain(torch.autograd.Function):
         _lib.call("rtk_bn_relu_fwd", S_, C, rows, ns, groups, zs[-1].data_ptr(), pars[-1].data_ptr(), 1, out.data_ptr(), _stream())
         ctx.save_for_backward(row_w, idx, dxyz, *zs, *pars, *[w for w in weights[1:]])
         ctx.cfg = (count, groups, L, n_src)
+        ctx.inv = inv
         return out
 
     @staticmethod
@@ -392,7 +395,9 @@ class _SAChain(torch.autograd.Function):
         _lib.call("rtk_bn_relu_bwd_apply", S_, C, rows, ns, groups, zs[-1].data_ptr(), dout.data_ptr(), pars[-1].data_ptr(), _ptr(row_w),
                   sums2.data_ptr(), float(count), 1, dz.data_ptr(), dgb.data_ptr(), _stream())
         grads = {L - 1: (None, dgb[0], dgb[1])}
-        dwbuf = _zeros((sum(w.numel() for w in weights[1:]),), torch.float32, dev)      # all dW of the chain
+        C1_ = zs[0].shape[1]
+        dwbuf = _zeros((sum(w.numel() for w in weights[1:]) + 3 * C1_,), torch.float32, dev)      # all dW of the chain | dWx
+        dwx = dwbuf[dwbuf.numel() - 3 * C1_:]
         dwoff = 0
         for i in range(L - 1, 0, -1):
             W = weights[i]
@@ -415,12 +420,18 @@ class _SAChain(torch.autograd.Function):
         flat = [grads[0][1], grads[0][2]]
         for i in range(1, L):
             flat += [grads[i][0], grads[i][1], grads[i][2]]
-        # first layer: z1 = proj[idx] + Wx.dxyz  ->  dproj = scatter of dz over idx (LDS kernel), dWx = sum_b dz_b dxyz_b^T
+        # first layer: z1 = proj[idx] + Wx.dxyz  ->  dproj = gather-sum of dz over each source point's positions, dWx = sum dz dxyz^T
         C1 = dz.shape[1]
         dproj = torch.empty(S_, C1, n_src, dtype=torch.float32, device=dev)
-        _lib.call("rtk_group_points_grad_set", S_, C1, n_src, rows, ns, dz.data_ptr(), idx.data_ptr(), dproj.data_ptr(), _stream())
-        dwx = torch.bmm(dz.view(S_, C1, -1), dxyz.view(S_, 3, -1).transpose(1, 2)).sum(0).view(C1, 3, 1, 1)
-        return (dproj, dwx, None, None, None, None, None, None) + tuple(flat)
+        if ctx.inv is not None:
+            off, inv = ctx.inv
+            _lib.call("rtk_sa_first_layer_bwd", S_, C1, rows, ns, n_src, dz.data_ptr(), dxyz.data_ptr(), off.data_ptr(), inv.data_ptr(),
+                      dproj.data_ptr(), dwx.data_ptr(), _stream())
+            dwx = dwx.view(C1, 3, 1, 1)
+        else:
+            _lib.call("rtk_group_points_grad_set", S_, C1, n_src, rows, ns, dz.data_ptr(), idx.data_ptr(), dproj.data_ptr(), _stream())
+            dwx = torch.bmm(dz.view(S_, C1, -1), dxyz.view(S_, 3, -1).transpose(1, 2)).sum(0).view(C1, 3, 1, 1)
+        return (dproj, dwx, None, None, None, None, None, None, None) + tuple(flat)
 
 
 def sa_chain_supported(layers):
@@ -428,17 +439,17 @@ def sa_chain_supported(layers):
     return len(layers) >= 2 and all(c in (16, 32, 64) for c in chans) and all(l.conv.bias is None for l in layers)
 
 
-def sa_chain(proj, wx, idx, dxyz, layers, row_w, count, groups):
+def sa_chain(proj, wx, idx, dxyz, layers, row_w, count, groups, inv=None):
     """proj (S,C1,n_src): per-point projection of the features by the first layer's feature columns; wx (C1,3,1,1): its
     offset columns; idx (S,rows,ns) int32 ball-query indices; dxyz (S,3,rows,ns) neighbour offsets; layers: the SharedMLP's
-    Conv2d blocks (conv, bn.bn).  Returns the max-pooled (S,C_last,rows) output.  Updates every BatchNorm's running
-    statistics."""
+    Conv2d blocks (conv, bn.bn); inv: optional (off, inv) inverse table of idx (rtk_group_inverse_index) for the gather-form
+    backward of the first layer.  Returns the max-pooled (S,C_last,rows) output.  Updates every BatchNorm's running statistics."""
     tensors = []
     for i, l in enumerate(layers):
         if i > 0:
             tensors.append(l.conv.weight)
         tensors += [l.bn.bn.weight, l.bn.bn.bias]
-    return _SAChain.apply(proj, wx, idx, dxyz, row_w, float(count), int(groups), tuple(l.bn.bn for l in layers), *tensors)
+    return _SAChain.apply(proj, wx, idx, dxyz, row_w, float(count), int(groups), tuple(l.bn.bn for l in layers), inv, *tensors)
 
 
 # ---- cost volume -------------------------------------------------------------------------------------------------------

@@ -47,10 +47,10 @@ class TrainGeometry:
             w = f32(S_, U)
             _lib.call("rtk_train_row_weights", S_, U, npoint, nu[lvl].data_ptr(), w.data_ptr(), st)
             self.row_w.append(w)
-        self.ball, self.dxyz = [], []
+        self.ball, self.dxyz, self.inv = [], [], []
         for lvl in range(3):
             src, dst = geo.xyz[lvl], geo.xyz[lvl + 1]             # (S_, n or npoint, 3), (S_, npoint, 3)
-            rows_b, rows_d = [], []
+            rows_b, rows_d, rows_i = [], [], []
             for s in range(2):
                 ball = geo.ball[lvl][s]
                 ns = ball.shape[2]
@@ -60,8 +60,18 @@ class TrainGeometry:
                           nu[lvl - 1].data_ptr() if lvl > 0 else None, idx.data_ptr(), d.data_ptr(), st)
                 rows_b.append(idx)
                 rows_d.append(d)
+                # positions sorted by the source row they gather: the first layer's backward is a gather instead of a scatter
+                n_src = n if lvl == 0 else U
+                if U * ns <= 65536 and n_src <= 8192 and ns % 4 == 0:
+                    off = i32(S_, n_src + 1)
+                    inv = torch.empty(S_, U * ns, dtype=torch.int16, device=dev)
+                    _lib.call("rtk_group_inverse_index", S_, n_src, U * ns, idx.data_ptr(), off.data_ptr(), inv.data_ptr(), st)
+                    rows_i.append((off, inv))
+                else:
+                    rows_i.append(None)
             self.ball.append(rows_b)
             self.dxyz.append(rows_d)
+            self.inv.append(rows_i)
         self.interp = {}
         for name, (u, k) in {"fp3": (2, 3), "fp2": (1, 2), "fp1": (0, 1)}.items():
             d2, idx, _ = geo.nn[name]
@@ -79,6 +89,7 @@ class TrainGeometry:
         g.row_w = [w[:count] for w in self.row_w]
         g.ball = [[b[:count] for b in row] for row in self.ball]
         g.dxyz = [[d[:count] for d in row] for row in self.dxyz]
+        g.inv = [[None if t is None else (t[0][:count], t[1][:count]) for t in row] for row in self.inv]
         g.interp = {k: (i[:count], w[:count]) for k, (i, w) in self.interp.items()}
         g.l3_xyz = self.l3_xyz[:count]
         return g
@@ -114,7 +125,7 @@ def _sa_scale(mlp, tg, lvl, s, feats, groups):
     proj = pw_linear(feats, w, cols=cols)
     wx = w[:, :3]
     if FUSED_SA_CHAIN and sa_chain_supported(layers) and ns >= 4:
-        return sa_chain(proj, wx, idx, tg.dxyz[lvl][s], layers, tg.row_w[lvl], count, groups)
+        return sa_chain(proj, wx, idx, tg.dxyz[lvl][s], layers, tg.row_w[lvl], count, groups, inv=tg.inv[lvl][s])
     z = conv1x1(tg.dxyz[lvl][s], wx) + PU.grouping_operation(proj, idx)
     x = None
     for i, layer in enumerate(layers):

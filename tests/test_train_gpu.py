@@ -517,3 +517,39 @@ def test_pw_bn_relu_matches_torch(S, P, cins, cout, groups, weighted):
         assert float((a[i] - r[i]).abs().max()) <= 2e-4 * float(r[i].abs().max()) + 1e-6, i
     for x, y in zip(a[4], r[4]):
         assert float(((x - y) * live).abs().max()) <= 2e-4 * float(y.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("S,C,rows,ns,n_src", [(4, 16, 256, 4, 256), (3, 32, 242, 8, 242), (2, 64, 256, 32, 256), (2, 64, 512, 32, 512),
+                                               (5, 16, 77, 4, 100), (2, 32, 300, 16, 1024)])
+def test_first_layer_backward_gather_form(S, C, rows, ns, n_src):
+    """rtk_group_inverse_index + rtk_sa_first_layer_bwd (scatter turned into a gather, dWx fused) against the LDS-atomic scatter
+    kernel + batched GEMM they replace; the inverse table itself against a stable argsort; run-to-run determinism."""
+    from ratrack_amd import _lib
+    from ratrack_amd import train_ops as T
+    g = torch.Generator(DEV).manual_seed(rows + ns)
+    P = rows * ns
+    idx = torch.randint(0, n_src, (S, rows, ns), device=DEV, generator=g, dtype=torch.int32)
+    idx[:, :, 1:] = torch.where(torch.rand(S, rows, ns - 1, device=DEV, generator=g) < 0.5, idx[:, :, :1].expand(-1, -1, ns - 1), idx[:, :, 1:])
+    idx[0, : rows // 2] = 0                                                    # a heavily shared source point
+    dz = torch.randn(S, C, rows, ns, device=DEV, generator=g)
+    dxyz = torch.randn(S, 3, rows, ns, device=DEV, generator=g)
+    off = torch.empty(S, n_src + 1, dtype=torch.int32, device=DEV)
+    inv = torch.empty(S, P, dtype=torch.int16, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.call("rtk_group_inverse_index", S, n_src, P, idx.data_ptr(), off.data_ptr(), inv.data_ptr(), st)
+    order = torch.sort(idx.view(S, P).long(), dim=1, stable=True).indices
+    assert torch.equal(inv.long() & 0xffff, order)
+    cnt = torch.zeros(S, n_src, dtype=torch.long, device=DEV).scatter_add_(1, idx.view(S, P).long(), torch.ones(S, P, dtype=torch.long, device=DEV))
+    assert torch.equal(off[:, 1:].long(), cnt.cumsum(1)) and (off[:, 0] == 0).all()
+    outs = []
+    for _ in range(2):
+        dproj = torch.empty(S, C, n_src, device=DEV)
+        dwx = torch.zeros(C, 3, device=DEV)
+        _lib.call("rtk_sa_first_layer_bwd", S, C, rows, ns, n_src, dz.data_ptr(), dxyz.data_ptr(), off.data_ptr(), inv.data_ptr(),
+                  dproj.data_ptr(), dwx.data_ptr(), st)
+        outs.append((dproj, dwx))
+    assert torch.equal(outs[0][0], outs[1][0])                                  # no float atomics on the data path
+    ref = torch.zeros(S, C, n_src, dtype=torch.float64, device=DEV).scatter_add_(2, idx.view(S, 1, P).long().expand(-1, C, -1), dz.view(S, C, P).double())
+    assert float((outs[0][0].double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    ref_w = torch.einsum("scp,sap->ca", dz.view(S, C, P).double(), dxyz.view(S, 3, P).double())
+    assert float((outs[0][1].double() - ref_w).abs().max()) <= 2e-5 * float(ref_w.abs().max()) + 1e-4
