@@ -71,8 +71,7 @@ RTK_EXPORT int rtk_sa_first_layer(int samples, int channels, int rows, int ns, i
 /* Backward of rtk_sa_first_layer.  rtk_group_inverse_index sorts the positions p = (row, k) of every sample by the source point
  * idx[s][p] they gather (once per geometry table and step): off (samples, n_src + 1) int32, inv (samples, positions) uint16 with
  * the positions referencing point q at inv[s][off[s][q] .. off[s][q+1]), ascending.  rtk_sa_first_layer_bwd reads dz
- * (samples, C, rows, ns) once: dproj (samples, C, n_src) = gather-sum of dz over each point's positions (fully written, no atomics,
- * deterministic); dwx (C, 3), ZERO-INITIALISED by the caller, += sum dz . dxyz (dxyz (samples, 3, rows, ns)).  ns % 4 == 0. */
+ * (samples, C, rows, ns) once: dproj (samples, C, n_src) = gather-sum of dz over each point's positions (fully written); dwx (C, 3), ZERO-INITIALISED by the caller, += sum dz . dxyz (dxyz (samples, 3, rows, ns)).  ns % 4 == 0. */
 RTK_EXPORT int rtk_group_inverse_index(int samples, int n_src, int positions, const int *idx, int *off, unsigned short *inv,
                                        rtk_stream_t stream);
 RTK_EXPORT int rtk_sa_first_layer_bwd(int samples, int channels, int rows, int ns, int n_src, const float *dz, const float *dxyz,

@@ -9,8 +9,8 @@
 // Here the scatter is turned into a GATHER.  rtk_group_inverse_index sorts every sample's positions by the source point they
 // reference -- once per (level, scale) and step, the table does not depend on the features -- and rtk_sa_first_layer_bwd
 // streams each dz1 plane through LDS exactly once: while a plane is being staged every thread multiplies its elements with
-// the (register-resident) offsets for dwx, then thread q sums the plane at its own positions.  No float atomics on the data
-// path, deterministic dproj, one read of dz1.
+// the (register-resident) offsets for dwx, then every thread sums an equal share of the sorted positions (runs of one source
+// point in registers, one LDS add per run end).  One read of dz1, a few hundred LDS adds per plane instead of one per element.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -50,17 +50,17 @@ __global__ __launch_bounds__(256) void inverse_index_kernel(int n_src, int P, co
     for (int q = t; q <= n_src; q += 256) off[(size_t)s * (n_src + 1) + q] = s_cnt[q];
     __syncthreads();
     unsigned short *iv = inv + (size_t)s * P;
-    for (int p = t; p < P; p += 256) iv[atomicAdd(&s_cur[id[p]], 1)] = (unsigned short)p;
+    unsigned short *s_tmp = reinterpret_cast<unsigned short *>(s_cur + n_src);      // [P] the lists as the atomic cursors filled them
+    for (int p = t; p < P; p += 256) s_tmp[atomicAdd(&s_cur[id[p]], 1)] = (unsigned short)p;
     __syncthreads();
-    // the atomic cursors filled every list in arbitrary order: sort each (short) list so that the sums are reproducible
-    for (int q = t; q < n_src; q += 256) {
-        const int a = s_cnt[q], b = s_cnt[q + 1];
-        for (int i = a + 1; i < b; ++i) {
-            const unsigned short v = iv[i];
-            int j = i - 1;
-            while (j >= a && iv[j] > v) { iv[j + 1] = iv[j]; --j; }
-            iv[j + 1] = v;
-        }
+    // the cursors filled every list in arbitrary order: every element finds its rank inside its own list (short lists, all
+    // elements in parallel) so that the table -- and every sum taken in its order -- is reproducible
+    for (int e = t; e < P; e += 256) {
+        const unsigned short v = s_tmp[e];
+        const int q = id[v], a = s_cnt[q], b = s_cnt[q + 1];
+        int r = 0;
+        for (int i = a; i < b; ++i) r += s_tmp[i] < v ? 1 : 0;
+        iv[a + r] = v;
     }
 }
 
@@ -74,11 +74,15 @@ __global__ __launch_bounds__(256) void sa_first_layer_bwd_kernel(int channels, i
     extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem[];
     float *s_plane = reinterpret_cast<float *>(fb_smem);                                  // [P]
     int *s_off = reinterpret_cast<int *>(s_plane + ((P + 3) & ~3));                       // [n_src + 1]
-    unsigned short *s_inv = reinterpret_cast<unsigned short *>(s_off + n_src + 1);        // [P]
+    float *s_out = reinterpret_cast<float *>(s_off + n_src + 1);                         // [n_src]
+    unsigned short *s_inv = reinterpret_cast<unsigned short *>(s_out + n_src);            // [P]
     __shared__ float s_red[4][3];
     const int s = blockIdx.y, c0 = blockIdx.x * FB_CG, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (int q = t; q <= n_src; q += 256) s_off[q] = off[(size_t)s * (n_src + 1) + q];
-    for (int p = t; p < P; p += 256) s_inv[p] = inv[(size_t)s * P + p];
+    // thread t later walks the sorted positions [t E, (t+1) E): one pad element per chunk keeps the 64 lanes of a wave on
+    // different LDS banks (a plain layout puts them 2E bytes apart: a 32-way conflict per read)
+    const int E = (P + 255) >> 8;
+    for (int p = t; p < P; p += 256) s_inv[p + p / E] = inv[(size_t)s * P + p];
     const int n4 = P >> 2;                        // P % 4 == 0 (ns >= 4)
     const float4 *dx4 = reinterpret_cast<const float4 *>(dxyz + (size_t)s * 3 * P);
     float4 ox[FB_MAXQ], oy[FB_MAXQ], oz[FB_MAXQ];
@@ -96,15 +100,20 @@ __global__ __launch_bounds__(256) void sa_first_layer_bwd_kernel(int channels, i
         float ax = 0.f, ay = 0.f, az = 0.f;
         __syncthreads();                           // the previous plane has been consumed
         if (in_regs) {
+            float4 v[FB_MAXQ];
+#pragma unroll
+            for (int i = 0; i < FB_MAXQ; ++i) {          // all of the plane's loads in flight before the first use
+                const int e = t + 256 * i;
+                v[i] = pl[e < n4 ? e : n4 - 1];
+            }
 #pragma unroll
             for (int i = 0; i < FB_MAXQ; ++i) {
                 const int e = t + 256 * i;
                 if (e < n4) {
-                    const float4 v = pl[e];
-                    reinterpret_cast<float4 *>(s_plane)[e] = v;
-                    ax += (v.x * ox[i].x + v.y * ox[i].y) + (v.z * ox[i].z + v.w * ox[i].w);
-                    ay += (v.x * oy[i].x + v.y * oy[i].y) + (v.z * oy[i].z + v.w * oy[i].w);
-                    az += (v.x * oz[i].x + v.y * oz[i].y) + (v.z * oz[i].z + v.w * oz[i].w);
+                    reinterpret_cast<float4 *>(s_plane)[e] = v[i];
+                    ax += (v[i].x * ox[i].x + v[i].y * ox[i].y) + (v[i].z * ox[i].z + v[i].w * ox[i].w);
+                    ay += (v[i].x * oy[i].x + v[i].y * oy[i].y) + (v[i].z * oy[i].z + v[i].w * oy[i].w);
+                    az += (v[i].x * oz[i].x + v[i].y * oz[i].y) + (v[i].z * oz[i].z + v[i].w * oz[i].w);
                 }
             }
         } else {
@@ -121,12 +130,31 @@ __global__ __launch_bounds__(256) void sa_first_layer_bwd_kernel(int channels, i
         if (lane == 0) { s_red[wave][0] = ax; s_red[wave][1] = ay; s_red[wave][2] = az; }
         __syncthreads();                           // plane staged, partials visible
         if (t < 3) atomicAdd(dwx + c * 3 + t, (s_red[0][t] + s_red[1][t]) + (s_red[2][t] + s_red[3][t]));
-        float *out = dproj + ((size_t)s * channels + c) * n_src;
-        for (int q = t; q < n_src; q += 256) {
-            float acc = 0.f;
-            for (int e = s_off[q]; e < s_off[q + 1]; ++e) acc += s_plane[s_inv[e]];
-            out[q] = acc;
+        // balanced segmented sum: thread t owns the sorted positions [t E, (t+1) E); runs of one source point inside the chunk
+        // are summed in registers, only the (few) run ends go to the LDS accumulator
+        for (int q = t; q < n_src; q += 256) s_out[q] = 0.f;
+        __syncthreads();
+        {
+            const int e0 = t * E, e1 = min(P, e0 + E);
+            if (e0 < e1) {
+                int lo = 0, hi = n_src;                     // the source point of position e0: last q with off[q] <= e0
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= e0) lo = mid; else hi = mid; }
+                int q = lo, nb = s_off[q + 1];
+                float acc = 0.f;
+                for (int e = e0; e < e1; ++e) {
+                    if (e >= nb) {
+                        atomicAdd(&s_out[q], acc);
+                        acc = 0.f;
+                        do { ++q; nb = s_off[q + 1]; } while (e >= nb);
+                    }
+                    acc += s_plane[s_inv[e + t]];
+                }
+                atomicAdd(&s_out[q], acc);
+            }
         }
+        __syncthreads();
+        float *out = dproj + ((size_t)s * channels + c) * n_src;
+        for (int q = t; q < n_src; q += 256) out[q] = s_out[q];
     }
 }
 
@@ -137,7 +165,14 @@ extern "C" int rtk_group_inverse_index(int samples, int n_src, int positions, co
     RTK_REQUIRE(samples > 0 && n_src > 0 && positions > 0 && idx && off && inv, "group_inverse_index: bad arguments");
     RTK_REQUIRE(positions <= 65536 && n_src <= 8192, "group_inverse_index: %d positions / %d source points exceed the 16-bit table",
                 positions, n_src);
-    inverse_index_kernel<<<samples, 256, (2 * (size_t)n_src + 1) * sizeof(int), (hipStream_t)stream>>>(n_src, positions, idx, off, inv);
+    const size_t lds = (2 * (size_t)n_src + 1) * sizeof(int) + (size_t)positions * sizeof(unsigned short);
+    RTK_REQUIRE(lds <= 150 * 1024, "group_inverse_index: table exceeds the LDS budget");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)inverse_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    inverse_index_kernel<<<samples, 256, lds, (hipStream_t)stream>>>(n_src, positions, idx, off, inv);
     RTK_CHECK_LAUNCH("group_inverse_index");
     return RTK_OK;
 }
@@ -147,7 +182,7 @@ extern "C" int rtk_sa_first_layer_bwd(int samples, int channels, int rows, int n
     RTK_REQUIRE(samples > 0 && channels > 0 && rows > 0 && ns >= 4 && (ns & 3) == 0 && n_src > 0 && dz && dxyz && off && inv && dproj &&
                 dwx, "sa_first_layer_bwd: bad arguments");
     const int P = rows * ns;
-    const size_t lds = (size_t)((P + 3) & ~3) * sizeof(float) + (size_t)(n_src + 1) * sizeof(int) + (size_t)P * sizeof(unsigned short);
+    const size_t lds = (size_t)((P + 3) & ~3) * sizeof(float) + (size_t)(2 * n_src + 1) * sizeof(int) + (size_t)(P + 256) * sizeof(unsigned short);
     RTK_REQUIRE(P <= 65536 && lds <= 150 * 1024 && samples <= 65535, "sa_first_layer_bwd: %d positions exceed the LDS budget", P);
     static bool attr_set = false;
     if (!attr_set) {
