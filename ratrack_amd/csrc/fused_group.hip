@@ -377,7 +377,10 @@ __device__ __forceinline__ f4 *cv_at(float *base, unsigned byte_off) {
     return reinterpret_cast<f4 *>(reinterpret_cast<char *>(base) + byte_off);
 }
 
-__global__ __launch_bounds__(64 * CV_NW, (CV_NW * CV_WGS_PER_CU) / 4) void cost_volume_bwd_kernel(const CvBwdParams Q) {
+#ifndef CVB_MIN_WAVES
+#define CVB_MIN_WAVES ((CV_NW * CV_WGS_PER_CU) / 4)
+#endif
+__global__ __launch_bounds__(64 * CV_NW, CVB_MIN_WAVES) void cost_volume_bwd_kernel(const CvBwdParams Q) {
     __shared__ __attribute__((aligned(16))) f4 s_w[2 * CV_F * 64];
     const CvParams &P = Q.f;
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;

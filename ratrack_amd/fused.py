@@ -459,8 +459,9 @@ def sa_scale(geo, W, lvl, s, q, qcol, out, out_offset):
               sc.chain.n, sc.chain.arr, optr, opitch, out_offset, src_nu, geo.nuniq[lvl].data_ptr(), _stream())
 
 
-def run_pnhead(W, geo, q1):
-    """q1 (samples*n, 32): per-point sa1 layer-1 projections (scale 0 | scale 1).  Returns l0_points (samples*n, 128).
+def run_pnhead(W, geo, q1, out=None):
+    """q1 (samples*n, 32): per-point sa1 layer-1 projections (scale 0 | scale 1).  Returns l0_points (samples*n, 128) (written
+    into `out`, a possibly column-sliced (samples*n, 128) view, when given).
     All centroid-level tensors hold valid data only in rows < geo.nuniq[level][sample]; the rest are duplicates of the
     sample's row 0 and are never read (consumers alias them)."""
     S_, n, S = geo.samples, geo.n, geo.npoint
@@ -491,8 +492,8 @@ def run_pnhead(W, geo, q1):
                    interp=(f3, 128, m, idx.reshape(-1, 3), d2.reshape(-1, 3), nu[1]))
     d2, idx, m = geo.nn["fp1"]
     gmax = torch.zeros(S_, 128, dtype=torch.float32, device=dev)          # global max-pool, fused into fp1's epilogue
-    out = pointwise(S_ * n, n, [], W.fp["fp1"], new(S_ * n, 128), interp=(f2, 128, m, idx.reshape(-1, 3), d2.reshape(-1, 3), nu[0]),
-                    colmax=gmax)
+    out = pointwise(S_ * n, n, [], W.fp["fp1"], out if out is not None else new(S_ * n, 128),
+                    interp=(f2, 128, m, idx.reshape(-1, 3), d2.reshape(-1, 3), nu[0]), colmax=gmax)
     return out, gmax
 
 
@@ -576,7 +577,12 @@ class FusedBackbone:
         geo = Geometry(xyz, self.npoint, side=self.side if self.use_side_stream else None, knn_frames=B, n_valid=n_valid)
         # ---- encoder over both frames at once (same weights; eval-mode BN is per-element) --------------
         q1 = pointwise(2 * B * N, N, [(raw, 2, False)], self.enc_q1, new(2 * B * N, 32))
-        loc, glob = run_pnhead(self.enc, geo, q1)                                        # (2B*N, 128), (2B, 128)
+        # pc{1,2}_features = [local (128) | global max broadcast (128)] (models/track4d.py:89-95) live in ONE point-major buffer:
+        # the encoder's last layer writes the local half in place, one broadcast copy fills the global half, and the API's
+        # (B,256,N) tensors are permuted VIEWS of it -- no layout pass over the outputs
+        feat12 = new(2 * B * N, 256)
+        loc, glob = run_pnhead(self.enc, geo, q1, out=feat12[:, 0:128])                  # (2B*N, 128) view, (2B, 128)
+        feat12.view(2 * B, N, 256)[:, :, 128:] = glob.unsqueeze(1)
         f1, f2, g1, g2 = loc[:B * N], loc[B * N:], glob[:B], glob[B:]
         # ---- cost volume ---------------------------------------------------------------------------------
         sb1 = pointwise(B, B, [(g1, 128, False)], self.p1_glob, new(B, 256))
@@ -622,18 +628,11 @@ class FusedBackbone:
         sbf = pointwise(B, B, [(gout, 128, False)], self.flow_glob, new(B, 128))
         flow = torch.empty(B, 3, N, dtype=torch.float32, device=dev)
         pointwise(B * N, N, [(prop, 128, False)], self.flow_head, flow, out_channels=3, sample_bias=sbf, channel_major=True)
-        # ---- API layouts (B,C,N) -------------------------------------------------------------------------
-        pc1_features = torch.empty(B, 256, N, dtype=torch.float32, device=dev)
-        pc2_features = torch.empty(B, 256, N, dtype=torch.float32, device=dev)
-        cor_cm = torch.empty(B, 256, N, dtype=torch.float32, device=dev)
-        prop_cm = torch.empty(B, 128, N, dtype=torch.float32, device=dev)
-        jobs = [(pc1_features, 0, f1, 128, 0), (pc1_features, 128, g1, 128, 1), (pc2_features, 0, f2, 128, 0),
-                (pc2_features, 128, g2, 128, 1), (cor_cm, 0, cor, 256, 0), (prop_cm, 0, prop, 128, 0)]
-        arr = (_LayoutJob * len(jobs))()
-        for i, (dst, off, src, ch, per) in enumerate(jobs):
-            arr[i].src, arr[i].dst, arr[i].channels, arr[i].src_pitch = src.data_ptr(), dst.data_ptr(), ch, src.stride(0)
-            arr[i].per_sample, arr[i].dst_channels, arr[i].dst_channel_offset = per, dst.shape[1], off
-        _lib.call("rtk_to_channel_major_multi", B, N, len(jobs), arr, _stream())
+        # ---- API layouts (B,C,N): permuted views of the point-major tensors (same values as the reference's, no copy) ------
+        f12 = feat12.view(2 * B, N, 256).permute(0, 2, 1)
+        pc1_features, pc2_features = f12[:B], f12[B:]
+        cor_cm = cor.view(B, N, 256).permute(0, 2, 1)
+        prop_cm = prop.view(B, N, 128).permute(0, 2, 1)
         return flow, h_out, cls, cor_cm, pc1_features, pc2_features, prop_cm
 
     # --------------------------------------------------------------------------------------------------
