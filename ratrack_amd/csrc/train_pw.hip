@@ -86,7 +86,9 @@ __device__ __forceinline__ void pw_load_block(const PwOp &op, const float *base,
 }
 
 
-__global__ __launch_bounds__(PW_T, 2) void pw_conv_kernel(const PwParams Q) {
+template <int NW>      // waves per workgroup: 4 (they share a weight tile) or 1 (small batches: four times the workgroups)
+__global__ __launch_bounds__(64 * NW) void pw_conv_kernel(const PwParams Q) {
+    constexpr int NT = 64 * NW;
     __shared__ __attribute__((aligned(16))) f4 s_w[2 * 16 * 64];    // double-buffered (64 out, 64 in) weight tile, fragment (u, v)
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
     const int b = blockIdx.z, P = Q.P;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(PW_T, 2) void pw_conv_kernel(const PwParams Q) {
     const int oc0 = Q.chunk_c0[blockIdx.y];                         // first channel of this chunk inside its destination
     const int orow0 = D.col0 + oc0;                                 // ... and its row of W
     const int nout = min(64, D.channels - oc0);
-    const int p0 = (blockIdx.x * (PW_T / 64) + wave) * 64;
+    const int p0 = (blockIdx.x * NW + wave) * 64;
     const int p = p0 + 4 * j;
     const bool pfull = p0 + 64 <= P;
     f4 acc[4][4];
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(PW_T, 2) void pw_conv_kernel(const PwParams Q) {
             // lane (fg, fi) = W[o = 16v + fi][k = 16u + 4fg .. +3].  One barrier per tile: a wave can only be one tile ahead.
             f4 *sw = s_w + buf * (16 * 64);
             if (!Q.transpose_w) {
-                for (int e = threadIdx.x; e < 16 * 64; e += PW_T) {
+                for (int e = threadIdx.x; e < 16 * 64; e += NT) {
                     const int f = e >> 6, l = e & 63, u = f >> 2, v = f & 3, fg = l >> 4, fi = l & 15;
                     const int o = 16 * v + fi, k = k0 + 16 * u + 4 * fg;
                     f4 w = f4_zero();
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(PW_T, 2) void pw_conv_kernel(const PwParams Q) {
                 }
             } else {      // element (o, k) = W[k][o]: read rows of W along o (contiguous), scatter the four values into their fragments
                 float *swf = reinterpret_cast<float *>(sw);
-                for (int e = threadIdx.x; e < 64 * 16; e += PW_T) {
+                for (int e = threadIdx.x; e < 64 * 16; e += NT) {
                     const int kk = e >> 4, o4 = (e & 15) * 4, k = k0 + kk;
                     f4 w = f4_zero();
                     if (k < S.channels) {
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(PW_T, 2) void pw_conv_kernel(const PwParams Q) {
     for (int t = 0; t < 4; ++t) wl[t] = (p + t < P) ? (Q.rw ? Q.rw[(size_t)b * P + p + t] : 1.f) : 0.f;
     float *db = const_cast<float *>(D.ptr) + (size_t)b * D.sample_stride;
     const bool dfast = pfull;
-    __shared__ double s_red[PW_T / 64][64][2];
+    __shared__ double s_red[NW][64][2];
     const bool stats = Q.sums != nullptr;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(PW_T, 2) void pw_conv_kernel(const PwParams Q) {
         if (threadIdx.x < nout) {
             double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-            for (int w = 0; w < PW_T / 64; ++w) { a0 += s_red[w][threadIdx.x][0]; a1 += s_red[w][threadIdx.x][1]; }
+            for (int w = 0; w < NW; ++w) { a0 += s_red[w][threadIdx.x][0]; a1 += s_red[w][threadIdx.x][1]; }
             const int grp = b / (Q.samples / Q.groups);
             double *dst = Q.sums + ((size_t)grp * Q.stat_channels + orow0 + threadIdx.x) * 2;
             atomicAdd(dst, a0);
@@ -394,8 +396,12 @@ extern "C" int rtk_pw_conv(int samples, int positions, int nsrc, const rtk_pw_op
     Q.nchunks = nch;
     Q.W = w; Q.w_pitch = w_pitch; Q.transpose_w = transpose_w; Q.bias = bias; Q.rw = row_weight; Q.sums = sums;
     Q.stat_channels = stat_channels; Q.accumulate = accumulate;
-    const dim3 grid(rtk_divup(positions, 256), nch, samples);
-    pw_conv_kernel<<<grid, PW_T, 0, (hipStream_t)stream>>>(Q);
+    // four waves sharing one staged weight tile -- unless that leaves most of the chip idle (small batches): then one wave each
+    if ((long)rtk_divup(positions, 256) * nch * samples >= 192) {
+        pw_conv_kernel<4><<<dim3(rtk_divup(positions, 256), nch, samples), 256, 0, (hipStream_t)stream>>>(Q);
+    } else {
+        pw_conv_kernel<1><<<dim3(rtk_divup(positions, 64), nch, samples), 64, 0, (hipStream_t)stream>>>(Q);
+    }
     RTK_CHECK_LAUNCH("pw_conv");
     return RTK_OK;
 }
@@ -425,9 +431,9 @@ extern "C" int rtk_pw_wgrad(int samples, int positions, const rtk_pw_operand_t *
     const long ntiles = (long)samples * ((positions + 15) / 16);
     const int ochunks = rtk_divup(dz->channels, 64);
     // enough workgroups to fill the chip, few enough that the 64 x 64 atomics per workgroup stay a small share of its work
-    long splits = 512 / ((long)nch * ochunks);
-    if (splits < 1) splits = 1;
-    if (splits > (ntiles + 31) / 32) splits = (ntiles + 31) / 32;      // >= 32 tiles (8 per wave) behind every 64 x 64 block of atomics
+    // about one workgroup per CU; at least one tile per wave behind every 64 x 64 block of atomics
+    long splits = (256 + (long)nch * ochunks - 1) / ((long)nch * ochunks);
+    if (splits > (ntiles + 3) / 4) splits = (ntiles + 3) / 4;
     if (splits < 1) splits = 1;
     Q.tiles_per_wg = (int)((ntiles + splits - 1) / splits);
     const dim3 grid(nch, ochunks, (unsigned)((ntiles + Q.tiles_per_wg - 1) / Q.tiles_per_wg));
