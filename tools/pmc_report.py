@@ -47,14 +47,15 @@ def main(fetch_db, write_db, trace_db, out_dir, tag="r02"):
             for k, (cname, n, avg, lo, hi) in sorted(tab.items(), key=lambda kv: -kv[1][2]):
                 f.write("%-100s %-12s n=%4d avg=%14.1f min=%14.1f max=%14.1f\n" % (dm[k][:100], cname, n, avg, lo, hi))
     # calibration: the 256 MiB clone
-    cal = [k for k in F if "direct_copy" in dm[k] or "copy_kernel" in dm[k].lower()]
-    cal_k = max(cal, key=lambda k: F[k][4]) if cal else None
+    # the 256 MiB clone is the dispatch with the largest WRITE_SIZE among the copy kernels (framework copy kernel or the runtime's blit)
+    cal = [k for k in W if "copy" in dm[k].lower()]
+    cal_k = max(cal, key=lambda k: W[k][4]) if cal else None
     fetch_scale, cal_note = 2.0, "no calibration kernel found; FETCH_SIZE doubled per the guide"
     if cal_k:
-        f_kib, w_kib = F[cal_k][4], W.get(cal_k, (0, 0, 0, 0, 0))[4]
+        f_kib, w_kib = F.get(cal_k, (0, 0, 0, 0, 0))[4], W[cal_k][4]
         fetch_scale = 262144.0 / f_kib if f_kib else 2.0
-        cal_note = ("256 MiB clone in the same run: max FETCH_SIZE = %.1f KiB -> scale %.3f (guide: 2), max WRITE_SIZE = %.1f KiB "
-                    "(expected 262144)" % (f_kib, fetch_scale, w_kib))
+        cal_note = ("256 MiB clone in the same run (%s): max FETCH_SIZE = %.1f KiB -> scale %.3f (guide: 2), max WRITE_SIZE = %.1f KiB "
+                    "(expected 262144)" % (dm[cal_k][:40], f_kib, fetch_scale, w_kib))
 
     def traffic(pred):
         ks = [k for k in set(F) | set(W) if pred(dm[k])]

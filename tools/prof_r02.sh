@@ -13,5 +13,6 @@ python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python tools/prof_summary.py $(find $O/bench -name "*.db" | head -1) > $O/r02_bench_default_kernel_stats.txt
 python tools/prof_summary.py $(find $O/train -name "*.db" | head -1) > $O/r02_train_step_kernel_stats.txt
 python tools/pmc_report.py $(find $O/fetch -name "*.db" | head -1) $(find $O/write -name "*.db" | head -1) $(find $O/trace -name "*.db" | head -1) $O r02
-find $O -name "*stats*.csv" | head; rm -rf $O/bench/*/*.db $O/train/*/*.db $O/trace $O/fetch $O/write 2>/dev/null
+cp $(find $O/bench -name "*kernel_stats.csv" | head -1) $O/r02_bench_default_kernel_stats.csv 2>/dev/null; cp $(find $O/train -name "*kernel_stats.csv" | head -1) $O/r02_train_step_kernel_stats.csv 2>/dev/null
+rm -rf $O/bench $O/train $O/trace $O/fetch $O/write 2>/dev/null
 ls $O
