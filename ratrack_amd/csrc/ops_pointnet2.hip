@@ -125,7 +125,11 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 template <int PPL>
 __device__ __forceinline__ int fps_wave_body(int n, int m, int block, const float *__restrict__ xyz, float *__restrict__ temp,
                                              int *__restrict__ idxs, float *__restrict__ new_xyz, float4 *s_pt, int lane,
-                                             bool &tie_out) {
+                                             int &tie_out, int settle_from = -1, bool *settled = nullptr, int j_start = 1,
+                                             float *__restrict__ snap = nullptr, int *__restrict__ first_tie = nullptr) {
+    // j_start > 1 (re-levelling): points 0 .. j_start-1 of the cloud are already selected in this order, `temp` holds the
+    // min-distances of that state, idxs / new_xyz [0, j_start) are the caller's.  snap / first_tie (level 1): at the FIRST round
+    // with a tie the min-distance state is saved by cloud index, so that a later level can resume there instead of at round 1.
     const int bits = 31 - __builtin_clz(block);
     const int q = n >> bits, rem = n & (block - 1);
     for (int k = lane; k < n; k += 64)      // coalesced read of the cloud, scattered into tie order
@@ -148,12 +152,16 @@ __device__ __forceinline__ int fps_wave_body(int n, int m, int block, const floa
         t[i] = ok ? __float_as_uint(temp ? temp[__float_as_int(v.w)] : 1e10f) : 0u;
     }
     float4 o = p0;
-    if (lane == 0) {
+    if (j_start > 1) {
+        o = s_pt[fps_index_to_pos(j_start - 1, block, bits, q, rem)];
+    } else if (lane == 0) {
         idxs[0] = 0;
         if (new_xyz) { new_xyz[0] = o.x; new_xyz[1] = o.y; new_xyz[2] = o.z; }
     }
-    bool tie = false;
-    int j = 1;
+    int tie = 0;            // last round whose maximum was attained by more than one position (0: none)
+    int kmax = j_start - 1; // largest index picked so far
+    bool early = false;
+    int j = j_start;
     for (; j < m; ++j) {
         const f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
         unsigned mloc = 0u;
@@ -185,7 +193,16 @@ __device__ __forceinline__ int fps_wave_body(int n, int m, int block, const floa
         const unsigned long long mask = __ballot(mloc == M);
         const int wl = __builtin_ctzll(mask);     // lowest lane holding the maximum
         const int w = __builtin_amdgcn_readlane(slh, wl);
-        tie |= ((mask & (mask - 1)) != 0ull) | ((w >> 8) != (w & 0xff));
+        const bool tied_now = ((mask & (mask - 1)) != 0ull) | ((w >> 8) != (w & 0xff));
+        if (tied_now && tie == 0 && snap) {       // wave-uniform, at most once per run: save the state this round started from
+#pragma unroll
+            for (int i = 0; i < PPL; ++i) {
+                const int p = lane * PPL + i;
+                if (p < n) snap[__float_as_int(s_pt[p].w)] = __uint_as_float(t[i]);
+            }
+            if (lane == 0) *first_tie = j;
+        }
+        tie = tied_now ? j : tie;
         const int pos = wl * PPL + (w & 0xff);
         o = s_pt[pos];                            // one uniform-address b128 read; lane 0 stores from registers
         asm volatile("" : "+v"(o.x), "+v"(o.y), "+v"(o.z), "+v"(o.w));
@@ -193,7 +210,14 @@ __device__ __forceinline__ int fps_wave_body(int n, int m, int block, const floa
             idxs[j] = __float_as_int(o.w);
             if (new_xyz) { new_xyz[j * 3 + 0] = o.x; new_xyz[j * 3 + 1] = o.y; new_xyz[j * 3 + 2] = o.z; }
         }
+        if (settle_from >= 0) {                   // re-levelling run (see fps_relevel_kernel): selected SET == {0..j} past the last tie
+            const int k = __float_as_int(o.w);
+            kmax = k > kmax ? k : kmax;
+            if (j >= settle_from && kmax <= j) { early = true; ++j; break; }
+        }
     }
+    if (settled) *settled = early;
+    if (early) { tie_out = tie; return j; }       // the caller completes the run as the identity from round j on
     for (int jj = j + lane; jj < m; jj += 64) {
         idxs[jj] = 0;
         if (new_xyz) { new_xyz[jj * 3 + 0] = p0.x; new_xyz[jj * 3 + 1] = p0.y; new_xyz[jj * 3 + 2] = p0.z; }
@@ -213,10 +237,11 @@ template <int PPL>
 __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, const float *__restrict__ xyz,
                                                       float *__restrict__ temp, int *__restrict__ idxs,
                                                       float *__restrict__ new_xyz, int *__restrict__ nuniq,
-                                                      int *__restrict__ tie, const int *__restrict__ nvalid) {
+                                                      int *__restrict__ tie, const int *__restrict__ nvalid,
+                                                      float *__restrict__ snap, int *__restrict__ first_tie) {
     extern __shared__ __attribute__((aligned(16))) float4 s_pt[];   // (x, y, z, bits(k)) by position
     const int b = blockIdx.x;
-    bool tied;
+    int tied;
     const int pitch = n;
     if (nvalid) {     // padded batch: this sample's cloud is its first nvalid[b] points; the tie rule follows ITS size
         n = nvalid[b] < n ? nvalid[b] : n;
@@ -226,48 +251,88 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, c
     }
     const int j = fps_wave_body<PPL>(n, m, block, xyz + (size_t)b * pitch * 3, temp ? temp + (size_t)b * pitch : nullptr,
                                      idxs + (size_t)b * m, new_xyz ? new_xyz + (size_t)b * m * 3 : nullptr, s_pt,
-                                     (int)threadIdx.x, tied);
+                                     (int)threadIdx.x, tied, -1, nullptr, 1, snap ? snap + (size_t)b * pitch : nullptr,
+                                     first_tie ? first_tie + b : nullptr);
     if (threadIdx.x == 0) {
         if (nuniq) nuniq[b] = j;
-        if (tie) tie[b] = tied ? 1 : 0;
+        if (tie) tie[b] = tied;
     }
 }
 
 // Levels 2.. of a PNHead: furthest point sampling of npoint out of the npoint centroids of the previous level
-// (model_utils.py:415-417).  Without a tie in the level-1 run (tie[b] == 0) every such run is the identity on the
-// coordinates: by induction the selected prefix is P[0..j), the running min-distances are bit-identical to the
-// level-1 run's (same formula on the same coordinates), whose UNIQUE maximum was P[j]; once the cloud is exhausted
-// both runs pick index 0, whose coordinates are those of the copies of P[0] that fill the tail.  So
-// new_xyz = xyz1, idx = (0 .. nuniq-1, 0, 0, ...), nuniq unchanged, and this kernel only copies.  With a tie the
-// reference re-breaks it by the POSITION in the new cloud (bit-reversed), which may differ from level 1's choice:
-// the full selection runs, level after level.
+// (model_utils.py:415-417).  Let P[0..U) be the level-1 selection (then the cloud is exhausted and index 0 repeats) and T the
+// last level-1 round whose maximum was attained by more than one position (tie[b]; 0 = none).
+//   * The running min-distances of a selection depend only on the selected SET.  So if, after some round r >= T, a later
+//     level has selected exactly {P[0..r]}, its min-distances are bit-identical to level 1's after round r (same formula on the
+//     same coordinates); level 1's rounds > r have a UNIQUE maximum, so the level picks P[r+1], P[r+2], ... -- the identity from
+//     round r on, exhaustion included.
+//   * T = 0: the condition holds at r = 0 -- the level is the identity on the coordinates and is only copied:
+//     idx = (0 .. U-1, 0, 0, ...), new_xyz = xyz1.
+//   * T > 0: the reference re-breaks the level-1 ties by the POSITION in the new cloud (bit-reversed), which may differ from
+//     level 1's choice, so the selection runs in full up to the first round r >= T at which the picked indices are exactly
+//     {0..r} (largest picked index <= r), typically T or T+1 (two tied points picked in the other order), and is completed as
+//     the identity.  The next level sees a cloud that agrees with P beyond r and uses r as its T.
 template <int PPL>
 __global__ __launch_bounds__(64) void fps_relevel_kernel(int samples, int npoint, int block, int levels,
                                                          const float *__restrict__ xyz1, const int *__restrict__ nuniq1,
                                                          const int *__restrict__ tie, int *__restrict__ idx,
-                                                         float *__restrict__ new_xyz, int *__restrict__ nuniq) {
+                                                         float *__restrict__ new_xyz, int *__restrict__ nuniq,
+                                                         const int *__restrict__ idx1, const float *__restrict__ snap1, int snap_pitch,
+                                                         const int *__restrict__ first_tie1, float *__restrict__ scratch) {
     extern __shared__ __attribute__((aligned(16))) float4 s_pt[];
     const int b = blockIdx.x, lane = threadIdx.x;
     const float *src = xyz1 + (size_t)b * npoint * 3;
-    if (!tie[b]) {
-        const int nu = nuniq1[b];
-        for (int l = 0; l < levels; ++l) {
-            int *io = idx + ((size_t)l * samples + b) * npoint;
-            float *xo = new_xyz + ((size_t)l * samples + b) * npoint * 3;
-            for (int jj = lane; jj < npoint; jj += 64) io[jj] = jj < nu ? jj : 0;
-            for (int jj = lane; jj < npoint * 3; jj += 64) xo[jj] = src[jj];
-            if (lane == 0) nuniq[(size_t)l * samples + b] = nu;
-        }
-        return;
+    const int nu = nuniq1[b];
+    int T = tie[b];
+    // Resume point: before the FIRST tied round T0 every level repeats level 1 exactly, so a level starts at round T0 from the
+    // min-distance state level 1 saved there (snap1, by level-1 cloud index) instead of re-running T0 - 1 rounds.  The state is a
+    // function of the POINT; it is carried to each level's own cloud through the index lists.
+    int resume = (snap1 && first_tie1 && scratch && T > 0 && T < npoint) ? first_tie1[b] : 0;
+    float *st_a = scratch ? scratch + (size_t)b * 2 * npoint : nullptr, *st_b = st_a ? st_a + npoint : nullptr;
+    if (resume > 1) {       // level 2's cloud P: P[r] = level-1 point idx1[r] (copies of P[0] past U: state 0, as point 0's)
+        const int *i1 = idx1 + (size_t)b * npoint;
+        const float *sn = snap1 + (size_t)b * snap_pitch;
+        for (int r = lane; r < npoint; r += 64) st_a[r] = sn[i1[r]];
+        __syncthreads();
     }
     for (int l = 0; l < levels; ++l) {
         int *io = idx + ((size_t)l * samples + b) * npoint;
         float *xo = new_xyz + ((size_t)l * samples + b) * npoint * 3;
-        bool tied;
-        const int j = fps_wave_body<PPL>(npoint, npoint, block, src, nullptr, io, xo, s_pt, lane, tied);
-        if (lane == 0) nuniq[(size_t)l * samples + b] = j;
-        __syncthreads();      // workgroup-scope fence: this wave's centroid stores are visible to its own next run
-        src = xo;
+        int j0 = 1;                                 // first round completed as the identity
+        if (T > 0) {
+            int tied;
+            bool settled;
+            const int js = resume > 1 ? resume : 1;
+            if (js > 1) {                           // rounds < T0: the identity
+                for (int jj = lane; jj < js; jj += 64) io[jj] = jj;
+                for (int jj = lane; jj < 3 * js; jj += 64) xo[jj] = src[jj];
+            }
+            j0 = fps_wave_body<PPL>(npoint, npoint, block, src, js > 1 ? st_a : nullptr, io, xo, s_pt, lane, tied, T, &settled, js);
+            __syncthreads();      // workgroup-scope fence: this wave's stores are visible to its own next run
+            if (!settled) {       // ran to the end (e.g. no tie information): a full, independent selection
+                if (lane == 0) nuniq[(size_t)l * samples + b] = j0;
+                src = xo;
+                T = npoint;
+                resume = 0;
+                continue;
+            }
+            T = j0 - 1;           // the next level's cloud agrees with P from here on
+        } else if (lane == 0) {
+            io[0] = 0;
+            xo[0] = src[0]; xo[1] = src[1]; xo[2] = src[2];
+        }
+        for (int jj = j0 + lane; jj < npoint; jj += 64) io[jj] = jj < nu ? jj : 0;
+        for (int jj = 3 * j0 + lane; jj < npoint * 3; jj += 64) xo[jj] = src[jj];      // src[jj] == P[jj] (and copies of P[0] past U)
+        if (lane == 0) nuniq[(size_t)l * samples + b] = nu;
+        __syncthreads();
+        if (T > 0) {
+            if (resume > 1 && l + 1 < levels) {     // the saved state, re-indexed for the next level's cloud (= this level's output)
+                for (int r = lane; r < npoint; r += 64) st_b[r] = st_a[io[r]];
+                __syncthreads();
+                float *tmp = st_a; st_a = st_b; st_b = tmp;
+            }
+            src = xo;             // a permuted prefix: the next level selects from this level's output
+        }
     }
 }
 
@@ -322,14 +387,14 @@ static int fps_block_size(int n) {  // cuda_utils.h:10-14 (host code in the refe
 }
 
 static int fps_launch(int b, int n, int npoint, const float *xyz, float *temp, int *idx, float *new_xyz, int *nuniq,
-                      int *tie, const int *nvalid, hipStream_t s) {
+                      int *tie, const int *nvalid, float *snap, int *first_tie, hipStream_t s) {
     const int block = fps_block_size(n);
     RTK_REQUIRE(n / block < 65536, "furthest_point_sampling: n=%d too large", n);
     const size_t lds = (size_t)n * sizeof(float4);
-    if (n <= 64 * 4) fps_wave_kernel<4><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid);
-    else if (n <= 64 * 8) fps_wave_kernel<8><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid);
-    else if (n <= 64 * 16) fps_wave_kernel<16><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid);
-    else if (n <= 64 * 32) fps_wave_kernel<32><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid);
+    if (n <= 64 * 4) fps_wave_kernel<4><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid, snap, first_tie);
+    else if (n <= 64 * 8) fps_wave_kernel<8><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid, snap, first_tie);
+    else if (n <= 64 * 16) fps_wave_kernel<16><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid, snap, first_tie);
+    else if (n <= 64 * 32) fps_wave_kernel<32><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid, snap, first_tie);
     else return 1;   // caller falls back to the block kernel
     return 0;
 }
@@ -339,7 +404,7 @@ extern "C" int rtk_furthest_point_sampling(int b, int n, int npoint, const float
     RTK_REQUIRE(b > 0 && n > 0 && xyz && temp && idx, "furthest_point_sampling: bad arguments (b=%d n=%d)", b, n);
     if (npoint <= 0) return RTK_OK;
     hipStream_t s = (hipStream_t)stream;
-    const int rc = fps_launch(b, n, npoint, xyz, temp, idx, nullptr, nullptr, nullptr, nullptr, s);
+    const int rc = fps_launch(b, n, npoint, xyz, temp, idx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s);
     if (rc < 0) return rc;
     if (rc == 1) fps_block_kernel<<<b, 256, 0, s>>>(n, npoint, fps_block_size(n), xyz, temp, idx);
     RTK_CHECK_LAUNCH("furthest_point_sampling");
@@ -347,27 +412,29 @@ extern "C" int rtk_furthest_point_sampling(int b, int n, int npoint, const float
 }
 
 extern "C" int rtk_fps_centroids(int b, int n, int npoint, const float *xyz, int *idx, float *new_xyz, int *nuniq,
-                                 int *tie, const int *n_valid, rtk_stream_t stream) {
+                                 int *tie, const int *n_valid, float *snap, int *first_tie, rtk_stream_t stream) {
     RTK_REQUIRE(b > 0 && n > 0 && npoint > 0 && xyz && idx && new_xyz, "fps_centroids: bad arguments (b=%d n=%d)", b, n);
     RTK_REQUIRE(n <= 2048, "fps_centroids: n=%d > 2048 (use rtk_furthest_point_sampling + rtk_gather_points)", n);
-    const int rc = fps_launch(b, n, npoint, xyz, nullptr, idx, new_xyz, nuniq, tie, n_valid, (hipStream_t)stream);
+    RTK_REQUIRE((snap == nullptr) == (first_tie == nullptr), "fps_centroids: snap and first_tie go together");
+    const int rc = fps_launch(b, n, npoint, xyz, nullptr, idx, new_xyz, nuniq, tie, n_valid, snap, first_tie, (hipStream_t)stream);
     if (rc < 0) return rc;
     RTK_CHECK_LAUNCH("fps_centroids");
     return RTK_OK;
 }
 
 extern "C" int rtk_fps_relevel(int b, int npoint, int levels, const float *xyz1, const int *nuniq1, const int *tie, int *idx,
-                               float *new_xyz, int *nuniq, rtk_stream_t stream) {
+                               float *new_xyz, int *nuniq, const int *idx1, const float *snap1, int snap_pitch, const int *first_tie1,
+                               float *scratch, rtk_stream_t stream) {
     RTK_REQUIRE(b > 0 && npoint > 0 && levels > 0 && xyz1 && nuniq1 && tie && idx && new_xyz && nuniq,
                 "fps_relevel: bad arguments (b=%d npoint=%d levels=%d)", b, npoint, levels);
     RTK_REQUIRE(npoint <= 2048, "fps_relevel: npoint=%d > 2048", npoint);
     hipStream_t s = (hipStream_t)stream;
     const int block = fps_block_size(npoint);
     const size_t lds = (size_t)npoint * sizeof(float4);
-    if (npoint <= 64 * 4) fps_relevel_kernel<4><<<b, 64, lds, s>>>(b, npoint, block, levels, xyz1, nuniq1, tie, idx, new_xyz, nuniq);
-    else if (npoint <= 64 * 8) fps_relevel_kernel<8><<<b, 64, lds, s>>>(b, npoint, block, levels, xyz1, nuniq1, tie, idx, new_xyz, nuniq);
-    else if (npoint <= 64 * 16) fps_relevel_kernel<16><<<b, 64, lds, s>>>(b, npoint, block, levels, xyz1, nuniq1, tie, idx, new_xyz, nuniq);
-    else fps_relevel_kernel<32><<<b, 64, lds, s>>>(b, npoint, block, levels, xyz1, nuniq1, tie, idx, new_xyz, nuniq);
+    if (npoint <= 64 * 4) fps_relevel_kernel<4><<<b, 64, lds, s>>>(b, npoint, block, levels, xyz1, nuniq1, tie, idx, new_xyz, nuniq, idx1, snap1, snap_pitch, first_tie1, scratch);
+    else if (npoint <= 64 * 8) fps_relevel_kernel<8><<<b, 64, lds, s>>>(b, npoint, block, levels, xyz1, nuniq1, tie, idx, new_xyz, nuniq, idx1, snap1, snap_pitch, first_tie1, scratch);
+    else if (npoint <= 64 * 16) fps_relevel_kernel<16><<<b, 64, lds, s>>>(b, npoint, block, levels, xyz1, nuniq1, tie, idx, new_xyz, nuniq, idx1, snap1, snap_pitch, first_tie1, scratch);
+    else fps_relevel_kernel<32><<<b, 64, lds, s>>>(b, npoint, block, levels, xyz1, nuniq1, tie, idx, new_xyz, nuniq, idx1, snap1, snap_pitch, first_tie1, scratch);
     RTK_CHECK_LAUNCH("fps_relevel");
     return RTK_OK;
 }

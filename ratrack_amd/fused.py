@@ -44,9 +44,9 @@ _lib.SIGNATURES.update({
     "rtk_cost_volume": [_ci] * 3 + [_vp] * 6 + [ctypes.POINTER(_Layer), ctypes.POINTER(_Layer), _vp, _ci, _vp],
     "rtk_patch_cost": [_ci] * 2 + [_vp] * 3 + [_ci, ctypes.POINTER(_Layer), _vp, _ci, _ci, _vp],
     "rtk_prepare_inputs": [_ci] * 2 + [_vp] * 6 + [_vp],
-    "rtk_fps_centroids": [_ci] * 3 + [_vp] * 6 + [_vp],
+    "rtk_fps_centroids": [_ci] * 3 + [_vp] * 8 + [_vp],
     "rtk_knn_point_masked": [_ci] * 4 + [_vp] * 4 + [_vp],
-    "rtk_fps_relevel": [_ci] * 3 + [_vp] * 6 + [_vp],
+    "rtk_fps_relevel": [_ci] * 3 + [_vp] * 8 + [_ci, _vp, _vp, _vp],
     "rtk_gru_step": [_ci] * 3 + [_vp] * 8 + [_vp],
     "rtk_to_channel_major": [_ci] * 3 + [_vp, _ci, _ci, _vp, _ci, _ci, _vp],
     "rtk_ball_query_pair": [_ci] * 3 + [ctypes.c_float, _ci, ctypes.c_float, _ci] + [_vp] * 5 + [_vp],
@@ -288,7 +288,8 @@ def check_fps_relevel(xyz1, idx, new_xyz, nuniq):
         i = torch.empty(S_, npoint, dtype=torch.int32, device=src.device)
         out = torch.empty(S_, npoint, 3, dtype=torch.float32, device=src.device)
         cnt = torch.empty(S_, dtype=torch.int32, device=src.device)
-        _lib.call("rtk_fps_centroids", S_, npoint, npoint, src.data_ptr(), i.data_ptr(), out.data_ptr(), cnt.data_ptr(), None, None, _stream())
+        _lib.call("rtk_fps_centroids", S_, npoint, npoint, src.data_ptr(), i.data_ptr(), out.data_ptr(), cnt.data_ptr(), None, None, None, None,
+                  _stream())
         assert torch.equal(i, idx[l].view(S_, npoint)), "fps_relevel: level %d indices differ from the full selection" % (l + 2)
         assert torch.equal(out, new_xyz[l].view(S_, npoint, 3)), "fps_relevel: level %d centroids differ" % (l + 2)
         assert torch.equal(cnt, nuniq[l].view(-1)), "fps_relevel: level %d exhausted-cloud counters differ" % (l + 2)
@@ -331,10 +332,12 @@ class Geometry:
         # and the 3 three-NN index tables
         ns_all = [ns for row in _PNHeadWeights.NSAMPLES for ns in row]
         nn_rows = [npoint, npoint, n]
-        sizes = [S_ * npoint] * 3 + [S_] * 4 + [S_ * npoint * ns for ns in ns_all] + [S_ * r * 3 for r in nn_rows]
+        sizes = [S_ * npoint] * 3 + [S_] * 5 + [S_ * npoint * ns for ns in ns_all] + [S_ * r * 3 for r in nn_rows]
         ws = torch.zeros(sum(sizes), dtype=torch.int32, device=dev)
         parts = list(torch.split(ws, sizes))
-        fps_idx, cnt, tie, ball, nn_idx = parts[0:3], parts[3:6], parts[6], parts[7:13], parts[13:16]
+        fps_idx, cnt, tie, first_tie, ball, nn_idx = parts[0:3], parts[3:6], parts[6], parts[7], parts[8:14], parts[14:17]
+        # level-1 min-distance state at the first tied round (written for tied samples only) + the re-levelling scratch
+        snap = torch.empty(S_ * n + S_ * 2 * npoint, dtype=torch.float32, device=dev) if n <= 2048 else None
         self.fps_idx = [t.view(S_, npoint) for t in fps_idx]
         self.tie = tie
         xyz_all = torch.empty(3, S_, npoint, 3, dtype=torch.float32, device=dev)
@@ -354,19 +357,20 @@ class Geometry:
             # ---- level 1: the only full furthest-point selection on the common path ---------------------------
             if not big:
                 _lib.call("rtk_fps_centroids", S_, n, npoint, xyz.data_ptr(), fps_idx[0].data_ptr(), new_xyz[0].data_ptr(),
-                          cnt[0].data_ptr(), tie.data_ptr(), nv, _stream())
+                          cnt[0].data_ptr(), tie.data_ptr(), nv, snap.data_ptr(), first_tie.data_ptr(), _stream())
             else:   # large clouds: generic FPS + gather, no exhausted-cloud / tie information
                 _native.furthest_point_sampling_wrapper(S_, n, npoint, xyz, temp, self.fps_idx[0])
                 new_xyz[0].copy_(torch.gather(xyz, 1, self.fps_idx[0].long().unsqueeze(-1).expand(-1, -1, 3)))
                 cnt[0].fill_(npoint)
-                tie.fill_(1)            # unknown: levels 2, 3 run the full selection
+                tie.fill_(npoint)       # unknown: levels 2, 3 run the full selection (no round can settle)
 
             def relevel():
                 # ---- levels 2, 3: FPS of npoint out of the previous level's npoint centroids (model_utils.py:415-417).
                 # One launch: samples without a level-1 tie are provably the identity on the coordinates and are copied,
                 # tied samples run the full selection (see fps_relevel_kernel) -- decided on the device, no host sync.
+                resume = (fps_idx[0].data_ptr(), snap.data_ptr(), n, first_tie.data_ptr(), snap.data_ptr() + 4 * S_ * n) if not big else (None, None, 0, None, None)
                 _lib.call("rtk_fps_relevel", S_, npoint, 2, new_xyz[0].data_ptr(), cnt[0].data_ptr(), tie.data_ptr(),
-                          fps_idx[1].data_ptr(), new_xyz[1].data_ptr(), cnt[1].data_ptr(), _stream())
+                          fps_idx[1].data_ptr(), new_xyz[1].data_ptr(), cnt[1].data_ptr(), *resume, _stream())
                 if CHECK_FPS_RELEVEL and not torch.cuda.is_current_stream_capturing():      # the check synchronises
                     check_fps_relevel(new_xyz[0], torch.stack(self.fps_idx[1:]), xyz_all[1:], torch.stack(list(cnt[1:3])))
             for lvl in range(3):

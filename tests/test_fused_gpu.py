@@ -240,7 +240,7 @@ def test_misc_kernels():
     nxyz = torch.empty(2 * B, 512, 3, device=DEV)
     cnt = torch.empty(2 * B, dtype=torch.int32, device=DEV)
     tie = torch.empty(2 * B, dtype=torch.int32, device=DEV)
-    _lib.call("rtk_fps_centroids", 2 * B, N, 512, xyz.data_ptr(), idx.data_ptr(), nxyz.data_ptr(), cnt.data_ptr(), tie.data_ptr(), None,
+    _lib.call("rtk_fps_centroids", 2 * B, N, 512, xyz.data_ptr(), idx.data_ptr(), nxyz.data_ptr(), cnt.data_ptr(), tie.data_ptr(), None, None, None,
               F._stream())
     assert (tie.cpu() == 0).all()              # generic float cloud: no round had two points at the maximum
     ref = P.fps(xyz.cpu(), 512)
@@ -295,13 +295,20 @@ def test_fps_relevel():
         idx = torch.empty(S_, 512, dtype=torch.int32, device=DEV)
         c1 = torch.empty(S_, dtype=torch.int32, device=DEV)
         tie = torch.empty(S_, dtype=torch.int32, device=DEV)
-        _lib.call("rtk_fps_centroids", S_, n, 512, xyz.data_ptr(), idx.data_ptr(), l1.data_ptr(), c1.data_ptr(), tie.data_ptr(), None, F._stream())
-        idx23 = torch.empty(2, S_, 512, dtype=torch.int32, device=DEV)
-        xyz23 = torch.empty(2, S_, 512, 3, device=DEV)
-        c23 = torch.empty(2, S_, dtype=torch.int32, device=DEV)
-        _lib.call("rtk_fps_relevel", S_, 512, 2, l1.data_ptr(), c1.data_ptr(), tie.data_ptr(), idx23.data_ptr(), xyz23.data_ptr(),
-                  c23.data_ptr(), F._stream())
-        F.check_fps_relevel(l1, idx23, xyz23, c23)
+        snap = torch.full((S_, n), float("nan"), device=DEV)
+        first = torch.zeros(S_, dtype=torch.int32, device=DEV)
+        scratch = torch.empty(S_, 2 * 512, device=DEV)
+        _lib.call("rtk_fps_centroids", S_, n, 512, xyz.data_ptr(), idx.data_ptr(), l1.data_ptr(), c1.data_ptr(), tie.data_ptr(), None,
+                  snap.data_ptr(), first.data_ptr(), F._stream())
+        assert ((first > 0) == (tie > 0)).all() and (first <= tie).all()
+        for resume in (True, False):          # tied samples resume at their first tied round / start over at round 1
+            idx23 = torch.empty(2, S_, 512, dtype=torch.int32, device=DEV)
+            xyz23 = torch.empty(2, S_, 512, 3, device=DEV)
+            c23 = torch.empty(2, S_, dtype=torch.int32, device=DEV)
+            extra = (idx.data_ptr(), snap.data_ptr(), n, first.data_ptr(), scratch.data_ptr()) if resume else (None, None, 0, None, None)
+            _lib.call("rtk_fps_relevel", S_, 512, 2, l1.data_ptr(), c1.data_ptr(), tie.data_ptr(), idx23.data_ptr(), xyz23.data_ptr(),
+                      c23.data_ptr(), *extra, F._stream())
+            F.check_fps_relevel(l1, idx23, xyz23, c23)
         # the CPU oracle, level after level
         src = l1.cpu()
         assert torch.equal(idx.cpu(), P.fps(xyz.cpu(), 512))

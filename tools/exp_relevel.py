@@ -11,13 +11,14 @@ for case, B, N in [(1000, 64, 256), (1001, 64, 256), (1005, 32, 1024)]:
     S_ = 2 * B
     i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
     idx, nx, cnt, tie = i32(S_, 512), torch.empty(S_, 512, 3, device=dev), i32(S_), i32(S_)
+    snap, first, scratch = torch.empty(S_, N, device=dev), i32(S_), torch.empty(S_, 1024, device=dev)
     st = fused._stream
-    f = lambda: _lib.call("rtk_fps_centroids", S_, N, 512, xyz.data_ptr(), idx.data_ptr(), nx.data_ptr(), cnt.data_ptr(), tie.data_ptr(), None, st())
+    f = lambda: _lib.call("rtk_fps_centroids", S_, N, 512, xyz.data_ptr(), idx.data_ptr(), nx.data_ptr(), cnt.data_ptr(), tie.data_ptr(), None, snap.data_ptr(), first.data_ptr(), st())
     t_fps = _time(f, 20)
     idx23, nx23, cnt23 = i32(2, S_, 512), torch.empty(2, S_, 512, 3, device=dev), i32(2, S_)
-    g = lambda: _lib.call("rtk_fps_relevel", S_, 512, 2, nx.data_ptr(), cnt.data_ptr(), tie.data_ptr(), idx23.data_ptr(), nx23.data_ptr(), cnt23.data_ptr(), st())
+    g = lambda: _lib.call("rtk_fps_relevel", S_, 512, 2, nx.data_ptr(), cnt.data_ptr(), tie.data_ptr(), idx23.data_ptr(), nx23.data_ptr(), cnt23.data_ptr(), idx.data_ptr(), snap.data_ptr(), N, first.data_ptr(), scratch.data_ptr(), st())
     t_rel = _time(g, 20)
-    ties = int(tie.sum())
+    ties = int((tie > 0).sum())
     tie0 = tie.clone(); tie.zero_()
     t_copy = _time(g, 20)
     tie.fill_(1)
