@@ -194,6 +194,15 @@ RTK_EXPORT int rtk_gru_step_bwd(int b, int layers, int hidden, const float *x, c
 RTK_EXPORT int rtk_scatter_add_rows(int samples, int m, int n, int channels, const int64_t *idx, const float *src, float *dst,
                                     rtk_stream_t stream);
 
+/* Multi-task loss of the backbone trainer (losses/loss.py:8-31,85-89,124-146, batch mean) and its gradients in one launch.
+ * pc1, flow, gt_warp (B,3,N) contiguous; cls (B,N) probabilities; gt_cls uint8/bool, sample b's row at gt_cls + b*gt_cls_stride
+ * (stride 0: one label vector for the whole batch).  items (4) fp32 ZERO-INITIALISED: += [Loss, SceneFlowLoss, TrackingLoss (left
+ * 0), SegLoss].  dflow (B,3,N) / dcls (B,N) (optional): d Loss / d flow (not written while pre-training: the loss does not depend
+ * on the flow then) and d Loss / d cls. */
+RTK_EXPORT int rtk_backbone_loss(int b, int n, const float *pc1, const float *flow, const float *gt_warp, const float *cls,
+                                 const unsigned char *gt_cls, int gt_cls_stride, int pretrain, float *items, float *dflow, float *dcls,
+                                 rtk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,7 @@
 // the channels per t -- both layouts load and store 16 bytes per lane.  Weights are staged per (64 out, 64 in) tile in LDS.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "fused_common.h"
 #include "rtk_common.h"
@@ -397,7 +398,10 @@ extern "C" int rtk_pw_conv(int samples, int positions, int nsrc, const rtk_pw_op
     Q.W = w; Q.w_pitch = w_pitch; Q.transpose_w = transpose_w; Q.bias = bias; Q.rw = row_weight; Q.sums = sums;
     Q.stat_channels = stat_channels; Q.accumulate = accumulate;
     // four waves sharing one staged weight tile -- unless that leaves most of the chip idle (small batches): then one wave each
-    if ((long)rtk_divup(positions, 256) * nch * samples >= 192) {
+    static const int force_nw = getenv("RTK_PW_NW") ? atoi(getenv("RTK_PW_NW")) : 0;      // experiment knob (tools/exp_pw.py)
+    if (force_nw == 2) {
+        pw_conv_kernel<2><<<dim3(rtk_divup(positions, 128), nch, samples), 128, 0, (hipStream_t)stream>>>(Q);
+    } else if (force_nw != 1 && (force_nw == 4 || (long)rtk_divup(positions, 256) * nch * samples >= 192)) {
         pw_conv_kernel<4><<<dim3(rtk_divup(positions, 256), nch, samples), 256, 0, (hipStream_t)stream>>>(Q);
     } else {
         pw_conv_kernel<1><<<dim3(rtk_divup(positions, 64), nch, samples), 64, 0, (hipStream_t)stream>>>(Q);

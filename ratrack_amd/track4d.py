@@ -53,7 +53,11 @@ class Track4D(nn.Module):
          pc2_features (B,256,N), prop_features (B,128,N)).  models/track4d.py:67-106.
         n_valid (2,B) int32 (optional): a padded batch of clouds of different sizes (vod_gt.pad_frame_pairs; the reference
         itself only runs B = 1): every sample's valid columns equal its own unpadded B = 1 result."""
-        if self.use_fused and not self.training and not torch.is_grad_enabled():
+        # eval mode runs the fused inference engine -- also with autograd enabled (the reference's evaluation loop calls
+        # net.eval() but never enters torch.no_grad(), main_utils.py:44-127), as long as no INPUT asks for a gradient; the
+        # outputs then carry no graph.  Set use_fused = False to differentiate through an eval-mode forward.
+        wants_graph = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (pc1, pc2, feature1, feature2, h))
+        if self.use_fused and not self.training and not wants_graph and pc1.is_cuda:
             eng = self._fused_engine()
             if eng is not None:
                 N1, N2 = pc1.shape[2], pc2.shape[2]
@@ -133,6 +137,10 @@ class Track4D(nn.Module):
         if mode:
             self._fused = None      # folded BN constants go stale once training resumes
         return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self._fused = None          # .to(device) / .float() / .cuda(): the packed weight images belong to the old tensors
+        return super()._apply(fn, *a, **k)
 
     @property
     def max_id(self):

@@ -56,7 +56,10 @@ class Trainer:
             self.opt.zero_grad(set_to_none=True)        # last step's gradients may be views of the arena that is cleared now
             train_ops.arena_begin_step(self._dev)
         flow, h_out, cls, *_ = self.model.backbone(pc1, pc2, feature1, feature2, h)
-        total, items = L.backbone_loss(pc1 + flow, cls, gt_warp, gt_cls, pretrain=pretrain)
+        if self._dev.type == "cuda":
+            total, items = train_ops.backbone_loss(pc1, flow, cls, gt_warp, gt_cls, pretrain=pretrain)      # one kernel, values + gradients
+        else:
+            total, items = L.backbone_loss(pc1 + flow, cls, gt_warp, gt_cls, pretrain=pretrain)
         self.opt.zero_grad(set_to_none=True)
         total.backward()
         if self._dev.type == "cuda":

@@ -43,6 +43,7 @@ _PwP = ctypes.POINTER(_PwOperand)
 _lib.SIGNATURES.update({
     "rtk_pw_conv": [_i, _i, _i, _PwP, _i, _PwP, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p],
     "rtk_pw_wgrad": [_i, _i, _PwP, _i, _PwP, _p, _i, _p, _p],
+    "rtk_backbone_loss": [_i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p],
 })
 
 
@@ -744,3 +745,38 @@ def gru_step(x, h_in, gru):
         params += [getattr(gru, "weight_ih_l%d" % l), getattr(gru, "weight_hh_l%d" % l), getattr(gru, "bias_ih_l%d" % l),
                    getattr(gru, "bias_hh_l%d" % l)]
     return _GRUStep.apply(x, h_in, *params)
+
+
+# ---- multi-task loss -------------------------------------------------------------------------------------------------------------
+
+class _BackboneLoss(torch.autograd.Function):
+    """loss.backbone_loss (values and gradients) as one kernel: -> items (4) = [Loss, SceneFlowLoss, TrackingLoss, SegLoss]."""
+
+    @staticmethod
+    def forward(ctx, flow, cls, pc1, gt_warp, gt_cls, pretrain):
+        B, _, N = pc1.shape
+        dev = pc1.device
+        flow, cls, pc1, gt_warp = flow.contiguous(), cls.contiguous(), pc1.contiguous(), gt_warp.contiguous()
+        g = gt_cls.to(torch.uint8) if gt_cls.dtype != torch.bool else gt_cls.view(torch.uint8)
+        g = g.contiguous()
+        stride = 0 if g.dim() == 1 else N
+        items = _zeros((4,), torch.float32, dev)
+        dflow = None if pretrain else torch.empty(B, 3, N, dtype=torch.float32, device=dev)
+        dcls = torch.empty(B, N, dtype=torch.float32, device=dev)
+        _lib.call("rtk_backbone_loss", B, N, pc1.data_ptr(), flow.data_ptr(), gt_warp.data_ptr(), cls.data_ptr(), g.data_ptr(), stride,
+                  int(bool(pretrain)), items.data_ptr(), _ptr(dflow), dcls.data_ptr(), _stream())
+        ctx.save_for_backward(dflow, dcls)
+        return items
+
+    @staticmethod
+    def backward(ctx, ditems):
+        dflow, dcls = ctx.saved_tensors
+        g = ditems[0]                                    # the caller differentiates items[0] (= Loss)
+        return (None if dflow is None else dflow * g), dcls * g, None, None, None, None
+
+
+def backbone_loss(pc1, flow, cls, gt_warp, gt_cls, pretrain=False):
+    """(total, items dict) of loss.backbone_loss(pc1 + flow, cls, gt_warp, gt_cls, pretrain) with total = items['Loss'];
+    CUDA fp32 only."""
+    it = _BackboneLoss.apply(flow, cls, pc1, gt_warp, gt_cls, bool(pretrain))
+    return it[0], {"Loss": it[0], "SceneFlowLoss": it[1], "TrackingLoss": it[2], "SegLoss": it[3]}

@@ -464,3 +464,27 @@ def test_dbscan_kernel_matches_host_restatement(n, eps, ms, seed):
     far = pf.clone()
     far[0, 3] = torch.arange(n).float() * 100
     assert A.cluster_objects_device(far.to(DEV), torch.ones(1, n, device=DEV), eps=eps, min_samples=2) == []
+
+
+def test_eval_mode_uses_fused_engine_with_autograd_enabled():
+    """The reference's evaluation loop calls net.eval() but never torch.no_grad() (main_utils.py:44-127): the fused engine must
+    serve that call too (outputs without a graph), and must be rebuilt after .to() / weight moves."""
+    from _util import reference_state_dict
+    from ratrack_amd.track4d import Args, Track4D
+    net = Track4D(Args()).to(DEV).eval()
+    net.load_state_dict(reference_state_dict(DEV), strict=True)
+    d = synth.make_frame_pairs(2, 256, 3)
+    t = [torch.from_numpy(d[k]).to(DEV) for k in ("pc1", "pc2", "feature1", "feature2")]
+    with torch.no_grad():
+        ref = net.backbone(*t, None)
+    eng = net._fused
+    assert eng
+    out = net.backbone(*t, None)                       # grad mode ON
+    assert net._fused is eng and all(o.grad_fn is None and not o.requires_grad for o in out)
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+    net.float()                                        # Module._apply
+    assert net._fused is None
+    x = t[0].clone().requires_grad_(True)              # an input that wants a gradient: the differentiable module path
+    flow = net.backbone(x, *t[1:], None)[0]
+    assert flow.grad_fn is not None

@@ -552,3 +552,33 @@ def test_first_layer_backward_gather_form(S, C, rows, ns, n_src):
     assert float((outs[0][0].double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
     ref_w = torch.einsum("scp,sap->ca", dz.view(S, C, P).double(), dxyz.view(S, 3, P).double())
     assert float((outs[0][1].double() - ref_w).abs().max()) <= 2e-5 * float(ref_w.abs().max()) + 1e-4
+
+
+@pytest.mark.parametrize("B,N,pretrain,vec", [(4, 256, False, False), (3, 242, True, False), (1, 256, False, True), (64, 256, False, False)])
+def test_fused_backbone_loss_matches_framework_formulation(B, N, pretrain, vec):
+    """rtk_backbone_loss (values + gradients, one launch) against ratrack_amd.loss.backbone_loss under autograd -- itself pinned
+    to the reference's losses in tests/test_loss_metrics_cpu.py -- incl. a sample without positives (its segmentation term and
+    gradient are zero) and the pre-training configuration (no gradient reaches the flow)."""
+    from ratrack_amd import loss as L
+    from ratrack_amd.train_ops import backbone_loss
+    g = torch.Generator(DEV).manual_seed(B + N)
+    pc1 = torch.randn(B, 3, N, device=DEV, generator=g) * 10
+    gt = pc1 + torch.randn(B, 3, N, device=DEV, generator=g) * 0.3
+    gt_cls = torch.rand(N if vec else B * N, device=DEV, generator=g).view((N,) if vec else (B, N)) > 0.7
+    if not vec and B > 1:
+        gt_cls[1] = False                                   # no positives in sample 1
+    res = []
+    for ours in (True, False):
+        flow = (torch.randn(B, 3, N, device=DEV, generator=torch.Generator(DEV).manual_seed(1)) * 0.2).requires_grad_(True)
+        cls = torch.rand(B, N, device=DEV, generator=torch.Generator(DEV).manual_seed(2)).clamp(1e-4, 1 - 1e-4).requires_grad_(True)
+        total, items = backbone_loss(pc1, flow, cls, gt, gt_cls, pretrain) if ours else L.backbone_loss(pc1 + flow, cls, gt, gt_cls, pretrain)
+        total.backward()
+        res.append(([float(items[k]) for k in ("Loss", "SceneFlowLoss", "TrackingLoss", "SegLoss")], flow.grad, cls.grad))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-5, atol=1e-7)
+    if pretrain:
+        assert res[0][1] is None and (res[1][1] is None or float(res[1][1].abs().max()) == 0)
+    else:
+        assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-5 * float(res[1][1].abs().max())
+    assert float((res[0][2] - res[1][2]).abs().max()) <= 2e-5 * float(res[1][2].abs().max())
+    if not vec and B > 1:
+        assert float(res[0][2][1].abs().max()) == 0
