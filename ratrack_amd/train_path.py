@@ -111,6 +111,7 @@ def supported(head):
 def _sa_scale(mlp, tg, lvl, s, feats, groups):
     """One MSG scale: (project -> gather) + offset conv -> [BN+ReLU -> conv]* -> BN+ReLU+max.  feats: list of (S_,C_i,n_src)
     tensors whose channel concatenation is the level's feature tensor (never materialised)."""
+    feats = list(feats) if isinstance(feats, (list, tuple)) else [feats]
     layers = list(mlp.children())
     w = layers[0].conv.weight                                     # (C1, 3+C, 1, 1): [d_xyz | features]
     idx = tg.ball[lvl][s]
@@ -125,7 +126,8 @@ def _sa_scale(mlp, tg, lvl, s, feats, groups):
     proj = pw_linear(feats, w, cols=cols)
     wx = w[:, :3]
     if FUSED_SA_CHAIN and sa_chain_supported(layers) and ns >= 4:
-        return sa_chain(proj, wx, idx, tg.dxyz[lvl][s], layers, tg.row_w[lvl], count, groups, inv=tg.inv[lvl][s])
+        return sa_chain(proj, wx, idx, tg.dxyz[lvl][s], layers, tg.row_w[lvl], count, groups,
+                        inv=tg.inv[lvl][s] if getattr(tg, "inv", None) is not None else None)
     z = conv1x1(tg.dxyz[lvl][s], wx) + PU.grouping_operation(proj, idx)
     x = None
     for i, layer in enumerate(layers):

@@ -470,6 +470,7 @@ def test_eval_mode_uses_fused_engine_with_autograd_enabled():
     """The reference's evaluation loop calls net.eval() but never torch.no_grad() (main_utils.py:44-127): the fused engine must
     serve that call too (outputs without a graph), and must be rebuilt after .to() / weight moves."""
     from _util import reference_state_dict
+    from ratrack_amd import synth
     from ratrack_amd.track4d import Args, Track4D
     net = Track4D(Args()).to(DEV).eval()
     net.load_state_dict(reference_state_dict(DEV), strict=True)

