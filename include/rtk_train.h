@@ -71,11 +71,14 @@ RTK_EXPORT int rtk_sa_first_layer(int samples, int channels, int rows, int ns, i
 /* Backward of rtk_sa_first_layer.  rtk_group_inverse_index sorts the positions p = (row, k) of every sample by the source point
  * idx[s][p] they gather (once per geometry table and step): off (samples, n_src + 1) int32, inv (samples, positions) uint16 with
  * the positions referencing point q at inv[s][off[s][q] .. off[s][q+1]), ascending.  rtk_sa_first_layer_bwd reads dz
- * (samples, C, rows, ns) once: dproj (samples, C, n_src) = gather-sum of dz over each point's positions (fully written); dwx (C, 3), ZERO-INITIALISED by the caller, += sum dz . dxyz (dxyz (samples, 3, rows, ns)).  ns % 4 == 0. */
+ * (samples, C, rows, ns) once: dproj (samples, C, n_src) = gather-sum of dz over each point's positions (fully written);
+ * dwx (C rows of dwx_pitch >= 3 floats, e.g. the first three columns of the layer's full weight gradient), ZERO-INITIALISED by
+ * the caller, += sum dz . dxyz (dxyz (samples, 3, rows, ns)).  ns % 4 == 0. */
 RTK_EXPORT int rtk_group_inverse_index(int samples, int n_src, int positions, const int *idx, int *off, unsigned short *inv,
                                        rtk_stream_t stream);
 RTK_EXPORT int rtk_sa_first_layer_bwd(int samples, int channels, int rows, int ns, int n_src, const float *dz, const float *dxyz,
-                                      const int *off, const unsigned short *inv, float *dproj, float *dwx, rtk_stream_t stream);
+                                      const int *off, const unsigned short *inv, float *dproj, float *dwx, int dwx_pitch,
+                                      rtk_stream_t stream);
 
 /* ---- 1x1 convolution fused with the BatchNorm work around it (set-abstraction SharedMLP layers 2, 3) ----------------
  * Tensors are NCHW planes (samples, C, rows*ns), ns a power of two >= 4, channel counts 16, 32 or 64.

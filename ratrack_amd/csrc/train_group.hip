@@ -70,7 +70,7 @@ constexpr int FB_MAXQ = 8;      // float4 per thread and plane: planes up to 819
 __global__ __launch_bounds__(256) void sa_first_layer_bwd_kernel(int channels, int n_src, int P, const float *__restrict__ dz,
                                                                  const float *__restrict__ dxyz, const int *__restrict__ off,
                                                                  const unsigned short *__restrict__ inv, float *__restrict__ dproj,
-                                                                 float *__restrict__ dwx) {
+                                                                 float *__restrict__ dwx, int dwx_pitch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem[];
     float *s_plane = reinterpret_cast<float *>(fb_smem);                                  // [P]
     int *s_off = reinterpret_cast<int *>(s_plane + ((P + 3) & ~3));                       // [n_src + 1]
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void sa_first_layer_bwd_kernel(int channels, i
         for (int o = 32; o > 0; o >>= 1) { ax += __shfl_xor(ax, o, 64); ay += __shfl_xor(ay, o, 64); az += __shfl_xor(az, o, 64); }
         if (lane == 0) { s_red[wave][0] = ax; s_red[wave][1] = ay; s_red[wave][2] = az; }
         __syncthreads();                           // plane staged, partials visible
-        if (t < 3) atomicAdd(dwx + c * 3 + t, (s_red[0][t] + s_red[1][t]) + (s_red[2][t] + s_red[3][t]));
+        if (t < 3) atomicAdd(dwx + (size_t)c * dwx_pitch + t, (s_red[0][t] + s_red[1][t]) + (s_red[2][t] + s_red[3][t]));
         // balanced segmented sum: thread t owns the sorted positions [t E, (t+1) E); runs of one source point inside the chunk
         // are summed in registers, only the (few) run ends go to the LDS accumulator
         for (int q = t; q < n_src; q += 256) s_out[q] = 0.f;
@@ -178,9 +178,10 @@ extern "C" int rtk_group_inverse_index(int samples, int n_src, int positions, co
 }
 
 extern "C" int rtk_sa_first_layer_bwd(int samples, int channels, int rows, int ns, int n_src, const float *dz, const float *dxyz,
-                                      const int *off, const unsigned short *inv, float *dproj, float *dwx, rtk_stream_t stream) {
+                                      const int *off, const unsigned short *inv, float *dproj, float *dwx, int dwx_pitch,
+                                      rtk_stream_t stream) {
     RTK_REQUIRE(samples > 0 && channels > 0 && rows > 0 && ns >= 4 && (ns & 3) == 0 && n_src > 0 && dz && dxyz && off && inv && dproj &&
-                dwx, "sa_first_layer_bwd: bad arguments");
+                dwx && dwx_pitch >= 3, "sa_first_layer_bwd: bad arguments");
     const int P = rows * ns;
     const size_t lds = (size_t)((P + 3) & ~3) * sizeof(float) + (size_t)(2 * n_src + 1) * sizeof(int) + (size_t)(P + 256) * sizeof(unsigned short);
     RTK_REQUIRE(P <= 65536 && lds <= 150 * 1024 && samples <= 65535, "sa_first_layer_bwd: %d positions exceed the LDS budget", P);
@@ -190,7 +191,7 @@ extern "C" int rtk_sa_first_layer_bwd(int samples, int channels, int rows, int n
         attr_set = true;
     }
     const dim3 grid((channels + FB_CG - 1) / FB_CG, samples);
-    sa_first_layer_bwd_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(channels, n_src, P, dz, dxyz, off, inv, dproj, dwx);
+    sa_first_layer_bwd_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(channels, n_src, P, dz, dxyz, off, inv, dproj, dwx, dwx_pitch);
     RTK_CHECK_LAUNCH("sa_first_layer_bwd");
     return RTK_OK;
 }

@@ -17,7 +17,7 @@ _lib.SIGNATURES.update({
     "rtk_scatter_add_rows": [_i] * 4 + [_p] * 3 + [_p],
     "rtk_sa_first_layer": [_i] * 6 + [_p] * 7 + [_p],
     "rtk_group_inverse_index": [_i] * 3 + [_p] * 3 + [_p],
-    "rtk_sa_first_layer_bwd": [_i] * 5 + [_p] * 6 + [_p],
+    "rtk_sa_first_layer_bwd": [_i] * 5 + [_p] * 6 + [_i, _p],
     "rtk_conv_bn_fwd": [_i] * 6 + [_p] * 7 + [_p],
     "rtk_conv_wgrad": [_i] * 6 + [_p] * 4 + [_p],
     "rtk_conv_bn_bwd": [_i] * 6 + [_p] * 6 + [_d, _i, _p, _p, _p],
@@ -195,13 +195,17 @@ def _pw_forward(srcs, cols, W, bias, out, row_w=None, groups=1, sums=None):
               _ptr(bias), 0, _ptr(row_w), groups, _ptr(sums), out.shape[1], _stream())
 
 
-def _pw_backward(ctx_needs, srcs, cols, W, dz, want_bias):
-    """-> (dW (full shape of W, zero outside the used columns), dbias or None, [dsrc_i or None])."""
+def _pw_backward(ctx_needs, srcs, cols, W, dz, want_bias, dW=None):
+    """-> (dW (full shape of W, zero outside the used columns; accumulated into the given zero-initialised dW if any), dbias or
+    None, [dsrc_i or None])."""
     S_, Co, P = dz.shape
     dz = _pw_tensor(dz)
-    buf = _zeros((W.shape[0] * W.shape[1] + (Co if want_bias else 0),), torch.float32, dz.device)      # dW | dbias
-    dW = buf[:W.shape[0] * W.shape[1]].view(W.shape[0], W.shape[1])
-    dbias = buf[W.shape[0] * W.shape[1]:] if want_bias else None
+    if dW is None:
+        buf = _zeros((W.shape[0] * W.shape[1] + (Co if want_bias else 0),), torch.float32, dz.device)      # dW | dbias
+        dW = buf[:W.shape[0] * W.shape[1]].view(W.shape[0], W.shape[1])
+        dbias = buf[W.shape[0] * W.shape[1]:] if want_bias else None
+    else:
+        dbias = _zeros((Co,), torch.float32, dz.device) if want_bias else None
     _lib.call("rtk_pw_wgrad", S_, P, _pw_operands([dz], [0]), len(srcs), _pw_operands(srcs, cols), dW.data_ptr(), dW.stride(0), _ptr(dbias),
               _stream())
     dsrcs = [None] * len(srcs)
@@ -342,13 +346,24 @@ class _SAChain(torch.autograd.Function):
     for the weight gradient; the normalised activations are stored once for that GEMM, nothing else is materialised."""
 
     @staticmethod
-    def forward(ctx, proj, wx, idx, dxyz, row_w, count, groups, bns, inv, *tensors):
-        proj = proj.contiguous()                                          # (S, C1, n_src)
-        S_, C1, n_src = proj.shape
+    def forward(ctx, w0, idx, dxyz, row_w, count, groups, bns, inv, nfeat, *tensors):
+        # tensors = feats_0 .. feats_{nfeat-1}, g0, b0, W1, g1, b1, W2, g2, b2.  w0 (C1, 3 + C[,1,1]) = [offset columns | feature columns]
+        feats = [_pw_tensor(t) for t in tensors[:nfeat]]
+        tensors = tensors[nfeat:]
+        S_, _, n_src = feats[0].shape
+        W0 = w0.detach().reshape(w0.shape[0], -1)
+        C1 = W0.shape[0]
+        cols, c = [], 3
+        for f in feats:
+            cols.append(c)
+            c += f.shape[1]
+        dev = feats[0].device
+        proj = torch.empty(S_, C1, n_src, dtype=torch.float32, device=dev)      # per-POINT projection by the feature columns
+        _pw_forward(feats, cols, W0, None, proj)
+        wx = W0[:, :3]
         _, rows, ns = idx.shape
-        dev = proj.device
         L = len(bns)
-        weights = [None] + [tensors[3 * i - 1] for i in range(1, L)]        # tensors = g0, b0, W1, g1, b1, W2, g2, b2
+        weights = [None] + [tensors[3 * i - 1] for i in range(1, L)]
         f64 = _SumsPool(groups, [C1] + [w.shape[0] for w in weights[1:]], dev)
         sums = f64(C1)
         z1 = torch.empty(S_, C1, rows, ns, dtype=torch.float32, device=dev)
@@ -369,19 +384,22 @@ class _SAChain(torch.autograd.Function):
         C = zs[-1].shape[1]
         out = torch.empty(S_, C, rows, dtype=torch.float32, device=dev)
         _lib.call("rtk_bn_relu_fwd", S_, C, rows, ns, groups, zs[-1].data_ptr(), pars[-1].data_ptr(), 1, out.data_ptr(), _stream())
-        ctx.save_for_backward(row_w, idx, dxyz, *zs, *pars, *[w for w in weights[1:]])
-        ctx.cfg = (count, groups, L, n_src)
+        ctx.save_for_backward(row_w, idx, dxyz, *zs, *pars, *[w for w in weights[1:]], w0, *feats)
+        ctx.cfg = (count, groups, L, n_src, nfeat, cols)
         ctx.inv = inv
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        count, groups, L, n_src = ctx.cfg
+        count, groups, L, n_src, nfeat, cols = ctx.cfg
         saved = list(ctx.saved_tensors)
+        feats, w0 = saved[len(saved) - nfeat:], saved[len(saved) - nfeat - 1]
+        saved = saved[:len(saved) - nfeat - 1]
         row_w, idx, dxyz = saved[0:3]
         saved = saved[2:]
         zs = saved[1:1 + L]
         pars, weights = saved[1 + L:1 + 2 * L], [None] + saved[1 + 2 * L:]
+        W0 = w0.detach().reshape(w0.shape[0], -1)
         S_, _, rows, ns = zs[0].shape
         dev = dout.device
         dout = dout.contiguous()
@@ -397,8 +415,8 @@ class _SAChain(torch.autograd.Function):
                   sums2.data_ptr(), float(count), 1, dz.data_ptr(), dgb.data_ptr(), _stream())
         grads = {L - 1: (None, dgb[0], dgb[1])}
         C1_ = zs[0].shape[1]
-        dwbuf = _zeros((sum(w.numel() for w in weights[1:]) + 3 * C1_,), torch.float32, dev)      # all dW of the chain | dWx
-        dwx = dwbuf[dwbuf.numel() - 3 * C1_:]
+        dwbuf = _zeros((sum(w.numel() for w in weights[1:]) + W0.numel(),), torch.float32, dev)      # all dW of the chain | dW0
+        dW0 = dwbuf[dwbuf.numel() - W0.numel():].view(W0.shape[0], W0.shape[1])
         dwoff = 0
         for i in range(L - 1, 0, -1):
             W = weights[i]
@@ -421,18 +439,19 @@ class _SAChain(torch.autograd.Function):
         flat = [grads[0][1], grads[0][2]]
         for i in range(1, L):
             flat += [grads[i][0], grads[i][1], grads[i][2]]
-        # first layer: z1 = proj[idx] + Wx.dxyz  ->  dproj = gather-sum of dz over each source point's positions, dWx = sum dz dxyz^T
+        # first layer: z1 = (Wf feats)[idx] + Wx.dxyz  ->  dproj = gather-sum of dz over each source point's positions, the offset
+        # columns of dW0 = sum dz dxyz^T (same kernel), then the projection's own backward: feature columns of dW0, dfeats
         C1 = dz.shape[1]
         dproj = torch.empty(S_, C1, n_src, dtype=torch.float32, device=dev)
         if ctx.inv is not None:
             off, inv = ctx.inv
             _lib.call("rtk_sa_first_layer_bwd", S_, C1, rows, ns, n_src, dz.data_ptr(), dxyz.data_ptr(), off.data_ptr(), inv.data_ptr(),
-                      dproj.data_ptr(), dwx.data_ptr(), _stream())
-            dwx = dwx.view(C1, 3, 1, 1)
+                      dproj.data_ptr(), dW0.data_ptr(), dW0.stride(0), _stream())
         else:
             _lib.call("rtk_group_points_grad_set", S_, C1, n_src, rows, ns, dz.data_ptr(), idx.data_ptr(), dproj.data_ptr(), _stream())
-            dwx = torch.bmm(dz.view(S_, C1, -1), dxyz.view(S_, 3, -1).transpose(1, 2)).sum(0).view(C1, 3, 1, 1)
-        return (dproj, dwx, None, None, None, None, None, None, None) + tuple(flat)
+            dW0[:, :3] = torch.bmm(dz.view(S_, C1, -1), dxyz.view(S_, 3, -1).transpose(1, 2)).sum(0)
+        _, _, dfeats = _pw_backward(ctx.needs_input_grad[9:9 + nfeat], feats, cols, W0, dproj, False, dW=dW0)
+        return (dW0.view_as(w0), None, None, None, None, None, None, None, None) + tuple(dfeats) + tuple(flat)
 
 
 def sa_chain_supported(layers):
@@ -440,9 +459,11 @@ def sa_chain_supported(layers):
     return len(layers) >= 2 and all(c in (16, 32, 64) for c in chans) and all(l.conv.bias is None for l in layers)
 
 
-def sa_chain(proj, wx, idx, dxyz, layers, row_w, count, groups, inv=None):
-    """proj (S,C1,n_src): per-point projection of the features by the first layer's feature columns; wx (C1,3,1,1): its
-    offset columns; idx (S,rows,ns) int32 ball-query indices; dxyz (S,3,rows,ns) neighbour offsets; layers: the SharedMLP's
+def sa_chain(feats, w0, idx, dxyz, layers, row_w, count, groups, inv=None):
+    """feats: list of (S,C_i,n_src) tensors whose (virtual) channel concatenation is the level's feature tensor; w0 (C1, 3 + C, 1, 1):
+    the first layer's weight [offset columns | feature columns] -- the features are projected per POINT by the feature columns (a
+    1x1 conv and a gather commute), gathered by idx and the 3-channel offset term added per (centroid, neighbour) pair;
+    idx (S,rows,ns) int32 ball-query indices; dxyz (S,3,rows,ns) neighbour offsets; layers: the SharedMLP's
     Conv2d blocks (conv, bn.bn); inv: optional (off, inv) inverse table of idx (rtk_group_inverse_index) for the gather-form
     backward of the first layer.  Returns the max-pooled (S,C_last,rows) output.  Updates every BatchNorm's running statistics."""
     tensors = []
@@ -450,7 +471,8 @@ def sa_chain(proj, wx, idx, dxyz, layers, row_w, count, groups, inv=None):
         if i > 0:
             tensors.append(l.conv.weight)
         tensors += [l.bn.bn.weight, l.bn.bn.bias]
-    return _SAChain.apply(proj, wx, idx, dxyz, row_w, float(count), int(groups), tuple(l.bn.bn for l in layers), inv, *tensors)
+    feats = list(feats)
+    return _SAChain.apply(w0, idx, dxyz, row_w, float(count), int(groups), tuple(l.bn.bn for l in layers), inv, len(feats), *feats, *tensors)
 
 
 # ---- cost volume -------------------------------------------------------------------------------------------------------

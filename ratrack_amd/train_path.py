@@ -117,17 +117,16 @@ def _sa_scale(mlp, tg, lvl, s, feats, groups):
     idx = tg.ball[lvl][s]
     ns = idx.shape[2]
     count = (tg.samples // groups) * tg.npoint * ns
-    # per-POINT projection of the features by the layer's feature columns (a 1x1 conv and a gather commute); the weight
-    # gradient comes back full-size with zeros in the three offset columns, which belong to wx below
+    if FUSED_SA_CHAIN and sa_chain_supported(layers) and ns >= 4:
+        return sa_chain(feats, w, idx, tg.dxyz[lvl][s], layers, tg.row_w[lvl], count, groups,
+                        inv=tg.inv[lvl][s] if getattr(tg, "inv", None) is not None else None)
+    # reference structure (kept for tests): per-POINT projection by the layer's feature columns (a 1x1 conv and a gather commute)
     cols, c = [], 3
     for f in feats:
         cols.append(c)
         c += f.shape[1]
     proj = pw_linear(feats, w, cols=cols)
     wx = w[:, :3]
-    if FUSED_SA_CHAIN and sa_chain_supported(layers) and ns >= 4:
-        return sa_chain(proj, wx, idx, tg.dxyz[lvl][s], layers, tg.row_w[lvl], count, groups,
-                        inv=tg.inv[lvl][s] if getattr(tg, "inv", None) is not None else None)
     z = conv1x1(tg.dxyz[lvl][s], wx) + PU.grouping_operation(proj, idx)
     x = None
     for i, layer in enumerate(layers):

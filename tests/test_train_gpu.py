@@ -553,7 +553,7 @@ def test_first_layer_backward_gather_form(S, C, rows, ns, n_src):
         dproj = torch.empty(S, C, n_src, device=DEV)
         dwx = torch.zeros(C, 3, device=DEV)
         _lib.call("rtk_sa_first_layer_bwd", S, C, rows, ns, n_src, dz.data_ptr(), dxyz.data_ptr(), off.data_ptr(), inv.data_ptr(),
-                  dproj.data_ptr(), dwx.data_ptr(), st)
+                  dproj.data_ptr(), dwx.data_ptr(), 3, st)
         outs.append((dproj, dwx))
     ref = torch.zeros(S, C, n_src, dtype=torch.float64, device=DEV).scatter_add_(2, idx.view(S, 1, P).long().expand(-1, C, -1), dz.view(S, C, P).double())
     assert float((outs[0][0].double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
