@@ -62,11 +62,24 @@ RTK_EXPORT int rtk_bn_relu_bwd_apply(int samples, int channels, int rows, int ns
 /* First layer of a set-abstraction SharedMLP from the per-point projection (conv([d_xyz || feats[idx]]) =
  * Wx.d_xyz + (Wf.feats)[idx]):  z[b][c][row][k] = proj[b][c][idx[b][row][k]] + wx[c] . dxyz[b][:, row, k], and the weighted
  * batch sums of z accumulated into sums (groups, C, 2) float64 (zero-initialised; as rtk_bn_train_stats).
- * proj (samples, C, n_src), idx (samples, rows, ns) int32 in [0, n_src), dxyz (samples, 3, rows, ns), wx (C, 3) row-major,
- * z (samples, C, rows, ns); ns a power of two >= 4. */
+ * proj (samples, C, n_src), idx (samples, rows, ns) int32 in [0, n_src), dxyz (samples, 3, rows, ns), wx: C rows of wx_pitch >= 3
+ * floats (the first three columns of the layer's weight), z (samples, C, rows, ns); ns a power of two >= 4. */
 RTK_EXPORT int rtk_sa_first_layer(int samples, int channels, int rows, int ns, int groups, int n_src, const float *proj, const int *idx,
-                                  const float *dxyz, const float *wx, const float *row_weight, float *z, double *sums,
+                                  const float *dxyz, const float *wx, int wx_pitch, const float *row_weight, float *z, double *sums,
                                   rtk_stream_t stream);
+
+/* Kernel images of live (trained) weights, all of an operator's matrices in ONE launch (the training path re-packs every step).
+ * kind 0: fragment-major MFMA A-operand image of a (rows, cols) matrix, packed[u][v][16g+i][r] = W[16v+i][16u+4g+r], zero padded to
+ *         multiples of 16 (fused.pack_layer); transpose != 0 packs W^T (element (o,k) = src[k*pitch + o]);
+ * kind 1: offset-layer image of [W(:, 0:3) | b]: img[v][16g+i] = (g < 3 ? W[16v+i][g] : b[16v+i]) (b = src2, may be NULL = 0);
+ * kind 2: vector copied and zero padded to a multiple of 16 (biases). */
+typedef struct {
+    const float *src;
+    const float *src2;
+    float *dst;
+    int rows, cols, pitch, transpose, kind;
+} rtk_pack_job_t;
+RTK_EXPORT int rtk_pack_weights(int njobs, const rtk_pack_job_t *jobs, rtk_stream_t stream);
 
 /* Backward of rtk_sa_first_layer.  rtk_group_inverse_index sorts the positions p = (row, k) of every sample by the source point
  * idx[s][p] they gather (once per geometry table and step): off (samples, n_src + 1) int32, inv (samples, positions) uint16 with

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(BN_T) void bn_stats_kernel(int samples, int channel
 template <int CPB>      // channels per workgroup: idx and d_xyz are read once per CPB output planes
 __global__ __launch_bounds__(BN_T) void sa_first_layer_kernel(int samples, int channels, int rows, int lg_ns, int groups, int n_src,
                                                               const float *__restrict__ proj, const int *__restrict__ idx,
-                                                              const float *__restrict__ dxyz, const float *__restrict__ wx,
+                                                              const float *__restrict__ dxyz, const float *__restrict__ wx, int wx_pitch,
                                                               const float *__restrict__ rw, float *__restrict__ z,
                                                               double *__restrict__ sums) {
     extern __shared__ float s_proj[];                              // [CPB][n_src]
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(BN_T) void sa_first_layer_kernel(int samples, int c
     __syncthreads();
     float w0[CPB], w1[CPB], w2[CPB];
 #pragma unroll
-    for (int q = 0; q < CPB; ++q) { w0[q] = wx[(c0 + q) * 3 + 0]; w1[q] = wx[(c0 + q) * 3 + 1]; w2[q] = wx[(c0 + q) * 3 + 2]; }
+    for (int q = 0; q < CPB; ++q) { const float *w = wx + (size_t)(c0 + q) * wx_pitch; w0[q] = w[0]; w1[q] = w[1]; w2[q] = w[2]; }
     const int *ib = idx + (size_t)b * E;
     const float *dx = dxyz + (size_t)b * 3 * E, *dy = dx + E, *dz = dy + E;
     const float *w = rw ? rw + (size_t)b * rows : nullptr;
@@ -497,18 +497,18 @@ extern "C" int rtk_bn_relu_bwd_apply(int samples, int channels, int rows, int ns
 }
 
 extern "C" int rtk_sa_first_layer(int samples, int channels, int rows, int ns, int groups, int n_src, const float *proj, const int *idx,
-                                  const float *dxyz, const float *wx, const float *row_weight, float *z, double *sums,
+                                  const float *dxyz, const float *wx, int wx_pitch, const float *row_weight, float *z, double *sums,
                                   rtk_stream_t stream) {
     RTK_BN_COMMON_CHECKS("rtk_sa_first_layer");
     RTK_REQUIRE(ns >= 4 && n_src > 0 && n_src <= 16384, "rtk_sa_first_layer: ns (%d) must be >= 4, n_src (%d) <= 16384", ns, n_src);
-    RTK_REQUIRE(proj && idx && dxyz && wx && z && sums, "rtk_sa_first_layer: null argument");
+    RTK_REQUIRE(proj && idx && dxyz && wx && wx_pitch >= 3 && z && sums, "rtk_sa_first_layer: null argument");
     hipStream_t s = (hipStream_t)stream;
     if (channels % 4 == 0 && (size_t)n_src * 16 <= 64 * 1024)
         sa_first_layer_kernel<4><<<dim3(channels / 4, samples), BN_T, (size_t)n_src * 16, s>>>(samples, channels, rows, ilog2_exact(ns), groups,
-                                                                                            n_src, proj, idx, dxyz, wx, row_weight, z, sums);
+                                                                                            n_src, proj, idx, dxyz, wx, wx_pitch, row_weight, z, sums);
     else
         sa_first_layer_kernel<1><<<dim3(channels, samples), BN_T, (size_t)n_src * 4, s>>>(samples, channels, rows, ilog2_exact(ns), groups, n_src,
-                                                                                       proj, idx, dxyz, wx, row_weight, z, sums);
+                                                                                       proj, idx, dxyz, wx, wx_pitch, row_weight, z, sums);
     RTK_CHECK_LAUNCH("rtk_sa_first_layer");
     return RTK_OK;
 }

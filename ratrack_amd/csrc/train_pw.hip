@@ -361,6 +361,36 @@ __global__ __launch_bounds__(PW_T, 2) void pw_wgrad_kernel(const PwWgParams Q) {
     }
 }
 
+// ---- weight images (rtk_pack_weights) ---------------------------------------------------------------------------------------
+constexpr int PK_MAX = 16;
+struct PkJobs { int n; rtk_pack_job_t j[PK_MAX]; int first_block[PK_MAX + 1]; };
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PkJobs Q) {
+    int ji = 0;
+    while (ji + 1 < Q.n && (int)blockIdx.x >= Q.first_block[ji + 1]) ++ji;
+    const rtk_pack_job_t &J = Q.j[ji];
+    const int e = ((int)blockIdx.x - Q.first_block[ji]) * 256 + threadIdx.x;
+    auto at = [&](int o, int k) -> float {
+        if (o >= J.rows || k >= J.cols) return 0.f;
+        return J.transpose ? J.src[(size_t)k * J.pitch + o] : J.src[(size_t)o * J.pitch + k];
+    };
+    if (J.kind == 0) {
+        const int V = (J.rows + 15) >> 4, U = (J.cols + 15) >> 4;
+        if (e >= U * V * 256) return;
+        const int r = e & 3, i = (e >> 2) & 15, g = (e >> 6) & 3, uv = e >> 8, v = uv % V, u = uv / V;
+        J.dst[e] = at(16 * v + i, 16 * u + 4 * g + r);
+    } else if (J.kind == 1) {
+        const int V = (J.rows + 15) >> 4;
+        if (e >= V * 64) return;
+        const int i = e & 15, g = (e >> 4) & 3, v = e >> 6, o = 16 * v + i;
+        J.dst[e] = g < 3 ? at(o, g) : ((J.src2 && o < J.rows) ? J.src2[o] : 0.f);
+    } else {
+        const int n16 = (J.rows + 15) & ~15;
+        if (e >= n16) return;
+        J.dst[e] = e < J.rows ? J.src[e] : 0.f;
+    }
+}
+
 int fill_op(PwOp &d, const rtk_pw_operand_t &s, const char *who) {
     if (!(s.layout == 2 || s.ptr) || s.channels <= 0 || s.layout < 0 || s.layout > 2) {
         rtk_set_error("%s: bad operand (channels %d, layout %d)", who, s.channels, s.layout);
@@ -443,5 +473,25 @@ extern "C" int rtk_pw_wgrad(int samples, int positions, const rtk_pw_operand_t *
     const dim3 grid(nch, ochunks, (unsigned)((ntiles + Q.tiles_per_wg - 1) / Q.tiles_per_wg));
     pw_wgrad_kernel<<<grid, PW_T, 0, (hipStream_t)stream>>>(Q);
     RTK_CHECK_LAUNCH("pw_wgrad");
+    return RTK_OK;
+}
+
+extern "C" int rtk_pack_weights(int njobs, const rtk_pack_job_t *jobs, rtk_stream_t stream) {
+    RTK_REQUIRE(njobs >= 1 && njobs <= PK_MAX && jobs, "pack_weights: 1..%d jobs", PK_MAX);
+    PkJobs Q = {};
+    Q.n = njobs;
+    int blocks = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const rtk_pack_job_t &J = jobs[i];
+        RTK_REQUIRE(J.src && J.dst && J.rows > 0 && (J.kind == 2 || J.cols > 0) && J.kind >= 0 && J.kind <= 2, "pack_weights: bad job %d", i);
+        Q.j[i] = J;
+        Q.first_block[i] = blocks;
+        const long elems = J.kind == 0 ? (long)((J.rows + 15) / 16) * ((J.cols + 15) / 16) * 256 : J.kind == 1 ? (long)((J.rows + 15) / 16) * 64
+                                                                                                          : (long)((J.rows + 15) & ~15);
+        blocks += (int)((elems + 255) / 256);
+    }
+    Q.first_block[njobs] = blocks;
+    pack_weights_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(Q);
+    RTK_CHECK_LAUNCH("pack_weights");
     return RTK_OK;
 }

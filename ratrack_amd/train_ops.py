@@ -15,7 +15,7 @@ _LayerP = ctypes.POINTER(fused._Layer)
 _lib.SIGNATURES.update({
     "rtk_cost_volume_bwd": [_i] * 3 + [_p] * 6 + [_LayerP, _LayerP, _p, _p, _i, _i] + [_p] * 10 + [_p],
     "rtk_scatter_add_rows": [_i] * 4 + [_p] * 3 + [_p],
-    "rtk_sa_first_layer": [_i] * 6 + [_p] * 7 + [_p],
+    "rtk_sa_first_layer": [_i] * 6 + [_p] * 4 + [_i] + [_p] * 3 + [_p],
     "rtk_group_inverse_index": [_i] * 3 + [_p] * 3 + [_p],
     "rtk_sa_first_layer_bwd": [_i] * 5 + [_p] * 6 + [_i, _p],
     "rtk_conv_bn_fwd": [_i] * 6 + [_p] * 7 + [_p],
@@ -44,6 +44,7 @@ _lib.SIGNATURES.update({
     "rtk_pw_conv": [_i, _i, _i, _PwP, _i, _PwP, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p],
     "rtk_pw_wgrad": [_i, _i, _PwP, _i, _PwP, _p, _i, _p, _p],
     "rtk_backbone_loss": [_i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p],
+    "rtk_pack_weights": [_i, _p, _p],
 })
 
 
@@ -367,9 +368,8 @@ class _SAChain(torch.autograd.Function):
         f64 = _SumsPool(groups, [C1] + [w.shape[0] for w in weights[1:]], dev)
         sums = f64(C1)
         z1 = torch.empty(S_, C1, rows, ns, dtype=torch.float32, device=dev)
-        wxc = wx.detach().reshape(C1, 3).contiguous()
-        _lib.call("rtk_sa_first_layer", S_, C1, rows, ns, groups, n_src, proj.data_ptr(), idx.data_ptr(), dxyz.data_ptr(), wxc.data_ptr(),
-                  _ptr(row_w), z1.data_ptr(), sums.data_ptr(), _stream())
+        _lib.call("rtk_sa_first_layer", S_, C1, rows, ns, groups, n_src, proj.data_ptr(), idx.data_ptr(), dxyz.data_ptr(), W0.data_ptr(),
+                  W0.stride(0), _ptr(row_w), z1.data_ptr(), sums.data_ptr(), _stream())      # the offset columns = the first three of W0
         zs, ys, pars = [z1], [], [_bn_finalize(bns[0], sums, count, groups)]
         for i in range(1, L):
             W = weights[i]
@@ -477,24 +477,68 @@ def sa_chain(feats, w0, idx, dxyz, layers, row_w, count, groups, inv=None):
 
 # ---- cost volume -------------------------------------------------------------------------------------------------------
 
+class _PackJob(ctypes.Structure):      # rtk_pack_job_t (include/rtk_train.h)
+    _fields_ = [("src", ctypes.c_void_p), ("src2", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("rows", ctypes.c_int), ("cols", ctypes.c_int),
+                ("pitch", ctypes.c_int), ("transpose", ctypes.c_int), ("kind", ctypes.c_int)]
+
+
+def _pack_weights(specs, device):
+    """specs: list of (kind, matrix-or-vector, transpose, second tensor or None): every kernel image of an operator's live weights in
+    ONE launch (rtk_pack_weights) into one workspace.  kind 0 = fragment-major MFMA image (fused.pack_layer), 1 = offset-layer image
+    of [W(:, :3) | b] (fused.offset_image), 2 = zero-padded vector (fused.pad_bias).  Returns the list of image tensors (views)."""
+    c16 = lambda v: (v + 15) // 16 * 16
+    sizes = []
+    for kind, t, tr, _ in specs:
+        if kind == 0:
+            r, c = (t.shape[1], t.shape[0]) if tr else (t.shape[0], t.shape[1])
+            sizes.append(c16(r) * c16(c))
+        elif kind == 1:
+            sizes.append(c16(t.shape[0]) * 4)
+        else:
+            sizes.append(c16(t.shape[0]))
+    ws = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+    outs = list(torch.split(ws, sizes))
+    jobs = (_PackJob * len(specs))()
+    keep = []
+    for j, ((kind, t, tr, t2), o) in enumerate(zip(specs, outs)):
+        t = t.detach()
+        if t.dim() == 2 and t.stride(1) != 1:
+            t = t.contiguous()
+        keep.append(t)
+        jobs[j].src, jobs[j].dst, jobs[j].kind, jobs[j].transpose = t.data_ptr(), o.data_ptr(), kind, int(bool(tr))
+        if kind == 2:
+            jobs[j].rows, jobs[j].cols, jobs[j].pitch = t.shape[0], 1, 1
+        else:
+            r, c = (t.shape[1], t.shape[0]) if tr else (t.shape[0], t.shape[1])
+            jobs[j].rows, jobs[j].cols, jobs[j].pitch = r, (3 if kind == 1 else c), t.stride(0)
+        if t2 is not None:
+            t2 = t2.detach().contiguous()
+            keep.append(t2)
+            jobs[j].src2 = t2.data_ptr()
+    _lib.call("rtk_pack_weights", len(specs), jobs, _stream())
+    return outs, (ws, keep)
+
+
 class _CvWeights:
-    """Packed kernel images of the live cost-volume weights (re-packed every step: the weights are being trained)."""
+    """Packed kernel images of the live cost-volume weights (re-packed every step: the weights are being trained): the four 256x256
+    layer images W2, W3, W3^T, W2^T, the offset image of Wd, the WeightNet's three layers and Wc^T -- one launch."""
 
     def __init__(self, wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, backward):
         dev = w2.device
         L = fused._Layer
-        mats = [w2, w3] + ([w3.t(), w2.t()] if backward else [])
-        self.blob = torch.cat([fused.pack_layer(m) for m in mats]).contiguous()
-        self.bias = torch.cat([b2.float(), b3.float()]).contiguous()
-        self.layers = (L * len(mats))()
-        for i in range(len(mats)):
-            self.layers[i].w_packed = self.blob.data_ptr() + 4 * i * 256 * 256
-            self.layers[i].bias = self.bias.data_ptr() + 4 * 256 * min(i, 1)
+        specs = [(0, w2, False, None), (0, w3, False, None)] + ([(0, w3, True, None), (0, w2, True, None)] if backward else [])
+        nm = len(specs)
+        specs += [(2, b2, False, None), (2, b3, False, None), (1, wd, False, None), (1, wa, False, ba), (0, wb, False, None), (2, bb, False, None),
+                  (0, wc, False, None), (2, bc, False, None), (0, wc, True, None)]
+        outs, self._keep = _pack_weights(specs, dev)
+        self.blob = outs[0]                       # the layer images are contiguous in the workspace (blob = W2 | W3 | W3^T | W2^T)
+        self.bias = outs[nm]                      # b2 | b3
+        self.layers = (L * nm)()
+        for i in range(nm):
+            self.layers[i].w_packed = outs[i].data_ptr()
+            self.layers[i].bias = outs[nm + min(i, 1)].data_ptr()
             self.layers[i].cin16, self.layers[i].cout16, self.layers[i].act = 16, 16, fused.ACT_LEAKY
-        self.wd = fused.offset_image(torch.cat([wd, torch.zeros(256, 1, device=dev, dtype=wd.dtype)], 1), dev)
-        self.wa = fused.offset_image(torch.cat([wa, ba[:, None]], 1), dev)
-        self.wb, self.bb = fused.pack_layer(wb), fused.pad_bias(bb, 8)
-        self.wc, self.bc = fused.pack_layer(wc), fused.pad_bias(bc, 256)
+        self.wd, self.wa, self.wb, self.bb, self.wc, self.bc, self.wct = outs[nm + 2:nm + 9]
         wn = (L * 3)()
         wn[0].w_packed, wn[0].cin16, wn[0].cout16 = self.wa.data_ptr(), 1, 1
         wn[1].w_packed, wn[1].bias, wn[1].cin16, wn[1].cout16 = self.wb.data_ptr(), self.bb.data_ptr(), 1, 1
@@ -526,7 +570,6 @@ class _CostVolume(torch.autograd.Function):
         p1, p2 = p1.contiguous(), p2.contiguous()
         # all kernel images are built once per step, here: the backward reuses them (ctx.images)
         W = _CvWeights(wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, backward=True)
-        W.wct = fused.pack_layer(wc.t())
         ctx.images = W
         out = torch.empty(B * n1, 256, dtype=torch.float32, device=p1.device)
         _lib.call("rtk_cost_volume", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
@@ -585,7 +628,6 @@ def time_cost_volume_bwd(batch, n, dev, iters=10):
     p1, p2, dout = r(B * n, 256), r(B * n, 256), r(B * n, 256)
     w2, w3 = r(256, 256) * 0.06, r(256, 256) * 0.06
     W = _CvWeights(r(256, 3), w2, r(256), w3, r(256), r(8, 3), r(8), r(8, 8), r(8), r(256, 8), r(256), backward=True)
-    wct = fused.pack_layer(r(8, 256))
     big = torch.empty(6, M, 256, device=dev)
     d4, dt2 = torch.empty(M, 4, device=dev), torch.empty(M, 8, device=dev)
     dp1, dpd = torch.empty(B * n, 256, device=dev), torch.empty(B * n, 3, 256, device=dev)
@@ -593,7 +635,7 @@ def time_cost_volume_bwd(batch, n, dev, iters=10):
 
     def launch():
         _lib.call("rtk_cost_volume_bwd", B, n, n, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
-                  W.wd.data_ptr(), W.layers, W.wn, wct.data_ptr(), dout.data_ptr(), 256, 256, big[0].data_ptr(), big[1].data_ptr(),
+                  W.wd.data_ptr(), W.layers, W.wn, W.wct.data_ptr(), dout.data_ptr(), 256, 256, big[0].data_ptr(), big[1].data_ptr(),
                   big[2].data_ptr(), big[3].data_ptr(), big[4].data_ptr(), big[5].data_ptr(), d4.data_ptr(), dp1.data_ptr(),
                   dpd.data_ptr(), dt2.data_ptr(), st)
     for _ in range(3):
@@ -610,16 +652,15 @@ def time_cost_volume_bwd(batch, n, dev, iters=10):
 
 
 def _weightnet_images(wa, ba, wb, bb, wc, bc):
-    """Kernel images of a WeightNet 3 -> 8 -> 8 -> 256 (see fused._WeightNet) from live parameters."""
+    """Kernel images of a WeightNet 3 -> 8 -> 8 -> 256 (see fused._WeightNet) from live parameters, + Wc^T; one launch."""
     L = fused._Layer
-    dev = wa.device
-    keep = [fused.offset_image(torch.cat([wa, ba[:, None]], 1), dev), fused.pack_layer(wb), fused.pad_bias(bb, 8),
-            fused.pack_layer(wc), fused.pad_bias(bc, 256)]
+    outs, keep = _pack_weights([(1, wa, False, ba), (0, wb, False, None), (2, bb, False, None), (0, wc, False, None), (2, bc, False, None),
+                                (0, wc, True, None)], wa.device)
     wn = (L * 3)()
-    wn[0].w_packed, wn[0].cin16, wn[0].cout16 = keep[0].data_ptr(), 1, 1
-    wn[1].w_packed, wn[1].bias, wn[1].cin16, wn[1].cout16 = keep[1].data_ptr(), keep[2].data_ptr(), 1, 1
-    wn[2].w_packed, wn[2].bias, wn[2].cin16, wn[2].cout16 = keep[3].data_ptr(), keep[4].data_ptr(), 1, 16
-    return wn, keep
+    wn[0].w_packed, wn[0].cin16, wn[0].cout16 = outs[0].data_ptr(), 1, 1
+    wn[1].w_packed, wn[1].bias, wn[1].cin16, wn[1].cout16 = outs[1].data_ptr(), outs[2].data_ptr(), 1, 1
+    wn[2].w_packed, wn[2].bias, wn[2].cin16, wn[2].cout16 = outs[3].data_ptr(), outs[4].data_ptr(), 1, 16
+    return wn, (outs, keep)
 
 
 def _weightnet_backward(d4, dq3, dt2, wa, ba, wb, bb, wc):
@@ -649,7 +690,7 @@ class _PatchCost(torch.autograd.Function):
         B, n, _ = xyz.shape
         feat = feat.contiguous()
         wn, keep = _weightnet_images(wa, ba, wb, bb, wc, bc)
-        ctx.images = (wn, keep, fused.pack_layer(wc.t()))           # reused by the backward
+        ctx.images = (wn, keep, keep[0][5])                         # reused by the backward (keep[0][5] = packed Wc^T)
         out = torch.empty(B * n, 256, dtype=torch.float32, device=feat.device)
         _lib.call("rtk_patch_cost", B, n, xyz.data_ptr(), knn.data_ptr(), feat.data_ptr(), 256, wn, out.data_ptr(), 256, 0, _stream())
         ctx.save_for_backward(feat, wa, ba, wb, bb, wc, bc, xyz, knn)

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Where do the framework ('glue') ops of the train step come from: every aten op of one eager step that launches work, logged by a
+TorchDispatchMode with the innermost repository frame that issued it (ops issued by the autograd engine's built-in backward nodes
+have no Python frame: they are listed by op name)."""
+import os, sys, collections, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+from ratrack_amd import synth
+from ratrack_amd.track4d import Track4D, Args
+from ratrack_amd.train import Trainer
+dev = "cuda"; B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+net = Track4D(Args()).to(dev); synth.fill_state_dict(net.state_dict())
+d = synth.make_frame_pairs(B, 256, 0); t = {k: torch.from_numpy(v).to(dev) for k, v in d.items()}
+h = torch.zeros(5, B, 128, device=dev); tr = Trainer(net)
+step = lambda: tr.step(t["pc1"], t["pc2"], t["feature1"], t["feature2"], t["gt_warp"], t["gt_cls"], h)
+for _ in range(4): step()
+torch.cuda.synchronize()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NOKERNEL = ("view", "reshape", "permute", "transpose", "expand", "slice", "select", "unsqueeze", "squeeze", "detach", "alias", "as_strided",
+            "empty", "t.default", "split", "unbind", "narrow", "_unsafe_view", "size", "stride", "is_", "sym_", "_local_scalar", "lift", "unfold")
+sites = collections.defaultdict(collections.Counter)
+
+
+class Log(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        if not any(k in name for k in NOKERNEL):
+            site = "(autograd built-in backward)"
+            for fr in reversed(traceback.extract_stack()):
+                if fr.filename.startswith(ROOT) and "/tools/" not in fr.filename:
+                    site = "%s:%d %s" % (fr.filename.replace(ROOT + "/", ""), fr.lineno, fr.name)
+                    break
+            sites[site][name.replace("aten.", "")] += 1
+        return func(*args, **(kwargs or {}))
+
+
+with Log():
+    step()
+torch.cuda.synchronize()
+tot = sum(sum(c.values()) for c in sites.values())
+print("B=%d: %d kernel-launching framework ops in one step" % (B, tot))
+for site, c in sorted(sites.items(), key=lambda kv: -sum(kv[1].values())):
+    print("%4d  %-64s %s" % (sum(c.values()), site[:64], dict(c.most_common(6))))
