@@ -222,7 +222,12 @@ __device__ __forceinline__ f4 weightnet_out(const WnWeights &W, int lane, int g,
 #define CV_NW 4          // waves per workgroup (all share one weight stream)
 #endif
 #ifndef CV_F
-#define CV_F 32          // fragments (KiB) per half of the LDS double buffer
+#define CV_F 8           // fragments (KiB) per half of the LDS double buffer of the FORWARD kernel.  Standalone the kernel is the same
+                         // speed with 8, 16 or 32 (0.60-0.62 ms), but with two batches in flight the small footprint (2 x 16 KiB per CU
+                         // instead of 2 x 64) lets the other batch's kernels co-reside: 1.421 vs 1.440 ms per step (tools/exp_cvf.sh)
+#endif
+#ifndef CVB_F
+#define CVB_F 32         // ... of the backward kernel (runs alone in the train step)
 #endif
 #ifndef CV_WGS_PER_CU
 #define CV_WGS_PER_CU 2
@@ -381,7 +386,7 @@ __device__ __forceinline__ f4 *cv_at(float *base, unsigned byte_off) {
 #define CVB_MIN_WAVES ((CV_NW * CV_WGS_PER_CU) / 4)
 #endif
 __global__ __launch_bounds__(64 * CV_NW, CVB_MIN_WAVES) void cost_volume_bwd_kernel(const CvBwdParams Q) {
-    __shared__ __attribute__((aligned(16))) f4 s_w[2 * CV_F * 64];
+    __shared__ __attribute__((aligned(16))) f4 s_w[2 * CVB_F * 64];
     const CvParams &P = Q.f;
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     const int wave_in_wg = threadIdx.x >> 6;
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(64 * CV_NW, CVB_MIN_WAVES) void cost_volume_bwd_ker
     const int groups = (P.n1 + CV_NW - 1) / CV_NW;
     constexpr int NF = 4 * CV_V * CV_V;
     constexpr int L = CV_V * CV_V;
-    WStream<CV_NW, CV_F, NF> ws;
+    WStream<CV_NW, CVB_F, NF> ws;
     ws.start(P.blob, s_w, wave_in_wg, lane);
     for (int G = bx; G < groups; G += nbx) {
         asm volatile("" ::: "memory");

@@ -82,7 +82,10 @@ __device__ __forceinline__ void store_tile(const PwParams &P, const f4 (&acc)[V]
 }
 
 #define PW_NW 4    // waves per workgroup
-#define PW_F 32    // fragments (KiB) per half of the LDS weight double buffer
+#ifndef PW_F
+#define PW_F 16    // fragments (KiB) per half of the LDS weight double buffer (16 vs 32: same kernel speed, 1 % more end-to-end
+                   // throughput with two batches in flight -- smaller footprints co-reside, tools/exp_pwf.sh)
+#endif
 
 template <int U, int V1, int V2, int V3, int V4, bool INTERP>
 __global__ __launch_bounds__(64 * PW_NW, 2) void pointwise_mlp_kernel(const PwParams P) {

@@ -692,9 +692,9 @@ class FusedBackbone:
             self.kernel_events = saved
 
             def step(*new_inputs):
-                for dst, src in zip(static, new_inputs):
-                    if src is not None:
-                        dst.copy_(src, non_blocking=True)
+                pairs = [(d, s_) for d, s_ in zip(static, new_inputs) if s_ is not None]
+                if pairs:       # ONE multi-tensor copy into the static buffers instead of five device-to-device memcpys
+                    torch._foreach_copy_([p[0] for p in pairs], [p[1] for p in pairs])
                 graph.replay()
                 return outs
             step.graph = graph
@@ -723,9 +723,9 @@ class FusedBackbone:
         eng = self
 
         def step(*new_inputs):
-            for dst, src in zip(static, new_inputs):
-                if src is not None:
-                    dst.copy_(src, non_blocking=True)
+            pairs = [(d, s_) for d, s_ in zip(static, new_inputs) if s_ is not None]
+            if pairs:
+                torch._foreach_copy_([p[0] for p in pairs], [p[1] for p in pairs])
             g1.replay()
             ev = eng.kernel_events
             if ev is not None:
