@@ -210,6 +210,13 @@ RTK_EXPORT int rtk_gru_step_bwd(int b, int layers, int hidden, const float *x, c
 RTK_EXPORT int rtk_scatter_add_rows(int samples, int m, int n, int channels, const int64_t *idx, const float *src, float *dst,
                                     rtk_stream_t stream);
 
+/* Parameter gradients of a WeightNet(3 -> 8 -> 8 -> C) (utils/model_utils/model_utils.py:359-390) from what rtk_cost_volume_bwd /
+ * rtk_patch_cost_bwd emit per position: d4 (M,4), dq3 (M,C), dt2 (M,8).  wa (8,3) ba (8) wb (8,8) bb (8) row-major live weights;
+ * dwa (8,3) dba (8) dwb (8,8) dbb (8) dwc (C,8) dbc (C), all ZERO-INITIALISED by the caller, accumulated with float atomics. */
+RTK_EXPORT int rtk_weightnet_bwd(long positions, int channels, const float *d4, const float *dq3, const float *dt2, const float *wa,
+                                 const float *ba, const float *wb, const float *bb, float *dwa, float *dba, float *dwb, float *dbb,
+                                 float *dwc, float *dbc, rtk_stream_t stream);
+
 /* Multi-task loss of the backbone trainer (losses/loss.py:8-31,85-89,124-146, batch mean) and its gradients in one launch.
  * pc1, flow, gt_warp (B,3,N) contiguous; cls (B,N) probabilities; gt_cls uint8/bool, sample b's row at gt_cls + b*gt_cls_stride
  * (stride 0: one label vector for the whole batch).  items (4) fp32 ZERO-INITIALISED: += [Loss, SceneFlowLoss, TrackingLoss (left

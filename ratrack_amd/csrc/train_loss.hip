@@ -88,3 +88,115 @@ extern "C" int rtk_backbone_loss(int b, int n, const float *pc1, const float *fl
     RTK_CHECK_LAUNCH("backbone_loss");
     return RTK_OK;
 }
+
+// ---- WeightNet parameter gradients (rtk_weightnet_bwd) --------------------------------------------------------------------------
+// WeightNet(3 -> 8 -> 8 -> C, ReLU after every layer, utils/model_utils/model_utils.py:359-390) of the cost volume / patch
+// aggregation.  The backward kernels of those operators emit, per (point, neighbour) position m: d4[m] = (direction, 1),
+// dq3[m] (C) = gradient of the last pre-activation (ReLU mask applied) and dt2[m] (8) = Wc^T dq3[m].  Here the two hidden
+// activations are recomputed and all six parameter gradients accumulated in one pass over dq3 (the only large operand):
+//     t1 = relu(Wa d + ba), t2 = relu(Wb t1 + bb)
+//     dWc = sum dq3 t2^T, dbc = sum dq3;   g2 = dt2 [t2 > 0]: dWb = sum g2 t1^T, dbb = sum g2;
+//     g1 = (Wb^T g2) [t1 > 0]: dWa = sum g1 d^T, dba = sum g1.
+// Round 1 did this with ~20 framework kernels per call (addmm, relu, cat, three slab-split GEMMs + reductions, masks).
+namespace {
+
+constexpr int WN_SUB = 256;       // positions per LDS sub-block
+
+__global__ __launch_bounds__(256) void weightnet_bwd_kernel(long M, int C, int sub_per_wg, const float *__restrict__ d4,
+                                                            const float *__restrict__ dq3, const float *__restrict__ dt2,
+                                                            const float *__restrict__ wa, const float *__restrict__ ba,
+                                                            const float *__restrict__ wb, const float *__restrict__ bb,
+                                                            float *__restrict__ dwa, float *__restrict__ dba, float *__restrict__ dwb,
+                                                            float *__restrict__ dbb, float *__restrict__ dwc, float *__restrict__ dbc) {
+    __shared__ float s_t1[WN_SUB][9], s_t2[WN_SUB][9], s_g1[WN_SUB][9], s_g2[WN_SUB][9], s_d[WN_SUB][4];
+    __shared__ float s_wa[8][3], s_ba[8], s_wb[8][8], s_bb[8];
+    const int t = threadIdx.x;
+    if (t < 24) s_wa[t / 3][t % 3] = wa[t];
+    if (t < 8) { s_ba[t] = ba[t]; s_bb[t] = bb[t]; }
+    if (t < 64) s_wb[t >> 3][t & 7] = wb[t];
+    __syncthreads();
+    float accc[8][2];      // this thread's channels c = t and t + 256 (C <= 512): dWc[c][0..7]
+    float accb[2] = {0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 8; ++h) { accc[h][0] = 0.f; accc[h][1] = 0.f; }
+    float small = 0.f;     // threads 0..103: one element of dWb (64) | dbb (8) | dWa (24) | dba (8)
+    for (int sb = 0; sb < sub_per_wg; ++sb) {
+        const long m0 = ((long)blockIdx.x * sub_per_wg + sb) * WN_SUB;
+        if (m0 >= M) break;
+        const int cnt = (int)((M - m0) < WN_SUB ? (M - m0) : WN_SUB);
+        __syncthreads();
+        if (t < cnt) {       // hidden activations and their gradients of position m0 + t
+            const long m = m0 + t;
+            const float dx = d4[m * 4 + 0], dy = d4[m * 4 + 1], dz = d4[m * 4 + 2];
+            float t1[8], t2[8], g2[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t1[k] = fmaxf(s_wa[k][0] * dx + s_wa[k][1] * dy + s_wa[k][2] * dz + s_ba[k], 0.f);
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                float a = s_bb[h];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a += s_wb[h][k] * t1[k];
+                t2[h] = fmaxf(a, 0.f);
+                g2[h] = t2[h] > 0.f ? dt2[m * 8 + h] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float a = 0.f;
+#pragma unroll
+                for (int h = 0; h < 8; ++h) a += s_wb[h][k] * g2[h];
+                s_g1[t][k] = t1[k] > 0.f ? a : 0.f;
+                s_t1[t][k] = t1[k]; s_t2[t][k] = t2[k]; s_g2[t][k] = g2[k];
+            }
+            s_d[t][0] = dx; s_d[t][1] = dy; s_d[t][2] = dz;
+        }
+        __syncthreads();
+        // dWc / dbc: thread = channel, loop over the sub-block's positions (rows of dq3 are read coalesced)
+        for (int q = 0; q < 2; ++q) {
+            const int c = t + 256 * q;
+            if (c >= C) break;
+            const float *col = dq3 + m0 * C + c;
+            for (int p = 0; p < cnt; ++p) {
+                const float v = col[(long)p * C];
+                accb[q] += v;
+#pragma unroll
+                for (int h = 0; h < 8; ++h) accc[h][q] += v * s_t2[p][h];
+            }
+        }
+        if (t < 104) {
+            for (int p = 0; p < cnt; ++p) {
+                if (t < 64) small += s_g2[p][t >> 3] * s_t1[p][t & 7];
+                else if (t < 72) small += s_g2[p][t - 64];
+                else if (t < 96) small += s_g1[p][(t - 72) / 3] * s_d[p][(t - 72) % 3];
+                else small += s_g1[p][t - 96];
+            }
+        }
+    }
+    for (int q = 0; q < 2; ++q) {
+        const int c = t + 256 * q;
+        if (c >= C) break;
+        atomicAdd(dbc + c, accb[q]);
+#pragma unroll
+        for (int h = 0; h < 8; ++h) atomicAdd(dwc + c * 8 + h, accc[h][q]);
+    }
+    if (t < 64) atomicAdd(dwb + t, small);
+    else if (t < 72) atomicAdd(dbb + t - 64, small);
+    else if (t < 96) atomicAdd(dwa + t - 72, small);
+    else if (t < 104) atomicAdd(dba + t - 96, small);
+}
+
+}  // namespace
+
+extern "C" int rtk_weightnet_bwd(long positions, int channels, const float *d4, const float *dq3, const float *dt2, const float *wa,
+                                 const float *ba, const float *wb, const float *bb, float *dwa, float *dba, float *dwb, float *dbb,
+                                 float *dwc, float *dbc, rtk_stream_t stream) {
+    RTK_REQUIRE(positions > 0 && channels > 0 && channels <= 512 && d4 && dq3 && dt2 && wa && ba && wb && bb && dwa && dba && dwb && dbb &&
+                dwc && dbc, "weightnet_bwd: bad arguments");
+    const long subs = (positions + WN_SUB - 1) / WN_SUB;
+    int per = (int)((subs + 511) / 512);           // ~512 workgroups, each a few sub-blocks: its atomics stay a small share
+    if (per < 1) per = 1;
+    const int wgs = (int)((subs + per - 1) / per);
+    weightnet_bwd_kernel<<<wgs, 256, 0, (hipStream_t)stream>>>(positions, channels, per, d4, dq3, dt2, wa, ba, wb, bb, dwa, dba, dwb, dbb, dwc,
+                                                              dbc);
+    RTK_CHECK_LAUNCH("weightnet_bwd");
+    return RTK_OK;
+}

@@ -45,6 +45,7 @@ _lib.SIGNATURES.update({
     "rtk_pw_wgrad": [_i, _i, _PwP, _i, _PwP, _p, _i, _p, _p],
     "rtk_backbone_loss": [_i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p],
     "rtk_pack_weights": [_i, _p, _p],
+    "rtk_weightnet_bwd": [ctypes.c_long, _i] + [_p] * 13 + [_p],
 })
 
 
@@ -664,21 +665,17 @@ def _weightnet_images(wa, ba, wb, bb, wc, bc):
 
 
 def _weightnet_backward(d4, dq3, dt2, wa, ba, wb, bb, wc):
-    """Gradients of the WeightNet parameters from dq3 (M,256) (last pre-activation), dt2 = dq3 Wc (M,8) and the
-    direction vectors d4[:, :3]; the (M,8) hidden activations are recomputed."""
-    M = d4.shape[0]
+    """Gradients of the WeightNet parameters from dq3 (M,256) (last pre-activation), dt2 = dq3 Wc (M,8) and the direction vectors
+    d4[:, :3]: one kernel (rtk_weightnet_bwd) recomputes the (M,8) hidden activations and accumulates all six gradients."""
+    M, C = dq3.shape
     dev = d4.device
-    d3 = d4[:, :3]
-    t1 = torch.relu(torch.addmm(ba, d3, wa.t()))
-    t2 = torch.relu(torch.addmm(bb, t1, wb.t()))
-    t2p = torch.cat([t2, torch.ones(M, 1, dtype=torch.float32, device=dev), torch.zeros(M, 7, dtype=torch.float32, device=dev)], 1)
-    gc = _tall_tn(dq3, t2p)
-    dwc, dbc = gc[:, :8], gc[:, 8]
-    dt2 = dt2 * (t2 > 0)
-    dwb, dbb = _tall_tn(dt2, t1), dt2.sum(0)
-    dt1 = torch.mm(dt2, wb) * (t1 > 0)
-    dwa, dba = _tall_tn(dt1, d3), dt1.sum(0)
-    return dwa, dba, dwb, dbb, dwc, dbc
+    buf = _zeros((24 + 8 + 64 + 8 + C * 8 + C,), torch.float32, dev)
+    dwa, dba, dwb, dbb, dwc, dbc = torch.split(buf, [24, 8, 64, 8, C * 8, C])
+    c = lambda t: t.detach().contiguous()
+    wa_, ba_, wb_, bb_ = c(wa), c(ba), c(wb), c(bb)
+    _lib.call("rtk_weightnet_bwd", M, C, d4.data_ptr(), dq3.data_ptr(), dt2.data_ptr(), wa_.data_ptr(), ba_.data_ptr(), wb_.data_ptr(),
+              bb_.data_ptr(), dwa.data_ptr(), dba.data_ptr(), dwb.data_ptr(), dbb.data_ptr(), dwc.data_ptr(), dbc.data_ptr(), _stream())
+    return dwa.view(8, 3), dba, dwb.view(8, 8), dbb, dwc.view(C, 8), dbc
 
 
 class _PatchCost(torch.autograd.Function):
