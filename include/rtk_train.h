@@ -33,7 +33,13 @@
 extern "C" {
 #endif
 
-/* Weighted per-(group, channel) sums.  sums (groups, C, 2) float64, ZERO-INITIALISED by the caller:
+/* Batch-statistic buffers ("sums", "sums2" below) are float64 arrays of RTK_STAT_SLOTS replicas, (RTK_STAT_SLOTS, groups, C, 2),
+ * ZERO-INITIALISED by the caller: a producer's workgroups add their partial sums (float64 atomics) to the replica picked by
+ * their sample index, the consumers add the replicas up in a fixed order.  One replica made every statistics epilogue a chain
+ * of 64..256 serialised atomics on the same address (8..22 us per launch, more than the layers themselves at these sizes). */
+#define RTK_STAT_SLOTS 8
+
+/* Weighted per-(group, channel) sums.  sums (RTK_STAT_SLOTS, groups, C, 2) float64, ZERO-INITIALISED by the caller:
  * [..,0] += sum w z, [..,1] += sum w z^2.  ns must be a power of two; row_weight may be NULL (all ones). */
 RTK_EXPORT int rtk_bn_train_stats(int samples, int channels, int rows, int ns, int groups, const float *z,
                                   const float *row_weight, double *sums, rtk_stream_t stream);
@@ -144,9 +150,11 @@ RTK_EXPORT int rtk_pw_conv(int samples, int positions, int nsrc, const rtk_pw_op
                            int groups, double *sums, int stat_channels, rtk_stream_t stream);
 
 /* dw[o][src_i.col0 + k] += sum over samples and positions of dz[o] * src_i[k]; dbias[o] += sum dz[o] (optional).  dw (and dbias)
- * are ZERO-INITIALISED by the caller; workgroup partials are added with float atomics. */
+ * hold the values to add to (zeros for a plain gradient).  The position axis is split over workgroups whose 64 x 64 partial
+ * blocks go through `workspace` (workspace_floats floats, uninitialised, >= 4096 per split and block; 4 Mi floats serve every
+ * shape at full parallelism; NULL: no split) and are added by a second kernel in a fixed order: no atomics, deterministic. */
 RTK_EXPORT int rtk_pw_wgrad(int samples, int positions, const rtk_pw_operand_t *dz, int nsrc, const rtk_pw_operand_t *srcs, float *dw,
-                            int w_pitch, float *dbias, rtk_stream_t stream);
+                            int w_pitch, float *dbias, float *workspace, long workspace_floats, rtk_stream_t stream);
 
 /* ---- cost volume (utils/model_utils/model_utils.py:216-236) ------------------------------------------------------
  * Backward of rtk_cost_volume (rtk_fused.h; same forward arguments).  layers[0..3] = the packed 256x256 layers

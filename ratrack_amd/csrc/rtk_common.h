@@ -5,6 +5,16 @@
 #include <stdio.h>
 
 #include "rtk_pointnet2.h"
+#include "rtk_train.h"
+
+// Batch-statistic replicas (RTK_STAT_SLOTS, rtk_train.h): `gc2` = groups * channels * 2 doubles per replica.
+__device__ __forceinline__ double *rtk_stat_slot(double *sums, size_t gc2, unsigned key) { return sums + (size_t)(key % RTK_STAT_SLOTS) * gc2; }
+__device__ __forceinline__ double rtk_stat_read(const double *sums, size_t gc2, size_t idx) {
+    double a = 0.0;
+#pragma unroll
+    for (int s = 0; s < RTK_STAT_SLOTS; ++s) a += sums[(size_t)s * gc2 + idx];
+    return a;
+}
 
 #define RTK_WAVE 64
 

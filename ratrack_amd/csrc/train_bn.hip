@@ -82,7 +82,7 @@ __global__ __launch_bounds__(BN_T) void bn_stats_kernel(int samples, int channel
     }
     block_sum2(s, ss);
     if (threadIdx.x == 0) {
-        double *dst = sums + ((size_t)p.g * channels + blockIdx.x) * 2;
+        double *dst = rtk_stat_slot(sums, (size_t)groups * channels * 2, blockIdx.y) + ((size_t)p.g * channels + blockIdx.x) * 2;
         atomicAdd(dst, s);
         atomicAdd(dst + 1, ss);
     }
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(BN_T) void sa_first_layer_kernel(int samples, int c
         double a = s[q], c = ss[q];
         block_sum2(a, c);
         if (threadIdx.x == 0) {
-            double *dst = sums + ((size_t)grp * channels + c0 + q) * 2;
+            double *dst = rtk_stat_slot(sums, (size_t)groups * channels * 2, b) + ((size_t)grp * channels + c0 + q) * 2;
             atomicAdd(dst, a);
             atomicAdd(dst + 1, c);
         }
@@ -159,7 +159,7 @@ __global__ void bn_finalize_kernel(int channels, int groups, const double *__res
     const size_t GC = (size_t)groups * channels;
     float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
     for (int g = 0; g < groups; ++g) {
-        const double s = sums[((size_t)g * channels + c) * 2], ss = sums[((size_t)g * channels + c) * 2 + 1];
+        const double s = rtk_stat_read(sums, GC * 2, ((size_t)g * channels + c) * 2), ss = rtk_stat_read(sums, GC * 2, ((size_t)g * channels + c) * 2 + 1);
         const double mean = s / count;
         double var = ss / count - mean * mean;
         var = var > 0.0 ? var : 0.0;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(BN_T) void bn_relu_bwd_stats_kernel(int samples, in
     }
     block_sum2(s, sx);
     if (threadIdx.x == 0) {
-        double *dst = sums2 + o * 2;
+        double *dst = rtk_stat_slot(sums2, GC * 2, blockIdx.y) + o * 2;
         atomicAdd(dst, s);
         atomicAdd(dst + 1, sx);
     }
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(BN_T) void bn_relu_pool_bwd_stats_kernel(int sample
     }
     block_sum2(s, sx);
     if (threadIdx.x == 0) {
-        double *dst = sums2 + o * 2;
+        double *dst = rtk_stat_slot(sums2, GC * 2, blockIdx.y) + o * 2;
         atomicAdd(dst, s);
         atomicAdd(dst + 1, sx);
     }
@@ -325,13 +325,13 @@ __device__ __forceinline__ BwdCoef bwd_coef(int channels, int groups, int g, con
     const size_t GC = (size_t)groups * channels, o = (size_t)g * channels + c;
     BwdCoef k;
     k.mean = par[o]; k.rstd = par[GC + o]; k.sc = par[2 * GC + o]; k.sh = par[3 * GC + o];
-    k.c1 = (float)(sums2[o * 2] / count);
-    k.c2 = (float)(sums2[o * 2 + 1] / count);
+    k.c1 = (float)(rtk_stat_read(sums2, GC * 2, o * 2) / count);
+    k.c2 = (float)(rtk_stat_read(sums2, GC * 2, o * 2 + 1) / count);
     if (dgb && blockIdx.y == 0 && threadIdx.x == 0) {     // parameter gradients: sum over the groups
         double db = 0.0, dg = 0.0;
         for (int gg = 0; gg < groups; ++gg) {
-            db += sums2[((size_t)gg * channels + c) * 2];
-            dg += sums2[((size_t)gg * channels + c) * 2 + 1];
+            db += rtk_stat_read(sums2, GC * 2, ((size_t)gg * channels + c) * 2);
+            dg += rtk_stat_read(sums2, GC * 2, ((size_t)gg * channels + c) * 2 + 1);
         }
         dgb[c] = (float)dg;
         dgb[channels + c] = (float)db;

@@ -76,8 +76,8 @@ __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
             s_sc[c] = has_pre ? Q.pre[2 * GC + o + c] : 1.f;
             s_sh[c] = has_pre ? Q.pre[3 * GC + o + c] : 0.f;
             if (MODE == 2) {
-                s_c1[c] = (float)(Q.sums[(o + c) * 2] / Q.count);
-                s_c2[c] = (float)(Q.sums[(o + c) * 2 + 1] / Q.count);
+                s_c1[c] = (float)(rtk_stat_read(Q.sums, GC * 2, (o + c) * 2) / Q.count);
+                s_c2[c] = (float)(rtk_stat_read(Q.sums, GC * 2, (o + c) * 2 + 1) / Q.count);
             }
         }
     }
@@ -86,8 +86,8 @@ __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
         const int c = threadIdx.x;
         double db = 0.0, dg = 0.0;
         for (int gg = 0; gg < Q.groups; ++gg) {
-            db += Q.sums[((size_t)gg * 16 * V + c) * 2];
-            dg += Q.sums[((size_t)gg * 16 * V + c) * 2 + 1];
+            db += rtk_stat_read(Q.sums, (size_t)Q.groups * 16 * V * 2, ((size_t)gg * 16 * V + c) * 2);
+            dg += rtk_stat_read(Q.sums, (size_t)Q.groups * 16 * V * 2, ((size_t)gg * 16 * V + c) * 2 + 1);
         }
         Q.dgb[c] = (float)dg;
         Q.dgb[16 * V + c] = (float)db;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
         for (int w = 0; w < TC_T / 64; ++w) { a0 += s_red[w][threadIdx.x][0]; a1 += s_red[w][threadIdx.x][1]; }
-        double *dst = Q.sums + ((size_t)grp * 16 * V + threadIdx.x) * 2;
+        double *dst = rtk_stat_slot(Q.sums, (size_t)Q.groups * 16 * V * 2, b) + ((size_t)grp * 16 * V + threadIdx.x) * 2;
         atomicAdd(dst, a0);
         atomicAdd(dst + 1, a1);
     }

@@ -54,28 +54,38 @@ struct PwParams {
     double *sums;                   // (groups, stat_channels, 2) or NULL; indexed by the W row of the output channel
     int stat_channels;
     int nchunks;                    // output chunks of <= 64 channels: chunk -> (dst, first channel)
-    unsigned char chunk_dst[40];
-    short chunk_c0[40];
+    unsigned char chunk_dst[96];
+    short chunk_c0[96];
     int accumulate;                 // stores add to the destination (dgrad into a tensor that already holds a partial gradient)
 };
 
 __device__ __forceinline__ float pw_load1(const PwOp &op, const float *base, int c, int p, int P) {
-    if (c >= op.channels || p >= P) return 0.f;
-    return op.layout ? base[(size_t)p * op.pitch + c] : base[(size_t)c * op.pitch + p];
+    const int cc = min(c, op.channels - 1), pp = min(p, P - 1);          // unconditional load + select (see pw_load_block)
+    const float v = op.layout ? base[(size_t)pp * op.pitch + cc] : base[(size_t)cc * op.pitch + pp];
+    return (c < op.channels && p < P) ? v : 0.f;
 }
 
 // x[t][r] = X[channel c0 + 4g + r][position p + t] of one 16-channel block.  `fastp` (wave-uniform): the wave's 64 positions are in
 // range and the operand is 16-byte aligned, so every access is a vector load guarded only by the lane's channel range.
 __device__ __forceinline__ void pw_load_block(const PwOp &op, const float *base, int c0, int g, int p, int P, bool fastp, f4 (&x)[4]) {
     const int c = c0 + 4 * g;
-    if (fastp && op.layout && c + 4 <= op.channels) {
+    // The vector paths load unconditionally from a clamped (always valid) address and select afterwards: a conditional load is a
+    // basic block of its own, and the compiler then waits for each load before issuing the next (measured: 2x on the whole kernel).
+    if (fastp && op.layout && (op.channels & 3) == 0) {
+        const int cc = min(c, op.channels - 4);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) x[t] = pw_ld4(base + (size_t)(p + t) * op.pitch + c);
+        for (int t = 0; t < 4; ++t) x[t] = pw_ld4(base + (size_t)(p + t) * op.pitch + cc);
+        if (c >= op.channels) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x[t] = f4_zero();
+        }
     } else if (fastp && !op.layout) {
         f4 q[4];
 #pragma unroll
+        for (int r = 0; r < 4; ++r) q[r] = pw_ld4(base + (size_t)min(c + r, op.channels - 1) * op.pitch + p);
+#pragma unroll
         for (int r = 0; r < 4; ++r)
-            q[r] = c + r < op.channels ? pw_ld4(base + (size_t)(c + r) * op.pitch + p) : f4_zero();
+            if (c + r >= op.channels) q[r] = f4_zero();
 #pragma unroll
         for (int t = 0; t < 4; ++t) x[t] = (f4){q[0][t], q[1][t], q[2][t], q[3][t]};
     } else {
@@ -87,95 +97,128 @@ __device__ __forceinline__ void pw_load_block(const PwOp &op, const float *base,
 }
 
 
-template <int NW>      // waves per workgroup: 4 (they share a weight tile) or 1 (small batches: four times the workgroups)
+// NW waves per workgroup (they share a staged weight tile), VB 16-channel output blocks per workgroup.  <4,4> for large batches;
+// <1,1> for small ones: 16 times the workgroups, each a sixteenth of the serial work (at B = 1 the layers are pure latency)
+template <int NW, int VB>
 __global__ __launch_bounds__(64 * NW) void pw_conv_kernel(const PwParams Q) {
     constexpr int NT = 64 * NW;
-    __shared__ __attribute__((aligned(16))) f4 s_w[2 * 16 * 64];    // double-buffered (64 out, 64 in) weight tile, fragment (u, v)
+    constexpr int OC = 16 * VB;      // output channels per workgroup
+    __shared__ __attribute__((aligned(16))) f4 s_w[2 * 4 * VB * 64];    // double-buffered (16 VB out, 64 in) weight tile, fragment (u, v)
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
     const int b = blockIdx.z, P = Q.P;
     const PwOp &D = Q.dst[Q.chunk_dst[blockIdx.y]];
     const int oc0 = Q.chunk_c0[blockIdx.y];                         // first channel of this chunk inside its destination
     const int orow0 = D.col0 + oc0;                                 // ... and its row of W
-    const int nout = min(64, D.channels - oc0);
+    const int nout = min(OC, D.channels - oc0);
     const int p0 = (blockIdx.x * NW + wave) * 64;
     const int p = p0 + 4 * j;
     const bool pfull = p0 + 64 <= P;
-    f4 acc[4][4];
+    f4 acc[4][VB];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) acc[t][v] = f4_zero();
-    int buf = 0;
-    for (int s = 0; s < Q.nsrc; ++s) {
+        for (int v = 0; v < VB; ++v) acc[t][v] = f4_zero();
+    // K loop over the 64-channel tiles of all sources, software-pipelined: the weight tile and the input blocks of tile i + 1 are
+    // requested (into registers) before the MFMAs of tile i are issued, so a tile costs max(MFMA time, memory latency) instead of
+    // their sum -- with one wave per SIMD (a 256-position x 64-channel workgroup per CU is all these layers offer) nothing else
+    // hides a round trip.  One barrier per tile (double-buffered LDS tile: a wave can only be one tile ahead).
+    constexpr int NWL = 4 * VB * 64 / NT;                            // weight float4s staged per thread and tile
+    int nk = 0;
+    for (int s = 0; s < Q.nsrc; ++s) nk += (Q.src[s].channels + 63) >> 6;
+    f4 wreg[NWL], xn[4][4];
+    auto request = [&](int s, int k0) {
         const PwOp &S = Q.src[s];
-        const float *sb = S.ptr + (size_t)b * S.sample_stride;
-        for (int k0 = 0; k0 < S.channels; k0 += 64) {
-            // stage the (64 out, 64 in) weight tile as MFMA A fragments into the other half of the double buffer: fragment (u, v),
-            // lane (fg, fi) = W[o = 16v + fi][k = 16u + 4fg .. +3].  One barrier per tile: a wave can only be one tile ahead.
-            f4 *sw = s_w + buf * (16 * 64);
-            if (!Q.transpose_w) {
-                for (int e = threadIdx.x; e < 16 * 64; e += NT) {
-                    const int f = e >> 6, l = e & 63, u = f >> 2, v = f & 3, fg = l >> 4, fi = l & 15;
-                    const int o = 16 * v + fi, k = k0 + 16 * u + 4 * fg;
-                    f4 w = f4_zero();
-                    if (o < nout) {
-                        const float *src = Q.W + (size_t)(orow0 + o) * Q.w_pitch + S.col0 + k;
-                        if (k + 4 <= S.channels) w = pw_ld4(src);
-                        else {
+        // unconditional loads from clamped addresses, zeros selected afterwards (see pw_load_block); the vector form when the whole
+        // tile is inside the matrix (workgroup-uniform)
+        if (!Q.transpose_w) {                // fragment (u, v), lane (fg, fi) = W[o = 16v + fi][k = 16u + 4fg .. +3]
+            const bool kfull = k0 + 64 <= S.channels;
 #pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (k + q < S.channels) w[q] = src[q];
-                        }
-                    }
-                    sw[e] = w;
-                }
-            } else {      // element (o, k) = W[k][o]: read rows of W along o (contiguous), scatter the four values into their fragments
-                float *swf = reinterpret_cast<float *>(sw);
-                for (int e = threadIdx.x; e < 64 * 16; e += NT) {
-                    const int kk = e >> 4, o4 = (e & 15) * 4, k = k0 + kk;
-                    f4 w = f4_zero();
-                    if (k < S.channels) {
-                        const float *src = Q.W + (size_t)(S.col0 + k) * Q.w_pitch + orow0 + o4;
-                        if (o4 + 4 <= nout) w = pw_ld4(src);
-                        else {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                if (o4 + q < nout) w[q] = src[q];
-                        }
-                    }
-                    const int u = kk >> 4, fg = (kk >> 2) & 3, kq = kk & 3;
+            for (int i = 0; i < NWL; ++i) {
+                const int e = threadIdx.x + i * NT;
+                const int f = e >> 6, l = e & 63, u = f / VB, v = f % VB, fg = l >> 4, fi = l & 15;
+                const int o = 16 * v + fi, k = k0 + 16 * u + 4 * fg;
+                const float *row = Q.W + (size_t)(orow0 + min(o, nout - 1)) * Q.w_pitch + S.col0;
+                f4 w;
+                if (kfull) w = pw_ld4(row + k);
+                else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int o = o4 + q;
-                        swf[(((u * 4 + (o >> 4)) * 64) + fg * 16 + (o & 15)) * 4 + kq] = w[q];
+                        const float t = row[min(k + q, S.channels - 1)];
+                        w[q] = k + q < S.channels ? t : 0.f;
                     }
                 }
+                wreg[i] = o < nout ? w : f4_zero();
             }
-            // the tile's four input blocks are requested up front (all in flight across the barrier and the first MFMAs)
-            const int nu = min(4, (S.channels - k0 + 15) >> 4);
-            f4 x[4][4];
+        } else {                             // element (o, k) = W[k][o]: rows of W along o (contiguous)
+            const bool ofull = nout == OC;
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (u < nu) pw_load_block(S, sb, k0 + 16 * u, g, p, P, pfull, x[u]);
-            __syncthreads();
+            for (int i = 0; i < NWL; ++i) {
+                const int e = threadIdx.x + i * NT;
+                const int kk = e / (4 * VB), o4 = (e % (4 * VB)) * 4, k = k0 + kk;
+                const float *row = Q.W + (size_t)(S.col0 + min(k, S.channels - 1)) * Q.w_pitch + orow0;
+                f4 w;
+                if (ofull) w = pw_ld4(row + o4);
+                else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (u >= nu) break;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    if (16 * v >= nout) continue;                     // workgroup-uniform: narrow layers skip the empty blocks
-                    const f4 wf = sw[(u * 4 + v) * 64 + lane];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        acc[t][v] = mfma4(wf.x, x[u][t].x, acc[t][v]);
-                        acc[t][v] = mfma4(wf.y, x[u][t].y, acc[t][v]);
-                        acc[t][v] = mfma4(wf.z, x[u][t].z, acc[t][v]);
-                        acc[t][v] = mfma4(wf.w, x[u][t].w, acc[t][v]);
+                    for (int q = 0; q < 4; ++q) {
+                        const float t = row[min(o4 + q, nout - 1)];
+                        w[q] = o4 + q < nout ? t : 0.f;
                     }
                 }
+                wreg[i] = k < S.channels ? w : f4_zero();
             }
-            buf ^= 1;
         }
+        const float *sb = S.ptr + (size_t)b * S.sample_stride;
+        const int nu = min(4, (S.channels - k0 + 15) >> 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u < nu) pw_load_block(S, sb, k0 + 16 * u, g, p, P, pfull, xn[u]);
+    };
+    int buf = 0, s_cur = 0, k_cur = 0;
+    request(0, 0);
+    for (int it = 0; it < nk; ++it) {
+        f4 *sw = s_w + buf * (4 * VB * 64);
+        if (!Q.transpose_w) {
+#pragma unroll
+            for (int i = 0; i < NWL; ++i) sw[threadIdx.x + i * NT] = wreg[i];
+        } else {                             // scatter the four values of each read into their fragments
+            float *swf = reinterpret_cast<float *>(sw);
+#pragma unroll
+            for (int i = 0; i < NWL; ++i) {
+                const int e = threadIdx.x + i * NT;
+                const int kk = e / (4 * VB), o4 = (e % (4 * VB)) * 4;
+                const int u = kk >> 4, fg = (kk >> 2) & 3, kq = kk & 3;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = o4 + q;
+                    swf[(((u * VB + (o >> 4)) * 64) + fg * 16 + (o & 15)) * 4 + kq] = wreg[i][q];
+                }
+            }
+        }
+        f4 x[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x[u][t] = xn[u][t];
+        const int nu = min(4, (Q.src[s_cur].channels - k_cur + 15) >> 4);
+        k_cur += 64;
+        if (k_cur >= Q.src[s_cur].channels) { ++s_cur; k_cur = 0; }
+        if (it + 1 < nk) request(s_cur, k_cur);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u >= nu) break;
+#pragma unroll
+            for (int v = 0; v < VB; ++v) {
+                if (16 * v >= nout) continue;                     // workgroup-uniform: narrow layers skip the empty blocks
+                const f4 wf = sw[(u * VB + v) * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t][v] = mfma4(wf[q], x[u][t][q], acc[t][v]);
+            }
+        }
+        buf ^= 1;
     }
     // ---- epilogue: acc[t][v][r] = Z[channel oc0 + 16v + 4g + r][position p + t] -------------------------------------------------
     float wl[4];
@@ -183,10 +226,10 @@ __global__ __launch_bounds__(64 * NW) void pw_conv_kernel(const PwParams Q) {
     for (int t = 0; t < 4; ++t) wl[t] = (p + t < P) ? (Q.rw ? Q.rw[(size_t)b * P + p + t] : 1.f) : 0.f;
     float *db = const_cast<float *>(D.ptr) + (size_t)b * D.sample_stride;
     const bool dfast = pfull;
-    __shared__ double s_red[NW][64][2];
+    __shared__ double s_red[NW][OC][2];
     const bool stats = Q.sums != nullptr;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < VB; ++v) {
         if (16 * v >= nout) break;
         const bool cfull = 16 * v + 16 <= nout;
         f4 y[4];
@@ -241,7 +284,7 @@ __global__ __launch_bounds__(64 * NW) void pw_conv_kernel(const PwParams Q) {
 #pragma unroll
             for (int w = 0; w < NW; ++w) { a0 += s_red[w][threadIdx.x][0]; a1 += s_red[w][threadIdx.x][1]; }
             const int grp = b / (Q.samples / Q.groups);
-            double *dst = Q.sums + ((size_t)grp * Q.stat_channels + orow0 + threadIdx.x) * 2;
+            double *dst = rtk_stat_slot(Q.sums, (size_t)Q.groups * Q.stat_channels * 2, b) + ((size_t)grp * Q.stat_channels + orow0 + threadIdx.x) * 2;
             atomicAdd(dst, a0);
             atomicAdd(dst + 1, a1);
         }
@@ -262,16 +305,21 @@ __device__ __forceinline__ void pw_load_frags(const PwOp &op, const float *base,
             for (int s = 0; s < 4; ++s) val[blk][s] = (c0 + pw_frag_channel(0, blk, i) == 0 && pq + s < P) ? 1.f : 0.f;
         return;
     }
-    if (fastp && op.layout == 1 && c0 + 4 * i + 4 <= op.channels) {
+    // vector paths: unconditional loads from clamped addresses, zeros selected afterwards (see pw_load_block)
+    if (fastp && op.layout == 1 && (op.channels & 3) == 0) {
+        const int cc = min(c0 + 4 * i, op.channels - 4);
         f4 q[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) q[s] = pw_ld4(base + (size_t)(pq + s) * op.pitch + c0 + 4 * i);
+        for (int s = 0; s < 4; ++s) q[s] = pw_ld4(base + (size_t)(pq + s) * op.pitch + cc);
+        const bool ok = c0 + 4 * i < op.channels;
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk) val[blk] = (f4){q[0][blk], q[1][blk], q[2][blk], q[3][blk]};
+        for (int blk = 0; blk < 4; ++blk) val[blk] = ok ? (f4){q[0][blk], q[1][blk], q[2][blk], q[3][blk]} : f4_zero();
     } else if (fastp && op.layout == 0) {
 #pragma unroll
+        for (int blk = 0; blk < 4; ++blk) val[blk] = pw_ld4(base + (size_t)min(c0 + 16 * blk + i, op.channels - 1) * op.pitch + pq);
+#pragma unroll
         for (int blk = 0; blk < 4; ++blk)
-            val[blk] = c0 + 16 * blk + i < op.channels ? pw_ld4(base + (size_t)(c0 + 16 * blk + i) * op.pitch + pq) : f4_zero();
+            if (c0 + 16 * blk + i >= op.channels) val[blk] = f4_zero();
     } else {
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk)
@@ -291,6 +339,7 @@ struct PwWgParams {
     unsigned char chunk_src[40];
     short chunk_c0[40];
     int tiles_per_wg;               // (sample, 16-position tile) pairs per workgroup
+    float *partial;                 // gridDim.z > 1: [z][block = y * nchunks + x][64 x 64] workgroup partials (pw_wgrad_reduce_kernel adds them)
 };
 
 __global__ __launch_bounds__(PW_T, 2) void pw_wgrad_kernel(const PwWgParams Q) {
@@ -315,26 +364,23 @@ __global__ __launch_bounds__(PW_T, 2) void pw_wgrad_kernel(const PwWgParams Q) {
         pw_load_frags(Q.dz, Q.dz.ptr + (size_t)b * Q.dz.sample_stride, o0, j, pq, P, pfull, A);
         pw_load_frags(S, sbase ? sbase + (size_t)b * S.sample_stride : nullptr, k0, j, pq, P, pfull, B);
     };
-    f4 A[4], B[4];
+    // operands of the next two tiles are in flight during a tile's 64 MFMAs (a tile is 0.85 us of matrix work, a round trip to HBM more)
+    constexpr int STEP = PW_T / 64;
+    f4 A[4], B[4], A1[4], B1[4];
     long t = t_begin + wave;
     if (t < t_end) fetch(t, A, B);
-    for (; t < t_end; t += PW_T / 64) {
-        f4 An[4], Bn[4];
-        const bool more = t + PW_T / 64 < t_end;
-        if (more) fetch(t + PW_T / 64, An, Bn);       // the next tile's operands are in flight during this tile's 64 MFMAs
+    if (t + STEP < t_end) fetch(t + STEP, A1, B1);
+    for (; t < t_end; t += STEP) {
+        f4 A2[4], B2[4];
+        if (t + 2 * STEP < t_end) fetch(t + 2 * STEP, A2, B2);
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                acc[a][c] = mfma4(A[a].x, B[c].x, acc[a][c]);
-                acc[a][c] = mfma4(A[a].y, B[c].y, acc[a][c]);
-                acc[a][c] = mfma4(A[a].z, B[c].z, acc[a][c]);
-                acc[a][c] = mfma4(A[a].w, B[c].w, acc[a][c]);
-            }
-        if (more) {
+            for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { A[q] = An[q]; B[q] = Bn[q]; }
-        }
+                for (int c = 0; c < 4; ++c) acc[a][c] = mfma4(A[a][q], B[c][q], acc[a][c]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { A[q] = A1[q]; B[q] = B1[q]; A1[q] = A2[q]; B1[q] = B2[q]; }
     }
     // D layout: acc[a][c][r] = dW[o0 + chanA(a, 4g + r)][k0 + chanB(c, j)]; the four waves add into one LDS image in turn
     for (int w = 0; w < PW_T / 64; ++w) {
@@ -351,14 +397,48 @@ __global__ __launch_bounds__(PW_T, 2) void pw_wgrad_kernel(const PwWgParams Q) {
         }
         __syncthreads();
     }
+    if (gridDim.z > 1) {             // a partial block per workgroup, no atomics (a 64 x 64 block of float atomics per workgroup on
+                                     // 64..256 contended addresses cost more than the whole product)
+        float *dst = Q.partial + ((size_t)blockIdx.z * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4096;
+        for (int e = threadIdx.x; e < 64 * 64; e += PW_T) dst[e] = s_red[e >> 6][e & 63];
+        return;
+    }
     const int no = min(64, Q.dz.channels - o0), nk = min(64, S.channels - k0);
     for (int e = threadIdx.x; e < 64 * 64; e += PW_T) {
         const int o = e >> 6, k = e & 63;
         if (o < no && k < nk) {
             float *dst = S.layout == 2 ? Q.dbias + o0 + o : Q.dW + (size_t)(o0 + o) * Q.w_pitch + S.col0 + k0 + k;
-            atomicAdd(dst, s_red[o][k]);
+            *dst += s_red[o][k];                                   // this workgroup owns the block
         }
     }
+}
+
+// dW block (y, x) += sum over z of the workgroup partials.  A workgroup = 32 consecutive elements x 8 lanes over z (every load
+// independent: the sum over a few hundred partials is a latency problem, not a bandwidth one), then a fixed-order LDS reduction.
+__global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const PwWgParams Q, int splits, int ochunks) {
+    __shared__ float s_part[8][33];
+    const int el = threadIdx.x & 31, zl = threadIdx.x >> 5;
+    const int blk = blockIdx.x >> 7, e = (blockIdx.x & 127) * 32 + el;              // 128 workgroups per 64 x 64 block
+    const float *src = Q.partial + (size_t)blk * 4096 + e;
+    const size_t stride = (size_t)ochunks * Q.nchunks * 4096;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int z = zl;
+    for (; z + 24 < splits; z += 32) {
+        a0 += src[(size_t)z * stride]; a1 += src[(size_t)(z + 8) * stride]; a2 += src[(size_t)(z + 16) * stride]; a3 += src[(size_t)(z + 24) * stride];
+    }
+    for (; z < splits; z += 8) a0 += src[(size_t)z * stride];
+    s_part[zl][el] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (zl) return;
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sum += s_part[q][el];
+    const int x = blk % Q.nchunks, y = blk / Q.nchunks;
+    const PwOp &S = Q.src[Q.chunk_src[x]];
+    const int k0 = Q.chunk_c0[x], o0 = y * 64, o = e >> 6, k = e & 63;
+    if (o >= Q.dz.channels - o0 || k >= S.channels - k0) return;
+    float *dst = S.layout == 2 ? Q.dbias + o0 + o : Q.dW + (size_t)(o0 + o) * Q.w_pitch + S.col0 + k0 + k;
+    *dst += sum;
 }
 
 // ---- weight images (rtk_pack_weights) ---------------------------------------------------------------------------------------
@@ -414,12 +494,21 @@ extern "C" int rtk_pw_conv(int samples, int positions, int nsrc, const rtk_pw_op
         if (fill_op(Q.src[i], srcs[i], "pw_conv")) return RTK_ERR_INVALID;
         RTK_REQUIRE(srcs[i].layout != 2, "pw_conv: the constant-one operand is a wgrad source");
     }
+    // four waves sharing one staged 64-channel weight tile -- unless that leaves most of the chip idle (small batches): then one
+    // wave and one 16-channel block per workgroup
+    long big_wgs = 0;
+    for (int i = 0; i < ndst; ++i) big_wgs += (long)rtk_divup(dsts[i].channels, 64) * rtk_divup(positions, 256) * samples;
+    static const int force_nw = getenv("RTK_PW_NW") ? atoi(getenv("RTK_PW_NW")) : 0;      // experiment knobs (tools/exp_pw.py)
+    static const int force_vb = getenv("RTK_PW_VB") ? atoi(getenv("RTK_PW_VB")) : 0;
+    const bool small = force_nw == 1 || (force_nw != 4 && big_wgs < 192);
+    const int vb = small ? 1 : (force_vb ? force_vb : 4);
+    const int oc = 16 * vb;
     int nch = 0;
     for (int i = 0; i < ndst; ++i) {
         if (fill_op(Q.dst[i], dsts[i], "pw_conv")) return RTK_ERR_INVALID;
         RTK_REQUIRE(dsts[i].layout != 2, "pw_conv: bad destination layout");
-        for (int c0 = 0; c0 < dsts[i].channels; c0 += 64) {
-            RTK_REQUIRE(nch < 40, "pw_conv: more than 40 output chunks");
+        for (int c0 = 0; c0 < dsts[i].channels; c0 += oc) {
+            RTK_REQUIRE(nch < 96, "pw_conv: more than 96 output chunks");
             Q.chunk_dst[nch] = (unsigned char)i;
             Q.chunk_c0[nch++] = (short)c0;
         }
@@ -427,21 +516,16 @@ extern "C" int rtk_pw_conv(int samples, int positions, int nsrc, const rtk_pw_op
     Q.nchunks = nch;
     Q.W = w; Q.w_pitch = w_pitch; Q.transpose_w = transpose_w; Q.bias = bias; Q.rw = row_weight; Q.sums = sums;
     Q.stat_channels = stat_channels; Q.accumulate = accumulate;
-    // four waves sharing one staged weight tile -- unless that leaves most of the chip idle (small batches): then one wave each
-    static const int force_nw = getenv("RTK_PW_NW") ? atoi(getenv("RTK_PW_NW")) : 0;      // experiment knob (tools/exp_pw.py)
-    if (force_nw == 2) {
-        pw_conv_kernel<2><<<dim3(rtk_divup(positions, 128), nch, samples), 128, 0, (hipStream_t)stream>>>(Q);
-    } else if (force_nw != 1 && (force_nw == 4 || (long)rtk_divup(positions, 256) * nch * samples >= 192)) {
-        pw_conv_kernel<4><<<dim3(rtk_divup(positions, 256), nch, samples), 256, 0, (hipStream_t)stream>>>(Q);
-    } else {
-        pw_conv_kernel<1><<<dim3(rtk_divup(positions, 64), nch, samples), 64, 0, (hipStream_t)stream>>>(Q);
-    }
+    if (!small && vb == 4) pw_conv_kernel<4, 4><<<dim3(rtk_divup(positions, 256), nch, samples), 256, 0, (hipStream_t)stream>>>(Q);
+    else if (!small && vb == 2) pw_conv_kernel<4, 2><<<dim3(rtk_divup(positions, 256), nch, samples), 256, 0, (hipStream_t)stream>>>(Q);
+    else if (!small) pw_conv_kernel<4, 1><<<dim3(rtk_divup(positions, 256), nch, samples), 256, 0, (hipStream_t)stream>>>(Q);
+    else pw_conv_kernel<1, 1><<<dim3(rtk_divup(positions, 64), nch, samples), 64, 0, (hipStream_t)stream>>>(Q);
     RTK_CHECK_LAUNCH("pw_conv");
     return RTK_OK;
 }
 
 extern "C" int rtk_pw_wgrad(int samples, int positions, const rtk_pw_operand_t *dz, int nsrc, const rtk_pw_operand_t *srcs, float *dw,
-                            int w_pitch, float *dbias, rtk_stream_t stream) {
+                            int w_pitch, float *dbias, float *workspace, long workspace_floats, rtk_stream_t stream) {
     RTK_REQUIRE(samples > 0 && positions > 0 && dz && nsrc >= 1 && nsrc <= PW_MAXOP && srcs && dw, "pw_wgrad: bad arguments");
     PwWgParams Q = {};
     Q.samples = samples; Q.P = positions; Q.nsrc = nsrc; Q.dW = dw; Q.w_pitch = w_pitch; Q.dbias = dbias;
@@ -464,15 +548,24 @@ extern "C" int rtk_pw_wgrad(int samples, int positions, const rtk_pw_operand_t *
     Q.nchunks = nch;
     const long ntiles = (long)samples * ((positions + 15) / 16);
     const int ochunks = rtk_divup(dz->channels, 64);
-    // enough workgroups to fill the chip, few enough that the 64 x 64 atomics per workgroup stay a small share of its work
-    // about one workgroup per CU; at least one tile per wave behind every 64 x 64 block of atomics
-    long splits = (256 + (long)nch * ochunks - 1) / ((long)nch * ochunks);
-    if (splits > (ntiles + 3) / 4) splits = (ntiles + 3) / 4;
+    // about two workgroups per CU (more only adds partial blocks: tools/exp_pw.py), at least two tiles per wave, and no more
+    // position splits than the workspace holds partial blocks for
+    const long blocks = (long)nch * ochunks;
+    static const int want_wgs = getenv("RTK_WG_WGS") ? atoi(getenv("RTK_WG_WGS")) : 512;      // experiment knob
+    long splits = (want_wgs + blocks - 1) / blocks;
+    if (splits > (ntiles + 7) / 8) splits = (ntiles + 7) / 8;
+    if (splits > workspace_floats / (blocks * 4096)) splits = workspace ? workspace_floats / (blocks * 4096) : 1;
     if (splits < 1) splits = 1;
     Q.tiles_per_wg = (int)((ntiles + splits - 1) / splits);
-    const dim3 grid(nch, ochunks, (unsigned)((ntiles + Q.tiles_per_wg - 1) / Q.tiles_per_wg));
+    splits = (ntiles + Q.tiles_per_wg - 1) / Q.tiles_per_wg;
+    Q.partial = workspace;
+    const dim3 grid(nch, ochunks, (unsigned)splits);
     pw_wgrad_kernel<<<grid, PW_T, 0, (hipStream_t)stream>>>(Q);
     RTK_CHECK_LAUNCH("pw_wgrad");
+    if (splits > 1) {
+        pw_wgrad_reduce_kernel<<<(unsigned)(blocks * 128), 256, 0, (hipStream_t)stream>>>(Q, (int)splits, ochunks);
+        RTK_CHECK_LAUNCH("pw_wgrad_reduce");
+    }
     return RTK_OK;
 }
 

@@ -83,7 +83,7 @@ class Track4D(nn.Module):
                 with torch.no_grad():
                     tg = TP.TrainGeometry(torch.cat([pc1, pc2], 0).permute(0, 2, 1).contiguous(), self.pn_head.sa1.npoint)
                 f = TP.pnhead_train(self.pn_head, tg, torch.cat([feature1, feature2], 0), groups=2)
-                f1, f2, tg1 = f[:B], f[B:], tg.head(B)
+                (f1, f2), tg1 = f.view(2, B, f.shape[1], f.shape[2]).unbind(0), tg.head(B)
         if tg1 is None:
             xyz1_new, f1 = self.pn_head(pc1.permute(0, 2, 1).contiguous(), feature1)
             xyz2_new, f2 = self.pn_head(pc2.permute(0, 2, 1).contiguous(), feature2)

@@ -42,7 +42,7 @@ class _PwOperand(ctypes.Structure):      # rtk_pw_operand_t (include/rtk_train.h
 _PwP = ctypes.POINTER(_PwOperand)
 _lib.SIGNATURES.update({
     "rtk_pw_conv": [_i, _i, _i, _PwP, _i, _PwP, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p],
-    "rtk_pw_wgrad": [_i, _i, _PwP, _i, _PwP, _p, _i, _p, _p],
+    "rtk_pw_wgrad": [_i, _i, _PwP, _i, _PwP, _p, _i, _p, _p, ctypes.c_long, _p],
     "rtk_backbone_loss": [_i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p],
     "rtk_pack_weights": [_i, _p, _p],
     "rtk_weightnet_bwd": [ctypes.c_long, _i] + [_p] * 13 + [_p],
@@ -59,20 +59,24 @@ def _stream():
 # step.  With an arena (Trainer enables it) they are slices of ONE buffer that is cleared ONCE at the start of the step.
 # Slices live until the next arena_begin_step(): long enough for the step's backward and optimizer (weight gradients handed to
 # autograd may be arena views).  Without an arena (plain autograd use, tests) every request is a torch.zeros().
-_ARENA = {}
+_ARENA = {}      # device -> [buffer, next free word, active, zeroed extent (words), demand of the current step (words)]
 
 
-def enable_zero_arena(device, nbytes=48 << 20):
+def enable_zero_arena(device, nbytes=64 << 20):
     dev = torch.device(device)
     if dev.type == "cuda" and dev not in _ARENA:
-        _ARENA[dev] = [torch.zeros(nbytes // 8, dtype=torch.float64, device=dev), 0, False]
+        _ARENA[dev] = [torch.zeros(nbytes // 8, dtype=torch.float64, device=dev), 0, False, 0, 0]
 
 
 def arena_begin_step(device):
+    """Clears as much of the arena as the previous step asked for (the first step of a shape therefore takes torch.zeros();
+    a captured step bakes in the extent of the warm-up steps before it, which ran the same shapes)."""
     a = _ARENA.get(torch.device(device))
     if a is not None:
-        a[0].zero_()
-        a[1], a[2] = 0, True
+        a[3] = min(a[0].numel(), max(a[3], a[4]))
+        if a[3]:
+            a[0][:a[3]].zero_()
+        a[1], a[2], a[4] = 0, True, 0
 
 
 def arena_end_step(device):
@@ -88,7 +92,8 @@ def _zeros(shape, dtype, device):
         n *= int(d)
     if a is not None and a[2]:
         words = (n * (8 if dtype == torch.float64 else 4) + 15) // 16 * 2          # float64 words, 16-byte granules
-        if a[1] + words <= a[0].numel():
+        a[4] += words
+        if a[1] + words <= a[3]:                                                   # inside the part cleared for this step
             sl = a[0][a[1]:a[1] + words]
             a[1] += words
             return (sl if dtype == torch.float64 else sl.view(torch.float32))[:n].view(shape)
@@ -108,7 +113,7 @@ class _BNReLU(torch.autograd.Function):
         if row_weight is not None:
             assert row_weight.shape == (S_, rows) and row_weight.dtype == torch.float32 and row_weight.is_contiguous()
         dev = z.device
-        sums = _zeros((groups, C, 2), torch.float64, dev)
+        sums = _zeros((STAT_SLOTS, groups, C, 2), torch.float64, dev)
         _lib.call("rtk_bn_train_stats", S_, C, rows, ns, groups, z.data_ptr(), _ptr(row_weight), sums.data_ptr(), _stream())
         par = torch.empty(4, groups, C, dtype=torch.float32, device=dev)
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
@@ -127,7 +132,7 @@ class _BNReLU(torch.autograd.Function):
         S_, C, rows, ns = z.shape
         dy = dy.contiguous()
         dev = z.device
-        sums2 = _zeros((groups, C, 2), torch.float64, dev)
+        sums2 = _zeros((STAT_SLOTS, groups, C, 2), torch.float64, dev)
         _lib.call("rtk_bn_relu_bwd_stats", S_, C, rows, ns, groups, z.data_ptr(), dy.data_ptr(), par.data_ptr(), int(pool),
                   sums2.data_ptr(), _stream())
         dz = torch.empty_like(z)
@@ -197,6 +202,10 @@ def _pw_forward(srcs, cols, W, bias, out, row_w=None, groups=1, sums=None):
               _ptr(bias), 0, _ptr(row_w), groups, _ptr(sums), out.shape[1], _stream())
 
 
+STAT_SLOTS = 8             # RTK_STAT_SLOTS (include/rtk_train.h): replicas of every batch-statistics buffer
+_WGRAD_WS = 4 << 20        # floats: 1024 partial 64 x 64 blocks (rtk_pw_wgrad splits the position axis as far as this allows)
+
+
 def _pw_backward(ctx_needs, srcs, cols, W, dz, want_bias, dW=None):
     """-> (dW (full shape of W, zero outside the used columns; accumulated into the given zero-initialised dW if any), dbias or
     None, [dsrc_i or None])."""
@@ -208,8 +217,9 @@ def _pw_backward(ctx_needs, srcs, cols, W, dz, want_bias, dW=None):
         dbias = buf[W.shape[0] * W.shape[1]:] if want_bias else None
     else:
         dbias = _zeros((Co,), torch.float32, dz.device) if want_bias else None
+    ws = torch.empty(_WGRAD_WS, dtype=torch.float32, device=dz.device)          # workgroup partials (uninitialised scratch)
     _lib.call("rtk_pw_wgrad", S_, P, _pw_operands([dz], [0]), len(srcs), _pw_operands(srcs, cols), dW.data_ptr(), dW.stride(0), _ptr(dbias),
-              _stream())
+              ws.data_ptr(), _WGRAD_WS, _stream())
     dsrcs = [None] * len(srcs)
     todo = [i for i in range(len(srcs)) if ctx_needs[i]]
     if todo:
@@ -275,7 +285,7 @@ class _PwBnRelu(torch.autograd.Function):
         S_, _, P = srcs[0].shape
         Co = W2.shape[0]
         dev = srcs[0].device
-        sums = _zeros((groups, Co, 2), torch.float64, dev)
+        sums = _zeros((STAT_SLOTS, groups, Co, 2), torch.float64, dev)
         z = torch.empty(S_, Co, P, dtype=torch.float32, device=dev)
         _pw_forward(srcs, cols, W2, None, z, row_w, groups, sums)
         par = _bn_finalize(bn, sums, count, groups)
@@ -292,7 +302,7 @@ class _PwBnRelu(torch.autograd.Function):
         S_, Co, P = z.shape
         dev = z.device
         dy = dy.contiguous()
-        sums2 = _zeros((groups, Co, 2), torch.float64, dev)
+        sums2 = _zeros((STAT_SLOTS, groups, Co, 2), torch.float64, dev)
         _lib.call("rtk_bn_relu_bwd_stats", S_, Co, P, 1, groups, z.data_ptr(), dy.data_ptr(), par.data_ptr(), 0, sums2.data_ptr(), _stream())
         dz = torch.empty_like(z)
         dgb = torch.empty(2, Co, dtype=torch.float32, device=dev)
@@ -327,16 +337,16 @@ def _bn_finalize(bn, sums, count, groups):
 
 class _SumsPool:
     """The float64 statistics buffers of one chain pass, zeroed with ONE fill: call with a channel count to get the next
-    (groups, C, 2) slice."""
+    (STAT_SLOTS, groups, C, 2) slice."""
 
     def __init__(self, groups, channels, device):
         self.groups = groups
-        self.buf = _zeros((groups * 2 * sum(channels),), torch.float64, device)
+        self.buf = _zeros((STAT_SLOTS * groups * 2 * sum(channels),), torch.float64, device)
         self.off = 0
 
     def __call__(self, c):
-        n = self.groups * c * 2
-        t = self.buf[self.off:self.off + n].view(self.groups, c, 2)
+        n = STAT_SLOTS * self.groups * c * 2
+        t = self.buf[self.off:self.off + n].view(STAT_SLOTS, self.groups, c, 2)
         self.off += n
         return t
 
@@ -810,7 +820,7 @@ def gru_step(x, h_in, gru):
 # ---- multi-task loss -------------------------------------------------------------------------------------------------------------
 
 class _BackboneLoss(torch.autograd.Function):
-    """loss.backbone_loss (values and gradients) as one kernel: -> items (4) = [Loss, SceneFlowLoss, TrackingLoss, SegLoss]."""
+    """loss.backbone_loss (values and gradients) as one kernel: -> (Loss, items (4) = [Loss, SceneFlowLoss, TrackingLoss, SegLoss])."""
 
     @staticmethod
     def forward(ctx, flow, cls, pc1, gt_warp, gt_cls, pretrain):
@@ -826,17 +836,17 @@ class _BackboneLoss(torch.autograd.Function):
         _lib.call("rtk_backbone_loss", B, N, pc1.data_ptr(), flow.data_ptr(), gt_warp.data_ptr(), cls.data_ptr(), g.data_ptr(), stride,
                   int(bool(pretrain)), items.data_ptr(), _ptr(dflow), dcls.data_ptr(), _stream())
         ctx.save_for_backward(dflow, dcls)
-        return items
+        ctx.mark_non_differentiable(items)
+        return items[0], items                           # the differentiable total as its own output: no select_backward (zeros + copy)
 
     @staticmethod
-    def backward(ctx, ditems):
+    def backward(ctx, g, _):
         dflow, dcls = ctx.saved_tensors
-        g = ditems[0]                                    # the caller differentiates items[0] (= Loss)
         return (None if dflow is None else dflow * g), dcls * g, None, None, None, None
 
 
 def backbone_loss(pc1, flow, cls, gt_warp, gt_cls, pretrain=False):
     """(total, items dict) of loss.backbone_loss(pc1 + flow, cls, gt_warp, gt_cls, pretrain) with total = items['Loss'];
     CUDA fp32 only."""
-    it = _BackboneLoss.apply(flow, cls, pc1, gt_warp, gt_cls, bool(pretrain))
-    return it[0], {"Loss": it[0], "SceneFlowLoss": it[1], "TrackingLoss": it[2], "SegLoss": it[3]}
+    total, it = _BackboneLoss.apply(flow, cls, pc1, gt_warp, gt_cls, bool(pretrain))
+    return total, {"Loss": total, "SceneFlowLoss": it[1], "TrackingLoss": it[2], "SegLoss": it[3]}

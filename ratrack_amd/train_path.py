@@ -179,16 +179,16 @@ def correlator_train(fc, pc1, pc2, feature1, feature2):
     D1, D2 = feature1.shape[1], feature2.shape[1]
     knn = knn_point(16, x2, x1).contiguous()
     conv0, conv1, conv2 = fc.mlp_convs
-    w0 = conv0.weight[:, :, 0, 0]
+    w0 = conv0.weight.flatten(1)              # (a view whose backward is a view: `weight[:, :, 0, 0]` would cost two zeros + copy)
     # layer 1 of the cost-volume MLP split by input segment: per-point projections of both frames' features, written point-major
     p1 = pw_linear([feature1], conv0.weight, conv0.bias, cols=[0], out_point_major=True).permute(0, 2, 1).reshape(B * N1, 256)
     p2 = pw_linear([feature2], conv0.weight, None, cols=[D1], out_point_major=True).permute(0, 2, 1).reshape(-1, 256)
     wn = fc.weightnet1.mlp_convs
-    x = cost_volume(p1, p2, w0[:, D1 + D2:], conv1.weight[:, :, 0, 0], conv1.bias, conv2.weight[:, :, 0, 0], conv2.bias,
-                    wn[0].weight[:, :, 0, 0], wn[0].bias, wn[1].weight[:, :, 0, 0], wn[1].bias, wn[2].weight[:, :, 0, 0],
+    x = cost_volume(p1, p2, w0[:, D1 + D2:], conv1.weight.flatten(1), conv1.bias, conv2.weight.flatten(1), conv2.bias,
+                    wn[0].weight.flatten(1), wn[0].bias, wn[1].weight.flatten(1), wn[1].bias, wn[2].weight.flatten(1),
                     wn[2].bias, x1, x2, knn)                                   # (B*N1, 256) point-major
     knn = knn_point(16, x1, x1).contiguous()
     wn = fc.weightnet2.mlp_convs
-    x = patch_cost(x, wn[0].weight[:, :, 0, 0], wn[0].bias, wn[1].weight[:, :, 0, 0], wn[1].bias, wn[2].weight[:, :, 0, 0],
+    x = patch_cost(x, wn[0].weight.flatten(1), wn[0].bias, wn[1].weight.flatten(1), wn[1].bias, wn[2].weight.flatten(1),
                    wn[2].bias, x1, knn)
     return x.view(B, N1, 256).permute(0, 2, 1)

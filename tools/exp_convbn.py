@@ -11,7 +11,7 @@ x = torch.randn(S_, C, rows, ns, device=dev, generator=g); z = torch.empty_like(
 w = torch.randn(C, C, device=dev, generator=g) * 0.1
 par = torch.rand(4, groups, C, device=dev, generator=g) + 0.5
 rw = torch.ones(S_, rows, device=dev)
-sums = torch.zeros(groups, C, 2, dtype=torch.float64, device=dev); dw = torch.zeros(C, C, device=dev)
+sums = torch.zeros(8, groups, C, 2, dtype=torch.float64, device=dev); dw = torch.zeros(C, C, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 def t(name, fn, bytes_):
     for _ in range(3): fn()

@@ -25,7 +25,11 @@ sites = collections.defaultdict(collections.Counter)
 class Log(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func)
-        if not any(k in name for k in NOKERNEL):
+        sliced = any(k in name for k in ("slice", "select", "narrow", "split", "unbind", "index")) and "backward" not in name and \
+            any(isinstance(a, torch.Tensor) and a.requires_grad for a in args)
+        if sliced:                       # a differentiable slice: its built-in backward is a zeros + copy (+ an add where slices meet)
+            name = "GRADVIEW " + name
+        if sliced or "backward" in name or not any(k in name for k in NOKERNEL):
             site = "(autograd built-in backward)"
             for fr in reversed(traceback.extract_stack()):
                 if fr.filename.startswith(ROOT) and "/tools/" not in fr.filename:
