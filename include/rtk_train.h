@@ -119,11 +119,12 @@ RTK_EXPORT int rtk_conv_bn_bwd(int samples, int cprev, int cout, int rows, int n
                                const float *zprev, const float *pre_par, const float *row_weight, double *sums2, double count, int apply,
                                float *dzprev, float *dgamma_dbeta, rtk_stream_t stream);
 
-/* Weight gradient of the same layer: dw (cout, cprev) row-major fp32, ZERO-INITIALISED by the caller,
- * += sum over samples and positions of dz (x) relu(BatchNorm(zprev)); the normalised activation is recomputed from zprev
- * and pre_par on load.  Accumulated with float atomics (order-dependent in the last bits). */
+/* Weight gradient of the same layer: dw (cout, cprev) row-major fp32 += sum over samples and positions of
+ * dz (x) relu(BatchNorm(zprev)); the normalised activation is recomputed from zprev and pre_par on load.  One partial block per
+ * workgroup goes through `workspace` (uninitialised, >= samples * cout * cprev floats; 1024 blocks = full parallelism) and a
+ * second kernel adds them in a fixed order: no atomics, deterministic. */
 RTK_EXPORT int rtk_conv_wgrad(int samples, int cprev, int cout, int rows, int ns, int groups, const float *dz, const float *zprev,
-                              const float *pre_par, float *dw, rtk_stream_t stream);
+                              const float *pre_par, float *dw, float *workspace, long workspace_floats, rtk_stream_t stream);
 
 /* ---- per-point layers: 1x1 convolutions on one row per point / centroid (feature propagation, nn.Linear bottlenecks, layer-1
  * feature projections, predictor heads: lib/pointnet2_modules.py:140-158, utils/model_utils/model_utils.py:308-357,393-424) -----
@@ -220,10 +221,12 @@ RTK_EXPORT int rtk_scatter_add_rows(int samples, int m, int n, int channels, con
 
 /* Parameter gradients of a WeightNet(3 -> 8 -> 8 -> C) (utils/model_utils/model_utils.py:359-390) from what rtk_cost_volume_bwd /
  * rtk_patch_cost_bwd emit per position: d4 (M,4), dq3 (M,C), dt2 (M,8).  wa (8,3) ba (8) wb (8,8) bb (8) row-major live weights;
- * dwa (8,3) dba (8) dwb (8,8) dbb (8) dwc (C,8) dbc (C), all ZERO-INITIALISED by the caller, accumulated with float atomics. */
+ * dwa (8,3) dba (8) dwb (8,8) dbb (8) dwc (C,8) dbc (C) are added to (zeros for a plain gradient).  Workgroup partial vectors of
+ * (9C + 104) floats go through `workspace` (uninitialised, >= one vector; 1024 vectors = full parallelism) and are added up in a
+ * fixed order by a second kernel: no atomics, deterministic. */
 RTK_EXPORT int rtk_weightnet_bwd(long positions, int channels, const float *d4, const float *dq3, const float *dt2, const float *wa,
                                  const float *ba, const float *wb, const float *bb, float *dwa, float *dba, float *dwb, float *dbb,
-                                 float *dwc, float *dbc, rtk_stream_t stream);
+                                 float *dwc, float *dbc, float *workspace, long workspace_floats, rtk_stream_t stream);
 
 /* Multi-task loss of the backbone trainer (losses/loss.py:8-31,85-89,124-146, batch mean) and its gradients in one launch.
  * pc1, flow, gt_warp (B,3,N) contiguous; cls (B,N) probabilities; gt_cls uint8/bool, sample b's row at gt_cls + b*gt_cls_stride

@@ -21,6 +21,26 @@ def _time(fn, iters):
     return e0.elapsed_time(e1) / iters          # ms per launch, on the launch stream
 
 
+def time_graph(fn, reps=20, replays=5):
+    """ms per launch from a replayed hipGraph of `reps` launches of fn (an eager ctypes launch costs ~10 us: too coarse for the
+    microsecond kernels of the training path)."""
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(replays):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (replays * reps)
+
+
 def irregular_ops(batch, n, dev, npoint=512, iters=20, pmc=None):
     """One entry per irregular kernel of a forward / train step at B=batch frame-pairs of n points (2B clouds through the
     shared encoder): launches per step, ms per launch (HIP events, back-to-back launches on the current stream), the

@@ -140,19 +140,21 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void pointwise_mlp_kernel(const PwPa
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (u < ustart[0]) {
+                    // unconditional loads (lanes past the last channel re-read channel 0 and discard): a load under a per-lane
+                    // condition is a basic block of its own and the compiler waits for it before issuing the next one
                     const int c = 16 * u + 4 * g;
-                    if (c < P.interp.channels) {
-                        const f4 a0 = *reinterpret_cast<const f4 *>(k0 + c);
-                        const f4 a1 = *reinterpret_cast<const f4 *>(k1 + c);
-                        const f4 a2 = *reinterpret_cast<const f4 *>(k2 + c);
-                        // interpolate_gpu.cu:168  w0*p0 + w1*p1 + w2*p2  (nvcc: fma(w2,p2,fma(w1,p1,w0*p0)))
-                        h[u].x = __fmaf_rn(w2, a2.x, __fmaf_rn(w1, a1.x, __fmul_rn(w0, a0.x)));
-                        h[u].y = __fmaf_rn(w2, a2.y, __fmaf_rn(w1, a1.y, __fmul_rn(w0, a0.y)));
-                        h[u].z = __fmaf_rn(w2, a2.z, __fmaf_rn(w1, a1.z, __fmul_rn(w0, a0.z)));
-                        h[u].w = __fmaf_rn(w2, a2.w, __fmaf_rn(w1, a1.w, __fmul_rn(w0, a0.w)));
-                    } else {
-                        h[u] = f4_zero();
-                    }
+                    const bool ok = c < P.interp.channels;
+                    const int cc = ok ? c : 0;
+                    const f4 a0 = *reinterpret_cast<const f4 *>(k0 + cc);
+                    const f4 a1 = *reinterpret_cast<const f4 *>(k1 + cc);
+                    const f4 a2 = *reinterpret_cast<const f4 *>(k2 + cc);
+                    // interpolate_gpu.cu:168  w0*p0 + w1*p1 + w2*p2  (nvcc: fma(w2,p2,fma(w1,p1,w0*p0)))
+                    f4 v;
+                    v.x = __fmaf_rn(w2, a2.x, __fmaf_rn(w1, a1.x, __fmul_rn(w0, a0.x)));
+                    v.y = __fmaf_rn(w2, a2.y, __fmaf_rn(w1, a1.y, __fmul_rn(w0, a0.y)));
+                    v.z = __fmaf_rn(w2, a2.z, __fmaf_rn(w1, a1.z, __fmul_rn(w0, a0.z)));
+                    v.w = __fmaf_rn(w2, a2.w, __fmaf_rn(w1, a1.w, __fmul_rn(w0, a0.w)));
+                    h[u] = ok ? v : f4_zero();
                 }
             }
         }
@@ -160,6 +162,7 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void pointwise_mlp_kernel(const PwPa
         // per-lane row base of every source (row = point, or sample for broadcast sources), then one
         // load per 16-channel slot from the source that owns it (selection is wave-uniform)
         const float *rowp[RTK_MAX_SRC];
+        const float *dummy = reinterpret_cast<const float *>(P.layer[0].w_packed);      // any readable 16-byte aligned address
 #pragma unroll
         for (int q = 0; q < RTK_MAX_SRC; ++q)
             rowp[q] = q < P.nsrc ? P.src[q].ptr + (P.src[q].per_sample ? (size_t)b : (size_t)p) * P.src[q].pitch + 4 * g : nullptr;
@@ -172,7 +175,9 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void pointwise_mlp_kernel(const PwPa
                 for (int q = 1; q < RTK_MAX_SRC; ++q)
                     if (q < P.nsrc && u >= ustart[q]) { rp = rowp[q]; us = ustart[q]; ch = P.src[q].channels; }
                 const int c = 16 * (u - us);
-                h[u] = (u < uend && c + 4 * g < ch) ? *reinterpret_cast<const f4 *>(rp + c) : f4_zero();
+                const bool ok = u < uend && c + 4 * g < ch;
+                const f4 v = *reinterpret_cast<const f4 *>(ok ? rp + c : dummy);       // unconditional load, see above
+                h[u] = ok ? v : f4_zero();
             }
         }
 

@@ -39,6 +39,7 @@ struct TcParams {
     double *sums;           // (groups, 16V, 2)
     double count;
     float *dgb;             // backward pass 1: (2, 16V) dgamma | dbeta
+    float *partial;         // weight gradient: one (16V, 16U) partial block per workgroup
 };
 
 // MODE 0: forward.  MODE 1: backward statistics.  MODE 2: backward apply.
@@ -284,31 +285,42 @@ __global__ __launch_bounds__(TC_T, 2) void conv_wgrad_kernel(const TcParams Q) {
 #pragma unroll
         for (int u = 0; u < U; ++u) acc[v][u] = f4_zero();
     const int ntiles = (P + 15) / 16;
-    for (int t = blockIdx.x * (TC_T / 64) + wave; t < ntiles; t += gridDim.x * (TC_T / 64)) {
+    // unconditional loads (tail lanes re-read the last float4 of the plane and are zeroed afterwards: a load under a per-lane
+    // condition is a basic block of its own, waited for before the next one is issued); the next tile's operands are requested
+    // before this tile's MFMAs
+    auto fetch = [&](int t, f4 (&a)[V], f4 (&x)[U]) {
         const int p = 16 * t + 4 * g;
-        const bool ok = p < P;
+        const unsigned po = 4u * (unsigned)(p < P ? p : P - 4);
+#pragma unroll
+        for (int v = 0; v < V; ++v) a[v] = *reinterpret_cast<const f4 *>(dzb + (unsigned)(16 * v + j) * pitch + po);
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = *reinterpret_cast<const f4 *>(zpb + (unsigned)(16 * u + j) * pitch + po);
+    };
+    const int tstep = gridDim.x * (TC_T / 64);
+    int t = blockIdx.x * (TC_T / 64) + wave;
+    f4 an[V], xn[U];
+    if (t < ntiles) fetch(t, an, xn);
+    for (; t < ntiles; t += tstep) {
+        const bool ok = 16 * t + 4 * g < P;
         f4 a[V], bq[U];
 #pragma unroll
-        for (int v = 0; v < V; ++v)
-            a[v] = ok ? *reinterpret_cast<const f4 *>(dzb + (unsigned)(16 * v + j) * pitch + 4u * (unsigned)p) : f4_zero();
+        for (int v = 0; v < V; ++v) a[v] = ok ? an[v] : f4_zero();
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            f4 x = ok ? *reinterpret_cast<const f4 *>(zpb + (unsigned)(16 * u + j) * pitch + 4u * (unsigned)p) : f4_zero();
+            f4 x = xn[u];
             x.x = fmaxf(__fmaf_rn(x.x, sc[u], sh[u]), 0.f);
             x.y = fmaxf(__fmaf_rn(x.y, sc[u], sh[u]), 0.f);
             x.z = fmaxf(__fmaf_rn(x.z, sc[u], sh[u]), 0.f);
             x.w = fmaxf(__fmaf_rn(x.w, sc[u], sh[u]), 0.f);
-            bq[u] = ok ? x : f4_zero();
+            bq[u] = x;
         }
+        if (t + tstep < ntiles) fetch(t + tstep, an, xn);
 #pragma unroll
-        for (int v = 0; v < V; ++v)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                acc[v][u] = mfma4(a[v].x, bq[u].x, acc[v][u]);
-                acc[v][u] = mfma4(a[v].y, bq[u].y, acc[v][u]);
-                acc[v][u] = mfma4(a[v].z, bq[u].z, acc[v][u]);
-                acc[v][u] = mfma4(a[v].w, bq[u].w, acc[v][u]);
-            }
+            for (int v = 0; v < V; ++v)
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc[v][u] = mfma4(a[v][q], bq[u][q], acc[v][u]);
     }
     // D layout: acc[v][u][r] = dW[16v + 4g + r][16u + j]; the four waves add into one LDS image in turn
     for (int w = 0; w < TC_T / 64; ++w) {
@@ -325,11 +337,36 @@ __global__ __launch_bounds__(TC_T, 2) void conv_wgrad_kernel(const TcParams Q) {
         }
         __syncthreads();
     }
-    for (int e = threadIdx.x; e < 16 * V * 16 * U; e += TC_T) {
-        const int co = e / (16 * U), ci = e % (16 * U);
-        const float sum = s_red[co][ci];
-        atomicAdd(Q.out + (size_t)co * 16 * U + ci, sum);
+    // this workgroup's partial dW: plain stores, added up in a fixed order by conv_wgrad_reduce_kernel (as float atomics, 256 U V per
+    // workgroup and up to 512 workgroups deep on every address, they were a large part of the kernel)
+    float *part = Q.partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (256 * U * V);
+    for (int e = threadIdx.x; e < 16 * V * 16 * U; e += TC_T) part[e] = s_red[e / (16 * U)][e % (16 * U)];
+}
+
+// dw[e] += sum over the workgroups' partials: 16 outputs x 16 lanes over the workgroup axis, eight independent loads per lane and round
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(int n, int wgs, const float *__restrict__ partial, float *__restrict__ dw) {
+    __shared__ float s_part[16][17];
+    const int el = threadIdx.x & 15, zl = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
+    const float *src = partial + (e < n ? e : n - 1);
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = 0.f;
+    for (int z0 = zl; z0 < wgs; z0 += 128) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int z = z0 + 16 * k;
+            const float v = src[(size_t)(z < wgs ? z : 0) * n];
+            a[k] += z < wgs ? v : 0.f;
+        }
     }
+    s_part[zl][el] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    if (zl || e >= n) return;
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sum += s_part[q][el];
+    dw[e] += sum;
 }
 
 int ilog2x(int v) {
@@ -407,22 +444,26 @@ extern "C" int rtk_conv_bn_bwd(int samples, int cprev, int cout, int rows, int n
 }
 
 extern "C" int rtk_conv_wgrad(int samples, int cprev, int cout, int rows, int ns, int groups, const float *dz, const float *zprev,
-                              const float *pre_par, float *dw, rtk_stream_t stream) {
+                              const float *pre_par, float *dw, float *workspace, long workspace_floats, rtk_stream_t stream) {
     if (int rc = check("rtk_conv_wgrad", samples, cprev, cout, rows, ns, groups)) return rc;
-    RTK_REQUIRE(dz && zprev && pre_par && dw, "rtk_conv_wgrad: null argument");
+    RTK_REQUIRE(dz && zprev && pre_par && dw && workspace, "rtk_conv_wgrad: null argument");
     TcParams Q = {};
     Q.samples = samples; Q.rows = rows; Q.lg_ns = ilog2x(ns); Q.groups = groups; Q.P = rows * ns;
-    Q.in = dz; Q.zprev = zprev; Q.pre = pre_par; Q.out = dw;
+    Q.in = dz; Q.zprev = zprev; Q.pre = pre_par; Q.out = dw; Q.partial = workspace;
     const int U = cprev / 16, V = cout / 16;
     const int ntiles = (Q.P + 15) / 16;
-    int gx = (ntiles + 3) / 4;
-    while ((long)gx * samples > 512 && gx > 1) gx = (gx + 1) / 2;      // every workgroup ends with 256 U V atomics: keep them few
-    const dim3 grid(gx, samples);
+    RTK_REQUIRE(workspace_floats >= (long)samples * cprev * cout, "rtk_conv_wgrad: workspace of %ld floats < %ld", workspace_floats,
+                (long)samples * cprev * cout);
+    int gx = (ntiles + 7) / 8;                                           // at least two tiles per wave ...
+    while (((long)gx * samples > 1024 || (long)gx * samples * cprev * cout > workspace_floats) && gx > 1) gx = (gx + 1) / 2;
+    const dim3 grid(gx, samples);                                        // ... and about four workgroups (one partial dW each) per CU
     hipStream_t s = (hipStream_t)stream;
 #define TW_CASE(u, v)                                        \
     if (U == u && V == v) conv_wgrad_kernel<u, v><<<grid, TC_T, 0, s>>>(Q);
     TW_CASE(1, 1) TW_CASE(1, 2) TW_CASE(1, 4) TW_CASE(2, 1) TW_CASE(2, 2) TW_CASE(2, 4) TW_CASE(4, 1) TW_CASE(4, 2) TW_CASE(4, 4)
 #undef TW_CASE
+    RTK_CHECK_LAUNCH("rtk_conv_wgrad");
+    conv_wgrad_reduce_kernel<<<(cprev * cout + 15) / 16, 256, 0, s>>>(cprev * cout, gx * samples, workspace, dw);
     RTK_CHECK_LAUNCH("rtk_conv_wgrad");
     return RTK_OK;
 }

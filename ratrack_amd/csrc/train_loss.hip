@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 #include "rtk_common.h"
 #include "rtk_train.h"
 
@@ -106,19 +108,27 @@ __global__ __launch_bounds__(256) void weightnet_bwd_kernel(long M, int C, int s
                                                             const float *__restrict__ dq3, const float *__restrict__ dt2,
                                                             const float *__restrict__ wa, const float *__restrict__ ba,
                                                             const float *__restrict__ wb, const float *__restrict__ bb,
-                                                            float *__restrict__ dwa, float *__restrict__ dba, float *__restrict__ dwb,
-                                                            float *__restrict__ dbb, float *__restrict__ dwc, float *__restrict__ dbc) {
-    __shared__ float s_t1[WN_SUB][9], s_t2[WN_SUB][9], s_g1[WN_SUB][9], s_g2[WN_SUB][9], s_d[WN_SUB][4];
+                                                            float *__restrict__ partial, int partial_pitch) {
+    __shared__ float s_t1[WN_SUB][9], s_g1[WN_SUB][9], s_g2[WN_SUB][9], s_d[WN_SUB][4];
+    __shared__ __attribute__((aligned(16))) float s_t2[WN_SUB][8];      // read as two float4 per position (broadcast) in the dWc loop
     __shared__ float s_wa[8][3], s_ba[8], s_wb[8][8], s_bb[8];
     const int t = threadIdx.x;
     if (t < 24) s_wa[t / 3][t % 3] = wa[t];
     if (t < 8) { s_ba[t] = ba[t]; s_bb[t] = bb[t]; }
     if (t < 64) s_wb[t >> 3][t & 7] = wb[t];
     __syncthreads();
-    float accc[8][2];      // this thread's channels c = t and t + 256 (C <= 512): dWc[c][0..7]
-    float accb[2] = {0.f, 0.f};
+    // dWc / dbc: a thread owns FOUR consecutive channels (one float4 per dq3 row: 4x the bytes in flight of a thread-per-channel
+    // mapping, which left this stream at 1.3 TB/s) of the rows p = phase (mod 4), phase = its wave; two passes cover C <= 512
+    const int cq = (t & 63) * 4, ph = t >> 6;
+    float accc[2][4][8], accb[2][4];
 #pragma unroll
-    for (int h = 0; h < 8; ++h) { accc[h][0] = 0.f; accc[h][1] = 0.f; }
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            accb[q][i] = 0.f;
+#pragma unroll
+            for (int h = 0; h < 8; ++h) accc[q][i][h] = 0.f;
+        }
     float small = 0.f;     // threads 0..103: one element of dWb (64) | dbb (8) | dWa (24) | dba (8)
     for (int sb = 0; sb < sub_per_wg; ++sb) {
         const long m0 = ((long)blockIdx.x * sub_per_wg + sb) * WN_SUB;
@@ -129,6 +139,8 @@ __global__ __launch_bounds__(256) void weightnet_bwd_kernel(long M, int C, int s
             const long m = m0 + t;
             const float dx = d4[m * 4 + 0], dy = d4[m * 4 + 1], dz = d4[m * 4 + 2];
             float t1[8], t2[8], g2[8];
+            const float4 dta = *reinterpret_cast<const float4 *>(dt2 + m * 8), dtb = *reinterpret_cast<const float4 *>(dt2 + m * 8 + 4);
+            const float dtv[8] = {dta.x, dta.y, dta.z, dta.w, dtb.x, dtb.y, dtb.z, dtb.w};
 #pragma unroll
             for (int k = 0; k < 8; ++k) t1[k] = fmaxf(s_wa[k][0] * dx + s_wa[k][1] * dy + s_wa[k][2] * dz + s_ba[k], 0.f);
 #pragma unroll
@@ -137,7 +149,7 @@ __global__ __launch_bounds__(256) void weightnet_bwd_kernel(long M, int C, int s
 #pragma unroll
                 for (int k = 0; k < 8; ++k) a += s_wb[h][k] * t1[k];
                 t2[h] = fmaxf(a, 0.f);
-                g2[h] = t2[h] > 0.f ? dt2[m * 8 + h] : 0.f;
+                g2[h] = t2[h] > 0.f ? dtv[h] : 0.f;
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -150,16 +162,31 @@ __global__ __launch_bounds__(256) void weightnet_bwd_kernel(long M, int C, int s
             s_d[t][0] = dx; s_d[t][1] = dy; s_d[t][2] = dz;
         }
         __syncthreads();
-        // dWc / dbc: thread = channel, loop over the sub-block's positions (rows of dq3 are read coalesced)
+        // eight rows in flight per thread: unconditional loads from clamped rows, zeros selected afterwards
+#pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int c = t + 256 * q;
+            const int c = cq + 256 * q;
             if (c >= C) break;
             const float *col = dq3 + m0 * C + c;
-            for (int p = 0; p < cnt; ++p) {
-                const float v = col[(long)p * C];
-                accb[q] += v;
+            for (int p0 = ph; p0 < cnt; p0 += 32) {
+                float4 v[8];
 #pragma unroll
-                for (int h = 0; h < 8; ++h) accc[h][q] += v * s_t2[p][h];
+                for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4 *>(col + (long)min(p0 + 4 * k, cnt - 1) * C);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int row = p0 + 4 * k;
+                    if (row >= cnt) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int rr = min(row, cnt - 1);
+                    const float4 ta = *reinterpret_cast<const float4 *>(&s_t2[rr][0]), tb = *reinterpret_cast<const float4 *>(&s_t2[rr][4]);
+                    const float th[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+                    const float vv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        accb[q][i] += vv[i];
+#pragma unroll
+                        for (int h = 0; h < 8; ++h) accc[q][i][h] += vv[i] * th[h];
+                    }
+                }
             }
         }
         if (t < 104) {
@@ -171,32 +198,92 @@ __global__ __launch_bounds__(256) void weightnet_bwd_kernel(long M, int C, int s
             }
         }
     }
-    for (int q = 0; q < 2; ++q) {
-        const int c = t + 256 * q;
-        if (c >= C) break;
-        atomicAdd(dbc + c, accb[q]);
+    // this workgroup's partial gradients [dbc (C) | dWc (8C) | dWb (64) dbb (8) dWa (24) dba (8)]: plain stores, added up in a fixed
+    // order by weightnet_bwd_reduce_kernel.  (With float atomics on the 9C + 104 outputs -- 512 workgroups deep on every address --
+    // the kernel took 200 us for 38 us of streaming.)
+    // the four waves (row phases) add into one LDS image in turn, then the workgroup stores it
+    __shared__ float s_acc[9 * 512];
+    for (int w = 0; w < 4; ++w) {
+        if (ph == w) {
 #pragma unroll
-        for (int h = 0; h < 8; ++h) atomicAdd(dwc + c * 8 + h, accc[h][q]);
+            for (int q = 0; q < 2; ++q) {
+                const int c = cq + 256 * q;
+                if (c < C) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        s_acc[c + i] = w == 0 ? accb[q][i] : s_acc[c + i] + accb[q][i];
+#pragma unroll
+                        for (int h = 0; h < 8; ++h) {
+                            float &d = s_acc[C + (c + i) * 8 + h];
+                            d = w == 0 ? accc[q][i][h] : d + accc[q][i][h];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
-    if (t < 64) atomicAdd(dwb + t, small);
-    else if (t < 72) atomicAdd(dbb + t - 64, small);
-    else if (t < 96) atomicAdd(dwa + t - 72, small);
-    else if (t < 104) atomicAdd(dba + t - 96, small);
+    float *part = partial + (size_t)blockIdx.x * partial_pitch;
+    for (int e = t; e < 9 * C; e += 256) part[e] = s_acc[e];
+    if (t < 104) part[9 * C + t] = small;
+}
+
+__global__ __launch_bounds__(256) void weightnet_bwd_reduce_kernel(int C, int wgs, const float *__restrict__ partial, int partial_pitch,
+                                                                   float *__restrict__ dwa, float *__restrict__ dba, float *__restrict__ dwb,
+                                                                   float *__restrict__ dbb, float *__restrict__ dwc, float *__restrict__ dbc) {
+    // 16 outputs x 16 lanes over the workgroup axis, eight independent loads per lane and round: the sum over ~500 partial vectors
+    // is a latency problem (a few rounds of HBM/L2 round trips), not a bandwidth one
+    __shared__ float s_part[16][17];
+    const int el = threadIdx.x & 15, zl = threadIdx.x >> 4, L = 9 * C + 104;
+    const int e = blockIdx.x * 16 + el;
+    const float *src = partial + (e < L ? e : L - 1);
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = 0.f;
+    for (int z0 = zl; z0 < wgs; z0 += 128) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int z = z0 + 16 * k;
+            const float v = src[(size_t)(z < wgs ? z : 0) * partial_pitch];
+            a[k] += z < wgs ? v : 0.f;
+        }
+    }
+    s_part[zl][el] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    if (zl || e >= L) return;
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sum += s_part[q][el];
+    float *dst;
+    if (e < C) dst = dbc + e;
+    else if (e < 9 * C) dst = dwc + (e - C);
+    else {
+        const int r = e - 9 * C;
+        dst = r < 64 ? dwb + r : r < 72 ? dbb + (r - 64) : r < 96 ? dwa + (r - 72) : dba + (r - 96);
+    }
+    *dst += sum;
 }
 
 }  // namespace
 
 extern "C" int rtk_weightnet_bwd(long positions, int channels, const float *d4, const float *dq3, const float *dt2, const float *wa,
                                  const float *ba, const float *wb, const float *bb, float *dwa, float *dba, float *dwb, float *dbb,
-                                 float *dwc, float *dbc, rtk_stream_t stream) {
-    RTK_REQUIRE(positions > 0 && channels > 0 && channels <= 512 && d4 && dq3 && dt2 && wa && ba && wb && bb && dwa && dba && dwb && dbb &&
-                dwc && dbc, "weightnet_bwd: bad arguments");
+                                 float *dwc, float *dbc, float *workspace, long workspace_floats, rtk_stream_t stream) {
+    RTK_REQUIRE(positions > 0 && channels > 0 && channels <= 512 && (channels & 3) == 0 && d4 && dq3 && dt2 && wa && ba && wb && bb && dwa && dba && dwb && dbb &&
+                dwc && dbc && workspace, "weightnet_bwd: bad arguments");
+    const int pitch = (9 * channels + 104 + 3) & ~3;
+    RTK_REQUIRE(workspace_floats >= pitch, "weightnet_bwd: workspace of %ld floats < %d", workspace_floats, pitch);
     const long subs = (positions + WN_SUB - 1) / WN_SUB;
-    int per = (int)((subs + 511) / 512);           // ~512 workgroups, each a few sub-blocks: its atomics stay a small share
+    static const int want_env = getenv("RTK_WN_WGS") ? atoi(getenv("RTK_WN_WGS")) : 512;      // experiment knob (tools/exp_wnbwd.py)
+    long want = want_env;                           // workgroups (two per CU keep the dq3 stream near HBM speed), each one partial vector
+    if (want > workspace_floats / pitch) want = workspace_floats / pitch;
+    int per = (int)((subs + want - 1) / want);
     if (per < 1) per = 1;
     const int wgs = (int)((subs + per - 1) / per);
-    weightnet_bwd_kernel<<<wgs, 256, 0, (hipStream_t)stream>>>(positions, channels, per, d4, dq3, dt2, wa, ba, wb, bb, dwa, dba, dwb, dbb, dwc,
-                                                              dbc);
+    weightnet_bwd_kernel<<<wgs, 256, 0, (hipStream_t)stream>>>(positions, channels, per, d4, dq3, dt2, wa, ba, wb, bb, workspace, pitch);
     RTK_CHECK_LAUNCH("weightnet_bwd");
+    weightnet_bwd_reduce_kernel<<<(9 * channels + 104 + 15) / 16, 256, 0, (hipStream_t)stream>>>(channels, wgs, workspace, pitch, dwa, dba, dwb,
+                                                                                                  dbb, dwc, dbc);
+    RTK_CHECK_LAUNCH("weightnet_bwd_reduce");
     return RTK_OK;
 }

@@ -19,7 +19,7 @@ _lib.SIGNATURES.update({
     "rtk_group_inverse_index": [_i] * 3 + [_p] * 3 + [_p],
     "rtk_sa_first_layer_bwd": [_i] * 5 + [_p] * 6 + [_i, _p],
     "rtk_conv_bn_fwd": [_i] * 6 + [_p] * 7 + [_p],
-    "rtk_conv_wgrad": [_i] * 6 + [_p] * 4 + [_p],
+    "rtk_conv_wgrad": [_i] * 6 + [_p] * 5 + [ctypes.c_long, _p],
     "rtk_conv_bn_bwd": [_i] * 6 + [_p] * 6 + [_d, _i, _p, _p, _p],
     "rtk_train_group_geometry": [_i] * 5 + [_p] * 6 + [_p],
     "rtk_train_interp_weights": [_i] * 3 + [_p] * 5 + [_p],
@@ -45,7 +45,7 @@ _lib.SIGNATURES.update({
     "rtk_pw_wgrad": [_i, _i, _PwP, _i, _PwP, _p, _i, _p, _p, ctypes.c_long, _p],
     "rtk_backbone_loss": [_i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p],
     "rtk_pack_weights": [_i, _p, _p],
-    "rtk_weightnet_bwd": [ctypes.c_long, _i] + [_p] * 13 + [_p],
+    "rtk_weightnet_bwd": [ctypes.c_long, _i] + [_p] * 14 + [ctypes.c_long, _p],
 })
 
 
@@ -434,8 +434,9 @@ class _SAChain(torch.autograd.Function):
             Co, Ci = W.shape[0], W.shape[1]
             dW = dwbuf[dwoff:dwoff + W.numel()].view_as(W)
             dwoff += W.numel()
+            ws = torch.empty(max(S_, 1024) * Ci * Co, dtype=torch.float32, device=dev)       # workgroup partials (uninitialised scratch)
             _lib.call("rtk_conv_wgrad", S_, Ci, Co, rows, ns, groups, dz.data_ptr(), zs[i - 1].data_ptr(), pars[i - 1].data_ptr(),
-                      dW.data_ptr(), _stream())
+                      dW.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
             wc = W.contiguous()
             sums2 = f64(Ci)
             args = (S_, Ci, Co, rows, ns, groups, dz.data_ptr(), wc.data_ptr(), zs[i - 1].data_ptr(), pars[i - 1].data_ptr(), _ptr(row_w),
@@ -683,8 +684,10 @@ def _weightnet_backward(d4, dq3, dt2, wa, ba, wb, bb, wc):
     dwa, dba, dwb, dbb, dwc, dbc = torch.split(buf, [24, 8, 64, 8, C * 8, C])
     c = lambda t: t.detach().contiguous()
     wa_, ba_, wb_, bb_ = c(wa), c(ba), c(wb), c(bb)
+    ws = torch.empty(1024 * ((9 * C + 107) & ~3), dtype=torch.float32, device=dev)          # workgroup partials (uninitialised scratch)
     _lib.call("rtk_weightnet_bwd", M, C, d4.data_ptr(), dq3.data_ptr(), dt2.data_ptr(), wa_.data_ptr(), ba_.data_ptr(), wb_.data_ptr(),
-              bb_.data_ptr(), dwa.data_ptr(), dba.data_ptr(), dwb.data_ptr(), dbb.data_ptr(), dwc.data_ptr(), dbc.data_ptr(), _stream())
+              bb_.data_ptr(), dwa.data_ptr(), dba.data_ptr(), dwb.data_ptr(), dbb.data_ptr(), dwc.data_ptr(), dbc.data_ptr(), ws.data_ptr(),
+              ws.numel(), _stream())
     return dwa.view(8, 3), dba, dwb.view(8, 8), dbb, dwc.view(C, 8), dbc
 
 

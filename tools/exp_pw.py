@@ -6,22 +6,7 @@ import torch
 from ratrack_amd import _lib, train_ops as T
 
 
-def _time(fn, reps):
-    """ms per launch from a replayed graph of `reps` launches (eager ctypes launches cost ~10 us each: too coarse here)."""
-    fn(); torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        for _ in range(reps):
-            fn()
-    g.replay(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5):
-        g.replay()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / (5 * reps)
-
-
+from ratrack_amd.benchutil import time_graph as _time
 dev = "cuda"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 for S, P, cins, co in [(2 * B, 256, [64, 64], 128), (2 * B, 256, [128, 32], 128), (2 * B, 256, [128], 128), (2 * B, 256, [64], 96),
