@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 #include "rtk_common.h"
 #include "rtk_train.h"
 
@@ -64,10 +66,9 @@ __global__ __launch_bounds__(256) void inverse_index_kernel(int n_src, int P, co
     }
 }
 
-constexpr int FB_CG = 4;        // channel planes per workgroup
 constexpr int FB_MAXQ = 8;      // float4 per thread and plane: planes up to 8192 positions keep their offsets in registers
 
-__global__ __launch_bounds__(256) void sa_first_layer_bwd_kernel(int channels, int n_src, int P, const float *__restrict__ dz,
+__global__ __launch_bounds__(256) void sa_first_layer_bwd_kernel(int channels, int cg, int n_src, int P, const float *__restrict__ dz,
                                                                  const float *__restrict__ dxyz, const int *__restrict__ off,
                                                                  const unsigned short *__restrict__ inv, float *__restrict__ dproj,
                                                                  float *__restrict__ dwx, int dwx_pitch) {
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void sa_first_layer_bwd_kernel(int channels, i
     float *s_out = reinterpret_cast<float *>(s_off + n_src + 1);                         // [n_src]
     unsigned short *s_inv = reinterpret_cast<unsigned short *>(s_out + n_src);            // [P]
     __shared__ float s_red[4][3];
-    const int s = blockIdx.y, c0 = blockIdx.x * FB_CG, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int s = blockIdx.y, c0 = blockIdx.x * cg, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (int q = t; q <= n_src; q += 256) s_off[q] = off[(size_t)s * (n_src + 1) + q];
     // thread t later walks the sorted positions [t E, (t+1) E): one pad element per chunk keeps the 64 lanes of a wave on
     // different LDS banks (a plain layout puts them 2E bytes apart: a 32-way conflict per read)
@@ -91,21 +92,36 @@ __global__ __launch_bounds__(256) void sa_first_layer_bwd_kernel(int channels, i
 #pragma unroll
         for (int i = 0; i < FB_MAXQ; ++i) {
             const int e = t + 256 * i;
-            if (e < n4) { ox[i] = dx4[e]; oy[i] = dx4[n4 + e]; oz[i] = dx4[2 * n4 + e]; }
+            const int ec = e < n4 ? e : n4 - 1;      // unconditional (clamped) loads; tail threads never use theirs
+            ox[i] = dx4[ec]; oy[i] = dx4[n4 + ec]; oz[i] = dx4[2 * n4 + ec];
         }
     }
-    for (int cc = 0; cc < FB_CG && c0 + cc < channels; ++cc) {
+    // position of this thread's chunk of the sorted positions in the run structure (the same for every plane)
+    const int e0 = t * E, e1 = min(P, e0 + E);
+    int q_first = 0;
+    __syncthreads();                               // s_off is complete
+    if (e0 < e1) {
+        int lo = 0, hi = n_src;                    // the source point of position e0: last q with off[q] <= e0
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= e0) lo = mid; else hi = mid; }
+        q_first = lo;
+    }
+    const int nplanes = min(cg, channels - c0);
+    float4 v[FB_MAXQ];
+    auto request = [&](int c) {                    // all of a plane's loads in flight at once (tail threads re-read its last float4)
+        const float4 *pl = reinterpret_cast<const float4 *>(dz + ((size_t)s * channels + c) * P);
+#pragma unroll
+        for (int i = 0; i < FB_MAXQ; ++i) {
+            const int e = t + 256 * i;
+            v[i] = pl[e < n4 ? e : n4 - 1];
+        }
+    };
+    if (in_regs) request(c0);
+    for (int cc = 0; cc < nplanes; ++cc) {
         const int c = c0 + cc;
         const float4 *pl = reinterpret_cast<const float4 *>(dz + ((size_t)s * channels + c) * P);
         float ax = 0.f, ay = 0.f, az = 0.f;
         __syncthreads();                           // the previous plane has been consumed
         if (in_regs) {
-            float4 v[FB_MAXQ];
-#pragma unroll
-            for (int i = 0; i < FB_MAXQ; ++i) {          // all of the plane's loads in flight before the first use
-                const int e = t + 256 * i;
-                v[i] = pl[e < n4 ? e : n4 - 1];
-            }
 #pragma unroll
             for (int i = 0; i < FB_MAXQ; ++i) {
                 const int e = t + 256 * i;
@@ -116,6 +132,7 @@ __global__ __launch_bounds__(256) void sa_first_layer_bwd_kernel(int channels, i
                     az += (v[i].x * oz[i].x + v[i].y * oz[i].y) + (v[i].z * oz[i].z + v[i].w * oz[i].w);
                 }
             }
+            if (cc + 1 < nplanes) request(c + 1);  // the next plane travels while this one is gathered
         } else {
             for (int e = t; e < n4; e += 256) {
                 const float4 v = pl[e], a = dx4[e], b = dx4[n4 + e], d = dx4[2 * n4 + e];
@@ -135,11 +152,8 @@ __global__ __launch_bounds__(256) void sa_first_layer_bwd_kernel(int channels, i
         for (int q = t; q < n_src; q += 256) s_out[q] = 0.f;
         __syncthreads();
         {
-            const int e0 = t * E, e1 = min(P, e0 + E);
             if (e0 < e1) {
-                int lo = 0, hi = n_src;                     // the source point of position e0: last q with off[q] <= e0
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= e0) lo = mid; else hi = mid; }
-                int q = lo, nb = s_off[q + 1];
+                int q = q_first, nb = s_off[q + 1];
                 float acc = 0.f;
                 // eight gathered values at a time: the two dependent LDS reads (inverse index, then plane) of a batch are in flight
                 // together, the run bookkeeping is register work.  (Measured and rejected: 1024 threads per workgroup to overlap more
@@ -202,8 +216,12 @@ extern "C" int rtk_sa_first_layer_bwd(int samples, int channels, int rows, int n
         (void)hipFuncSetAttribute((const void *)sa_first_layer_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    const dim3 grid((channels + FB_CG - 1) / FB_CG, samples);
-    sa_first_layer_bwd_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(channels, n_src, P, dz, dxyz, off, inv, dproj, dwx, dwx_pitch);
+    // channel planes per workgroup: 4 (2, 8 and 16 measured within 5 % of it or worse, tools/exp_firstbwd.py: the per-plane phases,
+    // not the per-workgroup staging of the index tables and offset planes, set the pace)
+    static const int cg_env = getenv("RTK_FB_CG") ? atoi(getenv("RTK_FB_CG")) : 0;      // experiment knob
+    const int cg = cg_env ? cg_env : 4;
+    const dim3 grid((channels + cg - 1) / cg, samples);
+    sa_first_layer_bwd_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(channels, cg, n_src, P, dz, dxyz, off, inv, dproj, dwx, dwx_pitch);
     RTK_CHECK_LAUNCH("sa_first_layer_bwd");
     return RTK_OK;
 }
