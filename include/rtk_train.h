@@ -172,12 +172,14 @@ RTK_EXPORT int rtk_pw_wgrad(int samples, int positions, const rtk_pw_operand_t *
  *   d4 (M,4)         (neighbour - query, 1) of every position
  *   dp1 (samples*n1, 256)     gradient of p1 = sum of dz1 over the 16 neighbours
  *   dpd (samples*n1, 3, 256)  per-query partial sums of dz1 x direction; dWd[c][k] = sum over queries of dpd[q][k][c].
+ *   dbias_rows (samples*n1, 2, 256), optional (NULL: not computed)  per-query sums over the 16 neighbours of dz3 | dz2:
+ *                    db3 | db2 = their column sums (a 16x smaller reduction than the column sums of dz3, dz2 themselves).
  * The gradient of p2 is rtk_scatter_add_rows(knn_idx, dz1). */
 RTK_EXPORT int rtk_cost_volume_bwd(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
                                    const float *p1, const float *p2, const float *wd_packed, const rtk_layer_t *layers,
                                    const rtk_layer_t *wn, const float *wct_packed, const float *dout, int dout_pitch,
                                    int act_pitch, float *a1, float *a2, float *dz1, float *dz2, float *dz3, float *dq3,
-                                   float *d4, float *dp1, float *dpd, float *dt2, rtk_stream_t stream);
+                                   float *d4, float *dp1, float *dpd, float *dt2, float *dbias_rows, rtk_stream_t stream);
 
 /* Backward of rtk_patch_cost (rtk_fused.h; same forward arguments; feat point-major).  dout (samples*n, dout_pitch).
  * Outputs over the M = samples*n*16 positions: dxg (M,256) = dout * wn (scatter it onto feat's rows with

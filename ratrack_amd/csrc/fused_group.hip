@@ -367,6 +367,7 @@ struct CvBwdParams {
     int act_pitch;                // row pitch of a1 / a2 (>= 256; column 256 receives 1.0 when act_pitch > 256)
     const f4 *wct;                // packed Wc^T (WeightNet last layer transposed): [16][1] fragments
     float *a1, *a2, *dz1, *dz2, *dz3, *dq3, *d4, *dp1, *dpd, *dt2;
+    float *dbrows;                // optional (queries, 2, 256): per-query sums over the 16 neighbours of dz3 | dz2 (bias gradients = their column sums)
 };
 
 __device__ __forceinline__ f4 leaky_grad(f4 d, f4 a) {     // d * leaky'(z), the sign of z read off a = leaky(z)
@@ -472,6 +473,11 @@ __global__ __launch_bounds__(64 * CV_NW, CVB_MIN_WAVES) void cost_volume_bwd_ker
                 *cv_at(Q.dq3, ro + 64u * v) = q;
                 *cv_at(Q.dz3, ro + 64u * v) = h[v];
             }
+            if (Q.dbrows) {                          // (uniform) per-query neighbour sum: the host's bias sum shrinks 16x
+                f4 r = h[v];
+                row_sum16_f4(r);
+                if (valid && j == 0) *reinterpret_cast<f4 *>(Q.dbrows + i * 512 + 16 * v + 4 * g) = r;
+            }
             __builtin_amdgcn_sched_barrier(0);      // keep the 16 iterations' global loads from being hoisted together (spills)
         }
         if (valid && g < 2) *reinterpret_cast<f4 *>(Q.dt2 + pos * 8 + 4 * g) = dt2;     // 8 hidden units
@@ -484,6 +490,11 @@ __global__ __launch_bounds__(64 * CV_NW, CVB_MIN_WAVES) void cost_volume_bwd_ker
             const f4 act = *cv_at(Q.a2, ra + 64u * v);     // this lane's own store, above
             a[v] = leaky_grad(a[v], act);
             if (valid) *cv_at(Q.dz2, ro + 64u * v) = a[v];
+            if (Q.dbrows) {
+                f4 r = a[v];
+                row_sum16_f4(r);
+                if (valid && j == 0) *reinterpret_cast<f4 *>(Q.dbrows + i * 512 + 256 + 16 * v + 4 * g) = r;
+            }
         }
         // ---- da1 = W2^T dz2;  dz1 = da1 leaky'(z1);  dp1 = sum over the 16 neighbours ----------------------------------
 #pragma unroll
@@ -527,7 +538,7 @@ extern "C" int rtk_cost_volume_bwd(int samples, int n1, int n2, const float *xyz
                                    const float *p1, const float *p2, const float *wd_packed, const rtk_layer_t *layers,
                                    const rtk_layer_t *wn, const float *wct_packed, const float *dout, int dout_pitch,
                                    int act_pitch, float *a1, float *a2, float *dz1, float *dz2, float *dz3, float *dq3,
-                                   float *d4, float *dp1, float *dpd, float *dt2, rtk_stream_t stream) {
+                                   float *d4, float *dp1, float *dpd, float *dt2, float *dbias_rows, rtk_stream_t stream) {
     RTK_REQUIRE(samples > 0 && n1 > 0 && n2 >= 16 && xyz1 && xyz2 && knn_idx && p1 && p2 && wd_packed && layers && dout && a1 &&
                 a2 && dz1 && dz2 && dz3 && dq3 && d4 && dp1 && dpd && dt2 && wct_packed, "cost_volume_bwd: bad arguments");
     RTK_REQUIRE(act_pitch == 256 || (act_pitch >= 260 && act_pitch % 4 == 0), "cost_volume_bwd: bad act_pitch %d", act_pitch);
@@ -549,7 +560,7 @@ extern "C" int rtk_cost_volume_bwd(int samples, int n1, int n2, const float *xyz
     P.out = nullptr; P.out_pitch = 0;
     Q.dout = dout; Q.dout_pitch = dout_pitch;
     Q.act_pitch = act_pitch; Q.wct = reinterpret_cast<const f4 *>(wct_packed);
-    Q.a1 = a1; Q.a2 = a2; Q.dz1 = dz1; Q.dz2 = dz2; Q.dz3 = dz3; Q.dq3 = dq3; Q.d4 = d4; Q.dp1 = dp1; Q.dpd = dpd; Q.dt2 = dt2;
+    Q.a1 = a1; Q.a2 = a2; Q.dz1 = dz1; Q.dz2 = dz2; Q.dz3 = dz3; Q.dq3 = dq3; Q.d4 = d4; Q.dp1 = dp1; Q.dpd = dpd; Q.dt2 = dt2; Q.dbrows = dbias_rows;
     const int groups = (n1 + CV_NW - 1) / CV_NW;
     int gx = 256 * CV_WGS_PER_CU / samples;
     if (gx < 1) gx = 1;

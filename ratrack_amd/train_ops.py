@@ -13,7 +13,7 @@ from . import _lib, fused
 _i, _f, _d, _p = ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 _LayerP = ctypes.POINTER(fused._Layer)
 _lib.SIGNATURES.update({
-    "rtk_cost_volume_bwd": [_i] * 3 + [_p] * 6 + [_LayerP, _LayerP, _p, _p, _i, _i] + [_p] * 10 + [_p],
+    "rtk_cost_volume_bwd": [_i] * 3 + [_p] * 6 + [_LayerP, _LayerP, _p, _p, _i, _i] + [_p] * 11 + [_p],
     "rtk_scatter_add_rows": [_i] * 4 + [_p] * 3 + [_p],
     "rtk_sa_first_layer": [_i] * 6 + [_p] * 4 + [_i] + [_p] * 3 + [_p],
     "rtk_group_inverse_index": [_i] * 3 + [_p] * 3 + [_p],
@@ -605,16 +605,17 @@ class _CostVolume(torch.autograd.Function):
         dt2 = torch.empty(M, 8, dtype=torch.float32, device=dev)
         dp1 = torch.empty(B * n1, 256, dtype=torch.float32, device=dev)
         dpd = torch.empty(B * n1, 3, 256, dtype=torch.float32, device=dev)
+        dbr = torch.empty(B * n1, 512, dtype=torch.float32, device=dev)       # per-query neighbour sums of dz3 | dz2
         wct = W.wct
         _lib.call("rtk_cost_volume_bwd", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
                   W.wd.data_ptr(), W.layers, W.wn, wct.data_ptr(), dout.data_ptr(), 256, AP, a1.data_ptr(), a2.data_ptr(),
                   dz1.data_ptr(), dz2.data_ptr(), dz3.data_ptr(), dq3.data_ptr(), d4.data_ptr(), dp1.data_ptr(), dpd.data_ptr(),
-                  dt2.data_ptr(), _stream())
+                  dt2.data_ptr(), dbr.data_ptr(), _stream())
         dp2 = torch.empty(B * n2, 256, dtype=torch.float32, device=dev)
         _lib.call("rtk_scatter_add_rows", B, n1 * 16, n2, 256, knn.data_ptr(), dz1.data_ptr(), dp2.data_ptr(), _stream())
         # weight gradients: contractions over the M positions
-        dw3, db3 = _tall_tn(dz3, a2), dz3.sum(0)
-        dw2, db2 = _tall_tn(dz2, a1), dz2.sum(0)
+        dw3, dw2 = _tall_tn(dz3, a2), _tall_tn(dz2, a1)
+        db3, db2 = dbr.sum(0).split(256)
         dwd = dpd.sum(0).t()
         dwa, dba, dwb, dbb, dwc, dbc = _weightnet_backward(d4, dq3, dt2, wa, ba, wb, bb, wc)
         return dp1, dp2, dwd, dw2, db2, dw3, db3, dwa, dba, dwb, dbb, dwc, dbc, None, None, None
@@ -643,13 +644,14 @@ def time_cost_volume_bwd(batch, n, dev, iters=10):
     big = torch.empty(6, M, 256, device=dev)
     d4, dt2 = torch.empty(M, 4, device=dev), torch.empty(M, 8, device=dev)
     dp1, dpd = torch.empty(B * n, 256, device=dev), torch.empty(B * n, 3, 256, device=dev)
+    dbr = torch.empty(B * n, 512, device=dev)
     st = _stream()
 
     def launch():
         _lib.call("rtk_cost_volume_bwd", B, n, n, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
                   W.wd.data_ptr(), W.layers, W.wn, W.wct.data_ptr(), dout.data_ptr(), 256, 256, big[0].data_ptr(), big[1].data_ptr(),
                   big[2].data_ptr(), big[3].data_ptr(), big[4].data_ptr(), big[5].data_ptr(), d4.data_ptr(), dp1.data_ptr(),
-                  dpd.data_ptr(), dt2.data_ptr(), st)
+                  dpd.data_ptr(), dt2.data_ptr(), dbr.data_ptr(), st)
     for _ in range(3):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
