@@ -641,6 +641,16 @@ __global__ __launch_bounds__(256) void scatter_rows256_kernel(int m, int n, cons
         if (hit) s_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = tid | (t << 8);
         __syncthreads();
         int q = 0;
+        for (; q + 16 <= total; q += 16) {     // sixteen 1 KiB rows in flight (a chunk holds ~32 hits: two round trips; with four
+            int e[16];                          // in flight the kernel ran at 1.9 TB/s, with eight at 3.2)
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) e[k] = s_list[q + k];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = sb[(size_t)(base + (e[k] & 255)) * 256];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s_acc[e[k] >> 8][tid] += v[k];
+        }
         for (; q + 4 <= total; q += 4) {
             const int e0 = s_list[q], e1 = s_list[q + 1], e2 = s_list[q + 2], e3 = s_list[q + 3];
             const float v0 = sb[(size_t)(base + (e0 & 255)) * 256], v1 = sb[(size_t)(base + (e1 & 255)) * 256];
