@@ -158,16 +158,21 @@ RTK_EXPORT int rtk_pw_wgrad(int samples, int positions, const rtk_pw_operand_t *
                             int w_pitch, float *dbias, float *workspace, long workspace_floats, rtk_stream_t stream);
 
 /* ---- cost volume (utils/model_utils/model_utils.py:216-236) ------------------------------------------------------
- * Backward of rtk_cost_volume (rtk_fused.h; same forward arguments).  layers[0..3] = the packed 256x256 layers
- * W2, W3, W3^T, W2^T, contiguous in memory (biases of W2, W3 in layers[0], layers[1]); wct_packed = the packed
- * transpose of the WeightNet's last layer (8 x 256 -> [16][1] fragments).  dout (samples*n1, dout_pitch) is the
- * gradient of the forward output.  Outputs, all caller-allocated, M = samples*n1*16 positions (query-major,
- * neighbour minor):
- *   a1, a2 (M, act_pitch)  recomputed activations of layers 1 and 2; with act_pitch > 256 column 256 is set to 1 and
- *                    columns 257..259 to 0 (the rest of the padding is not written), so that ONE product
- *                    dz^T [a | 1] yields the weight and the bias gradient (dW2|db2 = dz2^T a1, dW3|db3 = dz3^T a2)
- *   dz1, dz2, dz3 (M,256)  gradients of the three pre-activations
- *   dq3 (M,256)      gradient of the WeightNet's last pre-activation  (dWc|dbc = dq3^T [t2 | 1])
+ * Training forward: rtk_cost_volume (rtk_fused.h; same arguments and result) that also keeps the three activations
+ * a1, a2, a3 (M, 256), M = samples*n1*16 positions (query-major, neighbour minor), for the backward (a1, a2: operands of its
+ * weight-gradient GEMMs; a3: read by rtk_cost_volume_bwd), and mask1, mask2 (M, 32 bytes each): the sign bits of a1, a2 in
+ * the kernel's own lane order (opaque; 1/32 of the bytes the backward would otherwise re-read for the leaky-ReLU slopes). */
+RTK_EXPORT int rtk_cost_volume_train(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
+                                     const float *p1, const float *p2, const float *wd_packed, const rtk_layer_t *layers,
+                                     const rtk_layer_t *wn, float *out, int out_pitch, float *a1, float *a2, float *a3,
+                                     void *mask1, void *mask2, rtk_stream_t stream);
+
+/* Backward of rtk_cost_volume_train.  layers_t[0..1] = the packed transposed 256x256 layers W3^T, W2^T, contiguous in
+ * memory; wn = the WeightNet images of the forward; wct_packed = the packed transpose of the WeightNet's last layer
+ * (8 x 256 -> [16][1] fragments).  dout (samples*n1, dout_pitch) is the gradient of the forward output; a3, mask1, mask2 what
+ * the forward saved.  Outputs, all caller-allocated:
+ *   dz1, dz2, dz3 (M,256)  gradients of the three pre-activations (dW2 = dz2^T a1, dW3 = dz3^T a2: GEMMs on the host side)
+ *   dq3 (M,256)      gradient of the WeightNet's last pre-activation  (dWc|dbc = dq3^T [t2 | 1], rtk_weightnet_bwd)
  *   dt2 (M,8)        Wc^T dq3: gradient of the WeightNet's second hidden activation (before its ReLU mask)
  *   d4 (M,4)         (neighbour - query, 1) of every position
  *   dp1 (samples*n1, 256)     gradient of p1 = sum of dz1 over the 16 neighbours
@@ -176,10 +181,9 @@ RTK_EXPORT int rtk_pw_wgrad(int samples, int positions, const rtk_pw_operand_t *
  *                    db3 | db2 = their column sums (a 16x smaller reduction than the column sums of dz3, dz2 themselves).
  * The gradient of p2 is rtk_scatter_add_rows(knn_idx, dz1). */
 RTK_EXPORT int rtk_cost_volume_bwd(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
-                                   const float *p1, const float *p2, const float *wd_packed, const rtk_layer_t *layers,
-                                   const rtk_layer_t *wn, const float *wct_packed, const float *dout, int dout_pitch,
-                                   int act_pitch, float *a1, float *a2, float *dz1, float *dz2, float *dz3, float *dq3,
-                                   float *d4, float *dp1, float *dpd, float *dt2, float *dbias_rows, rtk_stream_t stream);
+                                   const rtk_layer_t *layers_t, const rtk_layer_t *wn, const float *wct_packed, const float *dout,
+                                   int dout_pitch, const float *a3, const void *mask1, const void *mask2, float *dz1, float *dz2, float *dz3,
+                                   float *dq3, float *d4, float *dp1, float *dpd, float *dt2, float *dbias_rows, rtk_stream_t stream);
 
 /* Backward of rtk_patch_cost (rtk_fused.h; same forward arguments; feat point-major).  dout (samples*n, dout_pitch).
  * Outputs over the M = samples*n*16 positions: dxg (M,256) = dout * wn (scatter it onto feat's rows with

@@ -234,6 +234,14 @@ __device__ __forceinline__ f4 weightnet_out(const WnWeights &W, int lane, int g,
 #endif
 #define CV_V 16          // 256 channels
 
+__device__ __forceinline__ f4 *cv_at(float *base, unsigned byte_off) {
+    return reinterpret_cast<f4 *>(reinterpret_cast<char *>(base) + byte_off);
+}
+
+__device__ __forceinline__ const f4 *cv_at(const float *base, unsigned byte_off) {
+    return reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
 struct CvParams {
     int samples, n1, n2;
     const float *xyz1, *xyz2;
@@ -246,8 +254,28 @@ struct CvParams {
     float *out;
     int out_pitch;
     int gx;                       // workgroups per sample; > 0 selects the XCD-aware 1-D grid (rtk_decode_block)
+    float *sv1, *sv2, *sv3;       // training forward (SAVE): the three activations, (positions, 256) each, kept for the backward
+    uint2 *mk1, *mk2;             // ... and the sign masks of a1, a2: 64 bits per lane slot (position, g), bit 4v + r = [a[v][r] > 0]
 };
 
+// sign mask of an activation fragment set (the backward's leaky' selector: 8 bytes instead of the lane's 256 bytes of a1 / a2)
+template <int V>
+__device__ __forceinline__ uint2 sign_mask(const f4 (&a)[V]) {
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned bit = a[v][r] > 0.f ? 1u : 0u;
+            if (v < 8) lo |= bit << (4 * v + r);
+            else hi |= bit << (4 * (v - 8) + r);
+        }
+    return make_uint2(lo, hi);
+}
+
+// SAVE: the training forward (rtk_cost_volume_train) also stores a1, a2, a3 -- the backward then needs no recomputation (two of
+// its four 256 x 256 products) and its weight-gradient GEMMs read the same tensors.
+template <bool SAVE>
 __global__ __launch_bounds__(64 * CV_NW, (CV_NW * CV_WGS_PER_CU) / 4) void cost_volume_kernel(const CvParams P) {
     __shared__ __attribute__((aligned(16))) f4 s_w[2 * CV_F * 64];
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
@@ -278,16 +306,32 @@ __global__ __launch_bounds__(64 * CV_NW, (CV_NW * CV_WGS_PER_CU) / 4) void cost_
             for (int v = 0; v < CV_V; ++v) h[v] = mfma4(P.wd[v * 64 + lane], bop, h[v]);
             apply_act<CV_V>(h, RTK_ACT_LEAKY);
         }
+        // byte offset of this lane's 16-byte slot in a (position, 256) row (one 32-bit VGPR, added to uniform base pointers)
+        const unsigned ro = (unsigned)(i * 16 + j) * 1024u + 16u * g;
+        if (SAVE && valid) {
+#pragma unroll
+            for (int v = 0; v < CV_V; ++v) *cv_at(P.sv1, ro + 64u * v) = h[v];
+            P.mk1[(i * 16 + j) * 4 + g] = sign_mask<CV_V>(h);
+        }
         f4 a[CV_V];
 #pragma unroll
         for (int v = 0; v < CV_V; ++v) a[v] = bias_frag(P.bias2, v, g);
         mlp_layer_ws<CV_V, CV_V, 0>(ws, h, a);
         apply_act<CV_V>(a, RTK_ACT_LEAKY);
+        if (SAVE && valid) {
+#pragma unroll
+            for (int v = 0; v < CV_V; ++v) *cv_at(P.sv2, ro + 64u * v) = a[v];
+            P.mk2[(i * 16 + j) * 4 + g] = sign_mask<CV_V>(a);
+        }
 #pragma unroll
         for (int v = 0; v < CV_V; ++v) h[v] = bias_frag(P.bias3, v, g);
         mlp_layer_ws<CV_V, CV_V, CV_V * CV_V>(ws, a, h);
         apply_act<CV_V>(h, RTK_ACT_LEAKY);
         ws.next();   // wrap the stream to chunk 0 (NF > F)
+        if (SAVE && valid) {
+#pragma unroll
+            for (int v = 0; v < CV_V; ++v) *cv_at(P.sv3, ro + 64u * v) = h[v];
+        }
         // WeightNet(direction) and the weighted sum over the 16 neighbours
         const f4 t2 = weightnet_hidden(P.wn, lane, g, bop);
         float *o = P.out + i * P.out_pitch + 4 * g;
@@ -317,58 +361,86 @@ static int fill_wn(WnWeights &W, const rtk_layer_t *wn, const char *who) {
     return RTK_OK;
 }
 
-extern "C" int rtk_cost_volume(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
-                               const float *p1, const float *p2, const float *wd_packed, const rtk_layer_t *layers,
-                               const rtk_layer_t *wn, float *out, int out_pitch, rtk_stream_t stream) {
+static int cost_volume_launch(const char *who, int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
+                              const float *p1, const float *p2, const float *wd_packed, const rtk_layer_t *layers, const rtk_layer_t *wn,
+                              float *out, int out_pitch, float *a1, float *a2, float *a3, void *mask1, void *mask2, rtk_stream_t stream) {
     RTK_REQUIRE(samples > 0 && n1 > 0 && n2 >= 16 && xyz1 && xyz2 && knn_idx && p1 && p2 && wd_packed && layers && out,
-                "cost_volume: bad arguments");
+                "%s: bad arguments", who);
     RTK_REQUIRE(layers[0].cin16 == 16 && layers[0].cout16 == 16 && layers[1].cin16 == 16 && layers[1].cout16 == 16 &&
-                layers[1].w_packed == layers[0].w_packed + 256 * 256, "cost_volume: expects two contiguous 256x256 layers");
-    RTK_REQUIRE(out_pitch % 4 == 0 && out_pitch >= 256, "cost_volume: bad out_pitch");
+                layers[1].w_packed == layers[0].w_packed + 256 * 256, "%s: expects two contiguous 256x256 layers", who);
+    RTK_REQUIRE(out_pitch % 4 == 0 && out_pitch >= 256, "%s: bad out_pitch", who);
+    const bool save = a1 != nullptr;
+    RTK_REQUIRE(!save || ((double)samples * n1 * 16.0 * 1024.0 < 4294967296.0), "%s: more than 4 GiB per saved activation (32-bit row "
+                "offsets): split the batch", who);
     CvParams P;
     P.samples = samples; P.n1 = n1; P.n2 = n2;
     P.xyz1 = xyz1; P.xyz2 = xyz2; P.knn = knn_idx; P.p1 = p1; P.p2 = p2; P.wd = wd_packed;
     P.blob = reinterpret_cast<const f4 *>(layers[0].w_packed);
     P.bias2 = layers[0].bias; P.bias3 = layers[1].bias;
-    if (fill_wn(P.wn, wn, "cost_volume") != RTK_OK) return RTK_ERR_INVALID;
-    RTK_REQUIRE(wn[2].cout16 == 16, "cost_volume: WeightNet must produce 256 channels");
+    if (fill_wn(P.wn, wn, who) != RTK_OK) return RTK_ERR_INVALID;
+    RTK_REQUIRE(wn[2].cout16 == 16, "%s: WeightNet must produce 256 channels", who);
     P.out = out; P.out_pitch = out_pitch;
-    RTK_REQUIRE(samples <= 65535, "cost_volume: too many samples");
+    P.sv1 = a1; P.sv2 = a2; P.sv3 = a3; P.mk1 = (uint2 *)mask1; P.mk2 = (uint2 *)mask2;
+    RTK_REQUIRE(samples <= 65535, "%s: too many samples", who);
     const int groups = (n1 + CV_NW - 1) / CV_NW;
     int gx = 256 * CV_WGS_PER_CU / samples;           // resident workgroups; the rest is looped
     if (gx < 1) gx = 1;
     if (gx > groups) gx = groups;
-    if (samples % 8 == 0) {
-        P.gx = gx;
-        cost_volume_kernel<<<dim3(gx * samples), 64 * CV_NW, 0, (hipStream_t)stream>>>(P);
-    } else {
-        P.gx = 0;
-        cost_volume_kernel<<<dim3(gx, samples), 64 * CV_NW, 0, (hipStream_t)stream>>>(P);
-    }
-    RTK_CHECK_LAUNCH("cost_volume");
+    P.gx = samples % 8 == 0 ? gx : 0;
+    const dim3 grid = P.gx ? dim3(gx * samples) : dim3(gx, samples);
+    if (save) cost_volume_kernel<true><<<grid, 64 * CV_NW, 0, (hipStream_t)stream>>>(P);
+    else cost_volume_kernel<false><<<grid, 64 * CV_NW, 0, (hipStream_t)stream>>>(P);
+    RTK_CHECK_LAUNCH(who);
     return RTK_OK;
 }
 
+extern "C" int rtk_cost_volume(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
+                               const float *p1, const float *p2, const float *wd_packed, const rtk_layer_t *layers,
+                               const rtk_layer_t *wn, float *out, int out_pitch, rtk_stream_t stream) {
+    return cost_volume_launch("cost_volume", samples, n1, n2, xyz1, xyz2, knn_idx, p1, p2, wd_packed, layers, wn, out, out_pitch, nullptr,
+                              nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int rtk_cost_volume_train(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
+                                     const float *p1, const float *p2, const float *wd_packed, const rtk_layer_t *layers,
+                                     const rtk_layer_t *wn, float *out, int out_pitch, float *a1, float *a2, float *a3,
+                                     void *mask1, void *mask2, rtk_stream_t stream) {
+    RTK_REQUIRE(a1 && a2 && a3 && mask1 && mask2, "cost_volume_train: null activation buffer");
+    return cost_volume_launch("cost_volume_train", samples, n1, n2, xyz1, xyz2, knn_idx, p1, p2, wd_packed, layers, wn, out, out_pitch, a1,
+                              a2, a3, mask1, mask2, stream);
+}
+
 // =================================================================================================
-// rtk_cost_volume_bwd: backward of rtk_cost_volume (include/rtk_train.h).
+// rtk_cost_volume_bwd: backward of rtk_cost_volume_train (include/rtk_train.h).
 //
-// Same tiling as the forward (one wave = one query point x its 16 neighbours, activations stationary in registers):
-// the forward is recomputed, then the gradient walks back through the two 256x256 layers with the TRANSPOSED packed
-// weights streamed through the same LDS double buffer (blob order W2, W3, W3^T, W2^T = one pass per tile).
-// Weight gradients are contractions over all B*N*16 positions -- plain GEMMs -- so the kernel materialises exactly
-// their operands, point-major (position, 256): the recomputed activations a1, a2 and the pre-activation gradients
-// dz1, dz2, dz3 (+ dq3 for the WeightNet and the 4-vector (dx, dy, dz, 1) of every position); the host multiplies.
+// Same tiling as the forward (one wave = one query point x its 16 neighbours, gradients stationary in registers).  The
+// forward saved the three activations a1, a2, a3 (round 2, first half: they were recomputed here -- two more 256 x 256
+// products per position, a kernel at 0.55 of the MFMA peak with 184 bytes of scratch per lane); the gradient walks back
+// through the two 256x256 layers with the TRANSPOSED packed weights streamed through the LDS double buffer (W3^T, W2^T).
+// Weight gradients are contractions over all B*N*16 positions -- plain GEMMs -- whose operands are exactly the saved
+// activations and what this kernel materialises, point-major (position, 256): the pre-activation gradients dz1, dz2, dz3
+// (+ dq3 for the WeightNet and the 4-vector (dx, dy, dz, 1) of every position); the host multiplies.
 // dp1 (gradient of the per-query projection) is the sum of dz1 over the 16 neighbours, reduced in registers.
 // =================================================================================================
 struct CvBwdParams {
-    CvParams f;                   // forward arguments; f.blob holds 4 layers: W2, W3, W3^T, W2^T
+    CvParams f;                   // forward arguments (p1, p2, out unused); f.blob = W3^T, W2^T
     const float *dout;
     int dout_pitch;
-    int act_pitch;                // row pitch of a1 / a2 (>= 256; column 256 receives 1.0 when act_pitch > 256)
     const f4 *wct;                // packed Wc^T (WeightNet last layer transposed): [16][1] fragments
-    float *a1, *a2, *dz1, *dz2, *dz3, *dq3, *d4, *dp1, *dpd, *dt2;
+    const float *a3;              // saved by the forward: the last activation ...
+    const uint2 *mk1, *mk2;       // ... and the sign masks of the first two (sign_mask)
+    float *dz1, *dz2, *dz3, *dq3, *d4, *dp1, *dpd, *dt2;
     float *dbrows;                // optional (queries, 2, 256): per-query sums over the 16 neighbours of dz3 | dz2 (bias gradients = their column sums)
 };
+
+__device__ __forceinline__ f4 leaky_grad_bits(f4 d, unsigned bits) {     // d * leaky'(z), [z > 0] in the low four bits
+    f4 r;
+    r.x = (bits & 1u) ? d.x : 0.1f * d.x;
+    r.y = (bits & 2u) ? d.y : 0.1f * d.y;
+    r.z = (bits & 4u) ? d.z : 0.1f * d.z;
+    r.w = (bits & 8u) ? d.w : 0.1f * d.w;
+    return r;
+}
 
 __device__ __forceinline__ f4 leaky_grad(f4 d, f4 a) {     // d * leaky'(z), the sign of z read off a = leaky(z)
     f4 r;
@@ -377,10 +449,6 @@ __device__ __forceinline__ f4 leaky_grad(f4 d, f4 a) {     // d * leaky'(z), the
     r.z = a.z > 0.f ? d.z : 0.1f * d.z;
     r.w = a.w > 0.f ? d.w : 0.1f * d.w;
     return r;
-}
-
-__device__ __forceinline__ f4 *cv_at(float *base, unsigned byte_off) {
-    return reinterpret_cast<f4 *>(reinterpret_cast<char *>(base) + byte_off);
 }
 
 #ifndef CVB_MIN_WAVES
@@ -394,7 +462,7 @@ __global__ __launch_bounds__(64 * CV_NW, CVB_MIN_WAVES) void cost_volume_bwd_ker
     int b, bx, nbx;
     rtk_decode_block(P.gx, b, bx, nbx);
     const int groups = (P.n1 + CV_NW - 1) / CV_NW;
-    constexpr int NF = 4 * CV_V * CV_V;
+    constexpr int NF = 2 * CV_V * CV_V;
     constexpr int L = CV_V * CV_V;
     WStream<CV_NW, CVB_F, NF> ws;
     ws.start(P.blob, s_w, wave_in_wg, lane);
@@ -409,47 +477,15 @@ __global__ __launch_bounds__(64 * CV_NW, CVB_MIN_WAVES) void cost_volume_bwd_ker
         const long i = (long)b * P.n1 + (valid ? pt : P.n1 - 1);
         const long nb = (long)b * P.n2 + (long)P.knn[i * 16 + j];
         const float bop = g < 3 ? __fsub_rn(P.xyz2[nb * 3 + g], P.xyz1[i * 3 + g]) : 1.0f;
-        const long pos = i * 16 + j;                                     // row of the materialised (position, 256) tensors
-        // byte offsets of this lane's 16-byte slot in a (position, 256) / (position, act_pitch) row: one 32-bit VGPR each,
-        // added to the tensors' uniform base pointers (SGPR-base addressing; 64-bit per-tensor addresses would spill)
+        const long pos = i * 16 + j;                                     // row of the (position, 256) tensors
+        // byte offset of this lane's 16-byte slot in a (position, 256) row: one 32-bit VGPR, added to the tensors' uniform
+        // base pointers (SGPR-base addressing; 64-bit per-tensor addresses would spill)
         const unsigned ro = (unsigned)pos * 1024u + 16u * g;
-        const unsigned ra = (unsigned)pos * (4u * Q.act_pitch) + 16u * g;   // a1 / a2 rows carry a trailing ones column
-        if (valid) {
-            Q.d4[pos * 4 + g] = bop;
-            if (Q.act_pitch > 256 && g == 0) {
-                const f4 one = {1.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f4 *>(Q.a1 + pos * Q.act_pitch + 256) = one;
-                *reinterpret_cast<f4 *>(Q.a2 + pos * Q.act_pitch + 256) = one;
-            }
-        }
-        // ---- forward recompute ---------------------------------------------------------------------------------------
-        f4 h[CV_V];
-        {
-            const float *r1 = P.p1 + i * 256 + 4 * g, *r2 = P.p2 + nb * 256 + 4 * g;
+        if (valid) Q.d4[pos * 4 + g] = bop;
+        const uint2 m2 = Q.mk2[pos * 4 + g], m1 = Q.mk1[pos * 4 + g];     // requested now, used after the first / second product
+        f4 h[CV_V], a[CV_V];
 #pragma unroll
-            for (int v = 0; v < CV_V; ++v)
-                h[v] = *reinterpret_cast<const f4 *>(r1 + 16 * v) + *reinterpret_cast<const f4 *>(r2 + 16 * v);
-#pragma unroll
-            for (int v = 0; v < CV_V; ++v) h[v] = mfma4(P.wd[v * 64 + lane], bop, h[v]);
-            apply_act<CV_V>(h, RTK_ACT_LEAKY);
-        }
-        if (valid) {
-#pragma unroll
-            for (int v = 0; v < CV_V; ++v) *cv_at(Q.a1, ra + 64u * v) = h[v];
-        }
-        f4 a[CV_V];
-#pragma unroll
-        for (int v = 0; v < CV_V; ++v) a[v] = bias_frag(P.bias2, v, g);
-        mlp_layer_ws<CV_V, CV_V, 0>(ws, h, a);
-        apply_act<CV_V>(a, RTK_ACT_LEAKY);
-        if (valid) {
-#pragma unroll
-            for (int v = 0; v < CV_V; ++v) *cv_at(Q.a2, ra + 64u * v) = a[v];
-        }
-#pragma unroll
-        for (int v = 0; v < CV_V; ++v) h[v] = bias_frag(P.bias3, v, g);
-        mlp_layer_ws<CV_V, CV_V, L>(ws, a, h);
-        apply_act<CV_V>(h, RTK_ACT_LEAKY);                               // h = a3
+        for (int v = 0; v < CV_V; ++v) h[v] = *cv_at(Q.a3, ro + 64u * v);       // a3 = leaky(z3)
         // ---- out = sum_k wn * a3:  dz3 = dout wn leaky'(z3),  dq3 = dout a3 [wn > 0] ---------------------------------
         const f4 t2 = weightnet_hidden(P.wn, lane, g, bop);
         const float *dor = Q.dout + i * Q.dout_pitch + 4 * g;
@@ -478,17 +514,15 @@ __global__ __launch_bounds__(64 * CV_NW, CVB_MIN_WAVES) void cost_volume_bwd_ker
                 row_sum16_f4(r);
                 if (valid && j == 0) *reinterpret_cast<f4 *>(Q.dbrows + i * 512 + 16 * v + 4 * g) = r;
             }
-            __builtin_amdgcn_sched_barrier(0);      // keep the 16 iterations' global loads from being hoisted together (spills)
         }
         if (valid && g < 2) *reinterpret_cast<f4 *>(Q.dt2 + pos * 8 + 4 * g) = dt2;     // 8 hidden units
         // ---- da2 = W3^T dz3;  dz2 = da2 leaky'(z2) ---------------------------------------------------------------------
 #pragma unroll
         for (int v = 0; v < CV_V; ++v) a[v] = f4_zero();
-        mlp_layer_ws<CV_V, CV_V, 2 * L>(ws, h, a);
+        mlp_layer_ws<CV_V, CV_V, 0>(ws, h, a);
 #pragma unroll
         for (int v = 0; v < CV_V; ++v) {
-            const f4 act = *cv_at(Q.a2, ra + 64u * v);     // this lane's own store, above
-            a[v] = leaky_grad(a[v], act);
+            a[v] = leaky_grad_bits(a[v], (v < 8 ? m2.x : m2.y) >> (4 * (v & 7)));
             if (valid) *cv_at(Q.dz2, ro + 64u * v) = a[v];
             if (Q.dbrows) {
                 f4 r = a[v];
@@ -499,13 +533,12 @@ __global__ __launch_bounds__(64 * CV_NW, CVB_MIN_WAVES) void cost_volume_bwd_ker
         // ---- da1 = W2^T dz2;  dz1 = da1 leaky'(z1);  dp1 = sum over the 16 neighbours ----------------------------------
 #pragma unroll
         for (int v = 0; v < CV_V; ++v) h[v] = f4_zero();
-        mlp_layer_ws<CV_V, CV_V, 3 * L>(ws, a, h);
+        mlp_layer_ws<CV_V, CV_V, L>(ws, a, h);
         ws.next();   // wrap the stream to chunk 0
         float *dpr = Q.dp1 + i * 256 + 4 * g;
 #pragma unroll
         for (int v = 0; v < CV_V; ++v) {
-            const f4 act = *cv_at(Q.a1, ra + 64u * v);
-            f4 r = leaky_grad(h[v], act);
+            f4 r = leaky_grad_bits(h[v], (v < 8 ? m1.x : m1.y) >> (4 * (v & 7)));
             if (valid) *cv_at(Q.dz1, ro + 64u * v) = r;
             row_sum16_f4(r);
             if (valid && j == 0) *reinterpret_cast<f4 *>(dpr + 16 * v) = r;
@@ -535,43 +568,37 @@ __global__ __launch_bounds__(64 * CV_NW, CVB_MIN_WAVES) void cost_volume_bwd_ker
 }
 
 extern "C" int rtk_cost_volume_bwd(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
-                                   const float *p1, const float *p2, const float *wd_packed, const rtk_layer_t *layers,
-                                   const rtk_layer_t *wn, const float *wct_packed, const float *dout, int dout_pitch,
-                                   int act_pitch, float *a1, float *a2, float *dz1, float *dz2, float *dz3, float *dq3,
-                                   float *d4, float *dp1, float *dpd, float *dt2, float *dbias_rows, rtk_stream_t stream) {
-    RTK_REQUIRE(samples > 0 && n1 > 0 && n2 >= 16 && xyz1 && xyz2 && knn_idx && p1 && p2 && wd_packed && layers && dout && a1 &&
-                a2 && dz1 && dz2 && dz3 && dq3 && d4 && dp1 && dpd && dt2 && wct_packed, "cost_volume_bwd: bad arguments");
-    RTK_REQUIRE(act_pitch == 256 || (act_pitch >= 260 && act_pitch % 4 == 0), "cost_volume_bwd: bad act_pitch %d", act_pitch);
-    RTK_REQUIRE((double)samples * n1 * 16.0 * 4.0 * act_pitch < 4294967296.0, "cost_volume_bwd: more than 4 GiB per materialised tensor "
+                                   const rtk_layer_t *layers_t, const rtk_layer_t *wn, const float *wct_packed, const float *dout,
+                                   int dout_pitch, const float *a3, const void *mask1, const void *mask2, float *dz1, float *dz2, float *dz3,
+                                   float *dq3, float *d4, float *dp1, float *dpd, float *dt2, float *dbias_rows, rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && n1 > 0 && n2 >= 16 && xyz1 && xyz2 && knn_idx && layers_t && dout && mask1 && mask2 && a3 && dz1 && dz2 && dz3 &&
+                dq3 && d4 && dp1 && dpd && dt2 && wct_packed, "cost_volume_bwd: bad arguments");
+    RTK_REQUIRE((double)samples * n1 * 16.0 * 1024.0 < 4294967296.0, "cost_volume_bwd: more than 4 GiB per (position, 256) tensor "
                 "(32-bit row offsets): split the batch");
-    for (int l = 0; l < 4; ++l)
-        RTK_REQUIRE(layers[l].cin16 == 16 && layers[l].cout16 == 16 && layers[l].w_packed == layers[0].w_packed + (size_t)l * 256 * 256,
-                    "cost_volume_bwd: expects four contiguous 256x256 layers (W2, W3, W3^T, W2^T)");
+    RTK_REQUIRE(layers_t[0].cin16 == 16 && layers_t[0].cout16 == 16 && layers_t[1].cin16 == 16 && layers_t[1].cout16 == 16 &&
+                layers_t[1].w_packed == layers_t[0].w_packed + 256 * 256, "cost_volume_bwd: expects two contiguous 256x256 layers (W3^T, W2^T)");
     RTK_REQUIRE(dout_pitch % 4 == 0 && dout_pitch >= 256, "cost_volume_bwd: bad dout_pitch");
     RTK_REQUIRE(samples <= 65535, "cost_volume_bwd: too many samples");
     CvBwdParams Q;
     CvParams &P = Q.f;
     P.samples = samples; P.n1 = n1; P.n2 = n2;
-    P.xyz1 = xyz1; P.xyz2 = xyz2; P.knn = knn_idx; P.p1 = p1; P.p2 = p2; P.wd = wd_packed;
-    P.blob = reinterpret_cast<const f4 *>(layers[0].w_packed);
-    P.bias2 = layers[0].bias; P.bias3 = layers[1].bias;
+    P.xyz1 = xyz1; P.xyz2 = xyz2; P.knn = knn_idx; P.p1 = nullptr; P.p2 = nullptr; P.wd = nullptr;
+    P.blob = reinterpret_cast<const f4 *>(layers_t[0].w_packed);
+    P.bias2 = nullptr; P.bias3 = nullptr;
     if (fill_wn(P.wn, wn, "cost_volume_bwd") != RTK_OK) return RTK_ERR_INVALID;
     RTK_REQUIRE(wn[2].cout16 == 16, "cost_volume_bwd: WeightNet must produce 256 channels");
-    P.out = nullptr; P.out_pitch = 0;
+    P.out = nullptr; P.out_pitch = 0; P.sv1 = P.sv2 = P.sv3 = nullptr; P.mk1 = P.mk2 = nullptr;
     Q.dout = dout; Q.dout_pitch = dout_pitch;
-    Q.act_pitch = act_pitch; Q.wct = reinterpret_cast<const f4 *>(wct_packed);
-    Q.a1 = a1; Q.a2 = a2; Q.dz1 = dz1; Q.dz2 = dz2; Q.dz3 = dz3; Q.dq3 = dq3; Q.d4 = d4; Q.dp1 = dp1; Q.dpd = dpd; Q.dt2 = dt2; Q.dbrows = dbias_rows;
+    Q.wct = reinterpret_cast<const f4 *>(wct_packed);
+    Q.a3 = a3; Q.mk1 = (const uint2 *)mask1; Q.mk2 = (const uint2 *)mask2; Q.dz1 = dz1; Q.dz2 = dz2; Q.dz3 = dz3; Q.dq3 = dq3; Q.d4 = d4; Q.dp1 = dp1; Q.dpd = dpd; Q.dt2 = dt2;
+    Q.dbrows = dbias_rows;
     const int groups = (n1 + CV_NW - 1) / CV_NW;
     int gx = 256 * CV_WGS_PER_CU / samples;
     if (gx < 1) gx = 1;
     if (gx > groups) gx = groups;
-    if (samples % 8 == 0) {
-        P.gx = gx;
-        cost_volume_bwd_kernel<<<dim3(gx * samples), 64 * CV_NW, 0, (hipStream_t)stream>>>(Q);
-    } else {
-        P.gx = 0;
-        cost_volume_bwd_kernel<<<dim3(gx, samples), 64 * CV_NW, 0, (hipStream_t)stream>>>(Q);
-    }
+    P.gx = samples % 8 == 0 ? gx : 0;
+    const dim3 grid = P.gx ? dim3(gx * samples) : dim3(gx, samples);
+    cost_volume_bwd_kernel<<<grid, 64 * CV_NW, 0, (hipStream_t)stream>>>(Q);
     RTK_CHECK_LAUNCH("cost_volume_bwd");
     return RTK_OK;
 }

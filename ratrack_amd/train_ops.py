@@ -13,7 +13,8 @@ from . import _lib, fused
 _i, _f, _d, _p = ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 _LayerP = ctypes.POINTER(fused._Layer)
 _lib.SIGNATURES.update({
-    "rtk_cost_volume_bwd": [_i] * 3 + [_p] * 6 + [_LayerP, _LayerP, _p, _p, _i, _i] + [_p] * 11 + [_p],
+    "rtk_cost_volume_train": [_i] * 3 + [_p] * 6 + [_LayerP, _LayerP, _p, _i, _p, _p, _p, _p, _p, _p],
+    "rtk_cost_volume_bwd": [_i] * 3 + [_p] * 3 + [_LayerP, _LayerP, _p, _p, _i] + [_p] * 12 + [_p],
     "rtk_scatter_add_rows": [_i] * 4 + [_p] * 3 + [_p],
     "rtk_sa_first_layer": [_i] * 6 + [_p] * 4 + [_i] + [_p] * 3 + [_p],
     "rtk_group_inverse_index": [_i] * 3 + [_p] * 3 + [_p],
@@ -556,6 +557,8 @@ class _CvWeights:
         wn[1].w_packed, wn[1].bias, wn[1].cin16, wn[1].cout16 = self.wb.data_ptr(), self.bb.data_ptr(), 1, 1
         wn[2].w_packed, wn[2].bias, wn[2].cin16, wn[2].cout16 = self.wc.data_ptr(), self.bc.data_ptr(), 1, 16
         self.wn = wn
+        if backward:
+            self.layers_t = ctypes.cast(ctypes.byref(self.layers, 2 * ctypes.sizeof(L)), ctypes.POINTER(L))      # W3^T, W2^T
 
 
 def _tall_tn(a, b):
@@ -584,33 +587,36 @@ class _CostVolume(torch.autograd.Function):
         W = _CvWeights(wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, backward=True)
         ctx.images = W
         out = torch.empty(B * n1, 256, dtype=torch.float32, device=p1.device)
-        _lib.call("rtk_cost_volume", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
-                  W.wd.data_ptr(), W.layers, W.wn, out.data_ptr(), 256, _stream())
-        ctx.save_for_backward(p1, p2, wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, xyz1, xyz2, knn)
+        # the three activations are kept for the backward (3 x 268 MB at B = 64 of 288 GB): it then needs no recomputation and its
+        # weight-gradient GEMMs read the same tensors
+        acts = torch.empty(3, B * n1 * 16, 256, dtype=torch.float32, device=p1.device)
+        masks = torch.empty(2, B * n1 * 16, 4, dtype=torch.int64, device=p1.device)          # sign bits of a1, a2 (kernel lane order)
+        _lib.call("rtk_cost_volume_train", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
+                  W.wd.data_ptr(), W.layers, W.wn, out.data_ptr(), 256, acts[0].data_ptr(), acts[1].data_ptr(), acts[2].data_ptr(),
+                  masks[0].data_ptr(), masks[1].data_ptr(), _stream())
+        ctx.save_for_backward(acts, masks, wa, ba, wb, bb, wc, xyz1, xyz2, knn)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        p1, p2, wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, xyz1, xyz2, knn = ctx.saved_tensors
+        acts, masks, wa, ba, wb, bb, wc, xyz1, xyz2, knn = ctx.saved_tensors
         B, n1, _ = xyz1.shape
         n2 = xyz2.shape[1]
-        dev = p1.device
+        dev = acts.device
         M = B * n1 * 16
         dout = dout.contiguous()
         W = ctx.images
-        AP = 256      # a ones column (AP = 272) would fold the bias sums into the GEMMs, but N = 272 runs 2.2x slower than N = 256
-        big = torch.empty(6, M, 256, dtype=torch.float32, device=dev)
-        a1, a2, dz1, dz2, dz3, dq3 = big.unbind(0)
+        a1, a2, a3 = acts.unbind(0)
+        big = torch.empty(4, M, 256, dtype=torch.float32, device=dev)
+        dz1, dz2, dz3, dq3 = big.unbind(0)
         d4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
         dt2 = torch.empty(M, 8, dtype=torch.float32, device=dev)
         dp1 = torch.empty(B * n1, 256, dtype=torch.float32, device=dev)
         dpd = torch.empty(B * n1, 3, 256, dtype=torch.float32, device=dev)
         dbr = torch.empty(B * n1, 512, dtype=torch.float32, device=dev)       # per-query neighbour sums of dz3 | dz2
-        wct = W.wct
-        _lib.call("rtk_cost_volume_bwd", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
-                  W.wd.data_ptr(), W.layers, W.wn, wct.data_ptr(), dout.data_ptr(), 256, AP, a1.data_ptr(), a2.data_ptr(),
-                  dz1.data_ptr(), dz2.data_ptr(), dz3.data_ptr(), dq3.data_ptr(), d4.data_ptr(), dp1.data_ptr(), dpd.data_ptr(),
-                  dt2.data_ptr(), dbr.data_ptr(), _stream())
+        _lib.call("rtk_cost_volume_bwd", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), W.layers_t, W.wn, W.wct.data_ptr(),
+                  dout.data_ptr(), 256, a3.data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), dz1.data_ptr(), dz2.data_ptr(), dz3.data_ptr(),
+                  dq3.data_ptr(), d4.data_ptr(), dp1.data_ptr(), dpd.data_ptr(), dt2.data_ptr(), dbr.data_ptr(), _stream())
         dp2 = torch.empty(B * n2, 256, dtype=torch.float32, device=dev)
         _lib.call("rtk_scatter_add_rows", B, n1 * 16, n2, 256, knn.data_ptr(), dz1.data_ptr(), dp2.data_ptr(), _stream())
         # weight gradients: contractions over the M positions
@@ -632,26 +638,27 @@ def cost_volume(p1, p2, wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, xyz1, xyz2, 
 def time_cost_volume_bwd(batch, n, dev, iters=10):
     """Measurement helper (bench.py): rtk_cost_volume_bwd at the bench shape on random operands, `iters` back-to-back launches
     between two HIP events on the current stream.  Returns (ms per launch, FLOPs per launch): per (point, neighbour) pair the
-    forward recompute (2 x 256x256 + direction term + WeightNet + weighted sum) and the two 256x256 input gradients + Wc^T dq3."""
+    two 256x256 input gradients, Wc^T dq3 and the WeightNet recomputation + masks."""
     g = torch.Generator(dev).manual_seed(0)
     r = lambda *sh: torch.randn(*sh, device=dev, generator=g)
     B, M = batch, batch * n * 16
     xyz1, xyz2 = r(B, n, 3).contiguous(), r(B, n, 3).contiguous()
     knn = torch.randint(0, n, (B, n, 16), device=dev, generator=g)
-    p1, p2, dout = r(B * n, 256), r(B * n, 256), r(B * n, 256)
+    dout = r(B * n, 256)
     w2, w3 = r(256, 256) * 0.06, r(256, 256) * 0.06
     W = _CvWeights(r(256, 3), w2, r(256), w3, r(256), r(8, 3), r(8), r(8, 8), r(8), r(256, 8), r(256), backward=True)
-    big = torch.empty(6, M, 256, device=dev)
+    acts = r(3, M, 256)
+    masks = torch.randint(-2 ** 62, 2 ** 62, (2, M, 4), device=dev, generator=g)
+    big = torch.empty(4, M, 256, device=dev)
     d4, dt2 = torch.empty(M, 4, device=dev), torch.empty(M, 8, device=dev)
     dp1, dpd = torch.empty(B * n, 256, device=dev), torch.empty(B * n, 3, 256, device=dev)
     dbr = torch.empty(B * n, 512, device=dev)
     st = _stream()
 
     def launch():
-        _lib.call("rtk_cost_volume_bwd", B, n, n, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
-                  W.wd.data_ptr(), W.layers, W.wn, W.wct.data_ptr(), dout.data_ptr(), 256, 256, big[0].data_ptr(), big[1].data_ptr(),
-                  big[2].data_ptr(), big[3].data_ptr(), big[4].data_ptr(), big[5].data_ptr(), d4.data_ptr(), dp1.data_ptr(),
-                  dpd.data_ptr(), dt2.data_ptr(), dbr.data_ptr(), st)
+        _lib.call("rtk_cost_volume_bwd", B, n, n, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), W.layers_t, W.wn, W.wct.data_ptr(),
+                  dout.data_ptr(), 256, acts[2].data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), big[0].data_ptr(), big[1].data_ptr(),
+                  big[2].data_ptr(), big[3].data_ptr(), d4.data_ptr(), dp1.data_ptr(), dpd.data_ptr(), dt2.data_ptr(), dbr.data_ptr(), st)
     for _ in range(3):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -661,7 +668,7 @@ def time_cost_volume_bwd(batch, n, dev, iters=10):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    flops = 2.0 * M * (4 * 256 * 256 + 3 * 256 + 2136 + 256 + 8 * 256)
+    flops = 2.0 * M * (2 * 256 * 256 + (3 * 8 + 8 * 8 + 8 * 256) + 256 + 8 * 256)
     return ms, flops
 
 
