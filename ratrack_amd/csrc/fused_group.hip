@@ -535,32 +535,25 @@ __global__ __launch_bounds__(64 * CV_NW, CVB_MIN_WAVES) void cost_volume_bwd_ker
         for (int v = 0; v < CV_V; ++v) h[v] = f4_zero();
         mlp_layer_ws<CV_V, CV_V, L>(ws, a, h);
         ws.next();   // wrap the stream to chunk 0
+        // dz1 -> its store, dp1 (sum over the 16 neighbours) and the per-query partials of dWd = dz1^T d.  Direction components of
+        // position j are held by lanes (0,j), (1,j), (2,j) as their MFMA B operand.
         float *dpr = Q.dp1 + i * 256 + 4 * g;
+        float *dpd = Q.dpd + i * 768 + 4 * g;
+        const float dx = __shfl(bop, j, 64), dy = __shfl(bop, 16 + j, 64), dzc = __shfl(bop, 32 + j, 64);
 #pragma unroll
         for (int v = 0; v < CV_V; ++v) {
             f4 r = leaky_grad_bits(h[v], (v < 8 ? m1.x : m1.y) >> (4 * (v & 7)));
             if (valid) *cv_at(Q.dz1, ro + 64u * v) = r;
+            f4 rx = r * dx, ry = r * dy, rz = r * dzc;
             row_sum16_f4(r);
-            if (valid && j == 0) *reinterpret_cast<f4 *>(dpr + 16 * v) = r;
-        }
-        // per-query partials of dWd = dz1^T d, in a second sweep over this lane's own dz1 stores (the activation registers
-        // are dead by now; doing it in the loop above spills).  Direction components of position j are held by lanes
-        // (0,j), (1,j), (2,j) as their MFMA B operand.
-        if (valid) {
-            float *dpd = Q.dpd + i * 768 + 4 * g;
-            const float dx = __shfl(bop, j, 64), dy = __shfl(bop, 16 + j, 64), dzc = __shfl(bop, 32 + j, 64);
-#pragma unroll 4
-            for (int v = 0; v < CV_V; ++v) {
-                const f4 r = *cv_at(Q.dz1, ro + 64u * v);
-                f4 rx = r * dx, ry = r * dy, rz = r * dzc;
-                row_sum16_f4(rx);
-                row_sum16_f4(ry);
-                row_sum16_f4(rz);
-                if (j == 0) {
-                    *reinterpret_cast<f4 *>(dpd + 16 * v) = rx;
-                    *reinterpret_cast<f4 *>(dpd + 256 + 16 * v) = ry;
-                    *reinterpret_cast<f4 *>(dpd + 512 + 16 * v) = rz;
-                }
+            row_sum16_f4(rx);
+            row_sum16_f4(ry);
+            row_sum16_f4(rz);
+            if (valid && j == 0) {
+                *reinterpret_cast<f4 *>(dpr + 16 * v) = r;
+                *reinterpret_cast<f4 *>(dpd + 16 * v) = rx;
+                *reinterpret_cast<f4 *>(dpd + 256 + 16 * v) = ry;
+                *reinterpret_cast<f4 *>(dpd + 512 + 16 * v) = rz;
             }
         }
     }
