@@ -308,7 +308,7 @@ class Geometry:
     """FPS centroids, ball-query indices and three-NN tables of one batch of clouds (feature independent,
     so the decoder's PNHead over pc1 reuses the encoder's)."""
 
-    def __init__(self, xyz, npoint, side=None, knn_frames=0, finite=False, n_valid=None):
+    def __init__(self, xyz, npoint, side=None, knn_frames=0, finite=False, n_valid=None, level_hook=None, tail_hook=None):
         """xyz (S_,n,3).  With `side` (a torch.cuda.Stream) every geometry kernel is enqueued on that stream, forked from
         the current one, and consumers call wait(stage) -- the feature kernels overlap the latency-bound FPS chain.
         knn_frames = B > 0: also the two kNN tables of the cost volume, frame 1 = xyz[:B], frame 2 = xyz[B:].
@@ -316,7 +316,9 @@ class Geometry:
         (the training path computes -- and ignores -- those rows, so they must hold finite numbers).
         n_valid (S_,) int32: padded batch (ratrack_amd/vod_gt.pad_frame_pairs) -- cloud s consists of its first n_valid[s]
         points, the rest are copies of its point 0; FPS applies the unpadded cloud's tie rule and the kNN tables only
-        hold valid candidates, everything else is exact through the duplicate-of-point-0 property."""
+        hold valid candidates, everything else is exact through the duplicate-of-point-0 property.
+        level_hook(geo, lvl) / tail_hook(geo): called (on the geometry stream) right after level lvl's ball query, before its
+        event is recorded / after the three-NN tables -- the training path enqueues its per-level tables there."""
         S_, n, _ = xyz.shape
         if n_valid is not None:
             assert n_valid.shape == (S_,) and n_valid.dtype == torch.int32 and n_valid.is_contiguous() and n <= 2048
@@ -396,6 +398,8 @@ class Geometry:
                     for s in range(2):
                         _native.ball_query_wrapper(S_, nsrc, npoint, float(_PNHeadWeights.RADII[lvl][s]), _PNHeadWeights.NSAMPLES[lvl][s],
                                                    self.xyz[lvl + 1], self.xyz[lvl], self.ball[lvl][s])
+                if level_hook is not None:
+                    level_hook(self, lvl)
                 self._record(lvl, side)
                 if lvl == 0:
                     relevel()
@@ -421,6 +425,8 @@ class Geometry:
                     _lib.call("rtk_knn_point_masked", B, n, n, 16, x1.data_ptr(), x1.data_ptr(), self.knn[1].data_ptr(),
                               n_valid[:B].data_ptr(), _stream())
                 self._record("knn", side)
+            if tail_hook is not None:
+                tail_hook(self)
 
     def _record(self, key, side):
         if side is not None:

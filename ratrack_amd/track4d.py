@@ -9,8 +9,15 @@ reference's forward (moving-point clustering, Affinity MLP, log-Sinkhorn associa
 import torch
 import torch.nn as nn
 
+import os
+
 from . import association as A
 from .model_utils import FeatureCorrelator, FlowDecoder, PNHead
+
+# Experiment knob, default off: the training path's geometry kernels (FPS, ball queries, three-NN, index tables) on a forked stream,
+# as the inference engine does.  Measured inside the captured train step: 10.98 ms vs 10.86 ms (B=64), 3.92 vs 3.64 ms (B=1) --
+# the cross-stream dependencies of the replayed graph cost more than the ~0.5 ms of overlapped geometry saves.
+TRAIN_SIDE_STREAM = bool(int(os.environ.get("RTK_TRAIN_SIDE", "0")))
 
 
 class Affinity(nn.Module):
@@ -81,7 +88,10 @@ class Track4D(nn.Module):
                 # training step: both frames as one stacked batch (per-frame BatchNorm statistics) on de-duplicated levels
                 B = pc1.shape[0]
                 with torch.no_grad():
-                    tg = TP.TrainGeometry(torch.cat([pc1, pc2], 0).permute(0, 2, 1).contiguous(), self.pn_head.sa1.npoint)
+                    if TRAIN_SIDE_STREAM and getattr(self, "_train_side", None) is None:
+                        self._train_side = torch.cuda.Stream(device=pc1.device)
+                    tg = TP.TrainGeometry(torch.cat([pc1, pc2], 0).permute(0, 2, 1).contiguous(), self.pn_head.sa1.npoint,
+                                          side=self._train_side if TRAIN_SIDE_STREAM else None)
                 f = TP.pnhead_train(self.pn_head, tg, torch.cat([feature1, feature2], 0), groups=2)
                 (f1, f2), tg1 = f.view(2, B, f.shape[1], f.shape[2]).unbind(0), tg.head(B)
         if tg1 is None:
@@ -96,6 +106,8 @@ class Track4D(nn.Module):
         else:
             cor_features = self.fc_layer(pc1, pc2, pc1_features, pc2_features)
         output, h, prop_features, cls = self.fd_layer(pc1, feature1, pc1_features, cor_features, h, train_geo=tg1)
+        if tg1 is not None:
+            tg1.join()          # every forked stream is joined before the forward returns (a requirement inside a stream capture)
         return output, h, cls, cor_features, pc1_features, pc2_features, prop_features
 
     def _backbone_per_sample(self, pc1, pc2, feature1, feature2, h, n_valid):

@@ -457,7 +457,9 @@ class _SAChain(torch.autograd.Function):
         C1 = dz.shape[1]
         dproj = torch.empty(S_, C1, n_src, dtype=torch.float32, device=dev)
         if ctx.inv is not None:
-            off, inv = ctx.inv
+            off, inv = ctx.inv[0], ctx.inv[1]
+            if len(ctx.inv) > 2 and ctx.inv[2] is not None:        # table built on the geometry stream (TrainGeometry)
+                torch.cuda.current_stream().wait_event(ctx.inv[2])
             _lib.call("rtk_sa_first_layer_bwd", S_, C1, rows, ns, n_src, dz.data_ptr(), dxyz.data_ptr(), off.data_ptr(), inv.data_ptr(),
                       dproj.data_ptr(), dW0.data_ptr(), dW0.stride(0), _stream())
         else:

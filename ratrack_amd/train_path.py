@@ -29,58 +29,79 @@ FUSED_SA_CHAIN = True      # False: one bn_relu + framework convolution per laye
 
 
 class TrainGeometry:
-    """De-duplicated view of fused.Geometry for one stacked batch of clouds xyz (S_, n, 3)."""
+    """De-duplicated view of fused.Geometry for one stacked batch of clouds xyz (S_, n, 3).
 
-    def __init__(self, xyz, npoint):
+    With `side` (a torch.cuda.Stream) every geometry kernel -- FPS, ball queries, three-NN, and this class's own tables -- is
+    enqueued on that stream, forked from the current one; consumers call wait(key) (key = level 0..2, "interp", "inv") before
+    the first use, so the ~0.5 ms chain of small latency-bound geometry kernels overlaps the feature kernels instead of
+    preceding them.  All buffers are allocated on the current stream before the fork; join() makes the current stream wait
+    for everything (the forward ends with it: inside a stream capture every forked stream must be joined)."""
+
+    def __init__(self, xyz, npoint, side=None):
         from . import fused
-        geo = fused.Geometry(xyz, npoint, side=None, knn_frames=0, finite=True)
         S_, n, _ = xyz.shape
         self.samples, self.n, self.npoint = S_, n, npoint
         U = self.U = min(n, npoint)
         dev = xyz.device
-        nu = geo.nuniq                                            # per level: (S_,) int32 unique-centroid counts
-        st = torch.cuda.current_stream().cuda_stream
         f32 = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
         i32 = lambda *sh: torch.empty(*sh, dtype=torch.int32, device=dev)
-        self.row_w = []
+        NS = fused._PNHeadWeights.NSAMPLES
+        self.row_w = [f32(S_, U) for _ in range(3)]
+        self.ball = [[i32(S_, U, ns) for ns in NS[lvl]] for lvl in range(3)]
+        self.dxyz = [[f32(S_, 3, U, ns) for ns in NS[lvl]] for lvl in range(3)]
+        self.inv = []
         for lvl in range(3):
-            w = f32(S_, U)
-            _lib.call("rtk_train_row_weights", S_, U, npoint, nu[lvl].data_ptr(), w.data_ptr(), st)
-            self.row_w.append(w)
-        self.ball, self.dxyz, self.inv = [], [], []
-        for lvl in range(3):
-            src, dst = geo.xyz[lvl], geo.xyz[lvl + 1]             # (S_, n or npoint, 3), (S_, npoint, 3)
-            rows_b, rows_d, rows_i = [], [], []
-            for s in range(2):
-                ball = geo.ball[lvl][s]
-                ns = ball.shape[2]
-                idx, d = i32(S_, U, ns), f32(S_, 3, U, ns)
-                # source rows >= nuniq are copies of row 0: redirect; neighbour - centroid offsets (no gradient)
-                _lib.call("rtk_train_group_geometry", S_, src.shape[1], npoint, U, ns, src.data_ptr(), dst.data_ptr(), ball.data_ptr(),
-                          nu[lvl - 1].data_ptr() if lvl > 0 else None, idx.data_ptr(), d.data_ptr(), st)
-                rows_b.append(idx)
-                rows_d.append(d)
-                # positions sorted by the source row they gather: the first layer's backward is a gather instead of a scatter
+            row = []
+            for ns in NS[lvl]:
                 n_src = n if lvl == 0 else U
-                if U * ns <= 65536 and n_src <= 8192 and ns % 4 == 0:
-                    off = i32(S_, n_src + 1)
-                    inv = torch.empty(S_, U * ns, dtype=torch.int16, device=dev)
-                    _lib.call("rtk_group_inverse_index", S_, n_src, U * ns, idx.data_ptr(), off.data_ptr(), inv.data_ptr(), st)
-                    rows_i.append((off, inv))
-                else:
-                    rows_i.append(None)
-            self.ball.append(rows_b)
-            self.dxyz.append(rows_d)
-            self.inv.append(rows_i)
-        self.interp = {}
-        for name, (u, k) in {"fp3": (2, 3), "fp2": (1, 2), "fp1": (0, 1)}.items():
-            d2, idx, _ = geo.nn[name]
-            rows = n if u == 0 else U
-            io, wo = i32(S_, rows, 3), f32(S_, rows, 3)
-            _lib.call("rtk_train_interp_weights", S_, d2.shape[1], rows, d2.data_ptr(), idx.data_ptr(), nu[k - 1].data_ptr(), io.data_ptr(),
-                      wo.data_ptr(), st)
-            self.interp[name] = (io, wo)
+                # positions sorted by the source row they gather: the first layer's backward is a gather instead of a scatter
+                row.append((i32(S_, n_src + 1), torch.empty(S_, U * ns, dtype=torch.int16, device=dev))
+                           if U * ns <= 65536 and n_src <= 8192 and ns % 4 == 0 else None)
+            self.inv.append(row)
+        self.interp = {name: (i32(S_, n if u == 0 else U, 3), f32(S_, n if u == 0 else U, 3))
+                       for name, (u, k) in {"fp3": (2, 3), "fp2": (1, 2), "fp1": (0, 1)}.items()}
+        st = lambda: torch.cuda.current_stream().cuda_stream
+
+        def level_tables(geo, lvl):
+            nu = geo.nuniq
+            _lib.call("rtk_train_row_weights", S_, U, npoint, nu[lvl].data_ptr(), self.row_w[lvl].data_ptr(), st())
+            src, dst = geo.xyz[lvl], geo.xyz[lvl + 1]             # (S_, n or npoint, 3), (S_, npoint, 3)
+            for s in range(2):
+                # source rows >= nuniq are copies of row 0: redirect; neighbour - centroid offsets (no gradient)
+                _lib.call("rtk_train_group_geometry", S_, src.shape[1], npoint, U, NS[lvl][s], src.data_ptr(), dst.data_ptr(),
+                          geo.ball[lvl][s].data_ptr(), nu[lvl - 1].data_ptr() if lvl > 0 else None, self.ball[lvl][s].data_ptr(),
+                          self.dxyz[lvl][s].data_ptr(), st())
+
+        def tail_tables(geo):
+            nu = geo.nuniq
+            for name, (u, k) in {"fp3": (2, 3), "fp2": (1, 2), "fp1": (0, 1)}.items():
+                d2, idx, _ = geo.nn[name]
+                io, wo = self.interp[name]
+                _lib.call("rtk_train_interp_weights", S_, d2.shape[1], io.shape[1], d2.data_ptr(), idx.data_ptr(), nu[k - 1].data_ptr(),
+                          io.data_ptr(), wo.data_ptr(), st())
+            geo._record("interp", side)
+            for lvl in range(3):                                   # needed by the backward only: last
+                for s in range(2):
+                    if self.inv[lvl][s] is not None:
+                        off, inv = self.inv[lvl][s]
+                        _lib.call("rtk_group_inverse_index", S_, n if lvl == 0 else U, U * NS[lvl][s], self.ball[lvl][s].data_ptr(),
+                                  off.data_ptr(), inv.data_ptr(), st())
+            geo._record("inv", side)
+
+        geo = fused.Geometry(xyz, npoint, side=side, knn_frames=0, finite=True, level_hook=level_tables, tail_hook=tail_tables)
+        self.events, self.side = geo.events, side
         self.l3_xyz = geo.xyz[3]
+        self._geo = geo                                            # keeps the tables' inputs alive until the side stream is joined
+
+    def wait(self, key):
+        """Make the current stream wait for stage `key`: 0..2 (level tables), "interp", "inv"."""
+        ev = self.events.get(key)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def join(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
 
     def head(self, count):
         """View on the first `count` samples (the pc1 half of a stacked batch)."""
@@ -92,6 +113,7 @@ class TrainGeometry:
         g.inv = [[None if t is None else (t[0][:count], t[1][:count]) for t in row] for row in self.inv]
         g.interp = {k: (i[:count], w[:count]) for k, (i, w) in self.interp.items()}
         g.l3_xyz = self.l3_xyz[:count]
+        g.events, g.side, g._geo = self.events, self.side, self._geo
         return g
 
 
@@ -114,12 +136,16 @@ def _sa_scale(mlp, tg, lvl, s, feats, groups):
     feats = list(feats) if isinstance(feats, (list, tuple)) else [feats]
     layers = list(mlp.children())
     w = layers[0].conv.weight                                     # (C1, 3+C, 1, 1): [d_xyz | features]
+    if hasattr(tg, "wait"):
+        tg.wait(lvl)
     idx = tg.ball[lvl][s]
     ns = idx.shape[2]
     count = (tg.samples // groups) * tg.npoint * ns
     if FUSED_SA_CHAIN and sa_chain_supported(layers) and ns >= 4:
-        return sa_chain(feats, w, idx, tg.dxyz[lvl][s], layers, tg.row_w[lvl], count, groups,
-                        inv=tg.inv[lvl][s] if getattr(tg, "inv", None) is not None else None)
+        inv = tg.inv[lvl][s] if getattr(tg, "inv", None) is not None else None
+        if inv is not None and getattr(tg, "events", None):
+            inv = inv + (tg.events.get("inv"),)                    # the backward waits for the table (built last on the side stream)
+        return sa_chain(feats, w, idx, tg.dxyz[lvl][s], layers, tg.row_w[lvl], count, groups, inv=inv)
     # reference structure (kept for tests): per-POINT projection by the layer's feature columns (a 1x1 conv and a gather commute)
     cols, c = [], 3
     for f in feats:
@@ -137,6 +163,8 @@ def _sa_scale(mlp, tg, lvl, s, feats, groups):
 
 
 def _fp(fp, tg, name, skip, known_feats, row_w, count_rows, groups):
+    if hasattr(tg, "wait"):
+        tg.wait("interp")
     idx, weight = tg.interp[name]
     x = PU.three_interpolate(known_feats.contiguous(), idx, weight)
     srcs = [x] if skip is None else [x, skip]                      # lib/pointnet2_modules.py:150-153: cat([interpolated, skip])
