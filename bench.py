@@ -252,7 +252,7 @@ def main():
     ap.add_argument("--no-train", action="store_true", help="skip the train-step leg of the default (forward) run")
     ap.add_argument("--no-irregular", action="store_true", help="skip the irregular-op roofline leg")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
-    ap.add_argument("--pipeline", type=int, default=2, help="captured graphs in flight (batch-level pipelining on streams)")
+    ap.add_argument("--pipeline", type=int, default=4, help="captured graphs in flight (batch-level pipelining on streams)")
     ap.add_argument("--train-steps", type=int, default=20)
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
                     help="forward = the headline metric (eval backbone, fused kernels) with the train step embedded as `train`; "
@@ -357,6 +357,10 @@ def main():
         torch.cuda.synchronize()
         events = events[-a.steps:]
         kern_ms = sum(s.elapsed_time(e) for s, e in events) / max(len(events), 1)
+        # the same kernel on the same operands with nothing else on the GPU (what a serialising profiler such as
+        # rocprofv3 --kernel-trace reports for it)
+        alone = eng.time_dominant_kernel(20)
+        alone_ms = sum(s.elapsed_time(e) for s, e in alone) / len(alone)
 
     res = None
     if rank == 0:
@@ -382,8 +386,13 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4),
                          "traffic": pm["traffic_bytes_per_launch"] if pm else None,
                          "kernel_ms": round(kern_ms, 4), "flops_per_launch": cv_flops,
+                         "alone": {"kernel_ms": round(alone_ms, 4), "frac": round(cv_flops / (alone_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                                   "what": "the same launch with nothing else in flight (back-to-back launches between HIP events; what "
+                                           "rocprofv3 --kernel-trace, which serialises dispatches, shows): in situ the kernel shares the "
+                                           "CUs with the kernels of the other batches in flight, which is what the pipelining is for"},
                          "measured": "in situ: %d launches between HIP events inside a timed region of the same pipelined workload "
-                                     "(graphs split around the kernel; %.4f ms/step there)" % (len(events), insitu / a.steps * 1e3)},
+                                     "(graphs split around the kernel, the measured kernels of the batches in flight chained by events "
+                                     "so that they do not time-share the CUs; %.4f ms/step there)" % (len(events), insitu / a.steps * 1e3)},
             # whole path per GPU against both rooflines (SURVEY.md H1 asks for both).  "algorithmic" = the reference
             # formulation's 14.15 MB / 4.003 GFLOP per pair; "executed" = the multiply-adds this design issues (per-point
             # layer-1 projections, duplicate centroids skipped), counted from this run's launch shapes.

@@ -521,8 +521,9 @@ class FusedBackbone:
         self.gru_whh = g("weight_hh").transpose(1, 2).contiguous()
         self.gru_bih, self.gru_bhh = g("bias_ih").contiguous(), g("bias_hh").contiguous()
         self.kernel_events = None      # set to a list to record (start, stop) events around the dominant kernel
+        self.kernel_token = None       # [last stop event] shared by the engines of a GraphPipeline while kernel_events is set
         self._split_hook = None
-        self.side, self.use_side_stream = None, True    # geometry kernels run on a forked stream
+        self.side, self.use_side_stream = None, bool(int(__import__("os").environ.get("RTK_EVAL_SIDE", "1")))    # geometry kernels on a forked stream
         self._last_cv = None
         self.enc = _PNHeadWeights(sd, "pn_head.", dev)
         self.dec = _PNHeadWeights(sd, "fd_layer.mse.", dev)
@@ -735,12 +736,19 @@ class FusedBackbone:
             g1.replay()
             ev = eng.kernel_events
             if ev is not None:
+                tok = eng.kernel_token
+                if tok is not None and tok[0] is not None:
+                    # the measured kernels of the batches in flight run one after the other (they would otherwise time-share the
+                    # CUs and every event pair would span its neighbours' run time as well); everything else still overlaps
+                    torch.cuda.current_stream().wait_event(tok[0])
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             eng._cost_volume(*cv_args)
             if ev is not None:
                 e1.record()
                 ev.append((e0, e1))
+                if tok is not None:
+                    tok[0] = e1
             g2.replay()
             return outs
         step.graph = (g1, g2)
@@ -751,19 +759,28 @@ class GraphPipeline:
     """Batch-level software pipeline for throughput: `depth` captured backbone graphs, each with its own static
     buffers and geometry side stream, replayed round-robin on `depth` streams.  While one batch sits in its
     latency-bound phases (FPS chain, small gathers) the MFMA stages of the previous/next batch keep the CUs busy
-    (measured on MI355X at B=64, N=256: 1.85 -> 1.57 ms per batch with depth 2; depth 3 gives nothing more).
+    (measured on MI355X at B=64, N=256, round 2: 1.71 ms per batch with one graph in flight, 1.41 with two, 1.31 with four).
+    With more than two batches in flight the engines run their geometry kernels on their own stream instead of a forked one:
+    depth x 2 streams oversubscribe the four hardware queues and serialise falsely (1.43 ms at depth 4 with forked geometry
+    streams), and four independent chains fill the idle phases better than two forked ones.
     Weights are shared between the engines.  Usage:  p = GraphPipeline(net, example_inputs); outs = p.submit(*inputs)
     ... p.drain().  Outputs of a submit stay valid until the same slot is reused, `depth` submits later."""
 
     def __init__(self, model_or_engine, example_inputs, depth=2, split_cost_volume=False):
         import copy
         eng = model_or_engine if isinstance(model_or_engine, FusedBackbone) else FusedBackbone(model_or_engine)
+        if depth > 2:
+            eng = copy.copy(eng)
+            eng.use_side_stream, eng.side = False, None
         self.engines = [eng]
         for _ in range(depth - 1):
             e = copy.copy(eng)          # shallow: packed weights are shared, per-engine state is reset below
             e.side, e._last_cv, e.kernel_events = None, None, None
             self.engines.append(e)
         self.depth = depth
+        self._token = [None]
+        for e in self.engines:
+            e.kernel_token = self._token
         with torch.no_grad():
             self.steps = [e.capture(*example_inputs, split_cost_volume=split_cost_volume) for e in self.engines]
         self.streams = [torch.cuda.Stream() for _ in range(depth)]
