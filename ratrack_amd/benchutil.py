@@ -110,11 +110,20 @@ def irregular_ops(batch, n, dev, npoint=512, iters=20, pmc=None):
                                  st()), iters)
     add("scatter_add_rows_kernel", 2, ms, M * 256 * 4 + M * 8 + batch * n * 256 * 4,
         "gather backward of the cost volume: %d rows x 256 ch -> %d rows, atomic-free" % (M, batch * n))
-    rows, ns, C = int(min(n, npoint)), 32, 64
-    gidx = torch.randint(0, rows, (S_, rows, ns), dtype=torch.int32, device=dev)
-    dz, dq = torch.randn(S_, C, rows, ns, device=dev), f32(S_, C, rows)
-    ms = _time(lambda: _lib.call("rtk_group_points_grad_set", S_, C, rows, rows, ns, dz.data_ptr(), gidx.data_ptr(), dq.data_ptr(), st()),
-               iters)
-    add("group_points_grad_kernel", 12, ms, S_ * (C * rows * ns * 4 + rows * ns * 4 + C * rows * 4),
-        "grouping backward, largest SA shape: %d ch x %d centroids x %d neighbours (LDS float atomics)" % (C, rows, ns))
+    # first-layer backward of the largest set-abstraction scale (level 3, 64 channels x 32 neighbours): gather form over the inverse
+    # index (the reference scatters with one atomicAdd per element, group_points_gpu.cu:8-25)
+    from .train_path import TrainGeometry
+    tg = TrainGeometry(xyz, npoint)
+    idx3, dxyz3 = tg.ball[2][1], tg.dxyz[2][1]
+    rows, ns, C = idx3.shape[1], idx3.shape[2], 64
+    off, inv = tg.inv[2][1]
+    ms = _time(lambda: _lib.call("rtk_group_inverse_index", S_, rows, rows * ns, idx3.data_ptr(), off.data_ptr(), inv.data_ptr(), st()), iters)
+    add("inverse_index_kernel", 6, ms, S_ * (rows * ns * 4 + rows * ns * 2 + (rows + 1) * 4),
+        "positions sorted by gathered source row, largest table: %d centroids x %d neighbours" % (rows, ns))
+    dz, dproj, dwx = torch.randn(S_, C, rows, ns, device=dev), f32(S_, C, rows), torch.zeros(C, 3, device=dev)
+    ms = _time(lambda: _lib.call("rtk_sa_first_layer_bwd", S_, C, rows, ns, rows, dz.data_ptr(), dxyz3.data_ptr(), off.data_ptr(),
+                                 inv.data_ptr(), dproj.data_ptr(), dwx.data_ptr(), 3, st()), iters)
+    add("sa_first_layer_bwd_kernel", 12, ms, S_ * (C * rows * ns * 4 + 3 * rows * ns * 4 + rows * ns * 2 + C * rows * 4),
+        "first-layer backward (projection gradient + offset-weight gradient), largest SA shape: %d ch x %d centroids x %d neighbours"
+        % (C, rows, ns))
     return out
