@@ -589,3 +589,70 @@ def test_fused_backbone_loss_matches_framework_formulation(B, N, pretrain, vec):
     assert float((res[0][2] - res[1][2]).abs().max()) <= 2e-5 * float(res[1][2].abs().max())
     if not vec and B > 1:
         assert float(res[0][2][1].abs().max()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N", [(2, 256), (3, 77)])
+def test_cost_volume_train_forward_keeps_what_the_backward_needs(B, N):
+    """rtk_cost_volume_train = rtk_cost_volume (bit for bit) + the three activations and the sign masks of the first two, in the
+    backward kernel's lane order: bit 4v + r of word (position, g) <-> channel 16v + 4g + r."""
+    from ratrack_amd import _lib, train_ops as T
+    from ratrack_amd.model_utils import knn_point
+    g = torch.Generator(DEV).manual_seed(4)
+    r = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    d = synth.make_frame_pairs(B, N, 5)
+    x1 = torch.from_numpy(d["pc1"]).to(DEV).permute(0, 2, 1).contiguous()
+    x2 = torch.from_numpy(d["pc2"]).to(DEV).permute(0, 2, 1).contiguous()
+    knn = knn_point(16, x2, x1).contiguous()
+    p1, p2 = r(B * N, 256) * 0.5, r(B * N, 256) * 0.5
+    W = T._CvWeights(r(256, 3), r(256, 256) * 0.06, r(256) * 0.1, r(256, 256) * 0.06, r(256) * 0.1, r(8, 3), r(8), r(8, 8) * 0.3, r(8),
+                     r(256, 8) * 0.3, r(256), backward=True)
+    M = B * N * 16
+    st = torch.cuda.current_stream().cuda_stream
+    out_a, out_b = torch.empty(B * N, 256, device=DEV), torch.empty(B * N, 256, device=DEV)
+    acts = torch.full((3, M, 256), float("nan"), device=DEV)
+    masks = torch.zeros(2, M, 4, dtype=torch.int64, device=DEV)
+    common = (B, N, N, x1.data_ptr(), x2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(), W.wd.data_ptr(), W.layers, W.wn)
+    _lib.call("rtk_cost_volume", *common, out_a.data_ptr(), 256, st)
+    _lib.call("rtk_cost_volume_train", *common, out_b.data_ptr(), 256, acts[0].data_ptr(), acts[1].data_ptr(), acts[2].data_ptr(),
+              masks[0].data_ptr(), masks[1].data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b)
+    assert torch.isfinite(acts).all()
+    # layer 1 from its definition: leaky(p1[i] + p2[nbr] + Wd d)   (the kernel's offset product is an MFMA: compare with a tolerance)
+    nbr = (knn + (torch.arange(B, device=DEV) * N).view(B, 1, 1)).view(-1)
+    dvec = (x2.reshape(B * N, 3)[nbr] - x1.reshape(B * N, 3).repeat_interleave(16, 0))
+    a1 = torch.nn.functional.leaky_relu(p1.repeat_interleave(16, 0) + p2[nbr] + dvec @ r_wd(W, DEV).t(), 0.1)
+    assert float((acts[0] - a1).abs().max()) <= 1e-4 * float(a1.abs().max())
+    for a, m in ((acts[0], masks[0]), (acts[1], masks[1])):
+        words = m.view(M, 4, 1)                                                    # (position, g): 64 bits
+        bits = (words >> torch.arange(64, device=DEV).view(1, 1, 64)) & 1          # bit 4v + r
+        got = bits.view(M, 4, 16, 4).permute(0, 2, 1, 3).reshape(M, 256).bool()    # channel 16v + 4g + r
+        assert torch.equal(got, a > 0)
+
+
+def r_wd(W, dev):
+    """The (256, 3) offset weights back from the packed [16][64] image of _CvWeights (fragment v, lane (g, i): row 16v + i, column g)."""
+    img = W.wd.view(16, 4, 16)                                                     # [v][g][i]
+    return img.permute(0, 2, 1).reshape(256, 4)[:, :3].contiguous()
+
+
+@pytest.mark.gpu
+def test_weight_gradient_operators_are_deterministic():
+    """Round 2 replaced the float atomics of the weight-gradient operators by workgroup partials added in a fixed order: the same
+    inputs give the same bits."""
+    from ratrack_amd import train_ops as T
+    g = torch.Generator(DEV).manual_seed(8)
+    r = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    srcs = [r(24, 64, 200), r(24, 35, 200)]
+    W, dz = r(128, 99), r(24, 128, 200)
+    runs = [T._pw_backward([False, False], srcs, [0, 64], W, dz, True) for _ in range(3)]
+    for dW, db, _ in runs[1:]:
+        assert torch.equal(dW, runs[0][0]) and torch.equal(db, runs[0][1])
+    M, C = 5000, 256
+    d4, dq3, dt2 = r(M, 4), r(M, C), r(M, 8)
+    wa, ba, wb, bb, wc = r(8, 3), r(8), r(8, 8), r(8), r(C, 8)
+    runs = [T._weightnet_backward(d4, dq3, dt2, wa, ba, wb, bb, wc) for _ in range(3)]
+    for res in runs[1:]:
+        for a, b in zip(res, runs[0]):
+            assert torch.equal(a, b)
