@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 #include "fused_common.h"
 #include "rtk_common.h"
 #include "rtk_train.h"
@@ -380,7 +382,11 @@ int launch(const TcParams &Q, int cin, int cout, hipStream_t s) {
     const int U = cin / 16, V = cout / 16;
     const int nchunks = (Q.P + TC_CHUNK - 1) / TC_CHUNK;
     int gx = (nchunks + 3) / 4;                       // one chunk per wave per pass ...
-    while ((long)gx * Q.samples > 2048 && gx > 1) gx = (gx + 1) / 2;   // ... but few, fat workgroups: LDS fill + atomics are paid per workgroup
+    // ... but few, fat workgroups (the weight tile and the BatchNorm constants are staged per workgroup); measured per mode at the
+    // largest set-abstraction shape (tools/exp_convbn.py): the forward and the statistics pass like them fatter than the apply pass
+    static const int env_wgs = getenv("RTK_TC_WGS") ? atoi(getenv("RTK_TC_WGS")) : 0;      // experiment knob
+    const int max_wgs = env_wgs ? env_wgs : MODE == 0 ? 1024 : MODE == 1 ? 512 : 4096;
+    while ((long)gx * Q.samples > max_wgs && gx > 1) gx = (gx + 1) / 2;
     const dim3 grid(gx, Q.samples);
 #define TC_CASE(u, v)                                                    \
     if (U == u && V == v) {                                              \
