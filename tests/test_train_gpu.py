@@ -656,3 +656,40 @@ def test_weight_gradient_operators_are_deterministic():
     for res in runs[1:]:
         for a, b in zip(res, runs[0]):
             assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_weight_gradient_workspaces_of_any_size_give_the_same_sums():
+    """The partial-block workspaces only set how far the position axis is split: no workspace (one workgroup per block), a
+    one-block workspace and the full one agree to rounding; an undersized workspace of rtk_conv_wgrad / rtk_weightnet_bwd is refused."""
+    from ratrack_amd import _lib, train_ops as T
+    g = torch.Generator(DEV).manual_seed(9)
+    r = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    st = torch.cuda.current_stream().cuda_stream
+    S, P, ci, co = 16, 200, 70, 96
+    x, dz = r(S, ci, P), r(S, co, P)
+    ref = torch.einsum("sop,skp->ok", dz.double(), x.double()).float()
+    for nfloats in (0, 4096 * 4, 4 << 20):
+        ws = torch.empty(max(nfloats, 1), device=DEV)
+        dW, db = torch.zeros(co, ci, device=DEV), torch.zeros(co, device=DEV)
+        _lib.call("rtk_pw_wgrad", S, P, T._pw_operands([dz], [0]), 1, T._pw_operands([x], [0]), dW.data_ptr(), dW.stride(0), db.data_ptr(),
+                  ws.data_ptr() if nfloats else None, nfloats, st)
+        assert float((dW - ref).norm()) <= 1e-5 * float(ref.norm()), nfloats
+        assert torch.allclose(db, dz.sum((0, 2)), rtol=1e-4, atol=1e-3)
+    # rtk_weightnet_bwd: one partial vector is enough; less is an error, not a silent fallback
+    M, C = 3000, 64
+    d4, dq3, dt2 = r(M, 4), r(M, C), r(M, 8)
+    wa, ba, wb, bb = r(8, 3), r(8), r(8, 8), r(8)
+    outs = []
+    for vectors in (1, 1024):
+        ws = torch.empty(vectors * ((9 * C + 107) & ~3), device=DEV)
+        z = [torch.zeros(n, device=DEV) for n in (24, 8, 64, 8, C * 8, C)]
+        _lib.call("rtk_weightnet_bwd", M, C, d4.data_ptr(), dq3.data_ptr(), dt2.data_ptr(), wa.data_ptr(), ba.data_ptr(), wb.data_ptr(),
+                  bb.data_ptr(), *[t.data_ptr() for t in z], ws.data_ptr(), ws.numel(), st)
+        outs.append(z)
+    for a, b in zip(*outs):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-3 * float(b.abs().max()))
+    with pytest.raises(_lib.RtkError):
+        ws = torch.empty(16, device=DEV)
+        _lib.call("rtk_weightnet_bwd", M, C, d4.data_ptr(), dq3.data_ptr(), dt2.data_ptr(), wa.data_ptr(), ba.data_ptr(), wb.data_ptr(),
+                  bb.data_ptr(), *[t.data_ptr() for t in outs[0]], ws.data_ptr(), ws.numel(), st)
