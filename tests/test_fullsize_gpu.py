@@ -97,13 +97,15 @@ def test_b64_fused_matches_module_path():
         assert rel_err(a.cpu(), b.cpu()) <= RTOL, name
 
 
-def test_graph_pipeline_matches_eager():
+@pytest.mark.parametrize("depth", [2, 4])      # 2: forked geometry streams; 4 (the bench default): one stream per batch in flight
+def test_graph_pipeline_matches_eager(depth):
     net, t = make(8, 256, 1002)
     h = torch.zeros(5, 8, 128, device=DEV)
     with torch.no_grad():
         ref = [x.clone() for x in net.backbone(*t, h)]
-        pipe = F.GraphPipeline(net._fused, (*t, h), depth=2)
-        outs = [pipe.submit(*t, h) for _ in range(5)]      # slots are reused round-robin
+        pipe = F.GraphPipeline(net._fused, (*t, h), depth=depth)
+        assert all(e.use_side_stream == (depth <= 2) for e in pipe.engines)
+        outs = [pipe.submit(*t, h) for _ in range(2 * depth + 1)]      # slots are reused round-robin
         pipe.drain()
         torch.cuda.synchronize()
         for a, b in zip(outs[-1], ref):
