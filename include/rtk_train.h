@@ -95,6 +95,14 @@ RTK_EXPORT int rtk_pack_weights(int njobs, const rtk_pack_job_t *jobs, rtk_strea
  * the caller, += sum dz . dxyz (dxyz (samples, 3, rows, ns)).  ns % 4 == 0. */
 RTK_EXPORT int rtk_group_inverse_index(int samples, int n_src, int positions, const int *idx, int *off, unsigned short *inv,
                                        rtk_stream_t stream);
+
+/* Backward of rtk_three_interpolate (lib/src/interpolate_gpu.cu:192-214, one atomicAdd per term) in gather form:
+ * grad_points (b, c, m) = for every known point the sum of weight * grad_out over the (unknown point, slot) positions that
+ * reference it, read off the inverse table (off (b, m+1), inv (b, 3n)) that rtk_group_inverse_index builds from the
+ * interpolation indices idx (b, n, 3) taken as b lists of 3n positions.  Writes every element (no zero-fill needed), no
+ * atomics, deterministic. */
+RTK_EXPORT int rtk_three_interpolate_grad_gather(int b, int c, int n, int m, const float *grad_out, const float *weight, const int *off,
+                                                 const unsigned short *inv, float *grad_points, rtk_stream_t stream);
 RTK_EXPORT int rtk_sa_first_layer_bwd(int samples, int channels, int rows, int ns, int n_src, const float *dz, const float *dxyz,
                                       const int *off, const unsigned short *inv, float *dproj, float *dwx, int dwx_pitch,
                                       rtk_stream_t stream);

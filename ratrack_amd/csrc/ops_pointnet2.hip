@@ -1004,27 +1004,40 @@ extern "C" int rtk_three_interpolate(int b, int c, int m, int n, const float *po
     return RTK_OK;
 }
 
-// As group_points_grad_lds_kernel: one workgroup per (batch, channel) row, LDS accumulation, no global atomics.
+// As group_points_grad_lds_kernel: LDS accumulation, no global atomics.  One workgroup per (batch, TIG_CPB channels): the three
+// indices and weights of a point are the same for every channel, so a thread loads them once and scatters TIG_CPB gradients with
+// them (one channel per workgroup was 16 384 workgroups of one point per thread at the train-step shapes: pure launch latency).
+constexpr int TIG_CPB = 8;
 template <bool SET>
 __global__ __launch_bounds__(256) void three_interpolate_grad_lds_kernel(int c, int n, int m, const float *__restrict__ grad_out,
                                                                          const int *__restrict__ idx, const float *__restrict__ weight,
                                                                          float *__restrict__ grad_points) {
-    extern __shared__ float s_acc[];
-    const int bs = blockIdx.y, ci = blockIdx.x, tid = threadIdx.x;
-    for (int k = tid; k < m; k += 256) s_acc[k] = 0.f;
+    extern __shared__ float s_acc[];                               // [TIG_CPB][m]
+    const int bs = blockIdx.y, c0 = blockIdx.x * TIG_CPB, tid = threadIdx.x;
+    const int nc = min(TIG_CPB, c - c0);
+    for (int k = tid; k < nc * m; k += 256) s_acc[k] = 0.f;
     __syncthreads();
-    const float *go = grad_out + ((size_t)bs * c + ci) * n;
+    const float *go = grad_out + ((size_t)bs * c + c0) * n;
     for (int pt = tid; pt < n; pt += 256) {
-        const float g = go[pt];
         const float *w = weight + ((size_t)bs * n + pt) * 3;
         const int *id = idx + ((size_t)bs * n + pt) * 3;
-        atomicAdd(&s_acc[id[0]], __fmul_rn(g, w[0]));
-        atomicAdd(&s_acc[id[1]], __fmul_rn(g, w[1]));
-        atomicAdd(&s_acc[id[2]], __fmul_rn(g, w[2]));
+        const float w0 = w[0], w1 = w[1], w2 = w[2];
+        const int i0 = id[0], i1 = id[1], i2 = id[2];
+        float g[TIG_CPB];
+#pragma unroll
+        for (int q = 0; q < TIG_CPB; ++q) g[q] = go[(size_t)min(q, nc - 1) * n + pt];      // unconditional (clamped) loads
+#pragma unroll
+        for (int q = 0; q < TIG_CPB; ++q) {
+            if (q < nc) {
+                atomicAdd(&s_acc[q * m + i0], __fmul_rn(g[q], w0));
+                atomicAdd(&s_acc[q * m + i1], __fmul_rn(g[q], w1));
+                atomicAdd(&s_acc[q * m + i2], __fmul_rn(g[q], w2));
+            }
+        }
     }
     __syncthreads();
-    float *gp = grad_points + ((size_t)bs * c + ci) * m;
-    for (int k = tid; k < m; k += 256) gp[k] = SET ? s_acc[k] : gp[k] + s_acc[k];
+    float *gp = grad_points + ((size_t)bs * c + c0) * m;
+    for (int k = tid; k < nc * m; k += 256) gp[k] = SET ? s_acc[k] : gp[k] + s_acc[k];
 }
 
 static int three_interpolate_grad_impl(bool set, int b, int c, int n, int m, const float *grad_out, const int *idx, const float *weight,
@@ -1033,9 +1046,11 @@ static int three_interpolate_grad_impl(bool set, int b, int c, int n, int m, con
                 "three_interpolate_grad: bad arguments");
     RTK_REQUIRE(c <= 65535 && b <= 65535, "three_interpolate_grad: c/b exceed grid limits");
     hipStream_t s = (hipStream_t)stream;
-    if ((size_t)m * sizeof(float) <= 64 * 1024) {
-        if (set) three_interpolate_grad_lds_kernel<true><<<dim3(c, b), 256, (size_t)m * sizeof(float), s>>>(c, n, m, grad_out, idx, weight, grad_points);
-        else three_interpolate_grad_lds_kernel<false><<<dim3(c, b), 256, (size_t)m * sizeof(float), s>>>(c, n, m, grad_out, idx, weight, grad_points);
+    if ((size_t)TIG_CPB * m * sizeof(float) <= 64 * 1024) {
+        const dim3 grid(rtk_divup(c, TIG_CPB), b);
+        const size_t lds = (size_t)TIG_CPB * m * sizeof(float);
+        if (set) three_interpolate_grad_lds_kernel<true><<<grid, 256, lds, s>>>(c, n, m, grad_out, idx, weight, grad_points);
+        else three_interpolate_grad_lds_kernel<false><<<grid, 256, lds, s>>>(c, n, m, grad_out, idx, weight, grad_points);
     } else {
         if (set) (void)hipMemsetAsync(grad_points, 0, (size_t)b * c * m * sizeof(float), s);
         three_interpolate_grad_kernel<<<dim3(rtk_divup(n, 256), c, b), 256, 0, s>>>(c, n, m, grad_out, idx, weight, grad_points);

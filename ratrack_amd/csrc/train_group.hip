@@ -184,6 +184,41 @@ __global__ __launch_bounds__(256) void sa_first_layer_bwd_kernel(int channels, i
     }
 }
 
+// Backward of three_interpolate in gather form: known point k sums w * grad over the (unknown point, neighbour slot) positions that
+// reference it (the inverse table of the interpolation indices, rtk_group_inverse_index with positions = 3 n), for TG_CPB channels
+// at a time with the gradient planes staged in LDS.  The scatter form (one ds_add_f32 per term, ops_pointnet2.hip) runs at
+// ~3 clocks per LANE: LDS float atomics are the slowest instruction of this path (270 us per step for 50 MB of data).
+constexpr int TG_CPB = 8;
+__global__ __launch_bounds__(256) void three_interp_grad_gather_kernel(int c, int n, int m, const float *__restrict__ grad_out,
+                                                                       const float *__restrict__ weight, const int *__restrict__ off,
+                                                                       const unsigned short *__restrict__ inv, float *__restrict__ grad_points) {
+    extern __shared__ float s_go[];                                // [TG_CPB][n]
+    const int bs = blockIdx.y, c0 = blockIdx.x * TG_CPB, tid = threadIdx.x;
+    const int nc = min(TG_CPB, c - c0);
+    const float *go = grad_out + ((size_t)bs * c + c0) * n;
+    for (int e = tid; e < nc * n; e += 256) s_go[e] = go[e];
+    __syncthreads();
+    const int *ob = off + (size_t)bs * (m + 1);
+    const unsigned short *ib = inv + (size_t)bs * 3 * n;
+    const float *wb = weight + (size_t)bs * 3 * n;
+    for (int k = tid; k < m; k += 256) {
+        const int a = ob[k], b = ob[k + 1];
+        float acc[TG_CPB];
+#pragma unroll
+        for (int q = 0; q < TG_CPB; ++q) acc[q] = 0.f;
+        for (int i = a; i < b; ++i) {
+            const int pos = ib[i], pt = pos / 3;
+            const float w = wb[pos];
+#pragma unroll
+            for (int q = 0; q < TG_CPB; ++q) acc[q] += s_go[min(q, nc - 1) * n + pt] * w;
+        }
+        float *gp = grad_points + ((size_t)bs * c + c0) * m + k;
+#pragma unroll
+        for (int q = 0; q < TG_CPB; ++q)
+            if (q < nc) gp[(size_t)q * m] = acc[q];
+    }
+}
+
 }  // namespace
 
 extern "C" int rtk_group_inverse_index(int samples, int n_src, int positions, const int *idx, int *off, unsigned short *inv,
@@ -223,5 +258,16 @@ extern "C" int rtk_sa_first_layer_bwd(int samples, int channels, int rows, int n
     const dim3 grid((channels + cg - 1) / cg, samples);
     sa_first_layer_bwd_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(channels, cg, n_src, P, dz, dxyz, off, inv, dproj, dwx, dwx_pitch);
     RTK_CHECK_LAUNCH("sa_first_layer_bwd");
+    return RTK_OK;
+}
+
+extern "C" int rtk_three_interpolate_grad_gather(int b, int c, int n, int m, const float *grad_out, const float *weight, const int *off,
+                                                 const unsigned short *inv, float *grad_points, rtk_stream_t stream) {
+    RTK_REQUIRE(b > 0 && c > 0 && n > 0 && m > 0 && grad_out && weight && off && inv && grad_points, "three_interpolate_grad_gather: bad arguments");
+    RTK_REQUIRE(3 * (long)n <= 65536 && (size_t)TG_CPB * n * sizeof(float) <= 64 * 1024 && b <= 65535,
+                "three_interpolate_grad_gather: %d unknown points exceed the 16-bit table / the LDS planes", n);
+    three_interp_grad_gather_kernel<<<dim3((c + TG_CPB - 1) / TG_CPB, b), 256, (size_t)TG_CPB * n * sizeof(float), (hipStream_t)stream>>>(
+        c, n, m, grad_out, weight, off, inv, grad_points);
+    RTK_CHECK_LAUNCH("three_interpolate_grad_gather");
     return RTK_OK;
 }

@@ -18,6 +18,7 @@ _lib.SIGNATURES.update({
     "rtk_scatter_add_rows": [_i] * 4 + [_p] * 3 + [_p],
     "rtk_sa_first_layer": [_i] * 6 + [_p] * 4 + [_i] + [_p] * 3 + [_p],
     "rtk_group_inverse_index": [_i] * 3 + [_p] * 3 + [_p],
+    "rtk_three_interpolate_grad_gather": [_i] * 4 + [_p] * 5 + [_p],
     "rtk_sa_first_layer_bwd": [_i] * 5 + [_p] * 6 + [_i, _p],
     "rtk_conv_bn_fwd": [_i] * 6 + [_p] * 7 + [_p],
     "rtk_conv_wgrad": [_i] * 6 + [_p] * 5 + [ctypes.c_long, _p],
@@ -829,6 +830,41 @@ def gru_step(x, h_in, gru):
         params += [getattr(gru, "weight_ih_l%d" % l), getattr(gru, "weight_hh_l%d" % l), getattr(gru, "bias_ih_l%d" % l),
                    getattr(gru, "bias_hh_l%d" % l)]
     return _GRUStep.apply(x, h_in, *params)
+
+
+# ---- three-NN interpolation with a gather-form backward --------------------------------------------------------------------------
+
+class _ThreeInterpolate(torch.autograd.Function):
+    """pointnet2_utils.three_interpolate (features (B,C,M), idx (B,n,3), weight (B,n,3) -> (B,C,n)) whose backward reads the
+    inverse table of idx (off (B,M+1), inv (B,3n), rtk_group_inverse_index) instead of scattering with LDS float atomics."""
+
+    @staticmethod
+    def forward(ctx, features, idx, weight, off, inv, event):
+        from . import pointnet2_hip as _native
+        features = features.contiguous()
+        B, c, m = features.shape
+        n = idx.shape[1]
+        out = torch.empty((B, c, n), dtype=torch.float32, device=features.device)
+        _native.three_interpolate_wrapper(B, c, m, n, features, idx, weight, out)
+        ctx.save_for_backward(weight, off, inv)
+        ctx.m, ctx.event = m, event
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        weight, off, inv = ctx.saved_tensors
+        B, c, n = grad_out.shape
+        if ctx.event is not None:                                  # table built on the geometry stream (TrainGeometry)
+            torch.cuda.current_stream().wait_event(ctx.event)
+        grad = torch.empty((B, c, ctx.m), dtype=torch.float32, device=grad_out.device)
+        _lib.call("rtk_three_interpolate_grad_gather", B, c, n, ctx.m, grad_out.contiguous().data_ptr(), weight.data_ptr(), off.data_ptr(),
+                  inv.data_ptr(), grad.data_ptr(), _stream())
+        return grad, None, None, None, None, None
+
+
+def three_interpolate(features, idx, weight, inv_table, event=None):
+    """inv_table = (off, inv) of idx.view(B, 3n) over the M known points."""
+    return _ThreeInterpolate.apply(features, idx, weight, inv_table[0], inv_table[1], event)
 
 
 # ---- multi-task loss -------------------------------------------------------------------------------------------------------------

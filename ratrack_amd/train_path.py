@@ -60,6 +60,10 @@ class TrainGeometry:
             self.inv.append(row)
         self.interp = {name: (i32(S_, n if u == 0 else U, 3), f32(S_, n if u == 0 else U, 3))
                        for name, (u, k) in {"fp3": (2, 3), "fp2": (1, 2), "fp1": (0, 1)}.items()}
+        # inverse tables of the interpolation indices (known point -> the (unknown point, slot) positions that use it): the
+        # interpolation's backward is a gather as well
+        self.interp_inv = {name: (i32(S_, U + 1), torch.empty(S_, 3 * io.shape[1], dtype=torch.int16, device=dev))
+                           if 3 * io.shape[1] <= 65536 and io.shape[1] <= 2048 else None for name, (io, _) in self.interp.items()}
         st = lambda: torch.cuda.current_stream().cuda_stream
 
         def level_tables(geo, lvl):
@@ -79,6 +83,9 @@ class TrainGeometry:
                 io, wo = self.interp[name]
                 _lib.call("rtk_train_interp_weights", S_, d2.shape[1], io.shape[1], d2.data_ptr(), idx.data_ptr(), nu[k - 1].data_ptr(),
                           io.data_ptr(), wo.data_ptr(), st())
+                if self.interp_inv[name] is not None:              # the redirected indices point at rows < nuniq <= U
+                    off, inv = self.interp_inv[name]
+                    _lib.call("rtk_group_inverse_index", S_, U, 3 * io.shape[1], io.data_ptr(), off.data_ptr(), inv.data_ptr(), st())
             geo._record("interp", side)
             for lvl in range(3):                                   # needed by the backward only: last
                 for s in range(2):
@@ -112,6 +119,7 @@ class TrainGeometry:
         g.dxyz = [[d[:count] for d in row] for row in self.dxyz]
         g.inv = [[None if t is None else (t[0][:count], t[1][:count]) for t in row] for row in self.inv]
         g.interp = {k: (i[:count], w[:count]) for k, (i, w) in self.interp.items()}
+        g.interp_inv = {k: None if t is None else (t[0][:count], t[1][:count]) for k, t in self.interp_inv.items()}
         g.l3_xyz = self.l3_xyz[:count]
         g.events, g.side, g._geo = self.events, self.side, self._geo
         return g
@@ -166,7 +174,12 @@ def _fp(fp, tg, name, skip, known_feats, row_w, count_rows, groups):
     if hasattr(tg, "wait"):
         tg.wait("interp")
     idx, weight = tg.interp[name]
-    x = PU.three_interpolate(known_feats.contiguous(), idx, weight)
+    table = getattr(tg, "interp_inv", {}).get(name)
+    if table is not None and known_feats.shape[2] + 1 == table[0].shape[1]:
+        from .train_ops import three_interpolate
+        x = three_interpolate(known_feats, idx, weight, table)
+    else:
+        x = PU.three_interpolate(known_feats.contiguous(), idx, weight)
     srcs = [x] if skip is None else [x, skip]                      # lib/pointnet2_modules.py:150-153: cat([interpolated, skip])
     for layer in fp.mlp.children():
         x = pw_bn_relu(srcs, layer.conv.weight, layer.bn.bn, row_w, (tg.samples // groups) * count_rows, groups)

@@ -693,3 +693,35 @@ def test_weight_gradient_workspaces_of_any_size_give_the_same_sums():
         ws = torch.empty(16, device=DEV)
         _lib.call("rtk_weightnet_bwd", M, C, d4.data_ptr(), dq3.data_ptr(), dt2.data_ptr(), wa.data_ptr(), ba.data_ptr(), wb.data_ptr(),
                   bb.data_ptr(), *[t.data_ptr() for t in outs[0]], ws.data_ptr(), ws.numel(), st)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,n,m", [(3, 13, 77, 50), (4, 128, 256, 256), (2, 64, 1024, 512)])
+def test_three_interpolate_backward_gather_form(B, C, n, m):
+    """rtk_three_interpolate_grad_gather over the inverse table of the interpolation indices against the reference-style scatter
+    (rtk_three_interpolate_grad_set) and a float64 scatter_add: known points nobody references get exact zeros."""
+    from ratrack_amd import _lib, train_ops as T
+    g = torch.Generator(DEV).manual_seed(12)
+    go = torch.randn(B, C, n, device=DEV, generator=g)
+    idx = torch.randint(0, max(m - 5, 1), (B, n, 3), device=DEV, generator=g, dtype=torch.int32)      # the last known points stay unused
+    w = torch.rand(B, n, 3, device=DEV, generator=g)
+    st = torch.cuda.current_stream().cuda_stream
+    off = torch.empty(B, m + 1, dtype=torch.int32, device=DEV)
+    inv = torch.empty(B, 3 * n, dtype=torch.int16, device=DEV)
+    _lib.call("rtk_group_inverse_index", B, m, 3 * n, idx.data_ptr(), off.data_ptr(), inv.data_ptr(), st)
+    a = torch.full((B, C, m), float("nan"), device=DEV)
+    b = torch.full((B, C, m), float("nan"), device=DEV)
+    _lib.call("rtk_three_interpolate_grad_gather", B, C, n, m, go.data_ptr(), w.data_ptr(), off.data_ptr(), inv.data_ptr(), a.data_ptr(), st)
+    _lib.call("rtk_three_interpolate_grad_set", B, C, n, m, go.data_ptr(), idx.data_ptr(), w.data_ptr(), b.data_ptr(), st)
+    ref = torch.zeros(B, C, m, device=DEV, dtype=torch.float64)
+    for k in range(3):
+        ref.scatter_add_(2, idx[:, :, k].long().unsqueeze(1).expand(-1, C, -1), (go * w[:, :, k].unsqueeze(1)).double())
+    assert torch.isfinite(a).all()
+    assert float((a.double() - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1.0)
+    assert float((a - b).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1.0)
+    assert torch.equal(a[:, :, m - 5:], torch.zeros_like(a[:, :, m - 5:])) if m > 5 else True
+    # through the autograd operator
+    feats = torch.randn(B, C, m, device=DEV, generator=g, requires_grad=True)
+    out = T.three_interpolate(feats, idx, w, (off, inv))
+    out.backward(go)
+    assert float((feats.grad.double() - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1.0)

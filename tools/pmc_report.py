@@ -71,7 +71,7 @@ def main(fetch_db, write_db, trace_db, out_dir, tag="r02"):
     irregular = {"fps_wave_kernel": "fps_wave_kernel", "fps_relevel_kernel": "fps_relevel_kernel", "ball_query_pair_kernel": "ball_query_pair_kernel",
                  "three_nn_kernel": "three_nn_kernel", "knn_point_kernel": "knn_point_kernel", "scatter_add_rows_kernel": "scatter_rows256_kernel",
                  "group_points_grad_kernel": "group_points_grad_lds_kernel", "sa_first_layer_bwd_kernel": "sa_first_layer_bwd_kernel",
-                 "three_interpolate_grad_kernel": "three_interpolate_grad_lds_kernel", "inverse_index_kernel": "inverse_index_kernel"}
+                 "three_interpolate_grad_kernel": "three_interp_grad_gather_kernel", "inverse_index_kernel": "inverse_index_kernel"}
     rows = {k: traffic(lambda n, pat=pat: pat in n) for k, pat in irregular.items()}
     rows = {k: v for k, v in rows.items() if v}
     json.dump({"workload": "B=64, N=256: forward + train step kernels (eager) and the irregular-op launches of ratrack_amd.benchutil",
