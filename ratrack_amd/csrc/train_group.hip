@@ -22,15 +22,17 @@
 namespace {
 
 // off (samples, n_src + 1) int32: positions referencing source point q are inv[s][off[q] .. off[q+1]), ascending.
-__global__ __launch_bounds__(256) void inverse_index_kernel(int n_src, int P, const int *__restrict__ idx, int *__restrict__ off,
+// II_T threads: at 256 a thread runs a few thousand serial LDS operations and there is only one workgroup per sample
+constexpr int II_T = 1024;
+__global__ __launch_bounds__(II_T) void inverse_index_kernel(int n_src, int P, const int *__restrict__ idx, int *__restrict__ off,
                                                             unsigned short *__restrict__ inv) {
     extern __shared__ int s_cnt[];                 // [n_src + 1] counts -> offsets, [n_src] cursors
     int *s_cur = s_cnt + n_src + 1;
     const int s = blockIdx.x, t = threadIdx.x;
     const int *id = idx + (size_t)s * P;
-    for (int q = t; q <= n_src; q += 256) s_cnt[q] = 0;
+    for (int q = t; q <= n_src; q += II_T) s_cnt[q] = 0;
     __syncthreads();
-    for (int p = t; p < P; p += 256) atomicAdd(&s_cnt[id[p]], 1);
+    for (int p = t; p < P; p += II_T) atomicAdd(&s_cnt[id[p]], 1);
     __syncthreads();
     if (t < 64) {                                  // exclusive scan by one wave
         int carry = 0;
@@ -48,16 +50,16 @@ __global__ __launch_bounds__(256) void inverse_index_kernel(int n_src, int P, co
         }
     }
     __syncthreads();
-    for (int q = t; q < n_src; q += 256) s_cur[q] = s_cnt[q];
-    for (int q = t; q <= n_src; q += 256) off[(size_t)s * (n_src + 1) + q] = s_cnt[q];
+    for (int q = t; q < n_src; q += II_T) s_cur[q] = s_cnt[q];
+    for (int q = t; q <= n_src; q += II_T) off[(size_t)s * (n_src + 1) + q] = s_cnt[q];
     __syncthreads();
     unsigned short *iv = inv + (size_t)s * P;
     unsigned short *s_tmp = reinterpret_cast<unsigned short *>(s_cur + n_src);      // [P] the lists as the atomic cursors filled them
-    for (int p = t; p < P; p += 256) s_tmp[atomicAdd(&s_cur[id[p]], 1)] = (unsigned short)p;
+    for (int p = t; p < P; p += II_T) s_tmp[atomicAdd(&s_cur[id[p]], 1)] = (unsigned short)p;
     __syncthreads();
     // the cursors filled every list in arbitrary order: every element finds its rank inside its own list (short lists, all
     // elements in parallel) so that the table -- and every sum taken in its order -- is reproducible
-    for (int e = t; e < P; e += 256) {
+    for (int e = t; e < P; e += II_T) {
         const unsigned short v = s_tmp[e];
         const int q = id[v], a = s_cnt[q], b = s_cnt[q + 1];
         int r = 0;
@@ -233,7 +235,7 @@ extern "C" int rtk_group_inverse_index(int samples, int n_src, int positions, co
         (void)hipFuncSetAttribute((const void *)inverse_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    inverse_index_kernel<<<samples, 256, lds, (hipStream_t)stream>>>(n_src, positions, idx, off, inv);
+    inverse_index_kernel<<<samples, II_T, lds, (hipStream_t)stream>>>(n_src, positions, idx, off, inv);
     RTK_CHECK_LAUNCH("group_inverse_index");
     return RTK_OK;
 }
