@@ -112,8 +112,12 @@ class Trainer:
                 self._g_opt, _ = self._capture(self._optimize)
             else:
                 self._g, self._out = self._capture(lambda: self._step(*self._static, pretrain))
-        for dst, src in zip(self._static, args):
-            if dst is not None:
+        pairs = [(dst, src) for dst, src in zip(self._static, args) if dst is not None]
+        same = [p for p in pairs if p[0].dtype == p[1].dtype]
+        if same:                               # ONE multi-tensor copy into the static buffers instead of seven device-to-device memcpys
+            torch._foreach_copy_([p[0] for p in same], [p[1] for p in same])
+        for dst, src in pairs:
+            if dst.dtype != src.dtype:
                 dst.copy_(src)
         self._g.replay()
         if self._g_opt is not None:
