@@ -739,7 +739,7 @@ __global__ __launch_bounds__(256) void patch_cost_kernel(const PcParams P) {
 #pragma unroll
         for (int v = 0; v < CV_V; ++v) {
             const f4 w = weightnet_out(P.wn, lane, g, v, t2);
-            const f4 f = *reinterpret_cast<const f4 *>(fr + 16 * v);
+            const f4 f = *reinterpret_cast<const f4 *>(fr + 16 * v);      // (requesting the whole row up front: 122 vs 71 us -- registers)
             f4 r = w * f;
             row_sum16_f4(r);
             if (j == 0) {
@@ -804,11 +804,17 @@ __global__ __launch_bounds__(256) void patch_cost_bwd_kernel(const PcBwdParams Q
         const float *fr = P.feat + nb * P.feat_pitch + 4 * g;
         const float *dor = Q.dout + i * Q.dout_pitch + 4 * g;
         f4 dt2 = f4_zero();
+        // both rows requested in full before the first use (32 loads in flight per lane; one pair per iteration was a round trip each)
+        f4 fv[CV_V], dv[CV_V];
+#pragma unroll
+        for (int v = 0; v < CV_V; ++v) {
+            fv[v] = *reinterpret_cast<const f4 *>(fr + 16 * v);
+            dv[v] = *reinterpret_cast<const f4 *>(dor + 16 * v);
+        }
 #pragma unroll
         for (int v = 0; v < CV_V; ++v) {
             const f4 w = weightnet_out(P.wn, lane, g, v, t2);
-            const f4 f = *reinterpret_cast<const f4 *>(fr + 16 * v);
-            const f4 d = *reinterpret_cast<const f4 *>(dor + 16 * v);
+            const f4 f = fv[v], d = dv[v];
             f4 q;
             q.x = w.x > 0.f ? d.x * f.x : 0.f;
             q.y = w.y > 0.f ? d.y * f.y : 0.f;

@@ -18,3 +18,19 @@ e0.record()
 for _ in range(50): f()
 e1.record(); torch.cuda.synchronize()
 print("patch_cost %.1f us" % (e0.elapsed_time(e1) * 20))
+# backward
+M = B * n * 16
+dout = r(B * n, 256)
+wct = keep[-1] if isinstance(keep, (list, tuple)) else None
+outs, _k = wn, keep
+import ctypes
+big = torch.empty(2, M, 256, device=dev); dt2 = torch.empty(M, 8, device=dev); d4 = torch.empty(M, 4, device=dev)
+wct_t = _k[0][5] if isinstance(_k, tuple) else None
+fb = lambda: _lib.call("rtk_patch_cost_bwd", B, n, xyz.data_ptr(), knn.data_ptr(), feat.data_ptr(), 256, wn, wct_t.data_ptr(), dout.data_ptr(), 256,
+                       big[0].data_ptr(), big[1].data_ptr(), dt2.data_ptr(), d4.data_ptr(), st)
+for _ in range(5): fb()
+torch.cuda.synchronize()
+e0.record()
+for _ in range(50): fb()
+e1.record(); torch.cuda.synchronize()
+print("patch_cost_bwd %.1f us" % (e0.elapsed_time(e1) * 20))
