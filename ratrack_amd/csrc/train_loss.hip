@@ -129,7 +129,11 @@ __global__ __launch_bounds__(256) void weightnet_bwd_kernel(long M, int C, int s
 #pragma unroll
             for (int h = 0; h < 8; ++h) accc[q][i][h] = 0.f;
         }
-    float small = 0.f;     // threads 0..103: one element of dWb (64) | dbb (8) | dWa (24) | dba (8)
+    // The four small gradients as ONE 16 x 16 MFMA accumulator per wave: rows = [g2 (8) | g1 (8)], columns = [t1 (8) | d (3) | 1 | 0..],
+    // contracted over the positions (4 per instruction): dWb = g2 x t1, dbb = g2 x 1, dWa = g1 x d, dba = g1 x 1 sit in its blocks.
+    // (A serial loop of 104 threads over the sub-block's 256 positions was half of the kernel's run time.)
+    typedef float wn_f4 __attribute__((ext_vector_type(4)));
+    wn_f4 accs = {0.f, 0.f, 0.f, 0.f};
     for (int sb = 0; sb < sub_per_wg; ++sb) {
         const long m0 = ((long)blockIdx.x * sub_per_wg + sb) * WN_SUB;
         if (m0 >= M) break;
@@ -189,12 +193,16 @@ __global__ __launch_bounds__(256) void weightnet_bwd_kernel(long M, int C, int s
                 }
             }
         }
-        if (t < 104) {
-            for (int p = 0; p < cnt; ++p) {
-                if (t < 64) small += s_g2[p][t >> 3] * s_t1[p][t & 7];
-                else if (t < 72) small += s_g2[p][t - 64];
-                else if (t < 96) small += s_g1[p][(t - 72) / 3] * s_d[p][(t - 72) % 3];
-                else small += s_g1[p][t - 96];
+        {
+            const int lane = t & 63, g = lane >> 4, i = lane & 15;
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                const int p = 64 * ph + 4 * q + g;                 // wave ph contracts positions [64 ph, 64 ph + 64)
+                const bool ok = p < cnt;
+                const int pc = ok ? p : 0;
+                const float a = i < 8 ? s_g2[pc][i] : s_g1[pc][i - 8];
+                const float bq = i < 8 ? s_t1[pc][i] : i < 11 ? s_d[pc][i - 8] : (i == 11 ? 1.f : 0.f);
+                accs = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? a : 0.f, ok ? bq : 0.f, accs, 0, 0, 0);
             }
         }
     }
@@ -225,7 +233,23 @@ __global__ __launch_bounds__(256) void weightnet_bwd_kernel(long M, int C, int s
     }
     float *part = partial + (size_t)blockIdx.x * partial_pitch;
     for (int e = t; e < 9 * C; e += 256) part[e] = s_acc[e];
-    if (t < 104) part[9 * C + t] = small;
+    // accs[r] = D[row 4g + r][column i] of this wave; the four waves' tiles are added through LDS (s_acc is free again)
+    __syncthreads();
+    {
+        const int lane = t & 63, g = lane >> 4, i = lane & 15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_acc[ph * 256 + (4 * g + r) * 16 + i] = accs[r];
+    }
+    __syncthreads();
+    if (t < 104) {
+        int row, col;
+        if (t < 64) { row = t >> 3; col = t & 7; }                        // dWb[h][k]
+        else if (t < 72) { row = t - 64; col = 11; }                     // dbb[h]
+        else if (t < 96) { row = 8 + (t - 72) / 3; col = 8 + (t - 72) % 3; }      // dWa[k][j]
+        else { row = 8 + (t - 96); col = 11; }                           // dba[k]
+        const int e = row * 16 + col;
+        part[9 * C + t] = (s_acc[e] + s_acc[256 + e]) + (s_acc[512 + e] + s_acc[768 + e]);
+    }
 }
 
 __global__ __launch_bounds__(256) void weightnet_bwd_reduce_kernel(int C, int wgs, const float *__restrict__ partial, int partial_pitch,
