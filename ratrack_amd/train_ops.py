@@ -5,6 +5,7 @@ neighbourhood axis) -- the tail of every SharedMLP layer of the reference (lib/p
 lib/pointnet2_modules.py:44-47) -- on a de-duplicated, row-weighted tensor.  No CPU / eager fallback.
 """
 import ctypes
+import os
 
 import torch
 
@@ -623,7 +624,16 @@ class _CostVolume(torch.autograd.Function):
         dp2 = torch.empty(B * n2, 256, dtype=torch.float32, device=dev)
         _lib.call("rtk_scatter_add_rows", B, n1 * 16, n2, 256, knn.data_ptr(), dz1.data_ptr(), dp2.data_ptr(), _stream())
         # weight gradients: contractions over the M positions
-        dw3, dw2 = _tall_tn(dz3, a2), _tall_tn(dz2, a1)
+        # dW2 = dz2^T a1 and dW3 = dz3^T a2 as ONE batched GEMM over the slabs of both products (the operands are adjacent slices of
+        # `big` / `acts`: (dz2, dz3) and (a1, a2)), then one sum per product
+        c = 256
+        while M % c:
+            c //= 2
+        if c >= 8:
+            prod = torch.bmm(big[1:3].view(2 * c, M // c, 256).transpose(1, 2), acts[0:2].view(2 * c, M // c, 256))
+            dw2, dw3 = prod.view(2, c, 256, 256).sum(1).unbind(0)
+        else:
+            dw3, dw2 = _tall_tn(dz3, a2), _tall_tn(dz2, a1)
         db3, db2 = dbr.sum(0).split(256)
         dwd = dpd.sum(0).t()
         dwa, dba, dwb, dbb, dwc, dbc = _weightnet_backward(d4, dq3, dt2, wa, ba, wb, bb, wc)
