@@ -55,6 +55,20 @@ RTK_EXPORT int rtk_bn_train_finalize(int channels, int groups, const double *sum
 RTK_EXPORT int rtk_bn_relu_fwd(int samples, int channels, int rows, int ns, int groups, const float *z, const float *par,
                                int pool, float *y, rtk_stream_t stream);
 
+/* BatchNorm finalisation folded into the consumer: instead of reading par, the kernel derives (mean, rstd, scale, shift) of its
+ * channels from the batch sums (as rtk_bn_train_finalize would), and its first workgroups also store them into par_out
+ * (4, groups, C) -- for the backward -- and update the running statistics.  One launch less per BatchNorm layer and step. */
+typedef struct {
+    const double *sums;             /* (RTK_STAT_SLOTS, groups, C, 2), complete */
+    double count;
+    const float *gamma, *beta;
+    float eps, momentum;
+    float *running_mean, *running_var;      /* optional */
+    int64_t *num_batches_tracked;           /* optional */
+} rtk_bn_fin_t;
+RTK_EXPORT int rtk_bn_relu_fwd_fin(int samples, int channels, int rows, int ns, int groups, const float *z, const rtk_bn_fin_t *fin,
+                                   float *par_out, int pool, float *y, rtk_stream_t stream);
+
 /* Backward, pass 1.  dy has the shape of y.  sums2 (groups, C, 2) float64 zero-initialised:
  * [..,0] += sum dy [y>0], [..,1] += sum dy [y>0] xhat   (pool: only the first arg-max position of each row counts). */
 RTK_EXPORT int rtk_bn_relu_bwd_stats(int samples, int channels, int rows, int ns, int groups, const float *z,
@@ -117,6 +131,11 @@ RTK_EXPORT int rtk_sa_first_layer_bwd(int samples, int channels, int rows, int n
 RTK_EXPORT int rtk_conv_bn_fwd(int samples, int cin, int cout, int rows, int ns, int groups, const float *x, const float *pre_par,
                                const float *w, float *z, float *act_out, const float *row_weight, double *sums,
                                rtk_stream_t stream);
+
+/* rtk_conv_bn_fwd with the PREVIOUS layer's BatchNorm finalised on the fly (rtk_bn_fin_t above; pre_par_out (4, groups, cin)). */
+RTK_EXPORT int rtk_conv_bn_fwd_fin(int samples, int cin, int cout, int rows, int ns, int groups, const float *x, const rtk_bn_fin_t *pre_fin,
+                                   float *pre_par_out, const float *w, float *z, float *act_out, const float *row_weight, double *sums,
+                                   rtk_stream_t stream);
 
 /* rtk_conv_bn_bwd: backward through z = W relu(BatchNorm(zprev)) down to zprev.  dz (samples, cout, P) is the gradient of z,
  * w the SAME row-major (cout, cprev) weight as in the forward, pre_par the (4, groups, cprev) constants of the BatchNorm applied to

@@ -48,3 +48,45 @@ __device__ __forceinline__ float rtk_sqdist(float ax, float ay, float az, float 
     return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
 }
 #endif
+
+// ---- BatchNorm finalisation inside a consumer kernel (rtk_bn_fin_t, rtk_train.h) -------------------------------------------------
+// Same arithmetic as bn_finalize_kernel (train_bn.hip): every workgroup derives the constants of its own (group, channel) from the
+// replica sums; bn_fin_publish -- called by ONE thread per channel in the whole grid -- also stores all groups' constants into par
+// and updates the running statistics (group 0, then group 1, ...: the reference calls the module once per frame).
+__device__ __forceinline__ void bn_fin_constants(const rtk_bn_fin_t &F, int channels, int groups, int g, int c, float &mean, float &rstd,
+                                                 float &sc, float &sh) {
+    const size_t GC = (size_t)groups * channels, o = ((size_t)g * channels + c) * 2;
+    const double s = rtk_stat_read(F.sums, GC * 2, o), ss = rtk_stat_read(F.sums, GC * 2, o + 1);
+    const double m = s / F.count;
+    double var = ss / F.count - m * m;
+    var = var > 0.0 ? var : 0.0;
+    rstd = (float)(1.0 / sqrt(var + (double)F.eps));
+    sc = F.gamma[c] * rstd;
+    mean = (float)m;
+    sh = F.beta[c] - mean * sc;
+}
+
+__device__ __forceinline__ void bn_fin_publish(const rtk_bn_fin_t &F, int channels, int groups, int c, float *par) {
+    const size_t GC = (size_t)groups * channels;
+    if (c == 0 && F.num_batches_tracked) *F.num_batches_tracked += groups;
+    float rm = F.running_mean ? F.running_mean[c] : 0.f, rv = F.running_var ? F.running_var[c] : 0.f;
+    for (int g = 0; g < groups; ++g) {
+        const size_t o2 = ((size_t)g * channels + c) * 2;
+        const double s = rtk_stat_read(F.sums, GC * 2, o2), ss = rtk_stat_read(F.sums, GC * 2, o2 + 1);
+        const double mean = s / F.count;
+        double var = ss / F.count - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)F.eps));
+        const float sc = F.gamma[c] * rstd;
+        const size_t o = (size_t)g * channels + c;
+        par[o] = (float)mean;
+        par[GC + o] = rstd;
+        par[2 * GC + o] = sc;
+        par[3 * GC + o] = F.beta[c] - (float)mean * sc;
+        rm = (1.f - F.momentum) * rm + F.momentum * (float)mean;
+        rv = (1.f - F.momentum) * rv + F.momentum * (float)(var * (F.count / (F.count - 1.0)));
+    }
+    if (F.running_mean) F.running_mean[c] = rm;
+    if (F.running_var) F.running_var[c] = rv;
+}
+

@@ -179,12 +179,32 @@ __global__ void bn_finalize_kernel(int channels, int groups, const double *__res
 }
 
 // ---- forward: normalise + ReLU --------------------------------------------------------------------------------------
+// (scale, shift) of this workgroup's (group, channel): read from par, or -- fin.sums given -- finalised here from the batch sums, in
+// which case the sample-0 workgroup of every channel also publishes par and the running statistics (bn_fin_publish)
+__device__ __forceinline__ void fwd_constants(const rtk_bn_fin_t &fin, float *par, int channels, int groups, int g, float &sc, float &sh) {
+    const size_t GC = (size_t)groups * channels, o = (size_t)g * channels + blockIdx.x;
+    if (!fin.sums) {
+        sc = par[2 * GC + o];
+        sh = par[3 * GC + o];
+        return;
+    }
+    __shared__ float s_c[2];
+    if (threadIdx.x == 0) {
+        float mean, rstd;
+        bn_fin_constants(fin, channels, groups, g, blockIdx.x, mean, rstd, s_c[0], s_c[1]);
+        if (blockIdx.y == 0) bn_fin_publish(fin, channels, groups, blockIdx.x, par);
+    }
+    __syncthreads();
+    sc = s_c[0];
+    sh = s_c[1];
+}
+
 __global__ __launch_bounds__(BN_T) void bn_relu_fwd_kernel(int samples, int channels, int rows, int ns, int groups,
-                                                           const float *__restrict__ z, const float *__restrict__ par,
+                                                           const float *__restrict__ z, float *par, const rtk_bn_fin_t fin,
                                                            float *__restrict__ y) {
     const Plane p = plane_of(samples, channels, rows, ns, groups);
-    const size_t GC = (size_t)groups * channels, o = (size_t)p.g * channels + blockIdx.x;
-    const float sc = par[2 * GC + o], sh = par[3 * GC + o];
+    float sc, sh;
+    fwd_constants(fin, par, channels, groups, p.g, sc, sh);
     const int E = rows * ns;
     const float *zp = z + p.base;
     float *yp = y + p.base;
@@ -228,12 +248,12 @@ __device__ __forceinline__ void row_argmax(const float4 v, float sc, float sh, i
 
 template <int G>
 __global__ __launch_bounds__(BN_T) void bn_relu_pool_fwd_kernel(int samples, int channels, int rows, int groups,
-                                                                const float *__restrict__ z, const float *__restrict__ par,
+                                                                const float *__restrict__ z, float *par, const rtk_bn_fin_t fin,
                                                                 float *__restrict__ y) {
     constexpr int NS = 4 * G;
     const Plane p = plane_of(samples, channels, rows, NS, groups);
-    const size_t GC = (size_t)groups * channels, o = (size_t)p.g * channels + blockIdx.x;
-    const float sc = par[2 * GC + o], sh = par[3 * GC + o];
+    float sc, sh;
+    fwd_constants(fin, par, channels, groups, p.g, sc, sh);
     const float *zp = z + p.base;
     float *yp = y + ((size_t)blockIdx.y * channels + blockIdx.x) * rows;
     const int E4 = rows * G;
@@ -451,18 +471,30 @@ extern "C" int rtk_bn_train_finalize(int channels, int groups, const double *sum
     return RTK_OK;
 }
 
-extern "C" int rtk_bn_relu_fwd(int samples, int channels, int rows, int ns, int groups, const float *z, const float *par, int pool,
-                               float *y, rtk_stream_t stream) {
+static int bn_relu_fwd_launch(int samples, int channels, int rows, int ns, int groups, const float *z, float *par,
+                              const rtk_bn_fin_t &fin, int pool, float *y, rtk_stream_t stream) {
     RTK_BN_COMMON_CHECKS("rtk_bn_relu_fwd");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(channels, samples);
     if (pool) {
-        RTK_BN_POOL_DISPATCH(bn_relu_pool_fwd_kernel, samples, channels, rows, groups, z, par, y)
+        RTK_BN_POOL_DISPATCH(bn_relu_pool_fwd_kernel, samples, channels, rows, groups, z, par, fin, y)
     } else {
-        bn_relu_fwd_kernel<<<grid, BN_T, 0, s>>>(samples, channels, rows, ns, groups, z, par, y);
+        bn_relu_fwd_kernel<<<grid, BN_T, 0, s>>>(samples, channels, rows, ns, groups, z, par, fin, y);
     }
     RTK_CHECK_LAUNCH("rtk_bn_relu_fwd");
     return RTK_OK;
+}
+
+extern "C" int rtk_bn_relu_fwd(int samples, int channels, int rows, int ns, int groups, const float *z, const float *par, int pool,
+                               float *y, rtk_stream_t stream) {
+    rtk_bn_fin_t none = {};
+    return bn_relu_fwd_launch(samples, channels, rows, ns, groups, z, const_cast<float *>(par), none, pool, y, stream);
+}
+
+extern "C" int rtk_bn_relu_fwd_fin(int samples, int channels, int rows, int ns, int groups, const float *z, const rtk_bn_fin_t *fin,
+                                   float *par_out, int pool, float *y, rtk_stream_t stream) {
+    RTK_REQUIRE(fin && fin->sums && fin->gamma && fin->beta && fin->count > 1.0 && par_out, "rtk_bn_relu_fwd_fin: bad finalisation arguments");
+    return bn_relu_fwd_launch(samples, channels, rows, ns, groups, z, par_out, *fin, pool, y, stream);
 }
 
 extern "C" int rtk_bn_relu_bwd_stats(int samples, int channels, int rows, int ns, int groups, const float *z, const float *dy,

@@ -42,6 +42,8 @@ struct TcParams {
     double count;
     float *dgb;             // backward pass 1: (2, 16V) dgamma | dbeta
     float *partial;         // weight gradient: one (16V, 16U) partial block per workgroup
+    rtk_bn_fin_t fin;       // forward: fin.sums != NULL: the previous layer's BatchNorm is finalised here (and published into pre_out)
+    float *pre_out;
 };
 
 // MODE 0: forward.  MODE 1: backward statistics.  MODE 2: backward apply.
@@ -70,10 +72,16 @@ __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
     // lanes that share g read the same word (broadcast), and 6 x 16V registers per lane would spill
     constexpr int CA = 16 * (MODE == 0 ? U : V);
     __shared__ float s_sc[CA], s_sh[CA], s_mu[CA], s_rs[CA], s_c1[CA], s_c2[CA];
-    const bool has_pre = Q.pre != nullptr;
+    const bool fin_pre = MODE == 0 && Q.fin.sums != nullptr;
+    const bool has_pre = Q.pre != nullptr || fin_pre;
     {
         const size_t GC = (size_t)Q.groups * CA, o = (size_t)grp * CA;
         for (int c = threadIdx.x; c < CA; c += TC_T) {
+            if (fin_pre) {      // finalise the previous BatchNorm from its batch sums; the first workgroup publishes par + running statistics
+                bn_fin_constants(Q.fin, CA, Q.groups, grp, c, s_mu[c], s_rs[c], s_sc[c], s_sh[c]);
+                if (b == 0 && blockIdx.x == 0) bn_fin_publish(Q.fin, CA, Q.groups, c, Q.pre_out);
+                continue;
+            }
             s_mu[c] = has_pre ? Q.pre[o + c] : 0.f;
             s_rs[c] = has_pre ? Q.pre[GC + o + c] : 1.f;
             s_sc[c] = has_pre ? Q.pre[2 * GC + o + c] : 1.f;
@@ -431,6 +439,21 @@ extern "C" int rtk_conv_bn_fwd(int samples, int cin, int cout, int rows, int ns,
     Q.in = x; Q.w_packed = w; Q.pre = pre_par; Q.rw = row_weight; Q.out = z; Q.act_out = act_out; Q.sums = sums;
     launch<0>(Q, cin, cout, (hipStream_t)stream);
     RTK_CHECK_LAUNCH("rtk_conv_bn_fwd");
+    return RTK_OK;
+}
+
+extern "C" int rtk_conv_bn_fwd_fin(int samples, int cin, int cout, int rows, int ns, int groups, const float *x, const rtk_bn_fin_t *pre_fin,
+                                   float *pre_par_out, const float *w, float *z, float *act_out, const float *row_weight, double *sums,
+                                   rtk_stream_t stream) {
+    if (int rc = check("rtk_conv_bn_fwd_fin", samples, cin, cout, rows, ns, groups)) return rc;
+    RTK_REQUIRE(x && w && z && sums && pre_fin && pre_fin->sums && pre_fin->gamma && pre_fin->beta && pre_fin->count > 1.0 && pre_par_out,
+                "rtk_conv_bn_fwd_fin: null argument");
+    TcParams Q = {};
+    Q.samples = samples; Q.rows = rows; Q.lg_ns = ilog2x(ns); Q.groups = groups; Q.P = rows * ns;
+    Q.in = x; Q.w_packed = w; Q.pre = nullptr; Q.rw = row_weight; Q.out = z; Q.act_out = act_out; Q.sums = sums;
+    Q.fin = *pre_fin; Q.pre_out = pre_par_out;
+    launch<0>(Q, cin, cout, (hipStream_t)stream);
+    RTK_CHECK_LAUNCH("rtk_conv_bn_fwd_fin");
     return RTK_OK;
 }
 

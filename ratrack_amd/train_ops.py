@@ -32,6 +32,8 @@ _lib.SIGNATURES.update({
     "rtk_bn_train_stats": [_i] * 5 + [_p] * 3 + [_p],
     "rtk_bn_train_finalize": [_i, _i, _p, _d, _p, _p, _f, _f, _p, _p, _p, _p, _p],
     "rtk_bn_relu_fwd": [_i] * 5 + [_p, _p, _i, _p, _p],
+    "rtk_bn_relu_fwd_fin": [_i] * 5 + [_p, _p, _p, _i, _p, _p],
+    "rtk_conv_bn_fwd_fin": [_i] * 6 + [_p] * 8 + [_p],
     "rtk_bn_relu_bwd_stats": [_i] * 5 + [_p, _p, _p, _i, _p, _p],
     "rtk_bn_relu_bwd_apply": [_i] * 5 + [_p] * 5 + [_d, _i, _p, _p, _p],
 })
@@ -120,10 +122,11 @@ class _BNReLU(torch.autograd.Function):
         _lib.call("rtk_bn_train_stats", S_, C, rows, ns, groups, z.data_ptr(), _ptr(row_weight), sums.data_ptr(), _stream())
         par = torch.empty(4, groups, C, dtype=torch.float32, device=dev)
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
-        _lib.call("rtk_bn_train_finalize", C, groups, sums.data_ptr(), float(count), g.data_ptr(), b.data_ptr(), float(eps),
-                  float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(nbt), par.data_ptr(), _stream())
+        fin = _BnFin(sums.data_ptr(), float(count), g.data_ptr(), b.data_ptr(), float(eps), float(momentum), _ptr(running_mean),
+                     _ptr(running_var), _ptr(nbt))
         y = torch.empty((S_, C, rows) if pool else (S_, C, rows, ns), dtype=torch.float32, device=dev)
-        _lib.call("rtk_bn_relu_fwd", S_, C, rows, ns, groups, z.data_ptr(), par.data_ptr(), int(pool), y.data_ptr(), _stream())
+        _lib.call("rtk_bn_relu_fwd_fin", S_, C, rows, ns, groups, z.data_ptr(), ctypes.byref(fin), par.data_ptr(), int(pool), y.data_ptr(),
+                  _stream())      # finalisation + normalise + ReLU (+ max-pool) in one launch
         ctx.save_for_backward(z, par, row_weight)
         ctx.cfg = (count, groups, pool)
         return y
@@ -291,9 +294,9 @@ class _PwBnRelu(torch.autograd.Function):
         sums = _zeros((STAT_SLOTS, groups, Co, 2), torch.float64, dev)
         z = torch.empty(S_, Co, P, dtype=torch.float32, device=dev)
         _pw_forward(srcs, cols, W2, None, z, row_w, groups, sums)
-        par = _bn_finalize(bn, sums, count, groups)
+        fin, par, _keep = _bn_fin(bn, sums, count, groups)
         y = torch.empty_like(z)
-        _lib.call("rtk_bn_relu_fwd", S_, Co, P, 1, groups, z.data_ptr(), par.data_ptr(), 0, y.data_ptr(), _stream())
+        _lib.call("rtk_bn_relu_fwd_fin", S_, Co, P, 1, groups, z.data_ptr(), fin, par.data_ptr(), 0, y.data_ptr(), _stream())
         ctx.save_for_backward(W, z, par, row_w, *srcs)
         ctx.cfg = (count, groups, cols)
         return y
@@ -326,6 +329,25 @@ def pw_bn_relu(srcs, weight, bn, row_weight=None, count=None, groups=1, cols=Non
 
 
 # ---- SharedMLP chain of one set-abstraction scale ------------------------------------------------------------------------
+
+class _BnFin(ctypes.Structure):          # rtk_bn_fin_t (include/rtk_train.h)
+    _fields_ = [("sums", ctypes.c_void_p), ("count", ctypes.c_double), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
+                ("eps", ctypes.c_float), ("momentum", ctypes.c_float), ("running_mean", ctypes.c_void_p), ("running_var", ctypes.c_void_p),
+                ("num_batches_tracked", ctypes.c_void_p)]
+
+
+def _bn_fin(bn, sums, count, groups):
+    """(rtk_bn_fin_t by reference, par buffer): the BatchNorm of `sums` is finalised by the kernel that consumes it (one launch less
+    per layer and step than rtk_bn_train_finalize + consumer); par is written for the backward."""
+    C = bn.num_features
+    par = torch.empty(4, groups, C, dtype=torch.float32, device=sums.device)
+    momentum = bn.momentum if bn.momentum is not None else 0.1
+    track = bn.track_running_stats
+    f = _BnFin(sums.data_ptr(), float(count), bn.weight.detach().data_ptr(), bn.bias.detach().data_ptr(), float(bn.eps), float(momentum),
+               _ptr(bn.running_mean if track else None), _ptr(bn.running_var if track else None),
+               _ptr(bn.num_batches_tracked if track else None))
+    return ctypes.byref(f), par, f
+
 
 def _bn_finalize(bn, sums, count, groups):
     C = bn.num_features
@@ -384,20 +406,24 @@ class _SAChain(torch.autograd.Function):
         z1 = torch.empty(S_, C1, rows, ns, dtype=torch.float32, device=dev)
         _lib.call("rtk_sa_first_layer", S_, C1, rows, ns, groups, n_src, proj.data_ptr(), idx.data_ptr(), dxyz.data_ptr(), W0.data_ptr(),
                   W0.stride(0), _ptr(row_w), z1.data_ptr(), sums.data_ptr(), _stream())      # the offset columns = the first three of W0
-        zs, ys, pars = [z1], [], [_bn_finalize(bns[0], sums, count, groups)]
+        # every BatchNorm is finalised by the kernel that consumes it (the next convolution, the pooling pass at the end)
+        zs, ys, pars = [z1], [], []
+        fin, par, _keep = _bn_fin(bns[0], sums, count, groups)
         for i in range(1, L):
             W = weights[i]
             Co, Ci = W.shape[0], W.shape[1]
             wc = W.detach().contiguous()
             z = torch.empty(S_, Co, rows, ns, dtype=torch.float32, device=dev)
             sums = f64(Co)
-            _lib.call("rtk_conv_bn_fwd", S_, Ci, Co, rows, ns, groups, zs[-1].data_ptr(), pars[-1].data_ptr(), wc.data_ptr(), z.data_ptr(),
+            _lib.call("rtk_conv_bn_fwd_fin", S_, Ci, Co, rows, ns, groups, zs[-1].data_ptr(), fin, par.data_ptr(), wc.data_ptr(), z.data_ptr(),
                       None, _ptr(row_w), sums.data_ptr(), _stream())      # the normalised input is NOT stored (rtk_conv_wgrad recomputes it)
-            pars.append(_bn_finalize(bns[i], sums, count, groups))
+            pars.append(par)
+            fin, par, _keep = _bn_fin(bns[i], sums, count, groups)
             zs.append(z)
         C = zs[-1].shape[1]
         out = torch.empty(S_, C, rows, dtype=torch.float32, device=dev)
-        _lib.call("rtk_bn_relu_fwd", S_, C, rows, ns, groups, zs[-1].data_ptr(), pars[-1].data_ptr(), 1, out.data_ptr(), _stream())
+        _lib.call("rtk_bn_relu_fwd_fin", S_, C, rows, ns, groups, zs[-1].data_ptr(), fin, par.data_ptr(), 1, out.data_ptr(), _stream())
+        pars.append(par)
         ctx.save_for_backward(row_w, idx, dxyz, *zs, *pars, *[w for w in weights[1:]], w0, *feats)
         ctx.cfg = (count, groups, L, n_src, nfeat, cols)
         ctx.inv = inv
