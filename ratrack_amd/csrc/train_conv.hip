@@ -272,7 +272,7 @@ __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
 // in registers over the wave's whole position range; waves are reduced through LDS, workgroups with float atomics.
 template <int U, int V>
 __global__ __launch_bounds__(TC_T, 2) void conv_wgrad_kernel(const TcParams Q) {
-    __shared__ float s_red[16 * V][16 * U + 1];
+    __shared__ float s_red[TC_T / 64][16 * V][16 * U + 1];      // one image per wave: written in parallel, added on the way out
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int grp = b / (Q.samples / Q.groups);
@@ -332,25 +332,23 @@ __global__ __launch_bounds__(TC_T, 2) void conv_wgrad_kernel(const TcParams Q) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) acc[v][u] = mfma4(a[v][q], bq[u][q], acc[v][u]);
     }
-    // D layout: acc[v][u][r] = dW[16v + 4g + r][16u + j]; the four waves add into one LDS image in turn
-    for (int w = 0; w < TC_T / 64; ++w) {
-        if (wave == w) {
+    // D layout: acc[v][u][r] = dW[16v + 4g + r][16u + j]; every wave stores its own LDS image (one round, one barrier), the images
+    // are added on the way out
 #pragma unroll
-            for (int v = 0; v < V; ++v)
+    for (int v = 0; v < V; ++v)
 #pragma unroll
-                for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float &d = s_red[16 * v + 4 * g + r][16 * u + j];
-                        d = w == 0 ? acc[v][u][r] : d + acc[v][u][r];
-                    }
-        }
-        __syncthreads();
-    }
+            for (int r = 0; r < 4; ++r) s_red[wave][16 * v + 4 * g + r][16 * u + j] = acc[v][u][r];
+    __syncthreads();
+    static_assert(TC_T == 256, "four waves");
     // this workgroup's partial dW: plain stores, added up in a fixed order by conv_wgrad_reduce_kernel (as float atomics, 256 U V per
     // workgroup and up to 512 workgroups deep on every address, they were a large part of the kernel)
     float *part = Q.partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (256 * U * V);
-    for (int e = threadIdx.x; e < 16 * V * 16 * U; e += TC_T) part[e] = s_red[e / (16 * U)][e % (16 * U)];
+    for (int e = threadIdx.x; e < 16 * V * 16 * U; e += TC_T) {
+        const int co = e / (16 * U), ci = e % (16 * U);
+        part[e] = (s_red[0][co][ci] + s_red[1][co][ci]) + (s_red[2][co][ci] + s_red[3][co][ci]);
+    }
 }
 
 // dw[e] += sum over the workgroups' partials: 16 outputs x 16 lanes over the workgroup axis, eight independent loads per lane and round

@@ -343,7 +343,7 @@ struct PwWgParams {
 };
 
 __global__ __launch_bounds__(PW_T, 2) void pw_wgrad_kernel(const PwWgParams Q) {
-    __shared__ float s_red[64][65];
+    __shared__ float s_red[PW_T / 64][64][65];      // one image per wave: written in parallel, added on the way out
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
     const PwOp &S = Q.src[Q.chunk_src[blockIdx.x]];
     const int k0 = Q.chunk_c0[blockIdx.x];
@@ -382,25 +382,22 @@ __global__ __launch_bounds__(PW_T, 2) void pw_wgrad_kernel(const PwWgParams Q) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) { A[q] = A1[q]; B[q] = B1[q]; A1[q] = A2[q]; B1[q] = B2[q]; }
     }
-    // D layout: acc[a][c][r] = dW[o0 + chanA(a, 4g + r)][k0 + chanB(c, j)]; the four waves add into one LDS image in turn
-    for (int w = 0; w < PW_T / 64; ++w) {
-        if (wave == w) {
+    // D layout: acc[a][c][r] = dW[o0 + chanA(a, 4g + r)][k0 + chanB(c, j)]; every wave stores its own LDS image (one round, one
+    // barrier; adding into a single image in turn was four), the images are added on the way out
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float &d = s_red[pw_frag_channel(Q.dz.layout, a, 4 * g + r)][pw_frag_channel(S.layout, c, j)];
-                        d = w == 0 ? acc[a][c][r] : d + acc[a][c][r];
-                    }
-        }
-        __syncthreads();
-    }
+            for (int r = 0; r < 4; ++r)
+                s_red[wave][pw_frag_channel(Q.dz.layout, a, 4 * g + r)][pw_frag_channel(S.layout, c, j)] = acc[a][c][r];
+    __syncthreads();
+    auto total = [&](int o, int k) { return (s_red[0][o][k] + s_red[1][o][k]) + (s_red[2][o][k] + s_red[3][o][k]); };
+    static_assert(PW_T == 256, "four waves");
     if (gridDim.z > 1) {             // a partial block per workgroup, no atomics (a 64 x 64 block of float atomics per workgroup on
                                      // 64..256 contended addresses cost more than the whole product)
         float *dst = Q.partial + ((size_t)blockIdx.z * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4096;
-        for (int e = threadIdx.x; e < 64 * 64; e += PW_T) dst[e] = s_red[e >> 6][e & 63];
+        for (int e = threadIdx.x; e < 64 * 64; e += PW_T) dst[e] = total(e >> 6, e & 63);
         return;
     }
     const int no = min(64, Q.dz.channels - o0), nk = min(64, S.channels - k0);
@@ -408,7 +405,7 @@ __global__ __launch_bounds__(PW_T, 2) void pw_wgrad_kernel(const PwWgParams Q) {
         const int o = e >> 6, k = e & 63;
         if (o < no && k < nk) {
             float *dst = S.layout == 2 ? Q.dbias + o0 + o : Q.dW + (size_t)(o0 + o) * Q.w_pitch + S.col0 + k0 + k;
-            *dst += s_red[o][k];                                   // this workgroup owns the block
+            *dst += total(o, k);                                   // this workgroup owns the block
         }
     }
 }
