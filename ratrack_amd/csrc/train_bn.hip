@@ -334,6 +334,114 @@ __global__ __launch_bounds__(BN_T) void bn_relu_pool_bwd_stats_kernel(int sample
     }
 }
 
+// ---- small planes (per-point layers: ns = 1, a plane is a few hundred elements) ---------------------------------------------------
+// One WAVE per (channel, sample) plane, four planes per workgroup: with one workgroup per plane these passes were 16 384 workgroups
+// of one element per thread -- launch rounds, not bandwidth.  Same arithmetic as the kernels above; planes of E <= 1024, E % 4 == 0.
+__device__ __forceinline__ float wave_bcast(float v) { return __shfl(v, 0, 64); }
+
+__global__ __launch_bounds__(BN_T) void bn_relu_fwd_small_kernel(int samples, int channels, int E, int groups, const float *__restrict__ z,
+                                                                 float *par, const rtk_bn_fin_t fin, float *__restrict__ y) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    if (c >= channels) return;
+    const int g = b / (samples / groups);
+    const size_t GC = (size_t)groups * channels, o = (size_t)g * channels + c;
+    float sc = 0.f, sh = 0.f;
+    if (lane == 0) {
+        if (fin.sums) {
+            float mean, rstd;
+            bn_fin_constants(fin, channels, groups, g, c, mean, rstd, sc, sh);
+            if (b == 0) bn_fin_publish(fin, channels, groups, c, par);
+        } else {
+            sc = par[2 * GC + o];
+            sh = par[3 * GC + o];
+        }
+    }
+    sc = wave_bcast(sc);
+    sh = wave_bcast(sh);
+    const size_t base = ((size_t)b * channels + c) * E;
+    for (int e4 = lane; e4 < (E >> 2); e4 += 64) {
+        float4 v = *reinterpret_cast<const float4 *>(z + base + 4 * e4);
+        v.x = fmaxf(__fmaf_rn(v.x, sc, sh), 0.f);
+        v.y = fmaxf(__fmaf_rn(v.y, sc, sh), 0.f);
+        v.z = fmaxf(__fmaf_rn(v.z, sc, sh), 0.f);
+        v.w = fmaxf(__fmaf_rn(v.w, sc, sh), 0.f);
+        *reinterpret_cast<float4 *>(y + base + 4 * e4) = v;
+    }
+}
+
+__global__ __launch_bounds__(BN_T) void bn_relu_bwd_stats_small_kernel(int samples, int channels, int E, int groups, const float *__restrict__ z,
+                                                                       const float *__restrict__ dy, const float *__restrict__ par,
+                                                                       double *__restrict__ sums2) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    if (c >= channels) return;
+    const int g = b / (samples / groups);
+    const size_t GC = (size_t)groups * channels, o = (size_t)g * channels + c;
+    const float mean = par[o], rstd = par[GC + o], sc = par[2 * GC + o], sh = par[3 * GC + o];
+    const size_t base = ((size_t)b * channels + c) * E;
+    double s = 0.0, sx = 0.0;
+    auto acc = [&](float zi, float di) {
+        const bool on = __fmaf_rn(zi, sc, sh) > 0.f;
+        const float d = on ? di : 0.f;
+        s += (double)d;
+        sx += (double)d * (double)((zi - mean) * rstd);
+    };
+    for (int e4 = lane; e4 < (E >> 2); e4 += 64) {
+        const float4 v = *reinterpret_cast<const float4 *>(z + base + 4 * e4);
+        const float4 d = *reinterpret_cast<const float4 *>(dy + base + 4 * e4);
+        acc(v.x, d.x); acc(v.y, d.y); acc(v.z, d.z); acc(v.w, d.w);
+    }
+    s = wave_sum_f64(s);
+    sx = wave_sum_f64(sx);
+    if (lane == 0) {
+        double *dst = rtk_stat_slot(sums2, GC * 2, b) + o * 2;
+        atomicAdd(dst, s);
+        atomicAdd(dst + 1, sx);
+    }
+}
+
+__global__ __launch_bounds__(BN_T) void bn_relu_bwd_apply_small_kernel(int samples, int channels, int E, int groups, const float *__restrict__ z,
+                                                                       const float *__restrict__ dy, const float *__restrict__ par,
+                                                                       const float *__restrict__ rw, const double *__restrict__ sums2,
+                                                                       double count, float *__restrict__ dz, float *__restrict__ dgb) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    if (c >= channels) return;
+    const int g = b / (samples / groups);
+    const size_t GC = (size_t)groups * channels, o = (size_t)g * channels + c;
+    const float mean = par[o], rstd = par[GC + o], sc = par[2 * GC + o], sh = par[3 * GC + o];
+    float c1 = 0.f, c2 = 0.f;
+    if (lane == 0) {
+        c1 = (float)(rtk_stat_read(sums2, GC * 2, o * 2) / count);
+        c2 = (float)(rtk_stat_read(sums2, GC * 2, o * 2 + 1) / count);
+        if (dgb && b == 0) {                                       // parameter gradients: sum over the groups
+            double db = 0.0, dg = 0.0;
+            for (int gg = 0; gg < groups; ++gg) {
+                db += rtk_stat_read(sums2, GC * 2, ((size_t)gg * channels + c) * 2);
+                dg += rtk_stat_read(sums2, GC * 2, ((size_t)gg * channels + c) * 2 + 1);
+            }
+            dgb[c] = (float)dg;
+            dgb[channels + c] = (float)db;
+        }
+    }
+    c1 = wave_bcast(c1);
+    c2 = wave_bcast(c2);
+    const size_t base = ((size_t)b * channels + c) * E;
+    const float *w = rw ? rw + (size_t)b * E : nullptr;            // ns = 1: one weight per element
+    auto one = [&](float zi, float di, int e) -> float {
+        const bool on = __fmaf_rn(zi, sc, sh) > 0.f;
+        const float wi = w ? w[e] : 1.f;
+        const float xh = (zi - mean) * rstd;
+        return sc * ((on ? di : 0.f) - wi * (c1 + xh * c2));
+    };
+    for (int e4 = lane; e4 < (E >> 2); e4 += 64) {
+        const float4 v = *reinterpret_cast<const float4 *>(z + base + 4 * e4);
+        const float4 d = *reinterpret_cast<const float4 *>(dy + base + 4 * e4);
+        float4 r;
+        r.x = one(v.x, d.x, 4 * e4); r.y = one(v.y, d.y, 4 * e4 + 1);
+        r.z = one(v.z, d.z, 4 * e4 + 2); r.w = one(v.w, d.w, 4 * e4 + 3);
+        *reinterpret_cast<float4 *>(dz + base + 4 * e4) = r;
+    }
+}
+
 // ---- backward, pass 2 -------------------------------------------------------------------------------------------------
 struct BwdCoef {
     float mean, rstd, sc, sh, c1, c2;
@@ -440,6 +548,9 @@ int ilog2_exact(int v) {
     RTK_REQUIRE(ilog2_exact(ns) >= 0, name ": ns (%d) must be a power of two", ns);                                 \
     RTK_REQUIRE(samples <= 65535, name ": too many samples (%d)", samples)
 
+// per-point layers: one wave per plane (bn_relu_*_small_kernel)
+#define BN_SMALL_PLANE (ns == 1 && rows <= 1024 && (rows & 3) == 0)
+
 #define RTK_BN_POOL_DISPATCH(KERNEL, ...)                                                   \
     switch (ns) {                                                                           \
     case 4: KERNEL<1><<<grid, BN_T, 0, s>>>(__VA_ARGS__); break;                            \
@@ -478,6 +589,8 @@ static int bn_relu_fwd_launch(int samples, int channels, int rows, int ns, int g
     const dim3 grid(channels, samples);
     if (pool) {
         RTK_BN_POOL_DISPATCH(bn_relu_pool_fwd_kernel, samples, channels, rows, groups, z, par, fin, y)
+    } else if (BN_SMALL_PLANE) {
+        bn_relu_fwd_small_kernel<<<dim3(rtk_divup(channels, 4), samples), BN_T, 0, s>>>(samples, channels, rows, groups, z, par, fin, y);
     } else {
         bn_relu_fwd_kernel<<<grid, BN_T, 0, s>>>(samples, channels, rows, ns, groups, z, par, fin, y);
     }
@@ -504,6 +617,8 @@ extern "C" int rtk_bn_relu_bwd_stats(int samples, int channels, int rows, int ns
     const dim3 grid(channels, samples);
     if (pool) {
         RTK_BN_POOL_DISPATCH(bn_relu_pool_bwd_stats_kernel, samples, channels, rows, groups, z, dy, par, sums2)
+    } else if (BN_SMALL_PLANE) {
+        bn_relu_bwd_stats_small_kernel<<<dim3(rtk_divup(channels, 4), samples), BN_T, 0, s>>>(samples, channels, rows, groups, z, dy, par, sums2);
     } else {
         bn_relu_bwd_stats_kernel<<<grid, BN_T, 0, s>>>(samples, channels, rows, ns, groups, z, dy, par, sums2);
     }
@@ -520,6 +635,9 @@ extern "C" int rtk_bn_relu_bwd_apply(int samples, int channels, int rows, int ns
     if (pool) {
         RTK_BN_POOL_DISPATCH(bn_relu_pool_bwd_apply_kernel, samples, channels, rows, groups, z, dy, par, row_weight, sums2, count, dz,
                              dgamma_dbeta)
+    } else if (BN_SMALL_PLANE) {
+        bn_relu_bwd_apply_small_kernel<<<dim3(rtk_divup(channels, 4), samples), BN_T, 0, s>>>(samples, channels, rows, groups, z, dy, par, row_weight,
+                                                                                           sums2, count, dz, dgamma_dbeta);
     } else {
         bn_relu_bwd_apply_kernel<<<grid, BN_T, 0, s>>>(samples, channels, rows, ilog2_exact(ns), groups, z, dy, par, row_weight, sums2,
                                                        count, dz, dgamma_dbeta);
