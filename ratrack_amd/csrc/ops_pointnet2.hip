@@ -970,15 +970,26 @@ extern "C" int rtk_knn(int b, int n, int m, int k, const float *unknown, const f
 // ------------------------------------------------------------------------------------------------
 // three_interpolate / grad   (interpolate_gpu.cu:149-169, 192-214)
 // ------------------------------------------------------------------------------------------------
+// A thread interpolates its point for TI_CPB channels: the three indices and weights are loaded once (with one channel per thread
+// the launch was 16 384 workgroups of three gathers per thread at the training shapes).
+template <int TI_CPB>       // 8 for large batches; 1 where that would leave most of the chip idle
 __global__ void three_interpolate_kernel(int c, int m, int n, const float *__restrict__ points,
                                          const int *__restrict__ idx, const float *__restrict__ weight,
                                          float *__restrict__ out) {
-    const int bs = blockIdx.z, ci = blockIdx.y, pt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int bs = blockIdx.z, c0 = blockIdx.y * TI_CPB, pt = blockIdx.x * blockDim.x + threadIdx.x;
     if (pt >= n) return;
     const float *w = weight + ((size_t)bs * n + pt) * 3;
     const int *id = idx + ((size_t)bs * n + pt) * 3;
-    const float *p = points + ((size_t)bs * c + ci) * m;
-    out[((size_t)bs * c + ci) * n + pt] = __fmaf_rn(w[2], p[id[2]], __fmaf_rn(w[1], p[id[1]], __fmul_rn(w[0], p[id[0]])));
+    const float w0 = w[0], w1 = w[1], w2 = w[2];
+    const int i0 = id[0], i1 = id[1], i2 = id[2];
+    const int nc = min(TI_CPB, c - c0);
+#pragma unroll
+    for (int q = 0; q < TI_CPB; ++q) {
+        if (q < nc) {
+            const float *p = points + ((size_t)bs * c + c0 + q) * m;
+            out[((size_t)bs * c + c0 + q) * n + pt] = __fmaf_rn(w2, p[i2], __fmaf_rn(w1, p[i1], __fmul_rn(w0, p[i0])));
+        }
+    }
 }
 
 __global__ void three_interpolate_grad_kernel(int c, int n, int m, const float *__restrict__ grad_out,
@@ -999,7 +1010,10 @@ extern "C" int rtk_three_interpolate(int b, int c, int m, int n, const float *po
                                      const float *weight, float *out, rtk_stream_t stream) {
     RTK_REQUIRE(b > 0 && c > 0 && m > 0 && n > 0 && points && idx && weight && out, "three_interpolate: bad arguments");
     RTK_REQUIRE(c <= 65535 && b <= 65535, "three_interpolate: c/b exceed grid limits");
-    three_interpolate_kernel<<<dim3(rtk_divup(n, 256), c, b), 256, 0, (hipStream_t)stream>>>(c, m, n, points, idx, weight, out);
+    if ((long)b * c * rtk_divup(n, 256) >= 4096)
+        three_interpolate_kernel<8><<<dim3(rtk_divup(n, 256), rtk_divup(c, 8), b), 256, 0, (hipStream_t)stream>>>(c, m, n, points, idx, weight, out);
+    else
+        three_interpolate_kernel<1><<<dim3(rtk_divup(n, 256), c, b), 256, 0, (hipStream_t)stream>>>(c, m, n, points, idx, weight, out);
     RTK_CHECK_LAUNCH("three_interpolate");
     return RTK_OK;
 }
