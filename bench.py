@@ -405,6 +405,13 @@ def main():
     # ---- train step (config 3; config 4 when world > 1) ---------------------------------------------------------------
     if not a.no_train:
         try:
+            # the forward leg's pipelines (eight captured graphs with their private pools, events, streams) are released first: the
+            # train leg starts from the allocator state a fresh `--mode train` process has
+            pipe = pipe2 = eng = events = alone = None
+            net._fused = None
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
             tr = run_train(a, net, d, dev, dist, world, rank, a.train_steps, 5)
         except Exception as e:                  # never lose the headline over the extra leg
             tr = {"error": repr(e)[:300]}

@@ -652,7 +652,7 @@ class _CostVolume(torch.autograd.Function):
         # weight gradients: contractions over the M positions
         # dW2 = dz2^T a1 and dW3 = dz3^T a2 as ONE batched GEMM over the slabs of both products (the operands are adjacent slices of
         # `big` / `acts`: (dz2, dz3) and (a1, a2)), then one sum per product
-        c = 256
+        c = 64                                 # slabs per product (32 .. 256 measured within 0.5 % of each other; fewer = a smaller sum)
         while M % c:
             c //= 2
         if c >= 8:
