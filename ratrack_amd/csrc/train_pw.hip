@@ -545,12 +545,12 @@ extern "C" int rtk_pw_wgrad(int samples, int positions, const rtk_pw_operand_t *
     Q.nchunks = nch;
     const long ntiles = (long)samples * ((positions + 15) / 16);
     const int ochunks = rtk_divup(dz->channels, 64);
-    // about two workgroups per CU (more only adds partial blocks: tools/exp_pw.py), at least two tiles per wave, and no more
+    // about two workgroups per CU (more only adds partial blocks: tools/exp_pw.py), at least one tile per wave, and no more
     // position splits than the workspace holds partial blocks for
     const long blocks = (long)nch * ochunks;
     static const int want_wgs = getenv("RTK_WG_WGS") ? atoi(getenv("RTK_WG_WGS")) : 512;      // experiment knob
     long splits = (want_wgs + blocks - 1) / blocks;
-    if (splits > (ntiles + 7) / 8) splits = (ntiles + 7) / 8;
+    if (splits > (ntiles + 3) / 4) splits = (ntiles + 3) / 4;      // ... and at least one tile per wave (tiny batches: the serial depth counts)
     if (splits > workspace_floats / (blocks * 4096)) splits = workspace ? workspace_floats / (blocks * 4096) : 1;
     if (splits < 1) splits = 1;
     Q.tiles_per_wg = (int)((ntiles + splits - 1) / splits);
