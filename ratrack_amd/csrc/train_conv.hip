@@ -481,7 +481,7 @@ extern "C" int rtk_conv_wgrad(int samples, int cprev, int cout, int rows, int ns
     const int ntiles = (Q.P + 15) / 16;
     RTK_REQUIRE(workspace_floats >= (long)samples * cprev * cout, "rtk_conv_wgrad: workspace of %ld floats < %ld", workspace_floats,
                 (long)samples * cprev * cout);
-    int gx = (ntiles + 7) / 8;                                           // at least two tiles per wave ...
+    int gx = (ntiles + 3) / 4;                                           // at least one tile per wave ...
     while (((long)gx * samples > 1024 || (long)gx * samples * cprev * cout > workspace_floats) && gx > 1) gx = (gx + 1) / 2;
     const dim3 grid(gx, samples);                                        // ... and about four workgroups (one partial dW each) per CU
     hipStream_t s = (hipStream_t)stream;
