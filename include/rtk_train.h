@@ -213,11 +213,20 @@ RTK_EXPORT int rtk_cost_volume_bwd(int samples, int n1, int n2, const float *xyz
                                    float *dq3, float *d4, float *dp1, float *dpd, float *dt2, float *dbias_rows, rtk_stream_t stream);
 
 /* Backward of rtk_patch_cost (rtk_fused.h; same forward arguments; feat point-major).  dout (samples*n, dout_pitch).
- * Outputs over the M = samples*n*16 positions: dxg (M,256) = dout * wn (scatter it onto feat's rows with
- * rtk_scatter_add_rows(knn_idx, dxg)), dq3 (M,256), dt2 (M,8), d4 (M,4) as in rtk_cost_volume_bwd. */
+ * Outputs over the M = samples*n*16 positions: dxg (M,256) = dout * wn (optional; scatter it onto feat's rows with
+ * rtk_scatter_add_rows(knn_idx, dxg), or pass NULL and use rtk_patch_dfeat_gather), dq3 (M,256), dt2 (M,8), d4 (M,4) as in
+ * rtk_cost_volume_bwd, t2 (M,8) (optional). */
 RTK_EXPORT int rtk_patch_cost_bwd(int samples, int n, const float *xyz, const int64_t *knn_idx, const float *feat, int feat_pitch,
                                   const rtk_layer_t *wn, const float *wct_packed, const float *dout, int dout_pitch, float *dxg,
-                                  float *dq3, float *dt2, float *d4, rtk_stream_t stream);
+                                  float *dq3, float *dt2, float *d4, float *t2, rtk_stream_t stream);
+
+/* The feature gradient of rtk_patch_cost without dxg: rtk_patch_cost_bwd with dxg = NULL and t2 (M, 8) (the WeightNet's hidden
+ * activation per position), then  dfeat (samples*n, 256)[m] = sum over the positions (i,k) with knn[i,k] = m of
+ * relu(wc t2 + bc) * dout[i]  over the inverse table (off (samples, n+1), inv (samples, 16n)) that rtk_group_inverse_index
+ * builds from the kNN table (as int32, n_src = n, positions = 16 n).  wc (256, 8), bc (256): the live last-layer parameters.
+ * Fully written, no atomics, deterministic. */
+RTK_EXPORT int rtk_patch_dfeat_gather(int samples, int n, const int *off, const unsigned short *inv, const float *t2, const float *wc,
+                                      const float *bc, const float *dout, int dout_pitch, float *dfeat, rtk_stream_t stream);
 
 /* ---- de-duplicated geometry tables (ratrack_amd/train_path.py) ---------------------------------------------------------
  * rtk_train_group_geometry: for the first `rows` centroids of every sample, idx_out (samples, rows, ns) = ball_idx

@@ -786,7 +786,8 @@ struct PcBwdParams {
     const float *dout;
     int dout_pitch;
     const f4 *wct;
-    float *dxg, *dq3, *dt2, *d4;
+    float *dxg, *dq3, *dt2, *d4;      // dxg optional (NULL: the feature gradient is gathered by rtk_patch_dfeat_gather instead)
+    float *t2;                        // optional (M, 8): the WeightNet's hidden activation of every position, for that gather
 };
 
 __global__ __launch_bounds__(256) void patch_cost_bwd_kernel(const PcBwdParams Q) {
@@ -801,6 +802,7 @@ __global__ __launch_bounds__(256) void patch_cost_bwd_kernel(const PcBwdParams Q
         const long pos = i * 16 + j;
         Q.d4[pos * 4 + g] = bop;
         const f4 t2 = weightnet_hidden(P.wn, lane, g, bop);
+        if (Q.t2 && g < 2) *reinterpret_cast<f4 *>(Q.t2 + pos * 8 + 4 * g) = t2;      // rows 4g .. 4g+3 = hidden units, column j = position
         const float *fr = P.feat + nb * P.feat_pitch + 4 * g;
         const float *dor = Q.dout + i * Q.dout_pitch + 4 * g;
         f4 dt2 = f4_zero();
@@ -826,7 +828,7 @@ __global__ __launch_bounds__(256) void patch_cost_bwd_kernel(const PcBwdParams Q
             dt2 = mfma4(ft.z, q.z, dt2);
             dt2 = mfma4(ft.w, q.w, dt2);
             *reinterpret_cast<f4 *>(Q.dq3 + pos * 256 + 16 * v + 4 * g) = q;
-            *reinterpret_cast<f4 *>(Q.dxg + pos * 256 + 16 * v + 4 * g) = d * w;
+            if (Q.dxg) *reinterpret_cast<f4 *>(Q.dxg + pos * 256 + 16 * v + 4 * g) = d * w;
         }
         if (g < 2) *reinterpret_cast<f4 *>(Q.dt2 + pos * 8 + 4 * g) = dt2;
     }
@@ -834,8 +836,8 @@ __global__ __launch_bounds__(256) void patch_cost_bwd_kernel(const PcBwdParams Q
 
 extern "C" int rtk_patch_cost_bwd(int samples, int n, const float *xyz, const int64_t *knn_idx, const float *feat, int feat_pitch,
                                   const rtk_layer_t *wn, const float *wct_packed, const float *dout, int dout_pitch, float *dxg,
-                                  float *dq3, float *dt2, float *d4, rtk_stream_t stream) {
-    RTK_REQUIRE(samples > 0 && n >= 16 && xyz && knn_idx && feat && dout && dxg && dq3 && dt2 && d4 && wct_packed &&
+                                  float *dq3, float *dt2, float *d4, float *t2, rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && n >= 16 && xyz && knn_idx && feat && dout && (dxg || t2) && dq3 && dt2 && d4 && wct_packed &&
                 feat_pitch % 4 == 0 && feat_pitch >= 256 && dout_pitch % 4 == 0 && dout_pitch >= 256, "patch_cost_bwd: bad arguments");
     PcBwdParams Q;
     PcParams &P = Q.f;
@@ -844,7 +846,7 @@ extern "C" int rtk_patch_cost_bwd(int samples, int n, const float *xyz, const in
     RTK_REQUIRE(wn[2].cout16 == 16, "patch_cost_bwd: WeightNet must produce 256 channels");
     P.out = nullptr; P.out_pitch = 0; P.out_cm = 0;
     Q.dout = dout; Q.dout_pitch = dout_pitch; Q.wct = reinterpret_cast<const f4 *>(wct_packed);
-    Q.dxg = dxg; Q.dq3 = dq3; Q.dt2 = dt2; Q.d4 = d4;
+    Q.dxg = dxg; Q.dq3 = dq3; Q.dt2 = dt2; Q.d4 = d4; Q.t2 = t2;
     RTK_REQUIRE(samples <= 65535, "patch_cost_bwd: too many samples");
     int gx = (n + 3) / 4;
     while ((long)gx * samples > 4096 && gx > 1) gx = (gx + 1) / 2;

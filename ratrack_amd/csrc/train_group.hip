@@ -221,6 +221,51 @@ __global__ __launch_bounds__(256) void three_interp_grad_gather_kernel(int c, in
     }
 }
 
+// Feature gradient of the patch aggregation (rtk_patch_cost: out[i] = sum_k wn(i,k) * feat[knn[i,k]]) in gather form:
+// dfeat[m] = sum over the positions (i, k) with knn[i,k] = m of wn(i,k) * dout[i], wn recomputed from the position's hidden
+// activation t2 (8 values, stored by rtk_patch_cost_bwd): 8 multiply-adds per element instead of materialising wn * dout for every
+// position (268 MB at B = 64) and scattering it.  Thread = channel, PG_R destination rows per workgroup, four positions in flight.
+constexpr int PG_R = 8;
+__global__ __launch_bounds__(256) void patch_dfeat_gather_kernel(int n, const int *__restrict__ off, const unsigned short *__restrict__ inv,
+                                                                 const float *__restrict__ t2, const float *__restrict__ wc,
+                                                                 const float *__restrict__ bc, const float *__restrict__ dout, int dout_pitch,
+                                                                 float *__restrict__ dfeat) {
+    const int b = blockIdx.y, m0 = blockIdx.x * PG_R, c = threadIdx.x;
+    float w[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) w[h] = wc[c * 8 + h];
+    const float bias = bc[c];
+    const int *ob = off + (size_t)b * (n + 1);
+    const unsigned short *ib = inv + (size_t)b * 16 * n;
+    const float *tb = t2 + (size_t)b * 16 * n * 8;
+    const float *db = dout + (size_t)b * n * dout_pitch + c;
+    for (int r = 0; r < PG_R && m0 + r < n; ++r) {
+        const int m = m0 + r, a = ob[m], e = ob[m + 1];
+        float acc = 0.f;
+        for (int i = a; i < e; i += 4) {
+            int pos[4];
+            float d[4];
+            float4 ta[4], tb4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pos[k] = ib[min(i + k, e - 1)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                d[k] = db[(size_t)(pos[k] >> 4) * dout_pitch];
+                ta[k] = *reinterpret_cast<const float4 *>(tb + (size_t)pos[k] * 8);
+                tb4[k] = *reinterpret_cast<const float4 *>(tb + (size_t)pos[k] * 8 + 4);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float o = bias;
+                o = __fmaf_rn(w[0], ta[k].x, o); o = __fmaf_rn(w[1], ta[k].y, o); o = __fmaf_rn(w[2], ta[k].z, o); o = __fmaf_rn(w[3], ta[k].w, o);
+                o = __fmaf_rn(w[4], tb4[k].x, o); o = __fmaf_rn(w[5], tb4[k].y, o); o = __fmaf_rn(w[6], tb4[k].z, o); o = __fmaf_rn(w[7], tb4[k].w, o);
+                if (i + k < e) acc += fmaxf(o, 0.f) * d[k];
+            }
+        }
+        dfeat[((size_t)b * n + m) * 256 + c] = acc;
+    }
+}
+
 }  // namespace
 
 extern "C" int rtk_group_inverse_index(int samples, int n_src, int positions, const int *idx, int *off, unsigned short *inv,
@@ -272,5 +317,15 @@ extern "C" int rtk_three_interpolate_grad_gather(int b, int c, int n, int m, con
     three_interp_grad_gather_kernel<<<dim3((c + TG_CPB - 1) / TG_CPB, b), 256, (size_t)TG_CPB * n * sizeof(float), (hipStream_t)stream>>>(
         c, n, m, grad_out, weight, off, inv, grad_points);
     RTK_CHECK_LAUNCH("three_interpolate_grad_gather");
+    return RTK_OK;
+}
+
+extern "C" int rtk_patch_dfeat_gather(int samples, int n, const int *off, const unsigned short *inv, const float *t2, const float *wc,
+                                      const float *bc, const float *dout, int dout_pitch, float *dfeat, rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && n >= 16 && 16 * (long)n <= 65536 && off && inv && t2 && wc && bc && dout && dfeat && dout_pitch >= 256 &&
+                samples <= 65535, "patch_dfeat_gather: bad arguments");
+    patch_dfeat_gather_kernel<<<dim3((n + PG_R - 1) / PG_R, samples), 256, 0, (hipStream_t)stream>>>(n, off, inv, t2, wc, bc, dout, dout_pitch,
+                                                                                                     dfeat);
+    RTK_CHECK_LAUNCH("patch_dfeat_gather");
     return RTK_OK;
 }

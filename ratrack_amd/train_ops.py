@@ -28,7 +28,8 @@ _lib.SIGNATURES.update({
     "rtk_train_interp_weights": [_i] * 3 + [_p] * 5 + [_p],
     "rtk_train_row_weights": [_i] * 3 + [_p] * 2 + [_p],
     "rtk_gru_step_bwd": [_i] * 3 + [_p] * 15 + [_p],
-    "rtk_patch_cost_bwd": [_i, _i, _p, _p, _p, _i, _LayerP, _p, _p, _i, _p, _p, _p, _p, _p],
+    "rtk_patch_cost_bwd": [_i, _i, _p, _p, _p, _i, _LayerP, _p, _p, _i, _p, _p, _p, _p, _p, _p],
+    "rtk_patch_dfeat_gather": [_i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p],
     "rtk_bn_train_stats": [_i] * 5 + [_p] * 3 + [_p],
     "rtk_bn_train_finalize": [_i, _i, _p, _d, _p, _p, _f, _f, _p, _p, _p, _p, _p],
     "rtk_bn_relu_fwd": [_i] * 5 + [_p, _p, _i, _p, _p],
@@ -762,14 +763,28 @@ class _PatchCost(torch.autograd.Function):
         dev = feat.device
         dout = dout.contiguous()
         wn, keep, wct = ctx.images
-        big = torch.empty(2, M, 256, dtype=torch.float32, device=dev)
-        dxg, dq3 = big.unbind(0)
+        dq3 = torch.empty(M, 256, dtype=torch.float32, device=dev)
         dt2 = torch.empty(M, 8, dtype=torch.float32, device=dev)
         d4 = torch.empty(M, 4, dtype=torch.float32, device=dev)
-        _lib.call("rtk_patch_cost_bwd", B, n, xyz.data_ptr(), knn.data_ptr(), feat.data_ptr(), 256, wn, wct.data_ptr(), dout.data_ptr(),
-                  256, dxg.data_ptr(), dq3.data_ptr(), dt2.data_ptr(), d4.data_ptr(), _stream())
         dfeat = torch.empty(B * n, 256, dtype=torch.float32, device=dev)
-        _lib.call("rtk_scatter_add_rows", B, n * 16, n, 256, knn.data_ptr(), dxg.data_ptr(), dfeat.data_ptr(), _stream())
+        if n <= 2048:                          # the 16-bit inverse table and its LDS budget (rtk_group_inverse_index)
+            # feature gradient as a gather over the inverse kNN table (positions sorted by the row they gathered), the WeightNet output
+            # recomputed from its hidden activation: nothing of size (M, 256) is materialised for it
+            t2 = torch.empty(M, 8, dtype=torch.float32, device=dev)
+            _lib.call("rtk_patch_cost_bwd", B, n, xyz.data_ptr(), knn.data_ptr(), feat.data_ptr(), 256, wn, wct.data_ptr(), dout.data_ptr(),
+                      256, None, dq3.data_ptr(), dt2.data_ptr(), d4.data_ptr(), t2.data_ptr(), _stream())
+            k32 = knn.to(torch.int32)
+            off = torch.empty(B, n + 1, dtype=torch.int32, device=dev)
+            inv = torch.empty(B, 16 * n, dtype=torch.int16, device=dev)
+            _lib.call("rtk_group_inverse_index", B, n, 16 * n, k32.data_ptr(), off.data_ptr(), inv.data_ptr(), _stream())
+            wc_, bc_ = wc.detach().reshape(256, 8).contiguous(), bc.detach().contiguous()
+            _lib.call("rtk_patch_dfeat_gather", B, n, off.data_ptr(), inv.data_ptr(), t2.data_ptr(), wc_.data_ptr(), bc_.data_ptr(),
+                      dout.data_ptr(), 256, dfeat.data_ptr(), _stream())
+        else:
+            dxg = torch.empty(M, 256, dtype=torch.float32, device=dev)
+            _lib.call("rtk_patch_cost_bwd", B, n, xyz.data_ptr(), knn.data_ptr(), feat.data_ptr(), 256, wn, wct.data_ptr(), dout.data_ptr(),
+                      256, dxg.data_ptr(), dq3.data_ptr(), dt2.data_ptr(), d4.data_ptr(), None, _stream())
+            _lib.call("rtk_scatter_add_rows", B, n * 16, n, 256, knn.data_ptr(), dxg.data_ptr(), dfeat.data_ptr(), _stream())
         return (dfeat,) + _weightnet_backward(d4, dq3, dt2, wa, ba, wb, bb, wc) + (None, None)
 
 
