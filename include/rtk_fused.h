@@ -98,6 +98,27 @@ RTK_EXPORT int rtk_patch_cost(int samples, int n, const float *xyz, const int64_
                               const float *feat, int feat_pitch, const rtk_layer_t *wn, float *out,
                               int out_pitch, int out_channel_major, rtk_stream_t stream);
 
+/* ---- split-bf16 matrix path (csrc/split_mfma.h): fp32 results from the bf16 matrix pipe --------------------------------
+ * Every fp32 operand is the exact sum of three bf16 pieces; a product is the six partial products of total order <= 2,
+ * accumulated in fp32.  The error is that of an fp32 fmaf chain (the dropped terms are below one fp32 rounding of the
+ * product); the matrix time is 6/16 of the fp32-input MFMA's, the only exact-fp32 matrix instruction of gfx950.
+ *
+ * rtk_pack_split_layer: w (cout, cin) row-major fp32, both multiples of 32 -> image of cin/16 * cout/32 * 3 fragments
+ * of 1 KiB (6 * cout * cin bytes), fragment (s, v, p) = piece p of rows 32 v .. +31 against the 16 input channels of k-step s
+ * in the lane order of v_mfma_f32_32x32x16_bf16.
+ * rtk_split_mlp2: y = leaky(W2 leaky(W1 x + b1) + b2), LeakyReLU(0.1), x / y (positions, 256) point-major; images = the split
+ * images of W1 and W2 back to back.  The inner layers of the cost volume (utils/model_utils/model_utils.py:216-236) as a
+ * standalone operator: what tests and tools time the matrix path with. */
+RTK_EXPORT int rtk_pack_split_layer(int cout, int cin, const float *w, void *image, rtk_stream_t stream);
+/* rtk_cost_volume with its two 256 x 256 layers on the split path: same arguments, the layers as their split images (W2, W3
+ * back to back, 2 * 393216 bytes) and fp32 biases instead of the packed rtk_layer_t pair. */
+RTK_EXPORT int rtk_cost_volume_split(int samples, int n1, int n2, const float *xyz1, const float *xyz2,
+                                     const int64_t *knn_idx, const float *p1, const float *p2, const float *wd_packed,
+                                     const void *split_images, const float *bias2, const float *bias3,
+                                     const rtk_layer_t *wn, float *out, int out_pitch, rtk_stream_t stream);
+RTK_EXPORT int rtk_split_mlp2(int positions, const float *x, const void *images, const float *bias1, const float *bias2,
+                              float *y, rtk_stream_t stream);
+
 /* Layout glue of Track4D.backbone (models/track4d.py:104-105): (B,3,N)/(B,2,N) channel-major inputs of both
  * frames -> xyz (2B,N,3) and raw (2B,N,4) = (RCS, v_r, 0, 0) point-major, frame 1 first. */
 RTK_EXPORT int rtk_prepare_inputs(int b, int n, const float *pc1, const float *pc2, const float *feature1,

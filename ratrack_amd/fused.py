@@ -12,6 +12,7 @@ Per step: geometry kernels (FPS / ball query / three-NN / kNN) + fused stages on
 All results agree with the module path / CPU oracle within fp32 rounding (tests: 1e-4 rel-to-scale).
 """
 import ctypes
+import os
 
 import torch
 
@@ -43,6 +44,9 @@ _lib.SIGNATURES.update({
     "rtk_sa_scale": [_ci] * 4 + [_vp] * 4 + [_ci, _ci, _vp, _ci, ctypes.POINTER(_Layer), _vp, _ci, _ci, _vp, _vp, _vp],
     "rtk_cost_volume": [_ci] * 3 + [_vp] * 6 + [ctypes.POINTER(_Layer), ctypes.POINTER(_Layer), _vp, _ci, _vp],
     "rtk_patch_cost": [_ci] * 2 + [_vp] * 3 + [_ci, ctypes.POINTER(_Layer), _vp, _ci, _ci, _vp],
+    "rtk_pack_split_layer": [_ci, _ci, _vp, _vp, _vp],
+    "rtk_cost_volume_split": [_ci] * 3 + [_vp] * 9 + [ctypes.POINTER(_Layer), _vp, _ci, _vp],
+    "rtk_split_mlp2": [_ci, _vp, _vp, _vp, _vp, _vp, _vp],
     "rtk_prepare_inputs": [_ci] * 2 + [_vp] * 6 + [_vp],
     "rtk_fps_centroids": [_ci] * 3 + [_vp] * 8 + [_vp],
     "rtk_knn_point_masked": [_ci] * 4 + [_vp] * 4 + [_vp],
@@ -127,6 +131,29 @@ def pack_layer(w):
         wp = torch.zeros(V * 16, U * 16, dtype=torch.float32, device=w.device)
         wp[:cout, :cin] = w.float()
     return wp.reshape(V, 16, U, 4, 4).permute(2, 0, 3, 1, 4).contiguous().reshape(-1)   # (U, V, g, i, r)
+
+
+def split3_bf16(w):
+    """The three bf16 pieces of an fp32 tensor (truncation splits: p0 + p1 + p2 == w exactly), as the upper 16 bits of each
+    piece (int16), stacked on a new first axis.  csrc/split_mfma.h."""
+    x = w.float().contiguous()
+    out = []
+    for _ in range(3):
+        top = (x.view(torch.int32) & -65536)
+        out.append((top >> 16).to(torch.int16))
+        x = x - top.view(torch.float32)
+    return torch.stack(out)
+
+
+def pack_layer_split(w):
+    """(Cout, Cin) fp32, both multiples of 32 -> split image of csrc/split_mfma.h as int16:
+    frag[s][v][p][lane = 32 hh + i][t] = piece_p(W[32 v + i][32 (s / 2) + 16 (s % 2) + 8 (t / 4) + 4 hh + t % 4]).
+    (The product path packs on the device, rtk_pack_split_layer; this is the host restatement the tests compare it with.)"""
+    cout, cin = w.shape
+    assert cout % 32 == 0 and cin % 32 == 0
+    p = split3_bf16(w)                                                   # (3, cout, cin)
+    p = p.reshape(3, cout // 32, 32, cin // 32, 2, 2, 2, 4)               # (p, v, i, a, e, d, hh, r): c = 32 a + 16 e + 8 d + 4 hh + r
+    return p.permute(3, 4, 1, 0, 6, 2, 5, 7).contiguous().reshape(-1)     # (a, e, v, p, hh, i, d, r): s = 2 a + e, t = 4 d + r
 
 
 def pad_bias(b, cout):
@@ -540,6 +567,14 @@ class FusedBackbone:
         self.cv_wd = offset_image(torch.cat([w0[:, 512:515], z(256)[:, None]], 1), dev)
         self.cv_layers = Chain([(sd["fc_layer.mlp_convs.%d.weight" % i].double().reshape(256, 256),
                                  sd["fc_layer.mlp_convs.%d.bias" % i].double(), ACT_LEAKY) for i in (1, 2)], dev)
+        # the same two layers as split images (csrc/split_mfma.h): fp32 results from the bf16 matrix pipe, 6/16 of the matrix time
+        self.cv_split = os.environ.get("RTK_CV_SPLIT", "1") != "0"
+        w23 = [sd["fc_layer.mlp_convs.%d.weight" % i].double().reshape(256, 256).float().to(dev).contiguous() for i in (1, 2)]
+        self.cv_bias23 = torch.stack([sd["fc_layer.mlp_convs.%d.bias" % i].double().float() for i in (1, 2)]).to(dev).contiguous()
+        self.cv_images = torch.empty(2 * 3 * 256 * 256, dtype=torch.int16, device=dev)
+        for l, w in enumerate(w23):
+            _lib.call("rtk_pack_split_layer", 256, 256, w.data_ptr(), self.cv_images[l * 3 * 256 * 256:].data_ptr(), _stream())
+        torch.cuda.current_stream().synchronize()      # w23 may go
         self.wn1 = _WeightNet(sd, "fc_layer.weightnet1", dev)
         self.wn2 = _WeightNet(sd, "fc_layer.weightnet2", dev)
         # heads
@@ -650,6 +685,11 @@ class FusedBackbone:
     def _cost_volume(self, B, N, x1, x2, knn1, p1, p2, cor1):
         if _TRACE is not None:      # per (point, neighbour) pair: direction term, layers 2+3, WeightNet 3-8-8-256, weighted sum
             _TRACE.append(("cost_volume", B * N * 16, 3 * 256 + 2 * 256 * 256 + (3 * 8 + 8 * 8 + 8 * 256) + 256))
+        if self.cv_split:
+            _lib.call("rtk_cost_volume_split", B, N, N, x1.data_ptr(), x2.data_ptr(), knn1.data_ptr(), p1.data_ptr(), p2.data_ptr(),
+                      self.cv_wd.data_ptr(), self.cv_images.data_ptr(), self.cv_bias23[0].data_ptr(), self.cv_bias23[1].data_ptr(),
+                      self.wn1.arr, cor1.data_ptr(), 256, _stream())
+            return
         _lib.call("rtk_cost_volume", B, N, N, x1.data_ptr(), x2.data_ptr(), knn1.data_ptr(), p1.data_ptr(), p2.data_ptr(),
                   self.cv_wd.data_ptr(), self.cv_layers.arr, self.wn1.arr, cor1.data_ptr(), 256, _stream())
 
