@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
 void split_mlp2_kernel(int positions, const float *__restrict__ x, const f4 *__restrict__ blob, const float *__restrict__ bias1,
                        const float *__restrict__ bias2, float *__restrict__ y) {
     __shared__ __attribute__((aligned(16))) f4 s_w[2 * SP_F * 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, col = lane & 31;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hh = lane >> 5, col = lane & 31;
     constexpr int NF = 2 * SPLIT_NF;
     WStreamA<SP_NW, SP_F, NF> ws;
     ws.start_parts(blob, s_w, wave, lane);
@@ -117,7 +117,8 @@ __device__ __forceinline__ f4 leaky4(f4 t) { return (f4){fmaxf(t.x, 0.1f * t.x),
 
 __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1))) void cost_volume_split_kernel(const CvSplitParams P) {
     __shared__ __attribute__((aligned(16))) f4 s_w[2 * SP_F * 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, col = lane & 31, pp = col >> 4, j = col & 15;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hh = lane >> 5, col = lane & 31, pp = col >> 4,
+              j = col & 15;      // wave index in an SGPR: the DMA's LDS destination (M0) is then scalar arithmetic
     int b, bx, nbx;
     rtk_decode_block(P.gx, b, bx, nbx);
     constexpr int PPW = 2 * SP_NW;                                  // points per workgroup iteration

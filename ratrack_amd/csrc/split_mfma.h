@@ -62,6 +62,9 @@ __device__ __forceinline__ void split3_word(const f4 x0, const f4 x1, u4v (&b)[3
     b[2][W] = pack_hi16(sa, sb);
 }
 
+#ifndef SPLIT_ISSUE_GROUPS
+#define SPLIT_ISSUE_GROUPS 3
+#endif
 constexpr int SPLIT_KS = 16;      // k-steps of a 256-channel contraction
 constexpr int SPLIT_VB = 8;       // 32-row output blocks of a 256-channel layer
 constexpr int SPLIT_NF = SPLIT_KS * SPLIT_VB * 3;      // fragments (KiB) of one 256 x 256 layer
@@ -111,6 +114,9 @@ struct WStreamA : WStream<NW, F, NF> {
 #pragma unroll
         for (int i = K; i < (F + NW - 1) / NW; i += PARTS) {
             const int f = this->wave + i * NW;
+#ifdef RTK_ABL_HALFDMA                   // ablation: every other request only (results are wrong)
+            if (i & 1) continue;
+#endif
             if (f < F)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (size_t)i * NW * 1024 + this->lane_off),
                                                  (__attribute__((address_space(3))) void *)(this->lds + ((this->buf ^ 1) * F + f) * 64), 16, 0, 0);
@@ -155,7 +161,9 @@ struct SplitStep {
     static __device__ __forceinline__ void load(WS &ws, f4 (&dst)[6]) {
         constexpr int f0 = FBASE + GJ * 6;      // F % 6 == 0: a group never straddles two chunks
         if constexpr (f0 % F == 0 && f0 != 0) ws.sync();
-        ws.template issue_part<(f0 % F) / 6, F / 6>();
+        // the requests go out during the first SPLIT_ISSUE_GROUPS group steps of a chunk: spread over all of them, the last ones are
+        // ~400 cycles old at the next sync() and every chunk waits for their L2 round trip (measured: 30 % of the kernel)
+        if constexpr ((f0 % F) / 6 < SPLIT_ISSUE_GROUPS) ws.template issue_part<(f0 % F) / 6, SPLIT_ISSUE_GROUPS>();
         dst[0] = ws.template frag_async<(f0 + 0) % F>();
         dst[1] = ws.template frag_async<(f0 + 1) % F>();
         dst[2] = ws.template frag_async<(f0 + 2) % F>();

@@ -154,8 +154,9 @@ def test_fused_pnhead_matches_modules(name):
     assert torch.equal(gmax, loc.view(B, N, 128).amax(1))          # fused global max-pool == max over points
 
 
+@pytest.mark.parametrize("split", [True, False])      # split-bf16 matrix path (the default) / fp32-input MFMA kernel
 @pytest.mark.parametrize("name", ["eval_b2_n256", "eval_b1_n242", "eval_b1_n1024"])
-def test_fused_cost_volume_matches_modules(name):
+def test_fused_cost_volume_matches_modules(name, split):
     from _util import inputs_of, load_case
     case = load_case(name)
     net = _net()
@@ -182,13 +183,69 @@ def test_fused_cost_volume_matches_modules(name):
         k1 = PU.knn_point(16, x2, x1)
         k2 = PU.knn_point(16, x1, x1)
         from ratrack_amd import _lib
-        cor1 = new(B * N, 256)
-        _lib.call("rtk_cost_volume", B, N, N, x1.data_ptr(), x2.data_ptr(), k1.data_ptr(), p1.data_ptr(), p2.data_ptr(),
-                  eng.cv_wd.data_ptr(), eng.cv_layers.arr, eng.wn1.arr, cor1.data_ptr(), 256, F._stream())
+        cor1 = torch.full((B * N, 256), float("nan"), device=DEV)
+        eng.cv_split = split
+        eng._cost_volume(B, N, x1, x2, k1, p1, p2, cor1)
         cor = new(B * N, 256)
         _lib.call("rtk_patch_cost", B, N, x1.data_ptr(), k2.data_ptr(), cor1.data_ptr(), 256, eng.wn2.arr, cor.data_ptr(), 256, 0, F._stream())
         got = cor.view(B, N, 256).permute(0, 2, 1)
     assert rel_err(got.cpu(), ref.cpu()) < 2e-5
+
+
+def test_split_images_are_exact_and_packed_as_documented():
+    """csrc/split_mfma.h: the three bf16 pieces sum to the fp32 weight EXACTLY, and the device packer writes the image the host
+    restatement (fused.pack_layer_split) describes."""
+    from ratrack_amd import _lib
+    torch.manual_seed(3)
+    w = torch.randn(256, 256, device=DEV) * torch.logspace(-6, 2, 256, device=DEV)[:, None]      # 8 decades of magnitudes
+    w[0, :3] = torch.tensor([0.0, 1.0, -1.5], device=DEV)                                        # a zero, exact bf16 values
+    pieces = F.split3_bf16(w)                                                                   # (3, 256, 256) int16 = upper halves
+    back = sum((pieces[i].to(torch.int32) << 16).view(torch.float32).double() for i in range(3))
+    assert torch.equal(back.float(), w) and torch.equal(back, w.double())
+    img = torch.empty(3 * 256 * 256, dtype=torch.int16, device=DEV)
+    _lib.call("rtk_pack_split_layer", 256, 256, w.data_ptr(), img.data_ptr(), F._stream())
+    assert torch.equal(img, F.pack_layer_split(w))
+    with pytest.raises(_lib.RtkError):
+        _lib.call("rtk_pack_split_layer", 250, 256, w.data_ptr(), img.data_ptr(), F._stream())
+
+
+@pytest.mark.parametrize("positions", [1, 77, 128, 5000])
+def test_split_layers_carry_fp32_accuracy(positions):
+    """Two 256x256 layers on the bf16 matrix pipe (six products of exact pieces) against float64: the error is that of an fp32
+    GEMM -- not of a bf16 one (2e-3) nor of a three-product split (3e-5)."""
+    from ratrack_amd import _lib
+    torch.manual_seed(positions)
+    W = [torch.randn(256, 256, device=DEV) / 16 for _ in range(2)]
+    b = [torch.randn(256, device=DEV) * 0.1 for _ in range(2)]
+    img = torch.cat([F.pack_layer_split(w) for w in W])
+    x = torch.randn(positions, 256, device=DEV) * 3
+    y = torch.full((positions, 256), float("nan"), device=DEV)
+    _lib.call("rtk_split_mlp2", positions, x.data_ptr(), img.data_ptr(), b[0].data_ptr(), b[1].data_ptr(), y.data_ptr(), F._stream())
+    lk = lambda t: torch.nn.functional.leaky_relu(t, 0.1)
+    r64 = lk(lk(x.double() @ W[0].double().T + b[0].double()) @ W[1].double().T + b[1].double())
+    r32 = lk(lk(x @ W[0].T + b[0]) @ W[1].T + b[1])
+    err = lambda t: float((t.double() - r64).abs().max() / r64.abs().max())
+    assert err(y) < 2e-6 and err(y) < 3 * err(r32) + 1e-7, (err(y), err(r32))
+
+
+def test_cost_volume_split_agrees_with_fp32_mfma_kernel():
+    """Both kernels on the same operands: samples not a multiple of 8 (plain 2-D grid), a point count that leaves the last
+    workgroup iteration partly empty, and rows beyond the last point untouched."""
+    net = _net()
+    eng = F.FusedBackbone(net)
+    B, N = 3, 243
+    torch.manual_seed(11)
+    x1, x2 = torch.randn(B, N, 3, device=DEV), torch.randn(B, N, 3, device=DEV)
+    p1, p2 = torch.randn(B * N, 256, device=DEV), torch.randn(B * N, 256, device=DEV)
+    k1 = PU.knn_point(16, x2, x1)
+    out = []
+    for split in (False, True):
+        eng.cv_split = split
+        o = torch.full((B * N + 4, 256), 7.0, device=DEV)
+        eng._cost_volume(B, N, x1, x2, k1, p1, p2, o)
+        assert torch.all(o[B * N:] == 7.0)
+        out.append(o[:B * N])
+    assert rel_err(out[1].cpu(), out[0].cpu()) < 5e-6
 
 
 @pytest.mark.parametrize("name", ["eval_b2_n256", "eval_b1_n242", "eval_b1_n1024", "eval_b1_n256_dups"])
