@@ -103,13 +103,14 @@ RTK_EXPORT int rtk_patch_cost(int samples, int n, const float *xyz, const int64_
  * accumulated in fp32.  The error is that of an fp32 fmaf chain (the dropped terms are below one fp32 rounding of the
  * product); the matrix time is 6/16 of the fp32-input MFMA's, the only exact-fp32 matrix instruction of gfx950.
  *
- * rtk_pack_split_layer: w (cout, cin) row-major fp32, both multiples of 32 -> image of cin/16 * cout/32 * 3 fragments
+ * rtk_pack_split_layer: w (cout, cin) row-major fp32 (transposed != 0: the layer is w^T, w stored (cin, cout) row-major -- the
+ * backward's W^T products from the forward's weights), both multiples of 32 -> image of cin/16 * cout/32 * 3 fragments
  * of 1 KiB (6 * cout * cin bytes), fragment (s, v, p) = piece p of rows 32 v .. +31 against the 16 input channels of k-step s
  * in the lane order of v_mfma_f32_32x32x16_bf16.
  * rtk_split_mlp2: y = leaky(W2 leaky(W1 x + b1) + b2), LeakyReLU(0.1), x / y (positions, 256) point-major; images = the split
  * images of W1 and W2 back to back.  The inner layers of the cost volume (utils/model_utils/model_utils.py:216-236) as a
  * standalone operator: what tests and tools time the matrix path with. */
-RTK_EXPORT int rtk_pack_split_layer(int cout, int cin, const float *w, void *image, rtk_stream_t stream);
+RTK_EXPORT int rtk_pack_split_layer(int cout, int cin, const float *w, int transposed, void *image, rtk_stream_t stream);
 /* rtk_cost_volume with its two 256 x 256 layers on the split path: same arguments, the layers as their split images (W2, W3
  * back to back, 2 * 393216 bytes) and fp32 biases instead of the packed rtk_layer_t pair. */
 RTK_EXPORT int rtk_cost_volume_split(int samples, int n1, int n2, const float *xyz1, const float *xyz2,

@@ -13,12 +13,19 @@ namespace {
 #endif
 
 // ---- packing: (256 x 256) row-major fp32 weights -> split image (split_mfma.h) ---------------------------------------------
-__global__ __launch_bounds__(256) void pack_split_kernel(int cout, int cin, const float *__restrict__ w, u4v *__restrict__ out) {
+__global__ __launch_bounds__(256) void pack_split_kernel(int cout, int cin, const float *__restrict__ w, int transposed, u4v *__restrict__ out) {
     const int VB = cout / 32, slot = blockIdx.x * 256 + threadIdx.x;      // slot = (s, v, lane)
     if (slot >= (cin / 16) * VB * 64) return;
     const int lane = slot & 63, v = (slot >> 6) % VB, s = (slot >> 6) / VB, hh = lane >> 5, i = lane & 31;
-    const float *row = w + (size_t)(32 * v + i) * cin + 32 * (s >> 1) + 16 * (s & 1) + 4 * hh;
-    const f4 x0 = *reinterpret_cast<const f4 *>(row), x1 = *reinterpret_cast<const f4 *>(row + 8);
+    const int o = 32 * v + i, c0 = 32 * (s >> 1) + 16 * (s & 1) + 4 * hh;      // this slot: W[o][c0 .. c0 + 3], W[o][c0 + 8 .. c0 + 11]
+    f4 x0, x1;
+    if (transposed) {                                                          // W = w^T, w (cin, cout) row-major
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { x0[r] = w[(size_t)(c0 + r) * cout + o]; x1[r] = w[(size_t)(c0 + 8 + r) * cout + o]; }
+    } else {
+        const float *row = w + (size_t)o * cin + c0;
+        x0 = *reinterpret_cast<const f4 *>(row); x1 = *reinterpret_cast<const f4 *>(row + 8);
+    }
     u4v b[3];
     split3(x0, x1, b);
 #pragma unroll
@@ -97,6 +104,14 @@ void split_mlp2_kernel(int positions, const float *__restrict__ x, const f4 *__r
 // the 32x32 tile), a workgroup (one wave per SIMD) eight points per iteration.  Layer 1 (K = 3) and the WeightNet's last
 // layer (K = 8) stay on the fp32-input MFMA (v_mfma_f32_32x32x2_f32, same C/D layout); the two 256 x 256 layers -- 99 % of the
 // flops -- run split.
+__device__ __forceinline__ f16v mfma_f32x2(float a, float b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+struct WnSplit {                  // WeightNet images as packed for the 16x16 kernels (fused_group.hip)
+    const float *wa;              // [Wa | ba]: Wa[o][k] = wa[16 k + o], ba[o] = wa[48 + o]
+    const float *wb, *wc;         // Wb[o][c] = wb[(16 (c / 4) + o) 4 + c % 4];  Wc[ch][k] = wc[((ch / 16) 64 + 16 (k / 4) + ch % 16) 4 + k % 4]
+    const float *bb, *bc;
+};
+
 struct CvSplitParams {
     int samples, n1, n2, gx;
     const float *xyz1, *xyz2;
@@ -105,16 +120,73 @@ struct CvSplitParams {
     const float *wd;              // [16][64] image of [Wd | 0] (fused_common.h): Wd[c][k] = wd[(c / 16) * 64 + 16 k + c % 16]
     const f4 *blob;               // split images of layers 2, 3
     const float *bias2, *bias3;
-    const float *wa, *wb, *wc;    // WeightNet images as packed for the 16x16 kernels: [Wa | ba], Wb (one fragment), Wc (16 fragments)
-    const float *bb, *bc;
+    WnSplit wn;
     float *out;
     int out_pitch;
+    float *sv1, *sv2, *sv3;       // training forward (SAVE): the three activations (positions, 256) ...
+    uint2 *mk1, *mk2;             // ... and the sign masks of a1, a2 in the format of cost_volume_kernel<true> (fused_group.hip): word
+                                  // (position, g), bit 4 v16 + r = [a[channel 16 v16 + 4 g + r] > 0]
 };
 
-__device__ __forceinline__ f16v mfma_f32x2(float a, float b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+// This lane's channels 32 v + 8 q + 4 hh + r are the 16-wide kernels' (v16 = 2 v + q / 2, g = 2 (q % 2) + hh, r): it owns the two
+// complete mask words g = hh (q even) and g = 2 + hh (q odd) of its position.
+__device__ __forceinline__ void split_sign_masks(const f4 (&a)[32], uint2 (&m)[2]) {
+    m[0] = m[1] = make_uint2(0u, 0u);
+#pragma unroll
+    for (int v = 0; v < SPLIT_VB; ++v)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned bit = (a[4 * v + q][r] > 0.f ? 1u : 0u) << (4 * ((2 * v + (q >> 1)) & 7) + r);
+                if (v < 4) m[q & 1].x |= bit; else m[q & 1].y |= bit;
+            }
+}
+__device__ __forceinline__ unsigned split_mask_bits(const uint2 (&m)[2], int v, int q) {      // [z > 0] of (v, q, r = 0..3) in the low four bits
+    return ((v < 4 ? m[q & 1].x : m[q & 1].y) >> (4 * ((2 * v + (q >> 1)) & 7))) & 15u;
+}
+
+__device__ __forceinline__ f4 *cv_at(float *base, unsigned byte_off) { return reinterpret_cast<f4 *>(reinterpret_cast<char *>(base) + byte_off); }
+__device__ __forceinline__ const f4 *cv_at(const float *base, unsigned byte_off) {
+    return reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
+// WeightNet hidden layers (3 -> 8 -> 8, ReLU) of this lane's position: uniform weights, every lane its own direction
+__device__ __forceinline__ void wn_hidden(const WnSplit &W, float dx, float dy, float dz, float (&t2)[8]) {
+    float t1[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        float a = __fmaf_rn(W.wa[o], dx, 0.f);
+        a = __fmaf_rn(W.wa[16 + o], dy, a);
+        a = __fmaf_rn(W.wa[32 + o], dz, a);
+        t1[o] = fmaxf(__fadd_rn(a, W.wa[48 + o]), 0.f);
+    }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        float a = W.bb[o];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a = __fmaf_rn(W.wb[(16 * (c >> 2) + o) * 4 + (c & 3)], t1[c], a);
+        t2[o] = fmaxf(a, 0.f);
+    }
+}
+// relu(Wc.t2 + bc) for the 32-channel block v in the tile layout (K = 8 on the fp32-input MFMA: four k-steps of two)
+__device__ __forceinline__ f16v wn_out(const WnSplit &W, int v, int hh, int col, const float (&t2)[8]) {
+    f16v w = split_bias(W.bc, v, hh);
+    const int ch = 32 * v + col;                                         // A[i = col][k = hh]
+    const float *wr = W.wc + ((ch >> 4) * 64 + (ch & 15)) * 4;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const int k = 2 * st + hh;
+        w = mfma_f32x2(wr[64 * (k >> 2) + (k & 3)], hh ? t2[2 * st + 1] : t2[2 * st], w);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) w[e] = fmaxf(w[e], 0.f);
+    return w;
+}
 
 __device__ __forceinline__ f4 leaky4(f4 t) { return (f4){fmaxf(t.x, 0.1f * t.x), fmaxf(t.y, 0.1f * t.y), fmaxf(t.z, 0.1f * t.z), fmaxf(t.w, 0.1f * t.w)}; }
 
+template <bool SAVE>
 __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1))) void cost_volume_split_kernel(const CvSplitParams P) {
     __shared__ __attribute__((aligned(16))) f4 s_w[2 * SP_F * 64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hh = lane >> 5, col = lane & 31, pp = col >> 4,
@@ -154,54 +226,54 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
                 for (int q = 0; q < 4; ++q) h[4 * v + q] = leaky4((f4){c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]});
             }
         }
+        // byte offset of this lane's first 16-byte slot in a (position, 256) row (one 32-bit VGPR on uniform base pointers)
+        const long pos = i * 16 + j;
+        const unsigned ro = (unsigned)pos * 1024u + 16u * hh;
+        if (SAVE && valid) {
+            uint2 m[2];
+            split_sign_masks(h, m);
+            P.mk1[pos * 4 + hh] = m[0];
+            P.mk1[pos * 4 + 2 + hh] = m[1];
+        }
         f16v acc[SPLIT_VB];
 #pragma unroll
         for (int v = 0; v < SPLIT_VB; ++v) acc[v] = split_bias(P.bias2, v, hh);
-        split_layer<0>(ws, h, acc);
+        if (SAVE) split_layer<0>(ws, h, acc, StoreRowsSide{P.sv1, ro, valid});      // a1 goes out while it is being consumed
+        else split_layer<0>(ws, h, acc);
 #pragma unroll
         for (int v = 0; v < SPLIT_VB; ++v)
 #pragma unroll
             for (int q = 0; q < 4; ++q) h[4 * v + q] = leaky4((f4){acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]});
+        if (SAVE && valid) {
+            uint2 m[2];
+            split_sign_masks(h, m);
+            P.mk2[pos * 4 + hh] = m[0];
+            P.mk2[pos * 4 + 2 + hh] = m[1];
+        }
 #pragma unroll
         for (int v = 0; v < SPLIT_VB; ++v) acc[v] = split_bias(P.bias3, v, hh);
-        split_layer<SPLIT_NF>(ws, h, acc);
+        if (SAVE) split_layer<SPLIT_NF>(ws, h, acc, StoreRowsSide{P.sv2, ro, valid});
+        else split_layer<SPLIT_NF>(ws, h, acc);
         ws.sync();                                                   // wrap the stream to chunk 0
-        // WeightNet hidden layers (3 -> 8 -> 8) of this lane's position: uniform weights, every lane its own direction
-        float t2[8];
-        {
-            float t1[8];
+        if (SAVE && valid) {
 #pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                float a = __fmaf_rn(P.wa[o], dx, 0.f);
-                a = __fmaf_rn(P.wa[16 + o], dy, a);
-                a = __fmaf_rn(P.wa[32 + o], dz, a);
-                t1[o] = fmaxf(__fadd_rn(a, P.wa[48 + o]), 0.f);
-            }
+            for (int v = 0; v < SPLIT_VB; ++v)
 #pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                float a = P.bb[o];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) a = __fmaf_rn(P.wb[(16 * (c >> 2) + o) * 4 + (c & 3)], t1[c], a);
-                t2[o] = fmaxf(a, 0.f);
-            }
+                for (int q = 0; q < 4; ++q)
+                    *cv_at(P.sv3, ro + 32u * (4 * v + q)) = leaky4((f4){acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]});
         }
+        float t2[8];
+        wn_hidden(P.wn, dx, dy, dz, t2);
         // out[i] = sum over the 16 neighbours of relu(Wc.t2 + bc) * a3, one 32-channel block at a time
         float *o = P.out + i * P.out_pitch + 4 * hh;
 #pragma unroll
         for (int v = 0; v < SPLIT_VB; ++v) {
-            f16v w = split_bias(P.bc, v, hh);
-            const int ch = 32 * v + col;
-            const float *wr = P.wc + ((ch >> 4) * 64 + (ch & 15)) * 4;      // Wc[ch][k] = wr[64 (k / 4) + k % 4]
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const int k = 2 * st + hh;
-                w = mfma_f32x2(wr[64 * (k >> 2) + (k & 3)], hh ? t2[2 * st + 1] : t2[2 * st], w);
-            }
+            const f16v w = wn_out(P.wn, v, hh, col, t2);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f4 r;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) r[e] = fmaxf(w[4 * q + e], 0.f) * fmaxf(acc[v][4 * q + e], 0.1f * acc[v][4 * q + e]);
+                for (int e = 0; e < 4; ++e) r[e] = w[4 * q + e] * fmaxf(acc[v][4 * q + e], 0.1f * acc[v][4 * q + e]);
                 row_sum16_f4(r);
                 if (valid && j == 0) *reinterpret_cast<f4 *>(o + 32 * v + 8 * q) = r;
             }
@@ -210,12 +282,143 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
     ws.finish();
 }
 
+// ---- rtk_cost_volume_bwd on the split path ------------------------------------------------------------------------------
+// Same outputs as cost_volume_bwd_kernel (fused_group.hip) from the same saved tensors; the tile of the split forward.  The two
+// transposed 256 x 256 products (W3^T dz3, W2^T dz2) run split; the WeightNet's hidden gradient dt2 = Wc^T dq3 (8 x 256 per
+// position) runs on the fp32-input MFMA against an LDS image of Wc^T built once per workgroup.
+struct CvSplitBwdParams {
+    CvSplitParams f;              // geometry, WeightNet, blob = split images of W3^T, W2^T
+    const float *dout;
+    int dout_pitch;
+    const float *a3;
+    const uint2 *mk1, *mk2;
+    float *dz1, *dz2, *dz3, *dq3, *d4, *dp1, *dpd, *dt2, *dbrows;
+};
+
+__device__ __forceinline__ f4 leaky_grad_bits4(f4 d, unsigned bits) {     // d * leaky'(z), [z > 0] in the low four bits
+    return (f4){(bits & 1u) ? d.x : 0.1f * d.x, (bits & 2u) ? d.y : 0.1f * d.y, (bits & 4u) ? d.z : 0.1f * d.z, (bits & 8u) ? d.w : 0.1f * d.w};
+}
+
+__global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1))) void cost_volume_bwd_split_kernel(const CvSplitBwdParams Q) {
+    __shared__ __attribute__((aligned(16))) f4 s_w[2 * SP_F * 64];
+    __shared__ float s_wct[128 * 64];                                    // [(v, q, r)][lane = 32 hh + o]: Wc[32 v + 8 q + 4 hh + r][o] (o < 8, else 0)
+    const CvSplitParams &P = Q.f;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hh = lane >> 5, col = lane & 31, pp = col >> 4,
+              j = col & 15;
+    for (int e = threadIdx.x; e < 128 * 64; e += 64 * SP_NW) {
+        const int l = e & 63, st = e >> 6, o = l & 31, ch = 32 * (st >> 4) + 8 * ((st >> 2) & 3) + 4 * (l >> 5) + (st & 3);
+        s_wct[e] = o < 8 ? P.wn.wc[((ch >> 4) * 64 + (o >> 2) * 16 + (ch & 15)) * 4 + (o & 3)] : 0.f;
+    }
+    int b, bx, nbx;
+    rtk_decode_block(P.gx, b, bx, nbx);
+    constexpr int PPW = 2 * SP_NW;
+    const int groups = (P.n1 + PPW - 1) / PPW;
+    WStreamA<SP_NW, SP_F, 2 * SPLIT_NF> ws;
+    ws.start_parts(P.blob, s_w, wave, lane);                             // (its barrier also publishes s_wct)
+    for (int G = bx; G < groups; G += nbx) {
+        asm volatile("" ::: "memory");
+        const int pt = G * PPW + 2 * wave + pp;
+        const bool valid = pt < P.n1;
+        const long i = (long)b * P.n1 + (valid ? pt : P.n1 - 1);
+        const long nb = (long)b * P.n2 + (long)P.knn[i * 16 + j];
+        const float dx = __fsub_rn(P.xyz2[nb * 3], P.xyz1[i * 3]), dy = __fsub_rn(P.xyz2[nb * 3 + 1], P.xyz1[i * 3 + 1]),
+                    dz = __fsub_rn(P.xyz2[nb * 3 + 2], P.xyz1[i * 3 + 2]);
+        const long pos = i * 16 + j;
+        const unsigned ro = (unsigned)pos * 1024u + 16u * hh;
+        if (valid && hh == 0) *reinterpret_cast<f4 *>(Q.d4 + pos * 4) = (f4){dx, dy, dz, 1.0f};
+        uint2 m2[2] = {Q.mk2[pos * 4 + hh], Q.mk2[pos * 4 + 2 + hh]}, m1[2] = {Q.mk1[pos * 4 + hh], Q.mk1[pos * 4 + 2 + hh]};
+        f4 h[32];
+#pragma unroll
+        for (int e = 0; e < 32; ++e) h[e] = *cv_at(Q.a3, ro + 32u * e);          // a3 = leaky(z3)
+        // ---- out = sum_k wn * a3:  dz3 = dout wn leaky'(z3),  dq3 = dout a3 [wn > 0],  dt2 = Wc^T dq3 -------------------------
+        float t2[8];
+        wn_hidden(P.wn, dx, dy, dz, t2);
+        const float *dor = Q.dout + i * Q.dout_pitch + 4 * hh;
+        f16v dt2;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dt2[e] = 0.f;
+#pragma unroll
+        for (int v = 0; v < SPLIT_VB; ++v) {
+            const f16v w = wn_out(P.wn, v, hh, col, t2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f4 d = *reinterpret_cast<const f4 *>(dor + 32 * v + 8 * q);
+                const f4 a = h[4 * v + q];
+                f4 qq, z;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float wv = w[4 * q + r];
+                    qq[r] = wv > 0.f ? d[r] * a[r] : 0.f;
+                    const float t = d[r] * wv;
+                    z[r] = a[r] > 0.f ? t : 0.1f * t;
+                    dt2 = mfma_f32x2(s_wct[(16 * v + 4 * q + r) * 64 + lane], qq[r], dt2);
+                }
+                h[4 * v + q] = z;
+                if (valid) *cv_at(Q.dq3, ro + 32u * (4 * v + q)) = qq;       // (dz3 goes out during the product that consumes it)
+                if (Q.dbrows) {                      // (uniform) per-query neighbour sum: the host's bias sum shrinks 16x
+                    f4 r = z;
+                    row_sum16_f4(r);
+                    if (valid && j == 0) *reinterpret_cast<f4 *>(Q.dbrows + i * 512 + 32 * v + 8 * q + 4 * hh) = r;
+                }
+            }
+        }
+        if (valid) *reinterpret_cast<f4 *>(Q.dt2 + pos * 8 + 4 * hh) = (f4){dt2[0], dt2[1], dt2[2], dt2[3]};      // rows 4 hh .. + 3 of the 8 hidden units
+        // ---- da2 = W3^T dz3;  dz2 = da2 leaky'(z2) ----------------------------------------------------------------------------
+        f16v acc[SPLIT_VB];
+#pragma unroll
+        for (int v = 0; v < SPLIT_VB; ++v)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[v][e] = 0.f;
+        split_layer<0>(ws, h, acc, StoreRowsSide{Q.dz3, ro, valid});
+#pragma unroll
+        for (int v = 0; v < SPLIT_VB; ++v)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f4 z = leaky_grad_bits4((f4){acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]}, split_mask_bits(m2, v, q));
+                h[4 * v + q] = z;
+                if (Q.dbrows) {
+                    f4 r = z;
+                    row_sum16_f4(r);
+                    if (valid && j == 0) *reinterpret_cast<f4 *>(Q.dbrows + i * 512 + 256 + 32 * v + 8 * q + 4 * hh) = r;
+                }
+            }
+        // ---- da1 = W2^T dz2;  dz1 = da1 leaky'(z1);  dp1 = sum over the 16 neighbours; per-query partials of dWd = dz1^T d -----
+#pragma unroll
+        for (int v = 0; v < SPLIT_VB; ++v)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[v][e] = 0.f;
+        split_layer<SPLIT_NF>(ws, h, acc, StoreRowsSide{Q.dz2, ro, valid});
+        ws.sync();                                                   // wrap the stream to chunk 0
+        float *dpr = Q.dp1 + i * 256 + 4 * hh;
+        float *dpd = Q.dpd + i * 768 + 4 * hh;
+#pragma unroll
+        for (int v = 0; v < SPLIT_VB; ++v)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f4 r = leaky_grad_bits4((f4){acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]}, split_mask_bits(m1, v, q));
+                if (valid) *cv_at(Q.dz1, ro + 32u * (4 * v + q)) = r;
+                f4 rx = r * dx, ry = r * dy, rz = r * dz;
+                row_sum16_f4(r);
+                row_sum16_f4(rx);
+                row_sum16_f4(ry);
+                row_sum16_f4(rz);
+                if (valid && j == 0) {
+                    *reinterpret_cast<f4 *>(dpr + 32 * v + 8 * q) = r;
+                    *reinterpret_cast<f4 *>(dpd + 32 * v + 8 * q) = rx;
+                    *reinterpret_cast<f4 *>(dpd + 256 + 32 * v + 8 * q) = ry;
+                    *reinterpret_cast<f4 *>(dpd + 512 + 32 * v + 8 * q) = rz;
+                }
+            }
+    }
+    ws.finish();
+}
+
 }  // namespace
 
-extern "C" int rtk_pack_split_layer(int cout, int cin, const float *w, void *image, rtk_stream_t stream) {
+extern "C" int rtk_pack_split_layer(int cout, int cin, const float *w, int transposed, void *image, rtk_stream_t stream) {
     RTK_REQUIRE(cout > 0 && cin > 0 && cout % 32 == 0 && cin % 32 == 0 && w && image, "pack_split_layer: bad arguments");
     const int slots = (cin / 16) * (cout / 32) * 64;
-    pack_split_kernel<<<(slots + 255) / 256, 256, 0, (hipStream_t)stream>>>(cout, cin, w, (u4v *)image);
+    pack_split_kernel<<<(slots + 255) / 256, 256, 0, (hipStream_t)stream>>>(cout, cin, w, transposed, (u4v *)image);
     RTK_CHECK_LAUNCH("pack_split_layer");
     return RTK_OK;
 }
@@ -229,28 +432,78 @@ extern "C" int rtk_split_mlp2(int positions, const float *x, const void *images,
     return RTK_OK;
 }
 
-extern "C" int rtk_cost_volume_split(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
-                                     const float *p1, const float *p2, const float *wd_packed, const void *split_images,
-                                     const float *bias2, const float *bias3, const rtk_layer_t *wn, float *out, int out_pitch,
-                                     rtk_stream_t stream) {
-    RTK_REQUIRE(samples > 0 && samples <= 65535 && n1 > 0 && n2 >= 16 && xyz1 && xyz2 && knn_idx && p1 && p2 && wd_packed && split_images &&
-                bias2 && bias3 && out, "cost_volume_split: bad arguments");
-    RTK_REQUIRE(out_pitch % 4 == 0 && out_pitch >= 256, "cost_volume_split: bad out_pitch");
+static int cv_split_fill(const char *who, CvSplitParams &P, int samples, int n1, int n2, const float *xyz1, const float *xyz2,
+                         const int64_t *knn_idx, const void *split_images, const rtk_layer_t *wn, dim3 &grid) {
+    RTK_REQUIRE(samples > 0 && samples <= 65535 && n1 > 0 && n2 >= 16 && xyz1 && xyz2 && knn_idx && split_images, "%s: bad arguments", who);
     RTK_REQUIRE(wn && wn[0].w_packed && wn[1].w_packed && wn[2].w_packed && wn[1].bias && wn[2].bias && wn[1].cin16 == 1 &&
-                wn[1].cout16 == 1 && wn[2].cin16 == 1 && wn[2].cout16 == 16, "cost_volume_split: bad WeightNet layers");
-    CvSplitParams P;
+                wn[1].cout16 == 1 && wn[2].cin16 == 1 && wn[2].cout16 == 16, "%s: bad WeightNet layers", who);
     P.samples = samples; P.n1 = n1; P.n2 = n2;
-    P.xyz1 = xyz1; P.xyz2 = xyz2; P.knn = knn_idx; P.p1 = p1; P.p2 = p2; P.wd = wd_packed;
-    P.blob = reinterpret_cast<const f4 *>(split_images); P.bias2 = bias2; P.bias3 = bias3;
-    P.wa = wn[0].w_packed; P.wb = wn[1].w_packed; P.wc = wn[2].w_packed; P.bb = wn[1].bias; P.bc = wn[2].bias;
-    P.out = out; P.out_pitch = out_pitch;
+    P.xyz1 = xyz1; P.xyz2 = xyz2; P.knn = knn_idx;
+    P.blob = reinterpret_cast<const f4 *>(split_images);
+    P.wn.wa = wn[0].w_packed; P.wn.wb = wn[1].w_packed; P.wn.wc = wn[2].w_packed; P.wn.bb = wn[1].bias; P.wn.bc = wn[2].bias;
+    P.p1 = P.p2 = P.wd = P.bias2 = P.bias3 = nullptr;
+    P.out = nullptr; P.out_pitch = 0; P.sv1 = P.sv2 = P.sv3 = nullptr; P.mk1 = P.mk2 = nullptr;
     const int groups = (n1 + 2 * SP_NW - 1) / (2 * SP_NW);
     int gx = 256 / samples;                           // one workgroup per CU (the tile keeps the whole register file); the rest is looped
     if (gx < 1) gx = 1;
     if (gx > groups) gx = groups;
     P.gx = samples % 8 == 0 ? gx : 0;
-    const dim3 grid = P.gx ? dim3(gx * samples) : dim3(gx, samples);
-    cost_volume_split_kernel<<<grid, 64 * SP_NW, 0, (hipStream_t)stream>>>(P);
-    RTK_CHECK_LAUNCH("cost_volume_split");
+    grid = P.gx ? dim3(gx * samples) : dim3(gx, samples);
+    return RTK_OK;
+}
+
+static int cv_split_forward(const char *who, int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
+                            const float *p1, const float *p2, const float *wd_packed, const void *split_images, const float *bias2,
+                            const float *bias3, const rtk_layer_t *wn, float *out, int out_pitch, float *a1, float *a2, float *a3,
+                            void *mask1, void *mask2, rtk_stream_t stream) {
+    CvSplitParams P;
+    dim3 grid;
+    if (cv_split_fill(who, P, samples, n1, n2, xyz1, xyz2, knn_idx, split_images, wn, grid) != RTK_OK) return RTK_ERR_INVALID;
+    RTK_REQUIRE(p1 && p2 && wd_packed && bias2 && bias3 && out, "%s: bad arguments", who);
+    RTK_REQUIRE(out_pitch % 4 == 0 && out_pitch >= 256, "%s: bad out_pitch", who);
+    const bool save = a1 != nullptr;
+    RTK_REQUIRE(!save || ((double)samples * n1 * 16.0 * 1024.0 < 4294967296.0), "%s: more than 4 GiB per saved activation (32-bit row "
+                "offsets): split the batch", who);
+    P.p1 = p1; P.p2 = p2; P.wd = wd_packed; P.bias2 = bias2; P.bias3 = bias3; P.out = out; P.out_pitch = out_pitch;
+    P.sv1 = a1; P.sv2 = a2; P.sv3 = a3; P.mk1 = (uint2 *)mask1; P.mk2 = (uint2 *)mask2;
+    if (save) cost_volume_split_kernel<true><<<grid, 64 * SP_NW, 0, (hipStream_t)stream>>>(P);
+    else cost_volume_split_kernel<false><<<grid, 64 * SP_NW, 0, (hipStream_t)stream>>>(P);
+    RTK_CHECK_LAUNCH(who);
+    return RTK_OK;
+}
+
+extern "C" int rtk_cost_volume_split(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
+                                     const float *p1, const float *p2, const float *wd_packed, const void *split_images,
+                                     const float *bias2, const float *bias3, const rtk_layer_t *wn, float *out, int out_pitch,
+                                     rtk_stream_t stream) {
+    return cv_split_forward("cost_volume_split", samples, n1, n2, xyz1, xyz2, knn_idx, p1, p2, wd_packed, split_images, bias2, bias3, wn, out,
+                            out_pitch, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int rtk_cost_volume_split_train(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
+                                           const float *p1, const float *p2, const float *wd_packed, const void *split_images,
+                                           const float *bias2, const float *bias3, const rtk_layer_t *wn, float *out, int out_pitch,
+                                           float *a1, float *a2, float *a3, void *mask1, void *mask2, rtk_stream_t stream) {
+    RTK_REQUIRE(a1 && a2 && a3 && mask1 && mask2, "cost_volume_split_train: null activation buffer");
+    return cv_split_forward("cost_volume_split_train", samples, n1, n2, xyz1, xyz2, knn_idx, p1, p2, wd_packed, split_images, bias2, bias3,
+                            wn, out, out_pitch, a1, a2, a3, mask1, mask2, stream);
+}
+
+extern "C" int rtk_cost_volume_bwd_split(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
+                                         const void *split_images_t, const rtk_layer_t *wn, const float *dout, int dout_pitch,
+                                         const float *a3, const void *mask1, const void *mask2, float *dz1, float *dz2, float *dz3,
+                                         float *dq3, float *d4, float *dp1, float *dpd, float *dt2, float *dbias_rows,
+                                         rtk_stream_t stream) {
+    CvSplitBwdParams Q;
+    dim3 grid;
+    if (cv_split_fill("cost_volume_bwd_split", Q.f, samples, n1, n2, xyz1, xyz2, knn_idx, split_images_t, wn, grid) != RTK_OK) return RTK_ERR_INVALID;
+    RTK_REQUIRE(dout && mask1 && mask2 && a3 && dz1 && dz2 && dz3 && dq3 && d4 && dp1 && dpd && dt2, "cost_volume_bwd_split: bad arguments");
+    RTK_REQUIRE((double)samples * n1 * 16.0 * 1024.0 < 4294967296.0, "cost_volume_bwd_split: more than 4 GiB per (position, 256) tensor "
+                "(32-bit row offsets): split the batch");
+    RTK_REQUIRE(dout_pitch % 4 == 0 && dout_pitch >= 256, "cost_volume_bwd_split: bad dout_pitch");
+    Q.dout = dout; Q.dout_pitch = dout_pitch; Q.a3 = a3; Q.mk1 = (const uint2 *)mask1; Q.mk2 = (const uint2 *)mask2;
+    Q.dz1 = dz1; Q.dz2 = dz2; Q.dz3 = dz3; Q.dq3 = dq3; Q.d4 = d4; Q.dp1 = dp1; Q.dpd = dpd; Q.dt2 = dt2; Q.dbrows = dbias_rows;
+    cost_volume_bwd_split_kernel<<<grid, 64 * SP_NW, 0, (hipStream_t)stream>>>(Q);
+    RTK_CHECK_LAUNCH("cost_volume_bwd_split");
     return RTK_OK;
 }

@@ -154,6 +154,27 @@ __device__ __forceinline__ void lds_wait(f4 (&c)[6]) {      // the six fragments
 // One group step: the six fragments of two output blocks (three pieces each) against the three B pieces of the k-step: twelve
 // MFMAs, the two blocks interleaved so that consecutive MFMAs never wait for each other's accumulator; small terms first.
 // The fragments of the next group (and, once per k-step, the B pieces of the next k-step) are fetched/split meanwhile.
+// Side job of a layer: called once per group step with the layer's INPUT activations.  The kernels that must also write those
+// activations to memory (saved activations of the training forward, dz of the backward) store one 16-byte slot every other group
+// step instead of 32 in a burst before the layer: the stream's chunk boundaries wait with vmcnt(0) -- loads and stores share the
+// counter and return out of order with respect to each other -- so a burst of stores ahead of a layer stalls its first boundary
+// until the whole burst has reached L2, with nothing else to run on the SIMD.
+struct NoSide {
+    template <int GI>
+    __device__ __forceinline__ void at(const f4 (&)[32]) const {}
+};
+struct StoreRowsSide {            // h[e] -> 16 bytes at base + ro + 32 e  (this lane's slots of a (position, 256) row)
+    float *base;
+    unsigned ro;
+    bool valid;
+    template <int GI>
+    __device__ __forceinline__ void at(const f4 (&h)[32]) const {
+        if constexpr ((GI & 1) == 0) {
+            if (valid) *reinterpret_cast<f4 *>(reinterpret_cast<char *>(base) + (ro + 32u * (GI / 2))) = h[GI / 2];
+        }
+    }
+};
+
 template <int FBASE, int GI, class WS, int F>
 struct SplitStep {
     static constexpr int NG = SPLIT_KS * (SPLIT_VB / 2);
@@ -171,7 +192,8 @@ struct SplitStep {
         dst[4] = ws.template frag_async<(f0 + 4) % F>();
         dst[5] = ws.template frag_async<(f0 + 5) % F>();
     }
-    static __device__ __forceinline__ void run(WS &ws, const f4 (&h)[32], f16v (&acc)[SPLIT_VB], f4 (&a)[2][6], u4v (&b)[2][3]) {
+    template <class Side>
+    static __device__ __forceinline__ void run(WS &ws, const f4 (&h)[32], f16v (&acc)[SPLIT_VB], f4 (&a)[2][6], u4v (&b)[2][3], const Side &side) {
         constexpr int s = GI / 4, v0 = (GI % 4) * 2;
         static_assert(F % 6 == 0, "a group step reads six consecutive fragments of one chunk");
         if constexpr (GI + 1 < NG) {
@@ -192,25 +214,26 @@ struct SplitStep {
         acc[v0 + 1] = mfma_bf(__builtin_bit_cast(u4v, c[3 + pa]), B[pb], acc[v0 + 1]);
         RTK_SPLIT_MM(2, 0) RTK_SPLIT_MM(0, 2) RTK_SPLIT_MM(1, 1) RTK_SPLIT_MM(1, 0) RTK_SPLIT_MM(0, 1) RTK_SPLIT_MM(0, 0)
 #undef RTK_SPLIT_MM
+        side.template at<GI>(h);
         __builtin_amdgcn_sched_barrier(0);
     }
 };
 
-template <int FBASE, class WS, int F, int... GI>
-__device__ __forceinline__ void split_layer_impl(WS &ws, const f4 (&h)[32], f16v (&acc)[SPLIT_VB], std::integer_sequence<int, GI...>) {
+template <int FBASE, class WS, int F, class Side, int... GI>
+__device__ __forceinline__ void split_layer_impl(WS &ws, const f4 (&h)[32], f16v (&acc)[SPLIT_VB], const Side &side, std::integer_sequence<int, GI...>) {
     f4 a[2][6];
     u4v b[2][3];
     SplitStep<FBASE, 0, WS, F>::template load<0>(ws, a[0]);
     split3(h[0], h[1], b[0]);
     __builtin_amdgcn_sched_barrier(0);
-    (SplitStep<FBASE, GI, WS, F>::run(ws, h, acc, a, b), ...);
+    (SplitStep<FBASE, GI, WS, F>::run(ws, h, acc, a, b, side), ...);
 }
 
 // acc += W . h for a 256 x 256 layer whose split image starts at fragment FBASE of the stream.  All waves of the workgroup call
 // this together (the stream has barriers).
-template <int FBASE, int NW, int F, int NF>
-__device__ __forceinline__ void split_layer(WStreamA<NW, F, NF> &ws, const f4 (&h)[32], f16v (&acc)[SPLIT_VB]) {
-    split_layer_impl<FBASE, WStreamA<NW, F, NF>, F>(ws, h, acc, std::make_integer_sequence<int, SPLIT_KS * (SPLIT_VB / 2)>{});
+template <int FBASE, int NW, int F, int NF, class Side = NoSide>
+__device__ __forceinline__ void split_layer(WStreamA<NW, F, NF> &ws, const f4 (&h)[32], f16v (&acc)[SPLIT_VB], const Side &side = Side()) {
+    split_layer_impl<FBASE, WStreamA<NW, F, NF>, F, Side>(ws, h, acc, side, std::make_integer_sequence<int, SPLIT_KS * (SPLIT_VB / 2)>{});
 }
 
 // this lane's bias for output block v: channels 32 v + 8 q + 4 hh + r

@@ -44,7 +44,7 @@ _lib.SIGNATURES.update({
     "rtk_sa_scale": [_ci] * 4 + [_vp] * 4 + [_ci, _ci, _vp, _ci, ctypes.POINTER(_Layer), _vp, _ci, _ci, _vp, _vp, _vp],
     "rtk_cost_volume": [_ci] * 3 + [_vp] * 6 + [ctypes.POINTER(_Layer), ctypes.POINTER(_Layer), _vp, _ci, _vp],
     "rtk_patch_cost": [_ci] * 2 + [_vp] * 3 + [_ci, ctypes.POINTER(_Layer), _vp, _ci, _ci, _vp],
-    "rtk_pack_split_layer": [_ci, _ci, _vp, _vp, _vp],
+    "rtk_pack_split_layer": [_ci, _ci, _vp, _ci, _vp, _vp],
     "rtk_cost_volume_split": [_ci] * 3 + [_vp] * 9 + [ctypes.POINTER(_Layer), _vp, _ci, _vp],
     "rtk_split_mlp2": [_ci, _vp, _vp, _vp, _vp, _vp, _vp],
     "rtk_prepare_inputs": [_ci] * 2 + [_vp] * 6 + [_vp],
@@ -573,7 +573,7 @@ class FusedBackbone:
         self.cv_bias23 = torch.stack([sd["fc_layer.mlp_convs.%d.bias" % i].double().float() for i in (1, 2)]).to(dev).contiguous()
         self.cv_images = torch.empty(2 * 3 * 256 * 256, dtype=torch.int16, device=dev)
         for l, w in enumerate(w23):
-            _lib.call("rtk_pack_split_layer", 256, 256, w.data_ptr(), self.cv_images[l * 3 * 256 * 256:].data_ptr(), _stream())
+            _lib.call("rtk_pack_split_layer", 256, 256, w.data_ptr(), 0, self.cv_images[l * 3 * 256 * 256:].data_ptr(), _stream())
         torch.cuda.current_stream().synchronize()      # w23 may go
         self.wn1 = _WeightNet(sd, "fc_layer.weightnet1", dev)
         self.wn2 = _WeightNet(sd, "fc_layer.weightnet2", dev)

@@ -16,6 +16,9 @@ _LayerP = ctypes.POINTER(fused._Layer)
 _lib.SIGNATURES.update({
     "rtk_cost_volume_train": [_i] * 3 + [_p] * 6 + [_LayerP, _LayerP, _p, _i, _p, _p, _p, _p, _p, _p],
     "rtk_cost_volume_bwd": [_i] * 3 + [_p] * 3 + [_LayerP, _LayerP, _p, _p, _i] + [_p] * 12 + [_p],
+    "rtk_cost_volume_split_train": [_i] * 3 + [_p] * 9 + [_LayerP, _p, _i, _p, _p, _p, _p, _p, _p],
+    "rtk_cost_volume_bwd_split": [_i] * 3 + [_p] * 4 + [_LayerP, _p, _i] + [_p] * 12 + [_p],
+    "rtk_pack_split_layer": [_i, _i, _p, _i, _p, _p],
     "rtk_scatter_add_rows": [_i] * 4 + [_p] * 3 + [_p],
     "rtk_sa_first_layer": [_i] * 6 + [_p] * 4 + [_i] + [_p] * 3 + [_p],
     "rtk_group_inverse_index": [_i] * 3 + [_p] * 3 + [_p],
@@ -563,6 +566,11 @@ def _pack_weights(specs, device):
     return outs, (ws, keep)
 
 
+# the cost volume's 256 x 256 products on the split-bf16 matrix path (csrc/split_mfma.h); RTK_CV_SPLIT=0: fp32-input MFMA kernels
+CV_SPLIT = os.environ.get("RTK_CV_SPLIT", "1") != "0"
+_SPLIT_IMAGE = 3 * 256 * 256          # int16 elements of one layer's split image
+
+
 class _CvWeights:
     """Packed kernel images of the live cost-volume weights (re-packed every step: the weights are being trained): the four 256x256
     layer images W2, W3, W3^T, W2^T, the offset image of Wd, the WeightNet's three layers and Wc^T -- one launch."""
@@ -571,12 +579,19 @@ class _CvWeights:
         dev = w2.device
         L = fused._Layer
         specs = [(0, w2, False, None), (0, w3, False, None)] + ([(0, w3, True, None), (0, w2, True, None)] if backward else [])
+        if CV_SPLIT:                              # split images instead: W2 | W3 | W3^T | W2^T (the transposes straight from w3, w2)
+            specs = []
+            self.split = torch.empty((4 if backward else 2) * _SPLIT_IMAGE, dtype=torch.int16, device=dev)
+            self._w = [w.detach().contiguous() for w in (w2, w3)]
+            for k, (w, t) in enumerate([(self._w[0], 0), (self._w[1], 0)] + ([(self._w[1], 1), (self._w[0], 1)] if backward else [])):
+                _lib.call("rtk_pack_split_layer", 256, 256, w.data_ptr(), t, self.split[k * _SPLIT_IMAGE:].data_ptr(), _stream())
         nm = len(specs)
         specs += [(2, b2, False, None), (2, b3, False, None), (1, wd, False, None), (1, wa, False, ba), (0, wb, False, None), (2, bb, False, None),
                   (0, wc, False, None), (2, bc, False, None), (0, wc, True, None)]
         outs, self._keep = _pack_weights(specs, dev)
-        self.blob = outs[0]                       # the layer images are contiguous in the workspace (blob = W2 | W3 | W3^T | W2^T)
+        self.blob = outs[0] if nm else None       # the layer images are contiguous in the workspace (blob = W2 | W3 | W3^T | W2^T)
         self.bias = outs[nm]                      # b2 | b3
+        self.b2, self.b3 = outs[nm], outs[nm + 1]
         self.layers = (L * nm)()
         for i in range(nm):
             self.layers[i].w_packed = outs[i].data_ptr()
@@ -588,7 +603,7 @@ class _CvWeights:
         wn[1].w_packed, wn[1].bias, wn[1].cin16, wn[1].cout16 = self.wb.data_ptr(), self.bb.data_ptr(), 1, 1
         wn[2].w_packed, wn[2].bias, wn[2].cin16, wn[2].cout16 = self.wc.data_ptr(), self.bc.data_ptr(), 1, 16
         self.wn = wn
-        if backward:
+        if backward and nm:
             self.layers_t = ctypes.cast(ctypes.byref(self.layers, 2 * ctypes.sizeof(L)), ctypes.POINTER(L))      # W3^T, W2^T
 
 
@@ -622,9 +637,14 @@ class _CostVolume(torch.autograd.Function):
         # weight-gradient GEMMs read the same tensors
         acts = torch.empty(3, B * n1 * 16, 256, dtype=torch.float32, device=p1.device)
         masks = torch.empty(2, B * n1 * 16, 4, dtype=torch.int64, device=p1.device)          # sign bits of a1, a2 (kernel lane order)
-        _lib.call("rtk_cost_volume_train", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
-                  W.wd.data_ptr(), W.layers, W.wn, out.data_ptr(), 256, acts[0].data_ptr(), acts[1].data_ptr(), acts[2].data_ptr(),
-                  masks[0].data_ptr(), masks[1].data_ptr(), _stream())
+        if CV_SPLIT:
+            _lib.call("rtk_cost_volume_split_train", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
+                      W.wd.data_ptr(), W.split.data_ptr(), W.b2.data_ptr(), W.b3.data_ptr(), W.wn, out.data_ptr(), 256, acts[0].data_ptr(),
+                      acts[1].data_ptr(), acts[2].data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), _stream())
+        else:
+            _lib.call("rtk_cost_volume_train", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
+                      W.wd.data_ptr(), W.layers, W.wn, out.data_ptr(), 256, acts[0].data_ptr(), acts[1].data_ptr(), acts[2].data_ptr(),
+                      masks[0].data_ptr(), masks[1].data_ptr(), _stream())
         ctx.save_for_backward(acts, masks, wa, ba, wb, bb, wc, xyz1, xyz2, knn)
         return out
 
@@ -645,9 +665,14 @@ class _CostVolume(torch.autograd.Function):
         dp1 = torch.empty(B * n1, 256, dtype=torch.float32, device=dev)
         dpd = torch.empty(B * n1, 3, 256, dtype=torch.float32, device=dev)
         dbr = torch.empty(B * n1, 512, dtype=torch.float32, device=dev)       # per-query neighbour sums of dz3 | dz2
-        _lib.call("rtk_cost_volume_bwd", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), W.layers_t, W.wn, W.wct.data_ptr(),
-                  dout.data_ptr(), 256, a3.data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), dz1.data_ptr(), dz2.data_ptr(), dz3.data_ptr(),
-                  dq3.data_ptr(), d4.data_ptr(), dp1.data_ptr(), dpd.data_ptr(), dt2.data_ptr(), dbr.data_ptr(), _stream())
+        if CV_SPLIT:
+            _lib.call("rtk_cost_volume_bwd_split", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), W.split[2 * _SPLIT_IMAGE:].data_ptr(),
+                      W.wn, dout.data_ptr(), 256, a3.data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), dz1.data_ptr(), dz2.data_ptr(),
+                      dz3.data_ptr(), dq3.data_ptr(), d4.data_ptr(), dp1.data_ptr(), dpd.data_ptr(), dt2.data_ptr(), dbr.data_ptr(), _stream())
+        else:
+            _lib.call("rtk_cost_volume_bwd", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), W.layers_t, W.wn, W.wct.data_ptr(),
+                      dout.data_ptr(), 256, a3.data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), dz1.data_ptr(), dz2.data_ptr(), dz3.data_ptr(),
+                      dq3.data_ptr(), d4.data_ptr(), dp1.data_ptr(), dpd.data_ptr(), dt2.data_ptr(), dbr.data_ptr(), _stream())
         dp2 = torch.empty(B * n2, 256, dtype=torch.float32, device=dev)
         _lib.call("rtk_scatter_add_rows", B, n1 * 16, n2, 256, knn.data_ptr(), dz1.data_ptr(), dp2.data_ptr(), _stream())
         # weight gradients: contractions over the M positions
@@ -696,6 +721,12 @@ def time_cost_volume_bwd(batch, n, dev, iters=10):
     st = _stream()
 
     def launch():
+        if CV_SPLIT:
+            _lib.call("rtk_cost_volume_bwd_split", B, n, n, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), W.split[2 * _SPLIT_IMAGE:].data_ptr(),
+                      W.wn, dout.data_ptr(), 256, acts[2].data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), big[0].data_ptr(),
+                      big[1].data_ptr(), big[2].data_ptr(), big[3].data_ptr(), d4.data_ptr(), dp1.data_ptr(), dpd.data_ptr(), dt2.data_ptr(),
+                      dbr.data_ptr(), st)
+            return
         _lib.call("rtk_cost_volume_bwd", B, n, n, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), W.layers_t, W.wn, W.wct.data_ptr(),
                   dout.data_ptr(), 256, acts[2].data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), big[0].data_ptr(), big[1].data_ptr(),
                   big[2].data_ptr(), big[3].data_ptr(), d4.data_ptr(), dp1.data_ptr(), dpd.data_ptr(), dt2.data_ptr(), dbr.data_ptr(), st)

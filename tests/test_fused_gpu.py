@@ -203,10 +203,10 @@ def test_split_images_are_exact_and_packed_as_documented():
     back = sum((pieces[i].to(torch.int32) << 16).view(torch.float32).double() for i in range(3))
     assert torch.equal(back.float(), w) and torch.equal(back, w.double())
     img = torch.empty(3 * 256 * 256, dtype=torch.int16, device=DEV)
-    _lib.call("rtk_pack_split_layer", 256, 256, w.data_ptr(), img.data_ptr(), F._stream())
+    _lib.call("rtk_pack_split_layer", 256, 256, w.data_ptr(), 0, img.data_ptr(), F._stream())
     assert torch.equal(img, F.pack_layer_split(w))
     with pytest.raises(_lib.RtkError):
-        _lib.call("rtk_pack_split_layer", 250, 256, w.data_ptr(), img.data_ptr(), F._stream())
+        _lib.call("rtk_pack_split_layer", 250, 256, w.data_ptr(), 0, img.data_ptr(), F._stream())
 
 
 @pytest.mark.parametrize("positions", [1, 77, 128, 5000])

@@ -16,7 +16,7 @@ from ratrack_amd import synth
 from ratrack_amd.track4d import Args, Track4D
 from ratrack_amd.train_ops import bn_relu
 
-from _util import reference_state_dict
+from _util import reference_state_dict, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -592,12 +592,15 @@ def test_fused_backbone_loss_matches_framework_formulation(B, N, pretrain, vec):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("split", [True, False])
 @pytest.mark.parametrize("B,N", [(2, 256), (3, 77)])
-def test_cost_volume_train_forward_keeps_what_the_backward_needs(B, N):
+def test_cost_volume_train_forward_keeps_what_the_backward_needs(B, N, split, monkeypatch):
     """rtk_cost_volume_train = rtk_cost_volume (bit for bit) + the three activations and the sign masks of the first two, in the
-    backward kernel's lane order: bit 4v + r of word (position, g) <-> channel 16v + 4g + r."""
+    backward kernel's lane order: bit 4v + r of word (position, g) <-> channel 16v + 4g + r.  The same for the split-bf16 pair
+    (rtk_cost_volume_split_train / rtk_cost_volume_split), which writes the same formats from a different tile."""
     from ratrack_amd import _lib, train_ops as T
     from ratrack_amd.model_utils import knn_point
+    monkeypatch.setattr(T, "CV_SPLIT", split)
     g = torch.Generator(DEV).manual_seed(4)
     r = lambda *s: torch.randn(*s, device=DEV, generator=g)
     d = synth.make_frame_pairs(B, N, 5)
@@ -612,10 +615,11 @@ def test_cost_volume_train_forward_keeps_what_the_backward_needs(B, N):
     out_a, out_b = torch.empty(B * N, 256, device=DEV), torch.empty(B * N, 256, device=DEV)
     acts = torch.full((3, M, 256), float("nan"), device=DEV)
     masks = torch.zeros(2, M, 4, dtype=torch.int64, device=DEV)
-    common = (B, N, N, x1.data_ptr(), x2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(), W.wd.data_ptr(), W.layers, W.wn)
-    _lib.call("rtk_cost_volume", *common, out_a.data_ptr(), 256, st)
-    _lib.call("rtk_cost_volume_train", *common, out_b.data_ptr(), 256, acts[0].data_ptr(), acts[1].data_ptr(), acts[2].data_ptr(),
-              masks[0].data_ptr(), masks[1].data_ptr(), st)
+    common = (B, N, N, x1.data_ptr(), x2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(), W.wd.data_ptr())
+    common += (W.split.data_ptr(), W.b2.data_ptr(), W.b3.data_ptr(), W.wn) if split else (W.layers, W.wn)
+    _lib.call("rtk_cost_volume_split" if split else "rtk_cost_volume", *common, out_a.data_ptr(), 256, st)
+    _lib.call("rtk_cost_volume_split_train" if split else "rtk_cost_volume_train", *common, out_b.data_ptr(), 256, acts[0].data_ptr(),
+              acts[1].data_ptr(), acts[2].data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), st)
     torch.cuda.synchronize()
     assert torch.equal(out_a, out_b)
     assert torch.isfinite(acts).all()
@@ -725,3 +729,43 @@ def test_three_interpolate_backward_gather_form(B, C, n, m):
     out = T.three_interpolate(feats, idx, w, (off, inv))
     out.backward(go)
     assert float((feats.grad.double() - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1.0)
+
+
+def test_cost_volume_split_train_and_backward_agree_with_fp32_mfma_kernels(monkeypatch):
+    """The split-bf16 kernels (csrc/fused_split.hip) and the fp32-input MFMA kernels (csrc/fused_group.hip) are two implementations
+    of the same operator pair with the same tensor formats: outputs, saved activations, sign masks and every gradient agree to
+    fp32 rounding (masks: except where an activation is a rounding error away from zero)."""
+    from ratrack_amd import train_ops as T
+    torch.manual_seed(5)
+    B, n = 3, 100                                     # 2-D grid (B % 8 != 0), last workgroup iteration partly empty
+    r = lambda *sh: torch.randn(*sh, device=DEV)
+    xyz1, xyz2 = r(B, n, 3), r(B, n, 3)
+    knn = torch.randint(0, n, (B, n, 16), device=DEV)
+    par = [r(256, 3) * 0.3, r(256, 256) * 0.06, r(256) * 0.1, r(256, 256) * 0.06, r(256) * 0.1, r(8, 3), r(8) * 0.1, r(8, 8) * 0.4, r(8) * 0.1,
+           r(256, 8) * 0.4, r(256) * 0.1]
+    p1, p2, dout = r(B * n, 256), r(B * n, 256), r(B * n, 256)
+    res = []
+    for split in (False, True):
+        monkeypatch.setattr(T, "CV_SPLIT", split)
+        leaves = [t.clone().requires_grad_(True) for t in [p1, p2] + par]
+        out = T.cost_volume(*leaves, xyz1, xyz2, knn)
+        acts, masks = out.grad_fn.saved_tensors[:2]
+        out.backward(dout)
+        res.append((out.detach(), acts.clone(), masks.clone(), [t.grad for t in leaves]))
+    (o0, a0, m0, g0), (o1, a1, m1, g1) = res
+    assert rel_err(o1.cpu(), o0.cpu()) < 5e-6
+    assert rel_err(a1.cpu(), a0.cpu()) < 5e-6
+    differing = (m0 ^ m1) != 0
+    assert differing.float().mean() < 1e-3            # a word differs only where some activation sits within rounding of zero
+    names = ["p1", "p2", "wd", "w2", "b2", "w3", "b3", "wa", "ba", "wb", "bb", "wc", "bc"]
+    for name, x, y in zip(names, g0, g1):
+        assert rel_err(y.cpu(), x.cpu()) < 2e-5, name
+
+
+def test_split_packer_transposed():
+    from ratrack_amd import _lib, fused as F
+    torch.manual_seed(2)
+    w = torch.randn(256, 256, device=DEV)
+    img = torch.empty(3 * 256 * 256, dtype=torch.int16, device=DEV)
+    _lib.call("rtk_pack_split_layer", 256, 256, w.data_ptr(), 1, img.data_ptr(), F._stream())
+    assert torch.equal(img, F.pack_layer_split(w.t().contiguous()))

@@ -12,7 +12,7 @@ b = [torch.randn(256, device=dev) * 0.1 for _ in range(2)]
 img = torch.empty(2 * 256 * 256 * 3, dtype=torch.int16, device=dev)
 st = lambda: torch.cuda.current_stream().cuda_stream
 for l in range(2):
-    _lib.call("rtk_pack_split_layer", 256, 256, W[l].data_ptr(), img[l * 196608:].data_ptr(), st())
+    _lib.call("rtk_pack_split_layer", 256, 256, W[l].data_ptr(), 0, img[l * 196608:].data_ptr(), st())
 ref_img = torch.cat([F.pack_layer_split(w) for w in W])
 print("device packer == host packer:", torch.equal(img, ref_img))
 for npos in (77, 128, 4096):
