@@ -51,6 +51,26 @@ HBM_PEAK_GBS = 8000.0
 PMC = {"forward": "r02_pmc_cost_volume.json", "train": "r02_pmc_cost_volume_bwd.json", "irregular": "r02_irregular_hbm.json"}
 
 
+def train_roofline(a, kms, kflops, ach, pm, ms_step):
+    """Roofline object of the train step's dominant kernel.  fp32-input MFMA kernel (RTK_CV_SPLIT=0): matrix-bound against 157.3
+    TFLOP/s.  Split kernel: its matrix floor (flops / (2500 / 6) TFLOP/s) has dropped below its HBM floor, so HBM is the binding
+    roofline: algorithmic bytes = per (point, neighbour) position a3 + two mask words read, dz1, dz2, dz3, dq3, d4, dt2 written
+    (5232 B), per query point dout read, dp1, dpd, bias rows written (7168 B)."""
+    from ratrack_amd import train_ops
+    common = {"traffic": pm["traffic_bytes_per_launch"] if pm else None, "kernel_ms": round(kms, 4), "flops_per_launch": kflops,
+              "share_of_step": round(kms / ms_step, 3)}
+    if not train_ops.CV_SPLIT:
+        return dict({"kernel": "cost_volume_bwd_kernel", "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4)}, **common)
+    m = a.batch * a.npoints * 16
+    nbytes = m * 5232 + (m // 16) * 7168
+    gbs = nbytes / (kms * 1e-3) / 1e9
+    return dict({"kernel": "cost_volume_bwd_split_kernel", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_launch": nbytes,
+                 "mfma": {"achieved": round(ach, 2), "peak": round(SPLIT_PEAK_TFLOPS, 1), "unit": "TFLOP/s (fp32-equivalent; bf16 peak / 6)",
+                          "frac": round(ach / SPLIT_PEAK_TFLOPS, 4), "vs_fp32_mfma_peak": round(ach / FP32_PEAK_TFLOPS, 4)}}, **common)
+
+
 def cost_volume_flops_per_pair(n, k=16):
     """Work of the stage the dominant kernel implements, counted in the reference's own arithmetic
     (model_utils.py:226-236; SURVEY.md Appendix B 'stage 1' minus the layer-1 feature part, which this
@@ -221,10 +241,7 @@ def run_train(a, net, d, dev, dist, world, rank, steps, warmup):
                "workload": "Track4D.backbone train step (fwd + multi-task loss + bwd + grad all-reduce + Adam), B=%d x N=%d per GPU"
                            % (a.batch, a.npoints),
                "allreduce_bytes": tr.reducer.payload_bytes or 4 * sum(p.numel() for p in net.parameters() if p.grad is not None),
-               "roofline": {"kernel": "cost_volume_bwd_kernel", "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS,
-                            "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4),
-                            "traffic": pm["traffic_bytes_per_launch"] if pm else None, "kernel_ms": round(kms, 4),
-                            "flops_per_launch": kflops, "share_of_step": round(kms / ms_step, 3)},
+               "roofline": train_roofline(a, kms, kflops, ach, pm, ms_step),
                "whole_step": {"hbm_frac_algorithmic_3x": round(3 * ALG_BYTES_PER_PAIR.get(a.npoints, 0) * a.batch / (ms_step * 1e-3)
                                                                / (HBM_PEAK_GBS * 1e9), 5),
                               "fp32_frac_algorithmic_3x": round(3 * ALG_FLOPS_PER_PAIR.get(a.npoints, 0) * a.batch / (ms_step * 1e-3)

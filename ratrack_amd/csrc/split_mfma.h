@@ -79,8 +79,11 @@ template <int NW, int F, int NF>
 struct WStreamA : WStream<NW, F, NF> {
     using Base = WStream<NW, F, NF>;
     unsigned rd;      // LDS byte address of this lane's slot in fragment 0 of the resident half
+    unsigned next_off;      // byte offset in the blob of the chunk after the resident one (cyclic), computed once per chunk
     __device__ __forceinline__ void set_rd() {
         rd = (unsigned)(size_t)(__attribute__((address_space(3))) void *)(this->lds) + (unsigned)((this->buf * F) * 64 + this->lane) * 16u;
+        const int nxt = this->cur + 1 == Base::NCHUNKS ? 0 : this->cur + 1;
+        next_off = (unsigned)nxt * (unsigned)(F * 1024);
     }
     __device__ __forceinline__ void start(const f4 *blob_, f4 *lds_, int wave_, int lane_) { Base::start(blob_, lds_, wave_, lane_); set_rd(); }
     __device__ __forceinline__ void next() { Base::next(); set_rd(); }
@@ -109,15 +112,14 @@ struct WStreamA : WStream<NW, F, NF> {
         return;
 #endif
         static_assert(NF % F == 0, "whole chunks only");
-        const int chunk = this->cur + 1 == Base::NCHUNKS ? 0 : this->cur + 1;
-        const char *base = this->blob + (size_t)chunk * F * 1024;
+        const char *base = this->blob + next_off;
 #pragma unroll
         for (int i = K; i < (F + NW - 1) / NW; i += PARTS) {
             const int f = this->wave + i * NW;
 #ifdef RTK_ABL_HALFDMA                   // ablation: every other request only (results are wrong)
             if (i & 1) continue;
 #endif
-            if (f < F)
+            if (F % NW == 0 || f < F)      // (F % NW == 0 folds the test away: a branch per request would cut the group step into blocks)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (size_t)i * NW * 1024 + this->lane_off),
                                                  (__attribute__((address_space(3))) void *)(this->lds + ((this->buf ^ 1) * F + f) * 64), 16, 0, 0);
         }

@@ -84,10 +84,12 @@ def main(fetch_db, write_db, trace_db, out_dir, tag="r02"):
                        "and none needs to -- together they move < 3 % of the step's bytes.",
                "traffic_bytes_per_launch": {k: v["traffic_bytes_per_launch"] for k, v in rows.items()}, "kernels": rows},
               open(os.path.join(out_dir, "%s_irregular_hbm.json" % tag), "w"), indent=1)
-    fwd = "cost_volume_split_kernel" if any("cost_volume_split_kernel" in n for n in dm.values()) else "cost_volume_kernel<false>"
-    for fname, pat, alg, what in (("pmc_cost_volume", fwd, 51773440, "one launch per backbone forward"),
-                                  ("pmc_cost_volume_train", "cost_volume_kernel<true>", None, "training forward: also stores a1, a2, a3 and two sign masks"),
-                                  ("pmc_cost_volume_bwd", "cost_volume_bwd_kernel", None, "one launch per train step")):
+    split = any("cost_volume_split_kernel" in n for n in dm.values())
+    stem = "cost_volume_split_kernel" if split else "cost_volume_kernel"
+    for fname, pat, alg, what in (("pmc_cost_volume", stem + "<false>", 51773440, "one launch per backbone forward"),
+                                  ("pmc_cost_volume_train", stem + "<true>", None, "training forward: also stores a1, a2, a3 and two sign masks"),
+                                  ("pmc_cost_volume_bwd", "cost_volume_bwd_split_kernel" if split else "cost_volume_bwd_kernel", None,
+                                   "one launch per train step")):
         r = traffic(lambda n, pat=pat: pat in n)
         if r:
             r.update({"workload": "B=64, N=256 (%s)" % what, "calibration": cal_note,
