@@ -444,7 +444,9 @@ static int cv_split_fill(const char *who, CvSplitParams &P, int samples, int n1,
     P.p1 = P.p2 = P.wd = P.bias2 = P.bias3 = nullptr;
     P.out = nullptr; P.out_pitch = 0; P.sv1 = P.sv2 = P.sv3 = nullptr; P.mk1 = P.mk2 = nullptr;
     const int groups = (n1 + 2 * SP_NW - 1) / (2 * SP_NW);
-    int gx = 256 / samples;                           // one workgroup per CU (the tile keeps the whole register file); the rest is looped
+    // one workgroup per CU (the tile keeps the whole register file); the rest is looped.  (Measured and rejected: 2 or 4 queued
+    // workgroups per CU to shorten the tail when other kernels of the pipelined batches hold CUs -- 1 to 1.5 % slower.)
+    int gx = 256 / samples;
     if (gx < 1) gx = 1;
     if (gx > groups) gx = groups;
     P.gx = samples % 8 == 0 ? gx : 0;

@@ -180,43 +180,62 @@ struct StoreRowsSide {            // h[e] -> 16 bytes at base + ro + 32 e  (this
 template <int FBASE, int GI, class WS, int F>
 struct SplitStep {
     static constexpr int NG = SPLIT_KS * (SPLIT_VB / 2);
+    // the six reads of group GJ, two at a time (PART = 0..2), so that they can be placed between the MFMAs of the group before
+    template <int GJ, int PART>
+    static __device__ __forceinline__ void load_part(WS &ws, f4 (&dst)[6]) {
+        constexpr int f0 = FBASE + GJ * 6;      // F % 6 == 0: a group never straddles two chunks
+        if constexpr (PART == 0) {
+            if constexpr (f0 % F == 0 && f0 != 0) ws.sync();
+            // the requests go out during the first SPLIT_ISSUE_GROUPS group steps of a chunk (the last ones must be old enough at
+            // the next sync() to have made their L2 round trip)
+            if constexpr ((f0 % F) / 6 < SPLIT_ISSUE_GROUPS) ws.template issue_part<(f0 % F) / 6, SPLIT_ISSUE_GROUPS>();
+        }
+        dst[2 * PART] = ws.template frag_async<(f0 + 2 * PART) % F>();
+        dst[2 * PART + 1] = ws.template frag_async<(f0 + 2 * PART + 1) % F>();
+    }
     template <int GJ>
     static __device__ __forceinline__ void load(WS &ws, f4 (&dst)[6]) {
-        constexpr int f0 = FBASE + GJ * 6;      // F % 6 == 0: a group never straddles two chunks
-        if constexpr (f0 % F == 0 && f0 != 0) ws.sync();
-        // the requests go out during the first SPLIT_ISSUE_GROUPS group steps of a chunk: spread over all of them, the last ones are
-        // ~400 cycles old at the next sync() and every chunk waits for their L2 round trip (measured: 30 % of the kernel)
-        if constexpr ((f0 % F) / 6 < SPLIT_ISSUE_GROUPS) ws.template issue_part<(f0 % F) / 6, SPLIT_ISSUE_GROUPS>();
-        dst[0] = ws.template frag_async<(f0 + 0) % F>();
-        dst[1] = ws.template frag_async<(f0 + 1) % F>();
-        dst[2] = ws.template frag_async<(f0 + 2) % F>();
-        dst[3] = ws.template frag_async<(f0 + 3) % F>();
-        dst[4] = ws.template frag_async<(f0 + 4) % F>();
-        dst[5] = ws.template frag_async<(f0 + 5) % F>();
+        load_part<GJ, 0>(ws, dst);
+        load_part<GJ, 1>(ws, dst);
+        load_part<GJ, 2>(ws, dst);
     }
+    // Schedule of a group step, pinned: hipcc left alone issues [6 reads, wait, all VALU, 12 MFMAs back to back] -- the matrix pipe
+    // idles while the ~25 other instructions issue (one wave per SIMD: nobody else feeds it).  Here the reads of the next group and
+    // the splitting of the next k-step's activations sit BETWEEN the MFMAs, whose 32-cycle issue slots hide about five
+    // single-issue instructions each.  The group's own fragments were requested a whole group step ago: lgkmcnt(0) up front costs
+    // nothing, and no read of the next group is outstanding yet when it is taken.
     template <class Side>
     static __device__ __forceinline__ void run(WS &ws, const f4 (&h)[32], f16v (&acc)[SPLIT_VB], f4 (&a)[2][6], u4v (&b)[2][3], const Side &side) {
         constexpr int s = GI / 4, v0 = (GI % 4) * 2;
         static_assert(F % 6 == 0, "a group step reads six consecutive fragments of one chunk");
-        if constexpr (GI + 1 < NG) {
-            load<GI + 1>(ws, a[(GI + 1) & 1]);
-            lds_wait<6>(a[GI & 1]);
-        } else {
-            lds_wait<0>(a[GI & 1]);
-        }
-#ifndef RTK_ABL_NOSPLIT                  // ablation: the B pieces of k-step 0 for every k-step (results are wrong)
-        if constexpr (s + 1 < SPLIT_KS) split3_word<GI % 4>(h[2 * (s + 1)], h[2 * (s + 1) + 1], b[(s + 1) & 1]);
-#else
-        if constexpr (GI % 4 == 0 && s + 1 < SPLIT_KS) { b[(s + 1) & 1][0] = b[s & 1][0]; b[(s + 1) & 1][1] = b[s & 1][1]; b[(s + 1) & 1][2] = b[s & 1][2]; }
-#endif
+        lds_wait<0>(a[GI & 1]);
         const f4(&c)[6] = a[GI & 1];
         const u4v(&B)[3] = b[s & 1];
 #define RTK_SPLIT_MM(pa, pb)                                                                          \
         acc[v0] = mfma_bf(__builtin_bit_cast(u4v, c[pa]), B[pb], acc[v0]);                            \
         acc[v0 + 1] = mfma_bf(__builtin_bit_cast(u4v, c[3 + pa]), B[pb], acc[v0 + 1]);
-        RTK_SPLIT_MM(2, 0) RTK_SPLIT_MM(0, 2) RTK_SPLIT_MM(1, 1) RTK_SPLIT_MM(1, 0) RTK_SPLIT_MM(0, 1) RTK_SPLIT_MM(0, 0)
-#undef RTK_SPLIT_MM
+        RTK_SPLIT_MM(2, 0)
+        if constexpr (GI + 1 < NG) load_part<GI + 1, 0>(ws, a[(GI + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        RTK_SPLIT_MM(0, 2)
+        if constexpr (GI + 1 < NG) load_part<GI + 1, 1>(ws, a[(GI + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        RTK_SPLIT_MM(1, 1)
+        if constexpr (GI + 1 < NG) load_part<GI + 1, 2>(ws, a[(GI + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef RTK_ABL_NOSPLIT                  // ablation: the B pieces of k-step 0 for every k-step (results are wrong)
+        if constexpr (s + 1 < SPLIT_KS) split3_word<GI % 4>(h[2 * (s + 1)], h[2 * (s + 1) + 1], b[(s + 1) & 1]);
+#else
+        if constexpr (GI % 4 == 0 && s + 1 < SPLIT_KS) { b[(s + 1) & 1][0] = b[s & 1][0]; b[(s + 1) & 1][1] = b[s & 1][1]; b[(s + 1) & 1][2] = b[s & 1][2]; }
+#endif
+        RTK_SPLIT_MM(1, 0) RTK_SPLIT_MM(0, 1) RTK_SPLIT_MM(0, 0)
         side.template at<GI>(h);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {            // one MFMA, then up to three of the splitting's VALU instructions, six times
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+#undef RTK_SPLIT_MM
         __builtin_amdgcn_sched_barrier(0);
     }
 };
