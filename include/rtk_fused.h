@@ -117,6 +117,12 @@ RTK_EXPORT int rtk_cost_volume_split(int samples, int n1, int n2, const float *x
                                      const int64_t *knn_idx, const float *p1, const float *p2, const float *wd_packed,
                                      const void *split_images, const float *bias2, const float *bias3,
                                      const rtk_layer_t *wn, float *out, int out_pitch, rtk_stream_t stream);
+/* rtk_sa_scale for the scales whose MLP is offset layer (c1 = 32 or 64 channels) + ONE layer c1 -> 64, nsample 16 or 32 (sa2 scale 1,
+ * sa3 scales 0 and 1 of the PNHead): same arguments, the layer as its split image (rtk_pack_split_layer(64, c1, ...)) + fp32 bias. */
+RTK_EXPORT int rtk_sa_scale_split(int samples, int n, int npoint, int nsample, const float *xyz, const float *new_xyz,
+                                  const int *idx, const float *q, int q_pitch, int c1, const float *w1xyz_packed,
+                                  const void *split_image, const float *bias2, float *out, int out_pitch, int out_offset,
+                                  const int *src_nuniq, const int *dst_nuniq, rtk_stream_t stream);
 RTK_EXPORT int rtk_split_mlp2(int positions, const float *x, const void *images, const float *bias1, const float *bias2,
                               float *y, rtk_stream_t stream);
 

@@ -184,6 +184,8 @@ __device__ __forceinline__ f16v wn_out(const WnSplit &W, int v, int hh, int col,
     return w;
 }
 
+__device__ __forceinline__ f4 f4_max(f4 a, f4 b) { return (f4){fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)}; }
+__device__ __forceinline__ f4 f4_relu(f4 a) { return (f4){fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)}; }
 __device__ __forceinline__ f4 leaky4(f4 t) { return (f4){fmaxf(t.x, 0.1f * t.x), fmaxf(t.y, 0.1f * t.y), fmaxf(t.z, 0.1f * t.z), fmaxf(t.w, 0.1f * t.w)}; }
 
 template <bool SAVE>
@@ -413,6 +415,98 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
     ws.finish();
 }
 
+// ---- rtk_sa_scale on the split path: the two-layer scales with 64 output channels (sa2 scale 1, sa3 scales 0 and 1) -------------
+// A wave owns 32 (centroid, neighbour) positions: one centroid of 32 neighbours or two of 16.  The offset layer (K = 4 with the
+// bias column) runs on the fp32-input MFMA, the C1 -> 64 layer split with its image RESIDENT in LDS (6 C1 x 64 bytes: no stream,
+// no barriers after the fill), the max over the neighbours in registers.
+struct SaSplitParams {
+    int samples, n, npoint, gx;
+    const float *xyz, *new_xyz;
+    const int *idx;
+    const float *q;
+    int q_pitch;
+    const float *w1;        // offset layer image [C1 / 16][64] of [Wx | b1]
+    const f4 *image;        // split image of the C1 -> 64 layer
+    const float *bias2;
+    float *out;
+    int out_pitch, out_offset;
+    const int *src_nuniq, *dst_nuniq;
+};
+
+template <int NS, int C1>
+__global__ __launch_bounds__(256) void sa_scale_split_kernel(const SaSplitParams P) {
+    constexpr int KS = C1 / 16, VB1 = C1 / 32, NFR = KS * 2 * 3, CPT = 32 / NS;      // k-steps, 32-blocks of layer 1, fragments, centroids per tile
+    __shared__ __attribute__((aligned(16))) f4 s_img[NFR * 64];
+    const int lane = threadIdx.x & 63, hh = lane >> 5, col = lane & 31, pp = col / NS, slot = col % NS;
+    int b, bx, nbx;
+    rtk_decode_block(P.gx, b, bx, nbx);
+    const int dst_e = P.dst_nuniq ? __builtin_amdgcn_readfirstlane(P.dst_nuniq[b]) : P.npoint;
+    const int live_units = (min(dst_e, P.npoint) + CPT - 1) / CPT;
+    if (bx * 4 >= live_units) return;
+    for (int i = threadIdx.x; i < NFR * 64; i += blockDim.x) s_img[i] = P.image[i];
+    __syncthreads();
+    const int src_e = P.src_nuniq ? P.src_nuniq[b] : 0x7fffffff;
+    for (int unit = bx * 4 + (threadIdx.x >> 6); unit < live_units; unit += nbx * 4) {
+        int cl = unit * CPT + pp;                                  // centroid of this lane within the sample
+        const bool valid = cl < P.npoint;
+        if (!valid) cl = P.npoint - 1;
+        const int c = b * P.npoint + cl;
+        const int id = P.idx[(long)c * NS + slot];
+        const long src = (long)b * P.n + id;
+        const float dx = __fsub_rn(P.xyz[src * 3], P.new_xyz[(long)c * 3]), dy = __fsub_rn(P.xyz[src * 3 + 1], P.new_xyz[(long)c * 3 + 1]),
+                    dz = __fsub_rn(P.xyz[src * 3 + 2], P.new_xyz[(long)c * 3 + 2]);
+        // layer 1: relu(q[id] + Wx.d + b1)      (duplicate source rows alias row 0)
+        const float *qrow = P.q + ((long)b * P.n + (id < src_e ? id : 0)) * P.q_pitch + 4 * hh;
+        const float b0 = hh ? dy : dx, b1 = hh ? 1.0f : dz;
+        f4 h[4 * VB1];
+#pragma unroll
+        for (int v = 0; v < VB1; ++v) {
+            f16v a;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f4 t = *reinterpret_cast<const f4 *>(qrow + 32 * v + 8 * q);
+                a[4 * q] = t.x; a[4 * q + 1] = t.y; a[4 * q + 2] = t.z; a[4 * q + 3] = t.w;
+            }
+            const int ch = 32 * v + col;
+            const float *wr = P.w1 + (ch >> 4) * 64 + (ch & 15);
+            a = mfma_f32x2(wr[16 * hh], b0, a);
+            a = mfma_f32x2(wr[16 * (2 + hh)], b1, a);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) h[4 * v + q] = f4_relu((f4){a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]});
+        }
+        // layer 2 (C1 -> 64), bias + ReLU after the max
+        f16v acc[2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[v][e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            u4v bp[3];
+            split3(h[2 * s], h[2 * s + 1], bp);
+            u4v fr[2][3];
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) fr[v][p] = __builtin_bit_cast(u4v, s_img[((s * 2 + v) * 3 + p) * 64 + lane]);
+#define RTK_SA_MM(pa, pb) acc[0] = mfma_bf(fr[0][pa], bp[pb], acc[0]); acc[1] = mfma_bf(fr[1][pa], bp[pb], acc[1]);
+            RTK_SA_MM(2, 0) RTK_SA_MM(0, 2) RTK_SA_MM(1, 1) RTK_SA_MM(1, 0) RTK_SA_MM(0, 1) RTK_SA_MM(0, 0)
+#undef RTK_SA_MM
+        }
+        float *o = P.out + (long)c * P.out_pitch + P.out_offset + 4 * hh;
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f4 m = (f4){acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]};
+                row_max_group_f4<16>(m);
+                if constexpr (NS == 32) m = f4_max(m, (f4){__shfl_xor(m.x, 16, 64), __shfl_xor(m.y, 16, 64), __shfl_xor(m.z, 16, 64), __shfl_xor(m.w, 16, 64)});
+                m = f4_relu(m + *reinterpret_cast<const f4 *>(P.bias2 + 32 * v + 8 * q + 4 * hh));
+                if (valid && slot == 0) *reinterpret_cast<f4 *>(o + 32 * v + 8 * q) = m;
+            }
+    }
+}
+
 }  // namespace
 
 extern "C" int rtk_pack_split_layer(int cout, int cin, const float *w, int transposed, void *image, rtk_stream_t stream) {
@@ -507,5 +601,36 @@ extern "C" int rtk_cost_volume_bwd_split(int samples, int n1, int n2, const floa
     Q.dz1 = dz1; Q.dz2 = dz2; Q.dz3 = dz3; Q.dq3 = dq3; Q.d4 = d4; Q.dp1 = dp1; Q.dpd = dpd; Q.dt2 = dt2; Q.dbrows = dbias_rows;
     cost_volume_bwd_split_kernel<<<grid, 64 * SP_NW, 0, (hipStream_t)stream>>>(Q);
     RTK_CHECK_LAUNCH("cost_volume_bwd_split");
+    return RTK_OK;
+}
+
+extern "C" int rtk_sa_scale_split(int samples, int n, int npoint, int nsample, const float *xyz, const float *new_xyz, const int *idx,
+                                  const float *q, int q_pitch, int c1, const float *w1xyz_packed, const void *split_image,
+                                  const float *bias2, float *out, int out_pitch, int out_offset, const int *src_nuniq,
+                                  const int *dst_nuniq, rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && n > 0 && npoint > 0 && xyz && new_xyz && idx && q && w1xyz_packed && split_image && bias2 && out,
+                "sa_scale_split: bad arguments");
+    RTK_REQUIRE(q_pitch % 4 == 0 && out_pitch % 4 == 0 && out_offset % 4 == 0, "sa_scale_split: pitches/offset must be multiples of 4");
+    RTK_REQUIRE((long)samples * npoint * nsample < 0x7fffffffL && (long)samples * n < 0x7fffffffL && samples <= 65535,
+                "sa_scale_split: problem too large for 32-bit indexing");
+    SaSplitParams P;
+    P.samples = samples; P.n = n; P.npoint = npoint;
+    P.xyz = xyz; P.new_xyz = new_xyz; P.idx = idx; P.q = q; P.q_pitch = q_pitch; P.w1 = w1xyz_packed;
+    P.image = reinterpret_cast<const f4 *>(split_image); P.bias2 = bias2;
+    P.out = out; P.out_pitch = out_pitch; P.out_offset = out_offset; P.src_nuniq = src_nuniq; P.dst_nuniq = dst_nuniq;
+    const int units = (npoint + 32 / nsample - 1) / (32 / nsample);
+    int bx = (units + 3) / 4;
+    while ((long)bx * samples > 1024 && bx > 1) bx = (bx + 1) / 2;      // few, fat workgroups: the LDS image fill is paid per workgroup
+    P.gx = samples % 8 == 0 ? bx : 0;
+    const dim3 blocks = P.gx ? dim3(bx * samples) : dim3(bx, samples);
+    hipStream_t s = (hipStream_t)stream;
+    if (nsample == 32 && c1 == 64) sa_scale_split_kernel<32, 64><<<blocks, 256, 0, s>>>(P);
+    else if (nsample == 16 && c1 == 64) sa_scale_split_kernel<16, 64><<<blocks, 256, 0, s>>>(P);
+    else if (nsample == 16 && c1 == 32) sa_scale_split_kernel<16, 32><<<blocks, 256, 0, s>>>(P);
+    else {
+        rtk_set_error("sa_scale_split: no kernel instance for nsample=%d, %d -> 64 channels", nsample, c1);
+        return RTK_ERR_UNSUPPORTED;
+    }
+    RTK_CHECK_LAUNCH("sa_scale_split");
     return RTK_OK;
 }

@@ -47,6 +47,7 @@ _lib.SIGNATURES.update({
     "rtk_pack_split_layer": [_ci, _ci, _vp, _ci, _vp, _vp],
     "rtk_cost_volume_split": [_ci] * 3 + [_vp] * 9 + [ctypes.POINTER(_Layer), _vp, _ci, _vp],
     "rtk_split_mlp2": [_ci, _vp, _vp, _vp, _vp, _vp, _vp],
+    "rtk_sa_scale_split": [_ci] * 4 + [_vp] * 4 + [_ci, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _vp, _vp, _vp],
     "rtk_prepare_inputs": [_ci] * 2 + [_vp] * 6 + [_vp],
     "rtk_fps_centroids": [_ci] * 3 + [_vp] * 8 + [_vp],
     "rtk_knn_point_masked": [_ci] * 4 + [_vp] * 4 + [_vp],
@@ -256,6 +257,9 @@ class _WeightNet:
         self.arr = arr
 
 
+SA_SPLIT = os.environ.get("RTK_SA_SPLIT", "1") != "0"
+
+
 class _SAScale:
     """One MSG scale: offset image + packed layers 2(,3) + the per-point projection matrix of layer 1."""
 
@@ -272,6 +276,14 @@ class _SAScale:
         self.w1img = offset_image(torch.cat([w1[:, :3], b1[:, None]], 1), device)
         self.chain = Chain([(w, b, ACT_RELU) for w, b in ws[1:]], device)
         self.cout = ws[-1][0].shape[0]
+        # the wide two-layer scales also as a split image (csrc/split_mfma.h): rtk_sa_scale_split
+        self.split_image = None
+        if SA_SPLIT and len(ws) == 2 and self.cout == 64 and self.c1 in (32, 64) and nsample in (16, 32) and torch.device(device).type == "cuda":
+            w2 = ws[1][0].float().to(device).contiguous()
+            self.split_bias = ws[1][1].float().to(device).contiguous()
+            self.split_image = torch.empty(3 * 64 * self.c1, dtype=torch.int16, device=device)
+            _lib.call("rtk_pack_split_layer", 64, self.c1, w2.data_ptr(), 0, self.split_image.data_ptr(), _stream())
+            torch.cuda.current_stream().synchronize()
 
 
 class _PNHeadWeights:
@@ -491,6 +503,11 @@ def sa_scale(geo, W, lvl, s, q, qcol, out, out_offset):
     if _TRACE is not None:      # per (centroid, neighbour) pair: offset layer (3 + bias) x C1, then the resident chain
         macs = sc.nsample * (4 * sc.c1 + sum(co * ci for co, ci in sc.chain.dims))
         _TRACE.append(("sa_scale", _live_rows(geo.nuniq[lvl], geo.npoint, geo.samples), macs))
+    if sc.split_image is not None:
+        _lib.call("rtk_sa_scale_split", geo.samples, src.shape[1], geo.npoint, sc.nsample, src.data_ptr(), dst.data_ptr(),
+                  geo.ball[lvl][s].data_ptr(), qptr, qpitch, sc.c1, sc.w1img.data_ptr(), sc.split_image.data_ptr(), sc.split_bias.data_ptr(),
+                  optr, opitch, out_offset, src_nu, geo.nuniq[lvl].data_ptr(), _stream())
+        return
     _lib.call("rtk_sa_scale", geo.samples, src.shape[1], geo.npoint, sc.nsample, src.data_ptr(), dst.data_ptr(),
               geo.ball[lvl][s].data_ptr(), qptr, qpitch, ceil16(sc.c1) // 16, sc.w1img.data_ptr(),
               sc.chain.n, sc.chain.arr, optr, opitch, out_offset, src_nu, geo.nuniq[lvl].data_ptr(), _stream())
