@@ -74,7 +74,7 @@ constexpr int SPLIT_NF = SPLIT_KS * SPLIT_VB * 3;      // fragments (KiB) of one
 // pays the LDS latency (one wave per SIMD: nothing else hides it; measured 0.6 of the MFMA issue rate).  Here the reads are
 // inline asm and the waits are counted by hand: LDS reads return in order, so "at most 6 outstanding" after issuing the
 // next group's six reads means the current group's six have landed (scalar loads that may share the counter only make the
-// wait longer, never shorter than needed: see DESIGN.md section 4.5).
+// wait longer, never shorter than needed: see DESIGN.md section 4.6).
 template <int NW, int F, int NF>
 struct WStreamA : WStream<NW, F, NF> {
     using Base = WStream<NW, F, NF>;
