@@ -320,7 +320,11 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
     for (int G = bx; G < groups; G += nbx) {
         asm volatile("" ::: "memory");
         const int pt = G * PPW + 2 * wave + pp;
+#ifdef CVB_NOSTORE      // ablation: no materialisation at all (results are wrong)
+        const bool valid = false;
+#else
         const bool valid = pt < P.n1;
+#endif
         const long i = (long)b * P.n1 + (valid ? pt : P.n1 - 1);
         const long nb = (long)b * P.n2 + (long)P.knn[i * 16 + j];
         const float dx = __fsub_rn(P.xyz2[nb * 3], P.xyz1[i * 3]), dy = __fsub_rn(P.xyz2[nb * 3 + 1], P.xyz1[i * 3 + 1]),

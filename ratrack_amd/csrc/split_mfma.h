@@ -158,9 +158,10 @@ __device__ __forceinline__ void lds_wait(f4 (&c)[6]) {      // the six fragments
 // The fragments of the next group (and, once per k-step, the B pieces of the next k-step) are fetched/split meanwhile.
 // Side job of a layer: called once per group step with the layer's INPUT activations.  The kernels that must also write those
 // activations to memory (saved activations of the training forward, dz of the backward) store one 16-byte slot every other group
-// step instead of 32 in a burst before the layer: the stream's chunk boundaries wait with vmcnt(0) -- loads and stores share the
-// counter and return out of order with respect to each other -- so a burst of stores ahead of a layer stalls its first boundary
-// until the whole burst has reached L2, with nothing else to run on the SIMD.
+// step instead of 32 in a burst before the layer.  A CU's store path drains ~7 bytes per cycle; a burst of 32 KiB per wave blocks
+// the wave -- the only one on its SIMD -- for as long as that takes, while 16 bytes per lane every other group step stay under
+// the drain rate and ride along with the MFMAs.  (Not a vmcnt effect: with every wait of the stream removed the stores of the
+// backward cost the same 0.28 ms; and issuing a chunk's share right after its boundary instead changes nothing.)
 struct NoSide {
     template <int GI>
     __device__ __forceinline__ void at(const f4 (&)[32]) const {}
