@@ -217,7 +217,11 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
                 f16v c;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
+#ifdef CV_ABL_NOGATHER   // ablation: no row gathers (results are wrong)
+                    const f4 t = (f4){dx, dy, dz, 1.f};
+#else
                     const f4 t = *reinterpret_cast<const f4 *>(r1 + 32 * v + 8 * q) + *reinterpret_cast<const f4 *>(r2 + 32 * v + 8 * q);
+#endif
                     c[4 * q] = t.x; c[4 * q + 1] = t.y; c[4 * q + 2] = t.z; c[4 * q + 3] = t.w;
                 }
                 const int ch = 32 * v + col;                         // A[i = col][k = hh]
@@ -270,13 +274,21 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
         float *o = P.out + i * P.out_pitch + 4 * hh;
 #pragma unroll
         for (int v = 0; v < SPLIT_VB; ++v) {
+#ifdef CV_ABL_NOWN       // ablation: no WeightNet (results are wrong)
+            f16v w;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) w[e] = t2[e & 7];
+#else
             const f16v w = wn_out(P.wn, v, hh, col, t2);
+#endif
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f4 r;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) r[e] = w[4 * q + e] * fmaxf(acc[v][4 * q + e], 0.1f * acc[v][4 * q + e]);
+#ifndef CV_ABL_NOSUM     // ablation: no neighbour sum (results are wrong)
                 row_sum16_f4(r);
+#endif
                 if (valid && j == 0) *reinterpret_cast<f4 *>(o + 32 * v + 8 * q) = r;
             }
         }
