@@ -457,15 +457,16 @@ __global__ __launch_bounds__(256) void sa_scale_split_kernel(const SaSplitParams
     int b, bx, nbx;
     rtk_decode_block(P.gx, b, bx, nbx);
     const int dst_e = P.dst_nuniq ? __builtin_amdgcn_readfirstlane(P.dst_nuniq[b]) : P.npoint;
-    const int live_units = (min(dst_e, P.npoint) + CPT - 1) / CPT;
+    const int live_c = min(dst_e, P.npoint);                      // centroids >= live_c are duplicates of centroid 0: neither computed nor written
+    const int live_units = (live_c + CPT - 1) / CPT;
     if (bx * 4 >= live_units) return;
     for (int i = threadIdx.x; i < NFR * 64; i += blockDim.x) s_img[i] = P.image[i];
     __syncthreads();
     const int src_e = P.src_nuniq ? P.src_nuniq[b] : 0x7fffffff;
     for (int unit = bx * 4 + (threadIdx.x >> 6); unit < live_units; unit += nbx * 4) {
         int cl = unit * CPT + pp;                                  // centroid of this lane within the sample
-        const bool valid = cl < P.npoint;
-        if (!valid) cl = P.npoint - 1;
+        const bool valid = cl < live_c;
+        if (!valid) cl = live_c - 1;
         const int c = b * P.npoint + cl;
         const int id = P.idx[(long)c * NS + slot];
         const long src = (long)b * P.n + id;

@@ -546,3 +546,34 @@ def test_eval_mode_uses_fused_engine_with_autograd_enabled():
     x = t[0].clone().requires_grad_(True)              # an input that wants a gradient: the differentiable module path
     flow = net.backbone(x, *t[1:], None)[0]
     assert flow.grad_fn is not None
+
+
+@pytest.mark.parametrize("nsample,c1,samples,n,npoint", [(32, 64, 3, 200, 77), (16, 64, 8, 256, 256), (16, 32, 5, 128, 130)])
+def test_sa_scale_split_agrees_with_fp32_mfma_kernel(nsample, c1, samples, n, npoint):
+    """rtk_sa_scale_split against rtk_sa_scale on the same operands: both grids (samples % 8), centroid counts that leave the last
+    tile partly empty, duplicate-centroid and duplicate-source counters (rows beyond them untouched / aliased to row 0)."""
+    from ratrack_amd import _lib
+    torch.manual_seed(nsample + c1)
+    xyz, new_xyz = torch.randn(samples, n, 3, device=DEV), torch.randn(samples, npoint, 3, device=DEV)
+    idx = torch.randint(0, n, (samples, npoint, nsample), device=DEV, dtype=torch.int32)
+    q = torch.randn(samples * n, c1, device=DEV)
+    w1 = torch.randn(c1, 4, device=DEV) * 0.3                                  # [Wx | b1]
+    w2, b2 = torch.randn(64, c1, device=DEV) / 8, torch.randn(64, device=DEV) * 0.1
+    w1img = F.offset_image(w1.double(), DEV)
+    chain = F.Chain([(w2.double(), b2.double(), F.ACT_RELU)], DEV)
+    img = torch.empty(3 * 64 * c1, dtype=torch.int16, device=DEV)
+    _lib.call("rtk_pack_split_layer", 64, c1, w2.data_ptr(), 0, img.data_ptr(), F._stream())
+    src_nu = torch.randint(n // 2, n + 1, (samples,), device=DEV, dtype=torch.int32)
+    dst_nu = torch.randint(npoint // 2, npoint + 1, (samples,), device=DEV, dtype=torch.int32)
+    a = torch.full((samples * npoint, 96), -5.0, device=DEV)
+    b = a.clone()
+    common = (samples, n, npoint, nsample, xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), q.data_ptr(), c1)
+    _lib.call("rtk_sa_scale", *common, c1 // 16, w1img.data_ptr(), 1, chain.arr, a.data_ptr(), 96, 16, src_nu.data_ptr(), dst_nu.data_ptr(),
+              F._stream())
+    _lib.call("rtk_sa_scale_split", *common, c1, w1img.data_ptr(), img.data_ptr(), b2.data_ptr(), b.data_ptr(), 96, 16, src_nu.data_ptr(),
+              dst_nu.data_ptr(), F._stream())
+    assert torch.equal(a == -5.0, b == -5.0)                                   # the same rows / columns are written
+    assert rel_err(b.cpu(), a.cpu()) < 5e-6
+    with pytest.raises(_lib.RtkError):
+        _lib.call("rtk_sa_scale_split", samples, n, npoint, 8, xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), q.data_ptr(), c1, c1,
+                  w1img.data_ptr(), img.data_ptr(), b2.data_ptr(), b.data_ptr(), 96, 16, None, None, F._stream())
