@@ -38,7 +38,10 @@ typedef struct {
     int per_sample;    /* 1: row index = sample (broadcast over the sample's points) */
 } rtk_src_t;
 
-/* One 1x1-conv layer with folded BN: y = act(W x + b).  w_packed is [cin16][cout16][64][4] floats. */
+/* One 1x1-conv layer with folded BN: y = act(W x + b).  w_packed is [cin16][cout16][64][4] floats -- or, with RTK_LAYER_SPLIT
+ * or-ed into act (rtk_pointwise_mlp only; all layers of a chain alike), the layer's 16-position split image: one 1 KiB fragment of
+ * 64 lanes x 8 bf16 per (pair of 16-channel input blocks, 16-channel output block, piece), see csrc/fused_common.h. */
+#define RTK_LAYER_SPLIT 0x100
 typedef struct {
     const float *w_packed;
     const float *bias; /* 16*cout16 floats (zero padded) */

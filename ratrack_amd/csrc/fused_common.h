@@ -227,6 +227,90 @@ __device__ __forceinline__ void mlp_layer_ws(WStream<NW, F, NF> &ws, const f4 (&
     mlp_layer_ws_impl<U, V, FBASE, WStream<NW, F, NF>, F>(ws, h, acc, std::make_integer_sequence<int, NG>{});
 }
 
+
+// ---- fp32 products on the bf16 matrix pipe (the scheme is described in split_mfma.h) -------------------------------------------
+// Shared pieces: the exact three-way bf16 split of eight activations, and the 16-position variant of the layer routine: the
+// tile, register layout and weight stream of mlp_layer_ws, with v_mfma_f32_16x16x32_bf16 (same C/D layout as the fp32-input
+// 16x16x4) taking two 16-channel input blocks per k-step -- lane (g, j) supplies B[k = 8 g + t][j] = channel
+// 16 (2 up + t / 4) + 4 g + t % 4, eight values it holds as h[2 up], h[2 up + 1].  Image: one 1 KiB fragment per
+// (input block pair, output block, piece): frag[up][v][p][lane = 16 g + i][t] = piece_p(W[16 v + i][16 (2 up + t / 4) + 4 g + t % 4]).
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_hi16(float lo, float hi) {      // the bf16 truncations of two floats in one register
+    return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+__device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+
+// the three bf16 pieces of eight activations (one k-step of this lane's B operand)
+__device__ __forceinline__ void split3(const f4 x0, const f4 x1, u4v (&b)[3]) {
+    float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w}, r1[8], r2[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        r1[t] = __fsub_rn(x[t], trunc_bf16(x[t]));          // exact
+        r2[t] = __fsub_rn(r1[t], trunc_bf16(r1[t]));        // exact; at most 8 significant bits are left
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        b[0][w] = pack_hi16(x[2 * w], x[2 * w + 1]);
+        b[1][w] = pack_hi16(r1[2 * w], r1[2 * w + 1]);
+        b[2][w] = pack_hi16(r2[2 * w], r2[2 * w + 1]);
+    }
+}
+
+
+__device__ __forceinline__ f4 mfma16_bf(u4v a, u4v b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
+}
+
+constexpr int split16_nf(int U, int V) { return ((U + 1) / 2) * V * 3; }      // fragments of a layer's split image
+
+// group step = one input block pair x two output blocks: six fragments, twelve MFMAs (the two blocks interleaved)
+template <int U, int V, int FBASE, int GI, class WS, int F>
+struct LayerStepS {
+    static constexpr int GV = (V + 1) / 2;
+    static constexpr int NG = ((U + 1) / 2) * GV;
+    template <int GJ>
+    static __device__ __forceinline__ void load(WS &ws, f4 (&dst)[6]) {
+        constexpr int up = GJ / GV, v0 = (GJ % GV) * 2;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            if (v0 + q / 3 < V) {
+                const int fi = FBASE + (up * V + v0 + q / 3) * 3 + q % 3;
+                if (fi % F == 0 && fi != 0) ws.next();
+                dst[q] = ws.frag(fi % F);
+            }
+        }
+    }
+    static __device__ __forceinline__ void run(WS &ws, const f4 (&h)[U], f4 (&acc)[V], f4 (&a)[2][6], u4v (&b)[3]) {
+        constexpr int up = GI / GV, v0 = (GI % GV) * 2;
+        if constexpr (GI + 1 < NG) load<GI + 1>(ws, a[(GI + 1) & 1]);
+        if constexpr (GI % GV == 0) split3(h[2 * up], 2 * up + 1 < U ? h[2 * up + 1] : f4_zero(), b);
+        const f4(&c)[6] = a[GI & 1];
+#define RTK_S16_MM(pa, pb)                                                                             \
+        acc[v0] = mfma16_bf(__builtin_bit_cast(u4v, c[pa]), b[pb], acc[v0]);                            \
+        if constexpr (v0 + 1 < V) acc[v0 + 1] = mfma16_bf(__builtin_bit_cast(u4v, c[3 + pa]), b[pb], acc[v0 + 1]);
+        RTK_S16_MM(2, 0) RTK_S16_MM(0, 2) RTK_S16_MM(1, 1) RTK_S16_MM(1, 0) RTK_S16_MM(0, 1) RTK_S16_MM(0, 0)
+#undef RTK_S16_MM
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+
+template <int U, int V, int FBASE, class WS, int F, int... GI>
+__device__ __forceinline__ void mlp_layer_split_impl(WS &ws, const f4 (&h)[U], f4 (&acc)[V], std::integer_sequence<int, GI...>) {
+    f4 a[2][6];
+    u4v b[3];
+    LayerStepS<U, V, FBASE, 0, WS, F>::template load<0>(ws, a[0]);
+    (LayerStepS<U, V, FBASE, GI, WS, F>::run(ws, h, acc, a, b), ...);
+}
+
+// acc[v] += W . h on the split path; FBASE = index of the layer's first fragment in the (split) blob
+template <int U, int V, int FBASE, int NW, int F, int NF>
+__device__ __forceinline__ void mlp_layer_ws_split(WStream<NW, F, NF> &ws, const f4 (&h)[U], f4 (&acc)[V]) {
+    constexpr int NG = ((U + 1) / 2) * ((V + 1) / 2);
+    mlp_layer_split_impl<U, V, FBASE, WStream<NW, F, NF>, F>(ws, h, acc, std::make_integer_sequence<int, NG>{});
+}
+
 // Weights resident in LDS (image [U][V][64] f4 at `w`): same pipeline without the stream.
 struct WResident {
     const f4 *w;

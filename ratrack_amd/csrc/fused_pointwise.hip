@@ -87,7 +87,9 @@ __device__ __forceinline__ void store_tile(const PwParams &P, const f4 (&acc)[V]
                    // throughput with two batches in flight -- smaller footprints co-reside, tools/exp_pwf.sh)
 #endif
 
-template <int U, int V1, int V2, int V3, int V4, bool INTERP>
+// SPLIT: the layers on the bf16 matrix pipe (six products of exact operand pieces per fp32 product, fused_common.h): same tile,
+// registers and stream, the blob holds split images.
+template <int U, int V1, int V2, int V3, int V4, bool INTERP, bool SPLIT>
 __global__ __launch_bounds__(64 * PW_NW, 2) void pointwise_mlp_kernel(const PwParams P) {
     __shared__ __attribute__((aligned(16))) f4 s_w[2 * PW_F * 64];
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
@@ -102,7 +104,9 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void pointwise_mlp_kernel(const PwPa
     const int live_rows = P.row_nuniq ? min(rps, __builtin_amdgcn_readfirstlane(P.row_nuniq[b])) : rps;
     const int live_groups = (live_rows + PW_NW * 16 - 1) / (PW_NW * 16);
     if (bx >= live_groups) return;
-    constexpr int NF = U * V1 + V1 * V2 + V2 * V3 + V3 * V4;
+    constexpr int F1 = SPLIT ? split16_nf(U, V1) : U * V1, F2 = SPLIT ? split16_nf(V1, V2) : V1 * V2,
+                  F3 = SPLIT ? split16_nf(V2, V3) : V2 * V3, F4 = SPLIT ? split16_nf(V3, V4) : V3 * V4;
+    constexpr int NF = F1 + F2 + F3 + F4;
     WStream<PW_NW, PW_F, NF> ws;
     ws.start(reinterpret_cast<const f4 *>(P.layer[0].w_packed), s_w, wave_in_wg, lane);
 
@@ -189,28 +193,32 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void pointwise_mlp_kernel(const PwPa
 #pragma unroll
             for (int v = 0; v < V1; ++v) a1[v] += bias_frag(sb, v, g);
         }
-        mlp_layer_ws<U, V1, 0>(ws, h, a1);
+        if constexpr (SPLIT) mlp_layer_ws_split<U, V1, 0>(ws, h, a1);
+        else mlp_layer_ws<U, V1, 0>(ws, h, a1);
         apply_act<V1>(a1, P.layer[0].act);
         if constexpr (V2 == 0) {
             store_tile<V1>(P, a1, p, b, g, valid);
         } else {
             f4 a2[V2];
             init_bias<V2>(a2, P.layer[1].bias, g);
-            mlp_layer_ws<V1, V2, U * V1>(ws, a1, a2);
+            if constexpr (SPLIT) mlp_layer_ws_split<V1, V2, F1>(ws, a1, a2);
+            else mlp_layer_ws<V1, V2, F1>(ws, a1, a2);
             apply_act<V2>(a2, P.layer[1].act);
             if constexpr (V3 == 0) {
                 store_tile<V2>(P, a2, p, b, g, valid);
             } else {
                 f4 a3[V3];
                 init_bias<V3>(a3, P.layer[2].bias, g);
-                mlp_layer_ws<V2, V3, U * V1 + V1 * V2>(ws, a2, a3);
+                if constexpr (SPLIT) mlp_layer_ws_split<V2, V3, F1 + F2>(ws, a2, a3);
+                else mlp_layer_ws<V2, V3, F1 + F2>(ws, a2, a3);
                 apply_act<V3>(a3, P.layer[2].act);
                 if constexpr (V4 == 0) {
                     store_tile<V3>(P, a3, p, b, g, valid);
                 } else {
                     f4 a4[V4];
                     init_bias<V4>(a4, P.layer[3].bias, g);
-                    mlp_layer_ws<V3, V4, U * V1 + V1 * V2 + V2 * V3>(ws, a3, a4);
+                    if constexpr (SPLIT) mlp_layer_ws_split<V3, V4, F1 + F2 + F3>(ws, a3, a4);
+                    else mlp_layer_ws<V3, V4, F1 + F2 + F3>(ws, a3, a4);
                     apply_act<V4>(a4, P.layer[3].act);
                     store_tile<V4>(P, a4, p, b, g, valid);
                 }
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void pointwise_mlp_kernel(const PwPa
 }
 
 template <int U, int V1, int V2, int V3, int V4>
-static int launch_pw(const PwParams &P0, bool interp, hipStream_t s) {
+static int launch_pw(const PwParams &P0, bool interp, bool split, hipStream_t s) {
     PwParams P = P0;
     const int samples = P.rows / P.rows_per_sample;
     const int groups = (P.rows_per_sample + PW_NW * 16 - 1) / (PW_NW * 16);
@@ -231,10 +239,10 @@ static int launch_pw(const PwParams &P0, bool interp, hipStream_t s) {
     if (gx > groups) gx = groups;
     P.gx = samples % 8 == 0 ? gx : 0;
     const dim3 blocks = P.gx ? dim3(gx * samples) : dim3(gx, samples);
-    if (interp)
-        pointwise_mlp_kernel<U, V1, V2, V3, V4, true><<<blocks, 256, 0, s>>>(P);
-    else
-        pointwise_mlp_kernel<U, V1, V2, V3, V4, false><<<blocks, 256, 0, s>>>(P);
+    if (interp && split) pointwise_mlp_kernel<U, V1, V2, V3, V4, true, true><<<blocks, 256, 0, s>>>(P);
+    else if (interp) pointwise_mlp_kernel<U, V1, V2, V3, V4, true, false><<<blocks, 256, 0, s>>>(P);
+    else if (split) pointwise_mlp_kernel<U, V1, V2, V3, V4, false, true><<<blocks, 256, 0, s>>>(P);
+    else pointwise_mlp_kernel<U, V1, V2, V3, V4, false, false><<<blocks, 256, 0, s>>>(P);
     return 0;
 }
 
@@ -267,12 +275,17 @@ extern "C" int rtk_pointwise_mlp(int rows, int rows_per_sample, const rtk_interp
     P.sample_bias = sample_bias;
     int V[RTK_MAX_LAYERS] = {0, 0, 0, 0};
     int cin = U;
+    const bool split = (layers[0].act & RTK_LAYER_SPLIT) != 0;      // the chain's images are split images (rtk_fused.h)
     for (int l = 0; l < nlayers; ++l) {
         RTK_REQUIRE(layers[l].w_packed && layers[l].bias && layers[l].cin16 == cin && layers[l].cout16 > 0,
                     "pointwise_mlp: layer %d expects cin16=%d, got %d (cout16=%d)", l, cin, layers[l].cin16, layers[l].cout16);
-        RTK_REQUIRE(l == 0 || layers[l].w_packed == layers[l - 1].w_packed + (size_t)layers[l - 1].cin16 * layers[l - 1].cout16 * 256,
+        RTK_REQUIRE(((layers[l].act & RTK_LAYER_SPLIT) != 0) == split, "pointwise_mlp: split and fp32 images in one chain (layer %d)", l);
+        const size_t prev_floats = l == 0 ? 0 : (split ? (size_t)split16_nf(layers[l - 1].cin16, layers[l - 1].cout16) * 256
+                                                        : (size_t)layers[l - 1].cin16 * layers[l - 1].cout16 * 256);
+        RTK_REQUIRE(l == 0 || layers[l].w_packed == layers[l - 1].w_packed + prev_floats,
                     "pointwise_mlp: the packed weights of a chain must be contiguous (layer %d)", l);
         P.layer[l] = layers[l];
+        P.layer[l].act = layers[l].act & 0xff;
         V[l] = layers[l].cout16;
         cin = V[l];
     }
@@ -289,7 +302,7 @@ extern "C" int rtk_pointwise_mlp(int rows, int rows_per_sample, const rtk_interp
     const long key = ((((long)U * 32 + V[0]) * 32 + V[1]) * 32 + V[2]) * 32 + V[3];
 #define PW_CASE(u, v1, v2, v3, v4)                                               \
     case ((((long)(u) * 32 + (v1)) * 32 + (v2)) * 32 + (v3)) * 32 + (v4):        \
-        launch_pw<u, v1, v2, v3, v4>(P, it, s);                                  \
+        launch_pw<u, v1, v2, v3, v4>(P, it, split, s);                           \
         break;
     switch (key) {
         PW_CASE(1, 2, 0, 0, 0)     // raw (RCS, v_r) -> sa1 layer-1 projections (2 scales x 16)

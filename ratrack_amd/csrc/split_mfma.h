@@ -23,32 +23,9 @@
 #include "fused_common.h"
 
 typedef float f16v __attribute__((ext_vector_type(16)));
-typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
-typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f16v mfma_bf(u4v a, u4v b, f16v c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
-}
-
-__device__ __forceinline__ unsigned pack_hi16(float lo, float hi) {      // the bf16 truncations of two floats in one register
-    return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
-}
-__device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
-
-// the three bf16 pieces of eight activations (one k-step of this lane's B operand)
-__device__ __forceinline__ void split3(const f4 x0, const f4 x1, u4v (&b)[3]) {
-    float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w}, r1[8], r2[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        r1[t] = __fsub_rn(x[t], trunc_bf16(x[t]));          // exact
-        r2[t] = __fsub_rn(r1[t], trunc_bf16(r1[t]));        // exact; at most 8 significant bits are left
-    }
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        b[0][w] = pack_hi16(x[2 * w], x[2 * w + 1]);
-        b[1][w] = pack_hi16(r1[2 * w], r1[2 * w + 1]);
-        b[2][w] = pack_hi16(r2[2 * w], r2[2 * w + 1]);
-    }
 }
 
 // ... one register (two activations) of each piece at a time: the k-step's splitting is spread over its four group steps

@@ -157,6 +157,22 @@ def pack_layer_split(w):
     return p.permute(3, 4, 1, 0, 6, 2, 5, 7).contiguous().reshape(-1)     # (a, e, v, p, hh, i, d, r): s = 2 a + e, t = 4 d + r
 
 
+def pack_layer_split16(w):
+    """(Cout, Cin) -> 16-position split image (csrc/fused_common.h), int16: one fragment per (pair of 16-channel input blocks,
+    16-channel output block, piece): frag[up][v][p][lane = 16 g + i][t] = piece_p(W[16 v + i][16 (2 up + t // 4) + 4 g + t % 4]),
+    zero beyond (Cout, Cin)."""
+    cout, cin = w.shape
+    V, U2 = ceil16(cout) // 16, (ceil16(cin) // 16 + 1) // 2
+    wp = torch.zeros(V * 16, U2 * 32, dtype=torch.float32, device=w.device)
+    wp[:cout, :cin] = w.float()
+    p = split3_bf16(wp).reshape(3, V, 16, U2, 2, 4, 4)                     # (p, v, i, up, d, g, r): c = 32 up + 16 d + 4 g + r
+    return p.permute(3, 1, 0, 5, 2, 4, 6).contiguous().reshape(-1)         # (up, v, p, g, i, d, r): lane = 16 g + i, t = 4 d + r
+
+
+PW_SPLIT = os.environ.get("RTK_PW_SPLIT", "1") != "0"
+LAYER_SPLIT = 0x100      # RTK_LAYER_SPLIT (include/rtk_fused.h)
+
+
 def pad_bias(b, cout):
     out = torch.zeros(ceil16(cout), dtype=torch.float32, device=b.device)
     out[:b.numel()] = b.float()
@@ -165,6 +181,23 @@ def pad_bias(b, cout):
 
 class Chain:
     """A chain of packed layers living in ONE contiguous device blob (the kernels stream it through LDS)."""
+
+    def split_arr(self):
+        """The same chain as split images (rtk_pointwise_mlp with RTK_LAYER_SPLIT), built on first use."""
+        if self._split is None:
+            blob = torch.cat([pack_layer_split16(w.to(self._device)) for w, _ in self._layers]).contiguous()
+            arr = (_Layer * len(self._layers))()
+            off = boff = 0
+            for i, (w, act) in enumerate(self._layers):
+                cout, cin = w.shape
+                u, v = ceil16(cin) // 16, ceil16(cout) // 16
+                arr[i].w_packed = blob.data_ptr() + 2 * off
+                arr[i].bias = self.bias.data_ptr() + 4 * boff
+                arr[i].cin16, arr[i].cout16, arr[i].act = u, v, act | LAYER_SPLIT
+                off += ((u + 1) // 2) * v * 3 * 512      # int16 elements per fragment: 64 lanes x 8
+                boff += v * 16
+            self._split = (arr, blob)
+        return self._split[0]
 
     def __init__(self, layers, device):
         """layers: list of (W (Cout,Cin) float64/32 tensor, bias (Cout,), act)."""
@@ -177,6 +210,7 @@ class Chain:
             meta.append((ceil16(cin) // 16, ceil16(cout) // 16, act))
         self.blob = torch.cat(packs).contiguous()
         self.bias = torch.cat(biases).contiguous()
+        self._layers, self._device, self._split = [(w, act) for w, _, act in layers], device, None
         arr = (_Layer * len(layers))()
         woff = boff = 0
         for i, (u, v, act) in enumerate(meta):
@@ -221,7 +255,7 @@ def pointwise(rows, rows_per_sample, srcs, chain, out, out_channels=None, sample
     else:
         optr, opitch = _colptr(out)
     _lib.call("rtk_pointwise_mlp", rows, rows_per_sample, ip, len(srcs), arr,
-              sample_bias.data_ptr() if sample_bias is not None else None, chain.n, chain.arr, optr, opitch, oc,
+              sample_bias.data_ptr() if sample_bias is not None else None, chain.n, chain.split_arr() if PW_SPLIT else chain.arr, optr, opitch, oc,
               int(channel_major), row_nuniq.data_ptr() if row_nuniq is not None else None,
               colmax.data_ptr() if colmax is not None else None, _stream())
     return out

@@ -30,7 +30,9 @@ def ref_act(x, act):
     (2 * 256, 256, 256, [128, 64, 32, 1], [F.ACT_RELU, F.ACT_RELU, F.ACT_RELU, F.ACT_SIGMOID]),
     (70 * 256, 256, 128, [128, 64, 32, 3], [F.ACT_RELU, F.ACT_RELU, F.ACT_RELU, F.ACT_NONE]),   # > one pass of the grid
 ])
-def test_pointwise_chain(rows, n, cin, widths, acts):
+@pytest.mark.parametrize("split", [True, False])      # split images (the default) / fp32-input MFMA images
+def test_pointwise_chain(rows, n, cin, widths, acts, split, monkeypatch):
+    monkeypatch.setattr(F, "PW_SPLIT", split)
     torch.manual_seed(rows + cin)
     x = torch.randn(rows, cin, dtype=torch.float64)
     layers, cur = [], cin
@@ -57,7 +59,9 @@ def test_pointwise_chain(rows, n, cin, widths, acts):
     assert rel_err(out_cm.permute(0, 2, 1).reshape(rows, -1).double().cpu(), ref) < 2e-6
 
 
-def test_pointwise_multi_source_and_broadcast():
+@pytest.mark.parametrize("split", [True, False])
+def test_pointwise_multi_source_and_broadcast(split, monkeypatch):
+    monkeypatch.setattr(F, "PW_SPLIT", split)
     """[2 raw channels (padded slot) || 128 local || per-sample 256] -> 32, as the decoder's embedding projection."""
     torch.manual_seed(1)
     B, n = 3, 256
@@ -91,7 +95,9 @@ def test_pointwise_multi_source_and_broadcast():
 
 
 @pytest.mark.parametrize("n_unknown,m,cint,cskip", [(512, 512, 64, 64), (512, 512, 128, 32), (256, 512, 128, 0), (242, 512, 128, 0)])
-def test_pointwise_interp_prologue(n_unknown, m, cint, cskip):
+@pytest.mark.parametrize("split", [True, False])
+def test_pointwise_interp_prologue(n_unknown, m, cint, cskip, split, monkeypatch):
+    monkeypatch.setattr(F, "PW_SPLIT", split)
     """FP module: three_nn weights + three_interpolate + cat(skip) + conv/BN/ReLU in one kernel."""
     torch.manual_seed(n_unknown + cint)
     B = 2
@@ -577,3 +583,22 @@ def test_sa_scale_split_agrees_with_fp32_mfma_kernel(nsample, c1, samples, n, np
     with pytest.raises(_lib.RtkError):
         _lib.call("rtk_sa_scale_split", samples, n, npoint, 8, xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), q.data_ptr(), c1, c1,
                   w1img.data_ptr(), img.data_ptr(), b2.data_ptr(), b.data_ptr(), 96, 16, None, None, F._stream())
+
+
+def test_split16_image_is_packed_as_documented():
+    """fused.pack_layer_split16 against its index formula, element by element, on a ragged layer (cout, cin not multiples of 16/32)."""
+    torch.manual_seed(9)
+    cout, cin = 40, 50
+    w = torch.randn(cout, cin)
+    img = F.pack_layer_split16(w).view(-1)                                  # (up, v, p, lane, t) int16
+    pieces = F.split3_bf16(torch.nn.functional.pad(w, (0, 64 - cin, 0, 48 - cout)))      # (3, 48, 64)
+    V, U2 = 3, 2
+    assert img.numel() == U2 * V * 3 * 64 * 8
+    for up in range(U2):
+        for v in range(V):
+            for p in range(3):
+                for lane in (0, 5, 17, 38, 63):
+                    g, i = lane // 16, lane % 16
+                    for t in range(8):
+                        got = img[(((up * V + v) * 3 + p) * 64 + lane) * 8 + t]
+                        assert got == pieces[p, 16 * v + i, 16 * (2 * up + t // 4) + 4 * g + t % 4]
