@@ -1,0 +1,82 @@
+"""CPU: the arithmetic the split-bf16 matrix path rests on (csrc/split_mfma.h), restated in numpy / torch-CPU -- no GPU involved.
+  * three bf16 pieces, split by truncation, sum to the fp32 number exactly;
+  * a bf16 x bf16 product is exact in fp32;
+  * six partial products (i + j <= 2) accumulated in fp32 carry the error of an fp32 product chain; three do not;
+  * the host packers write the images the headers describe."""
+import numpy as np
+import torch
+
+from ratrack_amd import fused as F
+
+
+def _split3(x):
+    x = x.astype(np.float32)
+    trunc = lambda v: (v.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+    p0 = trunc(x); r1 = x - p0; p1 = trunc(r1); r2 = r1 - p1; p2 = trunc(r2)
+    return p0, p1, p2, r2
+
+
+def test_three_truncated_pieces_are_exact():
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(200000) * np.exp(rng.uniform(-30, 30, 200000))).astype(np.float32)
+    x[:4] = [0.0, 1.0, -1.5, 3.0e38]
+    p0, p1, p2, r2 = _split3(x)
+    assert np.array_equal(p2, r2)                                             # nothing is left after the third piece
+    assert np.array_equal((p0.astype(np.float64) + p1 + p2).astype(np.float32), x)
+    for p in (p0, p1, p2):                                                    # every piece is a bf16 number
+        assert not (p.view(np.uint32) & np.uint32(0xFFFF)).any()
+    # the torch restatement the device packer is compared with (tests/test_fused_gpu.py) produces the same pieces
+    t = F.split3_bf16(torch.from_numpy(x))
+    for k, p in enumerate((p0, p1, p2)):
+        assert np.array_equal((t[k].numpy().astype(np.int32) << 16).view(np.float32), p)
+
+
+def test_bf16_products_are_exact_in_fp32():
+    rng = np.random.default_rng(1)
+    a = _split3(rng.standard_normal(100000).astype(np.float32))[0]
+    b = _split3(rng.standard_normal(100000).astype(np.float32))[1]
+    assert np.array_equal((a * b).astype(np.float64), a.astype(np.float64) * b.astype(np.float64))
+
+
+def test_six_products_carry_fp32_accuracy_three_do_not():
+    rng = np.random.default_rng(2)
+    K = 256
+    W = (rng.standard_normal((64, K)) / 16).astype(np.float32)
+    X = rng.standard_normal((K, 96)).astype(np.float32)
+    ref = W.astype(np.float64) @ X.astype(np.float64)
+    w, x = _split3(W)[:3], _split3(X)[:3]
+
+    def accumulate(terms):                                                    # fp32 accumulation, 16 exact products at a time
+        out = np.zeros(ref.shape, np.float32)
+        for k0 in range(0, K, 16):
+            for a, b in terms:
+                out = out + (a[:, k0:k0 + 16].astype(np.float64) @ b[k0:k0 + 16].astype(np.float64)).astype(np.float32)
+        return out
+    six = [(w[2], x[0]), (w[0], x[2]), (w[1], x[1]), (w[1], x[0]), (w[0], x[1]), (w[0], x[0])]      # the kernels' order: small terms first
+    err = lambda o: np.abs(o - ref).max() / np.abs(ref).max()
+    e32, e6, e3 = err(W @ X), err(accumulate(six)), err(accumulate(six[3:]))
+    assert e6 < 1.5 * e32 + 1e-7, (e6, e32)
+    assert e3 > 10 * e32, (e3, e32)
+
+
+def test_split_images_follow_their_index_formulas():
+    torch.manual_seed(0)
+    w = torch.randn(64, 96)
+    p = F.split3_bf16(w)
+    img = F.pack_layer_split(w).view(6, 2, 3, 64, 8)                           # (s, v, piece, lane, t)
+    for s in range(6):
+        for v in range(2):
+            for lane in (0, 7, 31, 32, 50, 63):
+                hh, i = lane // 32, lane % 32
+                for t in range(8):
+                    c = 32 * (s // 2) + 16 * (s % 2) + 8 * (t // 4) + 4 * hh + t % 4
+                    assert torch.equal(img[s, v, :, lane, t], p[:, 32 * v + i, c])
+    w = torch.randn(40, 50)                                                    # ragged: zero padded to (48, 64)
+    p = F.split3_bf16(torch.nn.functional.pad(w, (0, 14, 0, 8)))
+    img = F.pack_layer_split16(w).view(2, 3, 3, 64, 8)                         # (up, v, piece, lane, t)
+    for up in range(2):
+        for v in range(3):
+            for lane in (0, 5, 17, 38, 63):
+                g, i = lane // 16, lane % 16
+                for t in range(8):
+                    assert torch.equal(img[up, v, :, lane, t], p[:, 16 * v + i, 16 * (2 * up + t // 4) + 4 * g + t % 4])
