@@ -59,7 +59,7 @@ def train_roofline(a, kms, kflops, ach, pm, ms_step):
     from ratrack_amd import train_ops
     common = {"traffic": pm["traffic_bytes_per_launch"] if pm else None, "kernel_ms": round(kms, 4), "flops_per_launch": kflops,
               "share_of_step": round(kms / ms_step, 3)}
-    if not train_ops.CV_SPLIT:
+    if not train_ops._cv_split(a.batch * a.npoints):
         return dict({"kernel": "cost_volume_bwd_kernel", "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4)}, **common)
     m = a.batch * a.npoints * 16

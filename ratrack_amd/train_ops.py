@@ -568,18 +568,26 @@ def _pack_weights(specs, device):
 
 # the cost volume's 256 x 256 products on the split-bf16 matrix path (csrc/split_mfma.h); RTK_CV_SPLIT=0: fp32-input MFMA kernels
 CV_SPLIT = os.environ.get("RTK_CV_SPLIT", "1") != "0"
+# ... from this many query points on: the split kernels' workgroups are half as many and twice as heavy (8 points of one sample each),
+# below ~1 workgroup per CU the fp32-input kernels are faster (B = 1: 55 vs 81 us for the backward)
+CV_SPLIT_MIN_POINTS = int(os.environ.get("RTK_CV_SPLIT_MIN_POINTS", "2048"))
 _SPLIT_IMAGE = 3 * 256 * 256          # int16 elements of one layer's split image
+
+
+def _cv_split(points):
+    return CV_SPLIT and points >= CV_SPLIT_MIN_POINTS
 
 
 class _CvWeights:
     """Packed kernel images of the live cost-volume weights (re-packed every step: the weights are being trained): the four 256x256
     layer images W2, W3, W3^T, W2^T, the offset image of Wd, the WeightNet's three layers and Wc^T -- one launch."""
 
-    def __init__(self, wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, backward):
+    def __init__(self, wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, backward, split=None):
         dev = w2.device
+        self.is_split = split = CV_SPLIT if split is None else split
         L = fused._Layer
         specs = [(0, w2, False, None), (0, w3, False, None)] + ([(0, w3, True, None), (0, w2, True, None)] if backward else [])
-        if CV_SPLIT:                              # split images instead: W2 | W3 | W3^T | W2^T (the transposes straight from w3, w2)
+        if split:                                 # split images instead: W2 | W3 | W3^T | W2^T (the transposes straight from w3, w2)
             specs = []
             self.split = torch.empty((4 if backward else 2) * _SPLIT_IMAGE, dtype=torch.int16, device=dev)
             self._w = [w.detach().contiguous() for w in (w2, w3)]
@@ -630,14 +638,14 @@ class _CostVolume(torch.autograd.Function):
         n2 = xyz2.shape[1]
         p1, p2 = p1.contiguous(), p2.contiguous()
         # all kernel images are built once per step, here: the backward reuses them (ctx.images)
-        W = _CvWeights(wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, backward=True)
+        W = _CvWeights(wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, backward=True, split=_cv_split(B * n1))
         ctx.images = W
         out = torch.empty(B * n1, 256, dtype=torch.float32, device=p1.device)
         # the three activations are kept for the backward (3 x 268 MB at B = 64 of 288 GB): it then needs no recomputation and its
         # weight-gradient GEMMs read the same tensors
         acts = torch.empty(3, B * n1 * 16, 256, dtype=torch.float32, device=p1.device)
         masks = torch.empty(2, B * n1 * 16, 4, dtype=torch.int64, device=p1.device)          # sign bits of a1, a2 (kernel lane order)
-        if CV_SPLIT:
+        if W.is_split:
             _lib.call("rtk_cost_volume_split_train", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
                       W.wd.data_ptr(), W.split.data_ptr(), W.b2.data_ptr(), W.b3.data_ptr(), W.wn, out.data_ptr(), 256, acts[0].data_ptr(),
                       acts[1].data_ptr(), acts[2].data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), _stream())
@@ -665,7 +673,7 @@ class _CostVolume(torch.autograd.Function):
         dp1 = torch.empty(B * n1, 256, dtype=torch.float32, device=dev)
         dpd = torch.empty(B * n1, 3, 256, dtype=torch.float32, device=dev)
         dbr = torch.empty(B * n1, 512, dtype=torch.float32, device=dev)       # per-query neighbour sums of dz3 | dz2
-        if CV_SPLIT:
+        if W.is_split:
             _lib.call("rtk_cost_volume_bwd_split", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), W.split[2 * _SPLIT_IMAGE:].data_ptr(),
                       W.wn, dout.data_ptr(), 256, a3.data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), dz1.data_ptr(), dz2.data_ptr(),
                       dz3.data_ptr(), dq3.data_ptr(), d4.data_ptr(), dp1.data_ptr(), dpd.data_ptr(), dt2.data_ptr(), dbr.data_ptr(), _stream())
@@ -711,7 +719,7 @@ def time_cost_volume_bwd(batch, n, dev, iters=10):
     knn = torch.randint(0, n, (B, n, 16), device=dev, generator=g)
     dout = r(B * n, 256)
     w2, w3 = r(256, 256) * 0.06, r(256, 256) * 0.06
-    W = _CvWeights(r(256, 3), w2, r(256), w3, r(256), r(8, 3), r(8), r(8, 8), r(8), r(256, 8), r(256), backward=True)
+    W = _CvWeights(r(256, 3), w2, r(256), w3, r(256), r(8, 3), r(8), r(8, 8), r(8), r(256, 8), r(256), backward=True, split=_cv_split(B * n))
     acts = r(3, M, 256)
     masks = torch.randint(-2 ** 62, 2 ** 62, (2, M, 4), device=dev, generator=g)
     big = torch.empty(4, M, 256, device=dev)
@@ -721,7 +729,7 @@ def time_cost_volume_bwd(batch, n, dev, iters=10):
     st = _stream()
 
     def launch():
-        if CV_SPLIT:
+        if W.is_split:
             _lib.call("rtk_cost_volume_bwd_split", B, n, n, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), W.split[2 * _SPLIT_IMAGE:].data_ptr(),
                       W.wn, dout.data_ptr(), 256, acts[2].data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), big[0].data_ptr(),
                       big[1].data_ptr(), big[2].data_ptr(), big[3].data_ptr(), d4.data_ptr(), dp1.data_ptr(), dpd.data_ptr(), dt2.data_ptr(),
