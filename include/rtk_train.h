@@ -294,6 +294,14 @@ RTK_EXPORT int rtk_backbone_loss(int b, int n, const float *pc1, const float *fl
                                  const unsigned char *gt_cls, int gt_cls_stride, int pretrain, float *items, float *dflow, float *dcls,
                                  rtk_stream_t stream);
 
+/* Adam (torch.optim.Adam semantics: L2 weight decay in the gradient, bias-corrected, no amsgrad; main.py:61) over n_tensors fp32
+ * tensors in one launch.  table: n_tensors rows of seven 64-bit words {param, grad, exp_avg, exp_avg_sq, numel, first workgroup,
+ * step}, 4096 elements per workgroup, total_blocks = sum over tensors of ceil(numel / 4096); step: the parameter's own device
+ * scalar (float), the number of steps it has taken -- the kernel uses step + 1 and advances it.  lr_ptr (device scalar)
+ * overrides lr when not NULL.  ticket: device int, zero (the kernel leaves it zero). */
+RTK_EXPORT int rtk_adam_multi(int n_tensors, const void *table, long total_blocks, const float *lr_ptr, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int *ticket, rtk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -770,3 +770,35 @@ def test_split_packer_transposed():
     img = torch.empty(3 * 256 * 256, dtype=torch.int16, device=DEV)
     _lib.call("rtk_pack_split_layer", 256, 256, w.data_ptr(), 1, img.data_ptr(), F._stream())
     assert torch.equal(img, F.pack_layer_split(w.t().contiguous()))
+
+
+@pytest.mark.gpu
+def test_single_launch_adam_matches_torch_adam():
+    """ratrack_amd.optim.FusedAdam against torch.optim.Adam (the reference's optimizer, main.py:61) over several steps: ragged tensor
+    sizes (partial last workgroups), a parameter that has no gradient at first and gets one later, a decaying learning rate held in
+    a device tensor (StepLR), weight decay."""
+    from ratrack_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    shapes = [(5,), (64, 64), (4097,), (3, 7, 11), (256, 515), (1,)]
+    ref = [torch.randn(*s, device=DEV).requires_grad_(True) for s in shapes]
+    got = [p.detach().clone().requires_grad_(True) for p in ref]
+    o_ref = torch.optim.Adam(ref, lr=1e-2, weight_decay=1e-3)
+    lr = torch.tensor(1e-2, device=DEV)
+    o_got = FusedAdam(got, lr=lr, weight_decay=1e-3)
+    s_ref = torch.optim.lr_scheduler.StepLR(o_ref, step_size=1, gamma=0.9)
+    s_got = torch.optim.lr_scheduler.StepLR(o_got, step_size=1, gamma=0.9)
+    for it in range(6):
+        for k, (a, b) in enumerate(zip(ref, got)):
+            if k == 3 and it < 2:
+                a.grad = b.grad = None                                        # skipped by both, moments untouched
+                continue
+            gr = torch.randn_like(a)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        o_ref.step(); o_got.step()
+        s_ref.step(); s_got.step()
+    assert o_got._steps.tolist() == [6.0, 6.0, 6.0, 4.0, 6.0, 6.0] and int(o_got._ticket) == 0      # per-parameter counts, as torch's
+    for a, b in zip(ref, got):
+        np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-5, atol=1e-7)
+    # state layout of torch.optim.Adam
+    st = o_got.state_dict()["state"]
+    assert set(st[0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
