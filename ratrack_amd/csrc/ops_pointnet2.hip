@@ -483,8 +483,12 @@ extern "C" int rtk_gather_points_grad(int b, int c, int n, int npoint, const flo
 // index order -- the "first nsample in index order" semantics without any serial scan -- and the
 // scan stops (wave-uniformly) once nsample hits are found.
 // ------------------------------------------------------------------------------------------------
+#ifndef BQ_WAVES
 #define BQ_WAVES 4
-#define BQ_CENTROIDS_PER_WAVE 8
+#endif
+#ifndef BQ_CENTROIDS_PER_WAVE
+#define BQ_CENTROIDS_PER_WAVE 2      // (8: 24-33 us per launch, 2: 14-18 -- the per-centroid scan is a serial chain, more waves hide it)
+#endif
 
 template <bool USE_LDS>
 __global__ __launch_bounds__(64 * BQ_WAVES) void ball_query_kernel(int n, int m, float radius2, int nsample,
@@ -568,12 +572,15 @@ __global__ __launch_bounds__(64 * BQ_WAVES) void ball_query_pair_kernel(int n, i
         sy[k] = xyz[k * 3 + 1];
         sz[k] = xyz[k * 3 + 2];
     }
+    // the coordinates of all of this wave's centroids in ONE round trip (lane l: component l % 3 of centroid l / 3), handed out by
+    // shuffles: fetched at the top of each iteration they were eight dependent global-load latencies per wave -- most of the kernel
+    float cq = 0.f;
+    if (lane < 3 * BQ_CENTROIDS_PER_WAVE && c0 + lane / 3 < climit) cq = new_xyz[((size_t)bs * m + c0 + lane / 3) * 3 + lane % 3];
     __syncthreads();
     for (int ci = 0; ci < BQ_CENTROIDS_PER_WAVE; ++ci) {
         const int pt = c0 + ci;
         if (pt >= climit) break;
-        const float *q = new_xyz + ((size_t)bs * m + pt) * 3;
-        const float qx = q[0], qy = q[1], qz = q[2];
+        const float qx = __shfl(cq, 3 * ci, 64), qy = __shfl(cq, 3 * ci + 1, 64), qz = __shfl(cq, 3 * ci + 2, 64);
         int *oa = idxa + ((size_t)bs * m + pt) * nsa;
         int *ob = idxb + ((size_t)bs * m + pt) * nsb;
         int ca = 0, cb = 0, fa = -1, fb = -1;
