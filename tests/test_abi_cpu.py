@@ -40,6 +40,7 @@ def test_library_builds_loads_and_exports_everything():
     # the Python binding knows every compute entry point the headers declare (fused.py registers rtk_fused.h's)
     import ratrack_amd.fused  # noqa: F401
     import ratrack_amd.train_ops  # noqa: F401  (registers rtk_train.h)
+    import ratrack_amd.optim  # noqa: F401  (rtk_adam_multi)
     bound = set(_lib.SIGNATURES) | {"rtk_last_error", "rtk_version"}
     assert set(declared_symbols()) <= bound, set(declared_symbols()) - bound
 
