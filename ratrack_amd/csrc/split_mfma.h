@@ -15,8 +15,8 @@
 //     lane = 32 hh + col   (hh = 0..1, col = 0..31)        H[ch = 32 v + 8 q + 4 hh + r][position col] = h[4 v + q][r]
 //
 // A k-step (16 input channels) takes q in {q0, q0 + 1} of one 32-channel block: lane supplies B[k = 8 hh + t][col],
-// t = 4 (q - q0) + r -- eight values it already holds.  The weights are packed on the host with the same permutation
-// (pack_layer_split() in ratrack_amd/fused.py), one 1 KiB fragment (64 lanes x 8 bf16) per (k-step, 32-row block, piece):
+// t = 4 (q - q0) + r -- eight values it already holds.  The weights are packed with the same permutation
+// (rtk_pack_split_layer on the device; pack_layer_split() in ratrack_amd/fused.py is its host restatement), one 1 KiB fragment (64 lanes x 8 bf16) per (k-step, 32-row block, piece):
 //
 //     frag[s][v][p][lane = 32 hh + i][t] = piece_p( W[32 v + i][32 (s / 2) + 16 (s % 2) + 8 (t / 4) + 4 hh + t % 4] )
 #pragma once
@@ -49,9 +49,9 @@ constexpr int SPLIT_NF = SPLIT_KS * SPLIT_VB * 3;      // fragments (KiB) of one
 // The weight stream with LDS reads the compiler does not track.  With LDS-DMA (global_load_lds) in flight hipcc turns every
 // wait for an LDS read into s_waitcnt lgkmcnt(0) -- the reads issued a group ahead are waited for at once and every group
 // pays the LDS latency (one wave per SIMD: nothing else hides it; measured 0.6 of the MFMA issue rate).  Here the reads are
-// inline asm and the waits are counted by hand: LDS reads return in order, so "at most 6 outstanding" after issuing the
-// next group's six reads means the current group's six have landed (scalar loads that may share the counter only make the
-// wait longer, never shorter than needed: see DESIGN.md section 4.6).
+// inline asm, invisible to the compiler's waitcnt pass, and the group step that uses them waits itself: lgkmcnt(0) at its top
+// (lds_wait below) -- the reads were issued a whole group step earlier and have landed, and none of the next group's is
+// outstanding yet, so the wait is free and cannot be too short.
 template <int NW, int F, int NF>
 struct WStreamA : WStream<NW, F, NF> {
     using Base = WStream<NW, F, NF>;
