@@ -188,8 +188,15 @@ __device__ __forceinline__ f4 f4_max(f4 a, f4 b) { return (f4){fmaxf(a.x, b.x), 
 __device__ __forceinline__ f4 f4_relu(f4 a) { return (f4){fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)}; }
 __device__ __forceinline__ f4 leaky4(f4 t) { return (f4){fmaxf(t.x, 0.1f * t.x), fmaxf(t.y, 0.1f * t.y), fmaxf(t.z, 0.1f * t.z), fmaxf(t.w, 0.1f * t.w)}; }
 
+// Register cap of the forward kernel.  Left alone (512) hipcc spreads the tile over 500 registers and nothing else fits on the SIMD;
+// capped it allocates 404 without a spill, and the small-register geometry kernels of the other batches in flight (FPS 20, ball
+// query 16, three-NN 12, kNN 40 registers) can share the SIMDs with it: +0.7 % frame-pairs/s, the kernel alone unchanged.
+#ifndef CV_FWD_VGPRS
+#define CV_FWD_VGPRS 448
+#endif
 template <bool SAVE>
-__global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1))) void cost_volume_split_kernel(const CvSplitParams P) {
+__global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1), amdgpu_num_vgpr(CV_FWD_VGPRS)))
+void cost_volume_split_kernel(const CvSplitParams P) {
     __shared__ __attribute__((aligned(16))) f4 s_w[2 * SP_F * 64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hh = lane >> 5, col = lane & 31, pp = col >> 4,
               j = col & 15;      // wave index in an SGPR: the DMA's LDS destination (M0) is then scalar arithmetic
