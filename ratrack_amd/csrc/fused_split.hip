@@ -456,10 +456,12 @@ struct SaSplitParams {
     const int *src_nuniq, *dst_nuniq;
 };
 
-// Register cap: at 104 (105 / 102 / 86 allocated, no spill, against 136 / 132 / 120) the two 16-neighbour shapes fit on a SIMD next
-// to the forward cost volume of another batch (404 registers): +2.3 % frame-pairs/s in the pipelined forward.
+// Register cap (experiment knob, default: none).  At 104 the 16-neighbour shapes would fit on a SIMD next to another batch's forward
+// cost volume (+2.3 % frame-pairs/s measured) -- but the <16, 64> instance then computes WRONG maxima: with the accumulators in
+// arch VGPRs the last MFMA feeds the DPP inline asm of row_max_group_f4 directly, and the hazard recognizer does not see into
+// inline asm (an MFMA result needs up to 19 wait states before a VALU read).  Caught by test_sa_scale_split_agrees_with_fp32_mfma_kernel.
 #ifndef SA_SPLIT_VGPRS
-#define SA_SPLIT_VGPRS 104
+#define SA_SPLIT_VGPRS 256
 #endif
 template <int NS, int C1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(SA_SPLIT_VGPRS))) void sa_scale_split_kernel(const SaSplitParams P) {
