@@ -456,12 +456,11 @@ struct SaSplitParams {
     const int *src_nuniq, *dst_nuniq;
 };
 
-// Register cap (experiment knob, default: none).  At 104 the 16-neighbour shapes would fit on a SIMD next to another batch's forward
-// cost volume (+2.3 % frame-pairs/s measured) -- but the <16, 64> instance then computes WRONG maxima: with the accumulators in
-// arch VGPRs the last MFMA feeds the DPP inline asm of row_max_group_f4 directly, and the hazard recognizer does not see into
-// inline asm (an MFMA result needs up to 19 wait states before a VALU read).  Caught by test_sa_scale_split_agrees_with_fp32_mfma_kernel.
+// Register cap: at 104 (105 / 102 / 86 allocated, no spill, against 136 / 132 / 120) the 16-neighbour shapes fit on a SIMD next to
+// another batch's forward cost volume (404 registers): +2 % frame-pairs/s in the pipelined forward.  (The first capped build
+// computed wrong maxima for <16, 64>: see the epilogue.)
 #ifndef SA_SPLIT_VGPRS
-#define SA_SPLIT_VGPRS 256
+#define SA_SPLIT_VGPRS 104
 #endif
 template <int NS, int C1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(SA_SPLIT_VGPRS))) void sa_scale_split_kernel(const SaSplitParams P) {
@@ -529,10 +528,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(SA_SPLIT_VGPRS)
         for (int v = 0; v < 2; ++v)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                f4 m = (f4){acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]};
+                // bias BEFORE the maximum (max_j(x_j) + b == max_j(x_j + b) bit for bit: rounding is monotonic): the add is a VALU
+                // instruction the compiler knows, so it inserts the wait states an MFMA result needs before a VALU read; the inline-asm
+                // DPP reduction behind it only needs the VALU -> DPP ones its own s_nop covers.  Fed by the accumulators directly
+                // (register-capped build: accumulators in arch VGPRs) the asm computed wrong maxima.
+                f4 m = (f4){acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]} +
+                       *reinterpret_cast<const f4 *>(P.bias2 + 32 * v + 8 * q + 4 * hh);
                 row_max_group_f4<16>(m);
                 if constexpr (NS == 32) m = f4_max(m, (f4){__shfl_xor(m.x, 16, 64), __shfl_xor(m.y, 16, 64), __shfl_xor(m.z, 16, 64), __shfl_xor(m.w, 16, 64)});
-                m = f4_relu(m + *reinterpret_cast<const f4 *>(P.bias2 + 32 * v + 8 * q + 4 * hh));
+                m = f4_relu(m);
                 if (valid && slot == 0) *reinterpret_cast<f4 *>(o + 32 * v + 8 * q) = m;
             }
     }
