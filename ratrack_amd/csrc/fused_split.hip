@@ -456,14 +456,14 @@ struct SaSplitParams {
     const int *src_nuniq, *dst_nuniq;
 };
 
-// Register cap: at 104 (105 / 102 / 86 allocated, no spill, against 136 / 132 / 120) the 16-neighbour shapes fit on a SIMD next to
-// another batch's forward cost volume (404 registers): +2 % frame-pairs/s in the pipelined forward.  (The first capped build
-// computed wrong maxima for <16, 64>: see the epilogue.)
-#ifndef SA_SPLIT_VGPRS
-#define SA_SPLIT_VGPRS 104
+// Register budget: asked for five waves per SIMD the three shapes allocate 86 / 84 / 86 registers without a spill (136 / 132 / 120
+// unconstrained) and fit on a SIMD next to another batch's forward cost volume (404 of 512): +2-3 % frame-pairs/s in the
+// pipelined forward.  (The first capped build computed wrong maxima: see the epilogue.)
+#ifndef SA_SPLIT_WAVES
+#define SA_SPLIT_WAVES 5
 #endif
 template <int NS, int C1>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(SA_SPLIT_VGPRS))) void sa_scale_split_kernel(const SaSplitParams P) {
+__global__ __launch_bounds__(256, SA_SPLIT_WAVES) void sa_scale_split_kernel(const SaSplitParams P) {
     constexpr int KS = C1 / 16, VB1 = C1 / 32, NFR = KS * 2 * 3, CPT = 32 / NS;      // k-steps, 32-blocks of layer 1, fragments, centroids per tile
     __shared__ __attribute__((aligned(16))) f4 s_img[NFR * 64];
     const int lane = threadIdx.x & 63, hh = lane >> 5, col = lane & 31, pp = col / NS, slot = col % NS;
