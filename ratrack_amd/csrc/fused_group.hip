@@ -726,7 +726,10 @@ struct PcParams {
     int gx;                 // > 0: XCD-aware 1-D grid (rtk_decode_block)
 };
 
-__global__ __launch_bounds__(256) void patch_cost_kernel(const PcParams P) {
+// Register budget: five waves per SIMD and the block loop NOT unrolled (58 registers; fully unrolled hipcc hoists all sixteen row
+// loads and WeightNet fragments to the top: 200 registers, two waves per SIMD).  69.9 -> 54.6 us alone, and the kernel fits on a
+// SIMD next to another batch's forward cost volume: +1.5 % frame-pairs/s.
+__global__ __launch_bounds__(256, 5) void patch_cost_kernel(const PcParams P) {
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     int b, bx, nbx;                                                 // one sample per workgroup, its points strided
     rtk_decode_block(P.gx, b, bx, nbx);
@@ -736,7 +739,7 @@ __global__ __launch_bounds__(256) void patch_cost_kernel(const PcParams P) {
         const float bop = g < 3 ? __fsub_rn(P.xyz[nb * 3 + g], P.xyz[i * 3 + g]) : 1.0f;
         const f4 t2 = weightnet_hidden(P.wn, lane, g, bop);
         const float *fr = P.feat + nb * P.feat_pitch + 4 * g;
-#pragma unroll
+#pragma unroll 1
         for (int v = 0; v < CV_V; ++v) {
             const f4 w = weightnet_out(P.wn, lane, g, v, t2);
             const f4 f = *reinterpret_cast<const f4 *>(fr + 16 * v);      // (requesting the whole row up front: 122 vs 71 us -- registers)
