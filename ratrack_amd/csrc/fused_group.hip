@@ -113,13 +113,16 @@ __global__ __launch_bounds__(256) void sa_scale_kernel(const SaParams P) {
                 for (int v = 0; v < V3; ++v) best[v] = t == 0 ? a3[v] : f4_max(best[v], a3[v]);
             }
         }
-        // max over the neighbours of each centroid (DPP within the 16-lane row), then bias + ReLU
+        // bias, max over the neighbours of each centroid (DPP within the 16-lane row), ReLU.  The bias goes in BEFORE the maximum
+        // (max(x) + b == max(x + b) bit for bit: rounding is monotonic): with one tile per centroid best[] is the raw MFMA result, and
+        // the inline-asm reduction must sit behind a VALU instruction the compiler knows -- it inserts no MFMA -> VALU wait states in
+        // front of inline asm (the lesson of the register-capped split kernel).
         const float *bl = V3 ? P.bias3 : P.bias2;
 #pragma unroll
         for (int v = 0; v < VL; ++v) {
-            f4 m = best[v];
+            f4 m = best[v] + bias_frag(bl, v, g);
             row_max_group_f4<(NS > 16 ? 16 : NS)>(m);
-            best[v] = f4_relu(m + bias_frag(bl, v, g));
+            best[v] = f4_relu(m);
         }
         if (valid && slot0 == 0) {
             float *o = P.out + (long)c * P.out_pitch + P.out_offset + 4 * g;
