@@ -52,6 +52,33 @@ class _Interp(torch.autograd.Function):
         return g, None, None
 
 
+# ---- float64 arbiter mode -------------------------------------------------------------------------
+# Feed float64 weights / features and the graph runs in float64: the INDEX-producing ops (FPS, ball query, three-NN, kNN) still
+# see the fp32 coordinates (coordinates are fp32 values, the casts are exact), so the geometry is that of the fp32 run and the
+# result arbitrates between two fp32 implementations (tests: "which side does the rounding sit on").  Value ops (group,
+# interpolate) become differentiable torch gathers.
+
+def _f32(t):
+    return t if t.dtype == torch.float32 else t.float()
+
+
+def _group_any(features, idx):
+    if features.dtype == torch.float32:
+        return _Group.apply(features.contiguous(), idx)
+    B, C, _ = features.shape
+    _, M, ns = idx.shape
+    return torch.gather(features, 2, idx.long().view(B, 1, M * ns).expand(-1, C, -1)).view(B, C, M, ns)
+
+
+def _interp_any(feats, idx, weight):
+    if feats.dtype == torch.float32:
+        return _Interp.apply(feats.contiguous(), idx, weight)
+    B, C, _ = feats.shape
+    n = idx.shape[1]
+    g = torch.gather(feats, 2, idx.long().view(B, 1, n * 3).expand(-1, C, -1)).view(B, C, n, 3)
+    return (g * weight.unsqueeze(1)).sum(-1)
+
+
 # ---- building blocks ------------------------------------------------------------------------------
 
 def _bn(x, sd, p, training):
@@ -75,23 +102,23 @@ def shared_mlp(x, sd, prefix, training):
 
 def query_and_group(radius, nsample, xyz, new_xyz, features, trace=None):
     """lib/pointnet2_utils.py:269-292: [grouped_xyz - centroid (3) || grouped features (C)]."""
-    idx = P.ball_query(radius, nsample, xyz, new_xyz)
+    idx = P.ball_query(radius, nsample, _f32(xyz), _f32(new_xyz))
     if trace is not None:
         trace.setdefault("ball_idx", []).append(idx)
     xyz_trans = xyz.transpose(1, 2).contiguous()
-    grouped_xyz = P.group(xyz_trans, idx)
+    grouped_xyz = P.group(xyz_trans, idx) if xyz.dtype == torch.float32 else _group_any(xyz_trans, idx)
     grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
-    grouped_features = _Group.apply(features.contiguous(), idx)
+    grouped_features = _group_any(features.contiguous(), idx)
     return torch.cat([grouped_xyz, grouped_features], dim=1)
 
 
 def sa_module_msg(sd, prefix, xyz, features, npoint, radii, nsamples, training, trace=None):
     """lib/pointnet2_modules.py:19-55 (PointnetSAModuleMSG, max_pool)."""
     xyz_flipped = xyz.transpose(1, 2).contiguous()
-    fps_idx = P.fps(xyz, npoint)
+    fps_idx = P.fps(_f32(xyz), npoint)
     if trace is not None:
         trace.setdefault("fps_idx", []).append(fps_idx)
-    new_xyz = P.gather(xyz_flipped, fps_idx).transpose(1, 2).contiguous()
+    new_xyz = P.gather(_f32(xyz_flipped), fps_idx).transpose(1, 2).contiguous().to(xyz.dtype)
     outs = []
     for i, (r, ns) in enumerate(zip(radii, nsamples)):
         g = query_and_group(r, ns, xyz, new_xyz, features, trace)
@@ -103,14 +130,14 @@ def sa_module_msg(sd, prefix, xyz, features, npoint, radii, nsamples, training, 
 
 def fp_module(sd, prefix, unknown, known, unknown_feats, known_feats, training, trace=None):
     """lib/pointnet2_modules.py:129-158 (PointnetFPModule)."""
-    d2, idx = P.three_nn(unknown, known)
+    d2, idx = P.three_nn(_f32(unknown), _f32(known))
     if trace is not None:
         trace.setdefault("three_nn", []).append((d2, idx))
-    dist = torch.sqrt(d2)
+    dist = torch.sqrt(d2.to(unknown.dtype))
     dist_recip = 1.0 / (dist + 1e-8)
     norm = torch.sum(dist_recip, dim=2, keepdim=True)
     weight = dist_recip / norm
-    interp = _Interp.apply(known_feats.contiguous(), idx, weight)
+    interp = _interp_any(known_feats.contiguous(), idx, weight)
     x = torch.cat([interp, unknown_feats], dim=1) if unknown_feats is not None else interp
     x = shared_mlp(x.unsqueeze(-1), sd, prefix + ".mlp", training)
     return x.squeeze(-1)
@@ -166,7 +193,7 @@ def feature_correlator(sd, prefix, pc1, pc2, feature1, feature2, nsample=16, tra
     feature2 = feature2.permute(0, 2, 1)
     D1 = feature1.shape[2]
     # point-to-patch volume
-    knn_idx = P.knn_point(nsample, pc2, pc1)
+    knn_idx = P.knn_point(nsample, _f32(pc2), _f32(pc1))
     if trace is not None:
         trace.setdefault("knn_idx", []).append(knn_idx)
     neighbor_xyz = index_points(pc2, knn_idx)
@@ -179,7 +206,7 @@ def feature_correlator(sd, prefix, pc1, pc2, feature1, feature2, nsample=16, tra
     weights = weight_net(sd, prefix + ".weightnet1", direction_xyz.permute(0, 3, 2, 1))
     x = torch.sum(weights * x, dim=2)  # (B, C, N)
     # patch-to-patch cost
-    knn_idx = P.knn_point(nsample, pc1, pc1)
+    knn_idx = P.knn_point(nsample, _f32(pc1), _f32(pc1))
     if trace is not None:
         trace["knn_idx"].append(knn_idx)
     neighbor_xyz = index_points(pc1, knn_idx)
@@ -238,7 +265,7 @@ def backbone(sd, pc1, pc2, feature1, feature2, h, npoint=512, training=False, tr
     (flow, h, cls, cor_features, pc1_features, pc2_features, prop_features)."""
     B = pc1.shape[0]
     if h is None:
-        h = torch.zeros(5, B, 128)
+        h = torch.zeros(5, B, 128, dtype=feature1.dtype)
     _, f1 = pn_head(sd, "pn_head.", pc1.permute(0, 2, 1).contiguous(), feature1, npoint, training, trace)
     _, f2 = pn_head(sd, "pn_head.", pc2.permute(0, 2, 1).contiguous(), feature2, npoint, training,
                     None if trace is None else trace.setdefault("pc2", {}))
@@ -263,7 +290,7 @@ def flow_loss(pc1_warp, gt_flow):
 def motion_seg_loss(pred_cls, gt_cls):
     """losses/loss.py:124-146: 0.4*BCE(pos) + 0.6*BCE(neg); gt_cls bool (N,), pred (1,N)."""
     t, f = gt_cls == True, gt_cls == False  # noqa: E712
-    g = gt_cls.float().unsqueeze(0)
+    g = gt_cls.to(pred_cls.dtype).unsqueeze(0)
     bce = torch.nn.BCELoss(reduction="mean")
     return 0.4 * bce(pred_cls[:, t], g[:, t]) + 0.6 * bce(pred_cls[:, f], g[:, f])
 

@@ -8,7 +8,7 @@ from oracle import pointnet2_ref as P
 from oracle import track4d_ref as R
 from ratrack_amd import synth
 
-from _util import EVAL_CASES, assert_close, inputs_of, load_case, reference_state_dict
+from _util import EVAL_CASES, REAL_CASES, assert_close, grad_report, inputs_of, load_case, reference_state_dict
 
 
 def test_inputs_regenerate_bit_exact():
@@ -21,7 +21,7 @@ def test_inputs_regenerate_bit_exact():
             assert np.array_equal(case["in_" + k], v), (name, k)
 
 
-@pytest.mark.parametrize("name", EVAL_CASES)
+@pytest.mark.parametrize("name", EVAL_CASES + REAL_CASES)
 def test_backbone_eval_matches_reference(name):
     case = load_case(name)
     sd = reference_state_dict()
@@ -47,7 +47,7 @@ def test_backbone_eval_matches_reference(name):
         mine = np.sort(trace["knn_idx"][i].numpy(), axis=-1)
         ok = case["knn_kth_gap_%d" % i] > 0
         assert np.array_equal(mine[ok], case["knn_set_%d" % i][ok]), i
-        if name != "eval_b1_n256_dups":
+        if name != "eval_b1_n256_dups" and name not in REAL_CASES:      # (the real radar frames contain a few exact duplicate points)
             assert ok.all()
 
     # floats
@@ -111,6 +111,68 @@ def test_train_step_matches_reference():
                 assert int(sd[key]) == int(case[k]), key
             else:
                 assert_close(sd[key].detach(), case[k], 1e-5, key)
+
+
+def _oracle_train_step(case, prefix="", dtype=torch.float32):
+    sd = reference_state_dict()
+    sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
+    names = [str(k) for k in case[prefix + "grad_names"]]
+    for k in names:
+        sd[k].requires_grad_(True)
+    pc1, pc2, f1, f2 = (t.to(dtype) for t in inputs_of(case))
+    flow, h, cls, *_ = R.backbone(sd, pc1, pc2, f1, f2, None, training=True)
+    gt, gt_cls = torch.from_numpy(case["in_gt_warp"]).to(dtype), torch.from_numpy(case["in_gt_cls"])
+    B = pc1.shape[0]
+    total, acc = 0.0, {}
+    for b in range(B):
+        tb, it = R.track_4d_loss(pc1[b:b + 1] + flow[b:b + 1], cls[b:b + 1], gt[b:b + 1], gt_cls[b], pretrain=False)
+        total = total + tb / B
+        for k, v in it.items():
+            acc[k] = acc.get(k, 0.0) + float(v) / B
+    total.backward()
+    return sd, names, acc, flow.detach(), cls.detach()
+
+
+@pytest.mark.parametrize("name,prefix", [("train_b8_n256", "")] + [(n, "train/") for n in REAL_CASES])
+def test_train_step_gradient_tensors_match_reference(name, prefix):
+    """Round-3 fixtures: a B = 8 train step (batch-statistic BatchNorm over 8 samples; loss = batch mean of the reference's B = 1
+    loss) and B = 1 train steps on the reference's shipped radar frames (N1 != N2) -- losses, sampled gradient TENSORS of every
+    parameter, a whole-tensor probe product, BatchNorm running statistics.  Tolerance: 2e-3 of the tensor's largest element
+    (the fp32 reference itself sits up to 1.5e-3 from a float64 evaluation of the same step: `arb_fp32_oracle_relerr`)."""
+    case = load_case(name)
+    sd, names, acc, flow, cls = _oracle_train_step(case, prefix)
+    keys = [str(k) for k in case[prefix + "loss_keys"]]
+    np.testing.assert_allclose([acc[k] for k in keys], case[prefix + "loss_vals"], rtol=2e-5, atol=1e-7)
+    assert_close(flow, case[prefix + "flow"], 1e-5, "flow (train mode)")
+    assert_close(cls, case[prefix + "cls"], 1e-5, "cls (train mode)")
+    sub = {k[len(prefix):]: v for k, v in case.items() if k.startswith(prefix)} if prefix else case
+    rows = grad_report(sub, {k: (None if sd[k].grad is None else sd[k].grad.numpy()) for k in names})
+    assert len(rows) > 100
+    for r in rows:
+        assert r["e_ref"] <= (1.0 if r["zero"] else 2e-3), (r["name"], r["e_ref"])
+        # whole-tensor probe product: |<g - g_ref, u>| <= ||g - g_ref|| ||u||-ish; u uniform in [-1,1) has rms 0.577 per element
+        if not r["zero"]:
+            assert abs(r["probe"] - r["ref_probe"]) <= 5e-3 * r["ref_norm"], r
+    for k in sub:
+        if k.startswith("bn/"):
+            key = k[3:]
+            if key.endswith("num_batches_tracked"):
+                assert int(sd[key]) == int(sub[k]), key
+            else:
+                assert_close(sd[key].detach(), sub[k], 1e-5, key)
+
+
+def test_float64_arbiter_reproduces_the_fixture():
+    """The float64 evaluation stored in the fixtures (`arb_*`) is reproducible from the oracle alone, and the fp32 reference
+    gradients sit within 2e-3 of it (parameters with an exactly-zero gradient measured against the model's gradient scale)."""
+    case = load_case("real_549_1047")
+    sub = {k[len("train/"):]: v for k, v in case.items() if k.startswith("train/")}
+    sd, names, acc, flow, cls = _oracle_train_step(case, "train/", dtype=torch.float64)
+    assert abs(acc["Loss"] - float(sub["arb_loss"])) <= 1e-12
+    rows = grad_report(sub, {k: (None if sd[k].grad is None else sd[k].grad.numpy()) for k in names})
+    assert max(r["e_arb"] for r in rows) <= 1e-6                 # (float32 storage of the float64 values)
+    worst = max(rows, key=lambda r: r["e_ref"] / (1.0 if r["zero"] else 2e-3))
+    assert worst["e_ref"] <= (1.0 if worst["zero"] else 2e-3), worst
 
 
 def test_kernel_edge_cases():

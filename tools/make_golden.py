@@ -348,6 +348,182 @@ def forward_case(name, Track4D, args, rec, outdir):
     print("wrote %s (%d arrays)" % (name, len(out)))
 
 
+
+# ------------------------------------------------------------------------------------------------
+# round 3: gradient tensors, a batch that reaches the split-bf16 training kernels, real frames
+# ------------------------------------------------------------------------------------------------
+
+GRAD_SAMPLE = 1024          # elements kept per gradient tensor (flat, odd stride): every parameter, ~0.5 MB per fixture
+
+
+def grad_stride(numel):
+    s = -(-numel // GRAD_SAMPLE)
+    return s | 1 if s > 1 else 1
+
+
+def probe_vector(key, numel):
+    """Fixed pseudo-random direction in [-1, 1) for a parameter (raw PCG64 -> uniform, as synth.tensor_for_key)."""
+    return (2.0 * synth._uniform01("probe/" + key, numel, 77) - 1.0)
+
+
+def grad_records(named_grads, out, prefix="", samples=True):
+    """Per-parameter gradient records: L2 norm, the dot product with a fixed probe direction (covers the WHOLE tensor: a
+    wrong-direction gradient with the right norm fails it) and a flat odd-stride sample of the tensor itself."""
+    names, norms, probes = [], [], []
+    for k, g in named_grads:
+        names.append(k)
+        if g is None:
+            norms.append(-1.0)
+            probes.append(0.0)
+            continue
+        a = g.detach().cpu().numpy().astype(np.float64).ravel()
+        norms.append(float(np.sqrt((a * a).sum())))
+        probes.append(float((a * probe_vector(k, a.size)).sum()))
+        if samples:
+            out[prefix + "grad/" + k] = a[::grad_stride(a.size)].astype(np.float32)
+    if not prefix:
+        out["grad_names"] = np.array(names)
+    out[prefix + "grad_norms"] = np.array(norms, dtype=np.float64)
+    out[prefix + "grad_probes"] = np.array(probes, dtype=np.float64)
+
+
+def bn_records(sd, out, prefix="bn/"):
+    for k, v in sd.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            if k.startswith("pn_head.") or k.startswith("fd_layer.mse.") or k.startswith("fd_layer.fp.") or k.startswith("fd_layer.cp."):
+                out[prefix + k] = npf(v)
+        if k.endswith("num_batches_tracked") and (k.startswith("pn_head.sa1.mlps.0.layer0") or k.startswith("fd_layer.fp.sf_mlp.0")):
+            out[prefix + k] = v.numpy()
+
+
+def batch_mean_loss(ref_loss, pc1, pc2, pc1_warp, cls, gt, gt_cls, pretrain):
+    """The reference's loss is B = 1 code (losses/loss.py:89 takes batch element 0, :131-142 index a (1,N) target); for a batch
+    it is called per sample on B = 1 slices and averaged -- ratrack_amd.loss.backbone_loss is defined as exactly this."""
+    keys = ["Loss", "SceneFlowLoss", "TrackingLoss", "SegLoss"]
+    tot, acc = 0.0, {k: 0.0 for k in keys}
+    B = pc1.shape[0]
+    for b in range(B):
+        s = slice(b, b + 1)
+        t, it = ref_loss.track_4d_loss(None, None, {}, {}, None, None, None, pc1[s], pc2[s], pc1_warp[s], cls[s], gt[s], [],
+                                       None, gt_cls[b], None, None, None, pretrain=pretrain)
+        tot = tot + t / B
+        for k in keys:
+            acc[k] = acc[k] + (it[k] if torch.is_tensor(it[k]) else torch.tensor(float(it[k]))) / B
+    return tot, acc, keys
+
+
+def arbiter_train_step(d, out, pretrain=False, samples=True):
+    """The same train step through oracle/track4d_ref.py in FLOAT64 (index ops on the fp32 coordinates: same geometry) -- the
+    arbiter between two fp32 implementations.  Also the fp32 oracle's own distance to it (the noise floor of an fp32 train
+    step at this batch size)."""
+    from oracle import track4d_ref as R
+    res = {}
+    for tag, dt in (("f64", torch.float64), ("o32", torch.float32)):
+        net = build_net(_REF["Track4D"], _REF["args"], train=True)
+        sd = {k: (v.detach().clone().to(dt) if v.is_floating_point() else v.detach().clone()) for k, v in net.state_dict().items()}
+        names = [k for k, _ in net.named_parameters()]
+        for k in names:
+            sd[k].requires_grad_(True)
+        t = {k: torch.from_numpy(v).to(dt) for k, v in d.items() if k != "gt_cls"}
+        flow, h, cls, *_ = R.backbone(sd, t["pc1"], t["pc2"], t["feature1"], t["feature2"], None, training=True)
+        warp = t["pc1"] + flow
+        gcls = torch.from_numpy(d["gt_cls"])
+        B = warp.shape[0]
+        total = 0.0
+        for b in range(B):
+            tb, _ = R.track_4d_loss(warp[b:b + 1], cls[b:b + 1], t["gt_warp"][b:b + 1], gcls[b], pretrain=pretrain)
+            total = total + tb / B
+        total.backward()
+        res[tag] = (float(total), [(k, sd[k].grad) for k in names], flow.detach(), cls.detach())
+    grad_records(res["f64"][1], out, prefix="arb_", samples=samples)
+    out["arb_loss"] = np.float64(res["f64"][0])
+    out["arb_flow"], out["arb_cls"] = res["f64"][2].numpy().astype(np.float32), res["f64"][3].numpy().astype(np.float32)
+    # noise floor: fp32 oracle vs float64, per parameter, relative to the tensor's largest element
+    floor = []
+    for (k, g64), (_, g32) in zip(res["f64"][1], res["o32"][1]):
+        if g64 is None:
+            floor.append(-1.0)
+            continue
+        floor.append(float((g32.double() - g64).abs().max() / g64.abs().max().clamp_min(1e-300)))
+    out["arb_fp32_oracle_relerr"] = np.array(floor, dtype=np.float64)
+    return res
+
+
+def train_batch_case(name, d, ref, outdir, pretrain=False):
+    """B > 1 train step through the REFERENCE graph: batch-statistic BatchNorm over the batch, loss = batch mean of the
+    reference's B = 1 loss.  At B = 8 x N = 256 = 2 048 query points the product's split-bf16 training kernels run."""
+    rec, Track4D, args, mu, ref_loss = ref
+    net = build_net(Track4D, args, train=True)
+    out, tensors = run_backbone(net, rec, mu, d, capture=False)
+    out = {k: v for k, v in out.items() if not k.endswith("_s8")}          # (the strided activation samples are eval-case material)
+    flow, h_out, cls = tensors[0], tensors[1], tensors[2]
+    pc1, pc2 = torch.from_numpy(d["pc1"]), torch.from_numpy(d["pc2"])
+    gt, gt_cls = torch.from_numpy(d["gt_warp"]), torch.from_numpy(d["gt_cls"])
+    total, items, keys = batch_mean_loss(ref_loss, pc1, pc2, pc1 + flow, cls, gt, gt_cls, pretrain)
+    out["loss_keys"] = np.array(keys)
+    out["loss_vals"] = np.array([float(items[k]) for k in keys], dtype=np.float64)
+    net.zero_grad()
+    total.backward()
+    grad_records([(k, p.grad) for k, p in net.named_parameters()], out)
+    bn_records(net.state_dict(), out)
+    arbiter_train_step(d, out, pretrain)
+    save(os.path.join(outdir, name + ".npz"), d, out)
+
+
+REAL_FRAMES = ["00549", "01047", "01201"]
+
+
+def real_pair(later, earlier, seed):
+    """A frame pair of two of the radar frames the reference ships (different sizes, as every real consecutive pair) + seeded
+    stand-in GT of the right shapes (GT generation is pinned separately, tools/make_golden_gt.py)."""
+    from ratrack_amd import vod_io
+    ex = os.path.join(ROOT, "tests", "golden", "vod_example")
+    a = vod_io.load_radar_bin(os.path.join(ex, "radar_%s.bin" % later))
+    b = vod_io.load_radar_bin(os.path.join(ex, "radar_%s.bin" % earlier))
+    pc1, pc2, f1, f2 = vod_io.frame_pair_tensors(a, b)
+    rng = np.random.Generator(np.random.PCG64(4321 + seed))
+    n1 = pc1.shape[2]
+    gt_warp = pc1.numpy() + np.array([-0.8, 0.0, 0.0], np.float32).reshape(1, 3, 1) + rng.normal(0, 0.2, (1, 3, n1)).astype(np.float32)
+    gt_cls = (np.abs(a[:, 5]) > 1.0).reshape(1, n1)              # |compensated radial velocity| > 1 m/s
+    assert 0 < gt_cls.sum() < n1
+    return {"pc1": pc1.numpy(), "pc2": pc2.numpy(), "feature1": f1.numpy(), "feature2": f2.numpy(),
+            "gt_warp": gt_warp.astype(np.float32), "gt_cls": gt_cls}
+
+
+def real_case(name, later, earlier, seed, ref, ref_main_utils, outdir, arb_samples=True):
+    """B = 1, N1 != N2 through the reference graph, as the reference's epoch loop runs it (main_utils.py:76-80,127): one
+    eval-mode forward (everything eval_case captures) and one train step (loss, gradients, BatchNorm statistics)."""
+    rec, Track4D, args, mu, ref_loss = ref
+    d = real_pair(later, earlier, seed)
+    net = build_net(Track4D, args, train=False)
+    with torch.no_grad():
+        out, tensors = run_backbone(net, rec, mu, d)
+        flow, h_out, cls = tensors[0], tensors[1], tensors[2]
+        out2, _ = run_backbone(net, rec, mu, d, h=h_out, capture=False)
+        out["flow_step2"], out["h_out_step2"] = out2["flow"], out2["h_out"]
+        pc1 = torch.from_numpy(d["pc1"])
+        sf = ref_main_utils.eval_scene_flow(pc1, pc1 + flow, torch.from_numpy(d["gt_warp"]), torch.from_numpy(~d["gt_cls"]).float())
+        out["metric_sf_keys"] = np.array(sorted(sf.keys()))
+        out["metric_sf_vals"] = np.array([sf[k] for k in sorted(sf.keys())], dtype=np.float64)
+    # train step on the same pair
+    net = build_net(Track4D, args, train=True)
+    tout, tensors = run_backbone(net, rec, mu, d, capture=False)
+    flow, h_out, cls = tensors[0], tensors[1], tensors[2]
+    pc1, pc2 = torch.from_numpy(d["pc1"]), torch.from_numpy(d["pc2"])
+    total, items, keys = batch_mean_loss(ref_loss, pc1, pc2, pc1 + flow, cls, torch.from_numpy(d["gt_warp"]), torch.from_numpy(d["gt_cls"]), False)
+    tr = {"flow": tout["flow"], "cls": tout["cls"], "h_out": tout["h_out"], "loss_keys": np.array(keys),
+          "loss_vals": np.array([float(items[k]) for k in keys], dtype=np.float64)}
+    net.zero_grad()
+    total.backward()
+    grad_records([(k, p.grad) for k, p in net.named_parameters()], tr)
+    bn_records(net.state_dict(), tr)
+    arbiter_train_step(d, tr, samples=arb_samples)
+    out.update({"train/" + k: v for k, v in tr.items()})
+    save(os.path.join(outdir, name + ".npz"), d, out)
+
+
+_REF = {}
+
 FORWARD_CLS_BIAS_SHIFT = 0.09
 
 
@@ -359,6 +535,8 @@ def main():
     os.makedirs(a.out, exist_ok=True)
     torch.set_num_threads(8)
     rec, Track4D, args, mu, ref_loss, ref_main_utils = import_reference()
+    _REF.update(Track4D=Track4D, args=args)
+    ref = (rec, Track4D, args, mu, ref_loss)
 
     # checkpoint-compatibility contract: the reference's state-dict keys, shapes, dtypes
     net = Track4D(args)
@@ -377,6 +555,12 @@ def main():
         "eval_b1_n256_dups": lambda: eval_case("eval_b1_n256_dups", special_cloud(256), Track4D, args, rec, mu, ref_main_utils, a.out),
         "train_b1_n256": lambda: train_case("train_b1_n256", synth.make_frame_pairs(1, 256, 1), Track4D, args, rec, mu, ref_loss, a.out),
         "forward_b1_n256": lambda: forward_case("forward_b1_n256", Track4D, args, rec, a.out),
+        # round 3: 8 x 256 = 2 048 query points -> the split-bf16 training kernels; gradient tensors; float64 arbiter
+        "train_b8_n256": lambda: train_batch_case("train_b8_n256", synth.make_frame_pairs(8, 256, 11), ref, a.out),
+        # the reference's shipped radar frames, N = 322 / 352 / 242, every pair with N1 != N2
+        "real_549_1047": lambda: real_case("real_549_1047", "00549", "01047", 0, ref, ref_main_utils, a.out),
+        "real_1047_1201": lambda: real_case("real_1047_1201", "01047", "01201", 1, ref, ref_main_utils, a.out, arb_samples=False),
+        "real_1201_549": lambda: real_case("real_1201_549", "01201", "00549", 2, ref, ref_main_utils, a.out, arb_samples=False),
     }
     for name, fn in cases.items():
         if a.only and a.only != name:
