@@ -44,20 +44,14 @@ extern "C" {
 RTK_EXPORT int rtk_bn_train_stats(int samples, int channels, int rows, int ns, int groups, const float *z,
                                   const float *row_weight, double *sums, rtk_stream_t stream);
 
-/* sums -> par (4, groups, C) fp32 = [mean | rstd | scale = gamma rstd | shift = beta - mean scale]; updates
- * running_mean / running_var (momentum, unbiased variance) group by group and adds `groups` to
- * num_batches_tracked (int64, may be NULL).  count = reference elements per channel and group. */
-RTK_EXPORT int rtk_bn_train_finalize(int channels, int groups, const double *sums, double count, const float *gamma,
-                                     const float *beta, float eps, float momentum, float *running_mean,
-                                     float *running_var, int64_t *num_batches_tracked, float *par, rtk_stream_t stream);
-
 /* y = relu(z scale + shift).  pool == 0: y has the shape of z.  pool != 0: y (samples, C, rows) = max over ns. */
 RTK_EXPORT int rtk_bn_relu_fwd(int samples, int channels, int rows, int ns, int groups, const float *z, const float *par,
                                int pool, float *y, rtk_stream_t stream);
 
 /* BatchNorm finalisation folded into the consumer: instead of reading par, the kernel derives (mean, rstd, scale, shift) of its
- * channels from the batch sums (as rtk_bn_train_finalize would), and its first workgroups also store them into par_out
- * (4, groups, C) -- for the backward -- and update the running statistics.  One launch less per BatchNorm layer and step. */
+ * channels from the batch sums -- par (4, groups, C) fp32 = [mean | rstd | scale = gamma rstd | shift = beta - mean scale], count =
+ * reference elements per channel and group -- and its first workgroups also store them into par_out (for the backward) and update
+ * running_mean / running_var (momentum, unbiased variance) group by group, adding `groups` to num_batches_tracked.  One launch less per BatchNorm layer and step. */
 typedef struct {
     const double *sums;             /* (RTK_STAT_SLOTS, groups, C, 2), complete */
     double count;
@@ -65,6 +59,8 @@ typedef struct {
     float eps, momentum;
     float *running_mean, *running_var;      /* optional */
     int64_t *num_batches_tracked;           /* optional */
+    const double *group_counts;             /* optional DEVICE array (groups): per-group element counts that replace `count` -- padded
+                                             * batches of clouds of different sizes (rtk_train_point_weights writes it) */
 } rtk_bn_fin_t;
 RTK_EXPORT int rtk_bn_relu_fwd_fin(int samples, int channels, int rows, int ns, int groups, const float *z, const rtk_bn_fin_t *fin,
                                    float *par_out, int pool, float *y, rtk_stream_t stream);
@@ -74,10 +70,11 @@ RTK_EXPORT int rtk_bn_relu_fwd_fin(int samples, int channels, int rows, int ns, 
 RTK_EXPORT int rtk_bn_relu_bwd_stats(int samples, int channels, int rows, int ns, int groups, const float *z,
                                      const float *dy, const float *par, int pool, double *sums2, rtk_stream_t stream);
 
-/* Backward, pass 2: dz (shape of z); dgamma_dbeta (2, C) fp32 = [sum_g sums2[g][c][1] | sum_g sums2[g][c][0]]. */
+/* Backward, pass 2: dz (shape of z); dgamma_dbeta (2, C) fp32 = [sum_g sums2[g][c][1] | sum_g sums2[g][c][0]].
+ * group_counts: optional device array of per-group element counts replacing `count` (see rtk_bn_fin_t). */
 RTK_EXPORT int rtk_bn_relu_bwd_apply(int samples, int channels, int rows, int ns, int groups, const float *z,
                                      const float *dy, const float *par, const float *row_weight, const double *sums2,
-                                     double count, int pool, float *dz, float *dgamma_dbeta, rtk_stream_t stream);
+                                     double count, const double *group_counts, int pool, float *dz, float *dgamma_dbeta, rtk_stream_t stream);
 
 /* First layer of a set-abstraction SharedMLP from the per-point projection (conv([d_xyz || feats[idx]]) =
  * Wx.d_xyz + (Wf.feats)[idx]):  z[b][c][row][k] = proj[b][c][idx[b][row][k]] + wx[c] . dxyz[b][:, row, k], and the weighted
@@ -125,7 +122,7 @@ RTK_EXPORT int rtk_sa_first_layer_bwd(int samples, int channels, int rows, int n
  * Tensors are NCHW planes (samples, C, rows*ns), ns a power of two >= 4, channel counts 16, 32 or 64.
  *
  * rtk_conv_bn_fwd:  a = relu(scale x + shift) with (scale, shift) of the PREVIOUS layer's BatchNorm read from pre_par
- * ((4, groups, cin) as written by rtk_bn_train_finalize; NULL: a = x), z = W a with w the plain row-major (cout, cin)
+ * ((4, groups, cin) as written by the *_fin kernels; NULL: a = x), z = W a with w the plain row-major (cout, cin)
  * weight of the convolution, and this layer's weighted batch sums accumulated into sums (groups, cout, 2) float64,
  * zero-initialised by the caller (same meaning as rtk_bn_train_stats).  act_out (optional, shape of x) receives a. */
 RTK_EXPORT int rtk_conv_bn_fwd(int samples, int cin, int cout, int rows, int ns, int groups, const float *x, const float *pre_par,
@@ -257,6 +254,11 @@ RTK_EXPORT int rtk_train_interp_weights(int samples, int rows_total, int rows, c
                                         int *idx_out, float *weight_out, rtk_stream_t stream);
 /* BatchNorm row weights of a level: w[b][r] = [r < nuniq[b]] + [r == 0] (npoint - nuniq[b]). */
 RTK_EXPORT int rtk_train_row_weights(int samples, int rows, int npoint, const int *nuniq, float *weights, rtk_stream_t stream);
+/* Level-0 statistics weights of a padded batch (clouds of n_valid[s] <= rows points, the rest copies of their point 0):
+ * weights (samples, rows) = [r < n_valid[s]]; group_counts (groups) float64 = sum of n_valid over each group's samples -- the
+ * per-group element counts of the per-point BatchNorm layers (rtk_bn_fin_t.group_counts). */
+RTK_EXPORT int rtk_train_point_weights(int samples, int rows, int groups, const int *n_valid, float *weights, double *group_counts,
+                                       rtk_stream_t stream);
 
 /* ---- GRU step (fd_layer.torchGRU on a length-1 sequence, utils/model_utils/model_utils.py:279,296) -------------------
  * Backward of rtk_gru_step (rtk_fused.h).  x (B,H), h_in / h_out (L,B,H) as in the forward; w_ih_t, w_hh_t the TRANSPOSED
@@ -289,10 +291,11 @@ RTK_EXPORT int rtk_weightnet_bwd(long positions, int channels, const float *d4, 
  * pc1, flow, gt_warp (B,3,N) contiguous; cls (B,N) probabilities; gt_cls uint8/bool, sample b's row at gt_cls + b*gt_cls_stride
  * (stride 0: one label vector for the whole batch).  items (4) fp32 ZERO-INITIALISED: += [Loss, SceneFlowLoss, TrackingLoss (left
  * 0), SegLoss].  dflow (B,3,N) / dcls (B,N) (optional): d Loss / d flow (not written while pre-training: the loss does not depend
- * on the flow then) and d Loss / d cls. */
+ * on the flow then) and d Loss / d cls.  n_valid (B) int32, optional: padded batch -- sample b consists of its first n_valid[b]
+ * points; the padding columns enter no mean and get zero gradients. */
 RTK_EXPORT int rtk_backbone_loss(int b, int n, const float *pc1, const float *flow, const float *gt_warp, const float *cls,
                                  const unsigned char *gt_cls, int gt_cls_stride, int pretrain, float *items, float *dflow, float *dcls,
-                                 rtk_stream_t stream);
+                                 const int *n_valid, rtk_stream_t stream);
 
 /* Adam (torch.optim.Adam semantics: L2 weight decay in the gradient, bias-corrected, no amsgrad; main.py:61) over n_tensors fp32
  * tensors in one launch.  table: n_tensors rows of seven 64-bit words {param, grad, exp_avg, exp_avg_sq, numel, first workgroup,

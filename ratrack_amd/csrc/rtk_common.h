@@ -50,15 +50,20 @@ __device__ __forceinline__ float rtk_sqdist(float ax, float ay, float az, float 
 #endif
 
 // ---- BatchNorm finalisation inside a consumer kernel (rtk_bn_fin_t, rtk_train.h) -------------------------------------------------
-// Same arithmetic as bn_finalize_kernel (train_bn.hip): every workgroup derives the constants of its own (group, channel) from the
+// Every workgroup derives the constants of its own (group, channel) from the
 // replica sums; bn_fin_publish -- called by ONE thread per channel in the whole grid -- also stores all groups' constants into par
 // and updates the running statistics (group 0, then group 1, ...: the reference calls the module once per frame).
+// element count of group g: `count` for every group, or -- padded batches of clouds of different sizes (n_valid) -- the device
+// array group_counts[groups] (rtk_train_point_weights): the step stays one captured graph whatever the clouds' sizes
+__device__ __forceinline__ double rtk_group_count(double count, const double *group_counts, int g) { return group_counts ? group_counts[g] : count; }
+
 __device__ __forceinline__ void bn_fin_constants(const rtk_bn_fin_t &F, int channels, int groups, int g, int c, float &mean, float &rstd,
                                                  float &sc, float &sh) {
     const size_t GC = (size_t)groups * channels, o = ((size_t)g * channels + c) * 2;
     const double s = rtk_stat_read(F.sums, GC * 2, o), ss = rtk_stat_read(F.sums, GC * 2, o + 1);
-    const double m = s / F.count;
-    double var = ss / F.count - m * m;
+    const double cnt = rtk_group_count(F.count, F.group_counts, g);
+    const double m = s / cnt;
+    double var = ss / cnt - m * m;
     var = var > 0.0 ? var : 0.0;
     rstd = (float)(1.0 / sqrt(var + (double)F.eps));
     sc = F.gamma[c] * rstd;
@@ -73,8 +78,9 @@ __device__ __forceinline__ void bn_fin_publish(const rtk_bn_fin_t &F, int channe
     for (int g = 0; g < groups; ++g) {
         const size_t o2 = ((size_t)g * channels + c) * 2;
         const double s = rtk_stat_read(F.sums, GC * 2, o2), ss = rtk_stat_read(F.sums, GC * 2, o2 + 1);
-        const double mean = s / F.count;
-        double var = ss / F.count - mean * mean;
+        const double cnt = rtk_group_count(F.count, F.group_counts, g);
+        const double mean = s / cnt;
+        double var = ss / cnt - mean * mean;
         var = var > 0.0 ? var : 0.0;
         const float rstd = (float)(1.0 / sqrt(var + (double)F.eps));
         const float sc = F.gamma[c] * rstd;
@@ -84,7 +90,7 @@ __device__ __forceinline__ void bn_fin_publish(const rtk_bn_fin_t &F, int channe
         par[2 * GC + o] = sc;
         par[3 * GC + o] = F.beta[c] - (float)mean * sc;
         rm = (1.f - F.momentum) * rm + F.momentum * (float)mean;
-        rv = (1.f - F.momentum) * rv + F.momentum * (float)(var * (F.count / (F.count - 1.0)));
+        rv = (1.f - F.momentum) * rv + F.momentum * (float)(var * (cnt / (cnt - 1.0)));
     }
     if (F.running_mean) F.running_mean[c] = rm;
     if (F.running_var) F.running_var[c] = rv;

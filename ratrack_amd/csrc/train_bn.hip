@@ -149,35 +149,6 @@ __global__ __launch_bounds__(BN_T) void sa_first_layer_kernel(int samples, int c
     }
 }
 
-__global__ void bn_finalize_kernel(int channels, int groups, const double *__restrict__ sums, double count,
-                                   const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
-                                   float *__restrict__ running_mean, float *__restrict__ running_var,
-                                   int64_t *__restrict__ nbt, float *__restrict__ par) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && nbt) *nbt += groups;
-    if (c >= channels) return;
-    const size_t GC = (size_t)groups * channels;
-    float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
-    for (int g = 0; g < groups; ++g) {
-        const double s = rtk_stat_read(sums, GC * 2, ((size_t)g * channels + c) * 2), ss = rtk_stat_read(sums, GC * 2, ((size_t)g * channels + c) * 2 + 1);
-        const double mean = s / count;
-        double var = ss / count - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = gamma[c] * rstd;
-        const size_t o = (size_t)g * channels + c;
-        par[o] = (float)mean;
-        par[GC + o] = rstd;
-        par[2 * GC + o] = sc;
-        par[3 * GC + o] = beta[c] - (float)mean * sc;
-        // nn.BatchNorm2d: running = (1 - momentum) running + momentum batch; the variance unbiased
-        rm = (1.f - momentum) * rm + momentum * (float)mean;
-        rv = (1.f - momentum) * rv + momentum * (float)(var * (count / (count - 1.0)));
-    }
-    if (running_mean) running_mean[c] = rm;
-    if (running_var) running_var[c] = rv;
-}
-
 // ---- forward: normalise + ReLU --------------------------------------------------------------------------------------
 // (scale, shift) of this workgroup's (group, channel): read from par, or -- fin.sums given -- finalised here from the batch sums, in
 // which case the sample-0 workgroup of every channel also publishes par and the running statistics (bn_fin_publish)
@@ -402,10 +373,11 @@ __global__ __launch_bounds__(BN_T) void bn_relu_bwd_stats_small_kernel(int sampl
 __global__ __launch_bounds__(BN_T) void bn_relu_bwd_apply_small_kernel(int samples, int channels, int E, int groups, const float *__restrict__ z,
                                                                        const float *__restrict__ dy, const float *__restrict__ par,
                                                                        const float *__restrict__ rw, const double *__restrict__ sums2,
-                                                                       double count, float *__restrict__ dz, float *__restrict__ dgb) {
+                                                                       double count0, const double *__restrict__ gcnt, float *__restrict__ dz, float *__restrict__ dgb) {
     const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
     if (c >= channels) return;
     const int g = b / (samples / groups);
+    const double count = rtk_group_count(count0, gcnt, g);
     const size_t GC = (size_t)groups * channels, o = (size_t)g * channels + c;
     const float mean = par[o], rstd = par[GC + o], sc = par[2 * GC + o], sh = par[3 * GC + o];
     float c1 = 0.f, c2 = 0.f;
@@ -470,10 +442,10 @@ __device__ __forceinline__ BwdCoef bwd_coef(int channels, int groups, int g, con
 __global__ __launch_bounds__(BN_T) void bn_relu_bwd_apply_kernel(int samples, int channels, int rows, int lg_ns, int groups,
                                                                  const float *__restrict__ z, const float *__restrict__ dy,
                                                                  const float *__restrict__ par, const float *__restrict__ rw,
-                                                                 const double *__restrict__ sums2, double count,
+                                                                 const double *__restrict__ sums2, double count, const double *__restrict__ gcnt,
                                                                  float *__restrict__ dz, float *__restrict__ dgb) {
     const Plane p = plane_of(samples, channels, rows, 1 << lg_ns, groups);
-    const BwdCoef k = bwd_coef(channels, groups, p.g, par, sums2, count, dgb);
+    const BwdCoef k = bwd_coef(channels, groups, p.g, par, sums2, rtk_group_count(count, gcnt, p.g), dgb);
     const int E = rows << lg_ns;
     const float *zp = z + p.base, *dp = dy + p.base;
     float *op = dz + p.base;
@@ -502,11 +474,11 @@ template <int G>
 __global__ __launch_bounds__(BN_T) void bn_relu_pool_bwd_apply_kernel(int samples, int channels, int rows, int groups,
                                                                       const float *__restrict__ z, const float *__restrict__ dy,
                                                                       const float *__restrict__ par, const float *__restrict__ rw,
-                                                                      const double *__restrict__ sums2, double count,
+                                                                      const double *__restrict__ sums2, double count, const double *__restrict__ gcnt,
                                                                       float *__restrict__ dz, float *__restrict__ dgb) {
     constexpr int NS = 4 * G;
     const Plane p = plane_of(samples, channels, rows, NS, groups);
-    const BwdCoef k = bwd_coef(channels, groups, p.g, par, sums2, count, dgb);
+    const BwdCoef k = bwd_coef(channels, groups, p.g, par, sums2, rtk_group_count(count, gcnt, p.g), dgb);
     const float *zp = z + p.base;
     const float *dp = dy + ((size_t)blockIdx.y * channels + blockIdx.x) * rows;
     float *op = dz + p.base;
@@ -571,17 +543,6 @@ extern "C" int rtk_bn_train_stats(int samples, int channels, int rows, int ns, i
     return RTK_OK;
 }
 
-extern "C" int rtk_bn_train_finalize(int channels, int groups, const double *sums, double count, const float *gamma,
-                                     const float *beta, float eps, float momentum, float *running_mean, float *running_var,
-                                     int64_t *num_batches_tracked, float *par, rtk_stream_t stream) {
-    RTK_REQUIRE(channels > 0 && groups > 0 && count > 1.0, "rtk_bn_train_finalize: bad sizes");
-    hipStream_t s = (hipStream_t)stream;
-    bn_finalize_kernel<<<rtk_divup(channels, 128), 128, 0, s>>>(channels, groups, sums, count, gamma, beta, eps, momentum,
-                                                               running_mean, running_var, num_batches_tracked, par);
-    RTK_CHECK_LAUNCH("rtk_bn_train_finalize");
-    return RTK_OK;
-}
-
 static int bn_relu_fwd_launch(int samples, int channels, int rows, int ns, int groups, const float *z, float *par,
                               const rtk_bn_fin_t &fin, int pool, float *y, rtk_stream_t stream) {
     RTK_BN_COMMON_CHECKS("rtk_bn_relu_fwd");
@@ -627,20 +588,20 @@ extern "C" int rtk_bn_relu_bwd_stats(int samples, int channels, int rows, int ns
 }
 
 extern "C" int rtk_bn_relu_bwd_apply(int samples, int channels, int rows, int ns, int groups, const float *z, const float *dy,
-                                     const float *par, const float *row_weight, const double *sums2, double count, int pool,
+                                     const float *par, const float *row_weight, const double *sums2, double count, const double *group_counts, int pool,
                                      float *dz, float *dgamma_dbeta, rtk_stream_t stream) {
     RTK_BN_COMMON_CHECKS("rtk_bn_relu_bwd_apply");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(channels, samples);
     if (pool) {
-        RTK_BN_POOL_DISPATCH(bn_relu_pool_bwd_apply_kernel, samples, channels, rows, groups, z, dy, par, row_weight, sums2, count, dz,
+        RTK_BN_POOL_DISPATCH(bn_relu_pool_bwd_apply_kernel, samples, channels, rows, groups, z, dy, par, row_weight, sums2, count, group_counts, dz,
                              dgamma_dbeta)
     } else if (BN_SMALL_PLANE) {
         bn_relu_bwd_apply_small_kernel<<<dim3(rtk_divup(channels, 4), samples), BN_T, 0, s>>>(samples, channels, rows, groups, z, dy, par, row_weight,
-                                                                                           sums2, count, dz, dgamma_dbeta);
+                                                                                           sums2, count, group_counts, dz, dgamma_dbeta);
     } else {
         bn_relu_bwd_apply_kernel<<<grid, BN_T, 0, s>>>(samples, channels, rows, ilog2_exact(ns), groups, z, dy, par, row_weight, sums2,
-                                                       count, dz, dgamma_dbeta);
+                                                       count, group_counts, dz, dgamma_dbeta);
     }
     RTK_CHECK_LAUNCH("rtk_bn_relu_bwd_apply");
     return RTK_OK;
@@ -702,6 +663,20 @@ __global__ void train_interp_kernel(int rows_total, int rows, const float *__res
     io[0] = id[0] >= nu ? 0 : id[0]; io[1] = id[1] >= nu ? 0 : id[1]; io[2] = id[2] >= nu ? 0 : id[2];
 }
 
+// level-0 statistics weights of a padded batch: w[s][r] = r < n_valid[s]; counts[g] = sum of n_valid over group g's samples (float64,
+// what the BatchNorm kernels read as the group's element count)
+__global__ void train_point_weights_kernel(int samples, int rows, int groups, const int *__restrict__ n_valid, float *__restrict__ w,
+                                           double *__restrict__ counts) {
+    const int b = blockIdx.y, r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) w[(size_t)b * rows + r] = r < n_valid[b] ? 1.f : 0.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && b < groups) {
+        const int per = samples / groups;
+        long tot = 0;
+        for (int i = 0; i < per; ++i) tot += n_valid[b * per + i];
+        counts[b] = (double)tot;
+    }
+}
+
 __global__ void train_row_weights_kernel(int rows, int npoint, const int *__restrict__ nuniq, float *__restrict__ w) {
     const int b = blockIdx.y, r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
@@ -729,6 +704,16 @@ extern "C" int rtk_train_interp_weights(int samples, int rows_total, int rows, c
     train_interp_kernel<<<dim3(rtk_divup(rows, 256), samples), 256, 0, (hipStream_t)stream>>>(rows_total, rows, dist2, idx, known_nuniq,
                                                                                         idx_out, weight_out);
     RTK_CHECK_LAUNCH("rtk_train_interp_weights");
+    return RTK_OK;
+}
+
+extern "C" int rtk_train_point_weights(int samples, int rows, int groups, const int *n_valid, float *weights, double *group_counts,
+                                       rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && samples <= 65535 && rows > 0 && groups > 0 && groups <= samples && samples % groups == 0 && n_valid && weights &&
+                group_counts, "rtk_train_point_weights: bad arguments");
+    train_point_weights_kernel<<<dim3(rtk_divup(rows, 256), samples), 256, 0, (hipStream_t)stream>>>(samples, rows, groups, n_valid, weights,
+                                                                                                group_counts);
+    RTK_CHECK_LAUNCH("rtk_train_point_weights");
     return RTK_OK;
 }
 

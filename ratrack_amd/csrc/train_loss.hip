@@ -34,19 +34,27 @@ __global__ __launch_bounds__(256) void backbone_loss_kernel(int B, int N, const 
                                                             const float *__restrict__ gt, const float *__restrict__ cls,
                                                             const unsigned char *__restrict__ gt_cls, int gt_cls_stride, int pretrain,
                                                             float *__restrict__ items, float *__restrict__ dflow,
-                                                            float *__restrict__ dcls) {
+                                                            float *__restrict__ dcls, const int *__restrict__ n_valid) {
     __shared__ float s_red[4];
     const int b = blockIdx.x, t = threadIdx.x;
+    const int nv = n_valid ? n_valid[b] : N;        // padded batch: the sample's own point count (padding columns: zero gradient)
     const float *p1 = pc1 + (size_t)b * 3 * N, *fl = flow + (size_t)b * 3 * N, *g3 = gt + (size_t)b * 3 * N;
     const float *pc = cls + (size_t)b * N;
     const unsigned char *gc = gt_cls + (size_t)b * gt_cls_stride;
     float sf = 0.f, npos = 0.f, nneg = 0.f, spos = 0.f, sneg = 0.f;
     for (int n = t; n < N; n += 256) {
+        if (n >= nv) {
+            if (dflow && !pretrain) {
+                float *o = dflow + (size_t)b * 3 * N;
+                o[n] = 0.f; o[N + n] = 0.f; o[2 * N + n] = 0.f;
+            }
+            continue;
+        }
         const float dx = (p1[n] + fl[n]) - g3[n], dy = (p1[N + n] + fl[N + n]) - g3[N + n], dz = (p1[2 * N + n] + fl[2 * N + n]) - g3[2 * N + n];
         const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
         sf += nrm;
         if (dflow && !pretrain) {
-            const float k = nrm > 0.f ? 0.5f / ((float)B * (float)N) / nrm : 0.f;
+            const float k = nrm > 0.f ? 0.5f / ((float)B * (float)nv) / nrm : 0.f;
             float *o = dflow + (size_t)b * 3 * N;
             o[n] = k * dx; o[N + n] = k * dy; o[2 * N + n] = k * dz;
         }
@@ -65,12 +73,12 @@ __global__ __launch_bounds__(256) void backbone_loss_kernel(int B, int N, const 
     if (dcls) {
         for (int n = t; n < N; n += 256) {
             const float p = pc[n], g = gc[n] != 0 ? 1.f : 0.f;
-            const float w = defined ? (g != 0.f ? wp : wn) / (float)B : 0.f;
+            const float w = defined && n < nv ? (g != 0.f ? wp : wn) / (float)B : 0.f;
             dcls[(size_t)b * N + n] = w * (p - g) / fmaxf((1.f - p) * p, 1e-12f);
         }
     }
     if (t == 0) {
-        float sfb = sf / (float)N;
+        float sfb = sf / (float)nv;
         sfb = sfb != sfb ? 0.f : sfb;                               // NaN -> 0 (losses/loss.py:15-20)
         const float segb = defined ? wp * spos + wn * sneg : 0.f;
         const float sfm = sfb / (float)B, segm = segb / (float)B;
@@ -84,9 +92,10 @@ __global__ __launch_bounds__(256) void backbone_loss_kernel(int B, int N, const 
 
 extern "C" int rtk_backbone_loss(int b, int n, const float *pc1, const float *flow, const float *gt_warp, const float *cls,
                                  const unsigned char *gt_cls, int gt_cls_stride, int pretrain, float *items, float *dflow, float *dcls,
-                                 rtk_stream_t stream) {
+                                 const int *n_valid, rtk_stream_t stream) {
     RTK_REQUIRE(b > 0 && n > 0 && pc1 && flow && gt_warp && cls && gt_cls && items, "backbone_loss: bad arguments");
-    backbone_loss_kernel<<<b, 256, 0, (hipStream_t)stream>>>(b, n, pc1, flow, gt_warp, cls, gt_cls, gt_cls_stride, pretrain, items, dflow, dcls);
+    backbone_loss_kernel<<<b, 256, 0, (hipStream_t)stream>>>(b, n, pc1, flow, gt_warp, cls, gt_cls, gt_cls_stride, pretrain, items, dflow, dcls,
+                                                             n_valid);
     RTK_CHECK_LAUNCH("backbone_loss");
     return RTK_OK;
 }

@@ -124,7 +124,9 @@ class _Predictor(nn.Module):
             last = out
         self.conv2 = nn.Conv2d(mlp[-1], 3, 1, bias=False)
 
-    def _trunk(self, feat):
+    def _trunk(self, feat, point_w=None, point_counts=None):
+        """point_w (B,N) / point_counts (1,) device float64: statistics weights and element count of a padded batch
+        (train_path.TrainGeometry); training path only."""
         x = feat.unsqueeze(3)
         if self.training and feat.is_cuda and torch.is_grad_enabled():
             # training on the GPU: the per-point layer operators (train_ops.pw_bn_relu / pw_linear: conv + batch statistics in one
@@ -132,8 +134,9 @@ class _Predictor(nn.Module):
             from .train_ops import pw_bn_relu, pw_linear
             x = feat
             for block in self.sf_mlp:
-                x = pw_bn_relu([x], block[0].weight, block[1])
+                x = pw_bn_relu([x], block[0].weight, block[1], row_weight=point_w, group_counts=point_counts)
             return pw_linear([x], self.conv2.weight)
+        assert point_w is None, "padded batches train on the HIP training path only"
         for block in self.sf_mlp:
             x = block(x)
         return self.conv2(x).squeeze(3)
@@ -142,8 +145,8 @@ class _Predictor(nn.Module):
 class FlowPredictor(_Predictor):
     """(B,C,N) -> (B,3,N) scene flow.  model_utils.py:308-329."""
 
-    def forward(self, feat):
-        return self._trunk(feat)
+    def forward(self, feat, point_w=None, point_counts=None):
+        return self._trunk(feat, point_w, point_counts)
 
 
 class ClsPredictor(_Predictor):
@@ -153,8 +156,8 @@ class ClsPredictor(_Predictor):
         super().__init__(in_channel, mlp)
         self.linear = nn.Linear(3, 1)
 
-    def forward(self, feat):
-        t = self._trunk(feat)
+    def forward(self, feat, point_w=None, point_counts=None):
+        t = self._trunk(feat, point_w, point_counts)
         if self.training and t.is_cuda and torch.is_grad_enabled():
             from .train_ops import pw_linear
             return torch.sigmoid(pw_linear([t], self.linear.weight, self.linear.bias)).squeeze(1)     # Linear(3,1) over the channel axis
@@ -236,7 +239,8 @@ class FlowDecoder(nn.Module):
     def forward(self, pc1, feature1, pc1_features, cor_features, h, train_geo=None):
         """train_geo: optional train_path.TrainGeometry of pc1 (training mode): the 514-channel PNHead then runs on
         the de-duplicated levels."""
-        cls = self.cp(cor_features)
+        pw, pcnt = (getattr(train_geo, "point_w", None), getattr(train_geo, "point_counts", None)) if train_geo is not None else (None, None)
+        cls = self.cp(cor_features, pw, pcnt)
         parts = (feature1, pc1_features, cor_features) if feature1 is not None else (pc1_features, cor_features)
         if train_geo is not None:
             from .train_path import pnhead_train
@@ -253,5 +257,5 @@ class FlowDecoder(nn.Module):
         else:
             gfeat, h = self.torchGRU(gfeat.permute(2, 0, 1), h)
             gfeat = gfeat.permute(1, 2, 0).expand(prop.size(0), prop.size(1), pc1.size(2))
-        output = self.fp(torch.cat((prop, gfeat), dim=1))
+        output = self.fp(torch.cat((prop, gfeat), dim=1), pw, pcnt)
         return output, h, prop, cls

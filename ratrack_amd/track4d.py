@@ -79,21 +79,35 @@ class Track4D(nn.Module):
                 flow, h, cls, cor, f1, f2, prop = eng.backbone(pad(pc1), pad(pc2), pad(feature1), pad(feature2), h, n_valid=nv)
                 return (flow[:, :, :N1].contiguous(), h, cls[:, :N1].contiguous(), cor[:, :, :N1].contiguous(),
                         f1[:, :, :N1].contiguous(), f2[:, :, :N2].contiguous(), prop[:, :, :N1].contiguous())
-        if n_valid is not None:
-            return self._backbone_per_sample(pc1, pc2, feature1, feature2, h, n_valid)
-        tg1 = None
-        if self.training and self.dedup_train and pc1.is_cuda and pc1.shape == pc2.shape:
+        tg1 = nv = None
+        cut = None
+        if self.training and self.dedup_train and pc1.is_cuda:
             from . import train_path as TP
             if TP.supported(self.pn_head) and TP.supported(self.fd_layer.mse):
-                # training step: both frames as one stacked batch (per-frame BatchNorm statistics) on de-duplicated levels
-                B = pc1.shape[0]
+                # training step: both frames as one stacked batch (per-frame BatchNorm statistics) on de-duplicated levels.
+                # Clouds of different sizes -- every real consecutive pair (dataset_classes/track_vod_3d.py:80-84,119), or a padded
+                # batch with n_valid -- are padded with copies of their own point 0 and travel with their true counts on the
+                # device: same results, gradients and running statistics as the unpadded B = 1 runs (train_path.TrainGeometry)
+                B, N1, N2 = pc1.shape[0], pc1.shape[2], pc2.shape[2]
+                if n_valid is not None:
+                    assert N1 == N2, "n_valid batches are already padded to a common size"
+                    nv = n_valid.to(device=pc1.device, dtype=torch.int32).reshape(2 * B).contiguous()
+                elif N1 != N2:
+                    Nm = max(N1, N2)
+                    pad = lambda t: t if t.shape[2] == Nm else torch.cat([t, t[:, :, :1].expand(-1, -1, Nm - t.shape[2])], dim=2)
+                    nv = torch.cat([torch.full((B,), N1, dtype=torch.int32, device=pc1.device),
+                                    torch.full((B,), N2, dtype=torch.int32, device=pc1.device)])
+                    pc1, pc2, feature1, feature2 = pad(pc1), pad(pc2), pad(feature1), pad(feature2)
+                    cut = (N1, N2)
                 with torch.no_grad():
                     if TRAIN_SIDE_STREAM and getattr(self, "_train_side", None) is None:
                         self._train_side = torch.cuda.Stream(device=pc1.device)
                     tg = TP.TrainGeometry(torch.cat([pc1, pc2], 0).permute(0, 2, 1).contiguous(), self.pn_head.sa1.npoint,
-                                          side=self._train_side if TRAIN_SIDE_STREAM else None)
+                                          side=self._train_side if TRAIN_SIDE_STREAM else None, n_valid=nv, groups=2)
                 f = TP.pnhead_train(self.pn_head, tg, torch.cat([feature1, feature2], 0), groups=2)
                 (f1, f2), tg1 = f.view(2, B, f.shape[1], f.shape[2]).unbind(0), tg.head(B)
+        if tg1 is None and n_valid is not None:
+            return self._backbone_per_sample(pc1, pc2, feature1, feature2, h, n_valid)
         if tg1 is None:
             xyz1_new, f1 = self.pn_head(pc1.permute(0, 2, 1).contiguous(), feature1)
             xyz2_new, f2 = self.pn_head(pc2.permute(0, 2, 1).contiguous(), feature2)
@@ -102,12 +116,18 @@ class Track4D(nn.Module):
         pc1_features = torch.cat((f1, g1), dim=1)
         pc2_features = torch.cat((f2, g2), dim=1)
         if tg1 is not None and TP.correlator_supported(self.fc_layer):
-            cor_features = TP.correlator_train(self.fc_layer, pc1, pc2, pc1_features, pc2_features)
+            cor_features = TP.correlator_train(self.fc_layer, pc1, pc2, pc1_features, pc2_features,
+                                               n_valid1=None if nv is None else nv[:pc1.shape[0]], n_valid2=None if nv is None else nv[pc1.shape[0]:])
         else:
+            assert nv is None, "padded batches need the fused correlator of the training path"
             cor_features = self.fc_layer(pc1, pc2, pc1_features, pc2_features)
         output, h, prop_features, cls = self.fd_layer(pc1, feature1, pc1_features, cor_features, h, train_geo=tg1)
         if tg1 is not None:
             tg1.join()          # every forked stream is joined before the forward returns (a requirement inside a stream capture)
+        if cut is not None:     # frames of different sizes were padded above: hand back the callers' sizes
+            N1, N2 = cut
+            return (output[:, :, :N1], h, cls[:, :N1], cor_features[:, :, :N1], pc1_features[:, :, :N1], pc2_features[:, :, :N2],
+                    prop_features[:, :, :N1])
         return output, h, cls, cor_features, pc1_features, pc2_features, prop_features
 
     def _backbone_per_sample(self, pc1, pc2, feature1, feature2, h, n_valid):

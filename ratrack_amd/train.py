@@ -55,15 +55,20 @@ class Trainer:
         self._static = None
         self._key = None
 
-    def _forward_backward(self, pc1, pc2, feature1, feature2, gt_warp, gt_cls, h, pretrain):
+    def _forward_backward(self, pc1, pc2, feature1, feature2, gt_warp, gt_cls, h, n_valid, pretrain):
         if self._dev.type == "cuda":
             from . import train_ops
             self.opt.zero_grad(set_to_none=True)        # last step's gradients may be views of the arena that is cleared now
             train_ops.arena_begin_step(self._dev)
-        flow, h_out, cls, *_ = self.model.backbone(pc1, pc2, feature1, feature2, h)
-        if self._dev.type == "cuda":
-            total, items = train_ops.backbone_loss(pc1, flow, cls, gt_warp, gt_cls, pretrain=pretrain)      # one kernel, values + gradients
+        if n_valid is not None:
+            flow, h_out, cls, *_ = self.model.backbone(pc1, pc2, feature1, feature2, h, n_valid=n_valid)
         else:
+            flow, h_out, cls, *_ = self.model.backbone(pc1, pc2, feature1, feature2, h)
+        if self._dev.type == "cuda":
+            total, items = train_ops.backbone_loss(pc1, flow, cls, gt_warp, gt_cls, pretrain=pretrain,      # one kernel, values + gradients
+                                                   n_valid=None if n_valid is None else n_valid[0].contiguous())
+        else:
+            assert n_valid is None, "padded batches train on the GPU path"
             total, items = L.backbone_loss(pc1 + flow, cls, gt_warp, gt_cls, pretrain=pretrain)
         self.opt.zero_grad(set_to_none=True)
         total.backward()
@@ -95,11 +100,16 @@ class Trainer:
             out = fn()
         return g, out
 
-    def step(self, pc1, pc2, feature1, feature2, gt_warp, gt_cls, h=None, pretrain=False):
+    def step(self, pc1, pc2, feature1, feature2, gt_warp, gt_cls, h=None, pretrain=False, n_valid=None):
         """One optimisation step on this rank's shard.  Returns the loss items (python floats are NOT taken here:
-        no device->host sync inside the step)."""
+        no device->host sync inside the step).
+        n_valid (2,B) int32 on the device: a padded batch of clouds of different sizes (vod_gt.pad_frame_pairs; gt_warp / gt_cls
+        padded alike) -- the counts live on the device, so ONE captured graph serves every batch of that padded shape: real
+        radar frames (242 ... 352 points here, every consecutive pair of different sizes) train at B = 1 without re-capturing."""
         self.model.train()
-        args = [pc1, pc2, feature1, feature2, gt_warp, gt_cls, h]
+        if n_valid is not None:
+            assert n_valid.is_cuda and n_valid.dtype == torch.int32 and tuple(n_valid.shape) == (2, pc1.shape[0])
+        args = [pc1, pc2, feature1, feature2, gt_warp, gt_cls, h, n_valid]
         if not self.graph:
             return self._step(*args, pretrain)
         key = tuple((tuple(t.shape), t.dtype) if t is not None else None for t in args) + (bool(pretrain),)

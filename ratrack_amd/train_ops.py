@@ -34,12 +34,12 @@ _lib.SIGNATURES.update({
     "rtk_patch_cost_bwd": [_i, _i, _p, _p, _p, _i, _LayerP, _p, _p, _i, _p, _p, _p, _p, _p, _p],
     "rtk_patch_dfeat_gather": [_i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p],
     "rtk_bn_train_stats": [_i] * 5 + [_p] * 3 + [_p],
-    "rtk_bn_train_finalize": [_i, _i, _p, _d, _p, _p, _f, _f, _p, _p, _p, _p, _p],
     "rtk_bn_relu_fwd": [_i] * 5 + [_p, _p, _i, _p, _p],
     "rtk_bn_relu_fwd_fin": [_i] * 5 + [_p, _p, _p, _i, _p, _p],
     "rtk_conv_bn_fwd_fin": [_i] * 6 + [_p] * 8 + [_p],
     "rtk_bn_relu_bwd_stats": [_i] * 5 + [_p, _p, _p, _i, _p, _p],
-    "rtk_bn_relu_bwd_apply": [_i] * 5 + [_p] * 5 + [_d, _i, _p, _p, _p],
+    "rtk_bn_relu_bwd_apply": [_i] * 5 + [_p] * 5 + [_d, _p, _i, _p, _p, _p],
+    "rtk_train_point_weights": [_i] * 3 + [_p] * 3 + [_p],
 })
 
 
@@ -52,7 +52,7 @@ _PwP = ctypes.POINTER(_PwOperand)
 _lib.SIGNATURES.update({
     "rtk_pw_conv": [_i, _i, _i, _PwP, _i, _PwP, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p],
     "rtk_pw_wgrad": [_i, _i, _PwP, _i, _PwP, _p, _i, _p, _p, ctypes.c_long, _p],
-    "rtk_backbone_loss": [_i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p],
+    "rtk_backbone_loss": [_i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p],
     "rtk_pack_weights": [_i, _p, _p],
     "rtk_weightnet_bwd": [ctypes.c_long, _i] + [_p] * 14 + [ctypes.c_long, _p],
 })
@@ -127,7 +127,7 @@ class _BNReLU(torch.autograd.Function):
         par = torch.empty(4, groups, C, dtype=torch.float32, device=dev)
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
         fin = _BnFin(sums.data_ptr(), float(count), g.data_ptr(), b.data_ptr(), float(eps), float(momentum), _ptr(running_mean),
-                     _ptr(running_var), _ptr(nbt))
+                     _ptr(running_var), _ptr(nbt), None)
         y = torch.empty((S_, C, rows) if pool else (S_, C, rows, ns), dtype=torch.float32, device=dev)
         _lib.call("rtk_bn_relu_fwd_fin", S_, C, rows, ns, groups, z.data_ptr(), ctypes.byref(fin), par.data_ptr(), int(pool), y.data_ptr(),
                   _stream())      # finalisation + normalise + ReLU (+ max-pool) in one launch
@@ -148,7 +148,7 @@ class _BNReLU(torch.autograd.Function):
         dz = torch.empty_like(z)
         dgb = torch.empty(2, C, dtype=torch.float32, device=dev)
         _lib.call("rtk_bn_relu_bwd_apply", S_, C, rows, ns, groups, z.data_ptr(), dy.data_ptr(), par.data_ptr(), _ptr(row_weight),
-                  sums2.data_ptr(), float(count), int(pool), dz.data_ptr(), dgb.data_ptr(), _stream())
+                  sums2.data_ptr(), float(count), None, int(pool), dz.data_ptr(), dgb.data_ptr(), _stream())
         return dz, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None
 
 
@@ -289,7 +289,7 @@ class _PwBnRelu(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, W, gamma, beta, cfg, *srcs):
-        bn, row_w, count, groups, cols = cfg
+        bn, row_w, count, groups, cols, gcounts = cfg
         srcs = [_pw_tensor(t) for t in srcs]
         W2 = W.detach().reshape(W.shape[0], -1)
         S_, _, P = srcs[0].shape
@@ -298,16 +298,16 @@ class _PwBnRelu(torch.autograd.Function):
         sums = _zeros((STAT_SLOTS, groups, Co, 2), torch.float64, dev)
         z = torch.empty(S_, Co, P, dtype=torch.float32, device=dev)
         _pw_forward(srcs, cols, W2, None, z, row_w, groups, sums)
-        fin, par, _keep = _bn_fin(bn, sums, count, groups)
+        fin, par, _keep = _bn_fin(bn, sums, count, groups, gcounts)
         y = torch.empty_like(z)
         _lib.call("rtk_bn_relu_fwd_fin", S_, Co, P, 1, groups, z.data_ptr(), fin, par.data_ptr(), 0, y.data_ptr(), _stream())
-        ctx.save_for_backward(W, z, par, row_w, *srcs)
+        ctx.save_for_backward(W, z, par, row_w, gcounts, *srcs)
         ctx.cfg = (count, groups, cols)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        W, z, par, row_w, *srcs = ctx.saved_tensors
+        W, z, par, row_w, gcounts, *srcs = ctx.saved_tensors
         count, groups, cols = ctx.cfg
         S_, Co, P = z.shape
         dev = z.device
@@ -317,19 +317,20 @@ class _PwBnRelu(torch.autograd.Function):
         dz = torch.empty_like(z)
         dgb = torch.empty(2, Co, dtype=torch.float32, device=dev)
         _lib.call("rtk_bn_relu_bwd_apply", S_, Co, P, 1, groups, z.data_ptr(), dy.data_ptr(), par.data_ptr(), _ptr(row_w), sums2.data_ptr(),
-                  float(count), 0, dz.data_ptr(), dgb.data_ptr(), _stream())
+                  float(count), _ptr(gcounts), 0, dz.data_ptr(), dgb.data_ptr(), _stream())
         W2 = W.detach().reshape(W.shape[0], -1)
         dW, _, dsrcs = _pw_backward(ctx.needs_input_grad[4:], srcs, cols, W2, dz, False)
         return (dW.view_as(W), dgb[0], dgb[1], None) + tuple(dsrcs)
 
 
-def pw_bn_relu(srcs, weight, bn, row_weight=None, count=None, groups=1, cols=None):
+def pw_bn_relu(srcs, weight, bn, row_weight=None, count=None, groups=1, cols=None, group_counts=None):
     """relu(bn(conv1x1(cat(srcs)))) in training mode; bn: the nn.BatchNorm2d whose parameters / running statistics are used and
-    updated; row_weight (S,P), count: as bn_relu.  -> (S,Co,P) channel-major."""
+    updated; row_weight (S,P), count: as bn_relu; group_counts: optional device float64 (groups,) per-group element counts that
+    replace `count` (padded batches of clouds of different sizes: rtk_train_point_weights).  -> (S,Co,P) channel-major."""
     S_, _, P = srcs[0].shape
     if count is None:
         count = (S_ // groups) * P
-    return _PwBnRelu.apply(weight, bn.weight, bn.bias, (bn, row_weight, float(count), int(groups), _pw_cols(srcs, cols)), *srcs)
+    return _PwBnRelu.apply(weight, bn.weight, bn.bias, (bn, row_weight, float(count), int(groups), _pw_cols(srcs, cols), group_counts), *srcs)
 
 
 # ---- SharedMLP chain of one set-abstraction scale ------------------------------------------------------------------------
@@ -337,31 +338,20 @@ def pw_bn_relu(srcs, weight, bn, row_weight=None, count=None, groups=1, cols=Non
 class _BnFin(ctypes.Structure):          # rtk_bn_fin_t (include/rtk_train.h)
     _fields_ = [("sums", ctypes.c_void_p), ("count", ctypes.c_double), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
                 ("eps", ctypes.c_float), ("momentum", ctypes.c_float), ("running_mean", ctypes.c_void_p), ("running_var", ctypes.c_void_p),
-                ("num_batches_tracked", ctypes.c_void_p)]
+                ("num_batches_tracked", ctypes.c_void_p), ("group_counts", ctypes.c_void_p)]
 
 
-def _bn_fin(bn, sums, count, groups):
+def _bn_fin(bn, sums, count, groups, group_counts=None):
     """(rtk_bn_fin_t by reference, par buffer): the BatchNorm of `sums` is finalised by the kernel that consumes it (one launch less
-    per layer and step than rtk_bn_train_finalize + consumer); par is written for the backward."""
+    per layer and step than a separate finalisation kernel); par is written for the backward."""
     C = bn.num_features
     par = torch.empty(4, groups, C, dtype=torch.float32, device=sums.device)
     momentum = bn.momentum if bn.momentum is not None else 0.1
     track = bn.track_running_stats
     f = _BnFin(sums.data_ptr(), float(count), bn.weight.detach().data_ptr(), bn.bias.detach().data_ptr(), float(bn.eps), float(momentum),
                _ptr(bn.running_mean if track else None), _ptr(bn.running_var if track else None),
-               _ptr(bn.num_batches_tracked if track else None))
+               _ptr(bn.num_batches_tracked if track else None), _ptr(group_counts))
     return ctypes.byref(f), par, f
-
-
-def _bn_finalize(bn, sums, count, groups):
-    C = bn.num_features
-    par = torch.empty(4, groups, C, dtype=torch.float32, device=sums.device)
-    momentum = bn.momentum if bn.momentum is not None else 0.1
-    track = bn.track_running_stats
-    _lib.call("rtk_bn_train_finalize", C, groups, sums.data_ptr(), float(count), bn.weight.detach().data_ptr(), bn.bias.detach().data_ptr(),
-              float(bn.eps), float(momentum), _ptr(bn.running_mean if track else None), _ptr(bn.running_var if track else None),
-              _ptr(bn.num_batches_tracked if track else None), par.data_ptr(), _stream())
-    return par
 
 
 class _SumsPool:
@@ -456,7 +446,7 @@ class _SAChain(torch.autograd.Function):
         dz = torch.empty_like(zs[-1])
         dgb = torch.empty(2, C, dtype=torch.float32, device=dev)
         _lib.call("rtk_bn_relu_bwd_apply", S_, C, rows, ns, groups, zs[-1].data_ptr(), dout.data_ptr(), pars[-1].data_ptr(), _ptr(row_w),
-                  sums2.data_ptr(), float(count), 1, dz.data_ptr(), dgb.data_ptr(), _stream())
+                  sums2.data_ptr(), float(count), None, 1, dz.data_ptr(), dgb.data_ptr(), _stream())
         grads = {L - 1: (None, dgb[0], dgb[1])}
         C1_ = zs[0].shape[1]
         dwbuf = _zeros((sum(w.numel() for w in weights[1:]) + W0.numel(),), torch.float32, dev)      # all dW of the chain | dW0
@@ -963,18 +953,19 @@ class _BackboneLoss(torch.autograd.Function):
     """loss.backbone_loss (values and gradients) as one kernel: -> (Loss, items (4) = [Loss, SceneFlowLoss, TrackingLoss, SegLoss])."""
 
     @staticmethod
-    def forward(ctx, flow, cls, pc1, gt_warp, gt_cls, pretrain):
+    def forward(ctx, flow, cls, pc1, gt_warp, gt_cls, pretrain, n_valid=None):
         B, _, N = pc1.shape
         dev = pc1.device
         flow, cls, pc1, gt_warp = flow.contiguous(), cls.contiguous(), pc1.contiguous(), gt_warp.contiguous()
         g = gt_cls.to(torch.uint8) if gt_cls.dtype != torch.bool else gt_cls.view(torch.uint8)
         g = g.contiguous()
         stride = 0 if g.dim() == 1 else N
-        items = _zeros((4,), torch.float32, dev)
+        # NOT from the zero arena: the caller keeps the items across steps (Trainer.step returns them without a host sync)
+        items = torch.zeros(4, dtype=torch.float32, device=dev)
         dflow = None if pretrain else torch.empty(B, 3, N, dtype=torch.float32, device=dev)
         dcls = torch.empty(B, N, dtype=torch.float32, device=dev)
         _lib.call("rtk_backbone_loss", B, N, pc1.data_ptr(), flow.data_ptr(), gt_warp.data_ptr(), cls.data_ptr(), g.data_ptr(), stride,
-                  int(bool(pretrain)), items.data_ptr(), _ptr(dflow), dcls.data_ptr(), _stream())
+                  int(bool(pretrain)), items.data_ptr(), _ptr(dflow), dcls.data_ptr(), _ptr(n_valid), _stream())
         ctx.save_for_backward(dflow, dcls)
         ctx.mark_non_differentiable(items)
         return items[0], items                           # the differentiable total as its own output: no select_backward (zeros + copy)
@@ -982,11 +973,13 @@ class _BackboneLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _):
         dflow, dcls = ctx.saved_tensors
-        return (None if dflow is None else dflow * g), dcls * g, None, None, None, None
+        return (None if dflow is None else dflow * g), dcls * g, None, None, None, None, None
 
 
-def backbone_loss(pc1, flow, cls, gt_warp, gt_cls, pretrain=False):
+def backbone_loss(pc1, flow, cls, gt_warp, gt_cls, pretrain=False, n_valid=None):
     """(total, items dict) of loss.backbone_loss(pc1 + flow, cls, gt_warp, gt_cls, pretrain) with total = items['Loss'];
-    CUDA fp32 only."""
-    total, it = _BackboneLoss.apply(flow, cls, pc1, gt_warp, gt_cls, bool(pretrain))
+    CUDA fp32 only.  n_valid (B,) int32 on the device: padded batch -- sample b's loss is that of its first n_valid[b] points."""
+    if n_valid is not None:
+        assert n_valid.is_cuda and n_valid.dtype == torch.int32 and n_valid.is_contiguous() and n_valid.numel() == pc1.shape[0]
+    total, it = _BackboneLoss.apply(flow, cls, pc1, gt_warp, gt_cls, bool(pretrain), n_valid)
     return total, {"Loss": total, "SceneFlowLoss": it[1], "TrackingLoss": it[2], "SegLoss": it[3]}

@@ -37,10 +37,23 @@ class TrainGeometry:
     preceding them.  All buffers are allocated on the current stream before the fork; join() makes the current stream wait
     for everything (the forward ends with it: inside a stream capture every forked stream must be joined)."""
 
-    def __init__(self, xyz, npoint, side=None):
+    def __init__(self, xyz, npoint, side=None, n_valid=None, groups=1):
+        """n_valid (S_,) int32 on the device: padded batch (vod_gt.pad_frame_pairs) -- cloud s consists of its first n_valid[s] points,
+        the rest are copies of its point 0.  FPS applies the unpadded cloud's tie rule, ball indices that hit a padding row are
+        redirected to row 0 (same values), and the per-point BatchNorm layers weigh padding rows with 0 and take their per-group
+        element counts from the device (`point_w`, `point_counts`; groups = number of consecutive batch slices with their own
+        statistics): results, gradients and running statistics of every sample equal those of its own unpadded B = 1 run, and
+        the captured step does not depend on the clouds' sizes."""
         from . import fused
         S_, n, _ = xyz.shape
         self.samples, self.n, self.npoint = S_, n, npoint
+        self.n_valid, self.point_w, self.point_counts = n_valid, None, None
+        if n_valid is not None:
+            assert n_valid.shape == (S_,) and n_valid.dtype == torch.int32 and n_valid.is_cuda and n_valid.is_contiguous()
+            self.point_w = torch.empty(S_, n, dtype=torch.float32, device=xyz.device)
+            self.point_counts = torch.empty(groups, dtype=torch.float64, device=xyz.device)
+            _lib.call("rtk_train_point_weights", S_, n, groups, n_valid.data_ptr(), self.point_w.data_ptr(), self.point_counts.data_ptr(),
+                      torch.cuda.current_stream().cuda_stream)
         U = self.U = min(n, npoint)
         dev = xyz.device
         f32 = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
@@ -73,7 +86,8 @@ class TrainGeometry:
             for s in range(2):
                 # source rows >= nuniq are copies of row 0: redirect; neighbour - centroid offsets (no gradient)
                 _lib.call("rtk_train_group_geometry", S_, src.shape[1], npoint, U, NS[lvl][s], src.data_ptr(), dst.data_ptr(),
-                          geo.ball[lvl][s].data_ptr(), nu[lvl - 1].data_ptr() if lvl > 0 else None, self.ball[lvl][s].data_ptr(),
+                          geo.ball[lvl][s].data_ptr(), nu[lvl - 1].data_ptr() if lvl > 0 else (n_valid.data_ptr() if n_valid is not None else None),
+                          self.ball[lvl][s].data_ptr(),
                           self.dxyz[lvl][s].data_ptr(), st())
 
         def tail_tables(geo):
@@ -95,7 +109,7 @@ class TrainGeometry:
                                   off.data_ptr(), inv.data_ptr(), st())
             geo._record("inv", side)
 
-        geo = fused.Geometry(xyz, npoint, side=side, knn_frames=0, finite=True, level_hook=level_tables, tail_hook=tail_tables)
+        geo = fused.Geometry(xyz, npoint, side=side, knn_frames=0, finite=True, n_valid=n_valid, level_hook=level_tables, tail_hook=tail_tables)
         self.events, self.side = geo.events, side
         self.l3_xyz = geo.xyz[3]
         self._geo = geo                                            # keeps the tables' inputs alive until the side stream is joined
@@ -122,6 +136,10 @@ class TrainGeometry:
         g.interp_inv = {k: None if t is None else (t[0][:count], t[1][:count]) for k, t in self.interp_inv.items()}
         g.l3_xyz = self.l3_xyz[:count]
         g.events, g.side, g._geo = self.events, self.side, self._geo
+        # padded batch: the head is the first statistics group (frame 1 of a stacked pair batch)
+        g.n_valid = None if self.n_valid is None else self.n_valid[:count]
+        g.point_w = None if self.point_w is None else self.point_w[:count]
+        g.point_counts = None if self.point_counts is None else self.point_counts[:1]
         return g
 
 
@@ -170,7 +188,7 @@ def _sa_scale(mlp, tg, lvl, s, feats, groups):
     return x                                                      # (S_, C_out, U)
 
 
-def _fp(fp, tg, name, skip, known_feats, row_w, count_rows, groups):
+def _fp(fp, tg, name, skip, known_feats, row_w, count_rows, groups, group_counts=None):
     if hasattr(tg, "wait"):
         tg.wait("interp")
     idx, weight = tg.interp[name]
@@ -182,7 +200,7 @@ def _fp(fp, tg, name, skip, known_feats, row_w, count_rows, groups):
         x = PU.three_interpolate(known_feats.contiguous(), idx, weight)
     srcs = [x] if skip is None else [x, skip]                      # lib/pointnet2_modules.py:150-153: cat([interpolated, skip])
     for layer in fp.mlp.children():
-        x = pw_bn_relu(srcs, layer.conv.weight, layer.bn.bn, row_w, (tg.samples // groups) * count_rows, groups)
+        x = pw_bn_relu(srcs, layer.conv.weight, layer.bn.bn, row_w, (tg.samples // groups) * count_rows, groups, group_counts=group_counts)
         srcs = [x]
     return x
 
@@ -202,7 +220,8 @@ def pnhead_train(head, tg, features, groups=1):
     S, n = tg.npoint, tg.n
     l2 = _fp(head.fp3, tg, "fp3", l2, l3, tg.row_w[1], S, groups)
     l1 = _fp(head.fp2, tg, "fp2", l1, l2, tg.row_w[0], S, groups)
-    return _fp(head.fp1, tg, "fp1", None, l1, None, n, groups)
+    # level 0 = the clouds' own points: in a padded batch the padding rows carry statistics weight 0, counts come from the device
+    return _fp(head.fp1, tg, "fp1", None, l1, getattr(tg, "point_w", None), n, groups, group_counts=getattr(tg, "point_counts", None))
 
 
 def correlator_supported(fc):
@@ -210,15 +229,27 @@ def correlator_supported(fc):
             and all(c.out_channels == 256 for c in fc.mlp_convs) and not fc.weightnet1.bn and not fc.weightnet2.bn)
 
 
-def correlator_train(fc, pc1, pc2, feature1, feature2):
+def _knn16(points, query, n_valid):
+    """knn_point(16, points, query) (model_utils.py:85-99); n_valid (B,) int32: only the first n_valid[b] points are candidates."""
+    if n_valid is None:
+        from .model_utils import knn_point
+        return knn_point(16, points, query).contiguous()
+    B, S, _ = query.shape
+    idx = torch.empty(B, S, 16, dtype=torch.int64, device=query.device)
+    _lib.call("rtk_knn_point_masked", B, S, points.shape[1], 16, query.data_ptr(), points.data_ptr(), idx.data_ptr(), n_valid.data_ptr(),
+              torch.cuda.current_stream().cuda_stream)
+    return idx
+
+
+def correlator_train(fc, pc1, pc2, feature1, feature2, n_valid1=None, n_valid2=None):
     """FeatureCorrelator.forward (model_utils.py:166-250) in training mode: the point-to-patch cost volume is one
     fused operator (forward kernel of the inference engine + its backward kernel), and so is the patch-to-patch
-    aggregation.  pc (B,3,N), features (B,D,N) -> (B,256,N1)."""
-    from .model_utils import knn_point
+    aggregation.  pc (B,3,N), features (B,D,N) -> (B,256,N1).  n_valid1 / n_valid2 (B,) int32: padded batch -- kNN candidates
+    are the valid points of the frame searched (padding queries are copies of their cloud's point 0 and get its result)."""
     B, C, N1 = pc1.shape
     x1, x2 = pc1.permute(0, 2, 1).contiguous(), pc2.permute(0, 2, 1).contiguous()
     D1, D2 = feature1.shape[1], feature2.shape[1]
-    knn = knn_point(16, x2, x1).contiguous()
+    knn = _knn16(x2, x1, n_valid2)
     conv0, conv1, conv2 = fc.mlp_convs
     w0 = conv0.weight.flatten(1)              # (a view whose backward is a view: `weight[:, :, 0, 0]` would cost two zeros + copy)
     # layer 1 of the cost-volume MLP split by input segment: per-point projections of both frames' features, written point-major
@@ -228,7 +259,7 @@ def correlator_train(fc, pc1, pc2, feature1, feature2):
     x = cost_volume(p1, p2, w0[:, D1 + D2:], conv1.weight.flatten(1), conv1.bias, conv2.weight.flatten(1), conv2.bias,
                     wn[0].weight.flatten(1), wn[0].bias, wn[1].weight.flatten(1), wn[1].bias, wn[2].weight.flatten(1),
                     wn[2].bias, x1, x2, knn)                                   # (B*N1, 256) point-major
-    knn = knn_point(16, x1, x1).contiguous()
+    knn = _knn16(x1, x1, n_valid1)
     wn = fc.weightnet2.mlp_convs
     x = patch_cost(x, wn[0].weight.flatten(1), wn[0].bias, wn[1].weight.flatten(1), wn[1].bias, wn[2].weight.flatten(1),
                    wn[2].bias, x1, knn)
