@@ -234,6 +234,51 @@ def test_split_layers_carry_fp32_accuracy(positions):
     assert err(y) < 2e-6 and err(y) < 3 * err(r32) + 1e-7, (err(y), err(r32))
 
 
+@pytest.mark.parametrize("case", ["same_sign", "scale_1e6", "scale_1e-6", "mixed_range", "tiny_1e-30", "post_relu"])
+def test_split_layers_adversarial_operands(case):
+    """Truncation splitting drops same-signed terms (a bias, not noise: <= 2 x 2^-24 |a||b| per product).  Operands chosen to make
+    that bias coherent -- all-positive activations x all-positive weights, as after a ReLU --, dynamic ranges of 1e+-6 between
+    activations and weights, activations spanning six decades inside one row, and activations so small that their third bf16
+    piece is subnormal; float64 is the truth, the framework's fp32 GEMM the yardstick."""
+    from ratrack_amd import _lib
+    torch.manual_seed(7)
+    P = 640
+    W = [torch.randn(256, 256, device=DEV) / 16 for _ in range(2)]
+    b = [torch.randn(256, device=DEV) * 0.1 for _ in range(2)]
+    x = torch.randn(P, 256, device=DEV) * 3
+    if case == "same_sign":
+        x, W = x.abs(), [w.abs() for w in W]
+        b = [v.abs() for v in b]
+    elif case == "scale_1e6":
+        x, W[0] = x * 1e6, W[0] * 1e-6
+    elif case == "scale_1e-6":
+        x, W[0] = x * 1e-6, W[0] * 1e6
+    elif case == "mixed_range":
+        x = x * torch.pow(10.0, torch.randint(-3, 4, (P, 256), device=DEV).float())
+    elif case == "tiny_1e-30":
+        x, W[0], b[0] = x * 1e-30, W[0], b[0] * 0      # third pieces ~1e-35 * 2^-16: below the smallest normal bf16 / fp32 (1.2e-38)
+        W[1], b[1] = W[1] * 1e10, b[1] * 0
+    elif case == "post_relu":
+        x = torch.relu(x)                                 # half zeros, half positive
+        W = [w.abs() for w in W]
+    img = torch.cat([F.pack_layer_split(w) for w in W])
+    y = torch.full((P, 256), float("nan"), device=DEV)
+    _lib.call("rtk_split_mlp2", P, x.data_ptr(), img.data_ptr(), b[0].data_ptr(), b[1].data_ptr(), y.data_ptr(), F._stream())
+    lk = lambda t: torch.nn.functional.leaky_relu(t, 0.1)
+    r64 = lk(lk(x.double() @ W[0].double().T + b[0].double()) @ W[1].double().T + b[1].double())
+    r32 = lk(lk(x @ W[0].T + b[0]) @ W[1].T + b[1])
+    # per-element relative error where the result is not a cancellation (|r| >= 1e-3 of the row's largest), and error to scale
+    big = r64.abs() >= 1e-3 * r64.abs().amax(1, keepdim=True)
+    rel = lambda t: float(((t.double() - r64).abs() / r64.abs())[big].max())
+    sc = lambda t: float((t.double() - r64).abs().max() / r64.abs().max())
+    bias = lambda t: float(((t.double() - r64) / r64.abs())[big].mean())           # signed: a coherent truncation bias shows here
+    print("\n%s: split  rel %.2e scale %.2e mean signed %.2e | fp32 GEMM rel %.2e scale %.2e mean signed %.2e" % (
+        case, rel(y), sc(y), bias(y), rel(r32), sc(r32), bias(r32)))
+    assert torch.isfinite(y).all()
+    assert sc(y) < 2e-6 and sc(y) < 3 * sc(r32) + 2e-7, (case, sc(y), sc(r32))
+    assert abs(bias(y)) < 2.5e-7, (case, bias(y))                                   # two layers x 2^-23 worst case, fully coherent
+
+
 def test_cost_volume_split_agrees_with_fp32_mfma_kernel():
     """Both kernels on the same operands: samples not a multiple of 8 (plain 2-D grid), a point count that leaves the last
     workgroup iteration partly empty, and rows beyond the last point untouched."""
@@ -498,6 +543,63 @@ def test_padded_variable_n_batch():
             assert torch.equal(r, s_), name                                    # the per-sample fallback IS the B = 1 run
             assert rel_err(a.cpu(), s_.cpu()) <= RTOL, (b, name, rel_err(a.cpu(), s_.cpu()))
             assert rel_err(fs.cpu(), s_.cpu()) <= RTOL, (b, name, "B=1 fused with internal padding")
+
+
+def test_fused_real_frames_match_reference_fixture():
+    """The reference graph run on the radar frames it ships (tools/make_golden.py real_*: B = 1, N1 != N2, eval mode) against the
+    fused engine -- (a) every pair on its own (internal padding of the smaller cloud), (b) the three pairs as ONE padded batch with
+    n_valid: flow, cls, h, the recurrent second step, strided samples of cor / point features / prop, FPS / ball / three-NN
+    indices through the engine's geometry, EPE."""
+    from _util import REAL_CASES, RTOL, assert_close, inputs_of, load_case, reference_state_dict
+    from ratrack_amd import vod_gt
+    from ratrack_amd.track4d import Args, Track4D
+    net = Track4D(Args()).to(DEV).eval()
+    net.load_state_dict(reference_state_dict(DEV), strict=True)
+    cases = [load_case(n) for n in REAL_CASES]
+    cpu = lambda t: t.float().cpu().numpy()
+
+    def check(case, out, out2, b, n1, n2, what):
+        flow, h, cls, cor, pf1, pf2, prop = out
+        assert_close(cpu(flow[b, :, :n1])[None], case["flow"], RTOL, what + " flow")
+        assert_close(cpu(cls[b, :n1])[None], case["cls"], RTOL, what + " cls")
+        assert_close(cpu(h[:, b:b + 1]), case["h_out"], RTOL, what + " h")
+        assert_close(cpu(cor[b, :, :n1:8])[None], case["cor_s8"], RTOL, what + " cor")
+        assert_close(cpu(prop[b, :, :n1:8])[None], case["prop_s8"], RTOL, what + " prop")
+        assert_close(cpu(pf1[b, :, :n1:8])[None], case["pc1_features_s8"], RTOL, what + " pc1_features")
+        assert_close(cpu(pf2[b, :, :n2:8])[None], case["pc2_features_s8"], RTOL, what + " pc2_features")
+        assert_close(cpu(out2[0][b, :, :n1])[None], case["flow_step2"], RTOL, what + " flow (recurrent step)")
+        assert_close(cpu(out2[1][:, b:b + 1]), case["h_out_step2"], RTOL, what + " h (recurrent step)")
+        gt = torch.from_numpy(case["in_gt_warp"]).to(DEV)
+        pc1 = torch.from_numpy(case["in_pc1"]).to(DEV)
+        epe = float(torch.sqrt(((pc1 + flow[b:b + 1, :, :n1] - gt) ** 2).sum(1) + 1e-20).mean())
+        ref = float(case["metric_sf_vals"][list(case["metric_sf_keys"]).index("epe")])
+        assert abs(epe - ref) <= 1e-4 * max(ref, 1.0), (what, epe, ref)
+
+    with torch.no_grad():
+        for name, case in zip(REAL_CASES, cases):                           # (a) B = 1, frames of different sizes
+            pc1, pc2, f1, f2 = inputs_of(case, DEV)
+            out = net.backbone(pc1, pc2, f1, f2, None)
+            out2 = net.backbone(pc1, pc2, f1, f2, out[1])
+            check(case, out, out2, 0, pc1.shape[2], pc2.shape[2], name)
+        pairs = [inputs_of(c, DEV) for c in cases]                          # (b) one padded batch
+        pc1, pc2, f1, f2, nv = vod_gt.pad_frame_pairs(pairs, device=DEV)
+        out = net.backbone(pc1, pc2, f1, f2, None, n_valid=nv)
+        out2 = net.backbone(pc1, pc2, f1, f2, out[1], n_valid=nv)
+        for b, (name, case) in enumerate(zip(REAL_CASES, cases)):
+            check(case, out, out2, b, int(nv[0, b]), int(nv[1, b]), name + " (padded batch)")
+        # index tensors of the engine's geometry for the pc1 clouds of the padded batch: bit-exact with the reference's
+        from ratrack_amd import fused
+        xyz = torch.cat([pc1, pc2], 0).permute(0, 2, 1).contiguous()
+        geo = fused.Geometry(xyz, 512, knn_frames=3, n_valid=nv.reshape(-1).contiguous())
+        torch.cuda.synchronize()
+        for b, case in enumerate(cases):
+            n1 = int(nv[0, b])
+            nu = int(geo.nuniq[0][b])
+            assert np.array_equal(geo.fps_idx[0][b, :nu].cpu().numpy(), case["fps_idx_c0_l1"][0, :nu]), ("fps", b)
+            assert (case["fps_idx_c0_l1"][0, nu:] == 0).all()
+            k = np.sort(geo.knn[0][b, :n1].cpu().numpy(), axis=-1)
+            ok = case["knn_kth_gap_0"][0] > 0
+            assert np.array_equal(k[ok], case["knn_set_0"][0][ok]), ("knn", b)
 
 
 @pytest.mark.parametrize("n,eps,ms,seed", [(256, 1.5, 2, 0), (300, 1.5, 2, 1), (1000, 1.2, 4, 2), (2048, 0.9, 3, 3), (64, 0.5, 2, 4),
