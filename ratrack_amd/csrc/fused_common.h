@@ -336,9 +336,19 @@ __device__ __forceinline__ f4 bias_frag(const float *__restrict__ bias, int v, i
 // One instruction per step: v_max_f32 / v_add_f32 with a DPP-permuted first operand (row_ror rotates within a
 // 16-lane row, so 4 steps leave the full-row result in every lane).  Written as inline asm on a whole f4:
 // hipcc otherwise emits v_mov_b32_dpp + s_nop + canonicalising v_max per step (5x the instructions), which made
-// the epilogue, not the MFMAs, the cost of the small set-abstraction scales.  Hazard: a VGPR written by VALU needs
-// 2 wait states before a DPP read -- the leading s_nop 1 covers the producer of v, and inside the block each
-// register is re-read only after the 3 other components were issued.
+// the epilogue, not the MFMAs, the cost of the small set-abstraction scales.  Hazards: (1) a VGPR written by VALU needs
+// 2 wait states before a DPP read -- the leading s_nop 1 covers the producer of v, and inside the block each register is
+// re-read only after the 3 other components were issued; (2) a VGPR written by an MFMA needs up to 19 wait states before any
+// VALU read, and the compiler's hazard recognizer does not look inside inline asm: an accumulator that reached the asm block
+// directly was read too early (round 2: wrong maxima under a register cap).  rtk_dpp_fence makes every helper self-contained:
+// each component first goes through a compiler-VISIBLE DPP move (identity lane permutation), so the recognizer inserts exactly
+// the MFMA wait states the producer needs (none when the producer is an ordinary VALU op) in front of it.
+__device__ __forceinline__ void rtk_dpp_fence(f4 &v) {
+    v.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v.x), __builtin_bit_cast(int, v.x), 0xE4, 0xf, 0xf, false));
+    v.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v.y), __builtin_bit_cast(int, v.y), 0xE4, 0xf, 0xf, false));
+    v.z = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v.z), __builtin_bit_cast(int, v.z), 0xE4, 0xf, 0xf, false));
+    v.w = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v.w), __builtin_bit_cast(int, v.w), 0xE4, 0xf, 0xf, false));
+}
 #define RTK_DPP4(op, ctrl)                                                 \
     op " %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n"                 \
     op " %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n"                 \
@@ -346,12 +356,14 @@ __device__ __forceinline__ f4 bias_frag(const float *__restrict__ bias, int v, i
     op " %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf\n"
 
 __device__ __forceinline__ void row_max16_f4(f4 &v) {
+    rtk_dpp_fence(v);
     asm volatile("s_nop 1\n" RTK_DPP4("v_max_f32_dpp", "row_ror:8") RTK_DPP4("v_max_f32_dpp", "row_ror:4")
                  RTK_DPP4("v_max_f32_dpp", "row_ror:2") RTK_DPP4("v_max_f32_dpp", "row_ror:1")
                  : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
 }
 
 __device__ __forceinline__ void row_sum16_f4(f4 &v) {
+    rtk_dpp_fence(v);
     asm volatile("s_nop 1\n" RTK_DPP4("v_add_f32_dpp", "row_ror:8") RTK_DPP4("v_add_f32_dpp", "row_ror:4")
                  RTK_DPP4("v_add_f32_dpp", "row_ror:2") RTK_DPP4("v_add_f32_dpp", "row_ror:1")
                  : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
@@ -363,11 +375,13 @@ __device__ __forceinline__ void row_max_group_f4(f4 &v) {
     if constexpr (GROUP >= 16) {
         row_max16_f4(v);
     } else if constexpr (GROUP == 8) {
+        rtk_dpp_fence(v);
         // quad xor-1, quad xor-2, then row_half_mirror (lane i <-> 7-i inside each 8-lane half reaches the other quad)
         asm volatile("s_nop 1\n" RTK_DPP4("v_max_f32_dpp", "quad_perm:[1,0,3,2]") RTK_DPP4("v_max_f32_dpp", "quad_perm:[2,3,0,1]")
                      RTK_DPP4("v_max_f32_dpp", "row_half_mirror")
                      : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
     } else {
+        rtk_dpp_fence(v);
         asm volatile("s_nop 1\n" RTK_DPP4("v_max_f32_dpp", "quad_perm:[1,0,3,2]") RTK_DPP4("v_max_f32_dpp", "quad_perm:[2,3,0,1]")
                      : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
     }

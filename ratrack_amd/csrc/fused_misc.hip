@@ -419,11 +419,7 @@ extern "C" int rtk_dbscan(int n, const float *feat, int pitch, const int *channe
     RTK_REQUIRE(n > 0 && feat && channels && score && labels && pitch >= n && min_samples >= 1, "dbscan: bad arguments");
     const size_t lds = (size_t)n * (DB_D * sizeof(float) + 3 * sizeof(int));
     RTK_REQUIRE(lds <= 128 * 1024, "dbscan: %d points exceed the single-workgroup LDS budget", n);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)dbscan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        attr_set = true;
-    }
+    (void)hipFuncSetAttribute((const void *)dbscan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);      // per device and cheap: every call
     dbscan_kernel<<<1, 256, lds, (hipStream_t)stream>>>(n, feat, pitch, channels, score, threshold, eps, min_samples, labels);
     RTK_CHECK_LAUNCH("dbscan");
     return RTK_OK;

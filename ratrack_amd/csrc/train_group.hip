@@ -275,11 +275,7 @@ extern "C" int rtk_group_inverse_index(int samples, int n_src, int positions, co
                 positions, n_src);
     const size_t lds = (2 * (size_t)n_src + 1) * sizeof(int) + (size_t)positions * sizeof(unsigned short);
     RTK_REQUIRE(lds <= 150 * 1024, "group_inverse_index: table exceeds the LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)inverse_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
-    }
+    (void)hipFuncSetAttribute((const void *)inverse_index_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);      // per device and cheap: every call
     inverse_index_kernel<<<samples, II_T, lds, (hipStream_t)stream>>>(n_src, positions, idx, off, inv);
     RTK_CHECK_LAUNCH("group_inverse_index");
     return RTK_OK;
@@ -293,11 +289,7 @@ extern "C" int rtk_sa_first_layer_bwd(int samples, int channels, int rows, int n
     const int P = rows * ns;
     const size_t lds = (size_t)((P + 3) & ~3) * sizeof(float) + (size_t)(2 * n_src + 1) * sizeof(int) + (size_t)(P + 256) * sizeof(unsigned short);
     RTK_REQUIRE(P <= 65536 && lds <= 150 * 1024 && samples <= 65535, "sa_first_layer_bwd: %d positions exceed the LDS budget", P);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)sa_first_layer_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
-    }
+    (void)hipFuncSetAttribute((const void *)sa_first_layer_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);      // per device and cheap: every call
     // channel planes per workgroup: 4 (2, 8 and 16 measured within 5 % of it or worse, tools/exp_firstbwd.py: the per-plane phases,
     // not the per-workgroup staging of the index tables and offset planes, set the pace)
     static const int cg_env = getenv("RTK_FB_CG") ? atoi(getenv("RTK_FB_CG")) : 0;      // experiment knob

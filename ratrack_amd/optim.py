@@ -21,6 +21,7 @@ CHUNK = 4096
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        assert len(self.param_groups) == 1, "FusedAdam: one parameter group (the reference has one)"
         self._key, self._blocks = None, 0
         dev = self.param_groups[0]["params"][0].device
         assert dev.type == "cuda", "FusedAdam drives a HIP kernel; use torch.optim.Adam on the CPU"
@@ -32,12 +33,26 @@ class FusedAdam(torch.optim.Optimizer):
         self._pinned = torch.empty((n, 7), dtype=torch.int64).pin_memory()
         self._table = torch.empty((n, 7), dtype=torch.int64, device=dev)
 
+    def add_param_group(self, param_group):
+        if getattr(self, "_steps", None) is not None:
+            raise NotImplementedError("FusedAdam: one parameter group, fixed at construction (the device table is sized for it)")
+        return super().add_param_group(param_group)
+
     def _state_of(self, p):
         st = self.state[p]
+        slot = self._steps[self._index[id(p)]]
         if not st:
-            st["step"] = self._steps[self._index[id(p)]]
+            st["step"] = slot
             st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        elif st["step"].data_ptr() != slot.data_ptr():
+            # state that came in through load_state_dict (a torch.optim.Adam checkpoint, map_location='cpu', an int64 / float64
+            # counter ...): the kernel reads the step through a device pointer -- copy the value into this optimizer's own slot
+            slot.copy_(torch.as_tensor(st["step"], dtype=torch.float32).reshape(()))
+            st["step"] = slot
+            for k in ("exp_avg", "exp_avg_sq"):
+                if st[k].device != p.device or st[k].dtype != torch.float32 or not st[k].is_contiguous():
+                    st[k] = st[k].to(device=p.device, dtype=torch.float32).contiguous()
         return st
 
     @torch.no_grad()

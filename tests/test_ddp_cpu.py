@@ -54,7 +54,9 @@ def _worker(rank, world, port, q):
             loss.backward()
             red.reduce()
             opt.step()
-        assert "dead.weight" not in red.names and "bin_score" not in red.names and "a.weight" in red.names
+        # a slot for every trainable parameter (fixed size: every rank always enters the same collective), gradients only for the live ones
+        assert "dead.weight" in red.names and "a.weight" in red.names and net.dead.weight.grad is None
+        assert red.bucket_bytes == 4 * (sum(p.numel() for p in net.parameters() if p.requires_grad) + red.GUARD)
         # plain numpy: torch tensors travel through shared-memory handles that die with the worker
         q.put((rank, {k: v.detach().cpu().numpy().copy() for k, v in net.state_dict().items()}, red.payload_bytes))
     finally:
@@ -160,10 +162,45 @@ def _trainer_worker(rank, world, port, q):
             payloads.append(tr.reducer.payload_bytes)
             assert (net.flow.weight.grad is None) == pre          # no gradient under the pre-training loss: Adam skips it
             assert net.dead.weight.grad is None
-        assert "flow.weight" in tr.reducer.names and "dead.weight" not in tr.reducer.names
+        assert "flow.weight" in tr.reducer.names and "dead.weight" in tr.reducer.names
         q.put((rank, {k: v.detach().cpu().numpy().copy() for k, v in net.state_dict().items()}, payloads))
     finally:
         dist.destroy_process_group()
+
+
+def _diverging_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ratrack_amd.train import Trainer
+        torch.manual_seed(300)
+        net = TinyBackbone()
+        tr = Trainer(net, lr=1e-2)
+        t = shard_batch(next(iter(_tiny_batches(1, 4))), rank, world)
+        try:      # rank 1 runs the pre-training loss, rank 0 the full loss: different live sets
+            tr.step(t["pc1"], t["pc2"], t["feature1"], t["feature2"], t["gt_warp"], t["gt_cls"], torch.zeros(5, 2, 4), pretrain=(rank == 1))
+            q.put((rank, "no error"))
+        except RuntimeError as e:
+            q.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_diverging_live_sets_raise_instead_of_hanging():
+    """Advisor r2: ranks whose sets of parameters with a gradient differ used to enter DIFFERENT collectives (a hang).  The bucket
+    has a fixed size now and the live-set digest rides in the same all-reduce: both ranks get the error, before the optimizer step."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_diverging_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    msgs = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all("gradient buckets differ across ranks" in m for m in msgs.values()), msgs
 
 
 def test_trainer_over_gloo_matches_manual_gradient_averaging():
@@ -187,7 +224,8 @@ def test_trainer_over_gloo_matches_manual_gradient_averaging():
         p.join(60)
         assert p.exitcode == 0
     seg_bytes = 4 * (5 * 8 + 8 + 8 + 8 + 8 + 1)
-    assert res[0][1] == [seg_bytes] * 2 + [seg_bytes + 4 * 18] * 4, res[0][1]
+    full_bytes = seg_bytes + 4 * 18
+    assert res[0][1] == [seg_bytes, seg_bytes, full_bytes, full_bytes, seg_bytes, full_bytes], res[0][1]      # live gradients of each step
     for k in res[0][0]:
         if "running" in k:
             continue                                              # per-replica BatchNorm statistics
