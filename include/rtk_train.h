@@ -64,6 +64,16 @@ typedef struct {
 } rtk_bn_fin_t;
 RTK_EXPORT int rtk_bn_relu_fwd_fin(int samples, int channels, int rows, int ns, int groups, const float *z, const rtk_bn_fin_t *fin,
                                    float *par_out, int pool, float *y, rtk_stream_t stream);
+/* The pooled form that also records, per (sample, channel, row), the element the row's gradient will go to: zarg = its z value,
+ * karg = its index inside the row (first arg-max of y; 255 when the whole row is clipped by the ReLU and receives no gradient).
+ * With them the backward of the pooled layer needs no pass of its own over z:
+ *   rtk_pool_bwd_stats_arg: sums2 (RTK_STAT_SLOTS, groups, C, 2) float64 += (sum d, sum d xhat(zarg)) over the rows, d = dy [karg != 255];
+ *   the layer's dz = scale ((k == karg ? d : 0) - w (sums2[0] + xhat sums2[1]) / count) is formed ON LOAD by the consumers
+ *   (rtk_conv_wgrad_stats / rtk_conv_bn_bwd_apply with a pooled source) from z itself. */
+RTK_EXPORT int rtk_bn_relu_pool_fwd_fin_arg(int samples, int channels, int rows, int ns, int groups, const float *z, const rtk_bn_fin_t *fin,
+                                            float *par_out, float *y, float *zarg_out, unsigned char *karg_out, rtk_stream_t stream);
+RTK_EXPORT int rtk_pool_bwd_stats_arg(int samples, int channels, int rows, int groups, const float *dy, const float *zarg,
+                                      const unsigned char *karg, const float *par, double *sums2, rtk_stream_t stream);
 
 /* Backward, pass 1.  dy has the shape of y.  sums2 (groups, C, 2) float64 zero-initialised:
  * [..,0] += sum dy [y>0], [..,1] += sum dy [y>0] xhat   (pool: only the first arg-max position of each row counts). */
@@ -149,6 +159,34 @@ RTK_EXPORT int rtk_conv_bn_bwd(int samples, int cprev, int cout, int rows, int n
  * second kernel adds them in a fixed order: no atomics, deterministic. */
 RTK_EXPORT int rtk_conv_wgrad(int samples, int cprev, int cout, int rows, int ns, int groups, const float *dz, const float *zprev,
                               const float *pre_par, float *dw, float *workspace, long workspace_floats, rtk_stream_t stream);
+
+/* One pass instead of rtk_conv_wgrad + the statistics pass of rtk_conv_bn_bwd (both read dz and zprev):  dw (cout, cprev) +=
+ * sum dz a^T with a = relu(BatchNorm(zprev)), and sums2_out (RTK_STAT_SLOTS, groups, cprev, 2) float64, zero-initialised, +=
+ * (sum dy m, sum dy m xhat) with dy = W^T dz -- what rtk_conv_bn_bwd_apply then takes as `sums2`.  Computed as two position
+ * contractions G = dz m^T, H = dz (m xhat)^T per statistics group: dw = gamma H + beta G, sums2 = column sums of W o G, W o H.
+ * gamma_prev / beta_prev: affine parameters of zprev's BatchNorm; w: the layer's forward weight (cout, cprev).
+ * workspace: >= 2 * samples * cprev * cout floats of scratch (per-workgroup partials, added in a fixed order).
+ *
+ * Pooled source (`pool` != NULL, both functions): the first tensor is not dz but z of the pooled last layer of the chain, whose
+ * gradient is formed on load from the layer's output gradient and the arg-max recorded by rtk_bn_relu_pool_fwd_fin_arg:
+ *   dz = scale ((k == karg ? dout : 0) - w (c1 + xhat c2)),  (c1, c2) = pool.sums2 / count  (rtk_pool_bwd_stats_arg)
+ * -- the separate apply pass over z (read z, write dz) disappears.  pool.dgamma_dbeta (2, cout), optional, receives the pooled
+ * BatchNorm's parameter gradients from the apply kernel. */
+typedef struct {
+    const float *dout;              /* (samples, cout, rows) gradient of the pooled output */
+    const unsigned char *karg;      /* (samples, cout, rows) */
+    const float *par;               /* (4, groups, cout) of the pooled layer's BatchNorm */
+    const double *sums2;            /* (RTK_STAT_SLOTS, groups, cout, 2) */
+    float *dgamma_dbeta;            /* (2, cout) or NULL */
+} rtk_pool_src_t;
+RTK_EXPORT int rtk_conv_wgrad_stats(int samples, int cprev, int cout, int rows, int ns, int groups, const float *dz_or_z,
+                                    const rtk_pool_src_t *pool, const float *zprev, const float *pre_par, const float *row_weight, double count,
+                                    const float *w, const float *gamma_prev, const float *beta_prev, float *dw, double *sums2_out,
+                                    float *workspace, long workspace_floats, rtk_stream_t stream);
+RTK_EXPORT int rtk_conv_bn_bwd_apply(int samples, int cprev, int cout, int rows, int ns, int groups, const float *dz_or_z,
+                                     const rtk_pool_src_t *pool, const float *w, const float *zprev, const float *pre_par,
+                                     const float *row_weight, const double *sums2, double count, float *dzprev, float *dgamma_dbeta,
+                                     rtk_stream_t stream);
 
 /* ---- per-point layers: 1x1 convolutions on one row per point / centroid (feature propagation, nn.Linear bottlenecks, layer-1
  * feature projections, predictor heads: lib/pointnet2_modules.py:140-158, utils/model_utils/model_utils.py:308-357,393-424) -----

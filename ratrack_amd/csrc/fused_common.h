@@ -341,13 +341,18 @@ __device__ __forceinline__ f4 bias_frag(const float *__restrict__ bias, int v, i
 // re-read only after the 3 other components were issued; (2) a VGPR written by an MFMA needs up to 19 wait states before any
 // VALU read, and the compiler's hazard recognizer does not look inside inline asm: an accumulator that reached the asm block
 // directly was read too early (round 2: wrong maxima under a register cap).  rtk_dpp_fence makes every helper self-contained:
-// each component first goes through a compiler-VISIBLE DPP move (identity lane permutation), so the recognizer inserts exactly
-// the MFMA wait states the producer needs (none when the producer is an ordinary VALU op) in front of it.
+// each component first goes through a compiler-VISIBLE VALU instruction that cannot be folded away -- a bitwise OR with a zero
+// the optimiser cannot see (an SGPR written by a volatile asm) --, so the recognizer inserts exactly the MFMA wait states the
+// producer needs (none when the producer is an ordinary VALU op) in front of it; the block's own s_nop 1 then covers VALU -> DPP.
+// (Beware: __builtin_bit_cast(int, v.x) on an ext_vector_type ELEMENT reads element 0 whatever the element named -- hipcc 7.2;
+// __float_as_int on the element's value is fine.)
 __device__ __forceinline__ void rtk_dpp_fence(f4 &v) {
-    v.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v.x), __builtin_bit_cast(int, v.x), 0xE4, 0xf, 0xf, false));
-    v.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v.y), __builtin_bit_cast(int, v.y), 0xE4, 0xf, 0xf, false));
-    v.z = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v.z), __builtin_bit_cast(int, v.z), 0xE4, 0xf, 0xf, false));
-    v.w = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v.w), __builtin_bit_cast(int, v.w), 0xE4, 0xf, 0xf, false));
+    int zero;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+    v.x = __int_as_float(__float_as_int(v.x) | zero);
+    v.y = __int_as_float(__float_as_int(v.y) | zero);
+    v.z = __int_as_float(__float_as_int(v.z) | zero);
+    v.w = __int_as_float(__float_as_int(v.w) | zero);
 }
 #define RTK_DPP4(op, ctrl)                                                 \
     op " %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n"                 \

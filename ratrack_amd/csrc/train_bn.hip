@@ -220,13 +220,15 @@ __device__ __forceinline__ void row_argmax(const float4 v, float sc, float sh, i
 template <int G>
 __global__ __launch_bounds__(BN_T) void bn_relu_pool_fwd_kernel(int samples, int channels, int rows, int groups,
                                                                 const float *__restrict__ z, float *par, const rtk_bn_fin_t fin,
-                                                                float *__restrict__ y) {
+                                                                float *__restrict__ y, float *__restrict__ zarg_out,
+                                                                unsigned char *__restrict__ karg_out) {
     constexpr int NS = 4 * G;
     const Plane p = plane_of(samples, channels, rows, NS, groups);
     float sc, sh;
     fwd_constants(fin, par, channels, groups, p.g, sc, sh);
     const float *zp = z + p.base;
-    float *yp = y + ((size_t)blockIdx.y * channels + blockIdx.x) * rows;
+    const size_t rbase = ((size_t)blockIdx.y * channels + blockIdx.x) * rows;
+    float *yp = y + rbase;
     const int E4 = rows * G;
     for (int base = 0; base < E4; base += BN_T) {
         const int e4 = base + threadIdx.x;
@@ -235,7 +237,40 @@ __global__ __launch_bounds__(BN_T) void bn_relu_pool_fwd_kernel(int samples, int
         float ymax, zarg;
         int karg;
         row_argmax<G>(v, sc, sh, e4 % G, ymax, zarg, karg);
-        if (ok && (e4 % G) == 0) yp[e4 / G] = ymax;
+        if (ok && (e4 % G) == 0) {
+            yp[e4 / G] = ymax;
+            if (zarg_out) {      // for the backward: the element the row's gradient goes to (none while the whole row is clipped: 255)
+                zarg_out[rbase + e4 / G] = zarg;
+                karg_out[rbase + e4 / G] = ymax > 0.f ? (unsigned char)karg : (unsigned char)255;
+            }
+        }
+    }
+}
+
+// Backward statistics of a pooled BatchNorm + ReLU layer from the saved arg-max (zarg, karg): only one element per row carries a
+// gradient, so sums2 = (sum d, sum d xhat(zarg)) over the rows -- no pass over z.  One wave per (channel, sample) plane of `rows`.
+__global__ __launch_bounds__(BN_T) void pool_bwd_stats_arg_kernel(int samples, int channels, int rows, int groups,
+                                                                  const float *__restrict__ dy, const float *__restrict__ zarg,
+                                                                  const unsigned char *__restrict__ karg, const float *__restrict__ par,
+                                                                  double *__restrict__ sums2) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    if (c >= channels) return;
+    const int g = b / (samples / groups);
+    const size_t GC = (size_t)groups * channels, o = (size_t)g * channels + c;
+    const float mean = par[o], rstd = par[GC + o];
+    const size_t base = ((size_t)b * channels + c) * rows;
+    double s = 0.0, sx = 0.0;
+    for (int r = lane; r < rows; r += 64) {
+        const float d = karg[base + r] != 255 ? dy[base + r] : 0.f;
+        s += (double)d;
+        sx += (double)d * (double)((zarg[base + r] - mean) * rstd);
+    }
+    s = wave_sum_f64(s);
+    sx = wave_sum_f64(sx);
+    if (lane == 0) {
+        double *dst = rtk_stat_slot(sums2, GC * 2, b) + o * 2;
+        atomicAdd(dst, s);
+        atomicAdd(dst + 1, sx);
     }
 }
 
@@ -544,12 +579,13 @@ extern "C" int rtk_bn_train_stats(int samples, int channels, int rows, int ns, i
 }
 
 static int bn_relu_fwd_launch(int samples, int channels, int rows, int ns, int groups, const float *z, float *par,
-                              const rtk_bn_fin_t &fin, int pool, float *y, rtk_stream_t stream) {
+                              const rtk_bn_fin_t &fin, int pool, float *y, rtk_stream_t stream, float *zarg_out = nullptr,
+                              unsigned char *karg_out = nullptr) {
     RTK_BN_COMMON_CHECKS("rtk_bn_relu_fwd");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(channels, samples);
     if (pool) {
-        RTK_BN_POOL_DISPATCH(bn_relu_pool_fwd_kernel, samples, channels, rows, groups, z, par, fin, y)
+        RTK_BN_POOL_DISPATCH(bn_relu_pool_fwd_kernel, samples, channels, rows, groups, z, par, fin, y, zarg_out, karg_out)
     } else if (BN_SMALL_PLANE) {
         bn_relu_fwd_small_kernel<<<dim3(rtk_divup(channels, 4), samples), BN_T, 0, s>>>(samples, channels, rows, groups, z, par, fin, y);
     } else {
@@ -569,6 +605,23 @@ extern "C" int rtk_bn_relu_fwd_fin(int samples, int channels, int rows, int ns, 
                                    float *par_out, int pool, float *y, rtk_stream_t stream) {
     RTK_REQUIRE(fin && fin->sums && fin->gamma && fin->beta && fin->count > 1.0 && par_out, "rtk_bn_relu_fwd_fin: bad finalisation arguments");
     return bn_relu_fwd_launch(samples, channels, rows, ns, groups, z, par_out, *fin, pool, y, stream);
+}
+
+extern "C" int rtk_bn_relu_pool_fwd_fin_arg(int samples, int channels, int rows, int ns, int groups, const float *z, const rtk_bn_fin_t *fin,
+                                            float *par_out, float *y, float *zarg_out, unsigned char *karg_out, rtk_stream_t stream) {
+    RTK_REQUIRE(fin && fin->sums && fin->gamma && fin->beta && fin->count > 1.0 && par_out && zarg_out && karg_out,
+                "rtk_bn_relu_pool_fwd_fin_arg: bad arguments");
+    return bn_relu_fwd_launch(samples, channels, rows, ns, groups, z, par_out, *fin, 1, y, stream, zarg_out, karg_out);
+}
+
+extern "C" int rtk_pool_bwd_stats_arg(int samples, int channels, int rows, int groups, const float *dy, const float *zarg,
+                                      const unsigned char *karg, const float *par, double *sums2, rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && samples <= 65535 && channels > 0 && rows > 0 && groups > 0 && samples % groups == 0 && dy && zarg && karg && par &&
+                sums2, "rtk_pool_bwd_stats_arg: bad arguments");
+    pool_bwd_stats_arg_kernel<<<dim3(rtk_divup(channels, 4), samples), BN_T, 0, (hipStream_t)stream>>>(samples, channels, rows, groups, dy, zarg,
+                                                                                                 karg, par, sums2);
+    RTK_CHECK_LAUNCH("rtk_pool_bwd_stats_arg");
+    return RTK_OK;
 }
 
 extern "C" int rtk_bn_relu_bwd_stats(int samples, int channels, int rows, int ns, int groups, const float *z, const float *dy,

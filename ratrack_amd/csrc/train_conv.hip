@@ -44,10 +44,32 @@ struct TcParams {
     float *partial;         // weight gradient: one (16V, 16U) partial block per workgroup
     rtk_bn_fin_t fin;       // forward: fin.sums != NULL: the previous layer's BatchNorm is finalised here (and published into pre_out)
     float *pre_out;
+    // backward with a POOLED source: `in` is not dz but z of the pooled (last) layer; its dz is formed on load,
+    //     dz = scale ((k == karg ? d : 0) - w (c1 + xhat c2)),   d = dout[row], (c1, c2) = pool_sums / count, xhat = (z - mean) rstd
+    const float *pool_dout;         // (S, 16U, rows)
+    const unsigned char *pool_karg; // (S, 16U, rows): index of the row's arg-max element, 255 = no gradient
+    const float *pool_par;          // (4, groups, 16U) of the pooled layer's BatchNorm
+    const double *pool_sums;        // (RTK_STAT_SLOTS, groups, 16U, 2): rtk_pool_bwd_stats_arg
+    float *pool_dgb;                // (2, 16U) dgamma | dbeta of the pooled layer's BatchNorm (written by the apply pass)
+    const float *gamma_prev, *beta_prev;   // wgrad+stats: the previous layer's BatchNorm affine parameters (16 cin each)
+    double *stats_out;              // wgrad+stats: (RTK_STAT_SLOTS, groups, cin, 2) float64, zero-initialised
 };
 
-// MODE 0: forward.  MODE 1: backward statistics.  MODE 2: backward apply.
-template <int U, int V, int MODE>
+// dz of a pooled layer from z (four consecutive positions of one row: ns >= 4), see TcParams
+struct PoolCoef {
+    float mean, rstd, sc, c1, c2;
+};
+__device__ __forceinline__ f4 pool_dz(const f4 z, const PoolCoef k, float d, int karg, int k0, float wl) {
+    f4 o;
+    o.x = k.sc * ((karg == k0 ? d : 0.f) - wl * (k.c1 + (z.x - k.mean) * k.rstd * k.c2));
+    o.y = k.sc * ((karg == k0 + 1 ? d : 0.f) - wl * (k.c1 + (z.y - k.mean) * k.rstd * k.c2));
+    o.z = k.sc * ((karg == k0 + 2 ? d : 0.f) - wl * (k.c1 + (z.z - k.mean) * k.rstd * k.c2));
+    o.w = k.sc * ((karg == k0 + 3 ? d : 0.f) - wl * (k.c1 + (z.w - k.mean) * k.rstd * k.c2));
+    return o;
+}
+
+// MODE 0: forward.  MODE 1: backward statistics.  MODE 2: backward apply.  POOL (backward): pooled source, see TcParams.
+template <int U, int V, int MODE, bool POOL = false>
 __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
     __shared__ __attribute__((aligned(16))) f4 s_w[U * V * 64];
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
@@ -90,6 +112,28 @@ __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
                 s_c1[c] = (float)(rtk_stat_read(Q.sums, GC * 2, (o + c) * 2) / Q.count);
                 s_c2[c] = (float)(rtk_stat_read(Q.sums, GC * 2, (o + c) * 2 + 1) / Q.count);
             }
+        }
+    }
+    // pooled source: constants of the dz-side channels (16U)
+    __shared__ float s_pm[POOL ? 16 * U : 1], s_pr[POOL ? 16 * U : 1], s_ps[POOL ? 16 * U : 1], s_p1[POOL ? 16 * U : 1], s_p2[POOL ? 16 * U : 1];
+    if constexpr (POOL) {
+        const size_t GC = (size_t)Q.groups * 16 * U, o = (size_t)grp * 16 * U;
+        for (int c = threadIdx.x; c < 16 * U; c += TC_T) {
+            s_pm[c] = Q.pool_par[o + c];
+            s_pr[c] = Q.pool_par[GC + o + c];
+            s_ps[c] = Q.pool_par[2 * GC + o + c];
+            s_p1[c] = (float)(rtk_stat_read(Q.pool_sums, GC * 2, (o + c) * 2) / Q.count);
+            s_p2[c] = (float)(rtk_stat_read(Q.pool_sums, GC * 2, (o + c) * 2 + 1) / Q.count);
+        }
+        if (Q.pool_dgb && b == 0 && blockIdx.x == 0 && threadIdx.x < 16 * U) {
+            const int c = threadIdx.x;
+            double db = 0.0, dg = 0.0;
+            for (int gg = 0; gg < Q.groups; ++gg) {
+                db += rtk_stat_read(Q.pool_sums, GC * 2, ((size_t)gg * 16 * U + c) * 2);
+                dg += rtk_stat_read(Q.pool_sums, GC * 2, ((size_t)gg * 16 * U + c) * 2 + 1);
+            }
+            Q.pool_dgb[c] = (float)dg;
+            Q.pool_dgb[16 * U + c] = (float)db;
         }
     }
     __syncthreads();
@@ -152,6 +196,13 @@ __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 f4 x = xin[u][r];
+                if constexpr (POOL) {      // x holds z of the pooled layer: form its dz (the four positions share a row: ns >= 4)
+                    const int cc = 16 * u + 4 * g + r;
+                    const int pq = ok ? p : P - 4;
+                    const size_t ro = ((size_t)b * 16 * U + cc) * Q.rows + (pq >> Q.lg_ns);
+                    const PoolCoef kc = {s_pm[cc], s_pr[cc], s_ps[cc], s_p1[cc], s_p2[cc]};
+                    x = pool_dz(x, kc, Q.pool_dout[ro], (int)Q.pool_karg[ro], pq & ((1 << Q.lg_ns) - 1), wl);
+                }
                 if (MODE == 0) {
                     if (has_pre) {
                         const float sc = s_sc[16 * u + 4 * g + r], sh = s_sh[16 * u + 4 * g + r];
@@ -377,13 +428,189 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(int n, int wgs, 
     dw[e] += sum;
 }
 
+// ---- weight gradient + BatchNorm-backward statistics in ONE pass over (dz, zprev) -------------------------------------------------
+// For z = W a, a = relu(BatchNorm(zprev)) = m (gamma xhat + beta) with m the ReLU mask and xhat the normalised zprev, define
+//     G[co][ci] = sum_p dz[co][p] m[ci][p],      H[co][ci] = sum_p dz[co][p] m[ci][p] xhat[ci][p]        (per statistics group).
+// Then   dW[co][ci]  = sum_p dz a = gamma[ci] H + beta[ci] G                                              (summed over the groups)
+// and the statistics the backward of the previous BatchNorm needs, with dy = W^T dz:
+//     sum_p dy[ci] m      = sum_co W[co][ci] G[co][ci],        sum_p dy[ci] m xhat = sum_co W[co][ci] H[co][ci].
+// Two position-contractions on MFMA (the operands of the old weight-gradient kernel, B = m and B = m xhat instead of B = a) replace
+// the weight-gradient kernel AND the statistics pass of rtk_conv_bn_bwd, which read the same two tensors a second time.  One wave
+// per SIMD (two 16V x 16U accumulator blocks = 128 registers at 64 x 64), the next tile's operands in flight across the MFMAs.
+template <int U, int V, bool POOL>
+__global__ __launch_bounds__(TC_T, 1) void conv_wgrad_stats_kernel(const TcParams Q) {
+    __shared__ float s_red[TC_T / 64][16 * V][16 * U + 1];
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int grp = b / (Q.samples / Q.groups);
+    const int P = Q.P;
+    const unsigned pitch = 4u * (unsigned)P;
+    const char *dzb = reinterpret_cast<const char *>(Q.in + (size_t)b * 16 * V * P);        // dz, or z of the pooled layer (S, 16V, P)
+    const char *zpb = reinterpret_cast<const char *>(Q.zprev + (size_t)b * 16 * U * P);     // zprev (S, 16U, P)
+    float sc[U], sh[U], mu[U], rs[U];
+    {
+        const size_t GC = (size_t)Q.groups * 16 * U, o = (size_t)grp * 16 * U;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            mu[u] = Q.pre[o + 16 * u + j];
+            rs[u] = Q.pre[GC + o + 16 * u + j];
+            sc[u] = Q.pre[2 * GC + o + 16 * u + j];
+            sh[u] = Q.pre[3 * GC + o + 16 * u + j];
+        }
+    }
+    PoolCoef pk[POOL ? V : 1];
+    if constexpr (POOL) {
+        const size_t GC = (size_t)Q.groups * 16 * V, o = (size_t)grp * 16 * V;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int c = 16 * v + j;
+            pk[v].mean = Q.pool_par[o + c];
+            pk[v].rstd = Q.pool_par[GC + o + c];
+            pk[v].sc = Q.pool_par[2 * GC + o + c];
+            pk[v].c1 = (float)(rtk_stat_read(Q.pool_sums, GC * 2, (o + c) * 2) / Q.count);
+            pk[v].c2 = (float)(rtk_stat_read(Q.pool_sums, GC * 2, (o + c) * 2 + 1) / Q.count);
+        }
+    }
+    f4 accG[V][U], accH[V][U];
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int u = 0; u < U; ++u) { accG[v][u] = f4_zero(); accH[v][u] = f4_zero(); }
+    const int ntiles = (P + 15) / 16;
+    struct Tile {
+        f4 a[V], x[U];
+        float d[POOL ? V : 1];
+        int k[POOL ? V : 1];
+    };
+    auto fetch = [&](int t, Tile &T) {
+        const int p = 16 * t + 4 * g;
+        const int pq = p < P ? p : P - 4;
+        const unsigned po = 4u * (unsigned)pq;
+#pragma unroll
+        for (int v = 0; v < V; ++v) T.a[v] = *reinterpret_cast<const f4 *>(dzb + (unsigned)(16 * v + j) * pitch + po);
+#pragma unroll
+        for (int u = 0; u < U; ++u) T.x[u] = *reinterpret_cast<const f4 *>(zpb + (unsigned)(16 * u + j) * pitch + po);
+        if constexpr (POOL) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const size_t ro = ((size_t)b * 16 * V + 16 * v + j) * Q.rows + (pq >> Q.lg_ns);
+                T.d[v] = Q.pool_dout[ro];
+                T.k[v] = (int)Q.pool_karg[ro];
+            }
+        }
+    };
+    const int tstep = gridDim.x * (TC_T / 64);
+    int t = blockIdx.x * (TC_T / 64) + wave;
+    Tile nxt;
+    if (t < ntiles) fetch(t, nxt);
+    for (; t < ntiles; t += tstep) {
+        const int p = 16 * t + 4 * g;
+        const bool ok = p < P;
+        f4 a[V], bm[U], bx[U];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            f4 q = nxt.a[v];
+            if constexpr (POOL) {
+                const float wl = Q.rw ? Q.rw[(size_t)b * Q.rows + ((ok ? p : P - 4) >> Q.lg_ns)] : 1.f;
+                q = pool_dz(q, pk[v], nxt.d[v], nxt.k[v], (ok ? p : P - 4) & ((1 << Q.lg_ns) - 1), wl);
+            }
+            a[v] = ok ? q : f4_zero();
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const f4 x = nxt.x[u];
+            f4 m, xh;
+            m.x = __fmaf_rn(x.x, sc[u], sh[u]) > 0.f ? 1.f : 0.f;
+            m.y = __fmaf_rn(x.y, sc[u], sh[u]) > 0.f ? 1.f : 0.f;
+            m.z = __fmaf_rn(x.z, sc[u], sh[u]) > 0.f ? 1.f : 0.f;
+            m.w = __fmaf_rn(x.w, sc[u], sh[u]) > 0.f ? 1.f : 0.f;
+            xh.x = m.x * ((x.x - mu[u]) * rs[u]); xh.y = m.y * ((x.y - mu[u]) * rs[u]);
+            xh.z = m.z * ((x.z - mu[u]) * rs[u]); xh.w = m.w * ((x.w - mu[u]) * rs[u]);
+            bm[u] = m; bx[u] = xh;
+        }
+        if (t + tstep < ntiles) fetch(t + tstep, nxt);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    accG[v][u] = mfma4(a[v][q], bm[u][q], accG[v][u]);
+                    accH[v][u] = mfma4(a[v][q], bx[u][q], accH[v][u]);
+                }
+    }
+    // D layout: acc[v][u][r] = out[16v + 4g + r][16u + j]; per-wave LDS images added on the way out, G then H
+    float *part = Q.partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * 256 * U * V);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_red[wave][16 * v + 4 * g + r][16 * u + j] = half ? accH[v][u][r] : accG[v][u][r];
+        __syncthreads();
+        for (int e = threadIdx.x; e < 16 * V * 16 * U; e += TC_T) {
+            const int co = e / (16 * U), ci = e % (16 * U);
+            part[half * (256 * U * V) + e] = (s_red[0][co][ci] + s_red[1][co][ci]) + (s_red[2][co][ci] + s_red[3][co][ci]);
+        }
+    }
+}
+
+// partials (wgs, 2, n) -> per group G_g, H_g (fixed summation order) -> dw[e] += sum_g gamma[ci] H_g + beta[ci] G_g, and the
+// BatchNorm-backward statistics stats[g][ci] += (W[co][ci] G_g, W[co][ci] H_g) (float64 atomics: 16V contributions per address)
+__global__ __launch_bounds__(256) void conv_wgrad_stats_reduce_kernel(int n, int cin, int wgs, int groups, const float *__restrict__ partial,
+                                                                      const float *__restrict__ w, const float *__restrict__ gamma,
+                                                                      const float *__restrict__ beta, float *__restrict__ dw,
+                                                                      double *__restrict__ stats) {
+    __shared__ float s_part[2][16][17];
+    const int el = threadIdx.x & 15, zl = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
+    const float *src = partial + (e < n ? e : n - 1);
+    const int per = wgs / groups;
+    float dwe = 0.f;
+    for (int grp = 0; grp < groups; ++grp) {
+        float a[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[h][k] = 0.f;
+        for (int z0 = zl; z0 < per; z0 += 64) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int z = z0 + 16 * k;
+                const size_t row = (size_t)(grp * per + (z < per ? z : 0)) * 2 * n;
+                const float g0 = src[row], h0 = src[row + n];
+                a[0][k] += z < per ? g0 : 0.f;
+                a[1][k] += z < per ? h0 : 0.f;
+            }
+        }
+        __syncthreads();
+        s_part[0][zl][el] = (a[0][0] + a[0][1]) + (a[0][2] + a[0][3]);
+        s_part[1][zl][el] = (a[1][0] + a[1][1]) + (a[1][2] + a[1][3]);
+        __syncthreads();
+        if (zl == 0 && e < n) {
+            float G = 0.f, H = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { G += s_part[0][q][el]; H += s_part[1][q][el]; }
+            const int ci = e % cin;
+            dwe += gamma[ci] * H + beta[ci] * G;
+            double *dst = stats + ((size_t)grp * cin + ci) * 2;          // replica 0 of (RTK_STAT_SLOTS, groups, cin, 2)
+            atomicAdd(dst, (double)w[e] * (double)G);
+            atomicAdd(dst + 1, (double)w[e] * (double)H);
+        }
+    }
+    if (zl == 0 && e < n) dw[e] += dwe;
+}
+
 int ilog2x(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
     return (1 << l) == v ? l : -1;
 }
 
-template <int MODE>
+template <int MODE, bool POOL = false>
 int launch(const TcParams &Q, int cin, int cout, hipStream_t s) {
     const int U = cin / 16, V = cout / 16;
     const int nchunks = (Q.P + TC_CHUNK - 1) / TC_CHUNK;
@@ -396,7 +623,7 @@ int launch(const TcParams &Q, int cin, int cout, hipStream_t s) {
     const dim3 grid(gx, Q.samples);
 #define TC_CASE(u, v)                                                    \
     if (U == u && V == v) {                                              \
-        conv_bn_kernel<u, v, MODE><<<grid, TC_T, 0, s>>>(Q);             \
+        conv_bn_kernel<u, v, MODE, POOL><<<grid, TC_T, 0, s>>>(Q);       \
         return 0;                                                        \
     }
     TC_CASE(1, 1) TC_CASE(1, 2) TC_CASE(1, 4) TC_CASE(2, 1) TC_CASE(2, 2) TC_CASE(2, 4) TC_CASE(4, 1) TC_CASE(4, 2) TC_CASE(4, 4)
@@ -467,6 +694,63 @@ extern "C" int rtk_conv_bn_bwd(int samples, int cprev, int cout, int rows, int n
     if (apply) launch<2>(Q, cout, cprev, (hipStream_t)stream);
     else launch<1>(Q, cout, cprev, (hipStream_t)stream);
     RTK_CHECK_LAUNCH("rtk_conv_bn_bwd");
+    return RTK_OK;
+}
+
+static void set_pool(TcParams &Q, const rtk_pool_src_t *pool) {
+    Q.pool_dout = pool->dout; Q.pool_karg = pool->karg; Q.pool_par = pool->par; Q.pool_sums = pool->sums2; Q.pool_dgb = pool->dgamma_dbeta;
+}
+
+extern "C" int rtk_conv_bn_bwd_apply(int samples, int cprev, int cout, int rows, int ns, int groups, const float *dz_or_z, const rtk_pool_src_t *pool,
+                                     const float *w, const float *zprev, const float *pre_par, const float *row_weight, const double *sums2,
+                                     double count, float *dzprev, float *dgamma_dbeta, rtk_stream_t stream) {
+    if (int rc = check("rtk_conv_bn_bwd_apply", samples, cout, cprev, rows, ns, groups)) return rc;
+    RTK_REQUIRE(dz_or_z && w && zprev && pre_par && sums2 && dzprev, "rtk_conv_bn_bwd_apply: null argument");
+    RTK_REQUIRE(!pool || (pool->dout && pool->karg && pool->par && pool->sums2), "rtk_conv_bn_bwd_apply: incomplete pooled source");
+    TcParams Q = {};
+    Q.samples = samples; Q.rows = rows; Q.lg_ns = ilog2x(ns); Q.groups = groups; Q.P = rows * ns;
+    Q.in = dz_or_z; Q.w_packed = w; Q.pre = pre_par; Q.zprev = zprev; Q.rw = row_weight; Q.out = dzprev; Q.sums = const_cast<double *>(sums2);
+    Q.count = count; Q.dgb = dgamma_dbeta;
+    if (pool) {
+        set_pool(Q, pool);
+        launch<2, true>(Q, cout, cprev, (hipStream_t)stream);
+    } else {
+        launch<2, false>(Q, cout, cprev, (hipStream_t)stream);
+    }
+    RTK_CHECK_LAUNCH("rtk_conv_bn_bwd_apply");
+    return RTK_OK;
+}
+
+extern "C" int rtk_conv_wgrad_stats(int samples, int cprev, int cout, int rows, int ns, int groups, const float *dz_or_z, const rtk_pool_src_t *pool,
+                                    const float *zprev, const float *pre_par, const float *row_weight, double count, const float *w,
+                                    const float *gamma_prev, const float *beta_prev, float *dw, double *sums2_out, float *workspace,
+                                    long workspace_floats, rtk_stream_t stream) {
+    if (int rc = check("rtk_conv_wgrad_stats", samples, cprev, cout, rows, ns, groups)) return rc;
+    RTK_REQUIRE(dz_or_z && zprev && pre_par && w && gamma_prev && beta_prev && dw && sums2_out && workspace, "rtk_conv_wgrad_stats: null argument");
+    RTK_REQUIRE(!pool || (pool->dout && pool->karg && pool->par && pool->sums2), "rtk_conv_wgrad_stats: incomplete pooled source");
+    TcParams Q = {};
+    Q.samples = samples; Q.rows = rows; Q.lg_ns = ilog2x(ns); Q.groups = groups; Q.P = rows * ns;
+    Q.in = dz_or_z; Q.zprev = zprev; Q.pre = pre_par; Q.rw = row_weight; Q.count = count; Q.partial = workspace;
+    if (pool) set_pool(Q, pool);
+    const int U = cprev / 16, V = cout / 16;
+    const int ntiles = (Q.P + 15) / 16;
+    RTK_REQUIRE(workspace_floats >= 2L * samples * cprev * cout, "rtk_conv_wgrad_stats: workspace of %ld floats < %ld", workspace_floats,
+                2L * samples * cprev * cout);
+    int gx = (ntiles + 3) / 4;                                           // at least one tile per wave ...
+    while (((long)gx * samples > 512 || 2L * gx * samples * cprev * cout > workspace_floats) && gx > 1) gx = (gx + 1) / 2;
+    const dim3 grid(gx, samples);                                        // ... and about two one-wave-per-SIMD workgroups per CU
+    hipStream_t s = (hipStream_t)stream;
+#define TS_CASE(u, v)                                                                  \
+    if (U == u && V == v) {                                                            \
+        if (pool) conv_wgrad_stats_kernel<u, v, true><<<grid, TC_T, 0, s>>>(Q);        \
+        else conv_wgrad_stats_kernel<u, v, false><<<grid, TC_T, 0, s>>>(Q);            \
+    }
+    TS_CASE(1, 1) TS_CASE(1, 2) TS_CASE(1, 4) TS_CASE(2, 1) TS_CASE(2, 2) TS_CASE(2, 4) TS_CASE(4, 1) TS_CASE(4, 2) TS_CASE(4, 4)
+#undef TS_CASE
+    RTK_CHECK_LAUNCH("rtk_conv_wgrad_stats");
+    conv_wgrad_stats_reduce_kernel<<<(cprev * cout + 15) / 16, 256, 0, s>>>(cprev * cout, cprev, gx * samples, groups, workspace, w, gamma_prev,
+                                                                          beta_prev, dw, sums2_out);
+    RTK_CHECK_LAUNCH("rtk_conv_wgrad_stats");
     return RTK_OK;
 }
 
