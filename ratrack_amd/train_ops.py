@@ -43,6 +43,20 @@ _lib.SIGNATURES.update({
 })
 
 
+class _PoolSrc(ctypes.Structure):        # rtk_pool_src_t (include/rtk_train.h)
+    _fields_ = [("dout", ctypes.c_void_p), ("karg", ctypes.c_void_p), ("par", ctypes.c_void_p), ("sums2", ctypes.c_void_p),
+                ("dgamma_dbeta", ctypes.c_void_p)]
+
+
+_PoolP = ctypes.POINTER(_PoolSrc)
+_lib.SIGNATURES.update({
+    "rtk_bn_relu_pool_fwd_fin_arg": [_i] * 5 + [_p, _p, _p, _p, _p, _p, _p],
+    "rtk_pool_bwd_stats_arg": [_i] * 4 + [_p] * 5 + [_p],
+    "rtk_conv_wgrad_stats": [_i] * 6 + [_p, _PoolP, _p, _p, _p, _d, _p, _p, _p, _p, _p, _p, ctypes.c_long, _p],
+    "rtk_conv_bn_bwd_apply": [_i] * 6 + [_p, _PoolP, _p, _p, _p, _p, _p, _d, _p, _p, _p],
+})
+
+
 class _PwOperand(ctypes.Structure):      # rtk_pw_operand_t (include/rtk_train.h)
     _fields_ = [("ptr", ctypes.c_void_p), ("sample_stride", ctypes.c_long), ("pitch", ctypes.c_int), ("channels", ctypes.c_int),
                 ("layout", ctypes.c_int), ("col0", ctypes.c_int)]
@@ -416,9 +430,15 @@ class _SAChain(torch.autograd.Function):
             zs.append(z)
         C = zs[-1].shape[1]
         out = torch.empty(S_, C, rows, dtype=torch.float32, device=dev)
-        _lib.call("rtk_bn_relu_fwd_fin", S_, C, rows, ns, groups, zs[-1].data_ptr(), fin, par.data_ptr(), 1, out.data_ptr(), _stream())
+        # the pooled layer also records which element of every row its gradient will go to (and that element's z): the backward
+        # then needs no pass of its own over z for this layer
+        zarg = torch.empty(S_, C, rows, dtype=torch.float32, device=dev)
+        karg = torch.empty(S_, C, rows, dtype=torch.uint8, device=dev)
+        _lib.call("rtk_bn_relu_pool_fwd_fin_arg", S_, C, rows, ns, groups, zs[-1].data_ptr(), fin, par.data_ptr(), out.data_ptr(), zarg.data_ptr(),
+                  karg.data_ptr(), _stream())
         pars.append(par)
-        ctx.save_for_backward(row_w, idx, dxyz, *zs, *pars, *[w for w in weights[1:]], w0, *feats)
+        ctx.save_for_backward(row_w, idx, dxyz, zarg, karg, *zs, *pars, *[w for w in weights[1:]], w0, *feats)
+        ctx.bn_affine = [(b.weight.detach(), b.bias.detach()) for b in bns]
         ctx.cfg = (count, groups, L, n_src, nfeat, cols)
         ctx.inv = inv
         return out
@@ -429,8 +449,8 @@ class _SAChain(torch.autograd.Function):
         saved = list(ctx.saved_tensors)
         feats, w0 = saved[len(saved) - nfeat:], saved[len(saved) - nfeat - 1]
         saved = saved[:len(saved) - nfeat - 1]
-        row_w, idx, dxyz = saved[0:3]
-        saved = saved[2:]
+        row_w, idx, dxyz, zarg, karg = saved[0:5]
+        saved = saved[4:]
         zs = saved[1:1 + L]
         pars, weights = saved[1 + L:1 + 2 * L], [None] + saved[1 + 2 * L:]
         W0 = w0.detach().reshape(w0.shape[0], -1)
@@ -438,39 +458,40 @@ class _SAChain(torch.autograd.Function):
         dev = dout.device
         dout = dout.contiguous()
         f64 = _SumsPool(groups, [z.shape[1] for z in zs], dev)
-        # last layer: BN + ReLU + max-pool
+        # last layer (BatchNorm + ReLU + max-pool): its statistics from the recorded arg-max -- no pass over z --, its dz formed on load
+        # by the two consumers below (`pool` source)
         C = zs[-1].shape[1]
-        sums2 = f64(C)
-        _lib.call("rtk_bn_relu_bwd_stats", S_, C, rows, ns, groups, zs[-1].data_ptr(), dout.data_ptr(), pars[-1].data_ptr(), 1,
-                  sums2.data_ptr(), _stream())
-        dz = torch.empty_like(zs[-1])
-        dgb = torch.empty(2, C, dtype=torch.float32, device=dev)
-        _lib.call("rtk_bn_relu_bwd_apply", S_, C, rows, ns, groups, zs[-1].data_ptr(), dout.data_ptr(), pars[-1].data_ptr(), _ptr(row_w),
-                  sums2.data_ptr(), float(count), None, 1, dz.data_ptr(), dgb.data_ptr(), _stream())
-        grads = {L - 1: (None, dgb[0], dgb[1])}
-        C1_ = zs[0].shape[1]
+        sums_last = f64(C)
+        _lib.call("rtk_pool_bwd_stats_arg", S_, C, rows, groups, dout.data_ptr(), zarg.data_ptr(), karg.data_ptr(), pars[-1].data_ptr(),
+                  sums_last.data_ptr(), _stream())
+        dgb_last = torch.empty(2, C, dtype=torch.float32, device=dev)
+        pool = _PoolSrc(dout.data_ptr(), karg.data_ptr(), pars[-1].data_ptr(), sums_last.data_ptr(), dgb_last.data_ptr())
+        grads = {L - 1: (None, dgb_last[0], dgb_last[1])}
         dwbuf = _zeros((sum(w.numel() for w in weights[1:]) + W0.numel(),), torch.float32, dev)      # all dW of the chain | dW0
         dW0 = dwbuf[dwbuf.numel() - W0.numel():].view(W0.shape[0], W0.shape[1])
         dwoff = 0
+        src, src_pool = zs[-1], ctypes.byref(pool)             # the gradient source of the layer being walked: (z, pool) or (dz, None)
         for i in range(L - 1, 0, -1):
             W = weights[i]
             Co, Ci = W.shape[0], W.shape[1]
             dW = dwbuf[dwoff:dwoff + W.numel()].view_as(W)
             dwoff += W.numel()
-            ws = torch.empty(max(S_, 1024) * Ci * Co, dtype=torch.float32, device=dev)       # workgroup partials (uninitialised scratch)
-            _lib.call("rtk_conv_wgrad", S_, Ci, Co, rows, ns, groups, dz.data_ptr(), zs[i - 1].data_ptr(), pars[i - 1].data_ptr(),
-                      dW.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
-            wc = W.contiguous()
+            wc = W.detach().contiguous()
+            ga, be = ctx.bn_affine[i - 1]
+            ws = torch.empty(2 * max(S_, 512) * Ci * Co, dtype=torch.float32, device=dev)       # workgroup partials (uninitialised scratch)
             sums2 = f64(Ci)
-            args = (S_, Ci, Co, rows, ns, groups, dz.data_ptr(), wc.data_ptr(), zs[i - 1].data_ptr(), pars[i - 1].data_ptr(), _ptr(row_w),
-                    sums2.data_ptr(), float(count))
-            _lib.call("rtk_conv_bn_bwd", *args, 0, None, None, _stream())
+            # ONE pass over (dz, z[i-1]): the weight gradient AND the statistics of the previous BatchNorm's backward
+            _lib.call("rtk_conv_wgrad_stats", S_, Ci, Co, rows, ns, groups, src.data_ptr(), src_pool, zs[i - 1].data_ptr(), pars[i - 1].data_ptr(),
+                      _ptr(row_w), float(count), wc.data_ptr(), ga.data_ptr(), be.data_ptr(), dW.data_ptr(), sums2.data_ptr(), ws.data_ptr(),
+                      ws.numel(), _stream())
             dzp = torch.empty_like(zs[i - 1])
             dgb = torch.empty(2, Ci, dtype=torch.float32, device=dev)
-            _lib.call("rtk_conv_bn_bwd", *args, 1, dzp.data_ptr(), dgb.data_ptr(), _stream())
+            _lib.call("rtk_conv_bn_bwd_apply", S_, Ci, Co, rows, ns, groups, src.data_ptr(), src_pool, wc.data_ptr(), zs[i - 1].data_ptr(),
+                      pars[i - 1].data_ptr(), _ptr(row_w), sums2.data_ptr(), float(count), dzp.data_ptr(), dgb.data_ptr(), _stream())
             grads[i] = (dW, grads[i][1], grads[i][2])
             grads[i - 1] = (None, dgb[0], dgb[1])
-            dz = dzp
+            src, src_pool = dzp, None
+        dz = src
         flat = [grads[0][1], grads[0][2]]
         for i in range(1, L):
             flat += [grads[i][0], grads[i][1], grads[i][2]]
