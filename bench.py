@@ -14,7 +14,7 @@ synchronize on both sides and the maximum over ranks is reported.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline            the dominant kernel (cost_volume_split_kernel) against its matrix peak (dense bf16 / 6 products per fp32
-                      product; cost_volume_kernel against the fp32-input MFMA peak with RTK_CV_SPLIT=0); duration measured IN SITU:
+                      product; the fp32-input MFMA kernel it replaced is the tests' comparison implementation); duration measured IN SITU:
                       a second timed region replays the same pipelined workload with the graph split around the kernel,
                       which is launched eagerly between two HIP events on its own launch stream;
   whole_path          pairs/s against both rooflines (HBM on SURVEY's algorithmic bytes, fp32 on the reference
@@ -52,7 +52,7 @@ PMC = {"forward": "r02_pmc_cost_volume.json", "train": "r02_pmc_cost_volume_bwd.
 
 
 def train_roofline(a, kms, kflops, ach, pm, ms_step):
-    """Roofline object of the train step's dominant kernel.  fp32-input MFMA kernel (RTK_CV_SPLIT=0): matrix-bound against 157.3
+    """Roofline object of the train step's dominant kernel.  fp32-input MFMA kernel (train_ops.CV_SPLIT = False, tests only): matrix-bound against 157.3
     TFLOP/s.  Split kernel: its matrix floor (flops / (2500 / 6) TFLOP/s) has dropped below its HBM floor, so HBM is the binding
     roofline: algorithmic bytes = per (point, neighbour) position a3 + two mask words read, dz1, dz2, dz3, dq3, d4, dt2 written
     (5232 B), per query point dout read, dp1, dpd, bias rows written (7168 B)."""
@@ -275,7 +275,7 @@ def run_train(a, net, d, dev, dist, world, rank, steps, warmup, live_traffic=Non
     from ratrack_amd.train import Trainer
     broadcast_parameters(net)
     use_graph = not a.no_graph
-    tr = Trainer(net, graph=use_graph, graph_collective=os.environ.get("RTK_TRAIN_GRAPH_DDP") == "1")
+    tr = Trainer(net, graph=use_graph, graph_collective=a.graph_collective)
     t = {k: torch.from_numpy(v).to(dev) for k, v in d.items()}
     h = torch.zeros(5, a.batch, 128, device=dev)
     step = lambda: tr.step(t["pc1"], t["pc2"], t["feature1"], t["feature2"], t["gt_warp"], t["gt_cls"], h)
@@ -420,6 +420,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--pipeline", type=int, default=4, help="captured graphs in flight (batch-level pipelining on streams)")
     ap.add_argument("--train-steps", type=int, default=20)
+    ap.add_argument("--graph-collective", action="store_true", help="world > 1: capture the RCCL all-reduce inside the train graph (one graph) "
+                                                                     "instead of graph | eager all-reduce | graph")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo run of the distributed control flow with a stand-in step (tests)")
     ap.add_argument("--traffic", choices=["auto", "profiles", "off"], default="auto",
                     help="roofline.traffic: auto = measure now with two rocprofv3 --pmc child passes when rocprofv3 is present, else take the "

@@ -6,8 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# RTK_SO_PATH: experiment knob (tools/build_variant.sh builds one translation unit with extra -D flags into its own library)
-SO_PATH = os.environ.get("RTK_SO_PATH") or os.path.join(_HERE, "lib", "librtk_hip.so")
+
+SO_PATH = os.path.join(_HERE, "lib", "librtk_hip.so")
 
 _c_int, _c_float, _c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 

@@ -22,8 +22,6 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-
          "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-result"]
 
 
-EXTRA = os.environ.get("RTK_EXTRA_FLAGS", "").split()      # experiment knobs, e.g. -DCV_NW=8
-
 
 def _hipcc():
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
@@ -60,7 +58,7 @@ def build(force=False, verbose=True):
         deps = [src] + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h")) + [__file__]
         if not force and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in deps):
             continue
-        cmd = [hipcc] + FLAGS + EXTRA + inc + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + inc + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))

@@ -151,9 +151,6 @@ struct WStream {
     }
     // move from the resident chunk to the next one (cyclic)
     __device__ __forceinline__ void next() {
-#if defined(RTK_ABL) && RTK_ABL >= 1     // ablation: no weight streaming, no barriers (results are wrong)
-        return;
-#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         buf ^= 1;
@@ -164,11 +161,6 @@ struct WStream {
         issue(cur + 1 == NCHUNKS ? 0 : cur + 1, buf ^ 1);
     }
     __device__ __forceinline__ f4 frag(int f_in_chunk) const {
-#if defined(RTK_ABL) && RTK_ABL >= 2     // ablation: no LDS reads either
-        f4 r = {1.f + f_in_chunk, 2.f, 3.f, 4.f};
-        asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
-        return r;
-#endif
         return lds[(buf * F + f_in_chunk) * 64 + lane];
     }
     __device__ __forceinline__ void finish() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

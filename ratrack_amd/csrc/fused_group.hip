@@ -227,7 +227,7 @@ __device__ __forceinline__ f4 weightnet_out(const WnWeights &W, int lane, int g,
 #ifndef CV_F
 #define CV_F 8           // fragments (KiB) per half of the LDS double buffer of the FORWARD kernel.  Standalone the kernel is the same
                          // speed with 8, 16 or 32 (0.60-0.62 ms), but with two batches in flight the small footprint (2 x 16 KiB per CU
-                         // instead of 2 x 64) lets the other batch's kernels co-reside: 1.421 vs 1.440 ms per step (tools/exp_cvf.sh)
+                         // instead of 2 x 64) lets the other batch's kernels co-reside: 1.421 vs 1.440 ms per step (tools/experiments/exp_cvf.sh)
 #endif
 #ifndef CVB_F
 #define CVB_F 32         // ... of the backward kernel (runs alone in the train step)
@@ -472,11 +472,7 @@ __global__ __launch_bounds__(64 * CV_NW, CVB_MIN_WAVES) void cost_volume_bwd_ker
     for (int G = bx; G < groups; G += nbx) {
         asm volatile("" ::: "memory");
         const int pt = G * CV_NW + wave_in_wg;
-#ifdef CVB_NOSTORE      // ablation: no materialisation at all (results are wrong)
-        const bool valid = false;
-#else
         const bool valid = pt < P.n1;
-#endif
         const long i = (long)b * P.n1 + (valid ? pt : P.n1 - 1);
         const long nb = (long)b * P.n2 + (long)P.knn[i * 16 + j];
         const float bop = g < 3 ? __fsub_rn(P.xyz2[nb * 3 + g], P.xyz1[i * 3 + g]) : 1.0f;
@@ -774,11 +770,7 @@ extern "C" int rtk_patch_cost(int samples, int n, const float *xyz, const int64_
     RTK_REQUIRE(samples <= 65535, "patch_cost: too many samples");
     int gx = (n + 3) / 4;
     while ((long)gx * samples > 4096 && gx > 1) gx = (gx + 1) / 2;
-#ifdef PC_NO_XCD
-    P.gx = 0;
-#else
     P.gx = samples % 8 == 0 ? gx : 0;
-#endif
     patch_cost_kernel<<<P.gx ? dim3(gx * samples) : dim3(gx, samples), 256, 0, (hipStream_t)stream>>>(P);
     RTK_CHECK_LAUNCH("patch_cost");
     return RTK_OK;

@@ -84,7 +84,7 @@ __device__ __forceinline__ void store_tile(const PwParams &P, const f4 (&acc)[V]
 #define PW_NW 4    // waves per workgroup
 #ifndef PW_F
 #define PW_F 16    // fragments (KiB) per half of the LDS weight double buffer (16 vs 32: same kernel speed, 1 % more end-to-end
-                   // throughput with two batches in flight -- smaller footprints co-reside, tools/exp_pwf.sh)
+                   // throughput with two batches in flight -- smaller footprints co-reside, tools/experiments/exp_pwf.sh)
 #endif
 
 // SPLIT: the layers on the bf16 matrix pipe (six products of exact operand pieces per fp32 product, fused_common.h): same tile,

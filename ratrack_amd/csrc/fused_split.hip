@@ -51,25 +51,6 @@ void split_mlp2_kernel(int positions, const float *__restrict__ x, const f4 *__r
 #pragma unroll
         for (int i = 0; i < 32; ++i) h[i] = *reinterpret_cast<const f4 *>(xr + 8 * i);      // channels 32 (i/4) + 8 (i%4) + 4 hh ..
         f16v acc[SPLIT_VB];
-#ifdef SP_REP      // experiment: the two layers SP_REP times per tile (results are wrong), to time the matrix core without the tile's I/O
-        for (int rep = 1; rep < SP_REP; ++rep) {
-#pragma unroll
-            for (int v = 0; v < SPLIT_VB; ++v) acc[v] = split_bias(bias1, v, hh);
-            split_layer<0>(ws, h, acc);
-#pragma unroll
-            for (int v = 0; v < SPLIT_VB; ++v)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) h[4 * v + q] = (f4){acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]};
-#pragma unroll
-            for (int v = 0; v < SPLIT_VB; ++v) acc[v] = split_bias(bias2, v, hh);
-            split_layer<SPLIT_NF>(ws, h, acc);
-            ws.sync();
-#pragma unroll
-            for (int v = 0; v < SPLIT_VB; ++v)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) h[4 * v + q] = (f4){acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]};
-        }
-#endif
 #pragma unroll
         for (int v = 0; v < SPLIT_VB; ++v) acc[v] = split_bias(bias1, v, hh);
         split_layer<0>(ws, h, acc);
@@ -224,11 +205,7 @@ void cost_volume_split_kernel(const CvSplitParams P) {
                 f16v c;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-#ifdef CV_ABL_NOGATHER   // ablation: no row gathers (results are wrong)
-                    const f4 t = (f4){dx, dy, dz, 1.f};
-#else
                     const f4 t = *reinterpret_cast<const f4 *>(r1 + 32 * v + 8 * q) + *reinterpret_cast<const f4 *>(r2 + 32 * v + 8 * q);
-#endif
                     c[4 * q] = t.x; c[4 * q + 1] = t.y; c[4 * q + 2] = t.z; c[4 * q + 3] = t.w;
                 }
                 const int ch = 32 * v + col;                         // A[i = col][k = hh]
@@ -281,21 +258,13 @@ void cost_volume_split_kernel(const CvSplitParams P) {
         float *o = P.out + i * P.out_pitch + 4 * hh;
 #pragma unroll
         for (int v = 0; v < SPLIT_VB; ++v) {
-#ifdef CV_ABL_NOWN       // ablation: no WeightNet (results are wrong)
-            f16v w;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) w[e] = t2[e & 7];
-#else
             const f16v w = wn_out(P.wn, v, hh, col, t2);
-#endif
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f4 r;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) r[e] = w[4 * q + e] * fmaxf(acc[v][4 * q + e], 0.1f * acc[v][4 * q + e]);
-#ifndef CV_ABL_NOSUM     // ablation: no neighbour sum (results are wrong)
                 row_sum16_f4(r);
-#endif
                 if (valid && j == 0) *reinterpret_cast<f4 *>(o + 32 * v + 8 * q) = r;
             }
         }
@@ -339,11 +308,7 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
     for (int G = bx; G < groups; G += nbx) {
         asm volatile("" ::: "memory");
         const int pt = G * PPW + 2 * wave + pp;
-#ifdef CVB_NOSTORE      // ablation: no materialisation at all (results are wrong)
-        const bool valid = false;
-#else
         const bool valid = pt < P.n1;
-#endif
         const long i = (long)b * P.n1 + (valid ? pt : P.n1 - 1);
         const long nb = (long)b * P.n2 + (long)P.knn[i * 16 + j];
         const float dx = __fsub_rn(P.xyz2[nb * 3], P.xyz1[i * 3]), dy = __fsub_rn(P.xyz2[nb * 3 + 1], P.xyz1[i * 3 + 1]),

@@ -2,7 +2,7 @@
 // (8 + 8 + 8 significant bits, split by truncation), and a product a.b is taken as the six partial products
 // a_i.b_j with i + j <= 2, accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Each bf16 x bf16 product is exact in fp32
 // (16-bit significand); the three dropped terms are below 2^-24 |a||b| -- the size of one fp32 rounding -- so the result
-// carries the error of an fp32 fmaf chain (tools/exp_split_error.py: 5.0e-7 of max|y| on a 256-deep product against 6.4e-7
+// carries the error of an fp32 fmaf chain (tools/experiments/exp_split_error.py: 5.0e-7 of max|y| on a 256-deep product against 6.4e-7
 // for an fp32 GEMM, both measured against float64).
 //
 // Why: gfx950 has no xf32 and its fp32-input MFMA runs at the VECTOR rate (157 TFLOP/s, 1/16 of bf16).  The 256 x 256
@@ -68,13 +68,8 @@ struct WStreamA : WStream<NW, F, NF> {
     // if they come in one piece: sync() = the chunk requested during the previous chunk has landed everywhere, flip;
     // issue_part<K, PARTS>() = this wave's K-th share of the requests for the chunk after, one share per group step.
     __device__ __forceinline__ void sync() {
-#if defined(RTK_ABL) && RTK_ABL >= 1
-        return;
-#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifndef RTK_ABL_NOBAR
         __syncthreads();
-#endif
         this->buf ^= 1;
         this->cur = this->cur + 1 == Base::NCHUNKS ? 0 : this->cur + 1;
         asm volatile("" : "+s"(this->cur));
@@ -82,20 +77,11 @@ struct WStreamA : WStream<NW, F, NF> {
     }
     template <int K, int PARTS>
     __device__ __forceinline__ void issue_part() {
-#if defined(RTK_ABL) && RTK_ABL >= 1
-        return;
-#endif
-#ifdef RTK_ABL_NODMA
-        return;
-#endif
         static_assert(NF % F == 0, "whole chunks only");
         const char *base = this->blob + next_off;
 #pragma unroll
         for (int i = K; i < (F + NW - 1) / NW; i += PARTS) {
             const int f = this->wave + i * NW;
-#ifdef RTK_ABL_HALFDMA                   // ablation: every other request only (results are wrong)
-            if (i & 1) continue;
-#endif
             if (F % NW == 0 || f < F)      // (F % NW == 0 folds the test away: a branch per request would cut the group step into blocks)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (size_t)i * NW * 1024 + this->lane_off),
                                                  (__attribute__((address_space(3))) void *)(this->lds + ((this->buf ^ 1) * F + f) * 64), 16, 0, 0);
@@ -115,11 +101,6 @@ struct WStreamA : WStream<NW, F, NF> {
     template <int FI>
     __device__ __forceinline__ f4 frag_async() const {
         f4 r;
-#if defined(RTK_ABL) && RTK_ABL >= 2     // ablation: no LDS reads (results are wrong)
-        r = (f4){1.f + FI, 2.f, 3.f, 4.f};
-        asm volatile("" : "+v"(r));
-        return r;
-#endif
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(rd), "n"(FI * 1024));
         return r;
     }
@@ -201,11 +182,7 @@ struct SplitStep {
         RTK_SPLIT_MM(1, 1)
         if constexpr (GI + 1 < NG) load_part<GI + 1, 2>(ws, a[(GI + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
-#ifndef RTK_ABL_NOSPLIT                  // ablation: the B pieces of k-step 0 for every k-step (results are wrong)
         if constexpr (s + 1 < SPLIT_KS) split3_word<GI % 4>(h[2 * (s + 1)], h[2 * (s + 1) + 1], b[(s + 1) & 1]);
-#else
-        if constexpr (GI % 4 == 0 && s + 1 < SPLIT_KS) { b[(s + 1) & 1][0] = b[s & 1][0]; b[(s + 1) & 1][1] = b[s & 1][1]; b[(s + 1) & 1][2] = b[s & 1][2]; }
-#endif
         RTK_SPLIT_MM(1, 0) RTK_SPLIT_MM(0, 1) RTK_SPLIT_MM(0, 0)
         side.template at<GI>(h);
 #pragma unroll

@@ -437,8 +437,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(int n, int wgs, 
 // Two position-contractions on MFMA (the operands of the old weight-gradient kernel, B = m and B = m xhat instead of B = a) replace
 // the weight-gradient kernel AND the statistics pass of rtk_conv_bn_bwd, which read the same two tensors a second time.  One wave
 // per SIMD (two 16V x 16U accumulator blocks = 128 registers at 64 x 64), the next tile's operands in flight across the MFMAs.
+#ifndef TS_OCC
+#define TS_OCC 1      // 2 waves per SIMD: 256 registers, 139 spilled, the train step 8.94 -> 9.99 ms
+#endif
 template <int U, int V, bool POOL>
-__global__ __launch_bounds__(TC_T, 1) void conv_wgrad_stats_kernel(const TcParams Q) {
+__global__ __launch_bounds__(TC_T, TS_OCC) void conv_wgrad_stats_kernel(const TcParams Q) {
     __shared__ float s_red[TC_T / 64][16 * V][16 * U + 1];
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
@@ -616,9 +619,8 @@ int launch(const TcParams &Q, int cin, int cout, hipStream_t s) {
     const int nchunks = (Q.P + TC_CHUNK - 1) / TC_CHUNK;
     int gx = (nchunks + 3) / 4;                       // one chunk per wave per pass ...
     // ... but few, fat workgroups (the weight tile and the BatchNorm constants are staged per workgroup); measured per mode at the
-    // largest set-abstraction shape (tools/exp_convbn.py): the forward and the statistics pass like them fatter than the apply pass
-    static const int env_wgs = getenv("RTK_TC_WGS") ? atoi(getenv("RTK_TC_WGS")) : 0;      // experiment knob
-    const int max_wgs = env_wgs ? env_wgs : MODE == 0 ? 1024 : MODE == 1 ? 512 : 4096;
+    // largest set-abstraction shape (tools/experiments/exp_convbn.py): the forward and the statistics pass like them fatter than the apply pass
+    const int max_wgs = MODE == 0 ? 1024 : MODE == 1 ? 512 : 4096;
     while ((long)gx * Q.samples > max_wgs && gx > 1) gx = (gx + 1) / 2;
     const dim3 grid(gx, Q.samples);
 #define TC_CASE(u, v)                                                    \
@@ -737,7 +739,7 @@ extern "C" int rtk_conv_wgrad_stats(int samples, int cprev, int cout, int rows, 
     RTK_REQUIRE(workspace_floats >= 2L * samples * cprev * cout, "rtk_conv_wgrad_stats: workspace of %ld floats < %ld", workspace_floats,
                 2L * samples * cprev * cout);
     int gx = (ntiles + 3) / 4;                                           // at least one tile per wave ...
-    while (((long)gx * samples > 512 || 2L * gx * samples * cprev * cout > workspace_floats) && gx > 1) gx = (gx + 1) / 2;
+    while (((long)gx * samples > 512 * TS_OCC || 2L * gx * samples * cprev * cout > workspace_floats) && gx > 1) gx = (gx + 1) / 2;
     const dim3 grid(gx, samples);                                        // ... and about two one-wave-per-SIMD workgroups per CU
     hipStream_t s = (hipStream_t)stream;
 #define TS_CASE(u, v)                                                                  \

@@ -290,11 +290,10 @@ extern "C" int rtk_sa_first_layer_bwd(int samples, int channels, int rows, int n
     const size_t lds = (size_t)((P + 3) & ~3) * sizeof(float) + (size_t)(2 * n_src + 1) * sizeof(int) + (size_t)(P + 256) * sizeof(unsigned short);
     RTK_REQUIRE(P <= 65536 && lds <= 150 * 1024 && samples <= 65535, "sa_first_layer_bwd: %d positions exceed the LDS budget", P);
     (void)hipFuncSetAttribute((const void *)sa_first_layer_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);      // per device and cheap: every call
-    // channel planes per workgroup: 4 (2, 8 and 16 measured within 5 % of it or worse, tools/exp_firstbwd.py: the per-plane phases,
+    // channel planes per workgroup: 4 (2, 8 and 16 measured within 5 % of it or worse, tools/experiments/exp_firstbwd.py: the per-plane phases,
     // not the per-workgroup staging of the index tables and offset planes, set the pace)
-    static const int cg_env = getenv("RTK_FB_CG") ? atoi(getenv("RTK_FB_CG")) : 0;      // experiment knob
     // ... at large batches; with few samples one plane per workgroup (the serial chain per workgroup is what counts there)
-    const int cg = cg_env ? cg_env : ((long)((channels + 3) / 4) * samples >= 256 ? 4 : 1);
+    const int cg = ((long)((channels + 3) / 4) * samples >= 256 ? 4 : 1);
     const dim3 grid((channels + cg - 1) / cg, samples);
     sa_first_layer_bwd_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(channels, cg, n_src, P, dz, dxyz, off, inv, dproj, dwx, dwx_pitch);
     RTK_CHECK_LAUNCH("sa_first_layer_bwd");

@@ -307,8 +307,7 @@ extern "C" int rtk_weightnet_bwd(long positions, int channels, const float *d4, 
     const int pitch = (9 * channels + 104 + 3) & ~3;
     RTK_REQUIRE(workspace_floats >= pitch, "weightnet_bwd: workspace of %ld floats < %d", workspace_floats, pitch);
     const long subs = (positions + WN_SUB - 1) / WN_SUB;
-    static const int want_env = getenv("RTK_WN_WGS") ? atoi(getenv("RTK_WN_WGS")) : 512;      // experiment knob (tools/exp_wnbwd.py)
-    long want = want_env;                           // workgroups (two per CU keep the dq3 stream near HBM speed), each one partial vector
+    long want = 512;                                // workgroups (two per CU keep the dq3 stream near HBM speed), each one partial vector
     if (want > workspace_floats / pitch) want = workspace_floats / pitch;
     int per = (int)((subs + want - 1) / want);
     if (per < 1) per = 1;

@@ -495,10 +495,8 @@ extern "C" int rtk_pw_conv(int samples, int positions, int nsrc, const rtk_pw_op
     // wave and one 16-channel block per workgroup
     long big_wgs = 0;
     for (int i = 0; i < ndst; ++i) big_wgs += (long)rtk_divup(dsts[i].channels, 64) * rtk_divup(positions, 256) * samples;
-    static const int force_nw = getenv("RTK_PW_NW") ? atoi(getenv("RTK_PW_NW")) : 0;      // experiment knobs (tools/exp_pw.py)
-    static const int force_vb = getenv("RTK_PW_VB") ? atoi(getenv("RTK_PW_VB")) : 0;
-    const bool small = force_nw == 1 || (force_nw != 4 && big_wgs < 192);
-    const int vb = small ? 1 : (force_vb ? force_vb : 4);
+    const bool small = big_wgs < 192;
+    const int vb = small ? 1 : 4;
     const int oc = 16 * vb;
     int nch = 0;
     for (int i = 0; i < ndst; ++i) {
@@ -545,10 +543,10 @@ extern "C" int rtk_pw_wgrad(int samples, int positions, const rtk_pw_operand_t *
     Q.nchunks = nch;
     const long ntiles = (long)samples * ((positions + 15) / 16);
     const int ochunks = rtk_divup(dz->channels, 64);
-    // about two workgroups per CU (more only adds partial blocks: tools/exp_pw.py), at least one tile per wave, and no more
+    // about two workgroups per CU (more only adds partial blocks: tools/experiments/exp_pw.py), at least one tile per wave, and no more
     // position splits than the workspace holds partial blocks for
     const long blocks = (long)nch * ochunks;
-    static const int want_wgs = getenv("RTK_WG_WGS") ? atoi(getenv("RTK_WG_WGS")) : 512;      // experiment knob
+    const int want_wgs = 512;
     long splits = (want_wgs + blocks - 1) / blocks;
     if (splits > (ntiles + 3) / 4) splits = (ntiles + 3) / 4;      // ... and at least one tile per wave (tiny batches: the serial depth counts)
     if (splits > workspace_floats / (blocks * 4096)) splits = workspace ? workspace_floats / (blocks * 4096) : 1;

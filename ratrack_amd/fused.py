@@ -169,7 +169,9 @@ def pack_layer_split16(w):
     return p.permute(3, 1, 0, 5, 2, 4, 6).contiguous().reshape(-1)         # (up, v, p, g, i, d, r): lane = 16 g + i, t = 4 d + r
 
 
-PW_SPLIT = os.environ.get("RTK_PW_SPLIT", "1") != "0"
+# The product path runs every wide layer on the split-bf16 matrix path (csrc/split_mfma.h).  The fp32-input MFMA kernels stay compiled as
+# the second implementation the tests compare against: tests flip these module attributes / FusedBackbone(split=False).
+PW_SPLIT = True
 LAYER_SPLIT = 0x100      # RTK_LAYER_SPLIT (include/rtk_fused.h)
 
 
@@ -291,7 +293,7 @@ class _WeightNet:
         self.arr = arr
 
 
-SA_SPLIT = os.environ.get("RTK_SA_SPLIT", "1") != "0"
+SA_SPLIT = True
 
 
 class _SAScale:
@@ -349,7 +351,7 @@ class _PNHeadWeights:
             self.fp[name] = Chain([(w, b, ACT_RELU)], device)
 
 
-CHECK_FPS_RELEVEL = bool(int(__import__("os").environ.get("RTK_CHECK_FPS_RELEVEL", "0")))
+CHECK_FPS_RELEVEL = False      # debug: compare every re-levelling launch with the full selection (synchronises; tests set it)
 
 
 def check_fps_relevel(xyz1, idx, new_xyz, nuniq):
@@ -588,7 +590,8 @@ def run_pnhead(W, geo, q1, out=None):
 class FusedBackbone:
     """Eval-mode Track4D.backbone (models/track4d.py:67-106) on the fused kernels."""
 
-    def __init__(self, model):
+    def __init__(self, model, split=True):
+        """split=False: the cost volume on the fp32-input MFMA kernel (the comparison implementation of the tests)."""
         sd = {k: v.detach() for k, v in model.state_dict().items()}
         dev = next(model.parameters()).device
         self.dev = dev
@@ -601,7 +604,7 @@ class FusedBackbone:
         self.kernel_events = None      # set to a list to record (start, stop) events around the dominant kernel
         self.kernel_token = None       # [last stop event] shared by the engines of a GraphPipeline while kernel_events is set
         self._split_hook = None
-        self.side, self.use_side_stream = None, bool(int(__import__("os").environ.get("RTK_EVAL_SIDE", "1")))    # geometry kernels on a forked stream
+        self.side, self.use_side_stream = None, True    # geometry kernels on a forked stream (GraphPipeline drops it beyond depth 2)
         self._last_cv = None
         self.enc = _PNHeadWeights(sd, "pn_head.", dev)
         self.dec = _PNHeadWeights(sd, "fd_layer.mse.", dev)
@@ -619,7 +622,7 @@ class FusedBackbone:
         self.cv_layers = Chain([(sd["fc_layer.mlp_convs.%d.weight" % i].double().reshape(256, 256),
                                  sd["fc_layer.mlp_convs.%d.bias" % i].double(), ACT_LEAKY) for i in (1, 2)], dev)
         # the same two layers as split images (csrc/split_mfma.h): fp32 results from the bf16 matrix pipe, 6/16 of the matrix time
-        self.cv_split = os.environ.get("RTK_CV_SPLIT", "1") != "0"
+        self.cv_split = bool(split)
         w23 = [sd["fc_layer.mlp_convs.%d.weight" % i].double().reshape(256, 256).float().to(dev).contiguous() for i in (1, 2)]
         self.cv_bias23 = torch.stack([sd["fc_layer.mlp_convs.%d.bias" % i].double().float() for i in (1, 2)]).to(dev).contiguous()
         self.cv_images = torch.empty(2 * 3 * 256 * 256, dtype=torch.int16, device=dev)

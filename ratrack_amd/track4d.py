@@ -9,16 +9,8 @@ reference's forward (moving-point clustering, Affinity MLP, log-Sinkhorn associa
 import torch
 import torch.nn as nn
 
-import os
-
 from . import association as A
 from .model_utils import FeatureCorrelator, FlowDecoder, PNHead
-
-# Experiment knob, default off: the training path's geometry kernels (FPS, ball queries, three-NN, index tables) on a forked stream,
-# as the inference engine does.  Measured inside the captured train step: 10.98 ms vs 10.86 ms (B=64), 3.92 vs 3.64 ms (B=1) --
-# the cross-stream dependencies of the replayed graph cost more than the ~0.5 ms of overlapped geometry saves.
-TRAIN_SIDE_STREAM = bool(int(os.environ.get("RTK_TRAIN_SIDE", "0")))
-
 
 class Affinity(nn.Module):
     """Object-pair affinity MLP (models/track4d.py:226-246).  Not on the backbone path; kept so that
@@ -50,6 +42,7 @@ class Track4D(nn.Module):
         self.min_obj_points = args.min_obj_points
         self.associator = A.Associator(self.affinity)
         self._fused = None     # lazily built fused inference engine (ratrack_amd.fused)
+        self._fused_version = -1
         self.use_fused = True
         self.dedup_train = True   # training mode: PNHead on de-duplicated levels with the HIP BatchNorm operators (train_path.py)
 
@@ -99,11 +92,8 @@ class Track4D(nn.Module):
                                     torch.full((B,), N2, dtype=torch.int32, device=pc1.device)])
                     pc1, pc2, feature1, feature2 = pad(pc1), pad(pc2), pad(feature1), pad(feature2)
                     cut = (N1, N2)
-                with torch.no_grad():
-                    if TRAIN_SIDE_STREAM and getattr(self, "_train_side", None) is None:
-                        self._train_side = torch.cuda.Stream(device=pc1.device)
-                    tg = TP.TrainGeometry(torch.cat([pc1, pc2], 0).permute(0, 2, 1).contiguous(), self.pn_head.sa1.npoint,
-                                          side=self._train_side if TRAIN_SIDE_STREAM else None, n_valid=nv, groups=2)
+                with torch.no_grad():      # (geometry on a forked stream was measured slower inside the captured step: DESIGN.md section 5)
+                    tg = TP.TrainGeometry(torch.cat([pc1, pc2], 0).permute(0, 2, 1).contiguous(), self.pn_head.sa1.npoint, n_valid=nv, groups=2)
                 f = TP.pnhead_train(self.pn_head, tg, torch.cat([feature1, feature2], 0), groups=2)
                 (f1, f2), tg1 = f.view(2, B, f.shape[1], f.shape[2]).unbind(0), tg.head(B)
         if tg1 is None and n_valid is not None:
@@ -146,7 +136,14 @@ class Track4D(nn.Module):
         rest = [torch.cat([o[i] for o in outs], dim=0) for i in range(1, 7)]
         return (rest[0], hs) + tuple(rest[1:])
 
+    def _weights_version(self):
+        """Sum of the in-place modification counters of every parameter and buffer: `p.data.mul_(2)`, an optimizer step taken while the
+        model is in eval mode, `running_mean.copy_(...)` ... all bump it, so a stale folded engine is detected without a hook."""
+        return sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers())
+
     def _fused_engine(self):
+        if self._fused and self._fused_version != self._weights_version():
+            self._fused = None          # weights were edited in place since the engine folded / packed them
         if self._fused is None:
             try:
                 from . import fused
@@ -155,6 +152,7 @@ class Track4D(nn.Module):
             else:
                 cls = getattr(fused, "FusedBackbone", None)
                 self._fused = cls(self) if cls is not None else False
+                self._fused_version = self._weights_version()
         return self._fused or None
 
     def invalidate_fused(self):

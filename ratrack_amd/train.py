@@ -15,8 +15,7 @@ def make_optimizer(model, lr=1e-3, capturable=False):
     # fused: ONE multi-tensor kernel per step; the foreach implementation in capturable mode issues ~200 tiny kernels for the
     # per-parameter step counters and bias corrections
     on_gpu = next(model.parameters()).is_cuda
-    import os
-    if on_gpu and os.environ.get("RTK_FUSED_ADAM", "1") != "0":      # one launch for all parameters (ratrack_amd/optim.py): torch's fused Adam takes five
+    if on_gpu:      # one launch for all parameters (ratrack_amd/optim.py): torch's fused Adam takes five
         from .optim import FusedAdam
         opt = FusedAdam(model.parameters(), lr=lr, weight_decay=1e-10)
     else:

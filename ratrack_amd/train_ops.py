@@ -478,7 +478,7 @@ class _SAChain(torch.autograd.Function):
             dwoff += W.numel()
             wc = W.detach().contiguous()
             ga, be = ctx.bn_affine[i - 1]
-            ws = torch.empty(2 * max(S_, 512) * Ci * Co, dtype=torch.float32, device=dev)       # workgroup partials (uninitialised scratch)
+            ws = torch.empty(2 * max(S_, 1024) * Ci * Co, dtype=torch.float32, device=dev)      # workgroup partials (uninitialised scratch)
             sums2 = f64(Ci)
             # ONE pass over (dz, z[i-1]): the weight gradient AND the statistics of the previous BatchNorm's backward
             _lib.call("rtk_conv_wgrad_stats", S_, Ci, Co, rows, ns, groups, src.data_ptr(), src_pool, zs[i - 1].data_ptr(), pars[i - 1].data_ptr(),
@@ -577,16 +577,16 @@ def _pack_weights(specs, device):
     return outs, (ws, keep)
 
 
-# the cost volume's 256 x 256 products on the split-bf16 matrix path (csrc/split_mfma.h); RTK_CV_SPLIT=0: fp32-input MFMA kernels
-CV_SPLIT = os.environ.get("RTK_CV_SPLIT", "1") != "0"
-# ... from this many query points on: the split kernels' workgroups are half as many and twice as heavy (8 points of one sample each),
-# below ~1 workgroup per CU the fp32-input kernels are faster (B = 1: 55 vs 81 us for the backward)
-CV_SPLIT_MIN_POINTS = int(os.environ.get("RTK_CV_SPLIT_MIN_POINTS", "2048"))
+# The cost volume's 256 x 256 products run on the split-bf16 matrix path (csrc/split_mfma.h) at every batch size.  (At B = 1 the
+# fp32-input kernels are 1 % faster per step -- 3.09 vs 3.13 ms: half as many, twice as heavy workgroups on a mostly empty chip --, not
+# worth a second product path selected by a batch-size threshold.)  CV_SPLIT = False selects the fp32-input MFMA kernels: the
+# comparison implementation of the tests (tests/test_train_gpu.py, tools/grad_parity_report.py --fp32-cv).
+CV_SPLIT = True
 _SPLIT_IMAGE = 3 * 256 * 256          # int16 elements of one layer's split image
 
 
-def _cv_split(points):
-    return CV_SPLIT and points >= CV_SPLIT_MIN_POINTS
+def _cv_split(points=None):
+    return CV_SPLIT
 
 
 class _CvWeights:

@@ -545,6 +545,25 @@ def test_padded_variable_n_batch():
             assert rel_err(fs.cpu(), s_.cpu()) <= RTOL, (b, name, "B=1 fused with internal padding")
 
 
+def test_in_place_weight_edit_invalidates_the_folded_engine():
+    """Round-2 review: `load_state_dict` / `train()` / `.to()` rebuilt the engine, an in-place edit of a weight in eval mode did not."""
+    from _util import inputs_of, load_case
+    net = _net()
+    pc1, pc2, f1, f2 = inputs_of(load_case("eval_b2_n256"), DEV)
+    with torch.no_grad():
+        a = net.backbone(pc1, pc2, f1, f2, None)[0].clone()
+        eng = net._fused
+        assert torch.equal(a, net.backbone(pc1, pc2, f1, f2, None)[0]) and net._fused is eng      # untouched weights: same engine
+        net.fd_layer.fp.conv2.weight.mul_(2.0)                                                       # in place, eval mode
+        b = net.backbone(pc1, pc2, f1, f2, None)[0]
+        assert net._fused is not eng
+        assert torch.allclose(b, 2.0 * a, rtol=1e-5, atol=1e-6)                                      # the flow head's last layer is linear
+        net.fd_layer.fp.sf_mlp[0][1].running_var.add_(0.5)                                           # a buffer
+        eng2 = net._fused
+        net.backbone(pc1, pc2, f1, f2, None)
+        assert net._fused is not eng2
+
+
 def test_fused_real_frames_match_reference_fixture():
     """The reference graph run on the radar frames it ships (tools/make_golden.py real_*: B = 1, N1 != N2, eval mode) against the
     fused engine -- (a) every pair on its own (internal padding of the smaller cloud), (b) the three pairs as ONE padded batch with

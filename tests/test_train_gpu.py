@@ -745,7 +745,6 @@ def test_cost_volume_split_train_and_backward_agree_with_fp32_mfma_kernels(monke
            r(256, 8) * 0.4, r(256) * 0.1]
     p1, p2, dout = r(B * n, 256), r(B * n, 256), r(B * n, 256)
     res = []
-    monkeypatch.setattr(T, "CV_SPLIT_MIN_POINTS", 0)      # (the split kernels are otherwise reserved for >= 2048 query points)
     for split in (False, True):
         monkeypatch.setattr(T, "CV_SPLIT", split)
         leaves = [t.clone().requires_grad_(True) for t in [p1, p2] + par]

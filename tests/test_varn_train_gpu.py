@@ -1,7 +1,7 @@
 """GPU: the hand-written TRAINING path against reference-generated train steps (tools/make_golden.py, round 3):
 
-* `train_b8_n256` -- B = 8 x N = 256 = 2 048 query points: the split-bf16 cost-volume training kernels run (they are selected from
-  2 048 points on); every parameter's gradient TENSOR (sampled) + a whole-tensor probe product against the reference fp32 values
+* `train_b8_n256` -- B = 8 x N = 256: batch-statistic BatchNorm over eight samples, the split-bf16 cost-volume training kernels; every
+  parameter's gradient TENSOR (sampled) + a whole-tensor probe product against the reference fp32 values
   and against a float64 evaluation of the same step (the arbiter: which side of an fp32-vs-fp32 difference the error sits on);
 * `real_*` -- the three radar frames the reference ships, as B = 1 pairs with N1 != N2 (every real consecutive pair): the pair is
   padded with copies of each cloud's point 0 and carries its true sizes on the device (`n_valid`), nothing falls back to the
@@ -114,7 +114,7 @@ def test_b8_train_step_split_kernels_match_reference_gradient_tensors():
     """Config 3's kernels (split-bf16 cost volume forward/backward) against the reference graph at B = 8, per gradient tensor,
     and against the float64 evaluation of the same step (tolerances: GRAD_TOL above)."""
     case = load_case("train_b8_n256")
-    assert train_ops._cv_split(8 * 256), "B=8 x N=256 must select the split-bf16 training kernels"
+    assert train_ops.CV_SPLIT, "the product path is the split-bf16 one"
     net = make_net()
     items, flow, cls, grads, sd = train_step(net, case)
     rows = check_against_fixture(case, items, flow, cls, grads, sd, GRAD_TOL, "train_b8_n256")
