@@ -425,6 +425,11 @@ class Geometry:
         self.knn = [torch.empty(B, n, 16, dtype=torch.int64, device=dev) for _ in range(2)] if B else None
         big = n > 2048
         temp = torch.full((S_, n), 1e10, dtype=torch.float32, device=dev) if big else None
+        # scratch of the geometry kernels: must live as long as this object -- the kernels run asynchronously (on the side stream), and
+        # a buffer dropped at the end of __init__ goes back to the allocator's main-stream pool, whose next tenant (the encoder's first
+        # projection) is then written WHILE the selection kernel saves its tie snapshot into the same bytes (round 3: one real frame
+        # pair in three runs off by 2e-3, only for clouds with exact duplicate points, only with warm allocator pools)
+        self._scratch = (snap, temp)
 
         main = torch.cuda.current_stream()
         if side is not None:
