@@ -476,7 +476,10 @@ def main():
                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                    "config": {"workload": tr["workload"] + ", hipGraph=%s" % tr["hipGraph"], "global_batch": a.batch * world,
                               "parallelism": "dp%d, one flat RCCL all-reduce of %d bytes per step" % (world, tr["allreduce_bytes"])},
-                   "roofline": tr["roofline"], "whole_step": tr["whole_step"]}
+                   "roofline": tr["roofline"], "whole_step": tr["whole_step"],
+                   "train": {"hipGraph": tr["hipGraph"], "kernels_per_step": tr["kernels_per_step"], "allreduce_bytes": tr["allreduce_bytes"],
+                             "allreduce_gradient_bytes": tr["allreduce_gradient_bytes"], "allreduce_us": tr["allreduce_us"]},
+                   "per_rank_ms_per_step": tr["per_rank_ms_per_step"]}
             if world == 1 and not a.no_cpu_baseline:
                 try:
                     res["cpu_baseline"] = cpu_train_baseline(min(a.batch, 4), a.npoints)
@@ -495,6 +498,24 @@ def main():
         with fused.trace_work() as tw:
             net.backbone(pc1, pc2, f1, f2, h)
         exec_macs, exec_by_kernel = tw.executed_macs()
+        # every launch of one eager pass between two HIP events, one stream, nothing else on the GPU: per kernel family the time
+        # and -- for the FLOP-carrying ones -- the executed rate against the split-path matrix peak
+        from ratrack_amd import _lib as rtk_lib
+        eng.use_side_stream, side_saved = False, eng.use_side_stream
+        net.backbone(pc1, pc2, f1, f2, h)
+        torch.cuda.synchronize()
+        rtk_lib.TIMING = timing = []
+        net.backbone(pc1, pc2, f1, f2, h)
+        rtk_lib.TIMING = None
+        torch.cuda.synchronize()
+        eng.use_side_stream = side_saved
+        fam_of = {"rtk_pointwise_mlp": "pointwise", "rtk_sa_scale": "sa_scale", "rtk_sa_scale_split": "sa_scale", "rtk_cost_volume_split": "cost_volume",
+                  "rtk_cost_volume": "cost_volume", "rtk_patch_cost": "patch_cost", "rtk_gru_step": "gru"}
+        by_family = {}
+        for nm, e0, e1 in timing:
+            f = by_family.setdefault(fam_of.get(nm, nm.replace("rtk_", "")), [0, 0.0])
+            f[0] += 1
+            f[1] += e0.elapsed_time(e1) * 1e3
 
         spread = {}
 
@@ -610,6 +631,14 @@ def main():
                            "fp32_frac_executed": round(per_gpu * exec_flops_per_pair / (FP32_PEAK_TFLOPS * 1e12), 5),
                            "executed_gflop_per_pair": round(exec_flops_per_pair / 1e9, 4),
                            "executed_gflop_per_pair_by_kernel": {k: round(2.0 * v / a.batch / 1e9, 4) for k, v in exec_by_kernel.items()}},
+            # one eager pass, every launch between HIP events on one stream with nothing else in flight (what a serialising profiler
+            # shows); FLOP-carrying families: executed multiply-adds x 2 / time against the split matrix peak (bf16 / 6)
+            "kernels_alone": {k: dict({"launches": v[0], "us": round(v[1], 1)},
+                                      **({"gflop": round(2.0 * exec_by_kernel[k] / 1e9, 2),
+                                          "tflops": round(2.0 * exec_by_kernel[k] / (v[1] * 1e-6) / 1e12, 1),
+                                          "frac_of_split_peak": round(2.0 * exec_by_kernel[k] / (v[1] * 1e-6) / 1e12 / SPLIT_PEAK_TFLOPS, 3)}
+                                         if k in exec_by_kernel and v[1] > 0 else {}))
+                              for k, v in sorted(by_family.items(), key=lambda kv: -kv[1][1])},
         }
     # ---- train step (config 3; config 4 when world > 1) ---------------------------------------------------------------
     if not a.no_train:

@@ -71,9 +71,20 @@ def _fn(name):
     return fn
 
 
+TIMING = None      # a list: every call appends (entry point, start event, stop event) on the current stream (bench.py, one eager pass)
+
+
 def call(name, *args):
     lib = load()
-    rc = _fn(name)(*args)
+    if TIMING is not None:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = _fn(name)(*args)
+        e1.record()
+        TIMING.append((name, e0, e1))
+    else:
+        rc = _fn(name)(*args)
     if rc != 0:
         raise RtkError("%s failed (%d): %s" % (name, rc, lib.rtk_last_error().decode()))
     return rc
