@@ -280,12 +280,14 @@ RTK_EXPORT int rtk_patch_dfeat_gather(int samples, int n, const int *off, const 
 
 /* ---- de-duplicated geometry tables (ratrack_amd/train_path.py) ---------------------------------------------------------
  * rtk_train_group_geometry: for the first `rows` centroids of every sample, idx_out (samples, rows, ns) = ball_idx
- * (samples, npoint, ns) with entries >= src_nuniq[b] redirected to 0 (src_nuniq may be NULL), and
+ * (samples, npoint, ns) with entries >= src_live_rows -- source rows the de-duplicated level tensor does not hold: copies of row 0
+ * -- redirected to 0 (rows in [nuniq, src_live_rows) exist as computed copies of row 0 and are used as they are); centroid rows
+ * >= dst_nuniq[b] (copies of centroid 0 whose ball lists the query skipped; dst_nuniq may be NULL) take centroid 0's list; and
  * dxyz (samples, 3, rows, ns) = src_xyz[idx_out] - dst_xyz (neighbour - centroid, lib/pointnet2_utils.py:279-285);
  * src_xyz (samples, n_src_rows, 3), dst_xyz (samples, npoint, 3). */
 RTK_EXPORT int rtk_train_group_geometry(int samples, int n_src_rows, int npoint, int rows, int ns, const float *src_xyz,
-                                        const float *dst_xyz, const int *ball_idx, const int *src_nuniq, int *idx_out, float *dxyz,
-                                        rtk_stream_t stream);
+                                        const float *dst_xyz, const int *ball_idx, int src_live_rows, const int *dst_nuniq, int *idx_out,
+                                        float *dxyz, rtk_stream_t stream);
 /* three-NN tables -> interpolation weights (lib/pointnet2_modules.py:143-146: 1/(sqrt(d2)+1e-8), normalised) and indices with
  * entries >= known_nuniq[b] redirected to 0, for the first `rows` of `rows_total` unknown rows. */
 RTK_EXPORT int rtk_train_interp_weights(int samples, int rows_total, int rows, const float *dist2, const int *idx, const int *known_nuniq,

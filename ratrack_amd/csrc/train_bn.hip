@@ -683,13 +683,22 @@ namespace {
 
 __global__ void train_group_geometry_kernel(int n_src_rows, int npoint, int rows, int ns, const float *__restrict__ src_xyz,
                                             const float *__restrict__ dst_xyz, const int *__restrict__ ball,
-                                            const int *__restrict__ src_nuniq, int *__restrict__ idx_out, float *__restrict__ dxyz) {
+                                            int src_live_rows, const int *__restrict__ dst_nuniq, int *__restrict__ idx_out,
+                                            float *__restrict__ dxyz) {
     const int b = blockIdx.y;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;      // (row, k)
     if (e >= rows * ns) return;
     const int row = e / ns, k = e % ns;
-    int t = ball[((size_t)b * npoint + row) * ns + k];
-    if (src_nuniq && t >= src_nuniq[b]) t = 0;                // source rows >= nuniq are copies of row 0
+    // centroid rows >= nuniq are copies of centroid 0; the ball query skipped them (their lists are unwritten zeros): they take
+    // centroid 0's list, which makes the level's rows [nuniq, rows) true copies of row 0 -- values a later level may gather
+    const int brow = (dst_nuniq && row >= dst_nuniq[b]) ? 0 : row;
+    int t = ball[((size_t)b * npoint + brow) * ns + k];
+    // Source rows the de-duplicated level tensor does not hold (>= its row count) are copies of row 0.  Rows in [nuniq, rows) DO
+    // exist -- computed copies of row 0 with statistics weight 0 -- and are used as they are: redirecting them to row 0 as well
+    // piled thousands of references on one row (real radar frames padded to a common size: 142 copies), and the inverse tables of
+    // the gather-form backward rank every list in O(length^2).  Same values forward; the gradient of a copy reaches the weights
+    // through an identical chain.
+    if (t >= src_live_rows) t = 0;
     idx_out[(size_t)b * rows * ns + e] = t;
     const float *p = src_xyz + ((size_t)b * n_src_rows + t) * 3, *c = dst_xyz + ((size_t)b * npoint + row) * 3;
     float *o = dxyz + (size_t)b * 3 * rows * ns + e;
@@ -740,12 +749,13 @@ __global__ void train_row_weights_kernel(int rows, int npoint, const int *__rest
 }  // namespace
 
 extern "C" int rtk_train_group_geometry(int samples, int n_src_rows, int npoint, int rows, int ns, const float *src_xyz,
-                                        const float *dst_xyz, const int *ball_idx, const int *src_nuniq, int *idx_out, float *dxyz,
-                                        rtk_stream_t stream) {
+                                        const float *dst_xyz, const int *ball_idx, int src_live_rows, const int *dst_nuniq, int *idx_out,
+                                        float *dxyz, rtk_stream_t stream) {
     RTK_REQUIRE(samples > 0 && samples <= 65535 && n_src_rows > 0 && npoint > 0 && rows > 0 && rows <= npoint && ns > 0 && src_xyz &&
-                dst_xyz && ball_idx && idx_out && dxyz, "rtk_train_group_geometry: bad arguments");
+                dst_xyz && ball_idx && idx_out && dxyz && src_live_rows > 0 && src_live_rows <= n_src_rows,
+                "rtk_train_group_geometry: bad arguments");
     train_group_geometry_kernel<<<dim3(rtk_divup((long)rows * ns, 256), samples), 256, 0, (hipStream_t)stream>>>(
-        n_src_rows, npoint, rows, ns, src_xyz, dst_xyz, ball_idx, src_nuniq, idx_out, dxyz);
+        n_src_rows, npoint, rows, ns, src_xyz, dst_xyz, ball_idx, src_live_rows, dst_nuniq, idx_out, dxyz);
     RTK_CHECK_LAUNCH("rtk_train_group_geometry");
     return RTK_OK;
 }

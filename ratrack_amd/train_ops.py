@@ -27,7 +27,7 @@ _lib.SIGNATURES.update({
     "rtk_conv_bn_fwd": [_i] * 6 + [_p] * 7 + [_p],
     "rtk_conv_wgrad": [_i] * 6 + [_p] * 5 + [ctypes.c_long, _p],
     "rtk_conv_bn_bwd": [_i] * 6 + [_p] * 6 + [_d, _i, _p, _p, _p],
-    "rtk_train_group_geometry": [_i] * 5 + [_p] * 6 + [_p],
+    "rtk_train_group_geometry": [_i] * 5 + [_p] * 3 + [_i] + [_p] * 3 + [_p],
     "rtk_train_interp_weights": [_i] * 3 + [_p] * 5 + [_p],
     "rtk_train_row_weights": [_i] * 3 + [_p] * 2 + [_p],
     "rtk_gru_step_bwd": [_i] * 3 + [_p] * 15 + [_p],

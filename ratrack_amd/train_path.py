@@ -84,10 +84,10 @@ class TrainGeometry:
             _lib.call("rtk_train_row_weights", S_, U, npoint, nu[lvl].data_ptr(), self.row_w[lvl].data_ptr(), st())
             src, dst = geo.xyz[lvl], geo.xyz[lvl + 1]             # (S_, n or npoint, 3), (S_, npoint, 3)
             for s in range(2):
-                # source rows >= nuniq are copies of row 0: redirect; neighbour - centroid offsets (no gradient)
+                # source rows the level tensor does not hold (>= U; level 0 holds all n) are copies of row 0: redirect; neighbour -
+                # centroid offsets (no gradient).  Rows in [nuniq, U) and a padded batch's padding rows exist as copies and are used.
                 _lib.call("rtk_train_group_geometry", S_, src.shape[1], npoint, U, NS[lvl][s], src.data_ptr(), dst.data_ptr(),
-                          geo.ball[lvl][s].data_ptr(), nu[lvl - 1].data_ptr() if lvl > 0 else (n_valid.data_ptr() if n_valid is not None else None),
-                          self.ball[lvl][s].data_ptr(),
+                          geo.ball[lvl][s].data_ptr(), U if lvl > 0 else n, nu[lvl].data_ptr(), self.ball[lvl][s].data_ptr(),
                           self.dxyz[lvl][s].data_ptr(), st())
 
         def tail_tables(geo):
