@@ -116,6 +116,15 @@ RTK_EXPORT int rtk_pack_weights(int njobs, const rtk_pack_job_t *jobs, rtk_strea
  * the caller, += sum dz . dxyz (dxyz (samples, 3, rows, ns)).  ns % 4 == 0. */
 RTK_EXPORT int rtk_group_inverse_index(int samples, int n_src, int positions, const int *idx, int *off, unsigned short *inv,
                                        rtk_stream_t stream);
+/* The same for several tables in ONE launch (up to 12; every table over the same `samples` clouds): a table is one workgroup per
+ * cloud, so at small batches ten launches cost ten times the latency of one. */
+typedef struct {
+    int n_src, positions;
+    const int *idx;
+    int *off;
+    unsigned short *inv;
+} rtk_inverse_index_job_t;
+RTK_EXPORT int rtk_group_inverse_index_multi(int samples, int njobs, const rtk_inverse_index_job_t *jobs, rtk_stream_t stream);
 
 /* Backward of rtk_three_interpolate (lib/src/interpolate_gpu.cu:192-214, one atomicAdd per term) in gather form:
  * grad_points (b, c, m) = for every known point the sum of weight * grad_out over the (unknown point, slot) positions that

@@ -43,6 +43,24 @@ _lib.SIGNATURES.update({
 })
 
 
+class _IIJob(ctypes.Structure):          # rtk_inverse_index_job_t (include/rtk_train.h)
+    _fields_ = [("n_src", ctypes.c_int), ("positions", ctypes.c_int), ("idx", ctypes.c_void_p), ("off", ctypes.c_void_p), ("inv", ctypes.c_void_p)]
+
+
+_lib.SIGNATURES.update({"rtk_group_inverse_index_multi": [_i, _i, ctypes.POINTER(_IIJob), _p]})
+
+
+def group_inverse_index_multi(samples, jobs):
+    """jobs: list of (n_src, positions, idx int32 (samples, positions), off int32 (samples, n_src + 1), inv int16 (samples, positions)):
+    all inverse tables in one launch."""
+    for lo in range(0, len(jobs), 12):
+        part = jobs[lo:lo + 12]
+        arr = (_IIJob * len(part))()
+        for k, (n_src, P, idx, off, inv) in enumerate(part):
+            arr[k].n_src, arr[k].positions, arr[k].idx, arr[k].off, arr[k].inv = n_src, P, idx.data_ptr(), off.data_ptr(), inv.data_ptr()
+        _lib.call("rtk_group_inverse_index_multi", samples, len(part), arr, _stream())
+
+
 class _PoolSrc(ctypes.Structure):        # rtk_pool_src_t (include/rtk_train.h)
     _fields_ = [("dout", ctypes.c_void_p), ("karg", ctypes.c_void_p), ("par", ctypes.c_void_p), ("sums2", ctypes.c_void_p),
                 ("dgamma_dbeta", ctypes.c_void_p)]

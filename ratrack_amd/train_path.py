@@ -91,7 +91,9 @@ class TrainGeometry:
                           self.dxyz[lvl][s].data_ptr(), st())
 
         def tail_tables(geo):
+            from .train_ops import group_inverse_index_multi
             nu = geo.nuniq
+            jobs = []
             for name, (u, k) in {"fp3": (2, 3), "fp2": (1, 2), "fp1": (0, 1)}.items():
                 d2, idx, _ = geo.nn[name]
                 io, wo = self.interp[name]
@@ -99,14 +101,15 @@ class TrainGeometry:
                           io.data_ptr(), wo.data_ptr(), st())
                 if self.interp_inv[name] is not None:              # the redirected indices point at rows < nuniq <= U
                     off, inv = self.interp_inv[name]
-                    _lib.call("rtk_group_inverse_index", S_, U, 3 * io.shape[1], io.data_ptr(), off.data_ptr(), inv.data_ptr(), st())
+                    jobs.append((U, 3 * io.shape[1], io, off, inv))
             geo._record("interp", side)
-            for lvl in range(3):                                   # needed by the backward only: last
+            for lvl in range(3):                                   # needed by the backward only
                 for s in range(2):
                     if self.inv[lvl][s] is not None:
                         off, inv = self.inv[lvl][s]
-                        _lib.call("rtk_group_inverse_index", S_, n if lvl == 0 else U, U * NS[lvl][s], self.ball[lvl][s].data_ptr(),
-                                  off.data_ptr(), inv.data_ptr(), st())
+                        jobs.append((n if lvl == 0 else U, U * NS[lvl][s], self.ball[lvl][s], off, inv))
+            if jobs:                                               # all nine inverse tables: one launch
+                group_inverse_index_multi(S_, jobs)
             geo._record("inv", side)
 
         geo = fused.Geometry(xyz, npoint, side=side, knn_frames=0, finite=True, n_valid=n_valid, level_hook=level_tables, tail_hook=tail_tables)
