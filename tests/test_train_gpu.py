@@ -110,16 +110,25 @@ def test_dedup_train_step_matches_module_path(B, N):
         assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-6, k
     assert abs(out_d["total"] - out_m["total"]) <= 1e-4 * abs(out_m["total"])
     gmax = max(float(g.norm()) for g in g_m.values() if g is not None)
+    rels = []
     for k, gm in g_m.items():
         gd = g_d[k]
         if gm is None:
             assert gd is None or float(gd.norm()) == 0.0, k
             continue
         err = float((gd - gm).norm())
-        # two fp32 evaluations of a batch-statistic network: the 514-channel first decoder layer amplifies rounding
-        # differences to a few 1e-3 at small batch; a wrong weight or count shows up at O(1)
-        # ... and at B = 64 the first layers' BatchNorm gradients (norm ~1e-2 of the largest) sum 32x more rounding noise
+        if float(gm.norm()) > 1e-4 * gmax:
+            rels.append(err / float(gm.norm()))
+        # Two fp32 evaluations of a ReLU / max-pool network differ by discrete events -- an activation within rounding of 0 flips its
+        # mask and that element's upstream gradient enters or leaves a sum (profiles/r03_grad_parity.txt: the float64
+        # arbiter puts the fp32 REFERENCE up to 1.5e-3 from the truth for the same reason).  Observed worst tensors here: 3e-3 (B=2),
+        # 1.3e-2 (B=3, N=200), 6e-4 (N=640), 1.7e-2 (B=64) in relative L2 -- flips, not a bias: the MEDIAN over the 153 parameter tensors is 1e-5 where
+        # nothing flips (N=640), 3e-4 ... 2e-3 where a decision near the output flips and everything upstream feels it (B=3: 2.1e-3); a
+        # wrong term, count or weight moves it to O(1).  Asserted below at 5e-3.
         assert err <= (1.5e-2 if B < 32 else 4e-2) * float(gm.norm()) + (1e-5 if B < 32 else 3e-5) * gmax, (k, err, float(gm.norm()))
+    rels.sort()
+    print("\nB=%d N=%d: relative L2 gradient difference over %d parameter tensors: median %.2e, worst %.2e" % (B, N, len(rels), rels[len(rels) // 2], rels[-1]))
+    assert rels[len(rels) // 2] <= 5e-3, rels[len(rels) // 2]
     for k, v in s_m.items():
         if v.is_floating_point():
             assert float((s_d[k] - v).abs().max()) <= 1e-4 * float(v.abs().max()) + 1e-7, k
