@@ -95,6 +95,19 @@ RTK_EXPORT int rtk_sa_first_layer(int samples, int channels, int rows, int ns, i
                                   const float *dxyz, const float *wx, int wx_pitch, const float *row_weight, float *z, double *sums,
                                   rtk_stream_t stream);
 
+/* Weight gradients that are contractions over positions, on the split-bf16 matrix path (fp32 in, fp32 out, the error of an fp32
+ * fmaf chain; csrc/train_gemm.hip):  out[i][j] = sum_{r < m} x[r][i] * y[r][j]  for up to four (x, y, out) jobs in one launch.
+ * x, y (m, 256) fp32 row-major, 16-byte aligned; out 256 rows of out_pitch >= 256 floats, fully written.  workspace: at least
+ * njobs * 65536 floats; with njobs * 65536 * (256 / njobs) floats the grid is one slab per CU (the slabs' partial blocks are summed
+ * by a second kernel: deterministic).  Replaces the batched library GEMM of the cost volume's backward
+ * (utils/model_utils/model_utils.py:177-183,226-231: the two 256 x 256 convolutions over N x 16 positions). */
+typedef struct {
+    const float *x, *y;
+    float *out;
+    int out_pitch;
+} rtk_tn_job_t;
+RTK_EXPORT int rtk_tn_gemm256_split(int njobs, const rtk_tn_job_t *jobs, long m, float *workspace, long workspace_floats, rtk_stream_t stream);
+
 /* Kernel images of live (trained) weights, all of an operator's matrices in ONE launch (the training path re-packs every step).
  * kind 0: fragment-major MFMA A-operand image of a (rows, cols) matrix, packed[u][v][16g+i][r] = W[16v+i][16u+4g+r], zero padded to
  *         multiples of 16 (fused.pack_layer); transpose != 0 packs W^T (element (o,k) = src[k*pitch + o]);

@@ -644,22 +644,34 @@ class _CvWeights:
             self.layers_t = ctypes.cast(ctypes.byref(self.layers, 2 * ctypes.sizeof(L)), ctypes.POINTER(L))      # W3^T, W2^T
 
 
-def _tall_tn(a, b):
-    """a^T b for tall-skinny a (M,p), b (M,q) with M >> p, q: the (p,q) output is a handful of GEMM tiles, so a plain mm
-    walks the M dimension in one or two workgroups.  Split M into up to 256 slabs (batched GEMM), then add the slabs."""
-    M = a.shape[0]
-    c = 256
-    while M % c:
-        c //= 2
-    if c == 1:
-        return torch.mm(a.t(), b)
-    return torch.bmm(a.view(c, M // c, -1).transpose(1, 2), b.view(c, M // c, -1)).sum(0)
+class _TnJob(ctypes.Structure):          # rtk_tn_job_t (include/rtk_train.h)
+    _fields_ = [("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("out", ctypes.c_void_p), ("out_pitch", ctypes.c_int)]
+
+
+_lib.SIGNATURES.update({"rtk_tn_gemm256_split": [_i, ctypes.POINTER(_TnJob), ctypes.c_long, _p, ctypes.c_long, _p]})
+
+
+def tn_gemm256(pairs):
+    """[(x, y), ...] with x, y (m, 256) fp32 contiguous -> (len(pairs), 256, 256): x^T y of every pair in one launch on the
+    split-bf16 matrix path (rtk_tn_gemm256_split)."""
+    n, m = len(pairs), pairs[0][0].shape[0]
+    dev = pairs[0][0].device
+    out = torch.empty(n, 256, 256, dtype=torch.float32, device=dev)
+    jobs = (_TnJob * n)()
+    for k, (x, y) in enumerate(pairs):
+        assert x.shape == (m, 256) and y.shape == (m, 256) and x.is_contiguous() and y.is_contiguous() and x.dtype == y.dtype == torch.float32
+        jobs[k].x, jobs[k].y, jobs[k].out, jobs[k].out_pitch = x.data_ptr(), y.data_ptr(), out[k].data_ptr(), 256
+    steps = (m + 15) // 16
+    slabs = max(1, min(256 // n, (steps + 7) // 8))
+    ws = torch.empty(n * slabs * 65536, dtype=torch.float32, device=dev)
+    _lib.call("rtk_tn_gemm256_split", n, jobs, m, ws.data_ptr(), ws.numel(), _stream())
+    return out
 
 
 class _CostVolume(torch.autograd.Function):
     """out[i] = sum_k WeightNet(d_ik) * mlp(p1[i] + p2[knn[i,k]] + Wd d_ik),  d_ik = xyz2[knn[i,k]] - xyz1[i]
     (utils/model_utils/model_utils.py:216-236 with the first conv split by input segment).  Forward = the inference
-    kernel rtk_cost_volume; backward = rtk_cost_volume_bwd + GEMMs for the weight gradients."""
+    kernel rtk_cost_volume; backward = rtk_cost_volume_bwd + rtk_tn_gemm256_split for the weight gradients."""
 
     @staticmethod
     def forward(ctx, p1, p2, wd, w2, b2, w3, b3, wa, ba, wb, bb, wc, bc, xyz1, xyz2, knn):
@@ -712,17 +724,9 @@ class _CostVolume(torch.autograd.Function):
                       dq3.data_ptr(), d4.data_ptr(), dp1.data_ptr(), dpd.data_ptr(), dt2.data_ptr(), dbr.data_ptr(), _stream())
         dp2 = torch.empty(B * n2, 256, dtype=torch.float32, device=dev)
         _lib.call("rtk_scatter_add_rows", B, n1 * 16, n2, 256, knn.data_ptr(), dz1.data_ptr(), dp2.data_ptr(), _stream())
-        # weight gradients: contractions over the M positions
-        # dW2 = dz2^T a1 and dW3 = dz3^T a2 as ONE batched GEMM over the slabs of both products (the operands are adjacent slices of
-        # `big` / `acts`: (dz2, dz3) and (a1, a2)), then one sum per product
-        c = 64                                 # slabs per product (32 .. 256 measured within 0.5 % of each other; fewer = a smaller sum)
-        while M % c:
-            c //= 2
-        if c >= 8:
-            prod = torch.bmm(big[1:3].view(2 * c, M // c, 256).transpose(1, 2), acts[0:2].view(2 * c, M // c, 256))
-            dw2, dw3 = prod.view(2, c, 256, 256).sum(1).unbind(0)
-        else:
-            dw3, dw2 = _tall_tn(dz3, a2), _tall_tn(dz2, a1)
+        # weight gradients: contractions over the M positions, dW2 = dz2^T a1 and dW3 = dz3^T a2, in one launch on the split-bf16
+        # matrix path (rtk_tn_gemm256_split; until round 3 a batched library GEMM on the fp32 pipe)
+        dw2, dw3 = tn_gemm256([(dz2, a1), (dz3, a2)]).unbind(0)
         db3, db2 = dbr.sum(0).split(256)
         dwd = dpd.sum(0).t()
         dwa, dba, dwb, dbb, dwc, dbc = _weightnet_backward(d4, dq3, dt2, wa, ba, wb, bb, wc)

@@ -709,6 +709,35 @@ def test_weight_gradient_workspaces_of_any_size_give_the_same_sums():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("m", [1, 15, 16, 17, 1000, 4096, 5152, 40000])
+def test_position_contraction_on_the_split_path_carries_fp32_accuracy(m):
+    """rtk_tn_gemm256_split (the cost volume's two weight gradients, x^T y over m rows, six bf16 MFMA products per fp32 product)
+    against float64, with torch's fp32 GEMM as the yardstick; row counts that end inside a 16-row step, inside a thread's four rows,
+    and slabs that are rounded up with empty steps (out-of-range rows must read as zero)."""
+    from ratrack_amd import _lib, train_ops as T
+    g = torch.Generator(DEV).manual_seed(m)
+    x = torch.randn(2, m, 256, device=DEV, generator=g) * torch.rand(2, m, 1, device=DEV, generator=g) * 3
+    y = torch.relu(torch.randn(2, m, 256, device=DEV, generator=g)) + 0.25      # same-sign operand: no cancellation to hide behind
+    ref = torch.stack([x[k].double().t() @ y[k].double() for k in range(2)])
+    lib = torch.stack([x[k].t() @ y[k] for k in range(2)])
+    out = T.tn_gemm256([(x[0], y[0]), (x[1], y[1])])
+    scale = float(ref.abs().max())
+    err, err_lib = float((out - ref).abs().max()) / scale, float((lib - ref).abs().max()) / scale
+    assert err <= max(2.0 * err_lib, 3e-7), (err, err_lib)
+    # one job, the smallest legal workspace (one slab per job), a pitched output that must be left alone outside its 256 columns
+    big = torch.full((256, 300), 7.0, device=DEV)
+    ws = torch.empty(65536, device=DEV)
+    job = (T._TnJob * 1)()
+    job[0].x, job[0].y, job[0].out, job[0].out_pitch = x[1].data_ptr(), y[1].data_ptr(), big.data_ptr(), 300
+    _lib.call("rtk_tn_gemm256_split", 1, job, m, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+    assert float((big[:, :256] - ref[1]).abs().max()) / scale <= max(2.0 * err_lib, 3e-7)
+    assert bool((big[:, 256:] == 7.0).all())
+    assert torch.equal(T.tn_gemm256([(x[0], y[0]), (x[1], y[1])]), out)      # no atomics: the same bits every time
+    with pytest.raises(_lib.RtkError):
+        _lib.call("rtk_tn_gemm256_split", 1, job, m, ws.data_ptr(), 65535, torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,C,n,m", [(3, 13, 77, 50), (4, 128, 256, 256), (2, 64, 1024, 512)])
 def test_three_interpolate_backward_gather_form(B, C, n, m):
     """rtk_three_interpolate_grad_gather over the inverse table of the interpolation indices against the reference-style scatter

@@ -1,9 +1,22 @@
 #!/usr/bin/env python3
 """Ad-hoc timing of the host-side pieces of the cost-volume backward at bench shapes."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
-from ratrack_amd.train_ops import _tall_tn
+
+
+def _tall_tn(a, b):
+    """a^T b for tall-skinny a (M,p), b (M,q) with M >> p, q: the (p,q) output is a handful of GEMM tiles, so a plain mm
+    walks the M dimension in one or two workgroups.  Split M into up to 256 slabs (batched GEMM), then add the slabs."""
+    M = a.shape[0]
+    c = 256
+    while M % c:
+        c //= 2
+    if c == 1:
+        return torch.mm(a.t(), b)
+    return torch.bmm(a.view(c, M // c, -1).transpose(1, 2), b.view(c, M // c, -1)).sum(0)
+
+
 M = 64 * 256 * 16
 dev = "cuda"
 def timeit(name, fn, iters=10):
