@@ -240,6 +240,20 @@ RTK_EXPORT int rtk_pw_conv(int samples, int positions, int nsrc, const rtk_pw_op
  * shape at full parallelism; NULL: no split) and are added by a second kernel in a fixed order: no atomics, deterministic. */
 RTK_EXPORT int rtk_pw_wgrad(int samples, int positions, const rtk_pw_operand_t *dz, int nsrc, const rtk_pw_operand_t *srcs, float *dw,
                             int w_pitch, float *dbias, float *workspace, long workspace_floats, rtk_stream_t stream);
+/* Any number of such weight gradients with as few launches as possible (eight jobs per launch: their parameters travel in the kernel
+ * argument).  The weight gradients of a training step are leaves -- nothing but the optimizer reads them -- so the training path
+ * queues them during the backward and issues them together at its end.  The workspace is shared out equally among a launch's jobs. */
+typedef struct {
+    int samples, positions;
+    const rtk_pw_operand_t *dz;
+    int nsrc;
+    const rtk_pw_operand_t *srcs;
+    float *dw;
+    int w_pitch;
+    float *dbias;
+} rtk_pw_wgrad_job_t;
+RTK_EXPORT int rtk_pw_wgrad_multi(int njobs, const rtk_pw_wgrad_job_t *jobs, float *workspace, long workspace_floats, rtk_stream_t stream);
+
 
 /* ---- cost volume (utils/model_utils/model_utils.py:216-236) ------------------------------------------------------
  * Training forward: rtk_cost_volume (rtk_fused.h; same arguments and result) that also keeps the three activations

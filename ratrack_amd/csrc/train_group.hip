@@ -203,6 +203,118 @@ __global__ __launch_bounds__(256) void sa_first_layer_bwd_kernel(int channels, i
     }
 }
 
+// The same for planes of at most 8192 positions (every level of the N = 256 configurations), with the run structure -- which sorted
+// positions a thread owns, which source point each belongs to, where its runs end -- worked out ONCE per workgroup into registers
+// instead of once per plane inside the summation loop.  The generic kernel above re-walks the offset table while it sums: with runs
+// of ~32 positions and 64 lanes, some lane ends a run at almost every step and the whole wave takes the divergent
+// atomic-and-advance path (~300 cycles) 32 times per plane: 20 k cycles per plane, 1.5 TB/s at the largest shape.  Here a plane is
+// EMAX independent LDS reads, EMAX adds and a predicated ds_add_f32 at the precomputed run ends.
+// iq[k] = (source point << 16) | position of the thread's k-th sorted element; elements past the chunk point at a zero slot.
+template <int EMAX>
+__global__ __launch_bounds__(256, 2) void sa_first_layer_bwd_fast_kernel(int channels, int cg, int n_src, int P, const float *__restrict__ dz,
+                                                                      const float *__restrict__ dxyz, const int *__restrict__ off,
+                                                                      const unsigned short *__restrict__ inv, float *__restrict__ dproj,
+                                                                      float *__restrict__ dwx, int dwx_pitch) {
+    constexpr int NQ = EMAX / 4;      // float4 per thread and plane (P <= 256 EMAX)
+    extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem[];
+    float *s_plane = reinterpret_cast<float *>(fb_smem);                                  // [P + 4]: s_plane[P] = 0 (the slot of absent elements)
+    int *s_off = reinterpret_cast<int *>(s_plane + P + 4);                                // [n_src + 1]
+    float *s_out = reinterpret_cast<float *>(s_off + n_src + 1);                         // [n_src]
+    unsigned short *s_inv = reinterpret_cast<unsigned short *>(s_out + n_src);            // [P + 256] (padded, see the generic kernel)
+    __shared__ float s_red[4][3];
+    const int s = blockIdx.y, c0 = blockIdx.x * cg, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int q = t; q <= n_src; q += 256) s_off[q] = off[(size_t)s * (n_src + 1) + q];
+    const int E = (P + 255) >> 8;                 // <= EMAX
+    for (int p = t; p < P; p += 256) s_inv[p + p / E] = inv[(size_t)s * P + p];
+    if (t < 4) s_plane[P + t] = 0.f;
+    const int n4 = P >> 2;                        // P % 4 == 0 (ns >= 4), n4 <= 256 NQ
+    const float4 *dx4 = reinterpret_cast<const float4 *>(dxyz + (size_t)s * 3 * P);
+    float4 ox[NQ], oy[NQ], oz[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int e = t + 256 * i;
+        const int ec = e < n4 ? e : n4 - 1;      // unconditional (clamped) loads; tail threads never use theirs
+        ox[i] = dx4[ec]; oy[i] = dx4[n4 + ec]; oz[i] = dx4[2 * n4 + ec];
+    }
+    const int nplanes = min(cg, channels - c0);
+    float4 v[NQ];
+    auto request = [&](int c) {                    // all of a plane's loads in flight at once (tail threads re-read its last float4)
+        const float4 *pl = reinterpret_cast<const float4 *>(dz + ((size_t)s * channels + c) * P);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int e = t + 256 * i;
+            v[i] = pl[e < n4 ? e : n4 - 1];
+        }
+    };
+    request(c0);
+    // ---- the run structure of this thread's chunk [t E, (t + 1) E) of the sorted positions, once ----------------------------------
+    const int e0 = t * E, cnt = max(0, min(P, e0 + E) - e0);
+    unsigned iq[EMAX];
+    unsigned endmask = 0;
+    __syncthreads();                               // s_off, s_inv complete
+    {
+        int q = 0, nb = 0;
+        if (cnt > 0) {
+            int lo = 0, hi = n_src;                // the source point of position e0: last q with off[q] <= e0
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= e0) lo = mid; else hi = mid; }
+            q = lo;
+            nb = s_off[q + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < EMAX; ++k) {
+            const int e = e0 + k;
+            if (k < cnt) {
+                while (e >= nb) { ++q; nb = s_off[q + 1]; }
+                iq[k] = (unsigned)s_inv[e + t] | ((unsigned)q << 16);
+                if (k == cnt - 1 || e + 1 >= nb) endmask |= 1u << k;
+            } else {
+                iq[k] = (unsigned)P;               // the zero slot
+            }
+        }
+    }
+    for (int cc = 0; cc < nplanes; ++cc) {
+        const int c = c0 + cc;
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        __syncthreads();                           // the previous plane has been consumed
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int e = t + 256 * i;
+            if (e < n4) {
+                reinterpret_cast<float4 *>(s_plane)[e] = v[i];
+                ax += (v[i].x * ox[i].x + v[i].y * ox[i].y) + (v[i].z * ox[i].z + v[i].w * ox[i].w);
+                ay += (v[i].x * oy[i].x + v[i].y * oy[i].y) + (v[i].z * oy[i].z + v[i].w * oy[i].w);
+                az += (v[i].x * oz[i].x + v[i].y * oz[i].y) + (v[i].z * oz[i].z + v[i].w * oz[i].w);
+            }
+        }
+        if (cc + 1 < nplanes) request(c + 1);      // the next plane travels while this one is gathered
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { ax += __shfl_xor(ax, o, 64); ay += __shfl_xor(ay, o, 64); az += __shfl_xor(az, o, 64); }
+        if (lane == 0) { s_red[wave][0] = ax; s_red[wave][1] = ay; s_red[wave][2] = az; }
+        for (int q = t; q < n_src; q += 256) s_out[q] = 0.f;
+        __syncthreads();                           // plane staged, partials visible, accumulator clear
+        if (t < 3) atomicAdd(dwx + (size_t)c * dwx_pitch + t, (s_red[0][t] + s_red[1][t]) + (s_red[2][t] + s_red[3][t]));
+        float acc = 0.f;
+        constexpr int VB = EMAX < 16 ? EMAX : 16;      // values in flight (32 at once spill at two workgroups per CU)
+#pragma unroll
+        for (int k0 = 0; k0 < EMAX; k0 += VB) {
+            float val[VB];
+#pragma unroll
+            for (int k = 0; k < VB; ++k) val[k] = s_plane[iq[k0 + k] & 0xffffu];
+#pragma unroll
+            for (int k = 0; k < VB; ++k) {
+                acc += val[k];
+                if (endmask & (1u << (k0 + k))) {
+                    atomicAdd(&s_out[iq[k0 + k] >> 16], acc);
+                    acc = 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        float *out = dproj + ((size_t)s * channels + c) * n_src;
+        for (int q = t; q < n_src; q += 256) out[q] = s_out[q];
+    }
+}
+
 // Backward of three_interpolate in gather form: known point k sums w * grad over the (unknown point, neighbour slot) positions that
 // reference it (the inverse table of the interpolation indices, rtk_group_inverse_index with positions = 3 n), for TG_CPB channels
 // at a time with the gradient planes staged in LDS.  The scatter form (one ds_add_f32 per term, ops_pointnet2.hip) runs at
@@ -324,15 +436,33 @@ extern "C" int rtk_sa_first_layer_bwd(int samples, int channels, int rows, int n
     RTK_REQUIRE(samples > 0 && channels > 0 && rows > 0 && ns >= 4 && (ns & 3) == 0 && n_src > 0 && dz && dxyz && off && inv && dproj &&
                 dwx && dwx_pitch >= 3, "sa_first_layer_bwd: bad arguments");
     const int P = rows * ns;
-    const size_t lds = (size_t)((P + 3) & ~3) * sizeof(float) + (size_t)(2 * n_src + 1) * sizeof(int) + (size_t)(P + 256) * sizeof(unsigned short);
+    const size_t lds = (size_t)(P + 4) * sizeof(float) + (size_t)(2 * n_src + 1) * sizeof(int) + (size_t)(P + 256) * sizeof(unsigned short);
     RTK_REQUIRE(P <= 65536 && lds <= 150 * 1024 && samples <= 65535, "sa_first_layer_bwd: %d positions exceed the LDS budget", P);
+    hipStream_t st = (hipStream_t)stream;
+    if (P <= 8192 && n_src < 65536 && !getenv("RTK_FB_OLD")) {
+        // planes of up to 8192 positions: the run structure lives in registers, a plane costs little, so more planes per workgroup
+        // amortise the per-workgroup setup (index tables, offsets, the walk over the offset table)
+        const long planes = (long)channels * samples;
+        const int cg = planes >= 4096 ? 8 : planes >= 1024 ? 4 : 1;
+        const dim3 grid((channels + cg - 1) / cg, samples);
+        const int E = (P + 255) >> 8;
+#define FB_CASE(EM)                                                                                                                             \
+    {                                                                                                                                           \
+        (void)hipFuncSetAttribute((const void *)sa_first_layer_bwd_fast_kernel<EM>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);   \
+        sa_first_layer_bwd_fast_kernel<EM><<<grid, 256, lds, st>>>(channels, cg, n_src, P, dz, dxyz, off, inv, dproj, dwx, dwx_pitch);          \
+    }
+        if (E <= 8) FB_CASE(8) else if (E <= 16) FB_CASE(16) else FB_CASE(32)
+#undef FB_CASE
+        RTK_CHECK_LAUNCH("sa_first_layer_bwd");
+        return RTK_OK;
+    }
     (void)hipFuncSetAttribute((const void *)sa_first_layer_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);      // per device and cheap: every call
     // channel planes per workgroup: 4 (2, 8 and 16 measured within 5 % of it or worse, tools/experiments/exp_firstbwd.py: the per-plane phases,
     // not the per-workgroup staging of the index tables and offset planes, set the pace)
     // ... at large batches; with few samples one plane per workgroup (the serial chain per workgroup is what counts there)
     const int cg = ((long)((channels + 3) / 4) * samples >= 256 ? 4 : 1);
     const dim3 grid((channels + cg - 1) / cg, samples);
-    sa_first_layer_bwd_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(channels, cg, n_src, P, dz, dxyz, off, inv, dproj, dwx, dwx_pitch);
+    sa_first_layer_bwd_kernel<<<grid, 256, lds, st>>>(channels, cg, n_src, P, dz, dxyz, off, inv, dproj, dwx, dwx_pitch);
     RTK_CHECK_LAUNCH("sa_first_layer_bwd");
     return RTK_OK;
 }

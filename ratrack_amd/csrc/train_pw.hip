@@ -339,18 +339,37 @@ struct PwWgParams {
     unsigned char chunk_src[40];
     short chunk_c0[40];
     int tiles_per_wg;               // (sample, 16-position tile) pairs per workgroup
-    float *partial;                 // gridDim.z > 1: [z][block = y * nchunks + x][64 x 64] workgroup partials (pw_wgrad_reduce_kernel adds them)
+    int ochunks, splits;            // the job's grid: nchunks x ochunks x splits workgroups
+    float *partial;                 // splits > 1: [z][block = y * nchunks + x][64 x 64] workgroup partials (pw_wgrad_reduce_kernel adds them)
 };
 
-__global__ __launch_bounds__(PW_T, 2) void pw_wgrad_kernel(const PwWgParams Q) {
+// Several weight gradients in ONE launch (up to PW_WG_JOBS; the parameters of all of them travel in the kernel argument): the backward
+// of a step has 35 of them, every one a leaf of the graph (only the optimizer reads it), each a 10-20 us launch that fills the chip
+// for a few microseconds.  Deferred to the end of the backward and launched together they are one grid of ~1000 workgroups.
+constexpr int PW_WG_JOBS = 8;
+struct PwWgMulti {
+    int n;
+    int first_block[PW_WG_JOBS + 1];      // flat workgroup index -> job
+    PwWgParams q[PW_WG_JOBS];
+};
+static_assert(sizeof(PwWgMulti) <= 4096, "kernel arguments are limited to 4 KiB");
+
+__global__ __launch_bounds__(PW_T, 2) void pw_wgrad_kernel(const PwWgMulti M) {
     __shared__ float s_red[PW_T / 64][64][65];      // one image per wave: written in parallel, added on the way out
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15, wave = threadIdx.x >> 6;
-    const PwOp &S = Q.src[Q.chunk_src[blockIdx.x]];
-    const int k0 = Q.chunk_c0[blockIdx.x];
-    const int o0 = blockIdx.y * 64;
+    int ji = 0;
+    while (ji + 1 < M.n && (int)blockIdx.x >= M.first_block[ji + 1]) ++ji;
+    const PwWgParams &Q = M.q[ji];
+    // the job's own (input chunk, output chunk, position split) grid
+    const int flat = (int)blockIdx.x - M.first_block[ji];
+    const int gx = Q.nchunks, gy = Q.ochunks;
+    const int bx = flat % gx, by = (flat / gx) % gy, bz = flat / (gx * gy);
+    const PwOp &S = Q.src[Q.chunk_src[bx]];
+    const int k0 = Q.chunk_c0[bx];
+    const int o0 = by * 64;
     const int P = Q.P, tps = (P + 15) >> 4;                          // tiles per sample
     const long ntiles = (long)Q.samples * tps;
-    const long t_begin = (long)blockIdx.z * Q.tiles_per_wg, t_end = min(ntiles, t_begin + Q.tiles_per_wg);
+    const long t_begin = (long)bz * Q.tiles_per_wg, t_end = min(ntiles, t_begin + Q.tiles_per_wg);
     f4 acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -394,9 +413,9 @@ __global__ __launch_bounds__(PW_T, 2) void pw_wgrad_kernel(const PwWgParams Q) {
     __syncthreads();
     auto total = [&](int o, int k) { return (s_red[0][o][k] + s_red[1][o][k]) + (s_red[2][o][k] + s_red[3][o][k]); };
     static_assert(PW_T == 256, "four waves");
-    if (gridDim.z > 1) {             // a partial block per workgroup, no atomics (a 64 x 64 block of float atomics per workgroup on
+    if (Q.splits > 1) {              // a partial block per workgroup, no atomics (a 64 x 64 block of float atomics per workgroup on
                                      // 64..256 contended addresses cost more than the whole product)
-        float *dst = Q.partial + ((size_t)blockIdx.z * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4096;
+        float *dst = Q.partial + ((size_t)bz * gy * gx + (size_t)by * gx + bx) * 4096;
         for (int e = threadIdx.x; e < 64 * 64; e += PW_T) dst[e] = total(e >> 6, e & 63);
         return;
     }
@@ -412,10 +431,14 @@ __global__ __launch_bounds__(PW_T, 2) void pw_wgrad_kernel(const PwWgParams Q) {
 
 // dW block (y, x) += sum over z of the workgroup partials.  A workgroup = 32 consecutive elements x 8 lanes over z (every load
 // independent: the sum over a few hundred partials is a latency problem, not a bandwidth one), then a fixed-order LDS reduction.
-__global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const PwWgParams Q, int splits, int ochunks) {
+__global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const PwWgMulti M) {      // first_block: in units of 128 workgroups (one 64 x 64 block)
     __shared__ float s_part[8][33];
     const int el = threadIdx.x & 31, zl = threadIdx.x >> 5;
-    const int blk = blockIdx.x >> 7, e = (blockIdx.x & 127) * 32 + el;              // 128 workgroups per 64 x 64 block
+    int ji = 0;
+    while (ji + 1 < M.n && (int)(blockIdx.x >> 7) >= M.first_block[ji + 1]) ++ji;
+    const PwWgParams &Q = M.q[ji];
+    const int splits = Q.splits, ochunks = Q.ochunks;
+    const int blk = (int)(blockIdx.x >> 7) - M.first_block[ji], e = (blockIdx.x & 127) * 32 + el;              // 128 workgroups per 64 x 64 block
     const float *src = Q.partial + (size_t)blk * 4096 + e;
     const size_t stride = (size_t)ochunks * Q.nchunks * 4096;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -519,18 +542,18 @@ extern "C" int rtk_pw_conv(int samples, int positions, int nsrc, const rtk_pw_op
     return RTK_OK;
 }
 
-extern "C" int rtk_pw_wgrad(int samples, int positions, const rtk_pw_operand_t *dz, int nsrc, const rtk_pw_operand_t *srcs, float *dw,
-                            int w_pitch, float *dbias, float *workspace, long workspace_floats, rtk_stream_t stream) {
-    RTK_REQUIRE(samples > 0 && positions > 0 && dz && nsrc >= 1 && nsrc <= PW_MAXOP && srcs && dw, "pw_wgrad: bad arguments");
-    PwWgParams Q = {};
-    Q.samples = samples; Q.P = positions; Q.nsrc = nsrc; Q.dW = dw; Q.w_pitch = w_pitch; Q.dbias = dbias;
-    if (fill_op(Q.dz, *dz, "pw_wgrad")) return RTK_ERR_INVALID;
-    RTK_REQUIRE(dz->layout != 2, "pw_wgrad: bad dz layout");
+// one job's kernel parameters; want_wgs = workgroups to aim for (position splits), ws = its share of the partial workspace
+static int wgrad_job(PwWgParams &Q, const rtk_pw_wgrad_job_t &J, int want_wgs, float *ws, long ws_floats) {
+    RTK_REQUIRE(J.samples > 0 && J.positions > 0 && J.dz && J.nsrc >= 1 && J.nsrc <= PW_MAXOP && J.srcs && J.dw, "pw_wgrad: bad arguments");
+    Q = PwWgParams{};
+    Q.samples = J.samples; Q.P = J.positions; Q.nsrc = J.nsrc; Q.dW = J.dw; Q.w_pitch = J.w_pitch; Q.dbias = J.dbias;
+    if (fill_op(Q.dz, *J.dz, "pw_wgrad")) return RTK_ERR_INVALID;
+    RTK_REQUIRE(J.dz->layout != 2, "pw_wgrad: bad dz layout");
     int nch = 0;
-    for (int i = 0; i < nsrc + (dbias ? 1 : 0); ++i) {
-        if (i < nsrc) {
-            if (fill_op(Q.src[i], srcs[i], "pw_wgrad")) return RTK_ERR_INVALID;
-            RTK_REQUIRE(srcs[i].layout != 2, "pw_wgrad: pass dbias instead of a constant-one source");
+    for (int i = 0; i < J.nsrc + (J.dbias ? 1 : 0); ++i) {
+        if (i < J.nsrc) {
+            if (fill_op(Q.src[i], J.srcs[i], "pw_wgrad")) return RTK_ERR_INVALID;
+            RTK_REQUIRE(J.srcs[i].layout != 2, "pw_wgrad: pass dbias instead of a constant-one source");
         } else {
             Q.src[i] = PwOp{nullptr, 0, 0, 1, 2, 0};
         }
@@ -541,27 +564,58 @@ extern "C" int rtk_pw_wgrad(int samples, int positions, const rtk_pw_operand_t *
         }
     }
     Q.nchunks = nch;
-    const long ntiles = (long)samples * ((positions + 15) / 16);
-    const int ochunks = rtk_divup(dz->channels, 64);
-    // about two workgroups per CU (more only adds partial blocks: tools/experiments/exp_pw.py), at least one tile per wave, and no more
-    // position splits than the workspace holds partial blocks for
-    const long blocks = (long)nch * ochunks;
-    const int want_wgs = 512;
+    const long ntiles = (long)J.samples * ((J.positions + 15) / 16);
+    Q.ochunks = rtk_divup(J.dz->channels, 64);
+    // position splits: towards want_wgs workgroups (more only adds partial blocks: tools/experiments/exp_pw.py), at least one tile per
+    // wave, and no more than the workspace holds partial blocks for
+    const long blocks = (long)nch * Q.ochunks;
     long splits = (want_wgs + blocks - 1) / blocks;
     if (splits > (ntiles + 3) / 4) splits = (ntiles + 3) / 4;      // ... and at least one tile per wave (tiny batches: the serial depth counts)
-    if (splits > workspace_floats / (blocks * 4096)) splits = workspace ? workspace_floats / (blocks * 4096) : 1;
+    if (splits > ws_floats / (blocks * 4096)) splits = ws ? ws_floats / (blocks * 4096) : 1;
     if (splits < 1) splits = 1;
     Q.tiles_per_wg = (int)((ntiles + splits - 1) / splits);
-    splits = (ntiles + Q.tiles_per_wg - 1) / Q.tiles_per_wg;
-    Q.partial = workspace;
-    const dim3 grid(nch, ochunks, (unsigned)splits);
-    pw_wgrad_kernel<<<grid, PW_T, 0, (hipStream_t)stream>>>(Q);
-    RTK_CHECK_LAUNCH("pw_wgrad");
-    if (splits > 1) {
-        pw_wgrad_reduce_kernel<<<(unsigned)(blocks * 128), 256, 0, (hipStream_t)stream>>>(Q, (int)splits, ochunks);
-        RTK_CHECK_LAUNCH("pw_wgrad_reduce");
+    Q.splits = (int)((ntiles + Q.tiles_per_wg - 1) / Q.tiles_per_wg);
+    Q.partial = ws;
+    return RTK_OK;
+}
+
+extern "C" int rtk_pw_wgrad_multi(int njobs, const rtk_pw_wgrad_job_t *jobs, float *workspace, long workspace_floats, rtk_stream_t stream) {
+    RTK_REQUIRE(njobs >= 1 && jobs, "pw_wgrad_multi: bad arguments");
+    for (int j0 = 0; j0 < njobs; j0 += PW_WG_JOBS) {
+        const int n = njobs - j0 < PW_WG_JOBS ? njobs - j0 : PW_WG_JOBS;
+        PwWgMulti M = {}, R = {};
+        M.n = R.n = n;
+        // about two workgroups per CU for the launch as a whole; the workspace in equal shares
+        const int want = n == 1 ? 512 : (1024 + n - 1) / n;
+        const long share = workspace ? (workspace_floats / n) & ~4095L : 0;
+        int wgs = 0, rblocks = 0, nred = 0;
+        for (int k = 0; k < n; ++k) {
+            if (int rc = wgrad_job(M.q[k], jobs[j0 + k], want, workspace ? workspace + (size_t)k * share : nullptr, share)) return rc;
+            M.first_block[k] = wgs;
+            wgs += M.q[k].nchunks * M.q[k].ochunks * M.q[k].splits;
+            if (M.q[k].splits > 1) {
+                R.q[nred] = M.q[k];
+                R.first_block[nred++] = rblocks;
+                rblocks += M.q[k].nchunks * M.q[k].ochunks;
+            }
+        }
+        M.first_block[n] = wgs;
+        pw_wgrad_kernel<<<wgs, PW_T, 0, (hipStream_t)stream>>>(M);
+        RTK_CHECK_LAUNCH("pw_wgrad");
+        if (nred) {
+            R.n = nred;
+            R.first_block[nred] = rblocks;
+            pw_wgrad_reduce_kernel<<<(unsigned)(rblocks * 128), 256, 0, (hipStream_t)stream>>>(R);
+            RTK_CHECK_LAUNCH("pw_wgrad_reduce");
+        }
     }
     return RTK_OK;
+}
+
+extern "C" int rtk_pw_wgrad(int samples, int positions, const rtk_pw_operand_t *dz, int nsrc, const rtk_pw_operand_t *srcs, float *dw,
+                            int w_pitch, float *dbias, float *workspace, long workspace_floats, rtk_stream_t stream) {
+    const rtk_pw_wgrad_job_t job = {samples, positions, dz, nsrc, srcs, dw, w_pitch, dbias};
+    return rtk_pw_wgrad_multi(1, &job, workspace, workspace_floats, stream);
 }
 
 extern "C" int rtk_pack_weights(int njobs, const rtk_pack_job_t *jobs, rtk_stream_t stream) {

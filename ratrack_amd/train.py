@@ -70,9 +70,15 @@ class Trainer:
             assert n_valid is None, "padded batches train on the GPU path"
             total, items = L.backbone_loss(pc1 + flow, cls, gt_warp, gt_cls, pretrain=pretrain)
         self.opt.zero_grad(set_to_none=True)
-        total.backward()
         if self._dev.type == "cuda":
+            train_ops.begin_deferred_wgrads()           # the per-point layers queue their weight gradients ...
+            try:
+                total.backward()
+            finally:
+                train_ops.flush_deferred_wgrads()       # ... and they are issued together, eight per launch, and delivered to .grad
             train_ops.arena_end_step(self._dev)
+        else:
+            total.backward()
         self.reducer.pack()
         # detached: a caller holding last step's loss must not keep its autograd graph (and the parameters' gradient
         # accumulators, bound to the stream of that step) alive into the next step / into the graph capture

@@ -81,7 +81,15 @@ class _PwOperand(ctypes.Structure):      # rtk_pw_operand_t (include/rtk_train.h
 
 
 _PwP = ctypes.POINTER(_PwOperand)
+
+
+class _PwWgJob(ctypes.Structure):        # rtk_pw_wgrad_job_t (include/rtk_train.h)
+    _fields_ = [("samples", ctypes.c_int), ("positions", ctypes.c_int), ("dz", _PwP), ("nsrc", ctypes.c_int), ("srcs", _PwP),
+                ("dw", ctypes.c_void_p), ("w_pitch", ctypes.c_int), ("dbias", ctypes.c_void_p)]
+
+
 _lib.SIGNATURES.update({
+    "rtk_pw_wgrad_multi": [_i, ctypes.POINTER(_PwWgJob), _p, ctypes.c_long, _p],
     "rtk_pw_conv": [_i, _i, _i, _PwP, _i, _PwP, _p, _i, _i, _p, _i, _p, _i, _p, _i, _p],
     "rtk_pw_wgrad": [_i, _i, _PwP, _i, _PwP, _p, _i, _p, _p, ctypes.c_long, _p],
     "rtk_backbone_loss": [_i, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p],
@@ -248,9 +256,53 @@ STAT_SLOTS = 8             # RTK_STAT_SLOTS (include/rtk_train.h): replicas of e
 _WGRAD_WS = 4 << 20        # floats: 1024 partial 64 x 64 blocks (rtk_pw_wgrad splits the position axis as far as this allows)
 
 
-def _pw_backward(ctx_needs, srcs, cols, W, dz, want_bias, dW=None):
+# The weight gradients of a training step are leaves of its graph -- only the optimizer reads them.  Between begin_deferred_wgrads()
+# and flush_deferred_wgrads() (train.Trainer brackets the backward with them) the per-point layers queue theirs instead of launching
+# them: 35 launches of 10-20 us, each filling the chip for a few microseconds, become a handful of launches with eight jobs each
+# (rtk_pw_wgrad_multi).  A queued gradient does not travel through autograd -- the engine may copy what a backward returns, and would
+# copy it before it is computed -- the flush assigns / adds it to the parameter's .grad itself.
+_DEFERRED = None
+
+
+def begin_deferred_wgrads():
+    global _DEFERRED
+    _DEFERRED = {"jobs": [], "assign": []}
+
+
+def _run_wgrad_jobs(jobs):
+    """jobs: [(dz (S,Co,P), srcs, cols, dW, dbias or None)]: dW[:, cols_i + k] += sum dz x src_i, dbias += sum dz -- one call."""
+    arr = (_PwWgJob * len(jobs))()
+    keep = []
+    for k, (dz, srcs, cols, dW, dbias) in enumerate(jobs):
+        S_, _, P = dz.shape
+        a, b = _pw_operands([dz], [0]), _pw_operands(srcs, cols)
+        keep += [a, b]
+        arr[k].samples, arr[k].positions, arr[k].dz, arr[k].nsrc, arr[k].srcs = S_, P, a, len(srcs), b
+        arr[k].dw, arr[k].w_pitch, arr[k].dbias = dW.data_ptr(), dW.stride(0), _ptr(dbias)
+    ws = torch.empty(_WGRAD_WS, dtype=torch.float32, device=jobs[0][0].device)          # workgroup partials (uninitialised scratch)
+    _lib.call("rtk_pw_wgrad_multi", len(jobs), arr, ws.data_ptr(), _WGRAD_WS, _stream())
+
+
+def flush_deferred_wgrads():
+    """Issue the queued weight gradients and hand them to their parameters.  Always ends the deferral."""
+    global _DEFERRED
+    q, _DEFERRED = _DEFERRED, None
+    if not q or not q["jobs"]:
+        return
+    _run_wgrad_jobs(q["jobs"])
+    for param, grad in q["assign"]:
+        g = grad.view_as(param)
+        if param.grad is None:
+            param.grad = g
+        else:
+            param.grad = param.grad + g      # (out of place: the existing gradient may be a view of a shared buffer)
+
+
+def _pw_backward(ctx_needs, srcs, cols, W, dz, want_bias, dW=None, owner=None):
     """-> (dW (full shape of W, zero outside the used columns; accumulated into the given zero-initialised dW if any), dbias or
-    None, [dsrc_i or None])."""
+    None, [dsrc_i or None], deferred).  owner = (weight parameter, bias parameter or None): while weight gradients are being
+    deferred, dW / dbias are only queued -- they hold their values after flush_deferred_wgrads(), which also delivers them to the
+    owners' .grad -- and `deferred` tells the caller to return None for them to autograd."""
     S_, Co, P = dz.shape
     dz = _pw_tensor(dz)
     if dW is None:
@@ -259,9 +311,14 @@ def _pw_backward(ctx_needs, srcs, cols, W, dz, want_bias, dW=None):
         dbias = buf[W.shape[0] * W.shape[1]:] if want_bias else None
     else:
         dbias = _zeros((Co,), torch.float32, dz.device) if want_bias else None
-    ws = torch.empty(_WGRAD_WS, dtype=torch.float32, device=dz.device)          # workgroup partials (uninitialised scratch)
-    _lib.call("rtk_pw_wgrad", S_, P, _pw_operands([dz], [0]), len(srcs), _pw_operands(srcs, cols), dW.data_ptr(), dW.stride(0), _ptr(dbias),
-              ws.data_ptr(), _WGRAD_WS, _stream())
+    deferred = _DEFERRED is not None and owner is not None and owner[0] is not None and (dbias is None or owner[1] is not None)
+    if deferred:
+        _DEFERRED["jobs"].append((dz, list(srcs), list(cols), dW, dbias))
+        _DEFERRED["assign"].append((owner[0], dW))
+        if dbias is not None:
+            _DEFERRED["assign"].append((owner[1], dbias))
+    else:
+        _run_wgrad_jobs([(dz, srcs, cols, dW, dbias)])
     dsrcs = [None] * len(srcs)
     todo = [i for i in range(len(srcs)) if ctx_needs[i]]
     if todo:
@@ -270,7 +327,12 @@ def _pw_backward(ctx_needs, srcs, cols, W, dz, want_bias, dW=None):
                   W.stride(0), 1, None, 0, None, 1, None, 0, _stream())
         for i, o in zip(todo, outs):
             dsrcs[i] = o
-    return dW, dbias, dsrcs
+    return dW, dbias, dsrcs, deferred
+
+
+def _leaf(t):
+    """The parameter a deferred gradient can be delivered to: t itself if it is a leaf that wants a gradient."""
+    return t if (t is not None and t.is_leaf and t.requires_grad) else None
 
 
 class _PwLinear(torch.autograd.Function):
@@ -288,6 +350,7 @@ class _PwLinear(torch.autograd.Function):
         _pw_forward(srcs, cols, W2, bias.detach().contiguous() if bias is not None else None, out)
         ctx.save_for_backward(W, *srcs)
         ctx.cfg = (cols, bias is not None)
+        ctx.owner = (_leaf(W), _leaf(bias))
         return out
 
     @staticmethod
@@ -295,7 +358,10 @@ class _PwLinear(torch.autograd.Function):
         W, *srcs = ctx.saved_tensors
         cols, has_bias = ctx.cfg
         W2 = W.detach().reshape(W.shape[0], -1)
-        dW, dbias, dsrcs = _pw_backward(ctx.needs_input_grad[3:], srcs, cols, W2, dz, has_bias and ctx.needs_input_grad[1])
+        dW, dbias, dsrcs, deferred = _pw_backward(ctx.needs_input_grad[3:], srcs, cols, W2, dz, has_bias and ctx.needs_input_grad[1],
+                                                  owner=ctx.owner if ctx.needs_input_grad[0] else None)
+        if deferred:
+            return (None, None, None) + tuple(dsrcs)
         return (dW.view_as(W) if ctx.needs_input_grad[0] else None, dbias, None) + tuple(dsrcs)
 
 
@@ -334,6 +400,7 @@ class _PwBnRelu(torch.autograd.Function):
         y = torch.empty_like(z)
         _lib.call("rtk_bn_relu_fwd_fin", S_, Co, P, 1, groups, z.data_ptr(), fin, par.data_ptr(), 0, y.data_ptr(), _stream())
         ctx.save_for_backward(W, z, par, row_w, gcounts, *srcs)
+        ctx.owner = (_leaf(W), None)
         ctx.cfg = (count, groups, cols)
         return y
 
@@ -351,8 +418,8 @@ class _PwBnRelu(torch.autograd.Function):
         _lib.call("rtk_bn_relu_bwd_apply", S_, Co, P, 1, groups, z.data_ptr(), dy.data_ptr(), par.data_ptr(), _ptr(row_w), sums2.data_ptr(),
                   float(count), _ptr(gcounts), 0, dz.data_ptr(), dgb.data_ptr(), _stream())
         W2 = W.detach().reshape(W.shape[0], -1)
-        dW, _, dsrcs = _pw_backward(ctx.needs_input_grad[4:], srcs, cols, W2, dz, False)
-        return (dW.view_as(W), dgb[0], dgb[1], None) + tuple(dsrcs)
+        dW, _, dsrcs, deferred = _pw_backward(ctx.needs_input_grad[4:], srcs, cols, W2, dz, False, owner=ctx.owner)
+        return (None if deferred else dW.view_as(W), dgb[0], dgb[1], None) + tuple(dsrcs)
 
 
 def pw_bn_relu(srcs, weight, bn, row_weight=None, count=None, groups=1, cols=None, group_counts=None):
@@ -459,6 +526,7 @@ class _SAChain(torch.autograd.Function):
         ctx.bn_affine = [(b.weight.detach(), b.bias.detach()) for b in bns]
         ctx.cfg = (count, groups, L, n_src, nfeat, cols)
         ctx.inv = inv
+        ctx.owner = (_leaf(w0), None)
         return out
 
     @staticmethod
@@ -526,8 +594,8 @@ class _SAChain(torch.autograd.Function):
         else:
             _lib.call("rtk_group_points_grad_set", S_, C1, n_src, rows, ns, dz.data_ptr(), idx.data_ptr(), dproj.data_ptr(), _stream())
             dW0[:, :3] = torch.bmm(dz.view(S_, C1, -1), dxyz.view(S_, 3, -1).transpose(1, 2)).sum(0)
-        _, _, dfeats = _pw_backward(ctx.needs_input_grad[9:9 + nfeat], feats, cols, W0, dproj, False, dW=dW0)
-        return (dW0.view_as(w0), None, None, None, None, None, None, None, None) + tuple(dfeats) + tuple(flat)
+        _, _, dfeats, deferred = _pw_backward(ctx.needs_input_grad[9:9 + nfeat], feats, cols, W0, dproj, False, dW=dW0, owner=ctx.owner)
+        return (None if deferred else dW0.view_as(w0), None, None, None, None, None, None, None, None) + tuple(dfeats) + tuple(flat)
 
 
 def sa_chain_supported(layers):

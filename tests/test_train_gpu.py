@@ -659,7 +659,7 @@ def test_weight_gradient_operators_are_deterministic():
     r = lambda *s: torch.randn(*s, device=DEV, generator=g)
     srcs = [r(24, 64, 200), r(24, 35, 200)]
     W, dz = r(128, 99), r(24, 128, 200)
-    runs = [T._pw_backward([False, False], srcs, [0, 64], W, dz, True) for _ in range(3)]
+    runs = [T._pw_backward([False, False], srcs, [0, 64], W, dz, True)[:3] for _ in range(3)]
     for dW, db, _ in runs[1:]:
         assert torch.equal(dW, runs[0][0]) and torch.equal(db, runs[0][1])
     M, C = 5000, 256
@@ -669,6 +669,45 @@ def test_weight_gradient_operators_are_deterministic():
     for res in runs[1:]:
         for a, b in zip(res, runs[0]):
             assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_deferred_weight_gradients_equal_immediate_ones():
+    """Trainer queues the per-point layers' weight gradients during the backward and issues them eight per launch at its end
+    (rtk_pw_wgrad_multi), delivering them to .grad itself.  Same kernels, same partial sums: bit-identical gradients -- for a parameter
+    used once, a parameter used twice (the second delivery adds), a layer with bias, and input gradients untouched."""
+    from ratrack_amd import train_ops as T
+    g = torch.Generator(DEV).manual_seed(21)
+    r = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    x1, x2 = r(6, 70, 130).requires_grad_(), r(6, 33, 130).requires_grad_()
+    lin = torch.nn.Conv1d(103, 96, 1).to(DEV)
+    conv = torch.nn.Conv2d(96, 48, 1, bias=False).to(DEV)
+    bn = torch.nn.BatchNorm2d(48).to(DEV)
+    many = [torch.nn.Conv1d(48, 20 + 7 * k, 1).to(DEV) for k in range(11)]      # more jobs than one launch takes
+
+    def run(deferred):
+        for p in [x1, x2] + list(lin.parameters()) + list(conv.parameters()) + list(bn.parameters()) + [q for m in many for q in m.parameters()]:
+            p.grad = None
+        bn.running_mean.zero_(); bn.running_var.fill_(1.0); bn.num_batches_tracked.zero_()
+        y = T.pw_linear([x1, x2], lin.weight, lin.bias)
+        z = T.pw_bn_relu([y], conv.weight, bn) + T.pw_bn_relu([y * 0.5], conv.weight, bn)      # conv.weight twice
+        loss = sum((T.pw_linear([z], m.weight, m.bias) ** 2).mean() for m in many)
+        if deferred:
+            T.begin_deferred_wgrads()
+        try:
+            loss.backward()
+            if deferred:
+                assert lin.weight.grad is None and conv.weight.grad is None, "queued gradients must not travel through autograd"
+        finally:
+            if deferred:
+                T.flush_deferred_wgrads()
+        names = [x1, x2, lin.weight, lin.bias, conv.weight, bn.weight, bn.bias] + [q for m in many for q in m.parameters()]
+        return [p.grad.clone() for p in names]
+
+    a, b = run(False), run(True)
+    for k, (u, v) in enumerate(zip(a, b)):
+        assert torch.equal(u, v), (k, float((u - v).abs().max()))
+    assert T._DEFERRED is None
 
 
 @pytest.mark.gpu
