@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void sa_first_layer_bwd_kernel(int channels, i
 // EMAX independent LDS reads, EMAX adds and a predicated ds_add_f32 at the precomputed run ends.
 // iq[k] = (source point << 16) | position of the thread's k-th sorted element; elements past the chunk point at a zero slot.
 template <int EMAX>
-__global__ __launch_bounds__(256, 2) void sa_first_layer_bwd_fast_kernel(int channels, int cg, int n_src, int P, const float *__restrict__ dz,
+__global__ __launch_bounds__(256, 2) void sa_first_layer_bwd_fast_kernel(int channels, int cg, int gx, int n_src, int P, const float *__restrict__ dz,
                                                                       const float *__restrict__ dxyz, const int *__restrict__ off,
                                                                       const unsigned short *__restrict__ inv, float *__restrict__ dproj,
                                                                       float *__restrict__ dwx, int dwx_pitch) {
@@ -222,7 +222,19 @@ __global__ __launch_bounds__(256, 2) void sa_first_layer_bwd_fast_kernel(int cha
     float *s_out = reinterpret_cast<float *>(s_off + n_src + 1);                         // [n_src]
     unsigned short *s_inv = reinterpret_cast<unsigned short *>(s_out + n_src);            // [P + 256] (padded, see the generic kernel)
     __shared__ float s_red[4][3];
-    const int s = blockIdx.y, c0 = blockIdx.x * cg, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // gx > 0: 1-D grid decoded so that all workgroups of sample s run on XCD s % 8 (workgroup ids go round-robin over the XCDs, each
+    // with its own L2): the sample's index table and offset planes (16 + 96 KiB at the largest shape) are fetched from HBM once, not
+    // once per XCD that happens to get one of the sample's channel groups
+    int s, bx;
+    if (gx > 0) {
+        const int L = blockIdx.x, slot = L >> 3;
+        s = (slot / gx) * 8 + (L & 7);
+        bx = slot - (slot / gx) * gx;
+    } else {
+        s = blockIdx.y;
+        bx = blockIdx.x;
+    }
+    const int c0 = bx * cg, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (int q = t; q <= n_src; q += 256) s_off[q] = off[(size_t)s * (n_src + 1) + q];
     const int E = (P + 255) >> 8;                 // <= EMAX
     for (int p = t; p < P; p += 256) s_inv[p + p / E] = inv[(size_t)s * P + p];
@@ -444,12 +456,13 @@ extern "C" int rtk_sa_first_layer_bwd(int samples, int channels, int rows, int n
         // amortise the per-workgroup setup (index tables, offsets, the walk over the offset table)
         const long planes = (long)channels * samples;
         const int cg = planes >= 4096 ? 8 : planes >= 1024 ? 4 : 1;
-        const dim3 grid((channels + cg - 1) / cg, samples);
+        const int nbx = (channels + cg - 1) / cg, gx = samples % 8 == 0 ? nbx : 0;
+        const dim3 grid(gx ? nbx * samples : nbx, gx ? 1 : samples);
         const int E = (P + 255) >> 8;
 #define FB_CASE(EM)                                                                                                                             \
     {                                                                                                                                           \
         (void)hipFuncSetAttribute((const void *)sa_first_layer_bwd_fast_kernel<EM>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);   \
-        sa_first_layer_bwd_fast_kernel<EM><<<grid, 256, lds, st>>>(channels, cg, n_src, P, dz, dxyz, off, inv, dproj, dwx, dwx_pitch);          \
+        sa_first_layer_bwd_fast_kernel<EM><<<grid, 256, lds, st>>>(channels, cg, gx, n_src, P, dz, dxyz, off, inv, dproj, dwx, dwx_pitch);          \
     }
         if (E <= 8) FB_CASE(8) else if (E <= 16) FB_CASE(16) else FB_CASE(32)
 #undef FB_CASE
