@@ -336,6 +336,12 @@ RTK_EXPORT int rtk_train_row_weights(int samples, int rows, int npoint, const in
 RTK_EXPORT int rtk_train_point_weights(int samples, int rows, int groups, const int *n_valid, float *weights, double *group_counts,
                                        rtk_stream_t stream);
 
+/* The stacked weight images rtk_gru_step / rtk_gru_step_bwd take, from the nn.GRU's live per-layer parameters, in one launch:
+ * params = host array of 4 * layers device pointers (w_ih_l, w_hh_l (3H,H), b_ih_l, b_hh_l (3H) for l = 0 ..); w_ih / w_hh (L,3H,H),
+ * w_ih_t / w_hh_t (L,H,3H), b_ih / b_hh (L,3H). */
+RTK_EXPORT int rtk_gru_pack_params(int layers, int hidden, const float *const *params, float *w_ih, float *w_ih_t, float *w_hh, float *w_hh_t,
+                                   float *b_ih, float *b_hh, rtk_stream_t stream);
+
 /* ---- GRU step (fd_layer.torchGRU on a length-1 sequence, utils/model_utils/model_utils.py:279,296) -------------------
  * Backward of rtk_gru_step (rtk_fused.h).  x (B,H), h_in / h_out (L,B,H) as in the forward; w_ih_t, w_hh_t the TRANSPOSED
  * weights (L,H,3H) of the forward, w_ih, w_hh the original (L,3H,H), b_ih, b_hh (L,3H); dy (B,H) gradient of y = h_out[L-1],
@@ -346,6 +352,10 @@ RTK_EXPORT int rtk_gru_step_bwd(int b, int layers, int hidden, const float *x, c
                                 const float *w_ih_t, const float *w_hh_t, const float *w_ih, const float *w_hh, const float *b_ih,
                                 const float *b_hh, const float *dy, const float *dh_out, float *dx, float *dh_in, float *dgi, float *dgh,
                                 rtk_stream_t stream);
+
+/* The GRU's parameter gradients from those gate gradients, one launch: dw_ih, dw_hh (L,3H,H), db_ih, db_hh (L,3H), fully written. */
+RTK_EXPORT int rtk_gru_wgrad(int b, int layers, int hidden, const float *x, const float *h_in, const float *h_out, const float *dgi,
+                             const float *dgh, float *dw_ih, float *dw_hh, float *db_ih, float *db_hh, rtk_stream_t stream);
 
 /* dst[b][idx[b][r]][:] += src[b][r][:] for r < m, dst (samples, n, channels) fully written (no zero-fill needed):
  * the scatter half of the backward of a row gather.  idx (samples, m) int64 in [0, n); channels % 32 == 0.
@@ -362,6 +372,13 @@ RTK_EXPORT int rtk_scatter_add_rows(int samples, int m, int n, int channels, con
 RTK_EXPORT int rtk_weightnet_bwd(long positions, int channels, const float *d4, const float *dq3, const float *dt2, const float *wa,
                                  const float *ba, const float *wb, const float *bb, float *dwa, float *dba, float *dwb, float *dbb,
                                  float *dwc, float *dbc, float *workspace, long workspace_floats, rtk_stream_t stream);
+
+/* "Append the cloud's global feature to every point" (models/track4d.py:92-95: torch.max over the points, expand, cat) as one kernel:
+ * f (samples, C, n) -> out (samples, 2 C, n) = [f ; max_p f broadcast]; arg (samples, C) int32 = first arg-max of every row, for the
+ * backward: df[s][c][p] = dout[s][c][p] + (p == arg[s][c] ? sum_p' dout[s][C + c][p'] : 0)  (what autograd computes for
+ * cat + expand + max, in one pass).  All tensors contiguous. */
+RTK_EXPORT int rtk_gmax_cat_fwd(int samples, int channels, int n, const float *f, float *out, int *arg, rtk_stream_t stream);
+RTK_EXPORT int rtk_gmax_cat_bwd(int samples, int channels, int n, const float *dout, const int *arg, float *df, rtk_stream_t stream);
 
 /* Multi-task loss of the backbone trainer (losses/loss.py:8-31,85-89,124-146, batch mean) and its gradients in one launch.
  * pc1, flow, gt_warp (B,3,N) contiguous; cls (B,N) probabilities; gt_cls uint8/bool, sample b's row at gt_cls + b*gt_cls_stride

@@ -95,19 +95,25 @@ class Track4D(nn.Module):
                 with torch.no_grad():      # (geometry on a forked stream was measured slower inside the captured step: DESIGN.md section 5)
                     tg = TP.TrainGeometry(torch.cat([pc1, pc2], 0).permute(0, 2, 1).contiguous(), self.pn_head.sa1.npoint, n_valid=nv, groups=2)
                 f = TP.pnhead_train(self.pn_head, tg, torch.cat([feature1, feature2], 0), groups=2)
-                (f1, f2), tg1 = f.view(2, B, f.shape[1], f.shape[2]).unbind(0), tg.head(B)
+                # both frames' [per-point features ; global feature] in one kernel (and one in the backward) instead of max, expand,
+                # cat -- and sum, zero fill, scatter, accumulate -- per frame
+                from .train_ops import gmax_cat
+                pf = gmax_cat(f)
+                (pc1_features, pc2_features), tg1 = pf.view(2, B, pf.shape[1], pf.shape[2]).unbind(0), tg.head(B)
         if tg1 is None and n_valid is not None:
             return self._backbone_per_sample(pc1, pc2, feature1, feature2, h, n_valid)
         if tg1 is None:
             xyz1_new, f1 = self.pn_head(pc1.permute(0, 2, 1).contiguous(), feature1)
             xyz2_new, f2 = self.pn_head(pc2.permute(0, 2, 1).contiguous(), feature2)
-        g1 = torch.max(f1, -1)[0].unsqueeze(2).expand(-1, -1, pc1.size(2))
-        g2 = torch.max(f2, -1)[0].unsqueeze(2).expand(-1, -1, pc2.size(2))
-        pc1_features = torch.cat((f1, g1), dim=1)
-        pc2_features = torch.cat((f2, g2), dim=1)
+        if tg1 is None:
+            g1 = torch.max(f1, -1)[0].unsqueeze(2).expand(-1, -1, pc1.size(2))
+            g2 = torch.max(f2, -1)[0].unsqueeze(2).expand(-1, -1, pc2.size(2))
+            pc1_features = torch.cat((f1, g1), dim=1)
+            pc2_features = torch.cat((f2, g2), dim=1)
         if tg1 is not None and TP.correlator_supported(self.fc_layer):
             cor_features = TP.correlator_train(self.fc_layer, pc1, pc2, pc1_features, pc2_features,
-                                               n_valid1=None if nv is None else nv[:pc1.shape[0]], n_valid2=None if nv is None else nv[pc1.shape[0]:])
+                                               n_valid1=None if nv is None else nv[:pc1.shape[0]], n_valid2=None if nv is None else nv[pc1.shape[0]:],
+                                               xyz=(tg.xyz[:pc1.shape[0]], tg.xyz[pc1.shape[0]:]))
         else:
             assert nv is None, "padded batches need the fused correlator of the training path"
             cor_features = self.fc_layer(pc1, pc2, pc1_features, pc2_features)

@@ -43,6 +43,7 @@ class Trainer:
         if self._dev.type == "cuda":
             from . import train_ops
             train_ops.enable_zero_arena(self._dev)      # the step's ~200 small zero-initialised buffers: one fill
+        self._one = torch.ones((), dtype=torch.float32, device=self._dev)
         self.opt, self.sched = make_optimizer(model, lr, capturable=graph)
         self.reducer = FlatGradAllReducer(model, process_group)
         self.graph = graph
@@ -73,7 +74,7 @@ class Trainer:
         if self._dev.type == "cuda":
             train_ops.begin_deferred_wgrads()           # the per-point layers queue their weight gradients ...
             try:
-                total.backward()
+                total.backward(gradient=self._one)      # (a persistent seed: autograd would fill a new ones tensor every step)
             finally:
                 train_ops.flush_deferred_wgrads()       # ... and they are issued together, eight per launch, and delivered to .grad
             train_ops.arena_end_step(self._dev)

@@ -31,6 +31,8 @@ _lib.SIGNATURES.update({
     "rtk_train_interp_weights": [_i] * 3 + [_p] * 5 + [_p],
     "rtk_train_row_weights": [_i] * 3 + [_p] * 2 + [_p],
     "rtk_gru_step_bwd": [_i] * 3 + [_p] * 15 + [_p],
+    "rtk_gru_pack_params": [_i, _i, ctypes.POINTER(ctypes.c_void_p)] + [_p] * 6 + [_p],
+    "rtk_gru_wgrad": [_i] * 3 + [_p] * 9 + [_p],
     "rtk_patch_cost_bwd": [_i, _i, _p, _p, _p, _i, _LayerP, _p, _p, _i, _p, _p, _p, _p, _p, _p],
     "rtk_patch_dfeat_gather": [_i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p],
     "rtk_bn_train_stats": [_i] * 5 + [_p] * 3 + [_p],
@@ -430,6 +432,39 @@ def pw_bn_relu(srcs, weight, bn, row_weight=None, count=None, groups=1, cols=Non
     if count is None:
         count = (S_ // groups) * P
     return _PwBnRelu.apply(weight, bn.weight, bn.bias, (bn, row_weight, float(count), int(groups), _pw_cols(srcs, cols), group_counts), *srcs)
+
+
+# ---- global feature appended to every point ---------------------------------------------------------------------------------
+
+_lib.SIGNATURES.update({"rtk_gmax_cat_fwd": [_i, _i, _i, _p, _p, _p, _p], "rtk_gmax_cat_bwd": [_i, _i, _i, _p, _p, _p, _p]})
+
+
+class _GmaxCat(torch.autograd.Function):
+    """(S,C,N) -> (S,2C,N) = cat(f, max over the points broadcast) (models/track4d.py:92-95), one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, f):
+        f = f.contiguous()
+        S_, C, N = f.shape
+        out = torch.empty(S_, 2 * C, N, dtype=torch.float32, device=f.device)
+        arg = torch.empty(S_, C, dtype=torch.int32, device=f.device)
+        _lib.call("rtk_gmax_cat_fwd", S_, C, N, f.data_ptr(), out.data_ptr(), arg.data_ptr(), _stream())
+        ctx.save_for_backward(arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        arg, = ctx.saved_tensors
+        dout = dout.contiguous()
+        S_, C2, N = dout.shape
+        df = torch.empty(S_, C2 // 2, N, dtype=torch.float32, device=dout.device)
+        _lib.call("rtk_gmax_cat_bwd", S_, C2 // 2, N, dout.data_ptr(), arg.data_ptr(), df.data_ptr(), _stream())
+        return df
+
+
+def gmax_cat(f):
+    """f (S,C,N) fp32 on the GPU -> cat((f, f.max(-1)[0][:, :, None].expand(-1, -1, N)), dim=1)."""
+    return _GmaxCat.apply(f)
 
 
 # ---- SharedMLP chain of one set-abstraction scale ------------------------------------------------------------------------
@@ -969,19 +1004,23 @@ def conv1x1(x, w):
 
 class _GRUStep(torch.autograd.Function):
     """nn.GRU(H, H, L) on a length-1 sequence (model_utils.py:279,296): forward = the inference kernel rtk_gru_step, backward
-    = rtk_gru_step_bwd + two batched GEMMs for the weight gradients (MIOpen's RNN issues ~150 kernels for this 64 x 128
+    = rtk_gru_step_bwd + rtk_gru_wgrad for the parameter gradients (MIOpen's RNN issues ~150 kernels for this 64 x 128
     problem).  params = (w_ih_l0, w_hh_l0, b_ih_l0, b_hh_l0, w_ih_l1, ...)."""
 
     @staticmethod
     def forward(ctx, x, h_in, *params):
+        ctx.set_materialize_grads(False)      # (h_out usually feeds nothing: no zero tensor for its gradient)
         L = len(params) // 4
         B, H = x.shape
         x, h_in = x.contiguous(), h_in.contiguous()
-        w_ih = torch.stack([params[4 * l] for l in range(L)])              # (L,3H,H)
-        w_hh = torch.stack([params[4 * l + 1] for l in range(L)])
-        b_ih = torch.stack([params[4 * l + 2] for l in range(L)])
-        b_hh = torch.stack([params[4 * l + 3] for l in range(L)])
-        w_ih_t, w_hh_t = w_ih.transpose(1, 2).contiguous(), w_hh.transpose(1, 2).contiguous()
+        # the kernels' stacked weight images (plain and transposed) from the live per-layer parameters: one launch
+        buf = torch.empty(4 * L * 3 * H * H + 2 * L * 3 * H, dtype=torch.float32, device=x.device)
+        n = L * 3 * H * H
+        w_ih, w_ih_t, w_hh, w_hh_t = buf[:n].view(L, 3 * H, H), buf[n:2 * n].view(L, H, 3 * H), buf[2 * n:3 * n].view(L, 3 * H, H), buf[3 * n:4 * n].view(L, H, 3 * H)
+        b_ih, b_hh = buf[4 * n:4 * n + L * 3 * H].view(L, 3 * H), buf[4 * n + L * 3 * H:].view(L, 3 * H)
+        ptrs = (ctypes.c_void_p * (4 * L))(*[p.detach().contiguous().data_ptr() for p in params])
+        _lib.call("rtk_gru_pack_params", L, H, ptrs, w_ih.data_ptr(), w_ih_t.data_ptr(), w_hh.data_ptr(), w_hh_t.data_ptr(), b_ih.data_ptr(),
+                  b_hh.data_ptr(), _stream())
         h_out = torch.empty(L, B, H, dtype=torch.float32, device=x.device)
         y = torch.empty(B, H, dtype=torch.float32, device=x.device)
         _lib.call("rtk_gru_step", B, L, H, x.data_ptr(), h_in.data_ptr(), w_ih_t.data_ptr(), w_hh_t.data_ptr(), b_ih.data_ptr(),
@@ -1002,13 +1041,13 @@ class _GRUStep(torch.autograd.Function):
         _lib.call("rtk_gru_step_bwd", B, L, H, x.data_ptr(), h_in.data_ptr(), h_out.data_ptr(), w_ih_t.data_ptr(), w_hh_t.data_ptr(),
                   w_ih.data_ptr(), w_hh.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr(), dy.data_ptr(), _ptr(dho), dx.data_ptr(),
                   dh_in.data_ptr(), dg[0].data_ptr(), dg[1].data_ptr(), _stream())
-        xs = torch.cat([x.unsqueeze(0), h_out[:-1]], 0)                                   # layer inputs (L,B,H)
-        dw_ih = torch.bmm(dg[0].transpose(1, 2), xs)                                      # (L,3H,H)
-        dw_hh = torch.bmm(dg[1].transpose(1, 2), h_in)
-        db = dg.sum(2)                                                                    # (2,L,3H)
+        dw = torch.empty(2, L, 3 * H, H, dtype=torch.float32, device=dev)                 # dW_ih | dW_hh
+        db = torch.empty(2, L, 3 * H, dtype=torch.float32, device=dev)
+        _lib.call("rtk_gru_wgrad", B, L, H, x.data_ptr(), h_in.data_ptr(), h_out.data_ptr(), dg[0].data_ptr(), dg[1].data_ptr(), dw[0].data_ptr(),
+                  dw[1].data_ptr(), db[0].data_ptr(), db[1].data_ptr(), _stream())
         grads = []
         for l in range(L):
-            grads += [dw_ih[l], dw_hh[l], db[0, l], db[1, l]]
+            grads += [dw[0, l], dw[1, l], db[0, l], db[1, l]]
         return (dx, dh_in) + tuple(grads)
 
 

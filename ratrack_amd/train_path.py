@@ -47,6 +47,7 @@ class TrainGeometry:
         from . import fused
         S_, n, _ = xyz.shape
         self.samples, self.n, self.npoint = S_, n, npoint
+        self.xyz = xyz                            # (S_, n, 3) contiguous: the correlator takes its point-major coordinates from here
         self.n_valid, self.point_w, self.point_counts = n_valid, None, None
         if n_valid is not None:
             assert n_valid.shape == (S_,) and n_valid.dtype == torch.int32 and n_valid.is_cuda and n_valid.is_contiguous()
@@ -244,13 +245,15 @@ def _knn16(points, query, n_valid):
     return idx
 
 
-def correlator_train(fc, pc1, pc2, feature1, feature2, n_valid1=None, n_valid2=None):
+def correlator_train(fc, pc1, pc2, feature1, feature2, n_valid1=None, n_valid2=None, xyz=None):
     """FeatureCorrelator.forward (model_utils.py:166-250) in training mode: the point-to-patch cost volume is one
     fused operator (forward kernel of the inference engine + its backward kernel), and so is the patch-to-patch
-    aggregation.  pc (B,3,N), features (B,D,N) -> (B,256,N1).  n_valid1 / n_valid2 (B,) int32: padded batch -- kNN candidates
+    aggregation.  pc (B,3,N), features (B,D,N) -> (B,256,N1); xyz: optional ((B,N1,3), (B,N2,3)) contiguous point-major copies of
+    pc1, pc2.  n_valid1 / n_valid2 (B,) int32: padded batch -- kNN candidates
     are the valid points of the frame searched (padding queries are copies of their cloud's point 0 and get its result)."""
     B, C, N1 = pc1.shape
-    x1, x2 = pc1.permute(0, 2, 1).contiguous(), pc2.permute(0, 2, 1).contiguous()
+    # point-major coordinates: the caller's (TrainGeometry already holds both frames' as one contiguous tensor) or two transposed copies
+    x1, x2 = xyz if xyz is not None else (pc1.permute(0, 2, 1).contiguous(), pc2.permute(0, 2, 1).contiguous())
     D1, D2 = feature1.shape[1], feature2.shape[1]
     knn = _knn16(x2, x1, n_valid2)
     conv0, conv1, conv2 = fc.mlp_convs

@@ -672,6 +672,46 @@ def test_weight_gradient_operators_are_deterministic():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("S,C,N", [(4, 128, 256), (2, 37, 100), (1, 5, 1)])
+def test_gmax_cat_matches_max_expand_cat(S, C, N):
+    """rtk_gmax_cat (models/track4d.py:92-95 as one kernel each way) against torch.max / expand / cat and their autograd: values exactly,
+    gradients to summation order; ties (repeated columns, as in padded clouds) send the gradient to the FIRST maximum like torch.max."""
+    from ratrack_amd import train_ops as T
+    g = torch.Generator(DEV).manual_seed(S * 1000 + N)
+    f = torch.randn(S, C, N, device=DEV, generator=g)
+    if N > 8:
+        f[:, :, N - 4:] = f[:, :, :1]                      # padding columns: copies of point 0
+        f[:, ::3, 0] = f.max(-1)[0][:, ::3] + 1.0          # ... which is the maximum of every third channel: a tie of five columns
+    w = torch.randn(S, 2 * C, N, device=DEV, generator=g)
+    a = f.clone().requires_grad_()
+    ref = torch.cat((a, a.max(-1)[0].unsqueeze(2).expand(-1, -1, N)), dim=1)
+    (ref * w).sum().backward()
+    b = f.clone().requires_grad_()
+    out = T.gmax_cat(b)
+    (out * w).sum().backward()
+    assert torch.equal(out, ref)
+    assert torch.allclose(b.grad, a.grad, rtol=1e-5, atol=1e-5 * float(a.grad.abs().max()))
+
+
+@pytest.mark.gpu
+def test_gru_parameter_pack_is_stack_and_transpose():
+    from ratrack_amd import _lib, train_ops as T
+    import ctypes
+    gru = torch.nn.GRU(128, 128, num_layers=5).to(DEV)
+    L, H = 5, 128
+    params = []
+    for l in range(L):
+        params += [getattr(gru, "weight_ih_l%d" % l), getattr(gru, "weight_hh_l%d" % l), getattr(gru, "bias_ih_l%d" % l), getattr(gru, "bias_hh_l%d" % l)]
+    outs = [torch.empty(L, 3 * H, H, device=DEV), torch.empty(L, H, 3 * H, device=DEV), torch.empty(L, 3 * H, H, device=DEV),
+            torch.empty(L, H, 3 * H, device=DEV), torch.empty(L, 3 * H, device=DEV), torch.empty(L, 3 * H, device=DEV)]
+    ptrs = (ctypes.c_void_p * (4 * L))(*[p.data_ptr() for p in params])
+    _lib.call("rtk_gru_pack_params", L, H, ptrs, *[o.data_ptr() for o in outs], torch.cuda.current_stream().cuda_stream)
+    w_ih, w_hh = torch.stack(params[0::4]), torch.stack(params[1::4])
+    for got, want in zip(outs, [w_ih, w_ih.transpose(1, 2), w_hh, w_hh.transpose(1, 2), torch.stack(params[2::4]), torch.stack(params[3::4])]):
+        assert torch.equal(got, want.contiguous())
+
+
+@pytest.mark.gpu
 def test_deferred_weight_gradients_equal_immediate_ones():
     """Trainer queues the per-point layers' weight gradients during the backward and issues them eight per launch at its end
     (rtk_pw_wgrad_multi), delivering them to .grad itself.  Same kernels, same partial sums: bit-identical gradients -- for a parameter
