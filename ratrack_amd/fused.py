@@ -383,7 +383,7 @@ class Geometry:
     """FPS centroids, ball-query indices and three-NN tables of one batch of clouds (feature independent,
     so the decoder's PNHead over pc1 reuses the encoder's)."""
 
-    def __init__(self, xyz, npoint, side=None, knn_frames=0, finite=False, n_valid=None, level_hook=None, tail_hook=None):
+    def __init__(self, xyz, npoint, side=None, knn_frames=0, finite=False, n_valid=None, level_hook=None, tail_hook=None, zeros=None):
         """xyz (S_,n,3).  With `side` (a torch.cuda.Stream) every geometry kernel is enqueued on that stream, forked from
         the current one, and consumers call wait(stage) -- the feature kernels overlap the latency-bound FPS chain.
         knn_frames = B > 0: also the two kNN tables of the cost volume, frame 1 = xyz[:B], frame 2 = xyz[B:].
@@ -393,7 +393,10 @@ class Geometry:
         points, the rest are copies of its point 0; FPS applies the unpadded cloud's tie rule and the kNN tables only
         hold valid candidates, everything else is exact through the duplicate-of-point-0 property.
         level_hook(geo, lvl) / tail_hook(geo): called (on the geometry stream) right after level lvl's ball query, before its
-        event is recorded / after the three-NN tables -- the training path enqueues its per-level tables there."""
+        event is recorded / after the three-NN tables -- the training path enqueues its per-level tables there.
+        zeros(n, dtype, device): allocator of the zero-initialised workspaces (default torch.zeros; the training path passes its
+        step arena, whose one fill then covers these too)."""
+        zeros = zeros or (lambda n_, dtype, device: torch.zeros(n_, dtype=dtype, device=device))
         S_, n, _ = xyz.shape
         if n_valid is not None:
             assert n_valid.shape == (S_,) and n_valid.dtype == torch.int32 and n_valid.is_contiguous() and n <= 2048
@@ -410,7 +413,7 @@ class Geometry:
         ns_all = [ns for row in _PNHeadWeights.NSAMPLES for ns in row]
         nn_rows = [npoint, npoint, n]
         sizes = [S_ * npoint] * 3 + [S_] * 5 + [S_ * npoint * ns for ns in ns_all] + [S_ * r * 3 for r in nn_rows]
-        ws = torch.zeros(sum(sizes), dtype=torch.int32, device=dev)
+        ws = zeros(sum(sizes), torch.int32, dev)
         parts = list(torch.split(ws, sizes))
         fps_idx, cnt, tie, first_tie, ball, nn_idx = parts[0:3], parts[3:6], parts[6], parts[7], parts[8:14], parts[14:17]
         # level-1 min-distance state at the first tied round (written for tied samples only) + the re-levelling scratch
@@ -419,7 +422,7 @@ class Geometry:
         self.tie = tie
         xyz_all = torch.empty(3, S_, npoint, 3, dtype=torch.float32, device=dev)
         new_xyz = [xyz_all[l] for l in range(3)]
-        d2_all = (torch.zeros if finite else torch.empty)(sum(nn_rows) * S_ * 3, dtype=torch.float32, device=dev)
+        d2_all = zeros(sum(nn_rows) * S_ * 3, torch.float32, dev) if finite else torch.empty(sum(nn_rows) * S_ * 3, dtype=torch.float32, device=dev)
         d2_parts = torch.split(d2_all, [S_ * r * 3 for r in nn_rows])
         B = knn_frames
         self.knn = [torch.empty(B, n, 16, dtype=torch.int64, device=dev) for _ in range(2)] if B else None

@@ -151,6 +151,14 @@ def _zeros(shape, dtype, device):
     return torch.zeros(shape, dtype=dtype, device=device)
 
 
+def arena_zeros(n, dtype, device):
+    """Zero-initialised 1-D workspace of a 4- or 8-byte dtype from the step arena (torch.zeros outside a training step)."""
+    if dtype in (torch.float32, torch.float64):
+        return _zeros((n,), dtype, device)
+    assert dtype in (torch.int32,), dtype
+    return _zeros((n,), torch.float32, device).view(dtype)
+
+
 def _ptr(t):
     return t.data_ptr() if t is not None else None
 

@@ -113,7 +113,9 @@ class TrainGeometry:
                 group_inverse_index_multi(S_, jobs)
             geo._record("inv", side)
 
-        geo = fused.Geometry(xyz, npoint, side=side, knn_frames=0, finite=True, n_valid=n_valid, level_hook=level_tables, tail_hook=tail_tables)
+        from .train_ops import arena_zeros
+        geo = fused.Geometry(xyz, npoint, side=side, knn_frames=0, finite=True, n_valid=n_valid, level_hook=level_tables, tail_hook=tail_tables,
+                             zeros=arena_zeros)
         self.events, self.side = geo.events, side
         self.l3_xyz = geo.xyz[3]
         self._geo = geo                                            # keeps the tables' inputs alive until the side stream is joined
