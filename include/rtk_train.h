@@ -86,6 +86,13 @@ RTK_EXPORT int rtk_bn_relu_bwd_apply(int samples, int channels, int rows, int ns
                                      const float *dy, const float *par, const float *row_weight, const double *sums2,
                                      double count, const double *group_counts, int pool, float *dz, float *dgamma_dbeta, rtk_stream_t stream);
 
+/* Both backward passes in ONE launch for per-point layers (ns = 1; z, dy, dz (samples, C, positions), positions % 4 == 0, at most
+ * 65536 elements per channel): one workgroup owns a channel, sums it, then applies -- no float64 sums buffer, no second launch.
+ * dgamma_dbeta (2, C) as rtk_bn_relu_bwd_apply; row_weight (samples, positions) or NULL; count / group_counts as there. */
+RTK_EXPORT int rtk_bn_relu_bwd_small(int samples, int channels, int positions, int groups, const float *z, const float *dy, const float *par,
+                                     const float *row_weight, double count, const double *group_counts, float *dz, float *dgamma_dbeta,
+                                     rtk_stream_t stream);
+
 /* First layer of a set-abstraction SharedMLP from the per-point projection (conv([d_xyz || feats[idx]]) =
  * Wx.d_xyz + (Wf.feats)[idx]):  z[b][c][row][k] = proj[b][c][idx[b][row][k]] + wx[c] . dxyz[b][:, row, k], and the weighted
  * batch sums of z accumulated into sums (groups, C, 2) float64 (zero-initialised; as rtk_bn_train_stats).

@@ -449,6 +449,77 @@ __global__ __launch_bounds__(BN_T) void bn_relu_bwd_apply_small_kernel(int sampl
     }
 }
 
+// ---- per-point layers: BatchNorm + ReLU backward in ONE kernel -------------------------------------------------------------------
+// The two passes need the batch sums between them -- a grid-wide dependency, hence two launches (statistics, apply) in general.  A
+// per-point layer's channel, however, is small (samples x E <= 64 Ki elements): ONE workgroup takes a whole channel -- all samples of
+// group 0, then group 1, ... --, sums it (first pass), and applies (second pass; the re-read comes out of L2).  Same arithmetic as
+// bn_relu_bwd_stats_small_kernel + bn_relu_bwd_apply_small_kernel except for the order of the float64 sums.
+constexpr int BF_T = 1024;
+__global__ __launch_bounds__(BF_T) void bn_relu_bwd_fused_small_kernel(int samples, int channels, int E, int groups, const float *__restrict__ z,
+                                                                       const float *__restrict__ dy, const float *__restrict__ par,
+                                                                       const float *__restrict__ rw, double count0, const double *__restrict__ gcnt,
+                                                                       float *__restrict__ dz, float *__restrict__ dgb) {
+    __shared__ double s_red[2][BF_T / 64];
+    __shared__ float s_c[2];
+    const int c = blockIdx.x, t = threadIdx.x, per_group = samples / groups, E4 = E >> 2;
+    const size_t GC = (size_t)groups * channels;
+    double dg_all = 0.0, db_all = 0.0;
+    for (int g = 0; g < groups; ++g) {
+        const size_t o = (size_t)g * channels + c;
+        const float mean = par[o], rstd = par[GC + o], sc = par[2 * GC + o], sh = par[3 * GC + o];
+        const int n4 = per_group * E4;                              // float4 elements of this group's part of the channel
+        double s = 0.0, sx = 0.0;
+        for (int i = t; i < n4; i += BF_T) {
+            const int b = g * per_group + i / E4, e4 = i - (i / E4) * E4;
+            const size_t base = ((size_t)b * channels + c) * E + 4 * e4;
+            const float4 v = *reinterpret_cast<const float4 *>(z + base), d = *reinterpret_cast<const float4 *>(dy + base);
+            const float zz[4] = {v.x, v.y, v.z, v.w}, dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float di = __fmaf_rn(zz[k], sc, sh) > 0.f ? dd[k] : 0.f;
+                s += (double)di;
+                sx += (double)di * (double)((zz[k] - mean) * rstd);
+            }
+        }
+        s = wave_sum_f64(s);
+        sx = wave_sum_f64(sx);
+        __syncthreads();                                            // (the previous group's constants have been read)
+        if ((t & 63) == 0) { s_red[0][t >> 6] = s; s_red[1][t >> 6] = sx; }
+        __syncthreads();
+        if (t == 0) {
+            double a = 0.0, b2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < BF_T / 64; ++i) { a += s_red[0][i]; b2 += s_red[1][i]; }
+            const double count = rtk_group_count(count0, gcnt, g);
+            s_c[0] = (float)(a / count);
+            s_c[1] = (float)(b2 / count);
+            db_all += a;
+            dg_all += b2;
+        }
+        __syncthreads();
+        const float c1 = s_c[0], c2 = s_c[1];
+        for (int i = t; i < n4; i += BF_T) {
+            const int b = g * per_group + i / E4, e4 = i - (i / E4) * E4;
+            const size_t base = ((size_t)b * channels + c) * E + 4 * e4;
+            const float4 v = *reinterpret_cast<const float4 *>(z + base), d = *reinterpret_cast<const float4 *>(dy + base);
+            float4 w4 = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (rw) w4 = *reinterpret_cast<const float4 *>(rw + (size_t)b * E + 4 * e4);      // ns = 1: one weight per element
+            auto one = [&](float zi, float di, float wi) -> float {
+                const bool on = __fmaf_rn(zi, sc, sh) > 0.f;
+                const float xh = (zi - mean) * rstd;
+                return sc * ((on ? di : 0.f) - wi * (c1 + xh * c2));
+            };
+            float4 r;
+            r.x = one(v.x, d.x, w4.x); r.y = one(v.y, d.y, w4.y); r.z = one(v.z, d.z, w4.z); r.w = one(v.w, d.w, w4.w);
+            *reinterpret_cast<float4 *>(dz + base) = r;
+        }
+    }
+    if (t == 0 && dgb) {                                            // parameter gradients: sums over the groups
+        dgb[c] = (float)dg_all;
+        dgb[channels + c] = (float)db_all;
+    }
+}
+
 // ---- backward, pass 2 -------------------------------------------------------------------------------------------------
 struct BwdCoef {
     float mean, rstd, sc, sh, c1, c2;
@@ -657,6 +728,21 @@ extern "C" int rtk_bn_relu_bwd_apply(int samples, int channels, int rows, int ns
                                                        count, group_counts, dz, dgamma_dbeta);
     }
     RTK_CHECK_LAUNCH("rtk_bn_relu_bwd_apply");
+    return RTK_OK;
+}
+
+extern "C" int rtk_bn_relu_bwd_small(int samples, int channels, int positions, int groups, const float *z, const float *dy, const float *par,
+                                     const float *row_weight, double count, const double *group_counts, float *dz, float *dgamma_dbeta,
+                                     rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && channels > 0 && positions > 0 && (positions & 3) == 0 && groups > 0 && samples % groups == 0 && z && dy && par && dz,
+                "rtk_bn_relu_bwd_small: bad arguments (positions %% 4 == 0)");
+    RTK_REQUIRE((long)samples * positions <= 65536, "rtk_bn_relu_bwd_small: %d x %d elements per channel (at most 65536: use the two-pass kernels)",
+                samples, positions);
+    RTK_REQUIRE(((size_t)z & 15) == 0 && ((size_t)dy & 15) == 0 && ((size_t)dz & 15) == 0 && (!row_weight || ((size_t)row_weight & 15) == 0),
+                "rtk_bn_relu_bwd_small: tensors must be 16-byte aligned");
+    bn_relu_bwd_fused_small_kernel<<<channels, BF_T, 0, (hipStream_t)stream>>>(samples, channels, positions, groups, z, dy, par, row_weight, count,
+                                                                              group_counts, dz, dgamma_dbeta);
+    RTK_CHECK_LAUNCH("rtk_bn_relu_bwd_small");
     return RTK_OK;
 }
 

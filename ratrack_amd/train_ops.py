@@ -41,6 +41,7 @@ _lib.SIGNATURES.update({
     "rtk_conv_bn_fwd_fin": [_i] * 6 + [_p] * 8 + [_p],
     "rtk_bn_relu_bwd_stats": [_i] * 5 + [_p, _p, _p, _i, _p, _p],
     "rtk_bn_relu_bwd_apply": [_i] * 5 + [_p] * 5 + [_d, _p, _i, _p, _p, _p],
+    "rtk_bn_relu_bwd_small": [_i] * 4 + [_p] * 4 + [_d, _p, _p, _p, _p],
     "rtk_train_point_weights": [_i] * 3 + [_p] * 3 + [_p],
 })
 
@@ -421,12 +422,16 @@ class _PwBnRelu(torch.autograd.Function):
         S_, Co, P = z.shape
         dev = z.device
         dy = dy.contiguous()
-        sums2 = _zeros((STAT_SLOTS, groups, Co, 2), torch.float64, dev)
-        _lib.call("rtk_bn_relu_bwd_stats", S_, Co, P, 1, groups, z.data_ptr(), dy.data_ptr(), par.data_ptr(), 0, sums2.data_ptr(), _stream())
         dz = torch.empty_like(z)
         dgb = torch.empty(2, Co, dtype=torch.float32, device=dev)
-        _lib.call("rtk_bn_relu_bwd_apply", S_, Co, P, 1, groups, z.data_ptr(), dy.data_ptr(), par.data_ptr(), _ptr(row_w), sums2.data_ptr(),
-                  float(count), _ptr(gcounts), 0, dz.data_ptr(), dgb.data_ptr(), _stream())
+        if S_ * P <= 65536 and P % 4 == 0:      # a channel fits one workgroup: statistics and apply in one launch
+            _lib.call("rtk_bn_relu_bwd_small", S_, Co, P, groups, z.data_ptr(), dy.data_ptr(), par.data_ptr(), _ptr(row_w), float(count),
+                      _ptr(gcounts), dz.data_ptr(), dgb.data_ptr(), _stream())
+        else:
+            sums2 = _zeros((STAT_SLOTS, groups, Co, 2), torch.float64, dev)
+            _lib.call("rtk_bn_relu_bwd_stats", S_, Co, P, 1, groups, z.data_ptr(), dy.data_ptr(), par.data_ptr(), 0, sums2.data_ptr(), _stream())
+            _lib.call("rtk_bn_relu_bwd_apply", S_, Co, P, 1, groups, z.data_ptr(), dy.data_ptr(), par.data_ptr(), _ptr(row_w), sums2.data_ptr(),
+                      float(count), _ptr(gcounts), 0, dz.data_ptr(), dgb.data_ptr(), _stream())
         W2 = W.detach().reshape(W.shape[0], -1)
         dW, _, dsrcs, deferred = _pw_backward(ctx.needs_input_grad[4:], srcs, cols, W2, dz, False, owner=ctx.owner)
         return (None if deferred else dW.view_as(W), dgb[0], dgb[1], None) + tuple(dsrcs)
