@@ -85,8 +85,8 @@ __global__ __launch_bounds__(TN_T) void tn_gemm256_split_kernel(const TnParams Q
     // Rows through BUFFER loads: a row at or past m (the tail of the last step, the steps that round a slab up to a multiple of four)
     // is out of the resource's range and reads as zero -- no mask, no clamp, no branch in the pinned schedule of a k-step.
     // The row offset is wave-uniform (kq) and goes into the instruction's scalar offset.
-    const __amdgpu_buffer_rsrc_t RX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, (int)(m * 1024), 0x00020000);
-    const __amdgpu_buffer_rsrc_t RY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Y), 0, (int)(m * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t RX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, (int)(unsigned)(m * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t RY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Y), 0, (int)(unsigned)(m * 1024), 0x00020000);      // (m < 2^22: the byte count fits 32 bits)
     auto gload = [&](const __amdgpu_buffer_rsrc_t &R, int step, f4 (&v)[4]) {
         const unsigned r0 = (unsigned)((step * Q.nslabs + slab) * 16 + 4 * kq);
 #pragma unroll

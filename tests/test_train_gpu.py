@@ -537,7 +537,7 @@ def test_pw_bn_relu_matches_torch(S, P, cins, cout, groups, weighted):
 
 
 @pytest.mark.parametrize("S,C,rows,ns,n_src", [(4, 16, 256, 4, 256), (3, 32, 242, 8, 242), (2, 64, 256, 32, 256), (2, 64, 512, 32, 512),
-                                               (5, 16, 77, 4, 100), (2, 32, 300, 16, 1024)])
+                                               (5, 16, 77, 4, 100), (2, 32, 300, 16, 1024), (8, 16, 256, 8, 256)])
 def test_first_layer_backward_gather_form(S, C, rows, ns, n_src):
     """rtk_group_inverse_index + rtk_sa_first_layer_bwd (scatter turned into a gather, dWx fused) against the LDS-atomic scatter
     kernel + batched GEMM they replace; the inverse table itself against a stable argsort; run-to-run determinism."""
