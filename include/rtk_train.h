@@ -143,6 +143,8 @@ typedef struct {
     const int *idx;
     int *off;
     unsigned short *inv;
+    const int *live;      /* optional (samples) int32 on the device: only positions < live[s] * live_mult of sample s enter the table --  */
+    int live_mult;        /* for rows nothing downstream reads (duplicate centroid rows of a de-duplicated level); NULL: all positions      */
 } rtk_inverse_index_job_t;
 RTK_EXPORT int rtk_group_inverse_index_multi(int samples, int njobs, const rtk_inverse_index_job_t *jobs, rtk_stream_t stream);
 

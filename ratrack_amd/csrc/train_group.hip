@@ -24,12 +24,17 @@ namespace {
 // off (samples, n_src + 1) int32: positions referencing source point q are inv[s][off[q] .. off[q+1]), ascending.
 // II_T threads: at 256 a thread runs a few thousand serial LDS operations and there is only one workgroup per sample
 constexpr int II_T = 1024;
-__device__ __forceinline__ void inverse_index_body(int n_src, int P, const int *__restrict__ idx, int *__restrict__ off,
-                                                   unsigned short *__restrict__ inv, int s) {
+// live (optional): only the first live[s] * live_mult positions of sample s enter the table.  For rows that nothing downstream reads
+// (the duplicate centroid rows of a de-duplicated level: every consumer redirects them to a live row) the gradient is exactly zero,
+// and left in, their positions only lengthen the lists the gather kernels walk.  NOT for the padding rows of level 0: those are
+// referenced directly by the ball tables and do carry gradient.
+__device__ __forceinline__ void inverse_index_body(int n_src, int Pall, const int *__restrict__ idx, int *__restrict__ off,
+                                                   unsigned short *__restrict__ inv, int s, const int *__restrict__ live, int live_mult) {
     extern __shared__ int s_cnt[];                 // [n_src + 1] counts -> offsets, [n_src] cursors
     int *s_cur = s_cnt + n_src + 1;
     const int t = threadIdx.x;
-    const int *id = idx + (size_t)s * P;
+    const int *id = idx + (size_t)s * Pall;
+    const int P = live ? min(Pall, max(0, live[s]) * live_mult) : Pall;      // positions that enter the table
     for (int q = t; q <= n_src; q += II_T) s_cnt[q] = 0;
     __syncthreads();
     for (int p = t; p < P; p += II_T) atomicAdd(&s_cnt[id[p]], 1);
@@ -53,7 +58,7 @@ __device__ __forceinline__ void inverse_index_body(int n_src, int P, const int *
     for (int q = t; q < n_src; q += II_T) s_cur[q] = s_cnt[q];
     for (int q = t; q <= n_src; q += II_T) off[(size_t)s * (n_src + 1) + q] = s_cnt[q];
     __syncthreads();
-    unsigned short *iv = inv + (size_t)s * P;
+    unsigned short *iv = inv + (size_t)s * Pall;
     unsigned short *s_tmp = reinterpret_cast<unsigned short *>(s_cur + n_src);      // [P] the lists as the atomic cursors filled them
     for (int p = t; p < P; p += II_T) s_tmp[atomicAdd(&s_cur[id[p]], 1)] = (unsigned short)p;
     __syncthreads();
@@ -70,7 +75,7 @@ __device__ __forceinline__ void inverse_index_body(int n_src, int P, const int *
 
 __global__ __launch_bounds__(II_T) void inverse_index_kernel(int n_src, int P, const int *__restrict__ idx, int *__restrict__ off,
                                                             unsigned short *__restrict__ inv) {
-    inverse_index_body(n_src, P, idx, off, inv, blockIdx.x);
+    inverse_index_body(n_src, P, idx, off, inv, blockIdx.x, nullptr, 1);
 }
 
 // Several tables in one launch (blockIdx.y = table): a table is one workgroup per cloud walking serial phases, so at small batches
@@ -82,7 +87,7 @@ struct IIJobs {
 };
 __global__ __launch_bounds__(II_T) void inverse_index_multi_kernel(const IIJobs J) {
     const rtk_inverse_index_job_t &q = J.j[blockIdx.y];
-    inverse_index_body(q.n_src, q.positions, q.idx, q.off, q.inv, blockIdx.x);
+    inverse_index_body(q.n_src, q.positions, q.idx, q.off, q.inv, blockIdx.x, q.live, q.live_mult);
 }
 
 constexpr int FB_MAXQ = 8;      // float4 per thread and plane: planes up to 8192 positions keep their offsets in registers

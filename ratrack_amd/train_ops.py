@@ -47,20 +47,25 @@ _lib.SIGNATURES.update({
 
 
 class _IIJob(ctypes.Structure):          # rtk_inverse_index_job_t (include/rtk_train.h)
-    _fields_ = [("n_src", ctypes.c_int), ("positions", ctypes.c_int), ("idx", ctypes.c_void_p), ("off", ctypes.c_void_p), ("inv", ctypes.c_void_p)]
+    _fields_ = [("n_src", ctypes.c_int), ("positions", ctypes.c_int), ("idx", ctypes.c_void_p), ("off", ctypes.c_void_p), ("inv", ctypes.c_void_p),
+                ("live", ctypes.c_void_p), ("live_mult", ctypes.c_int)]
 
 
 _lib.SIGNATURES.update({"rtk_group_inverse_index_multi": [_i, _i, ctypes.POINTER(_IIJob), _p]})
 
 
 def group_inverse_index_multi(samples, jobs):
-    """jobs: list of (n_src, positions, idx int32 (samples, positions), off int32 (samples, n_src + 1), inv int16 (samples, positions)):
-    all inverse tables in one launch."""
+    """jobs: list of (n_src, positions, idx int32 (samples, positions), off int32 (samples, n_src + 1), inv int16 (samples, positions)
+    [, live int32 (samples) or None, live_mult]): all inverse tables in one launch.  live: only the first live[s] * live_mult positions
+    of sample s enter its table (rows nothing downstream reads: zero gradient)."""
     for lo in range(0, len(jobs), 12):
         part = jobs[lo:lo + 12]
         arr = (_IIJob * len(part))()
-        for k, (n_src, P, idx, off, inv) in enumerate(part):
+        for k, job in enumerate(part):
+            n_src, P, idx, off, inv = job[:5]
+            live, mult = (job[5], job[6]) if len(job) > 5 else (None, 1)
             arr[k].n_src, arr[k].positions, arr[k].idx, arr[k].off, arr[k].inv = n_src, P, idx.data_ptr(), off.data_ptr(), inv.data_ptr()
+            arr[k].live, arr[k].live_mult = _ptr(live), mult
         _lib.call("rtk_group_inverse_index_multi", samples, len(part), arr, _stream())
 
 

@@ -102,7 +102,9 @@ class TrainGeometry:
                           io.data_ptr(), wo.data_ptr(), st())
                 if self.interp_inv[name] is not None:              # the redirected indices point at rows < nuniq <= U
                     off, inv = self.interp_inv[name]
-                    jobs.append((U, 3 * io.shape[1], io, off, inv))
+                    # fp3 / fp2: the unknown rows are level centroids, the duplicate ones (>= nuniq) are read by nothing downstream
+                    # (every consumer redirects them): zero gradient, kept out of the table.  fp1's padding rows are NOT (section 7)
+                    jobs.append((U, 3 * io.shape[1], io, off, inv, nu[u - 1] if u > 0 else None, 3))
             geo._record("interp", side)
             for lvl in range(3):                                   # needed by the backward only
                 for s in range(2):
