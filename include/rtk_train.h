@@ -153,8 +153,11 @@ RTK_EXPORT int rtk_group_inverse_index_multi(int samples, int njobs, const rtk_i
  * reference it, read off the inverse table (off (b, m+1), inv (b, 3n)) that rtk_group_inverse_index builds from the
  * interpolation indices idx (b, n, 3) taken as b lists of 3n positions.  Writes every element (no zero-fill needed), no
  * atomics, deterministic. */
+/* n_valid (b) int32 or NULL: padded clouds -- the unknown points from n_valid[s] on are copies of point 0 (same neighbours and weights):
+ * their gradient is folded into point 0's inside the kernel, and the table must have been built WITHOUT their positions
+ * (rtk_inverse_index_job_t.live = n_valid, live_mult = 3). */
 RTK_EXPORT int rtk_three_interpolate_grad_gather(int b, int c, int n, int m, const float *grad_out, const float *weight, const int *off,
-                                                 const unsigned short *inv, float *grad_points, rtk_stream_t stream);
+                                                 const unsigned short *inv, float *grad_points, const int *n_valid, rtk_stream_t stream);
 RTK_EXPORT int rtk_sa_first_layer_bwd(int samples, int channels, int rows, int ns, int n_src, const float *dz, const float *dxyz,
                                       const int *off, const unsigned short *inv, float *dproj, float *dwx, int dwx_pitch,
                                       rtk_stream_t stream);
@@ -320,8 +323,12 @@ RTK_EXPORT int rtk_patch_cost_bwd(int samples, int n, const float *xyz, const in
  * relu(wc t2 + bc) * dout[i]  over the inverse table (off (samples, n+1), inv (samples, 16n)) that rtk_group_inverse_index
  * builds from the kNN table (as int32, n_src = n, positions = 16 n).  wc (256, 8), bc (256): the live last-layer parameters.
  * Fully written, no atomics, deterministic. */
+/* n_valid (samples) int32 + row0 (samples, 256) workspace, or both NULL: padded clouds -- the query points from n_valid[s] on are
+ * copies of point 0 (same neighbours, same WeightNet output): their dout rows are added to row 0's (into row0, one more small launch)
+ * and the table must have been built WITHOUT their positions (live = n_valid, live_mult = 16). */
 RTK_EXPORT int rtk_patch_dfeat_gather(int samples, int n, const int *off, const unsigned short *inv, const float *t2, const float *wc,
-                                      const float *bc, const float *dout, int dout_pitch, float *dfeat, rtk_stream_t stream);
+                                      const float *bc, const float *dout, int dout_pitch, float *dfeat, const int *n_valid, float *row0,
+                                      rtk_stream_t stream);
 
 /* ---- de-duplicated geometry tables (ratrack_amd/train_path.py) ---------------------------------------------------------
  * rtk_train_group_geometry: for the first `rows` centroids of every sample, idx_out (samples, rows, ns) = ball_idx

@@ -337,15 +337,30 @@ __global__ __launch_bounds__(256, 2) void sa_first_layer_bwd_fast_kernel(int cha
 // at a time with the gradient planes staged in LDS.  The scatter form (one ds_add_f32 per term, ops_pointnet2.hip) runs at
 // ~3 clocks per LANE: LDS float atomics are the slowest instruction of this path (270 us per step for 50 MB of data).
 constexpr int TG_CPB = 8;
+// n_valid (optional): padded clouds.  The unknown points from n_valid[b] on are copies of point 0 -- same neighbours, same weights --,
+// so their gradient is folded into point 0's plane element here and their positions are left out of the table
+// (rtk_inverse_index_job_t.live): sum_p go[p] w[p] over the copies = w[0] sum_p go[p].  Otherwise the three known points they all
+// reference get lists of 60-100 entries next to lists of 3, each walked by one thread.
 __global__ __launch_bounds__(256) void three_interp_grad_gather_kernel(int c, int n, int m, const float *__restrict__ grad_out,
                                                                        const float *__restrict__ weight, const int *__restrict__ off,
-                                                                       const unsigned short *__restrict__ inv, float *__restrict__ grad_points) {
+                                                                       const unsigned short *__restrict__ inv, float *__restrict__ grad_points,
+                                                                       const int *__restrict__ n_valid) {
     extern __shared__ float s_go[];                                // [TG_CPB][n]
     const int bs = blockIdx.y, c0 = blockIdx.x * TG_CPB, tid = threadIdx.x;
     const int nc = min(TG_CPB, c - c0);
     const float *go = grad_out + ((size_t)bs * c + c0) * n;
     for (int e = tid; e < nc * n; e += 256) s_go[e] = go[e];
     __syncthreads();
+    if (n_valid) {                                                 // 32 lanes per channel plane
+        const int nv = n_valid[bs], q = tid >> 5, l = tid & 31;
+        float part = 0.f;
+        if (q < nc)
+            for (int p = nv + l; p < n; p += 32) part += s_go[q * n + p];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        if (q < nc && l == 0 && nv < n) s_go[q * n] += part;
+        __syncthreads();
+    }
     const int *ob = off + (size_t)bs * (m + 1);
     const unsigned short *ib = inv + (size_t)bs * 3 * n;
     const float *wb = weight + (size_t)bs * 3 * n;
@@ -372,10 +387,21 @@ __global__ __launch_bounds__(256) void three_interp_grad_gather_kernel(int c, in
 // activation t2 (8 values, stored by rtk_patch_cost_bwd): 8 multiply-adds per element instead of materialising wn * dout for every
 // position (268 MB at B = 64) and scattering it.  Thread = channel, PG_R destination rows per workgroup, four positions in flight.
 constexpr int PG_R = 8;
+// row0 (optional, (samples, 256)): padded clouds -- the gradient row to use for query point 0: its own plus those of the padding copies
+// of point 0 (same neighbours, same WeightNet output), whose positions are left out of the table (patch_fold_padding_kernel).
+__global__ __launch_bounds__(256) void patch_fold_padding_kernel(int n, const int *__restrict__ n_valid, const float *__restrict__ dout,
+                                                                 int dout_pitch, float *__restrict__ row0) {
+    const int b = blockIdx.x, c = threadIdx.x;
+    const float *db = dout + (size_t)b * n * dout_pitch + c;
+    float a = db[0];
+    for (int i = n_valid[b]; i < n; ++i) a += db[(size_t)i * dout_pitch];
+    row0[(size_t)b * 256 + c] = a;
+}
+
 __global__ __launch_bounds__(256) void patch_dfeat_gather_kernel(int n, const int *__restrict__ off, const unsigned short *__restrict__ inv,
                                                                  const float *__restrict__ t2, const float *__restrict__ wc,
                                                                  const float *__restrict__ bc, const float *__restrict__ dout, int dout_pitch,
-                                                                 float *__restrict__ dfeat) {
+                                                                 float *__restrict__ dfeat, const float *__restrict__ row0) {
     const int b = blockIdx.y, m0 = blockIdx.x * PG_R, c = threadIdx.x;
     float w[8];
 #pragma unroll
@@ -396,7 +422,7 @@ __global__ __launch_bounds__(256) void patch_dfeat_gather_kernel(int n, const in
             for (int k = 0; k < 4; ++k) pos[k] = ib[min(i + k, e - 1)];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                d[k] = db[(size_t)(pos[k] >> 4) * dout_pitch];
+                d[k] = (row0 && (pos[k] >> 4) == 0) ? row0[(size_t)b * 256 + c] : db[(size_t)(pos[k] >> 4) * dout_pitch];
                 ta[k] = *reinterpret_cast<const float4 *>(tb + (size_t)pos[k] * 8);
                 tb4[k] = *reinterpret_cast<const float4 *>(tb + (size_t)pos[k] * 8 + 4);
             }
@@ -486,22 +512,28 @@ extern "C" int rtk_sa_first_layer_bwd(int samples, int channels, int rows, int n
 }
 
 extern "C" int rtk_three_interpolate_grad_gather(int b, int c, int n, int m, const float *grad_out, const float *weight, const int *off,
-                                                 const unsigned short *inv, float *grad_points, rtk_stream_t stream) {
+                                                 const unsigned short *inv, float *grad_points, const int *n_valid, rtk_stream_t stream) {
     RTK_REQUIRE(b > 0 && c > 0 && n > 0 && m > 0 && grad_out && weight && off && inv && grad_points, "three_interpolate_grad_gather: bad arguments");
     RTK_REQUIRE(3 * (long)n <= 65536 && (size_t)TG_CPB * n * sizeof(float) <= 64 * 1024 && b <= 65535,
                 "three_interpolate_grad_gather: %d unknown points exceed the 16-bit table / the LDS planes", n);
     three_interp_grad_gather_kernel<<<dim3((c + TG_CPB - 1) / TG_CPB, b), 256, (size_t)TG_CPB * n * sizeof(float), (hipStream_t)stream>>>(
-        c, n, m, grad_out, weight, off, inv, grad_points);
+        c, n, m, grad_out, weight, off, inv, grad_points, n_valid);
     RTK_CHECK_LAUNCH("three_interpolate_grad_gather");
     return RTK_OK;
 }
 
 extern "C" int rtk_patch_dfeat_gather(int samples, int n, const int *off, const unsigned short *inv, const float *t2, const float *wc,
-                                      const float *bc, const float *dout, int dout_pitch, float *dfeat, rtk_stream_t stream) {
+                                      const float *bc, const float *dout, int dout_pitch, float *dfeat, const int *n_valid, float *row0,
+                                      rtk_stream_t stream) {
+    RTK_REQUIRE(!n_valid == !row0, "patch_dfeat_gather: n_valid and the row-0 workspace go together");
+    if (n_valid) {
+        patch_fold_padding_kernel<<<samples, 256, 0, (hipStream_t)stream>>>(n, n_valid, dout, dout_pitch, row0);
+        RTK_CHECK_LAUNCH("patch_dfeat_gather");
+    }
     RTK_REQUIRE(samples > 0 && n >= 16 && 16 * (long)n <= 65536 && off && inv && t2 && wc && bc && dout && dfeat && dout_pitch >= 256 &&
                 samples <= 65535, "patch_dfeat_gather: bad arguments");
     patch_dfeat_gather_kernel<<<dim3((n + PG_R - 1) / PG_R, samples), 256, 0, (hipStream_t)stream>>>(n, off, inv, t2, wc, bc, dout, dout_pitch,
-                                                                                                     dfeat);
+                                                                                                     dfeat, row0);
     RTK_CHECK_LAUNCH("patch_dfeat_gather");
     return RTK_OK;
 }

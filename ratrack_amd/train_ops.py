@@ -22,7 +22,7 @@ _lib.SIGNATURES.update({
     "rtk_scatter_add_rows": [_i] * 4 + [_p] * 3 + [_p],
     "rtk_sa_first_layer": [_i] * 6 + [_p] * 4 + [_i] + [_p] * 3 + [_p],
     "rtk_group_inverse_index": [_i] * 3 + [_p] * 3 + [_p],
-    "rtk_three_interpolate_grad_gather": [_i] * 4 + [_p] * 5 + [_p],
+    "rtk_three_interpolate_grad_gather": [_i] * 4 + [_p] * 6 + [_p],
     "rtk_sa_first_layer_bwd": [_i] * 5 + [_p] * 6 + [_i, _p],
     "rtk_conv_bn_fwd": [_i] * 6 + [_p] * 7 + [_p],
     "rtk_conv_wgrad": [_i] * 6 + [_p] * 5 + [ctypes.c_long, _p],
@@ -34,7 +34,7 @@ _lib.SIGNATURES.update({
     "rtk_gru_pack_params": [_i, _i, ctypes.POINTER(ctypes.c_void_p)] + [_p] * 6 + [_p],
     "rtk_gru_wgrad": [_i] * 3 + [_p] * 9 + [_p],
     "rtk_patch_cost_bwd": [_i, _i, _p, _p, _p, _i, _LayerP, _p, _p, _i, _p, _p, _p, _p, _p, _p],
-    "rtk_patch_dfeat_gather": [_i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p],
+    "rtk_patch_dfeat_gather": [_i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p],
     "rtk_bn_train_stats": [_i] * 5 + [_p] * 3 + [_p],
     "rtk_bn_relu_fwd": [_i] * 5 + [_p, _p, _i, _p, _p],
     "rtk_bn_relu_fwd_fin": [_i] * 5 + [_p, _p, _p, _i, _p, _p],
@@ -938,11 +938,12 @@ class _PatchCost(torch.autograd.Function):
     kernel rtk_patch_cost, backward = rtk_patch_cost_bwd + the LDS scatter + the WeightNet's small GEMMs."""
 
     @staticmethod
-    def forward(ctx, feat, wa, ba, wb, bb, wc, bc, xyz, knn):
+    def forward(ctx, feat, wa, ba, wb, bb, wc, bc, xyz, knn, live):
         B, n, _ = xyz.shape
         feat = feat.contiguous()
         wn, keep = _weightnet_images(wa, ba, wb, bb, wc, bc)
         ctx.images = (wn, keep, keep[0][5])                         # reused by the backward (keep[0][5] = packed Wc^T)
+        ctx.live = live                                             # (B,) int32 or None: query points past it are padding copies of point 0
         out = torch.empty(B * n, 256, dtype=torch.float32, device=feat.device)
         _lib.call("rtk_patch_cost", B, n, xyz.data_ptr(), knn.data_ptr(), feat.data_ptr(), 256, wn, out.data_ptr(), 256, 0, _stream())
         ctx.save_for_backward(feat, wa, ba, wb, bb, wc, bc, xyz, knn)
@@ -969,22 +970,26 @@ class _PatchCost(torch.autograd.Function):
             k32 = knn.to(torch.int32)
             off = torch.empty(B, n + 1, dtype=torch.int32, device=dev)
             inv = torch.empty(B, 16 * n, dtype=torch.int16, device=dev)
-            _lib.call("rtk_group_inverse_index", B, n, 16 * n, k32.data_ptr(), off.data_ptr(), inv.data_ptr(), _stream())
+            # padded clouds: the padding queries (copies of point 0) stay out of the table, their gradient rows are added to row 0's
+            group_inverse_index_multi(B, [(n, 16 * n, k32, off, inv, ctx.live, 16)])
             wc_, bc_ = wc.detach().reshape(256, 8).contiguous(), bc.detach().contiguous()
+            row0 = torch.empty(B, 256, dtype=torch.float32, device=dev) if ctx.live is not None else None
             _lib.call("rtk_patch_dfeat_gather", B, n, off.data_ptr(), inv.data_ptr(), t2.data_ptr(), wc_.data_ptr(), bc_.data_ptr(),
-                      dout.data_ptr(), 256, dfeat.data_ptr(), _stream())
+                      dout.data_ptr(), 256, dfeat.data_ptr(), _ptr(ctx.live), _ptr(row0), _stream())
         else:
             dxg = torch.empty(M, 256, dtype=torch.float32, device=dev)
             _lib.call("rtk_patch_cost_bwd", B, n, xyz.data_ptr(), knn.data_ptr(), feat.data_ptr(), 256, wn, wct.data_ptr(), dout.data_ptr(),
                       256, dxg.data_ptr(), dq3.data_ptr(), dt2.data_ptr(), d4.data_ptr(), None, _stream())
             _lib.call("rtk_scatter_add_rows", B, n * 16, n, 256, knn.data_ptr(), dxg.data_ptr(), dfeat.data_ptr(), _stream())
-        return (dfeat,) + _weightnet_backward(d4, dq3, dt2, wa, ba, wb, bb, wc) + (None, None)
+        return (dfeat,) + _weightnet_backward(d4, dq3, dt2, wa, ba, wb, bb, wc) + (None, None, None)
 
 
-def patch_cost(feat, wa, ba, wb, bb, wc, bc, xyz, knn):
-    """feat (B*n,256) point-major, WeightNet parameters as in cost_volume, xyz (B,n,3), knn (B,n,16) int64 -> (B*n,256)."""
+def patch_cost(feat, wa, ba, wb, bb, wc, bc, xyz, knn, live=None):
+    """feat (B*n,256) point-major, WeightNet parameters as in cost_volume, xyz (B,n,3), knn (B,n,16) int64 -> (B*n,256).
+    live (B,) int32 on the device: padded clouds -- the query points from live[b] on are copies of point 0 (the backward folds their
+    gradient into point 0's instead of walking their entries in the inverse table)."""
     assert xyz.is_contiguous() and knn.is_contiguous() and knn.dtype == torch.int64
-    return _PatchCost.apply(feat, wa, ba, wb, bb, wc, bc, xyz, knn)
+    return _PatchCost.apply(feat, wa, ba, wb, bb, wc, bc, xyz, knn, live)
 
 
 # ---- 1x1 convolution with a GEMM weight gradient ----------------------------------------------------------------------
@@ -1087,7 +1092,7 @@ class _ThreeInterpolate(torch.autograd.Function):
     inverse table of idx (off (B,M+1), inv (B,3n), rtk_group_inverse_index) instead of scattering with LDS float atomics."""
 
     @staticmethod
-    def forward(ctx, features, idx, weight, off, inv, event):
+    def forward(ctx, features, idx, weight, off, inv, event, n_valid=None):
         from . import pointnet2_hip as _native
         features = features.contiguous()
         B, c, m = features.shape
@@ -1095,7 +1100,7 @@ class _ThreeInterpolate(torch.autograd.Function):
         out = torch.empty((B, c, n), dtype=torch.float32, device=features.device)
         _native.three_interpolate_wrapper(B, c, m, n, features, idx, weight, out)
         ctx.save_for_backward(weight, off, inv)
-        ctx.m, ctx.event = m, event
+        ctx.m, ctx.event, ctx.n_valid = m, event, n_valid
         return out
 
     @staticmethod
@@ -1106,13 +1111,14 @@ class _ThreeInterpolate(torch.autograd.Function):
             torch.cuda.current_stream().wait_event(ctx.event)
         grad = torch.empty((B, c, ctx.m), dtype=torch.float32, device=grad_out.device)
         _lib.call("rtk_three_interpolate_grad_gather", B, c, n, ctx.m, grad_out.contiguous().data_ptr(), weight.data_ptr(), off.data_ptr(),
-                  inv.data_ptr(), grad.data_ptr(), _stream())
-        return grad, None, None, None, None, None
+                  inv.data_ptr(), grad.data_ptr(), _ptr(ctx.n_valid), _stream())
+        return grad, None, None, None, None, None, None
 
 
-def three_interpolate(features, idx, weight, inv_table, event=None):
-    """inv_table = (off, inv) of idx.view(B, 3n) over the M known points."""
-    return _ThreeInterpolate.apply(features, idx, weight, inv_table[0], inv_table[1], event)
+def three_interpolate(features, idx, weight, inv_table, event=None, n_valid=None):
+    """inv_table = (off, inv) of idx.view(B, 3n) over the M known points.  n_valid (B,) int32: padded clouds whose table was built
+    without the padding points' positions (their gradient is folded into point 0's, rtk_three_interpolate_grad_gather)."""
+    return _ThreeInterpolate.apply(features, idx, weight, inv_table[0], inv_table[1], event, n_valid)
 
 
 # ---- multi-task loss -------------------------------------------------------------------------------------------------------------

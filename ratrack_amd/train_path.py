@@ -103,8 +103,10 @@ class TrainGeometry:
                 if self.interp_inv[name] is not None:              # the redirected indices point at rows < nuniq <= U
                     off, inv = self.interp_inv[name]
                     # fp3 / fp2: the unknown rows are level centroids, the duplicate ones (>= nuniq) are read by nothing downstream
-                    # (every consumer redirects them): zero gradient, kept out of the table.  fp1's padding rows are NOT (section 7)
-                    jobs.append((U, 3 * io.shape[1], io, off, inv, nu[u - 1] if u > 0 else None, 3))
+                    # (every consumer redirects them): zero gradient, kept out of the table
+                    # fp1 on padded clouds: the padding points are copies of point 0; their positions stay out as well and the
+                    # backward folds their gradient into point 0's (three_interpolate(..., n_valid))
+                    jobs.append((U, 3 * io.shape[1], io, off, inv, nu[u - 1] if u > 0 else self.n_valid, 3))
             geo._record("interp", side)
             for lvl in range(3):                                   # needed by the backward only
                 for s in range(2):
@@ -203,7 +205,7 @@ def _fp(fp, tg, name, skip, known_feats, row_w, count_rows, groups, group_counts
     table = getattr(tg, "interp_inv", {}).get(name)
     if table is not None and known_feats.shape[2] + 1 == table[0].shape[1]:
         from .train_ops import three_interpolate
-        x = three_interpolate(known_feats, idx, weight, table)
+        x = three_interpolate(known_feats, idx, weight, table, n_valid=tg.n_valid if name == "fp1" else None)
     else:
         x = PU.three_interpolate(known_feats.contiguous(), idx, weight)
     srcs = [x] if skip is None else [x, skip]                      # lib/pointnet2_modules.py:150-153: cat([interpolated, skip])
@@ -272,5 +274,5 @@ def correlator_train(fc, pc1, pc2, feature1, feature2, n_valid1=None, n_valid2=N
     knn = _knn16(x1, x1, n_valid1)
     wn = fc.weightnet2.mlp_convs
     x = patch_cost(x, wn[0].weight.flatten(1), wn[0].bias, wn[1].weight.flatten(1), wn[1].bias, wn[2].weight.flatten(1),
-                   wn[2].bias, x1, knn)
+                   wn[2].bias, x1, knn, live=n_valid1)
     return x.view(B, N1, 256).permute(0, 2, 1)

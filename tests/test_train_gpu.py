@@ -833,7 +833,7 @@ def test_three_interpolate_backward_gather_form(B, C, n, m):
     _lib.call("rtk_group_inverse_index", B, m, 3 * n, idx.data_ptr(), off.data_ptr(), inv.data_ptr(), st)
     a = torch.full((B, C, m), float("nan"), device=DEV)
     b = torch.full((B, C, m), float("nan"), device=DEV)
-    _lib.call("rtk_three_interpolate_grad_gather", B, C, n, m, go.data_ptr(), w.data_ptr(), off.data_ptr(), inv.data_ptr(), a.data_ptr(), st)
+    _lib.call("rtk_three_interpolate_grad_gather", B, C, n, m, go.data_ptr(), w.data_ptr(), off.data_ptr(), inv.data_ptr(), a.data_ptr(), None, st)
     _lib.call("rtk_three_interpolate_grad_set", B, C, n, m, go.data_ptr(), idx.data_ptr(), w.data_ptr(), b.data_ptr(), st)
     ref = torch.zeros(B, C, m, device=DEV, dtype=torch.float64)
     for k in range(3):
@@ -847,6 +847,22 @@ def test_three_interpolate_backward_gather_form(B, C, n, m):
     out = T.three_interpolate(feats, idx, w, (off, inv))
     out.backward(go)
     assert float((feats.grad.double() - ref).abs().max()) <= 1e-5 * max(float(ref.abs().max()), 1.0)
+    # padded clouds: the unknown points from n_valid[b] on are copies of point 0 (same indices, same weights).  The table is built
+    # without their positions and the kernel folds their gradient into point 0's: the same sums as the full scatter.
+    nv = torch.tensor([max(1, n - 7 * (s + 1)) for s in range(B)], dtype=torch.int32, device=DEV)
+    pad = torch.arange(n, device=DEV)[None, :] >= nv[:, None].long()
+    idx_p = torch.where(pad[:, :, None], idx[:, :1], idx).contiguous()
+    w_p = torch.where(pad[:, :, None], w[:, :1], w).contiguous()
+    job = [(m, 3 * n, idx_p, off, inv, nv, 3)]
+    T.group_inverse_index_multi(B, job)
+    assert torch.equal(off[:, -1], 3 * nv)
+    c = torch.full((B, C, m), float("nan"), device=DEV)
+    _lib.call("rtk_three_interpolate_grad_gather", B, C, n, m, go.data_ptr(), w_p.data_ptr(), off.data_ptr(), inv.data_ptr(), c.data_ptr(),
+              nv.data_ptr(), st)
+    ref = torch.zeros(B, C, m, device=DEV, dtype=torch.float64)
+    for k in range(3):
+        ref.scatter_add_(2, idx_p[:, :, k].long().unsqueeze(1).expand(-1, C, -1), (go * w_p[:, :, k].unsqueeze(1)).double())
+    assert float((c.double() - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1.0)
 
 
 def test_cost_volume_split_train_and_backward_agree_with_fp32_mfma_kernels(monkeypatch):
