@@ -163,12 +163,27 @@ __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
     // output blocks 32 + statistics 32.  The backward requests a pass's zprev rows before that pass's MFMAs and every mode
     // requests the next chunk's input at the end of the current one -- nothing is waited for right after issue.
     // output blocks per MFMA pass; the statistics pass (32 accumulator registers more) takes quarter passes and stays at 3 waves/SIMD
-    constexpr int VH = V >= 4 ? (MODE == 1 ? V / 4 : V / 2) : V;
+    constexpr int VH = V >= 4 ? ((MODE == 1 || (POOL && U >= 4)) ? V / 4 : V / 2) : V;      // (quarter passes where the prefetched pooled values need the registers)
     f4 xin[U][4];
+    // ... and with it what else the chunk needs from memory: the rows' weight and, with a pooled source, every channel's (dout, karg) of
+    // the row.  Loaded where they are used (the top of the chunk), each chunk waited a round trip for them before its first MFMA.
+    float wl_in = 1.f, pd_in[POOL ? U : 1][4];
+    int pk_in[POOL ? U : 1][4];
     auto load_in = [&](int chunk, f4 (&dst)[U][4]) {
         int pp = chunk * TC_CHUNK + 4 * j;
         pp = pp < P ? pp : P - 4;         // tail lanes re-read the last valid float4 (unconditional loads: no branch per row);
                                           // their results are never stored and enter no sum
+        wl_in = Q.rw ? Q.rw[(size_t)b * Q.rows + (pp >> Q.lg_ns)] : 1.f;
+        if constexpr (POOL) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t ro = ((size_t)b * 16 * U + 16 * u + 4 * g + r) * Q.rows + (pp >> Q.lg_ns);
+                    pd_in[u][r] = Q.pool_dout[ro];
+                    pk_in[u][r] = (int)Q.pool_karg[ro];
+                }
+        }
         // ONE per-lane byte offset (lane's channel group + position), opaque to the optimiser, added to uniform row pointers:
         // otherwise every one of the 16U + 32V row addresses is hoisted as a loop-invariant 64-bit VGPR pair and spills
         unsigned lo = (unsigned)(4 * g) * pitch + 4u * (unsigned)pp;
@@ -186,7 +201,7 @@ __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
         const bool ok = p < P;                                     // P % 4 == 0: all four or none
         unsigned lane_off = (unsigned)(4 * g) * pitch + 4u * (unsigned)(ok ? p : P - 4);      // see load_in
         asm volatile("" : "+v"(lane_off));
-        const float wl = ok ? (Q.rw ? Q.rw[(size_t)b * Q.rows + (p >> Q.lg_ns)] : 1.f) : 0.f;
+        const float wl = ok ? wl_in : 0.f;
         asm volatile("" ::: "memory");      // re-read the BatchNorm constants from LDS every chunk: hoisted, they pin 4 x 16V registers
 
         // ---- tiles: h[t][u][r] = in[channel 16u + 4g + r][position p + t] (previous BatchNorm + ReLU applied in the forward) ----
@@ -199,9 +214,8 @@ __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
                 if constexpr (POOL) {      // x holds z of the pooled layer: form its dz (the four positions share a row: ns >= 4)
                     const int cc = 16 * u + 4 * g + r;
                     const int pq = ok ? p : P - 4;
-                    const size_t ro = ((size_t)b * 16 * U + cc) * Q.rows + (pq >> Q.lg_ns);
                     const PoolCoef kc = {s_pm[cc], s_pr[cc], s_ps[cc], s_p1[cc], s_p2[cc]};
-                    x = pool_dz(x, kc, Q.pool_dout[ro], (int)Q.pool_karg[ro], pq & ((1 << Q.lg_ns) - 1), wl);
+                    x = pool_dz(x, kc, pd_in[u][r], pk_in[u][r], pq & ((1 << Q.lg_ns) - 1), wl);
                 }
                 if (MODE == 0) {
                     if (has_pre) {
@@ -479,26 +493,36 @@ __global__ __launch_bounds__(TC_T, TS_OCC) void conv_wgrad_stats_kernel(const Tc
     for (int v = 0; v < V; ++v)
 #pragma unroll
         for (int u = 0; u < U; ++u) { accG[v][u] = f4_zero(); accH[v][u] = f4_zero(); }
-    const int ntiles = (P + 15) / 16;
+    // The two contractions run on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16, the C/D layout of the fp32-input 16x16x4): a tile is
+    // 32 positions, lane (g, j) holds EIGHT consecutive positions p0 + 8g .. + 7 of row j of every operand block (two float4 loads,
+    // 128 contiguous bytes per row and tile).  dz and m xhat are taken as three exact bf16 pieces each (split_mfma.h), the mask m is
+    // 0 / 1 -- exact in ONE piece: G = dz m^T is three MFMAs per block, H = dz (m xhat)^T six, against 2 x 8 fp32-input MFMAs of twice
+    // the issue time for the same 32 positions (512 -> 144 cycles per block pair; the splitting is ~45 VALU per operand block).
+    const int ntiles = (P + 31) / 32;
     struct Tile {
-        f4 a[V], x[U];
-        float d[POOL ? V : 1];
-        int k[POOL ? V : 1];
+        f4 a[V][2], x[U][2];
+        float d[POOL ? V : 1][2];
+        int k[POOL ? V : 1][2];
+        float wl[2];      // the rows' weights, requested with the tile (loaded where they are used, each tile waited a round trip for them)
     };
     auto fetch = [&](int t, Tile &T) {
-        const int p = 16 * t + 4 * g;
-        const int pq = p < P ? p : P - 4;
-        const unsigned po = 4u * (unsigned)pq;
 #pragma unroll
-        for (int v = 0; v < V; ++v) T.a[v] = *reinterpret_cast<const f4 *>(dzb + (unsigned)(16 * v + j) * pitch + po);
+        for (int h = 0; h < 2; ++h) {
+            const int p = 32 * t + 8 * g + 4 * h;
+            const int pq = p < P ? p : P - 4;
+            const unsigned po = 4u * (unsigned)pq;
 #pragma unroll
-        for (int u = 0; u < U; ++u) T.x[u] = *reinterpret_cast<const f4 *>(zpb + (unsigned)(16 * u + j) * pitch + po);
-        if constexpr (POOL) {
+            for (int v = 0; v < V; ++v) T.a[v][h] = *reinterpret_cast<const f4 *>(dzb + (unsigned)(16 * v + j) * pitch + po);
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
-                const size_t ro = ((size_t)b * 16 * V + 16 * v + j) * Q.rows + (pq >> Q.lg_ns);
-                T.d[v] = Q.pool_dout[ro];
-                T.k[v] = (int)Q.pool_karg[ro];
+            for (int u = 0; u < U; ++u) T.x[u][h] = *reinterpret_cast<const f4 *>(zpb + (unsigned)(16 * u + j) * pitch + po);
+            if constexpr (POOL) {
+                T.wl[h] = Q.rw ? Q.rw[(size_t)b * Q.rows + (pq >> Q.lg_ns)] : 1.f;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const size_t ro = ((size_t)b * 16 * V + 16 * v + j) * Q.rows + (pq >> Q.lg_ns);
+                    T.d[v][h] = Q.pool_dout[ro];
+                    T.k[v][h] = (int)Q.pool_karg[ro];
+                }
             }
         }
     };
@@ -507,40 +531,53 @@ __global__ __launch_bounds__(TC_T, TS_OCC) void conv_wgrad_stats_kernel(const Tc
     Tile nxt;
     if (t < ntiles) fetch(t, nxt);
     for (; t < ntiles; t += tstep) {
-        const int p = 16 * t + 4 * g;
-        const bool ok = p < P;
-        f4 a[V], bm[U], bx[U];
+        u4v ap[V][3], bm[U], bx[U][3];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            f4 q = nxt.a[v];
-            if constexpr (POOL) {
-                const float wl = Q.rw ? Q.rw[(size_t)b * Q.rows + ((ok ? p : P - 4) >> Q.lg_ns)] : 1.f;
-                q = pool_dz(q, pk[v], nxt.d[v], nxt.k[v], (ok ? p : P - 4) & ((1 << Q.lg_ns) - 1), wl);
+            f4 q[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int p = 32 * t + 8 * g + 4 * h;
+                const bool ok = p < P;
+                q[h] = nxt.a[v][h];
+                if constexpr (POOL) q[h] = pool_dz(q[h], pk[v], nxt.d[v][h], nxt.k[v][h], (ok ? p : P - 4) & ((1 << Q.lg_ns) - 1), nxt.wl[h]);
+                q[h] = ok ? q[h] : f4_zero();
             }
-            a[v] = ok ? q : f4_zero();
+            split3(q[0], q[1], ap[v]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const f4 x = nxt.x[u];
-            f4 m, xh;
-            m.x = __fmaf_rn(x.x, sc[u], sh[u]) > 0.f ? 1.f : 0.f;
-            m.y = __fmaf_rn(x.y, sc[u], sh[u]) > 0.f ? 1.f : 0.f;
-            m.z = __fmaf_rn(x.z, sc[u], sh[u]) > 0.f ? 1.f : 0.f;
-            m.w = __fmaf_rn(x.w, sc[u], sh[u]) > 0.f ? 1.f : 0.f;
-            xh.x = m.x * ((x.x - mu[u]) * rs[u]); xh.y = m.y * ((x.y - mu[u]) * rs[u]);
-            xh.z = m.z * ((x.z - mu[u]) * rs[u]); xh.w = m.w * ((x.w - mu[u]) * rs[u]);
-            bm[u] = m; bx[u] = xh;
+            f4 xh[2];
+            unsigned mb[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f4 x = nxt.x[u][h];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool on = __fmaf_rn(x[e], sc[u], sh[u]) > 0.f;
+                    mb[4 * h + e] = on ? 0x3F80u : 0u;                       // bf16 1.0 / 0
+                    xh[h][e] = on ? (x[e] - mu[u]) * rs[u] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) bm[u][w] = mb[2 * w] | (mb[2 * w + 1] << 16);
+            split3(xh[0], xh[1], bx[u]);
         }
         if (t + tstep < ntiles) fetch(t + tstep, nxt);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int v = 0; v < V; ++v)
 #pragma unroll
-            for (int v = 0; v < V; ++v)
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    accG[v][u] = mfma4(a[v][q], bm[u][q], accG[v][u]);
-                    accH[v][u] = mfma4(a[v][q], bx[u][q], accH[v][u]);
-                }
+            for (int u = 0; u < U; ++u) {
+                accG[v][u] = mfma16_bf(ap[v][2], bm[u], accG[v][u]);
+                accG[v][u] = mfma16_bf(ap[v][1], bm[u], accG[v][u]);
+                accG[v][u] = mfma16_bf(ap[v][0], bm[u], accG[v][u]);
+                accH[v][u] = mfma16_bf(ap[v][2], bx[u][0], accH[v][u]);      // small terms first
+                accH[v][u] = mfma16_bf(ap[v][1], bx[u][1], accH[v][u]);
+                accH[v][u] = mfma16_bf(ap[v][0], bx[u][2], accH[v][u]);
+                accH[v][u] = mfma16_bf(ap[v][1], bx[u][0], accH[v][u]);
+                accH[v][u] = mfma16_bf(ap[v][0], bx[u][1], accH[v][u]);
+                accH[v][u] = mfma16_bf(ap[v][0], bx[u][0], accH[v][u]);
+            }
     }
     // D layout: acc[v][u][r] = out[16v + 4g + r][16u + j]; per-wave LDS images added on the way out, G then H
     float *part = Q.partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * 256 * U * V);
@@ -735,7 +772,7 @@ extern "C" int rtk_conv_wgrad_stats(int samples, int cprev, int cout, int rows, 
     Q.in = dz_or_z; Q.zprev = zprev; Q.pre = pre_par; Q.rw = row_weight; Q.count = count; Q.partial = workspace;
     if (pool) set_pool(Q, pool);
     const int U = cprev / 16, V = cout / 16;
-    const int ntiles = (Q.P + 15) / 16;
+    const int ntiles = (Q.P + 31) / 32;                                  // 32-position tiles (conv_wgrad_stats_kernel)
     RTK_REQUIRE(workspace_floats >= 2L * samples * cprev * cout, "rtk_conv_wgrad_stats: workspace of %ld floats < %ld", workspace_floats,
                 2L * samples * cprev * cout);
     int gx = (ntiles + 3) / 4;                                           // at least one tile per wave ...
