@@ -753,7 +753,10 @@ extern "C" int rtk_sa_first_layer(int samples, int channels, int rows, int ns, i
     RTK_REQUIRE(ns >= 4 && n_src > 0 && n_src <= 16384, "rtk_sa_first_layer: ns (%d) must be >= 4, n_src (%d) <= 16384", ns, n_src);
     RTK_REQUIRE(proj && idx && dxyz && wx && wx_pitch >= 3 && z && sums, "rtk_sa_first_layer: null argument");
     hipStream_t s = (hipStream_t)stream;
-    if (channels % 4 == 0 && (size_t)n_src * 16 <= 64 * 1024)
+    if (channels % 8 == 0 && (size_t)n_src * 32 <= 64 * 1024 && (long)(channels / 8) * samples >= 1024)      // (enough workgroups left)
+        sa_first_layer_kernel<8><<<dim3(channels / 8, samples), BN_T, (size_t)n_src * 32, s>>>(samples, channels, rows, ilog2_exact(ns), groups,
+                                                                                            n_src, proj, idx, dxyz, wx, wx_pitch, row_weight, z, sums);
+    else if (channels % 4 == 0 && (size_t)n_src * 16 <= 64 * 1024)
         sa_first_layer_kernel<4><<<dim3(channels / 4, samples), BN_T, (size_t)n_src * 16, s>>>(samples, channels, rows, ilog2_exact(ns), groups,
                                                                                             n_src, proj, idx, dxyz, wx, wx_pitch, row_weight, z, sums);
     else
