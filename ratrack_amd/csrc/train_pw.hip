@@ -585,11 +585,21 @@ extern "C" int rtk_pw_wgrad_multi(int njobs, const rtk_pw_wgrad_job_t *jobs, flo
         const int n = njobs - j0 < PW_WG_JOBS ? njobs - j0 : PW_WG_JOBS;
         PwWgMulti M = {}, R = {};
         M.n = R.n = n;
-        // about two workgroups per CU for the launch as a whole; the workspace in equal shares
-        const int want = n == 1 ? 512 : (1024 + n - 1) / n;
+        // about four workgroups per CU for the launch as a whole, shared out in proportion to the jobs' work (64 x 64 blocks x position
+        // tiles): with equal shares the launch lasts as long as its largest job on an eighth of the chip.  The workspace in equal shares.
+        double work[PW_WG_JOBS], total = 0.0;
+        for (int k = 0; k < n; ++k) {
+            const rtk_pw_wgrad_job_t &J = jobs[j0 + k];
+            RTK_REQUIRE(J.dz && J.srcs && J.nsrc >= 1 && J.nsrc <= PW_MAXOP, "pw_wgrad: bad arguments");
+            long cin = J.dbias ? 1 : 0;
+            for (int i = 0; i < J.nsrc; ++i) cin += (J.srcs[i].channels + 63) / 64;
+            work[k] = (double)cin * ((J.dz->channels + 63) / 64) * J.samples * ((J.positions + 15) / 16);
+            total += work[k];
+        }
         const long share = workspace ? (workspace_floats / n) & ~4095L : 0;
         int wgs = 0, rblocks = 0, nred = 0;
         for (int k = 0; k < n; ++k) {
+            const int want = n == 1 ? 512 : (int)(1024.0 * work[k] / total) + 1;
             if (int rc = wgrad_job(M.q[k], jobs[j0 + k], want, workspace ? workspace + (size_t)k * share : nullptr, share)) return rc;
             M.first_block[k] = wgs;
             wgs += M.q[k].nchunks * M.q[k].ochunks * M.q[k].splits;
