@@ -91,7 +91,9 @@ RTK_EXPORT int rtk_bn_relu_bwd_apply(int samples, int channels, int rows, int ns
  * dgamma_dbeta (2, C) as rtk_bn_relu_bwd_apply; row_weight (samples, positions) or NULL; count / group_counts as there. */
 RTK_EXPORT int rtk_bn_relu_bwd_small(int samples, int channels, int positions, int groups, const float *z, const float *dy, const float *par,
                                      const float *row_weight, double count, const double *group_counts, float *dz, float *dgamma_dbeta,
-                                     rtk_stream_t stream);
+                                     int split_groups, rtk_stream_t stream);
+/* (split_groups != 0 with groups == 2: one workgroup per (channel, group) instead of per channel; dgamma_dbeta must then be
+ * ZERO-INITIALISED -- the two groups' sums are added to it.) */
 
 /* First layer of a set-abstraction SharedMLP from the per-point projection (conv([d_xyz || feats[idx]]) =
  * Wx.d_xyz + (Wf.feats)[idx]):  z[b][c][row][k] = proj[b][c][idx[b][row][k]] + wx[c] . dxyz[b][:, row, k], and the weighted

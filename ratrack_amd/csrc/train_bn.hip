@@ -464,7 +464,12 @@ __global__ __launch_bounds__(BF_T) void bn_relu_bwd_fused_small_kernel(int sampl
     const int c = blockIdx.x, t = threadIdx.x, per_group = samples / groups, E4 = E >> 2;
     const size_t GC = (size_t)groups * channels;
     double dg_all = 0.0, db_all = 0.0;
-    for (int g = 0; g < groups; ++g) {
+    // gridDim.y == groups: a workgroup per (channel, group) -- twice the workgroups for the two-frame batches, whose channels alone
+    // fill only half the chip; dgamma / dbeta are then ADDED to a zeroed buffer (two commutative float adds per address: deterministic).
+    // (Keeping the group's elements in registers between the two phases -- all loads issued at once, nothing read twice -- was slower:
+    // 11 -> 13-15 us.)
+    const int g_lo = gridDim.y > 1 ? blockIdx.y : 0, g_hi = gridDim.y > 1 ? blockIdx.y + 1 : groups;
+    for (int g = g_lo; g < g_hi; ++g) {
         const size_t o = (size_t)g * channels + c;
         const float mean = par[o], rstd = par[GC + o], sc = par[2 * GC + o], sh = par[3 * GC + o];
         const int n4 = per_group * E4;                              // float4 elements of this group's part of the channel
@@ -515,8 +520,13 @@ __global__ __launch_bounds__(BF_T) void bn_relu_bwd_fused_small_kernel(int sampl
         }
     }
     if (t == 0 && dgb) {                                            // parameter gradients: sums over the groups
-        dgb[c] = (float)dg_all;
-        dgb[channels + c] = (float)db_all;
+        if (gridDim.y > 1) {
+            atomicAdd(dgb + c, (float)dg_all);
+            atomicAdd(dgb + channels + c, (float)db_all);
+        } else {
+            dgb[c] = (float)dg_all;
+            dgb[channels + c] = (float)db_all;
+        }
     }
 }
 
@@ -733,15 +743,17 @@ extern "C" int rtk_bn_relu_bwd_apply(int samples, int channels, int rows, int ns
 
 extern "C" int rtk_bn_relu_bwd_small(int samples, int channels, int positions, int groups, const float *z, const float *dy, const float *par,
                                      const float *row_weight, double count, const double *group_counts, float *dz, float *dgamma_dbeta,
-                                     rtk_stream_t stream) {
+                                     int split_groups, rtk_stream_t stream) {
     RTK_REQUIRE(samples > 0 && channels > 0 && positions > 0 && (positions & 3) == 0 && groups > 0 && samples % groups == 0 && z && dy && par && dz,
                 "rtk_bn_relu_bwd_small: bad arguments (positions %% 4 == 0)");
     RTK_REQUIRE((long)samples * positions <= 65536, "rtk_bn_relu_bwd_small: %d x %d elements per channel (at most 65536: use the two-pass kernels)",
                 samples, positions);
     RTK_REQUIRE(((size_t)z & 15) == 0 && ((size_t)dy & 15) == 0 && ((size_t)dz & 15) == 0 && (!row_weight || ((size_t)row_weight & 15) == 0),
                 "rtk_bn_relu_bwd_small: tensors must be 16-byte aligned");
-    bn_relu_bwd_fused_small_kernel<<<channels, BF_T, 0, (hipStream_t)stream>>>(samples, channels, positions, groups, z, dy, par, row_weight, count,
-                                                                              group_counts, dz, dgamma_dbeta);
+    // two groups: a workgroup per (channel, group); dgamma_dbeta must then arrive ZEROED (the two groups' sums are added to it)
+    const dim3 grid(channels, (groups == 2 && split_groups) ? 2 : 1);
+    bn_relu_bwd_fused_small_kernel<<<grid, BF_T, 0, (hipStream_t)stream>>>(samples, channels, positions, groups, z, dy, par, row_weight, count,
+                                                                          group_counts, dz, dgamma_dbeta);
     RTK_CHECK_LAUNCH("rtk_bn_relu_bwd_small");
     return RTK_OK;
 }

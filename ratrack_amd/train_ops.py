@@ -41,7 +41,7 @@ _lib.SIGNATURES.update({
     "rtk_conv_bn_fwd_fin": [_i] * 6 + [_p] * 8 + [_p],
     "rtk_bn_relu_bwd_stats": [_i] * 5 + [_p, _p, _p, _i, _p, _p],
     "rtk_bn_relu_bwd_apply": [_i] * 5 + [_p] * 5 + [_d, _p, _i, _p, _p, _p],
-    "rtk_bn_relu_bwd_small": [_i] * 4 + [_p] * 4 + [_d, _p, _p, _p, _p],
+    "rtk_bn_relu_bwd_small": [_i] * 4 + [_p] * 4 + [_d, _p, _p, _p, _i, _p],
     "rtk_train_point_weights": [_i] * 3 + [_p] * 3 + [_p],
 })
 
@@ -428,11 +428,13 @@ class _PwBnRelu(torch.autograd.Function):
         dev = z.device
         dy = dy.contiguous()
         dz = torch.empty_like(z)
-        dgb = torch.empty(2, Co, dtype=torch.float32, device=dev)
         if S_ * P <= 65536 and P % 4 == 0:      # a channel fits one workgroup: statistics and apply in one launch
+            split = groups == 2 and Co <= 128      # (two-frame batch: a workgroup per (channel, group), sums added to a zeroed dgb)
+            dgb = _zeros((2, Co), torch.float32, dev) if split else torch.empty(2, Co, dtype=torch.float32, device=dev)
             _lib.call("rtk_bn_relu_bwd_small", S_, Co, P, groups, z.data_ptr(), dy.data_ptr(), par.data_ptr(), _ptr(row_w), float(count),
-                      _ptr(gcounts), dz.data_ptr(), dgb.data_ptr(), _stream())
+                      _ptr(gcounts), dz.data_ptr(), dgb.data_ptr(), int(split), _stream())
         else:
+            dgb = torch.empty(2, Co, dtype=torch.float32, device=dev)
             sums2 = _zeros((STAT_SLOTS, groups, Co, 2), torch.float64, dev)
             _lib.call("rtk_bn_relu_bwd_stats", S_, Co, P, 1, groups, z.data_ptr(), dy.data_ptr(), par.data_ptr(), 0, sums2.data_ptr(), _stream())
             _lib.call("rtk_bn_relu_bwd_apply", S_, Co, P, 1, groups, z.data_ptr(), dy.data_ptr(), par.data_ptr(), _ptr(row_w), sums2.data_ptr(),
