@@ -522,7 +522,7 @@ def test_padded_variable_n_batch():
     net.load_state_dict(reference_state_dict(DEV), strict=True)
     names = ["flow", "h", "cls", "cor", "pc1_features", "pc2_features", "prop"]
     with torch.no_grad():
-        h0 = torch.randn(5, 3, 128, device=DEV) * 0.1
+        h0 = torch.randn(5, 3, 128, device=DEV, generator=torch.Generator(DEV).manual_seed(17)) * 0.1      # (seeded: the comparison is data dependent)
         out = net.backbone(pc1, pc2, f1, f2, h0, n_valid=nv)
         net.use_fused = False
         ref = net.backbone(pc1, pc2, f1, f2, h0, n_valid=nv)                  # per-sample, unpadded, module path
