@@ -482,7 +482,7 @@ extern "C" int rtk_sa_first_layer_bwd(int samples, int channels, int rows, int n
     const size_t lds = (size_t)(P + 4) * sizeof(float) + (size_t)(2 * n_src + 1) * sizeof(int) + (size_t)(P + 256) * sizeof(unsigned short);
     RTK_REQUIRE(P <= 65536 && lds <= 150 * 1024 && samples <= 65535, "sa_first_layer_bwd: %d positions exceed the LDS budget", P);
     hipStream_t st = (hipStream_t)stream;
-    if (P <= 8192 && n_src < 65536 && !getenv("RTK_FB_OLD")) {
+    if (P <= 8192 && n_src < 65536) {
         // planes of up to 8192 positions: the run structure lives in registers, a plane costs little, so more planes per workgroup
         // amortise the per-workgroup setup (index tables, offsets, the walk over the offset table)
         const long planes = (long)channels * samples;

@@ -432,7 +432,8 @@ class Geometry:
         # a buffer dropped at the end of __init__ goes back to the allocator's main-stream pool, whose next tenant (the encoder's first
         # projection) is then written WHILE the selection kernel saves its tie snapshot into the same bytes (round 3: one real frame
         # pair in three runs off by 2e-3, only for clouds with exact duplicate points, only with warm allocator pools)
-        self._scratch = (snap, temp)
+        # ... and so must every other operand a side-stream kernel reads through a raw pointer (the caller's n_valid, the cloud itself)
+        self._scratch = (snap, temp, n_valid, xyz)
 
         main = torch.cuda.current_stream()
         if side is not None:

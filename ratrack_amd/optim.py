@@ -45,7 +45,7 @@ class FusedAdam(torch.optim.Optimizer):
             st["step"] = slot
             st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-        elif st["step"].data_ptr() != slot.data_ptr():
+        elif not torch.is_tensor(st["step"]) or st["step"].data_ptr() != slot.data_ptr():
             # state that came in through load_state_dict (a torch.optim.Adam checkpoint, map_location='cpu', an int64 / float64
             # counter ...): the kernel reads the step through a device pointer -- copy the value into this optimizer's own slot
             slot.copy_(torch.as_tensor(st["step"], dtype=torch.float32).reshape(()))
@@ -86,4 +86,7 @@ class FusedAdam(torch.optim.Optimizer):
         _lib.call("rtk_adam_multi", len(rows), self._table.data_ptr(), self._blocks, lr_ptr, lr_val, float(g["betas"][0]),
                   float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._ticket.data_ptr(),
                   torch.cuda.current_stream().cuda_stream)
+        # the kernel wrote the parameters through raw pointers: bump their version counters, as an in-place torch op would have
+        # (Track4D's folded eval engine watches them; a graph replay re-runs the kernel, not this line -- Trainer drops the engine)
+        torch.autograd.graph.increment_version(live)
         return None

@@ -43,6 +43,7 @@ class Track4D(nn.Module):
         self.associator = A.Associator(self.affinity)
         self._fused = None     # lazily built fused inference engine (ratrack_amd.fused)
         self._fused_version = -1
+        self._fused_tensors = None
         self.use_fused = True
         self.dedup_train = True   # training mode: PNHead on de-duplicated levels with the HIP BatchNorm operators (train_path.py)
 
@@ -59,47 +60,50 @@ class Track4D(nn.Module):
         wants_graph = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (pc1, pc2, feature1, feature2, h))
         if self.use_fused and not self.training and not wants_graph and pc1.is_cuda:
             eng = self._fused_engine()
-            if eng is not None:
-                N1, N2 = pc1.shape[2], pc2.shape[2]
-                if N1 == N2:
-                    return eng.backbone(pc1, pc2, feature1, feature2, h, n_valid=n_valid)
-                # consecutive real frames differ in size: pad the smaller cloud with copies of its point 0 (exact, see
-                # vod_gt.pad_frame_pairs) and cut the outputs back
-                assert n_valid is None, "n_valid batches are already padded to a common size"
-                B, Nm = pc1.shape[0], max(N1, N2)
-                pad = lambda t: t if t.shape[2] == Nm else torch.cat([t, t[:, :, :1].expand(-1, -1, Nm - t.shape[2])], dim=2)
-                nv = torch.tensor([[N1] * B, [N2] * B], dtype=torch.int32, device=pc1.device)
-                flow, h, cls, cor, f1, f2, prop = eng.backbone(pad(pc1), pad(pc2), pad(feature1), pad(feature2), h, n_valid=nv)
-                return (flow[:, :, :N1].contiguous(), h, cls[:, :N1].contiguous(), cor[:, :, :N1].contiguous(),
-                        f1[:, :, :N1].contiguous(), f2[:, :, :N2].contiguous(), prop[:, :, :N1].contiguous())
+            N1, N2 = pc1.shape[2], pc2.shape[2]
+            if N1 == N2:
+                return eng.backbone(pc1, pc2, feature1, feature2, h, n_valid=n_valid)
+            # consecutive real frames differ in size: pad the smaller cloud with copies of its point 0 (exact, see
+            # vod_gt.pad_frame_pairs) and cut the outputs back
+            assert n_valid is None, "n_valid batches are already padded to a common size"
+            B, Nm = pc1.shape[0], max(N1, N2)
+            pad = lambda t: t if t.shape[2] == Nm else torch.cat([t, t[:, :, :1].expand(-1, -1, Nm - t.shape[2])], dim=2)
+            nv = torch.tensor([[N1] * B, [N2] * B], dtype=torch.int32, device=pc1.device)
+            flow, h, cls, cor, f1, f2, prop = eng.backbone(pad(pc1), pad(pc2), pad(feature1), pad(feature2), h, n_valid=nv)
+            return (flow[:, :, :N1].contiguous(), h, cls[:, :N1].contiguous(), cor[:, :, :N1].contiguous(),
+                    f1[:, :, :N1].contiguous(), f2[:, :, :N2].contiguous(), prop[:, :, :N1].contiguous())
         tg1 = nv = None
         cut = None
         if self.training and self.dedup_train and pc1.is_cuda:
             from . import train_path as TP
-            if TP.supported(self.pn_head) and TP.supported(self.fd_layer.mse):
-                # training step: both frames as one stacked batch (per-frame BatchNorm statistics) on de-duplicated levels.
-                # Clouds of different sizes -- every real consecutive pair (dataset_classes/track_vod_3d.py:80-84,119), or a padded
-                # batch with n_valid -- are padded with copies of their own point 0 and travel with their true counts on the
-                # device: same results, gradients and running statistics as the unpadded B = 1 runs (train_path.TrainGeometry)
-                B, N1, N2 = pc1.shape[0], pc1.shape[2], pc2.shape[2]
-                if n_valid is not None:
-                    assert N1 == N2, "n_valid batches are already padded to a common size"
-                    nv = n_valid.to(device=pc1.device, dtype=torch.int32).reshape(2 * B).contiguous()
-                elif N1 != N2:
-                    Nm = max(N1, N2)
-                    pad = lambda t: t if t.shape[2] == Nm else torch.cat([t, t[:, :, :1].expand(-1, -1, Nm - t.shape[2])], dim=2)
-                    nv = torch.cat([torch.full((B,), N1, dtype=torch.int32, device=pc1.device),
-                                    torch.full((B,), N2, dtype=torch.int32, device=pc1.device)])
-                    pc1, pc2, feature1, feature2 = pad(pc1), pad(pc2), pad(feature1), pad(feature2)
-                    cut = (N1, N2)
-                with torch.no_grad():      # (geometry on a forked stream was measured slower inside the captured step: DESIGN.md section 5)
-                    tg = TP.TrainGeometry(torch.cat([pc1, pc2], 0).permute(0, 2, 1).contiguous(), self.pn_head.sa1.npoint, n_valid=nv, groups=2)
-                f = TP.pnhead_train(self.pn_head, tg, torch.cat([feature1, feature2], 0), groups=2)
-                # both frames' [per-point features ; global feature] in one kernel (and one in the backward) instead of max, expand,
-                # cat -- and sum, zero fill, scatter, accumulate -- per frame
-                from .train_ops import gmax_cat
-                pf = gmax_cat(f)
-                (pc1_features, pc2_features), tg1 = pf.view(2, B, pf.shape[1], pf.shape[2]).unbind(0), tg.head(B)
+            if not (TP.supported(self.pn_head) and TP.supported(self.fd_layer.mse) and TP.correlator_supported(self.fc_layer)):
+                # no silent drop to the framework's convolutions: the module path is an explicit choice
+                raise NotImplementedError("Track4D: this layer configuration is outside the hand-written training path (max-pooled MSG "
+                                          "levels of Conv2d(no bias)+BatchNorm2d+ReLU, 3x256-channel correlator without BatchNorm); set "
+                                          "net.dedup_train = False to train it on the module path (PyTorch-ROCm dense layers)")
+            # training step: both frames as one stacked batch (per-frame BatchNorm statistics) on de-duplicated levels.
+            # Clouds of different sizes -- every real consecutive pair (dataset_classes/track_vod_3d.py:80-84,119), or a padded
+            # batch with n_valid -- are padded with copies of their own point 0 and travel with their true counts on the
+            # device: same results, gradients and running statistics as the unpadded B = 1 runs (train_path.TrainGeometry)
+            B, N1, N2 = pc1.shape[0], pc1.shape[2], pc2.shape[2]
+            if n_valid is not None:
+                assert N1 == N2, "n_valid batches are already padded to a common size"
+                nv = n_valid.to(device=pc1.device, dtype=torch.int32).reshape(2 * B).contiguous()
+            elif N1 != N2:
+                Nm = max(N1, N2)
+                pad = lambda t: t if t.shape[2] == Nm else torch.cat([t, t[:, :, :1].expand(-1, -1, Nm - t.shape[2])], dim=2)
+                nv = torch.cat([torch.full((B,), N1, dtype=torch.int32, device=pc1.device),
+                                torch.full((B,), N2, dtype=torch.int32, device=pc1.device)])
+                pc1, pc2, feature1, feature2 = pad(pc1), pad(pc2), pad(feature1), pad(feature2)
+                cut = (N1, N2)
+            with torch.no_grad():      # (geometry on a forked stream was measured slower inside the captured step: DESIGN.md section 5)
+                tg = TP.TrainGeometry(torch.cat([pc1, pc2], 0).permute(0, 2, 1).contiguous(), self.pn_head.sa1.npoint, n_valid=nv, groups=2)
+            f = TP.pnhead_train(self.pn_head, tg, torch.cat([feature1, feature2], 0), groups=2)
+            # both frames' [per-point features ; global feature] in one kernel (and one in the backward) instead of max, expand,
+            # cat -- and sum, zero fill, scatter, accumulate -- per frame
+            from .train_ops import gmax_cat
+            pf = gmax_cat(f)
+            (pc1_features, pc2_features), tg1 = pf.view(2, B, pf.shape[1], pf.shape[2]).unbind(0), tg.head(B)
         if tg1 is None and n_valid is not None:
             return self._backbone_per_sample(pc1, pc2, feature1, feature2, h, n_valid)
         if tg1 is None:
@@ -110,7 +114,7 @@ class Track4D(nn.Module):
             g2 = torch.max(f2, -1)[0].unsqueeze(2).expand(-1, -1, pc2.size(2))
             pc1_features = torch.cat((f1, g1), dim=1)
             pc2_features = torch.cat((f2, g2), dim=1)
-        if tg1 is not None and TP.correlator_supported(self.fc_layer):
+        if tg1 is not None:
             cor_features = TP.correlator_train(self.fc_layer, pc1, pc2, pc1_features, pc2_features,
                                                n_valid1=None if nv is None else nv[:pc1.shape[0]], n_valid2=None if nv is None else nv[pc1.shape[0]:],
                                                xyz=(tg.xyz[:pc1.shape[0]], tg.xyz[pc1.shape[0]:]))
@@ -143,39 +147,46 @@ class Track4D(nn.Module):
         return (rest[0], hs) + tuple(rest[1:])
 
     def _weights_version(self):
-        """Sum of the in-place modification counters of every parameter and buffer: `p.data.mul_(2)`, an optimizer step taken while the
-        model is in eval mode, `running_mean.copy_(...)` ... all bump it, so a stale folded engine is detected without a hook."""
-        return sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers())
+        """Sum of the in-place modification counters of every parameter and buffer the folded engine was built from: `p.data.mul_(2)`,
+        `running_mean.copy_(...)`, a torch optimizer step taken in eval mode ... all bump it, so a stale folded engine is detected
+        without a hook.  The tensor list is cached with the engine (walking the module tree costs 1 ms per call -- more than a B = 64
+        forward; the cached sum costs 35 us) and dropped with it (load_state_dict / train() / .to()).  Writers that go through raw
+        pointers bump the counters themselves: `optim.FusedAdam.step` (rtk_adam_multi) calls
+        `torch.autograd.graph.increment_version` on what it updated; the training BatchNorm kernels only run in train mode, and
+        `train()` drops the engine.  Replacing a Parameter OBJECT (`net.x.weight = nn.Parameter(...)`) is not seen: call
+        `invalidate_fused()`."""
+        ts = self._fused_tensors
+        if ts is None:
+            ts = self._fused_tensors = list(self.parameters()) + list(self.buffers())
+        return sum(t._version for t in ts)
 
     def _fused_engine(self):
-        if self._fused and self._fused_version != self._weights_version():
+        """The folded / packed inference engine (ratrack_amd.fused.FusedBackbone), rebuilt when the weights moved.  There is no
+        fallback: a missing HIP library or fused module raises (the module path is an explicit choice, `use_fused = False`)."""
+        if self._fused is not None and self._fused_version != self._weights_version():
             self._fused = None          # weights were edited in place since the engine folded / packed them
         if self._fused is None:
-            try:
-                from . import fused
-            except ImportError:
-                self._fused = False
-            else:
-                cls = getattr(fused, "FusedBackbone", None)
-                self._fused = cls(self) if cls is not None else False
-                self._fused_version = self._weights_version()
-        return self._fused or None
+            from . import fused
+            self._fused_tensors = None
+            self._fused = fused.FusedBackbone(self)
+            self._fused_version = self._weights_version()
+        return self._fused
 
     def invalidate_fused(self):
         """Call after changing weights (load_state_dict does it automatically)."""
-        self._fused = None
+        self._fused = self._fused_tensors = None
 
     def load_state_dict(self, *a, **k):
-        self._fused = None
+        self._fused = self._fused_tensors = None
         return super().load_state_dict(*a, **k)
 
     def train(self, mode=True):
         if mode:
-            self._fused = None      # folded BN constants go stale once training resumes
+            self._fused = self._fused_tensors = None      # folded BN constants go stale once training resumes
         return super().train(mode)
 
     def _apply(self, fn, *a, **k):
-        self._fused = None          # .to(device) / .float() / .cuda(): the packed weight images belong to the old tensors
+        self._fused = self._fused_tensors = None          # .to(device) / .float() / .cuda(): the packed weight images belong to the old tensors
         return super()._apply(fn, *a, **k)
 
     @property

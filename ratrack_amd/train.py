@@ -75,8 +75,10 @@ class Trainer:
             train_ops.begin_deferred_wgrads()           # the per-point layers queue their weight gradients ...
             try:
                 total.backward(gradient=self._one)      # (a persistent seed: autograd would fill a new ones tensor every step)
-            finally:
-                train_ops.flush_deferred_wgrads()       # ... and they are issued together, eight per launch, and delivered to .grad
+            except BaseException:
+                train_ops.drop_deferred_wgrads()        # a failed backward: nothing is launched on its half-built queue (the
+                raise                                   # original error is the one the caller sees)
+            train_ops.flush_deferred_wgrads()           # ... and they are issued together, eight per launch, and delivered to .grad
             train_ops.arena_end_step(self._dev)
         else:
             total.backward()
@@ -88,6 +90,10 @@ class Trainer:
     def _optimize(self):
         self.reducer.unpack()
         self.opt.step()
+        # a graph replay re-runs the optimizer kernel but not FusedAdam.step's version bump: the folded eval engine goes here
+        inv = getattr(self.model, "invalidate_fused", None)
+        if inv is not None:
+            inv()
 
     def _step(self, *args):
         out = self._forward_backward(*args)

@@ -299,12 +299,24 @@ def _run_wgrad_jobs(jobs):
     _lib.call("rtk_pw_wgrad_multi", len(jobs), arr, ws.data_ptr(), _WGRAD_WS, _stream())
 
 
+def drop_deferred_wgrads():
+    """End the deferral WITHOUT launching (the backward that was filling the queue failed)."""
+    global _DEFERRED
+    _DEFERRED = None
+
+
 def flush_deferred_wgrads():
-    """Issue the queued weight gradients and hand them to their parameters.  Always ends the deferral."""
+    """Issue the queued weight gradients and hand them to their parameters.  Always ends the deferral.
+    The queued gradients bypass autograd's accumulator, so tensor hooks / post-accumulate-grad hooks on those parameters would
+    never fire: refused here rather than silently skipped.  (Queued dz / source tensors stay alive until this call.)"""
     global _DEFERRED
     q, _DEFERRED = _DEFERRED, None
     if not q or not q["jobs"]:
         return
+    for param, _ in q["assign"]:
+        if param._backward_hooks or getattr(param, "_post_accumulate_grad_hooks", None):
+            raise RuntimeError("deferred weight gradients are delivered to .grad directly: gradient hooks on the per-point layers' "
+                               "parameters do not fire (run the backward outside begin_deferred_wgrads() to use hooks)")
     _run_wgrad_jobs(q["jobs"])
     for param, grad in q["assign"]:
         g = grad.view_as(param)
@@ -774,21 +786,30 @@ class _TnJob(ctypes.Structure):          # rtk_tn_job_t (include/rtk_train.h)
 _lib.SIGNATURES.update({"rtk_tn_gemm256_split": [_i, ctypes.POINTER(_TnJob), ctypes.c_long, _p, ctypes.c_long, _p]})
 
 
+TN_MAX_ROWS = (1 << 22) - 16      # rtk_tn_gemm256_split addresses its operands through 32-bit buffer resources: m < 2^22 rows per launch
+
+
 def tn_gemm256(pairs):
     """[(x, y), ...] with x, y (m, 256) fp32 contiguous -> (len(pairs), 256, 256): x^T y of every pair in one launch on the
-    split-bf16 matrix path (rtk_tn_gemm256_split)."""
+    split-bf16 matrix path (rtk_tn_gemm256_split).  More than TN_MAX_ROWS rows (B * N1 * 16 positions: B = 64 at N = 4096) go in
+    row chunks whose products are added."""
     n, m = len(pairs), pairs[0][0].shape[0]
     dev = pairs[0][0].device
-    out = torch.empty(n, 256, 256, dtype=torch.float32, device=dev)
-    jobs = (_TnJob * n)()
-    for k, (x, y) in enumerate(pairs):
+    for x, y in pairs:
         assert x.shape == (m, 256) and y.shape == (m, 256) and x.is_contiguous() and y.is_contiguous() and x.dtype == y.dtype == torch.float32
-        jobs[k].x, jobs[k].y, jobs[k].out, jobs[k].out_pitch = x.data_ptr(), y.data_ptr(), out[k].data_ptr(), 256
-    steps = (m + 15) // 16
-    slabs = max(1, min(256 // n, (steps + 7) // 8))
-    ws = torch.empty(n * slabs * 65536, dtype=torch.float32, device=dev)
-    _lib.call("rtk_tn_gemm256_split", n, jobs, m, ws.data_ptr(), ws.numel(), _stream())
-    return out
+    total = None
+    for r0 in range(0, m, TN_MAX_ROWS):
+        mc = min(TN_MAX_ROWS, m - r0)
+        out = torch.empty(n, 256, 256, dtype=torch.float32, device=dev)
+        jobs = (_TnJob * n)()
+        for k, (x, y) in enumerate(pairs):
+            jobs[k].x, jobs[k].y, jobs[k].out, jobs[k].out_pitch = x[r0:].data_ptr(), y[r0:].data_ptr(), out[k].data_ptr(), 256
+        steps = (mc + 15) // 16
+        slabs = max(1, min(256 // n, (steps + 7) // 8))
+        ws = torch.empty(n * slabs * 65536, dtype=torch.float32, device=dev)
+        _lib.call("rtk_tn_gemm256_split", n, jobs, mc, ws.data_ptr(), ws.numel(), _stream())
+        total = out if total is None else total.add_(out)
+    return total
 
 
 class _CostVolume(torch.autograd.Function):

@@ -818,6 +818,22 @@ def test_position_contraction_on_the_split_path_carries_fp32_accuracy(m):
 
 
 @pytest.mark.gpu
+def test_position_contraction_in_row_chunks(monkeypatch):
+    """More rows than one launch addresses (m >= 2^22: B * N1 * 16 positions at B = 64, N = 4096) go in row chunks whose products are
+    added (round-3 advisor: the backward raised there).  Exercised with a small chunk limit; chunk boundaries off the 16-row step."""
+    from ratrack_amd import train_ops as T
+    g = torch.Generator(DEV).manual_seed(5)
+    m = 40000
+    x, y = torch.randn(m, 256, device=DEV, generator=g), torch.rand(m, 256, device=DEV, generator=g)
+    ref = x.double().t() @ y.double()
+    whole = T.tn_gemm256([(x, y)])[0]
+    monkeypatch.setattr(T, "TN_MAX_ROWS", 16 * 617 + 4)
+    parts = T.tn_gemm256([(x, y)])[0]
+    scale = float(ref.abs().max())
+    assert float((whole - ref).abs().max()) / scale <= 3e-7 and float((parts - ref).abs().max()) / scale <= 3e-7
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,C,n,m", [(3, 13, 77, 50), (4, 128, 256, 256), (2, 64, 1024, 512)])
 def test_three_interpolate_backward_gather_form(B, C, n, m):
     """rtk_three_interpolate_grad_gather over the inverse table of the interpolation indices against the reference-style scatter
