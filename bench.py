@@ -12,7 +12,13 @@ already resident in HBM.  One process per GPU; frame-pairs are independent, so r
 batches with no data-path collective (weak scaling); the timed region is bracketed by a barrier +
 synchronize on both sides and the maximum over ranks is reported.
 
+The timed region is EXACTLY `steps` steps with steps = max(K asked for, the steps 1.5 s take) -- a K = 20 window is 18 ms, which nothing
+outside this process can check; the K-step window itself is reported as `k_step_window`.  NBATCH distinct resident batches rotate
+through the steps (no step re-reads its predecessor's inputs).
+
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  configs             BASELINE.json's other single-GPU forward configurations with the same method: config 2 (B=32, N=256) and
+                      config 5 (B=32, N=1024): ms/step, pairs/s, the dominant kernel alone against the split matrix peak;
   roofline            the dominant kernel (cost_volume_split_kernel) against its matrix peak (dense bf16 / 6 products per fp32
                       product; the fp32-input MFMA kernel it replaced is the tests' comparison implementation); duration measured IN SITU:
                       a second timed region replays the same pipelined workload with the graph split around the kernel,
@@ -23,7 +29,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                       all-reduce + Adam) at the same B, N, with the roofline of ITS dominant kernel (cost_volume_bwd_kernel);
   roofline_irregular  FPS / ball query / three-NN / kNN / gather-scatter gradients: algorithmic bytes / live duration vs 8 TB/s;
   cpu_baseline        the CPU oracle (oracle/track4d_ref.py: C restatement of the native ops + PyTorch-CPU dense layers)
-                      on this box's host cores per SURVEY 8(d): B in {1, 32}, threads in {all, 1, sweep}, median of runs.
+                      on this box's host cores, a bounded sample (~20 s): B=1 x {1, all} threads, B=32 x 32 threads, medians.
 
 `--mode train` makes the train step the headline line instead (same fields).
 """
@@ -48,6 +54,7 @@ BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 # the split path (csrc/split_mfma.h) pays six bf16 MFMA products for one fp32 product: its matrix roofline in fp32-equivalent terms
 SPLIT_PEAK_TFLOPS = BF16_PEAK_TFLOPS / 6.0
 HBM_PEAK_GBS = 8000.0
+NBATCH = 8                    # distinct synthetic batches resident in HBM, rotated through the timed steps
 PMC = {"forward": "r02_pmc_cost_volume.json", "train": "r02_pmc_cost_volume_bwd.json", "irregular": "r02_irregular_hbm.json"}
 
 
@@ -177,10 +184,11 @@ def _cpu_runs(fn, warmups, min_runs, max_runs, budget_s):
     return ts
 
 
-def cpu_baseline(n, budget_s=60.0):
-    """The CPU oracle's backbone forward on this box's host cores, SURVEY 8(d) protocol (2 warm-ups, median of 10 runs) for every
-    reported row: B=1 with all threads and with 1 thread, B=32 with the best of {8, 16, 32} threads (128 oversubscribed threads
-    are not the fastest setting for these small layers)."""
+def cpu_baseline(n, budget_s=20.0):
+    """The CPU oracle's backbone forward on this box's host cores, a BOUNDED sample (about 20 s of CPU work, so that the GPU is what
+    the run spends its time on): B=1 with 1 thread (2 warm-ups, median of 10 runs -- SURVEY 8(d)'s protocol, and the fastest setting on
+    every box measured so far), B=1 with all threads (1 warm-up, median of 5) and B=32 with min(32, cpus) threads (1 warm-up, median of
+    3; 8/16/32 threads measured within 10 % of each other in round 3, all-thread and 1-thread settings 3-10x slower)."""
     from oracle import track4d_ref as R
     from ratrack_amd import synth
     from ratrack_amd.track4d import Args, Track4D
@@ -195,41 +203,28 @@ def cpu_baseline(n, budget_s=60.0):
         data[b] = {k: torch.from_numpy(v) for k, v in d.items() if k != "gt_cls"}
     rows, t_start = [], time.perf_counter()
 
-    def measure(b, threads, warmups, min_runs, max_runs, seconds):
+    def measure(b, threads, warmups, runs):
+        if time.perf_counter() - t_start > budget_s:
+            return
         torch.set_num_threads(threads)
         t = data[b]
         with torch.no_grad():
-            ts = _cpu_runs(lambda: R.backbone(sd, t["pc1"], t["pc2"], t["feature1"], t["feature2"], None), warmups, min_runs, max_runs, seconds)
+            ts = _cpu_runs(lambda: R.backbone(sd, t["pc1"], t["pc2"], t["feature1"], t["feature2"], None), warmups, runs, runs, 0.0)
         med = statistics.median(ts)
         rows.append({"batch": b, "threads": threads, "warmups": warmups, "runs": len(ts), "median_s": round(med, 4),
                      "pairs_per_s": round(b / med, 2)})
-        return b / med
 
     try:
-        # 2 warm-ups, median of >= 10 runs -- for every row reported.  B=1 with all threads and with 1 thread; B=32 with
-        # the winner of a one-run thread sweep (the all-thread and 1-thread settings at B=32 are 3-10x slower than that and are
-        # not reported: they would take most of the run)
-        measure(1, all_threads, 2, 10, 10, 0.0)
-        measure(1, 1, 2, 10, 10, 0.0)
-        probe = {}
-        for th in sorted({8, 16, 32}):
-            if th <= ncpu:
-                torch.set_num_threads(th)
-                t = data[32]
-                with torch.no_grad():
-                    R.backbone(sd, t["pc1"], t["pc2"], t["feature1"], t["feature2"], None)
-                    t0 = time.perf_counter()
-                    R.backbone(sd, t["pc1"], t["pc2"], t["feature1"], t["feature2"], None)
-                    probe[th] = time.perf_counter() - t0
-        if probe:
-            measure(32, min(probe, key=probe.get), 2, 10, 10, 0.0)
+        measure(1, 1, 2, 10)
+        measure(1, all_threads, 1, 5)
+        measure(32, min(32, ncpu), 1, 3)
     finally:
         torch.set_num_threads(all_threads)
     best = max(rows, key=lambda r: r["pairs_per_s"])
     return {"value": best["pairs_per_s"], "unit": "frame-pairs/s", "cores": best["threads"], "kind": "port", "host_cpus": ncpu,
-            "sample": "CPU oracle backbone forward, N=%d: best of (B=1, %d threads), (B=1, 1 thread), (B=32, best of 8/16/32 threads) = B=%d "
-                      "with %d threads; every row: 2 warm-ups, median of %d runs; %.0f s of CPU work in total"
-                      % (n, all_threads, best["batch"], best["threads"], best["runs"], time.perf_counter() - t_start),
+            "sample": "CPU oracle backbone forward, N=%d: best of (B=1, 1 thread), (B=1, %d threads), (B=32, %d threads) = B=%d with %d "
+                      "threads (median of %d runs); %.0f s of CPU work in total"
+                      % (n, all_threads, min(32, ncpu), best["batch"], best["threads"], best["runs"], time.perf_counter() - t_start),
             "runs": rows}
 
 
@@ -276,9 +271,15 @@ def run_train(a, net, d, dev, dist, world, rank, steps, warmup, live_traffic=Non
     broadcast_parameters(net)
     use_graph = not a.no_graph
     tr = Trainer(net, graph=use_graph, graph_collective=a.graph_collective)
-    t = {k: torch.from_numpy(v).to(dev) for k, v in d.items()}
+    ds = d if isinstance(d, (list, tuple)) else [d]      # distinct resident batches, rotated through the steps
+    ts = [{k: torch.from_numpy(v).to(dev) for k, v in x.items()} for x in ds]
     h = torch.zeros(5, a.batch, 128, device=dev)
-    step = lambda: tr.step(t["pc1"], t["pc2"], t["feature1"], t["feature2"], t["gt_warp"], t["gt_cls"], h)
+    rot = {"i": 0}
+
+    def step():
+        t = ts[rot["i"] % len(ts)]
+        rot["i"] += 1
+        return tr.step(t["pc1"], t["pc2"], t["feature1"], t["feature2"], t["gt_warp"], t["gt_cls"], h)
 
     def barrier():
         if dist is not None:
@@ -335,8 +336,8 @@ def run_train(a, net, d, dev, dist, world, rank, steps, warmup, live_traffic=Non
         res = {"ms_per_step": round(ms_step, 3), "pairs_per_s": round(a.batch * world * steps / el, 1), "steps": steps,
                "hipGraph": ("one graph" if world == 1 or not tr.split else "graph | RCCL all-reduce | graph") if use_graph else False,
                "kernels_per_step": kernels,
-               "workload": "Track4D.backbone train step (fwd + multi-task loss + bwd + grad all-reduce + Adam), B=%d x N=%d per GPU"
-                           % (a.batch, a.npoints),
+               "workload": "Track4D.backbone train step (fwd + multi-task loss + bwd + grad all-reduce + Adam), B=%d x N=%d per GPU, %d distinct "
+                           "resident batches in rotation" % (a.batch, a.npoints, len(ts)),
                "allreduce_bytes": tr.reducer.bucket_bytes or 4 * sum(p.numel() for p in net.parameters() if p.requires_grad),
                "allreduce_gradient_bytes": tr.reducer.payload_bytes or 4 * sum(p.numel() for p in net.parameters() if p.grad is not None),
                "allreduce_us": None if ar_us is None else round(ar_us, 1),
@@ -394,6 +395,50 @@ def dry_run(a, world, rank):
         dist.destroy_process_group()
 
 
+def forward_config(net, batch, n, depth, dev, seconds=0.8, case0=3000):
+    """One of BASELINE.json's other single-GPU forward configurations with the headline's method (captured graphs, `depth` batches in
+    flight, NBATCH distinct resident batches in rotation, >= `seconds` timed after 0.3 s of untimed steps), plus its dominant kernel
+    alone between HIP events."""
+    from ratrack_amd import fused, synth
+    hosts = [synth.make_frame_pairs(batch, n, case_id=case0 + i) for i in range(NBATCH)]
+    bs = [tuple(torch.from_numpy(x[k]).to(dev) for k in ("pc1", "pc2", "feature1", "feature2")) for x in hosts]
+    h = torch.zeros(5, batch, 128, device=dev)
+    with torch.no_grad():
+        net.backbone(*bs[0], h)
+        eng = net._fused_engine()
+        pipe = fused.GraphPipeline(eng, (*bs[0], h), depth=depth)
+        i = 0
+
+        def run(steps):
+            nonlocal i
+            for _ in range(steps):
+                i += 1
+                pipe.submit(*bs[i % NBATCH], h)
+            pipe.drain()
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(8)
+        per = (time.perf_counter() - t0) / 8
+        run(max(8, int(0.3 / per)))
+        steps = max(20, int(seconds / per))
+        t0 = time.perf_counter()
+        run(steps)
+        el = time.perf_counter() - t0
+        pipe = None
+        net.backbone(*bs[0], h)      # (eager: the engine's last cost-volume operands)
+        alone = eng.time_dominant_kernel(10)
+        alone_ms = sum(s.elapsed_time(e) for s, e in alone) / len(alone)
+    cv_flops = cost_volume_flops_per_pair(n) * batch
+    pps = batch * steps / el
+    out = {"workload": "Track4D.backbone forward, B=%d x N=%d, %d batches in flight, %d resident batches in rotation" % (batch, n, depth, NBATCH),
+           "steps": steps, "ms_per_step": round(el / steps * 1e3, 4), "pairs_per_s": round(pps, 1),
+           "dominant_kernel": {"kernel": "cost_volume_split_kernel", "alone_ms": round(alone_ms, 4), "flops_per_launch": cv_flops,
+                               "frac_of_split_peak_alone": round(cv_flops / (alone_ms * 1e-3) / 1e12 / SPLIT_PEAK_TFLOPS, 4)}}
+    if n in ALG_BYTES_PER_PAIR:
+        out["hbm_frac_algorithmic"] = round(pps * ALG_BYTES_PER_PAIR[n] / (HBM_PEAK_GBS * 1e9), 5)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def _self_spawn(a):
     """`python bench.py --gpus N` with no launcher: become `python -m torch.distributed.run ... bench.py <same args>`."""
@@ -417,6 +462,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the train-step leg of the default (forward) run")
     ap.add_argument("--no-irregular", action="store_true", help="skip the irregular-op roofline leg")
+    ap.add_argument("--no-configs", action="store_true", help="skip the forward legs of BASELINE's other single-GPU configs (B=32 at N=256 / 1024)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--pipeline", type=int, default=4, help="captured graphs in flight (batch-level pipelining on streams)")
     ap.add_argument("--train-steps", type=int, default=20)
@@ -455,10 +501,18 @@ def main():
     net = Track4D(Args()).to(dev).eval()
     synth.fill_state_dict(net.state_dict())
     net.invalidate_fused()
-    d = synth.make_frame_pairs(a.batch, a.npoints, case_id=1000 + rank)          # every rank its own batch
-    pc1, pc2 = torch.from_numpy(d["pc1"]).to(dev), torch.from_numpy(d["pc2"]).to(dev)
-    f1, f2 = torch.from_numpy(d["feature1"]).to(dev), torch.from_numpy(d["feature2"]).to(dev)
+    # every rank its own batches; NBATCH distinct ones resident in HBM, rotated through the steps so that no step re-reads its
+    # predecessor's inputs (round-3 review: one re-submitted batch stays L2/MALL-hot)
+    hosts = [synth.make_frame_pairs(a.batch, a.npoints, case_id=1000 + rank + 100 * i) for i in range(NBATCH)]
+    d = hosts[0]
+    batches = [tuple(torch.from_numpy(x[k]).to(dev) for k in ("pc1", "pc2", "feature1", "feature2")) for x in hosts]
+    pc1, pc2, f1, f2 = batches[0]
     h = torch.zeros(5, a.batch, 128, device=dev)
+    rot = {"i": 0}
+
+    def next_batch():
+        rot["i"] += 1
+        return batches[rot["i"] % NBATCH]
 
     def finish(res):
         if rank == 0:
@@ -468,7 +522,7 @@ def main():
             dist.destroy_process_group()
 
     if a.mode == "train":
-        tr = run_train(a, net, d, dev, dist, world, rank, a.steps, a.warmup)
+        tr = run_train(a, net, hosts[:4], dev, dist, world, rank, a.steps, a.warmup)
         res = None
         if rank == 0:
             res = {"metric": "radar frame-pairs/sec (train step) at B=%d,N=%d per GPU" % (a.batch, a.npoints), "value": tr["pairs_per_s"],
@@ -547,23 +601,26 @@ def main():
 
         depth = max(1, a.pipeline)
         if a.no_graph:
-            elapsed = timed(lambda: net.backbone(pc1, pc2, f1, f2, h), lambda: None, a.steps, a.warmup, 0.5, "headline")
-            sustained_steps = max(a.steps, int(1.5 / max(elapsed / a.steps, 1e-6)))
-            sustained = timed(lambda: net.backbone(pc1, pc2, f1, f2, h), lambda: None, sustained_steps, 0)
+            step_fn, drain_fn = (lambda: net.backbone(*next_batch(), h)), (lambda: None)
+            kstep = timed(step_fn, drain_fn, a.steps, a.warmup, 0.5, "k_steps")
+            # the headline window: the same region over >= 1.5 s (never fewer than the K steps asked for) -- with the driver's
+            # --steps 20 the K-step window is 18 ms, which no clock outside this process resolves
+            timed_steps = max(a.steps, int(1.5 / max(kstep / a.steps, 1e-6)))
+            elapsed = timed(step_fn, drain_fn, timed_steps, 0, 0.0, "headline")
             eng.kernel_events = events = []
-            insitu = timed(lambda: net.backbone(pc1, pc2, f1, f2, h), lambda: None, a.steps, 2)
+            insitu = timed(step_fn, drain_fn, a.steps, 2)
             eng.kernel_events = None
         else:
             pipe = fused.GraphPipeline(eng, (pc1, pc2, f1, f2, h), depth=depth)
-            elapsed = timed(lambda: pipe.submit(pc1, pc2, f1, f2, h), pipe.drain, a.steps, a.warmup, 0.5, "headline")      # inputs are copied into the slot's static buffers
-            # the same region over >= 1.5 s: with the driver's --steps 20 the headline window is 20 ms -- this one an SMI sampler sees
-            sustained_steps = max(a.steps, int(1.5 / max(elapsed / a.steps, 1e-6)))
-            sustained = timed(lambda: pipe.submit(pc1, pc2, f1, f2, h), pipe.drain, sustained_steps, 0)
+            step_fn = lambda: pipe.submit(*next_batch(), h)      # inputs are copied into the slot's static buffers
+            kstep = timed(step_fn, pipe.drain, a.steps, a.warmup, 0.5, "k_steps")
+            timed_steps = max(a.steps, int(1.5 / max(kstep / a.steps, 1e-6)))
+            elapsed = timed(step_fn, pipe.drain, timed_steps, 0, 0.0, "headline")
             # second timed region, same workload and concurrency, graphs split around the dominant kernel: its duration in situ
             pipe2 = fused.GraphPipeline(eng, (pc1, pc2, f1, f2, h), depth=depth, split_cost_volume=True)
             events = []
             pipe2.set_kernel_events(events)
-            insitu = timed(lambda: pipe2.submit(pc1, pc2, f1, f2, h), pipe2.drain, a.steps, 3)
+            insitu = timed(lambda: pipe2.submit(*next_batch(), h), pipe2.drain, a.steps, 3)
             pipe2.set_kernel_events(None)
         torch.cuda.synchronize()
         events = events[-a.steps:]
@@ -575,7 +632,7 @@ def main():
 
     res = None
     if rank == 0:
-        pairs_per_s = a.batch * world * a.steps / elapsed
+        pairs_per_s = a.batch * world * timed_steps / elapsed
         cv_flops = cost_volume_flops_per_pair(a.npoints) * a.batch
         achieved = cv_flops / (kern_ms * 1e-3) / 1e12
         pm = _pmc("forward", a.batch, a.npoints)
@@ -593,14 +650,16 @@ def main():
             "metric": "radar frame-pairs/sec (backbone forward, eval) at B=%d,N=%d per GPU" % (a.batch, a.npoints),
             "value": round(pairs_per_s, 1),
             "unit": "frame-pairs/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+            "n_gpus": world, "steps": timed_steps, "steps_requested": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / timed_steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "per_rank_ms_per_step": spread.get("headline"),
-            "sustained": {"steps": sustained_steps, "seconds": round(sustained, 3), "ms_per_step": round(sustained / sustained_steps * 1e3, 4),
-                          "value": round(a.batch * world * sustained_steps / sustained, 1),
-                          "what": "the same timed region over >= 1.5 s, right after the headline's K steps"},
+            "timed_region": "EXACTLY `steps` steps between barrier + synchronize, max over ranks; steps = max(K asked for, what 1.5 s take): "
+                            "the K-step window alone is `k_step_window`; %d distinct resident batches rotate through the steps" % NBATCH,
+            "k_step_window": {"steps": a.steps, "ms_per_step": round(kstep / a.steps * 1e3, 4),
+                              "value": round(a.batch * world * a.steps / kstep, 1), "per_rank_ms_per_step": spread.get("k_steps"),
+                              "what": "the first K steps after the warm-up (>= 0.5 s of untimed steps)"},
             "config": {"workload": "Track4D.backbone forward, B=%d frame-pairs x N=%d points per GPU, S=512 centroids, "
                                    "eval-mode BN, random-init weights, hipGraph=%s, batches in flight=%d"
                                    % (a.batch, a.npoints, not a.no_graph, 1 if a.no_graph else depth),
@@ -640,6 +699,15 @@ def main():
                                          if k in exec_by_kernel and v[1] > 0 else {}))
                               for k, v in sorted(by_family.items(), key=lambda kv: -kv[1][1])},
         }
+    # ---- BASELINE.json's other single-GPU forward configurations (config 2: B=32, N=256; config 5: B=32, N=1024) -----------
+    if rank == 0 and world == 1 and not a.no_configs and (a.batch, a.npoints) == (64, 256):
+        res["configs"] = {}
+        for name, (b_, n_) in (("config2_B32_N256", (32, 256)), ("config5_B32_N1024", (32, 1024))):
+            try:
+                pipe = pipe2 = None
+                res["configs"][name] = forward_config(net, b_, n_, depth, dev)
+            except Exception as e:
+                res["configs"][name] = {"error": repr(e)[:300]}
     # ---- train step (config 3; config 4 when world > 1) ---------------------------------------------------------------
     if not a.no_train:
         try:
@@ -650,7 +718,7 @@ def main():
             import gc
             gc.collect()
             torch.cuda.empty_cache()
-            tr = run_train(a, net, d, dev, dist, world, rank, a.train_steps, 5, live_traffic=(live or {}).get("train") if rank == 0 else None)
+            tr = run_train(a, net, hosts[:4], dev, dist, world, rank, a.train_steps, 5, live_traffic=(live or {}).get("train") if rank == 0 else None)
         except Exception as e:                  # never lose the headline over the extra leg
             tr = {"error": repr(e)[:300]}
         if rank == 0:

@@ -1,6 +1,6 @@
-"""GPU: size-independent properties at BASELINE.json's full sizes (the oracle is too slow to run there):
-batch consistency (a sample's result does not depend on its batch neighbours), determinism, the module path
-as a second implementation, the pipelined graph path, and the N=1024 stress configuration."""
+"""GPU: size-independent properties at BASELINE.json's full sizes: batch consistency (a sample's result does not depend on
+its batch neighbours), determinism, the module path as a second implementation, the pipelined graph path, and the N=1024 stress
+configuration.  (The comparison with the CPU oracle at these sizes is tests/test_fullsize_oracle_gpu.py.)"""
 import numpy as np
 import pytest
 import torch
