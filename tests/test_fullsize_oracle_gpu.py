@@ -178,13 +178,20 @@ def test_train_step_matches_oracle_at_full_size():
     for r in sorted(live, key=lambda r: -r[3])[:8]:
         print("   %-50s vs fp32 oracle %.2e | vs float64 %.2e | fp32 oracle vs float64 %.2e" % (r[0], r[2], r[3], r[4]))
     assert len(rows) > 100
+    # Bounds.  At B = 64 the two fp32 evaluations (the oracle's and this path's) differ from float64 by DISCRETE events -- ReLU /
+    # max-pool decisions within rounding of a tie -- and the oracle's own fp32 run is the yardstick for how much that is on this
+    # batch (measured, round 4: this path median 2.2e-4 / 90th percentile 7.6e-4 / max 3.3e-3 from float64, the fp32 oracle
+    # 9.0e-4 / 1.6e-3 / 1.1e-2).  Required: no further from float64 than the reference arithmetic itself, with absolute floors for
+    # batches on which the oracle happens to have no flipped decision.
     for k, zero, e_ref, e_a, fl in rows:
-        assert (e_a <= 1.0 and e_ref <= 1.0) if zero else (e_a <= GRAD_MAX and e_ref <= GRAD_MAX), (k, zero, e_ref, e_a, fl)
-    # no further from the truth than the reference arithmetic itself is, up to a small factor (discrete ReLU / max-pool decisions
-    # within rounding of a tie move both fp32 evaluations by the same kind of amount)
-    assert np.median(e_arb) <= max(GRAD_MEDIAN, 4.0 * np.median(floor)), (np.median(e_arb), np.median(floor))
-    assert np.quantile(e_arb, 0.9) <= max(GRAD_P90, 4.0 * np.quantile(floor, 0.9)), (np.quantile(e_arb, 0.9), np.quantile(floor, 0.9))
+        if zero:
+            assert e_a <= 1.0, (k, "exact-zero gradient carries more than rounding noise", e_a)
+        else:
+            assert e_a <= max(GRAD_MAX, 2.0 * fl), (k, e_ref, e_a, fl)
+    assert np.median(e_arb) <= max(GRAD_MEDIAN, np.median(floor)), (np.median(e_arb), np.median(floor))
+    assert np.quantile(e_arb, 0.9) <= max(GRAD_P90, np.quantile(floor, 0.9)), (np.quantile(e_arb, 0.9), np.quantile(floor, 0.9))
+    assert e_arb.max() <= max(GRAD_MAX, floor.max()), (e_arb.max(), floor.max())
 
 
-# per-tensor bounds at B = 64 (every tensor; median; 90th percentile), as max|a - b| / max|b|
-GRAD_MAX, GRAD_MEDIAN, GRAD_P90 = 1e-2, 1e-3, 3e-3
+# absolute floors of the per-tensor bounds at B = 64 (every tensor; median; 90th percentile), as max|a - b| / max|b| against float64
+GRAD_MAX, GRAD_MEDIAN, GRAD_P90 = 5e-3, 3e-4, 1e-3

@@ -830,7 +830,9 @@ def test_position_contraction_in_row_chunks(monkeypatch):
     monkeypatch.setattr(T, "TN_MAX_ROWS", 16 * 617 + 4)
     parts = T.tn_gemm256([(x, y)])[0]
     scale = float(ref.abs().max())
-    assert float((whole - ref).abs().max()) / scale <= 3e-7 and float((parts - ref).abs().max()) / scale <= 3e-7
+    err_lib = float((x.t() @ y - ref).abs().max()) / scale          # torch's fp32 GEMM as the yardstick
+    assert float((whole - ref).abs().max()) / scale <= max(2.0 * err_lib, 3e-7)
+    assert float((parts - ref).abs().max()) / scale <= max(2.0 * err_lib, 3e-7)
 
 
 @pytest.mark.gpu
