@@ -125,11 +125,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 template <int PPL>
 __device__ __forceinline__ int fps_wave_body(int n, int m, int block, const float *__restrict__ xyz, float *__restrict__ temp,
                                              int *__restrict__ idxs, float *__restrict__ new_xyz, float4 *s_pt, int lane,
-                                             int &tie_out, int settle_from = -1, bool *settled = nullptr, int j_start = 1,
-                                             float *__restrict__ snap = nullptr, int *__restrict__ first_tie = nullptr) {
-    // j_start > 1 (re-levelling): points 0 .. j_start-1 of the cloud are already selected in this order, `temp` holds the
-    // min-distances of that state, idxs / new_xyz [0, j_start) are the caller's.  snap / first_tie (level 1): at the FIRST round
-    // with a tie the min-distance state is saved by cloud index, so that a later level can resume there instead of at round 1.
+                                             int &tie_out, float *__restrict__ snap = nullptr, int *__restrict__ first_tie = nullptr) {
+    // snap / first_tie (optional outputs): at the FIRST round with a tie, that round's number and the min-distance state it started
+    // from, by cloud index.
     const int bits = 31 - __builtin_clz(block);
     const int q = n >> bits, rem = n & (block - 1);
     for (int k = lane; k < n; k += 64)      // coalesced read of the cloud, scattered into tie order
@@ -152,16 +150,12 @@ __device__ __forceinline__ int fps_wave_body(int n, int m, int block, const floa
         t[i] = ok ? __float_as_uint(temp ? temp[__float_as_int(v.w)] : 1e10f) : 0u;
     }
     float4 o = p0;
-    if (j_start > 1) {
-        o = s_pt[fps_index_to_pos(j_start - 1, block, bits, q, rem)];
-    } else if (lane == 0) {
+    if (lane == 0) {
         idxs[0] = 0;
         if (new_xyz) { new_xyz[0] = o.x; new_xyz[1] = o.y; new_xyz[2] = o.z; }
     }
     int tie = 0;            // last round whose maximum was attained by more than one position (0: none)
-    int kmax = j_start - 1; // largest index picked so far
-    bool early = false;
-    int j = j_start;
+    int j = 1;
     for (; j < m; ++j) {
         const f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
         unsigned mloc = 0u;
@@ -210,14 +204,7 @@ __device__ __forceinline__ int fps_wave_body(int n, int m, int block, const floa
             idxs[j] = __float_as_int(o.w);
             if (new_xyz) { new_xyz[j * 3 + 0] = o.x; new_xyz[j * 3 + 1] = o.y; new_xyz[j * 3 + 2] = o.z; }
         }
-        if (settle_from >= 0) {                   // re-levelling run (see fps_relevel_kernel): selected SET == {0..j} past the last tie
-            const int k = __float_as_int(o.w);
-            kmax = k > kmax ? k : kmax;
-            if (j >= settle_from && kmax <= j) { early = true; ++j; break; }
-        }
     }
-    if (settled) *settled = early;
-    if (early) { tie_out = tie; return j; }       // the caller completes the run as the identity from round j on
     for (int jj = j + lane; jj < m; jj += 64) {
         idxs[jj] = 0;
         if (new_xyz) { new_xyz[jj * 3 + 0] = p0.x; new_xyz[jj * 3 + 1] = p0.y; new_xyz[jj * 3 + 2] = p0.z; }
@@ -238,11 +225,27 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, c
                                                       float *__restrict__ temp, int *__restrict__ idxs,
                                                       float *__restrict__ new_xyz, int *__restrict__ nuniq,
                                                       int *__restrict__ tie, const int *__restrict__ nvalid,
-                                                      float *__restrict__ snap, int *__restrict__ first_tie) {
+                                                      float *__restrict__ snap, int *__restrict__ first_tie,
+                                                      const int *__restrict__ tie_prev, const int *__restrict__ nuniq_prev) {
     extern __shared__ __attribute__((aligned(16))) float4 s_pt[];   // (x, y, z, bits(k)) by position
     const int b = blockIdx.x;
     int tied;
     const int pitch = n;
+    if (tie_prev && tie_prev[b] == 0) {
+        // Re-levelling (rtk_fps_relevel; n == m): the previous level's selection of this cloud had no tie, so this level is the
+        // identity on the coordinates (proof at rtk_fps_relevel) -- idx = (0 .. U-1, 0, 0, ...), new_xyz = xyz, no tie.
+        const int lane = (int)threadIdx.x, nu = nuniq_prev[b];
+        const float *src = xyz + (size_t)b * m * 3;
+        int *io = idxs + (size_t)b * m;
+        float *xo = new_xyz + (size_t)b * m * 3;
+        for (int jj = lane; jj < m; jj += 64) io[jj] = jj < nu ? jj : 0;
+        for (int jj = lane; jj < 3 * m; jj += 64) xo[jj] = src[jj];
+        if (lane == 0) {
+            nuniq[b] = nu;
+            if (tie) tie[b] = 0;
+        }
+        return;
+    }
     if (nvalid) {     // padded batch: this sample's cloud is its first nvalid[b] points; the tie rule follows ITS size
         n = nvalid[b] < n ? nvalid[b] : n;
         n = n < 1 ? 1 : n;
@@ -251,8 +254,7 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, c
     }
     const int j = fps_wave_body<PPL>(n, m, block, xyz + (size_t)b * pitch * 3, temp ? temp + (size_t)b * pitch : nullptr,
                                      idxs + (size_t)b * m, new_xyz ? new_xyz + (size_t)b * m * 3 : nullptr, s_pt,
-                                     (int)threadIdx.x, tied, -1, nullptr, 1, snap ? snap + (size_t)b * pitch : nullptr,
-                                     first_tie ? first_tie + b : nullptr);
+                                     (int)threadIdx.x, tied, snap ? snap + (size_t)b * pitch : nullptr, first_tie ? first_tie + b : nullptr);
     if (threadIdx.x == 0) {
         if (nuniq) nuniq[b] = j;
         if (tie) tie[b] = tied;
@@ -260,81 +262,22 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, c
 }
 
 // Levels 2.. of a PNHead: furthest point sampling of npoint out of the npoint centroids of the previous level
-// (model_utils.py:415-417).  Let P[0..U) be the level-1 selection (then the cloud is exhausted and index 0 repeats) and T the
-// last level-1 round whose maximum was attained by more than one position (tie[b]; 0 = none).
-//   * The running min-distances of a selection depend only on the selected SET.  So if, after some round r >= T, a later
-//     level has selected exactly {P[0..r]}, its min-distances are bit-identical to level 1's after round r (same formula on the
-//     same coordinates); level 1's rounds > r have a UNIQUE maximum, so the level picks P[r+1], P[r+2], ... -- the identity from
-//     round r on, exhaustion included.
-//   * T = 0: the condition holds at r = 0 -- the level is the identity on the coordinates and is only copied:
-//     idx = (0 .. U-1, 0, 0, ...), new_xyz = xyz1.
-//   * T > 0: the reference re-breaks the level-1 ties by the POSITION in the new cloud (bit-reversed), which may differ from
-//     level 1's choice, so the selection runs in full up to the first round r >= T at which the picked indices are exactly
-//     {0..r} (largest picked index <= r), typically T or T+1 (two tied points picked in the other order), and is completed as
-//     the identity.  The next level sees a cloud that agrees with P beyond r and uses r as its T.
-template <int PPL>
-__global__ __launch_bounds__(64) void fps_relevel_kernel(int samples, int npoint, int block, int levels,
-                                                         const float *__restrict__ xyz1, const int *__restrict__ nuniq1,
-                                                         const int *__restrict__ tie, int *__restrict__ idx,
-                                                         float *__restrict__ new_xyz, int *__restrict__ nuniq,
-                                                         const int *__restrict__ idx1, const float *__restrict__ snap1, int snap_pitch,
-                                                         const int *__restrict__ first_tie1, float *__restrict__ scratch) {
-    extern __shared__ __attribute__((aligned(16))) float4 s_pt[];
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const float *src = xyz1 + (size_t)b * npoint * 3;
-    const int nu = nuniq1[b];
-    int T = tie[b];
-    // Resume point: before the FIRST tied round T0 every level repeats level 1 exactly, so a level starts at round T0 from the
-    // min-distance state level 1 saved there (snap1, by level-1 cloud index) instead of re-running T0 - 1 rounds.  The state is a
-    // function of the POINT; it is carried to each level's own cloud through the index lists.
-    int resume = (snap1 && first_tie1 && scratch && T > 0 && T < npoint) ? first_tie1[b] : 0;
-    float *st_a = scratch ? scratch + (size_t)b * 2 * npoint : nullptr, *st_b = st_a ? st_a + npoint : nullptr;
-    if (resume > 1) {       // level 2's cloud P: P[r] = level-1 point idx1[r] (copies of P[0] past U: state 0, as point 0's)
-        const int *i1 = idx1 + (size_t)b * npoint;
-        const float *sn = snap1 + (size_t)b * snap_pitch;
-        for (int r = lane; r < npoint; r += 64) st_a[r] = sn[i1[r]];
-        __syncthreads();
-    }
-    for (int l = 0; l < levels; ++l) {
-        int *io = idx + ((size_t)l * samples + b) * npoint;
-        float *xo = new_xyz + ((size_t)l * samples + b) * npoint * 3;
-        int j0 = 1;                                 // first round completed as the identity
-        if (T > 0) {
-            int tied;
-            bool settled;
-            const int js = resume > 1 ? resume : 1;
-            if (js > 1) {                           // rounds < T0: the identity
-                for (int jj = lane; jj < js; jj += 64) io[jj] = jj;
-                for (int jj = lane; jj < 3 * js; jj += 64) xo[jj] = src[jj];
-            }
-            j0 = fps_wave_body<PPL>(npoint, npoint, block, src, js > 1 ? st_a : nullptr, io, xo, s_pt, lane, tied, T, &settled, js);
-            __syncthreads();      // workgroup-scope fence: this wave's stores are visible to its own next run
-            if (!settled) {       // ran to the end (e.g. no tie information): a full, independent selection
-                if (lane == 0) nuniq[(size_t)l * samples + b] = j0;
-                src = xo;
-                T = npoint;
-                resume = 0;
-                continue;
-            }
-            T = j0 - 1;           // the next level's cloud agrees with P from here on
-        } else if (lane == 0) {
-            io[0] = 0;
-            xo[0] = src[0]; xo[1] = src[1]; xo[2] = src[2];
-        }
-        for (int jj = j0 + lane; jj < npoint; jj += 64) io[jj] = jj < nu ? jj : 0;
-        for (int jj = 3 * j0 + lane; jj < npoint * 3; jj += 64) xo[jj] = src[jj];      // src[jj] == P[jj] (and copies of P[0] past U)
-        if (lane == 0) nuniq[(size_t)l * samples + b] = nu;
-        __syncthreads();
-        if (T > 0) {
-            if (resume > 1 && l + 1 < levels) {     // the saved state, re-indexed for the next level's cloud (= this level's output)
-                for (int r = lane; r < npoint; r += 64) st_b[r] = st_a[io[r]];
-                __syncthreads();
-                float *tmp = st_a; st_a = st_b; st_b = tmp;
-            }
-            src = xo;             // a permuted prefix: the next level selects from this level's output
-        }
-    }
-}
+// (model_utils.py:415-417) -- rtk_fps_relevel.  Let P[0..U) be the previous level's selection (then the cloud is exhausted and
+// index 0 repeats) and T the last round of that selection whose maximum was attained by more than one position (0 = none).
+//   * The running min-distances of a selection depend only on the selected SET.  T = 0: every round of the previous level had a
+//     UNIQUE maximum, the selection did not depend on the tie rule, and the same rounds on the same coordinates pick P[1], P[2], ...
+//     again -- the level is the identity on the coordinates and is only copied (the prologue of fps_wave_kernel):
+//     idx = (0 .. U-1, 0, 0, ...), new_xyz = xyz.
+//   * T > 0: the reference re-breaks the previous level's ties by the POSITION in the new cloud (bit-reversed), which may differ
+//     from the previous choice: the level runs the full selection (fps_wave_kernel, the level-1 kernel) and reports its own T.
+// Rounds 2 and 3 of this build resumed tied clouds at their first tied round from a saved state and stopped as soon as the picked
+// set was a prefix again, in ONE launch (fps_relevel_kernel).  Round 4 found that kernel irreproducible: with another batch's
+// split-bf16 kernels (rtk_pointwise_mlp, rtk_sa_scale_split) resident on the same CU, about one round in 10^4 picked a different --
+// valid, self-consistent -- point (tools/hazard_fps.py; never on an idle GPU, never with a CU to itself, not cured by fences,
+// wait states or any placement of delays, and code-generation dependent: the level-1 kernel, whose round loop is instruction for
+// instruction the same, is untouched by the same stress over 2 x 10^7 rounds until its body is compiled as a separate function).
+// The mechanism is not identified; the kernel is retired, tied clouds pay the full selection per level (2 x 79 us instead of ~23 us
+// for the roughly one cloud in a hundred that has a tie), and tests/test_hazard_gpu.py keeps the stress as a regression test.
 
 // General fallback for n > 2048: one 256-thread workgroup per sample, min-distances in global memory.
 __global__ __launch_bounds__(256) void fps_block_kernel(int n, int m, int block, const float *__restrict__ xyz,
@@ -387,14 +330,15 @@ static int fps_block_size(int n) {  // cuda_utils.h:10-14 (host code in the refe
 }
 
 static int fps_launch(int b, int n, int npoint, const float *xyz, float *temp, int *idx, float *new_xyz, int *nuniq,
-                      int *tie, const int *nvalid, float *snap, int *first_tie, hipStream_t s) {
+                      int *tie, const int *nvalid, float *snap, int *first_tie, hipStream_t s, const int *tie_prev = nullptr,
+                      const int *nuniq_prev = nullptr) {
     const int block = fps_block_size(n);
     RTK_REQUIRE(n / block < 65536, "furthest_point_sampling: n=%d too large", n);
     const size_t lds = (size_t)n * sizeof(float4);
-    if (n <= 64 * 4) fps_wave_kernel<4><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid, snap, first_tie);
-    else if (n <= 64 * 8) fps_wave_kernel<8><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid, snap, first_tie);
-    else if (n <= 64 * 16) fps_wave_kernel<16><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid, snap, first_tie);
-    else if (n <= 64 * 32) fps_wave_kernel<32><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid, snap, first_tie);
+    if (n <= 64 * 4) fps_wave_kernel<4><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid, snap, first_tie, tie_prev, nuniq_prev);
+    else if (n <= 64 * 8) fps_wave_kernel<8><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid, snap, first_tie, tie_prev, nuniq_prev);
+    else if (n <= 64 * 16) fps_wave_kernel<16><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid, snap, first_tie, tie_prev, nuniq_prev);
+    else if (n <= 64 * 32) fps_wave_kernel<32><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid, snap, first_tie, tie_prev, nuniq_prev);
     else return 1;   // caller falls back to the block kernel
     return 0;
 }
@@ -423,19 +367,23 @@ extern "C" int rtk_fps_centroids(int b, int n, int npoint, const float *xyz, int
 }
 
 extern "C" int rtk_fps_relevel(int b, int npoint, int levels, const float *xyz1, const int *nuniq1, const int *tie, int *idx,
-                               float *new_xyz, int *nuniq, const int *idx1, const float *snap1, int snap_pitch, const int *first_tie1,
-                               float *scratch, rtk_stream_t stream) {
+                               float *new_xyz, int *nuniq, int *tie_work, rtk_stream_t stream) {
     RTK_REQUIRE(b > 0 && npoint > 0 && levels > 0 && xyz1 && nuniq1 && tie && idx && new_xyz && nuniq,
                 "fps_relevel: bad arguments (b=%d npoint=%d levels=%d)", b, npoint, levels);
     RTK_REQUIRE(npoint <= 2048, "fps_relevel: npoint=%d > 2048", npoint);
+    RTK_REQUIRE(levels == 1 || tie_work, "fps_relevel: more than one level needs the (levels, b) tie workspace");
     hipStream_t s = (hipStream_t)stream;
-    const int block = fps_block_size(npoint);
-    const size_t lds = (size_t)npoint * sizeof(float4);
-    if (npoint <= 64 * 4) fps_relevel_kernel<4><<<b, 64, lds, s>>>(b, npoint, block, levels, xyz1, nuniq1, tie, idx, new_xyz, nuniq, idx1, snap1, snap_pitch, first_tie1, scratch);
-    else if (npoint <= 64 * 8) fps_relevel_kernel<8><<<b, 64, lds, s>>>(b, npoint, block, levels, xyz1, nuniq1, tie, idx, new_xyz, nuniq, idx1, snap1, snap_pitch, first_tie1, scratch);
-    else if (npoint <= 64 * 16) fps_relevel_kernel<16><<<b, 64, lds, s>>>(b, npoint, block, levels, xyz1, nuniq1, tie, idx, new_xyz, nuniq, idx1, snap1, snap_pitch, first_tie1, scratch);
-    else fps_relevel_kernel<32><<<b, 64, lds, s>>>(b, npoint, block, levels, xyz1, nuniq1, tie, idx, new_xyz, nuniq, idx1, snap1, snap_pitch, first_tie1, scratch);
-    RTK_CHECK_LAUNCH("fps_relevel");
+    const float *src = xyz1;
+    const int *tie_prev = tie, *nuniq_prev = nuniq1;
+    for (int l = 0; l < levels; ++l) {      // one launch per level: untied clouds copy, tied clouds select in full
+        int *tie_out = tie_work ? tie_work + (size_t)l * b : nullptr;
+        float *xo = new_xyz + (size_t)l * b * npoint * 3;
+        const int rc = fps_launch(b, npoint, npoint, src, nullptr, idx + (size_t)l * b * npoint, xo, nuniq + (size_t)l * b, tie_out, nullptr, nullptr,
+                                  nullptr, s, tie_prev, nuniq_prev);
+        RTK_REQUIRE(rc == 0, "fps_relevel: no kernel instance for npoint=%d", npoint);
+        RTK_CHECK_LAUNCH("fps_relevel");
+        src = xo; tie_prev = tie_out; nuniq_prev = nuniq + (size_t)l * b;
+    }
     return RTK_OK;
 }
 

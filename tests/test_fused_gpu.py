@@ -381,8 +381,8 @@ def test_misc_kernels():
 
 
 def test_fps_relevel():
-    """Levels 2/3 (FPS of 512 out of the previous level's 512 centroids): the one-launch rtk_fps_relevel -- copy when the
-    level-1 run had no tie, full selection otherwise -- against (a) the full selection kernel level after level and
+    """Levels 2/3 (FPS of 512 out of the previous level's 512 centroids): rtk_fps_relevel -- per cloud a copy when the
+    previous level had no tie, the full selection otherwise -- against (a) the full selection kernel level after level and
     (b) the CPU oracle, on every fixture cloud, on duplicate-heavy clouds and on lattices with exact distance ties
     between distinct points (where the reference's bit-reversed tie rule makes level 2 differ from level 1)."""
     from _util import EVAL_CASES, inputs_of, load_case
@@ -405,18 +405,17 @@ def test_fps_relevel():
         tie = torch.empty(S_, dtype=torch.int32, device=DEV)
         snap = torch.full((S_, n), float("nan"), device=DEV)
         first = torch.zeros(S_, dtype=torch.int32, device=DEV)
-        scratch = torch.empty(S_, 2 * 512, device=DEV)
         _lib.call("rtk_fps_centroids", S_, n, 512, xyz.data_ptr(), idx.data_ptr(), l1.data_ptr(), c1.data_ptr(), tie.data_ptr(), None,
                   snap.data_ptr(), first.data_ptr(), F._stream())
         assert ((first > 0) == (tie > 0)).all() and (first <= tie).all()
-        for resume in (True, False):          # tied samples resume at their first tied round / start over at round 1
-            idx23 = torch.empty(2, S_, 512, dtype=torch.int32, device=DEV)
-            xyz23 = torch.empty(2, S_, 512, 3, device=DEV)
-            c23 = torch.empty(2, S_, dtype=torch.int32, device=DEV)
-            extra = (idx.data_ptr(), snap.data_ptr(), n, first.data_ptr(), scratch.data_ptr()) if resume else (None, None, 0, None, None)
-            _lib.call("rtk_fps_relevel", S_, 512, 2, l1.data_ptr(), c1.data_ptr(), tie.data_ptr(), idx23.data_ptr(), xyz23.data_ptr(),
-                      c23.data_ptr(), *extra, F._stream())
-            F.check_fps_relevel(l1, idx23, xyz23, c23)
+        idx23 = torch.empty(2, S_, 512, dtype=torch.int32, device=DEV)
+        xyz23 = torch.empty(2, S_, 512, 3, device=DEV)
+        c23 = torch.empty(2, S_, dtype=torch.int32, device=DEV)
+        tie23 = torch.empty(2, S_, dtype=torch.int32, device=DEV)
+        _lib.call("rtk_fps_relevel", S_, 512, 2, l1.data_ptr(), c1.data_ptr(), tie.data_ptr(), idx23.data_ptr(), xyz23.data_ptr(),
+                  c23.data_ptr(), tie23.data_ptr(), F._stream())
+        F.check_fps_relevel(l1, idx23, xyz23, c23)
+        assert (tie23[0][tie == 0] == 0).all()      # an untied level stays untied
         # the CPU oracle, level after level
         src = l1.cpu()
         assert torch.equal(idx.cpu(), P.fps(xyz.cpu(), 512))

@@ -1,10 +1,15 @@
 #!/usr/bin/env python3
-"""Focused reproducer for the non-reproducible re-levelling launch (tools/hazard_stages.py pointed at rtk_fps_relevel):
-level-1 selection + rtk_fps_relevel on stream A, bit-compared with (i) its own first result and (ii) the full selection kernel
-run level after level, while stream B keeps the GPU busy with other kernels.
+"""Focused reproducer for the non-reproducible re-levelling launch that tools/hazard_stages.py pointed at (round 4):
+the geometry launches (level-1 selection + rtk_fps_relevel) on stream A, bit-compared with their own first result and with the
+full selection kernel run level after level, while stream B replays kernels of a recorded backbone pass.
 
-    python tools/hazard_fps.py --iters 3000
-"""
+    python tools/hazard_fps.py --iters 3000                          quiet GPU / FPS noise
+    python tools/hazard_fps.py --iters 1500 --study [--only rtk_pointwise_mlp,rtk_sa_scale_split]
+                                                                      which kernels, as noise, make which launches irreproducible
+
+History: the one-launch resume + settle kernel of rounds 2-3 (fps_relevel_kernel) failed this with rtk_pointwise_mlp or
+rtk_sa_scale_split as noise (2-8 % of the iterations per tied cloud; profiles/r04_hazard_fps_before.txt), the level-1 kernel never
+did; rtk_fps_relevel now runs on the level-1 kernel (csrc/ops_pointnet2.hip)."""
 import argparse
 import os
 import sys
@@ -29,41 +34,34 @@ def run_levels(xyz, npoint, stream, relevel=True):
     idx = torch.zeros(3, S_, npoint, dtype=torch.int32, device=DEV)
     out = torch.empty(3, S_, npoint, 3, dtype=torch.float32, device=DEV)
     cnt = torch.zeros(3, S_, dtype=torch.int32, device=DEV)
-    tie = torch.zeros(S_, dtype=torch.int32, device=DEV)
-    first = torch.zeros(S_, dtype=torch.int32, device=DEV)
-    snap = torch.empty(S_ * n + S_ * 2 * npoint, dtype=torch.float32, device=DEV)
+    tie = torch.zeros(3, S_, dtype=torch.int32, device=DEV)
     if relevel:
-        _lib.call("rtk_fps_centroids", S_, n, npoint, xyz.data_ptr(), idx[0].data_ptr(), out[0].data_ptr(), cnt[0].data_ptr(), tie.data_ptr(), None,
-                  snap.data_ptr(), first.data_ptr(), h)
-        _lib.call("rtk_fps_relevel", S_, npoint, 2, out[0].data_ptr(), cnt[0].data_ptr(), tie.data_ptr(), idx[1].data_ptr(), out[1].data_ptr(),
-                  cnt[1].data_ptr(), idx[0].data_ptr(), snap.data_ptr(), n, first.data_ptr(), snap.data_ptr() + 4 * S_ * n, h)
+        _lib.call("rtk_fps_centroids", S_, n, npoint, xyz.data_ptr(), idx[0].data_ptr(), out[0].data_ptr(), cnt[0].data_ptr(), tie[0].data_ptr(), None,
+                  None, None, h)
+        _lib.call("rtk_fps_relevel", S_, npoint, 2, out[0].data_ptr(), cnt[0].data_ptr(), tie[0].data_ptr(), idx[1].data_ptr(), out[1].data_ptr(),
+                  cnt[1].data_ptr(), tie[1].data_ptr(), h)
     else:
         src, ns = xyz, n
         for l in range(3):
             _lib.call("rtk_fps_centroids", S_, ns, npoint, src.data_ptr(), idx[l].data_ptr(), out[l].data_ptr(), cnt[l].data_ptr(), None, None, None,
                       None, h)
             src, ns = out[l], npoint
-    return idx, out, cnt, (tie, first, snap)
+    return idx, out, cnt, (tie[0], tie[0], None)
 
 
 def relevel_only(ref, npoint, stream, resume=True):
-    """Only the re-levelling launch, on the level-1 results of `ref` (a private copy of the resume state: the launch works in it)."""
+    """Only the re-levelling launches, on the level-1 results of `ref`."""
     idx0, out0, cnt0 = ref[0][0], ref[1][0], ref[2][0]
-    tie, first, snap0 = ref[3]
+    tie = ref[3][0]
     S_ = idx0.shape[0]
-    n = (snap0.numel() - S_ * 2 * npoint) // S_
     h = stream.cuda_stream
     idx = torch.zeros(2, S_, npoint, dtype=torch.int32, device=DEV)
     out = torch.empty(2, S_, npoint, 3, dtype=torch.float32, device=DEV)
     cnt = torch.zeros(2, S_, dtype=torch.int32, device=DEV)
-    snap = snap0.clone()
-    if resume:
-        _lib.call("rtk_fps_relevel", S_, npoint, 2, out0.data_ptr(), cnt0.data_ptr(), tie.data_ptr(), idx.data_ptr(), out.data_ptr(),
-                  cnt.data_ptr(), idx0.data_ptr(), snap.data_ptr(), n, first.data_ptr(), snap.data_ptr() + 4 * S_ * n, h)
-    else:       # every tied level from round 1 (no saved state, no scratch)
-        _lib.call("rtk_fps_relevel", S_, npoint, 2, out0.data_ptr(), cnt0.data_ptr(), tie.data_ptr(), idx.data_ptr(), out.data_ptr(),
-                  cnt.data_ptr(), None, None, 0, None, None, h)
-    return idx, out, cnt, snap
+    tie23 = torch.zeros(2, S_, dtype=torch.int32, device=DEV)
+    _lib.call("rtk_fps_relevel", S_, npoint, 2, out0.data_ptr(), cnt0.data_ptr(), tie.data_ptr(), idx.data_ptr(), out.data_ptr(),
+              cnt.data_ptr(), tie23.data_ptr(), h)
+    return idx, out, cnt, None
 
 
 DUMPS = [0]
@@ -133,7 +131,7 @@ def main():
     ap.add_argument("--iters", type=int, default=3000)
     ap.add_argument("--study", action="store_true")
     ap.add_argument("--only", default="")
-    ap.add_argument("--victims", default="relevel no resume")
+    ap.add_argument("--victims", default="both launches,relevel only,full selection")
     a = ap.parse_args()
     tb = tie_batch(8, 256, 4300)
     xyz = torch.cat([tb[0], tb[1]], 0).permute(0, 2, 1).contiguous()
