@@ -41,13 +41,25 @@ def no_framework_dense_layers():
         F.conv2d, F.conv1d, F.batch_norm, torch.nn.GRU.forward = saved
 
 
-# Gradient tolerances against the reference's fp32 gradients, per tensor, as max|a - b| / max|b| over the sampled elements.
-# Measured (tools/grad_parity_report.py, profiles/r03_grad_parity.txt): where no ReLU decision flips, this path is as close to the
-# reference as the reference is to float64 (real_1201_549: median 9e-6, max 4e-5).  One flipped mask element (flow head, layer 0,
-# y = 3.5e-7 vs 0: tools/experiments/dbg_decoder2.py) moves that layer's BatchNorm bias gradient by 7.6e-3 of its largest element and
-# everything upstream of it by ~1e-3 -- the fp32 reference itself sits up to 1.5e-3 from float64 for the same reason.  Hence: every
-# tensor within 1e-2, nine in ten within 3e-3, the median within 1e-3; a wrong term, count or weight shows up at O(1).
-GRAD_TOL, GRAD_TOL_P90, GRAD_TOL_MEDIAN = 1e-2, 3e-3, 1e-3
+# Gradient tolerances against the reference's fp32 gradients, per tensor, as max|a - b| / max|b| over the sampled elements:
+# (every tensor, 90th percentile, median) PER FIXTURE.  Two fp32 evaluations of a ReLU / max-pool network differ by discrete events --
+# an activation within rounding of 0 has its mask flipped and that element's upstream gradient appears in / vanishes from a sum.
+# Measured (tools/grad_parity_report.py, profiles/r03_grad_parity.txt, round 4 re-run in profiles/r04_grad_parity.txt):
+#   * real_1201_549, real_1047_1201: no decision flips -- this path is as close to the reference as the reference is to float64
+#     (max 4e-5 / 1e-4, median 9e-6 / 1e-5): held to 2e-4 / 5e-4 for every tensor;
+#   * real_549_1047: max 8e-4, median 1.5e-4 (small flips in the decoder's set-abstraction levels);
+#   * train_b8_n256: ONE mask element of the flow head's first layer differs between two fp32 runs (y = 3.5e-7 vs 0,
+#     tools/experiments/dbg_decoder2.py) and moves that layer's BatchNorm bias gradient by 7.6e-3 of its largest element and
+#     everything upstream of it by ~1e-3; the fp32 reference itself sits up to 1.5e-3 from float64 there.
+# A wrong term, count or weight shows up at O(1) in every case.  (The B = 64 step against the oracle with its own float64 arbiter:
+# tests/test_fullsize_oracle_gpu.py.)
+GRAD_TOLS = {
+    "real_1201_549": (2e-4, 1e-4, 5e-5),
+    "real_1047_1201": (5e-4, 2e-4, 5e-5),
+    "real_549_1047": (3e-3, 1.5e-3, 5e-4),
+    "train_b8_n256": (1e-2, 4e-3, 1.5e-3),
+}
+GRAD_TOL, GRAD_TOL_P90, GRAD_TOL_MEDIAN = GRAD_TOLS["train_b8_n256"]
 
 
 def make_net():
@@ -79,7 +91,9 @@ def train_step(net, case, prefix="", n_valid=None, pad_to=None):
             {k: v.detach().cpu() for k, v in net.state_dict().items()})
 
 
-def check_against_fixture(sub, items, flow, cls, grads, sd, grad_tol, what):
+def check_against_fixture(sub, items, flow, cls, grads, sd, grad_tol, what, tol_p90=None, tol_median=None):
+    tol_p90 = GRAD_TOL_P90 if tol_p90 is None else tol_p90
+    tol_median = GRAD_TOL_MEDIAN if tol_median is None else tol_median
     keys = [str(k) for k in sub["loss_keys"]]
     np.testing.assert_allclose([items[k] for k in keys], sub["loss_vals"], rtol=1e-4, atol=1e-6)
     assert_close(flow, sub["flow"], 1e-4, what + ": flow (train mode)")
@@ -99,7 +113,7 @@ def check_against_fixture(sub, items, flow, cls, grads, sd, grad_tol, what):
             assert abs(r["probe"] - r["ref_probe"]) <= 2.5 * grad_tol * r["ref_norm"], (what, r)
     live = np.array([r["e_ref"] for r in rows if not r["zero"]])
     print("   %d tensors: median %.1e, 90th percentile %.1e, max %.1e" % (len(live), np.median(live), np.quantile(live, 0.9), live.max()))
-    assert np.median(live) <= GRAD_TOL_MEDIAN and np.quantile(live, 0.9) <= GRAD_TOL_P90, (what, np.median(live), np.quantile(live, 0.9))
+    assert np.median(live) <= tol_median and np.quantile(live, 0.9) <= tol_p90, (what, np.median(live), np.quantile(live, 0.9))
     for k in sub:
         if k.startswith("bn/"):
             key = k[3:]
@@ -133,7 +147,7 @@ def test_real_frame_pair_train_step_matches_reference(name):
     sub.update({k: v for k, v in case.items() if k.startswith("in_")})
     net = make_net()
     items, flow, cls, grads, sd = train_step(net, sub)
-    check_against_fixture(sub, items, flow, cls, grads, sd, GRAD_TOL, name)
+    check_against_fixture(sub, items, flow, cls, grads, sd, GRAD_TOLS[name][0], name, GRAD_TOLS[name][1], GRAD_TOLS[name][2])
 
 
 def test_padded_pair_equals_unpadded_and_one_graph_serves_all_sizes():
@@ -147,7 +161,8 @@ def test_padded_pair_equals_unpadded_and_one_graph_serves_all_sizes():
         sub.update({k: v for k, v in case.items() if k.startswith("in_")})
         subs.append(sub)
     items_p, flow_p, cls_p, grads_p, sd_p = train_step(make_net(), subs[0], pad_to=384)
-    check_against_fixture(subs[0], items_p, flow_p, cls_p, grads_p, sd_p, GRAD_TOL, "padded to 384")
+    check_against_fixture(subs[0], items_p, flow_p, cls_p, grads_p, sd_p, *[GRAD_TOLS[REAL_CASES[0]][i] for i in (0,)], "padded to 384",
+                          GRAD_TOLS[REAL_CASES[0]][1], GRAD_TOLS[REAL_CASES[0]][2])
     items_u, flow_u, cls_u, grads_u, sd_u = train_step(make_net(), subs[0])
     gmax = max(float(np.abs(g).max()) for g in grads_u.values() if g is not None)
     for k, g in grads_u.items():
