@@ -92,7 +92,7 @@ def _pmc(kind, batch, n):
     """Fabric-side bytes per launch from the committed PMC passes (profiles/, same workload only)."""
     try:
         if batch == 64 and n == 256:
-            for name in (PMC[kind].replace("r02_", "r03_"), PMC[kind], PMC[kind].replace("r02_", "r01_")):
+            for name in (PMC[kind].replace("r02_", "r04_"), PMC[kind].replace("r02_", "r03_"), PMC[kind], PMC[kind].replace("r02_", "r01_")):
                 p = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(p):
                     d = json.load(open(p))
@@ -106,13 +106,14 @@ def _pmc(kind, batch, n):
 def _train_total_traffic(a):
     """HBM-side bytes of the whole train step from the committed all-kernel PMC pass (tools/pmc_train_total.py) and their ratio to
     SURVEY 8(d)'s 3 x forward algorithmic bytes."""
-    p = os.path.join(ROOT, "profiles", "r03_pmc_train_total.json")
-    if a.batch != 64 or a.npoints != 256 or not os.path.exists(p):
+    name = next((n for n in ("r04_pmc_train_total.json", "r03_pmc_train_total.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+    if a.batch != 64 or a.npoints != 256 or name is None:
         return {}
+    p = os.path.join(ROOT, "profiles", name)
     try:
         d = json.load(open(p))
         return {"traffic_bytes_per_step": d["bytes_per_step"], "traffic_ratio": d["traffic_ratio"],
-                "traffic_source": "profiles/r03_pmc_train_total.json (rocprofv3 --pmc passes over every kernel of the step)"}
+                "traffic_source": "profiles/%s (rocprofv3 --pmc passes over every kernel of the step)" % name}
     except Exception:
         return {}
 
