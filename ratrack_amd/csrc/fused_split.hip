@@ -187,14 +187,24 @@ void cost_volume_split_kernel(const CvSplitParams P) {
     const int groups = (P.n1 + PPW - 1) / PPW;
     WStreamA<SP_NW, SP_F, 2 * SPLIT_NF> ws;
     ws.start_parts(P.blob, s_w, wave, lane);
+    // The tile loop is software-pipelined by one tile (round 4): the NEXT tile's neighbour index and direction (the dependent chain
+    // index -> coordinates, two of the three round trips in front of a tile's 64 row loads) are requested inside the CURRENT tile's
+    // epilogue, whose WeightNet / neighbour-sum arithmetic (VALU + DPP, ~3 us at one wave per SIMD) runs while they arrive.  No
+    // weight-stream DMA is in flight there (the stream has just been wrapped), so the compiler's vmcnt waits for these loads touch
+    // nothing else.  (Also requesting the gathered p2 row there, into the dead activation registers, was tried: 512 registers and a
+    // spill, 0.364 -> 0.384 ms.)
+    int pt = bx * PPW + 2 * wave + pp;
+    bool valid = pt < P.n1;
+    long i = (long)b * P.n1 + (valid ? pt : P.n1 - 1);
+    long nb = 0;
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (bx < groups) {
+        nb = (long)b * P.n2 + (long)P.knn[i * 16 + j];
+        dx = __fsub_rn(P.xyz2[nb * 3], P.xyz1[i * 3]); dy = __fsub_rn(P.xyz2[nb * 3 + 1], P.xyz1[i * 3 + 1]);
+        dz = __fsub_rn(P.xyz2[nb * 3 + 2], P.xyz1[i * 3 + 2]);
+    }
     for (int G = bx; G < groups; G += nbx) {
         asm volatile("" ::: "memory");
-        const int pt = G * PPW + 2 * wave + pp;
-        const bool valid = pt < P.n1;
-        const long i = (long)b * P.n1 + (valid ? pt : P.n1 - 1);
-        const long nb = (long)b * P.n2 + (long)P.knn[i * 16 + j];
-        const float dx = __fsub_rn(P.xyz2[nb * 3], P.xyz1[i * 3]), dy = __fsub_rn(P.xyz2[nb * 3 + 1], P.xyz1[i * 3 + 1]),
-                    dz = __fsub_rn(P.xyz2[nb * 3 + 2], P.xyz1[i * 3 + 2]);
         // layer 1: leaky(p1[i] + p2[nb] + Wd.d)     (bias folded into p1)
         f4 h[32];
         {
@@ -245,6 +255,14 @@ void cost_volume_split_kernel(const CvSplitParams P) {
         if (SAVE) split_layer<SPLIT_NF>(ws, h, acc, StoreRowsSide{P.sv2, ro, valid});
         else split_layer<SPLIT_NF>(ws, h, acc);
         ws.sync();                                                   // wrap the stream to chunk 0
+        // ---- next tile, first request: its neighbour index (wave-uniform condition) -------------------------------------
+        const int Gn = G + nbx;
+        const bool more = Gn < groups;
+        const int ptn = Gn * PPW + 2 * wave + pp;
+        const bool validn = ptn < P.n1;
+        const long in_ = (long)b * P.n1 + (validn ? ptn : P.n1 - 1);
+        long knn_next = 0;
+        if (more) knn_next = (long)P.knn[in_ * 16 + j];
         if (SAVE && valid) {
 #pragma unroll
             for (int v = 0; v < SPLIT_VB; ++v)
@@ -256,8 +274,7 @@ void cost_volume_split_kernel(const CvSplitParams P) {
         wn_hidden(P.wn, dx, dy, dz, t2);
         // out[i] = sum over the 16 neighbours of relu(Wc.t2 + bc) * a3, one 32-channel block at a time
         float *o = P.out + i * P.out_pitch + 4 * hh;
-#pragma unroll
-        for (int v = 0; v < SPLIT_VB; ++v) {
+        auto out_block = [&](int v) {
             const f16v w = wn_out(P.wn, v, hh, col, t2);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -267,7 +284,20 @@ void cost_volume_split_kernel(const CvSplitParams P) {
                 row_sum16_f4(r);
                 if (valid && j == 0) *reinterpret_cast<f4 *>(o + 32 * v + 8 * q) = r;
             }
+        };
+        out_block(0);
+        out_block(1);
+        // ---- next tile, second request: its direction ---------------------------------------------------------------------------
+        long nbn = 0;
+        float dxn = 0.f, dyn = 0.f, dzn = 0.f;
+        if (more) {
+            nbn = (long)b * P.n2 + knn_next;
+            dxn = __fsub_rn(P.xyz2[nbn * 3], P.xyz1[in_ * 3]); dyn = __fsub_rn(P.xyz2[nbn * 3 + 1], P.xyz1[in_ * 3 + 1]);
+            dzn = __fsub_rn(P.xyz2[nbn * 3 + 2], P.xyz1[in_ * 3 + 2]);
         }
+#pragma unroll
+        for (int v = 2; v < SPLIT_VB; ++v) out_block(v);
+        pt = ptn; valid = validn; i = in_; nb = nbn; dx = dxn; dy = dyn; dz = dzn;
     }
     ws.finish();
 }
@@ -305,14 +335,19 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
     const int groups = (P.n1 + PPW - 1) / PPW;
     WStreamA<SP_NW, SP_F, 2 * SPLIT_NF> ws;
     ws.start_parts(P.blob, s_w, wave, lane);                             // (its barrier also publishes s_wct)
+    // software-pipelined by one tile like the forward kernel: the next tile's neighbour index and direction are requested in this
+    // tile's epilogue (the dz1 / neighbour-sum phase), not in front of its own first loads
+    int pt = bx * PPW + 2 * wave + pp;
+    bool valid = pt < P.n1;
+    long i = (long)b * P.n1 + (valid ? pt : P.n1 - 1);
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (bx < groups) {
+        const long nb = (long)b * P.n2 + (long)P.knn[i * 16 + j];
+        dx = __fsub_rn(P.xyz2[nb * 3], P.xyz1[i * 3]); dy = __fsub_rn(P.xyz2[nb * 3 + 1], P.xyz1[i * 3 + 1]);
+        dz = __fsub_rn(P.xyz2[nb * 3 + 2], P.xyz1[i * 3 + 2]);
+    }
     for (int G = bx; G < groups; G += nbx) {
         asm volatile("" ::: "memory");
-        const int pt = G * PPW + 2 * wave + pp;
-        const bool valid = pt < P.n1;
-        const long i = (long)b * P.n1 + (valid ? pt : P.n1 - 1);
-        const long nb = (long)b * P.n2 + (long)P.knn[i * 16 + j];
-        const float dx = __fsub_rn(P.xyz2[nb * 3], P.xyz1[i * 3]), dy = __fsub_rn(P.xyz2[nb * 3 + 1], P.xyz1[i * 3 + 1]),
-                    dz = __fsub_rn(P.xyz2[nb * 3 + 2], P.xyz1[i * 3 + 2]);
         const long pos = i * 16 + j;
         const unsigned ro = (unsigned)pos * 1024u + 16u * hh;
         if (valid && hh == 0) *reinterpret_cast<f4 *>(Q.d4 + pos * 4) = (f4){dx, dy, dz, 1.0f};
@@ -379,10 +414,24 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
             for (int e = 0; e < 16; ++e) acc[v][e] = 0.f;
         split_layer<SPLIT_NF>(ws, h, acc, StoreRowsSide{Q.dz2, ro, valid});
         ws.sync();                                                   // wrap the stream to chunk 0
+        // ---- next tile: neighbour index now, direction half way through the epilogue ---------------------------------------
+        const int Gn = G + nbx;
+        const bool more = Gn < groups;
+        const int ptn = Gn * PPW + 2 * wave + pp;
+        const bool validn = ptn < P.n1;
+        const long in_ = (long)b * P.n1 + (validn ? ptn : P.n1 - 1);
+        long knn_next = 0;
+        if (more) knn_next = (long)P.knn[in_ * 16 + j];
+        float dxn = 0.f, dyn = 0.f, dzn = 0.f;
         float *dpr = Q.dp1 + i * 256 + 4 * hh;
         float *dpd = Q.dpd + i * 768 + 4 * hh;
 #pragma unroll
-        for (int v = 0; v < SPLIT_VB; ++v)
+        for (int v = 0; v < SPLIT_VB; ++v) {
+            if (v == 2 && more) {
+                const long nbn = (long)b * P.n2 + knn_next;
+                dxn = __fsub_rn(P.xyz2[nbn * 3], P.xyz1[in_ * 3]); dyn = __fsub_rn(P.xyz2[nbn * 3 + 1], P.xyz1[in_ * 3 + 1]);
+                dzn = __fsub_rn(P.xyz2[nbn * 3 + 2], P.xyz1[in_ * 3 + 2]);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f4 r = leaky_grad_bits4((f4){acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]}, split_mask_bits(m1, v, q));
@@ -399,6 +448,8 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
                     *reinterpret_cast<f4 *>(dpd + 512 + 32 * v + 8 * q) = rz;
                 }
             }
+        }
+        pt = ptn; valid = validn; i = in_; dx = dxn; dy = dyn; dz = dzn;
     }
     ws.finish();
 }
