@@ -125,7 +125,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 template <int PPL>
 __device__ __forceinline__ int fps_wave_body(int n, int m, int block, const float *__restrict__ xyz, float *__restrict__ temp,
                                              int *__restrict__ idxs, float *__restrict__ new_xyz, float4 *s_pt, int lane,
-                                             int &tie_out, float *__restrict__ snap = nullptr, int *__restrict__ first_tie = nullptr) {
+                                             int &tie_out, float *__restrict__ snap = nullptr, int *__restrict__ first_tie = nullptr,
+                                             int settle_from = -1, int nu_prev = 0) {
     // snap / first_tie (optional outputs): at the FIRST round with a tie, that round's number and the min-distance state it started
     // from, by cloud index.
     const int bits = 31 - __builtin_clz(block);
@@ -155,6 +156,8 @@ __device__ __forceinline__ int fps_wave_body(int n, int m, int block, const floa
         if (new_xyz) { new_xyz[0] = o.x; new_xyz[1] = o.y; new_xyz[2] = o.z; }
     }
     int tie = 0;            // last round whose maximum was attained by more than one position (0: none)
+    int kmax = 0;           // largest index picked so far (re-levelling: settle once the picked set is the prefix {0..j})
+    bool settled = false;
     int j = 1;
     for (; j < m; ++j) {
         const f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
@@ -204,6 +207,17 @@ __device__ __forceinline__ int fps_wave_body(int n, int m, int block, const floa
             idxs[j] = __float_as_int(o.w);
             if (new_xyz) { new_xyz[j * 3 + 0] = o.x; new_xyz[j * 3 + 1] = o.y; new_xyz[j * 3 + 2] = o.z; }
         }
+        if (settle_from >= 0) {
+            const int k = __builtin_amdgcn_readfirstlane(__float_as_int(o.w));
+            kmax = k > kmax ? k : kmax;
+            if (j >= settle_from && kmax <= j) { settled = true; ++j; break; }
+        }
+    }
+    if (settled) {          // past the previous level's last tie with the prefix {0..j-1} picked: the rest is the identity
+        for (int jj = j + lane; jj < m; jj += 64) idxs[jj] = jj < nu_prev ? jj : 0;
+        for (int jj = 3 * j + lane; jj < 3 * m; jj += 64) new_xyz[jj] = xyz[jj];
+        tie_out = tie;
+        return nu_prev;
     }
     for (int jj = j + lane; jj < m; jj += 64) {
         idxs[jj] = 0;
@@ -254,7 +268,8 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, c
     }
     const int j = fps_wave_body<PPL>(n, m, block, xyz + (size_t)b * pitch * 3, temp ? temp + (size_t)b * pitch : nullptr,
                                      idxs + (size_t)b * m, new_xyz ? new_xyz + (size_t)b * m * 3 : nullptr, s_pt,
-                                     (int)threadIdx.x, tied, snap ? snap + (size_t)b * pitch : nullptr, first_tie ? first_tie + b : nullptr);
+                                     (int)threadIdx.x, tied, snap ? snap + (size_t)b * pitch : nullptr, first_tie ? first_tie + b : nullptr,
+                                     tie_prev ? tie_prev[b] : -1, tie_prev ? nuniq_prev[b] : 0);
     if (threadIdx.x == 0) {
         if (nuniq) nuniq[b] = j;
         if (tie) tie[b] = tied;
