@@ -143,8 +143,8 @@ RTK_EXPORT int rtk_prepare_inputs(int b, int n, const float *pc1, const float *p
  * n_valid (B) int32 (optional): padded batch -- sample b's cloud is its first n_valid[b] <= n points (row pitch n); the
  * selection, INCLUDING the size-dependent tie rule (block = 2^floor(log2 n_valid[b])), is that of the unpadded cloud.
  * snap (B,n) fp32 + first_tie (B) int32 (optional, together): at the first round with a tie, that round's number and the
- * min-distance state it started from (by point index).  Rows without a tie are not written.  (The resume path of rounds 2-3
- * that consumed them is retired; the product passes NULL.) */
+ * min-distance state it started from (by point index) -- what rtk_fps_relevel needs to resume there.  Rows without a tie are not
+ * written. */
 RTK_EXPORT int rtk_fps_centroids(int b, int n, int npoint, const float *xyz, int *idx, float *new_xyz, int *nuniq,
                                  int *tie, const int *n_valid, float *snap, int *first_tie, rtk_stream_t stream);
 
@@ -156,10 +156,14 @@ RTK_EXPORT int rtk_knn_point_masked(int b, int s, int n, int k, const float *que
  * centroids of the previous level, starting from the level-1 centroids xyz1 (B,npoint,3) with their counters
  * nuniq1 / tie (B) from rtk_fps_centroids.  One launch per level; decided per cloud on the device: a cloud whose previous level
  * had no tie is the identity on the coordinates (proof at rtk_fps_relevel in csrc/ops_pointnet2.hip) and is only copied, a tied
- * cloud runs the full selection of the level-1 kernel.  idx (levels,B,npoint) int32, new_xyz (levels,B,npoint,3), nuniq (levels,B);
- * tie_work (levels,B) int32: the levels' own tie counters (required for levels > 1). */
+ * cloud runs the selection of the level-1 kernel -- stopping as soon as, past the previous level's last tie, the picked set is a
+ * prefix again (the rest is then the identity).  idx (levels,B,npoint) int32, new_xyz (levels,B,npoint,3), nuniq (levels,B);
+ * tie_work (levels,B) int32: the levels' own tie counters (required for levels > 1).
+ * idx1 (B,npoint) / snap1 (B,snap_pitch) / first_tie1 (B) from rtk_fps_centroids (optional, together; levels <= 2): tied clouds
+ * resume at level 1's first tied round from the state saved there instead of at round 1. */
 RTK_EXPORT int rtk_fps_relevel(int b, int npoint, int levels, const float *xyz1, const int *nuniq1, const int *tie,
-                               int *idx, float *new_xyz, int *nuniq, int *tie_work, rtk_stream_t stream);
+                               int *idx, float *new_xyz, int *nuniq, int *tie_work, const int *idx1, const float *snap1,
+                               int snap_pitch, const int *first_tie1, rtk_stream_t stream);
 
 /* One time step of nn.GRU(hidden, hidden, layers) on a length-1 sequence (model_utils.py:279,296).
  * x (B,H); h_in, h_out (L,B,H); w_ih, w_hh TRANSPOSED (L,H,3H) = weight_{ih,hh}_l{l}.T, gate order (r,z,n);

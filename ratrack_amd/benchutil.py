@@ -69,13 +69,13 @@ def irregular_ops(batch, n, dev, npoint=512, iters=20, pmc=None):
     f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
     # ---- furthest point sampling + centroid gather, level 1 (the 511-round dependent chain) ----------------------------
     idx, nx, cnt, tie = i32(S_, npoint), f32(S_, npoint, 3), i32(S_), i32(S_)
-    tie23 = i32(2, S_)
+    tie23, first, snap = i32(2, S_), i32(S_), f32(S_, n)
     ms = _time(lambda: _lib.call("rtk_fps_centroids", S_, n, npoint, xyz.data_ptr(), idx.data_ptr(), nx.data_ptr(), cnt.data_ptr(),
-                                 tie.data_ptr(), None, None, None, st()), iters)
+                                 tie.data_ptr(), None, snap.data_ptr(), first.data_ptr(), st()), iters)
     add("fps_wave_kernel", 1, ms, S_ * (n * 12 + npoint * 16 + 8), "FPS %d -> %d + centroid gather, %d clouds" % (n, npoint, S_))
     idx23, nx23, cnt23 = i32(2, S_, npoint), f32(2, S_, npoint, 3), i32(2, S_)
     ms = _time(lambda: _lib.call("rtk_fps_relevel", S_, npoint, 2, nx.data_ptr(), cnt.data_ptr(), tie.data_ptr(), idx23.data_ptr(),
-                                 nx23.data_ptr(), cnt23.data_ptr(), tie23.data_ptr(), st()), iters)
+                                 nx23.data_ptr(), cnt23.data_ptr(), tie23.data_ptr(), idx.data_ptr(), snap.data_ptr(), n, first.data_ptr(), st()), iters)
     add("fps_wave_kernel (levels 2, 3)", 2, ms, S_ * (npoint * 12 + 2 * npoint * 16 + 12), "levels 2, 3 (copy unless a level-1 tie)")
     # ---- ball queries: both scales of a level in one scan ----------------------------------------------------------------
     for lvl in range(3):

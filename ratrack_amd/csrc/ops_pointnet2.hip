@@ -126,7 +126,13 @@ template <int PPL>
 __device__ __forceinline__ int fps_wave_body(int n, int m, int block, const float *__restrict__ xyz, float *__restrict__ temp,
                                              int *__restrict__ idxs, float *__restrict__ new_xyz, float4 *s_pt, int lane,
                                              int &tie_out, float *__restrict__ snap = nullptr, int *__restrict__ first_tie = nullptr,
-                                             int settle_from = -1, int nu_prev = 0) {
+                                             int settle_from = -1, int nu_prev = 0, int j_start = 1,
+                                             const float *__restrict__ st_snap = nullptr, const int *__restrict__ st_i1 = nullptr,
+                                             const int *__restrict__ st_i2 = nullptr) {
+    // Re-levelling (rtk_fps_relevel): settle_from = the previous level's last tied round; j_start > 1 = resume: rounds < j_start are
+    // the identity (every level repeats level 1 exactly before level 1's FIRST tied round) and the min-distance state of round
+    // j_start is level 1's, saved by ORIGINAL point index in st_snap -- a function of the point, carried to this level's cloud
+    // through the index lists: cloud index k -> st_i2[k] (level-2 index, if this is level 3) -> st_i1[...] (original point).
     // snap / first_tie (optional outputs): at the FIRST round with a tie, that round's number and the min-distance state it started
     // from, by cloud index.
     const int bits = 31 - __builtin_clz(block);
@@ -148,19 +154,37 @@ __device__ __forceinline__ int fps_wave_body(int n, int m, int block, const floa
         const bool ok = p < n;
         const float4 v = ok ? s_pt[p] : p0;
         x[i / 2][i % 2] = v.x; y[i / 2][i % 2] = v.y; z[i / 2][i % 2] = v.z;
-        t[i] = ok ? __float_as_uint(temp ? temp[__float_as_int(v.w)] : 1e10f) : 0u;
+        float t0 = 1e10f;
+        if (temp) t0 = temp[__float_as_int(v.w)];
+        if (j_start > 1 && ok) {
+            int k = __float_as_int(v.w);
+            if (st_i2) k = st_i2[k];
+            t0 = st_snap[st_i1[k]];
+        }
+        t[i] = ok ? __float_as_uint(t0) : 0u;
     }
     float4 o = p0;
-    if (lane == 0) {
+    if (j_start > 1) {          // rounds < j_start: the identity; the last of them picked cloud point j_start - 1
+        for (int jj = lane; jj < j_start; jj += 64) idxs[jj] = jj;
+        for (int jj = lane; jj < 3 * j_start; jj += 64) new_xyz[jj] = xyz[jj];
+        o = s_pt[fps_index_to_pos(j_start - 1, block, bits, q, rem)];
+    } else if (lane == 0) {
         idxs[0] = 0;
         if (new_xyz) { new_xyz[0] = o.x; new_xyz[1] = o.y; new_xyz[2] = o.z; }
     }
     int tie = 0;            // last round whose maximum was attained by more than one position (0: none)
-    int kmax = 0;           // largest index picked so far (re-levelling: settle once the picked set is the prefix {0..j})
+    int kmax = j_start - 1; // largest index picked so far (re-levelling: settle once the picked set is the prefix {0..j})
     bool settled = false;
-    int j = 1;
+    int j = j_start;
     for (; j < m; ++j) {
-        const f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+        // The winner's coordinates as REAL register pairs.  Left to itself hipcc broadcasts a component that sits in the odd half of
+        // a pair -- o.y straight out of the ds_read_b128 destination -- through the packed instruction's op_sel modifier
+        // (v_pk_add_f32 ..., v[14:15] op_sel:[0,1]), and on this hardware that form read a wrong value about once in 10^4 rounds
+        // whenever waves of another batch's split-bf16 kernels shared the SIMD: a different -- valid -- point was picked, run to run
+        // (round 4; every irreproducible build of this loop had the op_sel:[0,1] form, no reproducible one did).
+        // The empty asm pins each broadcast in a pair of its own; tests/test_isa_cpu.py keeps the op_sel form out of this file.
+        f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+        asm volatile("" : "+v"(ox), "+v"(oy), "+v"(oz));
         unsigned mloc = 0u;
 #pragma unroll
         for (int hh = 0; hh < H; ++hh) {
@@ -240,7 +264,9 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, c
                                                       float *__restrict__ new_xyz, int *__restrict__ nuniq,
                                                       int *__restrict__ tie, const int *__restrict__ nvalid,
                                                       float *__restrict__ snap, int *__restrict__ first_tie,
-                                                      const int *__restrict__ tie_prev, const int *__restrict__ nuniq_prev) {
+                                                      const int *__restrict__ tie_prev, const int *__restrict__ nuniq_prev,
+                                                      const int *__restrict__ first_tie1, const float *__restrict__ snap1, int snap_pitch,
+                                                      const int *__restrict__ idx1, const int *__restrict__ idx2) {
     extern __shared__ __attribute__((aligned(16))) float4 s_pt[];   // (x, y, z, bits(k)) by position
     const int b = blockIdx.x;
     int tied;
@@ -269,7 +295,10 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, c
     const int j = fps_wave_body<PPL>(n, m, block, xyz + (size_t)b * pitch * 3, temp ? temp + (size_t)b * pitch : nullptr,
                                      idxs + (size_t)b * m, new_xyz ? new_xyz + (size_t)b * m * 3 : nullptr, s_pt,
                                      (int)threadIdx.x, tied, snap ? snap + (size_t)b * pitch : nullptr, first_tie ? first_tie + b : nullptr,
-                                     tie_prev ? tie_prev[b] : -1, tie_prev ? nuniq_prev[b] : 0);
+                                     tie_prev ? tie_prev[b] : -1, tie_prev ? nuniq_prev[b] : 0,
+                                     (first_tie1 && first_tie1[b] > 1 && first_tie1[b] < m) ? first_tie1[b] : 1,
+                                     snap1 ? snap1 + (size_t)b * snap_pitch : nullptr, idx1 ? idx1 + (size_t)b * m : nullptr,
+                                     idx2 ? idx2 + (size_t)b * m : nullptr);
     if (threadIdx.x == 0) {
         if (nuniq) nuniq[b] = j;
         if (tie) tie[b] = tied;
@@ -277,22 +306,22 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, c
 }
 
 // Levels 2.. of a PNHead: furthest point sampling of npoint out of the npoint centroids of the previous level
-// (model_utils.py:415-417) -- rtk_fps_relevel.  Let P[0..U) be the previous level's selection (then the cloud is exhausted and
-// index 0 repeats) and T the last round of that selection whose maximum was attained by more than one position (0 = none).
+// (model_utils.py:415-417) -- rtk_fps_relevel, one launch of fps_wave_kernel per level.  Let P[0..U) be the previous level's
+// selection (then the cloud is exhausted and index 0 repeats) and T the last round of that selection whose maximum was attained by
+// more than one position (0 = none).
 //   * The running min-distances of a selection depend only on the selected SET.  T = 0: every round of the previous level had a
 //     UNIQUE maximum, the selection did not depend on the tie rule, and the same rounds on the same coordinates pick P[1], P[2], ...
-//     again -- the level is the identity on the coordinates and is only copied (the prologue of fps_wave_kernel):
+//     again -- the level is the identity on the coordinates and is only copied (the kernel's prologue):
 //     idx = (0 .. U-1, 0, 0, ...), new_xyz = xyz.
 //   * T > 0: the reference re-breaks the previous level's ties by the POSITION in the new cloud (bit-reversed), which may differ
-//     from the previous choice: the level runs the full selection (fps_wave_kernel, the level-1 kernel) and reports its own T.
-// Rounds 2 and 3 of this build resumed tied clouds at their first tied round from a saved state and stopped as soon as the picked
-// set was a prefix again, in ONE launch (fps_relevel_kernel).  Round 4 found that kernel irreproducible: with another batch's
-// split-bf16 kernels (rtk_pointwise_mlp, rtk_sa_scale_split) resident on the same CU, about one round in 10^4 picked a different --
-// valid, self-consistent -- point (tools/hazard_fps.py; never on an idle GPU, never with a CU to itself, not cured by fences,
-// wait states or any placement of delays, and code-generation dependent: the level-1 kernel, whose round loop is instruction for
-// instruction the same, is untouched by the same stress over 2 x 10^7 rounds until its body is compiled as a separate function).
-// The mechanism is not identified; the kernel is retired, tied clouds pay the full selection per level (2 x 79 us instead of ~23 us
-// for the roughly one cloud in a hundred that has a tie), and tests/test_hazard_gpu.py keeps the stress as a regression test.
+//     from the previous choice.  The level then runs the selection, (i) RESUMED at level 1's first tied round T0 -- before it every
+//     level repeats level 1 exactly -- from the min-distance state level 1 saved there (snap, by original point index: a function
+//     of the point, carried to the level's own cloud through the index lists), and (ii) STOPPED at the first round r >= T at which
+//     the picked indices are exactly {0..r} (largest picked index <= r; typically T or T+1: two tied points picked in the other
+//     order): from there on it is the identity again.  The level reports its own T for the next one.
+// (Rounds 2-3 did both levels in one launch, fps_relevel_kernel; round 4 found that launch irreproducible next to other kernels and
+// traced it to the op_sel form of the packed distance arithmetic -- see the round loop of fps_wave_body -- which the level-1
+// kernel's code generation happened to avoid.  One kernel now serves every level.)
 
 // General fallback for n > 2048: one 256-thread workgroup per sample, min-distances in global memory.
 __global__ __launch_bounds__(256) void fps_block_kernel(int n, int m, int block, const float *__restrict__ xyz,
@@ -346,14 +375,19 @@ static int fps_block_size(int n) {  // cuda_utils.h:10-14 (host code in the refe
 
 static int fps_launch(int b, int n, int npoint, const float *xyz, float *temp, int *idx, float *new_xyz, int *nuniq,
                       int *tie, const int *nvalid, float *snap, int *first_tie, hipStream_t s, const int *tie_prev = nullptr,
-                      const int *nuniq_prev = nullptr) {
+                      const int *nuniq_prev = nullptr, const int *first_tie1 = nullptr, const float *snap1 = nullptr, int snap_pitch = 0,
+                      const int *idx1 = nullptr, const int *idx2 = nullptr) {
     const int block = fps_block_size(n);
     RTK_REQUIRE(n / block < 65536, "furthest_point_sampling: n=%d too large", n);
     const size_t lds = (size_t)n * sizeof(float4);
-    if (n <= 64 * 4) fps_wave_kernel<4><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid, snap, first_tie, tie_prev, nuniq_prev);
-    else if (n <= 64 * 8) fps_wave_kernel<8><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid, snap, first_tie, tie_prev, nuniq_prev);
-    else if (n <= 64 * 16) fps_wave_kernel<16><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid, snap, first_tie, tie_prev, nuniq_prev);
-    else if (n <= 64 * 32) fps_wave_kernel<32><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid, snap, first_tie, tie_prev, nuniq_prev);
+    if (n <= 64 * 4) fps_wave_kernel<4><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid, snap, first_tie, tie_prev, nuniq_prev,
+                                              first_tie1, snap1, snap_pitch, idx1, idx2);
+    else if (n <= 64 * 8) fps_wave_kernel<8><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid, snap, first_tie, tie_prev, nuniq_prev,
+                                              first_tie1, snap1, snap_pitch, idx1, idx2);
+    else if (n <= 64 * 16) fps_wave_kernel<16><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid, snap, first_tie, tie_prev, nuniq_prev,
+                                              first_tie1, snap1, snap_pitch, idx1, idx2);
+    else if (n <= 64 * 32) fps_wave_kernel<32><<<b, 64, lds, s>>>(n, npoint, block, xyz, temp, idx, new_xyz, nuniq, tie, nvalid, snap, first_tie, tie_prev, nuniq_prev,
+                                              first_tie1, snap1, snap_pitch, idx1, idx2);
     else return 1;   // caller falls back to the block kernel
     return 0;
 }
@@ -382,19 +416,23 @@ extern "C" int rtk_fps_centroids(int b, int n, int npoint, const float *xyz, int
 }
 
 extern "C" int rtk_fps_relevel(int b, int npoint, int levels, const float *xyz1, const int *nuniq1, const int *tie, int *idx,
-                               float *new_xyz, int *nuniq, int *tie_work, rtk_stream_t stream) {
+                               float *new_xyz, int *nuniq, int *tie_work, const int *idx1, const float *snap1, int snap_pitch,
+                               const int *first_tie1, rtk_stream_t stream) {
     RTK_REQUIRE(b > 0 && npoint > 0 && levels > 0 && xyz1 && nuniq1 && tie && idx && new_xyz && nuniq,
                 "fps_relevel: bad arguments (b=%d npoint=%d levels=%d)", b, npoint, levels);
     RTK_REQUIRE(npoint <= 2048, "fps_relevel: npoint=%d > 2048", npoint);
     RTK_REQUIRE(levels == 1 || tie_work, "fps_relevel: more than one level needs the (levels, b) tie workspace");
+    RTK_REQUIRE((!idx1 && !snap1 && !first_tie1) || (idx1 && snap1 && first_tie1 && snap_pitch > 0),
+                "fps_relevel: idx1, snap1 and first_tie1 go together");
+    RTK_REQUIRE(!idx1 || levels <= 2, "fps_relevel: the saved state is carried through at most two levels");
     hipStream_t s = (hipStream_t)stream;
     const float *src = xyz1;
     const int *tie_prev = tie, *nuniq_prev = nuniq1;
-    for (int l = 0; l < levels; ++l) {      // one launch per level: untied clouds copy, tied clouds select in full
+    for (int l = 0; l < levels; ++l) {      // one launch per level: untied clouds copy, tied clouds select (resume + settle)
         int *tie_out = tie_work ? tie_work + (size_t)l * b : nullptr;
         float *xo = new_xyz + (size_t)l * b * npoint * 3;
         const int rc = fps_launch(b, npoint, npoint, src, nullptr, idx + (size_t)l * b * npoint, xo, nuniq + (size_t)l * b, tie_out, nullptr, nullptr,
-                                  nullptr, s, tie_prev, nuniq_prev);
+                                  nullptr, s, tie_prev, nuniq_prev, first_tie1, snap1, snap_pitch, idx1, l > 0 ? idx + (size_t)(l - 1) * b * npoint : nullptr);
         RTK_REQUIRE(rc == 0, "fps_relevel: no kernel instance for npoint=%d", npoint);
         RTK_CHECK_LAUNCH("fps_relevel");
         src = xo; tie_prev = tie_out; nuniq_prev = nuniq + (size_t)l * b;

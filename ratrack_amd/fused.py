@@ -51,7 +51,7 @@ _lib.SIGNATURES.update({
     "rtk_prepare_inputs": [_ci] * 2 + [_vp] * 6 + [_vp],
     "rtk_fps_centroids": [_ci] * 3 + [_vp] * 8 + [_vp],
     "rtk_knn_point_masked": [_ci] * 4 + [_vp] * 4 + [_vp],
-    "rtk_fps_relevel": [_ci] * 3 + [_vp] * 7 + [_vp],
+    "rtk_fps_relevel": [_ci] * 3 + [_vp] * 9 + [_ci, _vp, _vp],
     "rtk_gru_step": [_ci] * 3 + [_vp] * 8 + [_vp],
     "rtk_to_channel_major": [_ci] * 3 + [_vp, _ci, _ci, _vp, _ci, _ci, _vp],
     "rtk_ball_query_pair": [_ci] * 3 + [ctypes.c_float, _ci, ctypes.c_float, _ci] + [_vp] * 5 + [_vp],
@@ -412,10 +412,12 @@ class Geometry:
         # and the 3 three-NN index tables
         ns_all = [ns for row in _PNHeadWeights.NSAMPLES for ns in row]
         nn_rows = [npoint, npoint, n]
-        sizes = [S_ * npoint] * 3 + [S_] * 6 + [S_ * npoint * ns for ns in ns_all] + [S_ * r * 3 for r in nn_rows]
+        sizes = [S_ * npoint] * 3 + [S_] * 7 + [S_ * npoint * ns for ns in ns_all] + [S_ * r * 3 for r in nn_rows]
         ws = zeros(sum(sizes), torch.int32, dev)
         parts = list(torch.split(ws, sizes))
-        fps_idx, cnt, tie, tie23, ball, nn_idx = parts[0:3], parts[3:6], parts[6], parts[7:9], parts[9:15], parts[15:18]
+        fps_idx, cnt, tie, tie23, first_tie, ball, nn_idx = parts[0:3], parts[3:6], parts[6], parts[7:9], parts[9], parts[10:16], parts[16:19]
+        # level-1 min-distance state at the first tied round, by point index (written for tied clouds only)
+        snap = torch.empty(S_ * n, dtype=torch.float32, device=dev) if n <= 2048 else None
         self.fps_idx = [t.view(S_, npoint) for t in fps_idx]
         self.tie = tie
         xyz_all = torch.empty(3, S_, npoint, 3, dtype=torch.float32, device=dev)
@@ -430,7 +432,7 @@ class Geometry:
         # asynchronously (on the side stream), and a buffer dropped at the end of __init__ goes back to the allocator's main-stream
         # pool, whose next tenant is then written WHILE the kernel still uses the bytes (round 3: a tie snapshot buffer freed this way
         # put one real frame pair in three off by 2e-3, only with warm allocator pools)
-        self._scratch = (temp, n_valid, xyz)
+        self._scratch = (snap, temp, n_valid, xyz)
 
         main = torch.cuda.current_stream()
         if side is not None:
@@ -440,7 +442,7 @@ class Geometry:
             # ---- level 1: the only full furthest-point selection on the common path ---------------------------
             if not big:
                 _lib.call("rtk_fps_centroids", S_, n, npoint, xyz.data_ptr(), fps_idx[0].data_ptr(), new_xyz[0].data_ptr(),
-                          cnt[0].data_ptr(), tie.data_ptr(), nv, None, None, _stream())
+                          cnt[0].data_ptr(), tie.data_ptr(), nv, snap.data_ptr(), first_tie.data_ptr(), _stream())
             else:   # large clouds: generic FPS + gather, no exhausted-cloud / tie information
                 _native.furthest_point_sampling_wrapper(S_, n, npoint, xyz, temp, self.fps_idx[0])
                 new_xyz[0].copy_(torch.gather(xyz, 1, self.fps_idx[0].long().unsqueeze(-1).expand(-1, -1, 3)))
@@ -450,9 +452,11 @@ class Geometry:
             def relevel():
                 # ---- levels 2, 3: FPS of npoint out of the previous level's npoint centroids (model_utils.py:415-417).
                 # One launch per level, decided per cloud on the device (no host sync): a cloud whose previous level had no tie is
-                # provably the identity on the coordinates and is copied, a tied cloud runs the full selection (rtk_fps_relevel)
+                # provably the identity on the coordinates and is copied, a tied cloud runs the selection -- resumed at level 1's
+                # first tied round, stopped once its picked set is a prefix again (rtk_fps_relevel)
+                resume = (fps_idx[0].data_ptr(), snap.data_ptr(), n, first_tie.data_ptr()) if not big else (None, None, 0, None)
                 _lib.call("rtk_fps_relevel", S_, npoint, 2, new_xyz[0].data_ptr(), cnt[0].data_ptr(), tie.data_ptr(),
-                          fps_idx[1].data_ptr(), new_xyz[1].data_ptr(), cnt[1].data_ptr(), tie23[0].data_ptr(), _stream())
+                          fps_idx[1].data_ptr(), new_xyz[1].data_ptr(), cnt[1].data_ptr(), tie23[0].data_ptr(), *resume, _stream())
                 if CHECK_FPS_RELEVEL and not torch.cuda.is_current_stream_capturing():      # the check synchronises
                     check_fps_relevel(new_xyz[0], torch.stack(self.fps_idx[1:]), xyz_all[1:], torch.stack(list(cnt[1:3])))
             for lvl in range(3):

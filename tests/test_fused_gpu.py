@@ -408,14 +408,16 @@ def test_fps_relevel():
         _lib.call("rtk_fps_centroids", S_, n, 512, xyz.data_ptr(), idx.data_ptr(), l1.data_ptr(), c1.data_ptr(), tie.data_ptr(), None,
                   snap.data_ptr(), first.data_ptr(), F._stream())
         assert ((first > 0) == (tie > 0)).all() and (first <= tie).all()
-        idx23 = torch.empty(2, S_, 512, dtype=torch.int32, device=DEV)
-        xyz23 = torch.empty(2, S_, 512, 3, device=DEV)
-        c23 = torch.empty(2, S_, dtype=torch.int32, device=DEV)
-        tie23 = torch.empty(2, S_, dtype=torch.int32, device=DEV)
-        _lib.call("rtk_fps_relevel", S_, 512, 2, l1.data_ptr(), c1.data_ptr(), tie.data_ptr(), idx23.data_ptr(), xyz23.data_ptr(),
-                  c23.data_ptr(), tie23.data_ptr(), F._stream())
-        F.check_fps_relevel(l1, idx23, xyz23, c23)
-        assert (tie23[0][tie == 0] == 0).all()      # an untied level stays untied
+        for resume in (True, False):          # tied clouds resume at level 1's first tied round / start over at round 1
+            idx23 = torch.empty(2, S_, 512, dtype=torch.int32, device=DEV)
+            xyz23 = torch.empty(2, S_, 512, 3, device=DEV)
+            c23 = torch.empty(2, S_, dtype=torch.int32, device=DEV)
+            tie23 = torch.empty(2, S_, dtype=torch.int32, device=DEV)
+            extra = (idx.data_ptr(), snap.data_ptr(), n, first.data_ptr()) if resume else (None, None, 0, None)
+            _lib.call("rtk_fps_relevel", S_, 512, 2, l1.data_ptr(), c1.data_ptr(), tie.data_ptr(), idx23.data_ptr(), xyz23.data_ptr(),
+                      c23.data_ptr(), tie23.data_ptr(), *extra, F._stream())
+            F.check_fps_relevel(l1, idx23, xyz23, c23)
+            assert (tie23[0][tie == 0] == 0).all()      # an untied level stays untied
         # the CPU oracle, level after level
         src = l1.cpu()
         assert torch.equal(idx.cpu(), P.fps(xyz.cpu(), 512))

@@ -1,0 +1,32 @@
+"""CPU: a lint on the generated gfx950 code of the geometry kernels (hipcc cross-compiles without a GPU).
+
+Round 4 traced run-to-run differences of the furthest-point selection to ONE instruction form: a packed fp32 operation that
+broadcasts the odd half of a register pair through its op_sel modifier (`v_pk_add_f32 v[a:b], v[c:d], v[14:15] op_sel:[0,1]`) read a
+wrong value about once in 10^4 executions whenever waves of another batch's split-bf16 matrix kernels shared the SIMD (DESIGN
+section 8; tools/hazard_fps.py is the stress that shows it on a GPU, tests/test_hazard_gpu.py the regression test).  The source now
+pins its broadcasts in register pairs of their own; this test keeps the compiler from quietly bringing the form back into
+csrc/ops_pointnet2.hip, whose kernels decide INDICES -- where one wrong read changes the result instead of its last bit."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_geometry_kernels_have_no_op_sel_broadcast_in_packed_fp32_arithmetic(tmp_path):
+    from ratrack_amd import build as B
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(B.CSRC, "ops_pointnet2.hip")
+    out = str(tmp_path / "ops_pointnet2.s")
+    subprocess.check_call([hipcc] + [f for f in B.FLAGS if f != "-fPIC"] + ["-I", os.path.join(ROOT, "include"), "-I", B.CSRC, "-S", "--cuda-device-only",
+                                                                            "-o", out, src], stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    packed = re.findall(r"^\s*(v_pk_\w+_f32 .*)$", text, flags=re.M)
+    assert len(packed) >= 12, "the selection kernels' packed distance arithmetic was not found (%d packed fp32 instructions)" % len(packed)
+    bad = [ins for ins in packed if re.search(r"op_sel:\[(0,1|1,0|1,1)", ins)]
+    assert not bad, "packed fp32 instructions that read the odd half of a pair through op_sel:\n  " + "\n  ".join(bad[:8])

@@ -35,32 +35,36 @@ def run_levels(xyz, npoint, stream, relevel=True):
     out = torch.empty(3, S_, npoint, 3, dtype=torch.float32, device=DEV)
     cnt = torch.zeros(3, S_, dtype=torch.int32, device=DEV)
     tie = torch.zeros(3, S_, dtype=torch.int32, device=DEV)
+    first = torch.zeros(S_, dtype=torch.int32, device=DEV)
+    snap = torch.empty(S_, n, dtype=torch.float32, device=DEV)
     if relevel:
         _lib.call("rtk_fps_centroids", S_, n, npoint, xyz.data_ptr(), idx[0].data_ptr(), out[0].data_ptr(), cnt[0].data_ptr(), tie[0].data_ptr(), None,
-                  None, None, h)
+                  snap.data_ptr(), first.data_ptr(), h)
         _lib.call("rtk_fps_relevel", S_, npoint, 2, out[0].data_ptr(), cnt[0].data_ptr(), tie[0].data_ptr(), idx[1].data_ptr(), out[1].data_ptr(),
-                  cnt[1].data_ptr(), tie[1].data_ptr(), h)
+                  cnt[1].data_ptr(), tie[1].data_ptr(), idx[0].data_ptr(), snap.data_ptr(), n, first.data_ptr(), h)
     else:
         src, ns = xyz, n
         for l in range(3):
             _lib.call("rtk_fps_centroids", S_, ns, npoint, src.data_ptr(), idx[l].data_ptr(), out[l].data_ptr(), cnt[l].data_ptr(), None, None, None,
                       None, h)
             src, ns = out[l], npoint
-    return idx, out, cnt, (tie[0], tie[0], None)
+    return idx, out, cnt, (tie[0], first, snap)
 
 
 def relevel_only(ref, npoint, stream, resume=True):
     """Only the re-levelling launches, on the level-1 results of `ref`."""
     idx0, out0, cnt0 = ref[0][0], ref[1][0], ref[2][0]
-    tie = ref[3][0]
+    tie, first, snap = ref[3]
     S_ = idx0.shape[0]
+    n = snap.shape[1]
     h = stream.cuda_stream
     idx = torch.zeros(2, S_, npoint, dtype=torch.int32, device=DEV)
     out = torch.empty(2, S_, npoint, 3, dtype=torch.float32, device=DEV)
     cnt = torch.zeros(2, S_, dtype=torch.int32, device=DEV)
     tie23 = torch.zeros(2, S_, dtype=torch.int32, device=DEV)
+    extra = (idx0.data_ptr(), snap.data_ptr(), n, first.data_ptr()) if resume else (None, None, 0, None)
     _lib.call("rtk_fps_relevel", S_, npoint, 2, out0.data_ptr(), cnt0.data_ptr(), tie.data_ptr(), idx.data_ptr(), out.data_ptr(),
-              cnt.data_ptr(), tie23.data_ptr(), h)
+              cnt.data_ptr(), tie23.data_ptr(), *extra, h)
     return idx, out, cnt, None
 
 
@@ -131,7 +135,7 @@ def main():
     ap.add_argument("--iters", type=int, default=3000)
     ap.add_argument("--study", action="store_true")
     ap.add_argument("--only", default="")
-    ap.add_argument("--victims", default="both launches,relevel only,full selection")
+    ap.add_argument("--victims", default="both launches,relevel only,relevel no resume,full selection")
     a = ap.parse_args()
     tb = tie_batch(8, 256, 4300)
     xyz = torch.cat([tb[0], tb[1]], 0).permute(0, 2, 1).contiguous()
