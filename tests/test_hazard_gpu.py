@@ -1,11 +1,12 @@
 """GPU: reproducibility under concurrency (round-3 review item 1; the reference's forward is deterministic, models/track4d.py:67-106,
 and the fused path has no float atomics, so ANY run-to-run bit difference is a defect).
 
-Round 4 traced the one unexplained failure of test_padded_variable_n_batch to a kernel, not to a stream or lifetime hazard: the
-one-launch re-levelling kernel of rounds 2-3 picked a different (valid) point in about one round in 10^4 whenever another batch's
-split-bf16 kernels were resident on the same CU -- never on an idle GPU, which is why single-stream tests never saw it.  These
-tests keep that stress: they FAIL on the round-3 library (tools/hazard_fps.py --study shows 2-8 % of the iterations per tied cloud
-there) and pass on the level-1 kernel that rtk_fps_relevel uses now."""
+Round 4 traced the one unexplained failure of test_padded_variable_n_batch to an instruction, not to a stream or lifetime hazard:
+the furthest-point selection picked a different (valid) point in about one round in 10^4 whenever another batch's split-bf16
+kernels were resident on the same SIMD -- never on an idle GPU, which is why single-stream tests never saw it -- because its packed
+distance arithmetic read a broadcast operand from the odd half of a register pair through op_sel.  These tests
+keep the stress: they FAIL on the round-3 library (tools/hazard_fps.py --study: 2-8 % of the iterations per tied cloud) and failed
+on a round-4 build that brought the instruction form back (158 of 400); tests/test_isa_cpu.py lints the form on the CPU."""
 import os
 import sys
 
