@@ -18,7 +18,11 @@ SO = os.path.join(LIBDIR, "librtk_hip.so")
 
 ARCH = "gfx950"
 # -ffp-contract=off: the bit-exactness contract needs every fused op to be an explicit __fmaf_rn.
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
+# -fno-slp-vectorize (round 4): hipcc's SLP vectoriser turns scalar fp32 code into packed instructions that take one operand half
+# through the op_sel modifier (490 of them in the training kernels), the form that misreads next to bf16-MFMA waves on this hardware
+# (DESIGN section 8).  Without it no kernel of the library contains the form (tests/test_isa_cpu.py); measured cost: none (forward
+# 72.7 k pairs/s, train step 7.77 ms -- both inside the run-to-run spread of the vectorised build).
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-fvisibility=hidden",
          "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-result"]
 
 
