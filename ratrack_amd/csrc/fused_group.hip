@@ -631,7 +631,10 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(int m, int n, int cha
 // accumulators, thread = channel, so no atomics at all) and walks the index list once; matching source rows are compacted
 // per 256-entry chunk (ballot + prefix, position order) and fetched as full coalesced 1 KiB rows, four in flight.
 // Deterministic: every destination element is accumulated by one thread in position order.
-#define SC_RB 32
+// SC_RB = 32 destination rows per workgroup at large batches; 8 at small ones (B = 1, the reference's regime: 12 workgroups of 32 rows
+// leave the chip empty and one hot row -- real frames have exact duplicate points -- holds a whole workgroup up: 150 us on the real
+// pairs against 66 us on synthetic ones; every workgroup scans the whole index list either way, which is cheap at these sizes).
+template <int SC_RB>
 __global__ __launch_bounds__(256) void scatter_rows256_kernel(int m, int n, const int64_t *__restrict__ idx,
                                                               const float *__restrict__ src, float *__restrict__ dst) {
     __shared__ float s_acc[SC_RB][256];
@@ -696,7 +699,10 @@ extern "C" int rtk_scatter_add_rows(int samples, int m, int n, int channels, con
     RTK_REQUIRE(channels == 256 || (size_t)n * SC_CH * 4 <= 128 * 1024, "scatter_add_rows: n (%d) too large for the LDS slab", n);
     RTK_REQUIRE(samples <= 65535, "scatter_add_rows: too many samples");
     if (channels == 256) {
-        scatter_rows256_kernel<<<dim3((n + SC_RB - 1) / SC_RB, samples), 256, 0, (hipStream_t)stream>>>(m, n, idx, src, dst);
+        if ((long)samples * ((n + 31) / 32) >= 256)
+            scatter_rows256_kernel<32><<<dim3((n + 31) / 32, samples), 256, 0, (hipStream_t)stream>>>(m, n, idx, src, dst);
+        else
+            scatter_rows256_kernel<8><<<dim3((n + 7) / 8, samples), 256, 0, (hipStream_t)stream>>>(m, n, idx, src, dst);
         RTK_CHECK_LAUNCH("scatter_add_rows");
         return RTK_OK;
     }
