@@ -689,6 +689,11 @@ def main():
             "whole_path": {"hbm_frac_algorithmic": round(per_gpu * ALG_BYTES_PER_PAIR.get(a.npoints, 0) / (HBM_PEAK_GBS * 1e9), 5),
                            "fp32_frac_algorithmic": round(per_gpu * ALG_FLOPS_PER_PAIR.get(a.npoints, 0) / (FP32_PEAK_TFLOPS * 1e12), 5),
                            "fp32_frac_executed": round(per_gpu * exec_flops_per_pair / (FP32_PEAK_TFLOPS * 1e12), 5),
+                           # against the matrix roofline of this design's own arithmetic (bf16 peak / 6 products per fp32 product):
+                           # the ceiling of the path as formulated, and what the north star's "30 % of HBM" would need of it
+                           "split_frac_executed": round(per_gpu * exec_flops_per_pair / (SPLIT_PEAK_TFLOPS * 1e12), 5),
+                           "split_ceiling_pairs_per_s": round(SPLIT_PEAK_TFLOPS * 1e12 / exec_flops_per_pair, 0),
+                           "hbm_30pct_pairs_per_s": round(0.3 * HBM_PEAK_GBS * 1e9 / ALG_BYTES_PER_PAIR.get(a.npoints, 1), 0),
                            "executed_gflop_per_pair": round(exec_flops_per_pair / 1e9, 4),
                            "executed_gflop_per_pair_by_kernel": {k: round(2.0 * v / a.batch / 1e9, 4) for k, v in exec_by_kernel.items()}},
             # one eager pass, every launch between HIP events on one stream with nothing else in flight (what a serialising profiler
