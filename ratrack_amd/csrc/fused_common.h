@@ -366,6 +366,15 @@ __device__ __forceinline__ void row_sum16_f4(f4 &v) {
                  : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
 }
 
+// ... for an argument every component of which is the result of a VALU instruction the compiler sees (a product, a sum): it has
+// already placed the wait states a matrix-core producer further up needs, and the block's own s_nop 1 covers VALU -> DPP; the
+// fence's four ORs are saved (the cost volume's epilogue calls this 32 times per tile).
+__device__ __forceinline__ void row_sum16_valu_f4(f4 &v) {
+    asm volatile("s_nop 1\n" RTK_DPP4("v_add_f32_dpp", "row_ror:8") RTK_DPP4("v_add_f32_dpp", "row_ror:4")
+                 RTK_DPP4("v_add_f32_dpp", "row_ror:2") RTK_DPP4("v_add_f32_dpp", "row_ror:1")
+                 : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+}
+
 // max over aligned sub-groups of GROUP (4, 8 or 16) lanes within the row
 template <int GROUP>
 __device__ __forceinline__ void row_max_group_f4(f4 &v) {

@@ -11,10 +11,6 @@ namespace {
 #ifndef SP_F
 #define SP_F 48           // fragments (KiB) per half of the LDS double buffer: a multiple of 6 (one group step)
 #endif
-// The forward cost volume streams in halves of 24 KiB (four group steps per chunk: the kernel's clock count is the same as with 48
-// -- tools/experiments/cv_ticks.py --totals-only: 685.6 k against 688.7 k --, chunk boundaries cost nothing measurable), which leaves
-// LDS for the staged rows of layer 1 AND for the small geometry kernels of the other batches in flight on the same CU.
-constexpr int CV_F = 24;
 
 // ---- packing: (256 x 256) row-major fp32 weights -> split image (split_mfma.h) ---------------------------------------------
 __global__ __launch_bounds__(256) void pack_split_kernel(int cout, int cin, const float *__restrict__ w, int transposed, u4v *__restrict__ out) {
@@ -141,158 +137,37 @@ __device__ __forceinline__ void wn_hidden(const WnSplit &W, float dx, float dy, 
     float t1[8];
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
-        float a = __fmaf_rn(ldc(W.wa + o), dx, 0.f);
-        a = __fmaf_rn(ldc(W.wa + 16 + o), dy, a);
-        a = __fmaf_rn(ldc(W.wa + 32 + o), dz, a);
-        t1[o] = fmaxf(__fadd_rn(a, ldc(W.wa + 48 + o)), 0.f);
+        float a = __fmaf_rn(W.wa[o], dx, 0.f);
+        a = __fmaf_rn(W.wa[16 + o], dy, a);
+        a = __fmaf_rn(W.wa[32 + o], dz, a);
+        t1[o] = fmaxf(__fadd_rn(a, W.wa[48 + o]), 0.f);
     }
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
-        float a = ldc(W.bb + o);
+        float a = W.bb[o];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) a = __fmaf_rn(ldc(W.wb + (16 * (c >> 2) + o) * 4 + (c & 3)), t1[c], a);
+        for (int c = 0; c < 8; ++c) a = __fmaf_rn(W.wb[(16 * (c >> 2) + o) * 4 + (c & 3)], t1[c], a);
         t2[o] = fmaxf(a, 0.f);
     }
 }
-// relu(Wc.t2 + bc) for the 32-channel block v in the tile layout (K = 8 on the fp32-input MFMA: four k-steps of two), in two
-// halves: this lane's operands of the block (bias, four weights: 20 registers), and the product.  The epilogues request block
-// v + 1's operands before they work on block v -- the conditional stores of a block end a basic block each, and hipcc's scheduler
-// moves no load across them, so every block started with an exposed round trip.
-struct WnBlock {
-    f16v bias;
-    float w[4];
-};
-__device__ __forceinline__ WnBlock wn_block(const WnSplit &W, int v, int hh, int col) {
-    WnBlock k;
-    k.bias = split_bias(W.bc, v, hh);
+// relu(Wc.t2 + bc) for the 32-channel block v in the tile layout (K = 8 on the fp32-input MFMA: four k-steps of two)
+__device__ __forceinline__ f16v wn_out(const WnSplit &W, int v, int hh, int col, const float (&t2)[8]) {
+    f16v w = split_bias(W.bc, v, hh);
     const int ch = 32 * v + col;                                         // A[i = col][k = hh]
     const float *wr = W.wc + ((ch >> 4) * 64 + (ch & 15)) * 4;
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
-        const int kk = 2 * st + hh;
-        k.w[st] = ldc(wr + 64 * (kk >> 2) + (kk & 3));
+        const int k = 2 * st + hh;
+        w = mfma_f32x2(wr[64 * (k >> 2) + (k & 3)], hh ? t2[2 * st + 1] : t2[2 * st], w);
     }
-    return k;
-}
-__device__ __forceinline__ f16v wn_pre(const WnBlock &k, int hh, const float (&t2)[8]) {      // Wc.t2 + bc, before the ReLU
-    f16v w = k.bias;
-#pragma unroll
-    for (int st = 0; st < 4; ++st) w = mfma_f32x2(k.w[st], hh ? t2[2 * st + 1] : t2[2 * st], w);
-    return w;
-}
-__device__ __forceinline__ f16v wn_out(const WnBlock &k, int hh, const float (&t2)[8]) {
-    f16v w = wn_pre(k, hh, t2);
 #pragma unroll
     for (int e = 0; e < 16; ++e) w[e] = fmaxf(w[e], 0.f);
     return w;
 }
-__device__ __forceinline__ f16v wn_out(const WnSplit &W, int v, int hh, int col, const float (&t2)[8]) { return wn_out(wn_block(W, v, hh, col), hh, t2); }
 
 __device__ __forceinline__ f4 f4_max(f4 a, f4 b) { return (f4){fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)}; }
 __device__ __forceinline__ f4 f4_relu(f4 a) { return (f4){fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)}; }
-// max(x, 0.1 x) and max(x, 0) as medians with +inf: ONE instruction each.  fmaxf() costs two under IEEE mode -- hipcc first quiets a
-// possible signalling NaN in every operand it did not compute itself (v_max_f32 x, x, x on each accumulator read): 32 extra VALU
-// instructions per 32-channel block of the epilogue, 256 per layer boundary.  Same bits for every non-NaN input.
-__device__ __forceinline__ float leaky1(float x) { return __builtin_amdgcn_fmed3f(x, 0.1f * x, __builtin_inff()); }
-__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
-__device__ __forceinline__ f4 leaky4(f4 t) { return (f4){leaky1(t.x), leaky1(t.y), leaky1(t.z), leaky1(t.w)}; }
-
-// ---- layer 1's operands ---------------------------------------------------------------------------------------------------
-// The tile layout gives a lane 32 bytes of a gathered p2 row per load instruction (its own position's row, two lanes per position):
-// 32 partial cache lines per instruction, each fetched whole from L2 and -- four instructions in a row touching the same line
-// while it is still in flight -- fetched again (tools/experiments/cv_ticks.py: 12 k of a tile's 86 k clocks went into layer 1, 6 k
-// of them gone when every lane reads the same row).  So the rows come through LDS instead: one global_load_lds per two positions
-// moves 2 x 512 contiguous bytes (channels 128 HALF .. 128 HALF + 127 of both rows) into the wave's own 16 KiB of LDS, every line
-// fetched once, and the lanes read their slots from there.  Two rounds per tile (HALF = 0, 1: 64 KiB per workgroup next to the
-// weight stream's 48, so that a CU keeps 48 KiB for other kernels' workgroups); round 0 of the NEXT tile is requested right after layer 1 and lands under layers 2 and 3.
-// Slot p of a position's 512 bytes holds source chunk p ^ (position & 15): the 16 lanes that read together (one hh, 16 positions)
-// then hit 16 different bank groups.
-constexpr int CV_ROWS_F4 = 32 * 32;      // f4 per wave: 32 positions x 32 slots of 16 bytes
-struct CvRowsRequest {
-    const char *p2;                // the p2 rows (wave-uniform; byte offsets are 32-bit: at most 2^22 rows)
-    f4 *rows;                      // this wave's 16 KiB
-    int nbrow;                     // this lane's gathered row (lane col and lane 32 + col hold the same)
-    unsigned lanepart;             // 512 HALF + ((slot ^ sub) << 4): (slot ^ ((2 t + sub) & 15)) << 4 == lanepart ^ ((2 t & 15) << 4) below 512
-    int sub;
-    __device__ __forceinline__ CvRowsRequest(const float *p2_, f4 *rows_, int nbrow_, int half, int lane)
-        : p2(reinterpret_cast<const char *>(p2_)), rows(rows_), nbrow(nbrow_), lanepart(512u * half + (unsigned)(((lane & 31) ^ (lane >> 5)) << 4)), sub(lane >> 5) {}
-    // lanes 0..31: position 2 T, lanes 32..63: position 2 T + 1 (their row indices live in lanes 2 T, 2 T + 1)
-    template <int T>
-    __device__ __forceinline__ void one() const {
-        const int r0 = __builtin_amdgcn_readlane(nbrow, 2 * T), r1 = __builtin_amdgcn_readlane(nbrow, 2 * T + 1);
-        const unsigned off = ((unsigned)(sub ? r1 : r0) << 10) + (lanepart ^ (unsigned)(((2 * T) & 15) << 4));
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p2 + off),
-                                         (__attribute__((address_space(3))) void *)(rows + T * 64), 16, 0, 0);
-    }
-    template <int... T>
-    __device__ __forceinline__ void all(std::integer_sequence<int, T...>) const { (one<T>(), ...); }
-};
-template <int HALF>
-__device__ __forceinline__ void cv_rows_request(const float *p2, int nbrow, f4 *rows, int lane) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous round's reads have returned before their slots are overwritten
-    CvRowsRequest(p2, rows, nbrow, HALF, lane).all(std::make_integer_sequence<int, 16>{});
-}
-// Side job of layer 2 (split_mfma.h): the NEXT tile's round 0, three requests in each of the first group steps of the layer's first two
-// chunks -- where the weight stream issues its own, so that they are as old as those at the chunk's closing vmcnt(0) -- and, in the
-// training forward, the a1 stores.
-template <bool SAVE>
-struct CvLayer2Side {
-    StoreRowsSide st;
-    CvRowsRequest rq;
-    template <int GI>
-    __device__ __forceinline__ void at(const f4 (&h)[32]) const {
-        if constexpr (SAVE) st.template at<GI>(h);
-        constexpr int per_chunk = CV_F / 6, ig = split_issue_groups(CV_F), g = GI % per_chunk, n = (GI / per_chunk) * ig + g;
-        if constexpr (g < ig && 3 * n < 16) {
-            rq.template one<3 * n>();
-            if constexpr (3 * n + 1 < 16) rq.template one<3 * n + 1>();
-            if constexpr (3 * n + 2 < 16) rq.template one<3 * n + 2>();
-        }
-    }
-};
-// this lane's 16 slots of the round: channels 128 HALF + 8 e + 4 hh .. + 3, e = 0..15
-template <int HALF>
-__device__ __forceinline__ void cv_rows_read(const f4 *rows, int col, int hh, f4 (&h)[32]) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) h[16 * HALF + e] = rows[col * 32 + ((2 * e + hh) ^ (col & 15))];
-}
-// r + q as held by lane K of this lane's row of 16 (the p1 row of a point is the same for its 16 neighbours: each of them loads
-// two of its 32 slots and the additions pick the owner's copy -- 2 loads per lane instead of 32 returning the same bytes 16 times)
-template <int K>
-__device__ __forceinline__ f4 add_row_bcast(const f4 q, const f4 r) {
-    f4 o;
-    asm("s_nop 1\n"
-        "v_add_f32_dpp %0, %4, %8 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %1, %5, %9 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %2, %6, %10 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n"
-        "v_add_f32_dpp %3, %7, %11 row_newbcast:%12 row_mask:0xf bank_mask:0xf"
-        : "=&v"(o.x), "=&v"(o.y), "=&v"(o.z), "=&v"(o.w)
-        : "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w), "v"(r.x), "v"(r.y), "v"(r.z), "v"(r.w), "n"(K));
-    return o;
-}
-template <int V0, int V1>
-__device__ __forceinline__ void cv_layer1_blocks(const CvSplitParams &P, const f4 q0, const f4 q1, float b0, float b1, int hh, int col, f4 (&h)[32]) {
-    static_assert(V1 <= 8, "eight 32-channel blocks");
-    auto block = [&](auto vc) {
-        constexpr int v = decltype(vc)::value;
-        f16v c;
-        auto slot = [&](auto qc) {
-            constexpr int q = decltype(qc)::value, e = 4 * v + q;
-            const f4 t = add_row_bcast<e & 15>(e < 16 ? q0 : q1, h[e]);
-            c[4 * q] = t.x; c[4 * q + 1] = t.y; c[4 * q + 2] = t.z; c[4 * q + 3] = t.w;
-        };
-        slot(std::integral_constant<int, 0>{}); slot(std::integral_constant<int, 1>{});
-        slot(std::integral_constant<int, 2>{}); slot(std::integral_constant<int, 3>{});
-        const int ch = 32 * v + col;                         // A[i = col][k = hh]
-        const float *wr = P.wd + (ch >> 4) * 64 + (ch & 15);
-        c = mfma_f32x2(ldc(wr + 16 * hh), b0, c);
-        c = mfma_f32x2(ldc(wr + 16 * (2 + hh)), b1, c);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) h[4 * v + q] = leaky4((f4){c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]});
-    };
-    block(std::integral_constant<int, V0>{}); block(std::integral_constant<int, V0 + 1>{});
-    block(std::integral_constant<int, V0 + 2>{}); block(std::integral_constant<int, V0 + 3>{});
-}
+__device__ __forceinline__ f4 leaky4(f4 t) { return (f4){fmaxf(t.x, 0.1f * t.x), fmaxf(t.y, 0.1f * t.y), fmaxf(t.z, 0.1f * t.z), fmaxf(t.w, 0.1f * t.w)}; }
 
 // Register cap of the forward kernel.  Left alone (512) hipcc spreads the tile over 500 registers and nothing else fits on the SIMD;
 // capped it allocates 404 without a spill, and the small-register geometry kernels of the other batches in flight (FPS 20, ball
@@ -303,55 +178,54 @@ __device__ __forceinline__ void cv_layer1_blocks(const CvSplitParams &P, const f
 template <bool SAVE>
 __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1), amdgpu_num_vgpr(CV_FWD_VGPRS)))
 void cost_volume_split_kernel(const CvSplitParams P) {
-    __shared__ __attribute__((aligned(16))) f4 s_w[2 * CV_F * 64];
-    __shared__ __attribute__((aligned(16))) f4 s_rows[SP_NW * CV_ROWS_F4];
+    __shared__ __attribute__((aligned(16))) f4 s_w[2 * SP_F * 64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hh = lane >> 5, col = lane & 31, pp = col >> 4,
               j = col & 15;      // wave index in an SGPR: the DMA's LDS destination (M0) is then scalar arithmetic
-    f4 *rows = s_rows + wave * CV_ROWS_F4;
     int b, bx, nbx;
     rtk_decode_block(P.gx, b, bx, nbx);
     constexpr int PPW = 2 * SP_NW;                                  // points per workgroup iteration
     const int groups = (P.n1 + PPW - 1) / PPW;
-    WStreamA<SP_NW, CV_F, 2 * SPLIT_NF> ws;
+    WStreamA<SP_NW, SP_F, 2 * SPLIT_NF> ws;
     ws.start_parts(P.blob, s_w, wave, lane);
-    // The tile loop is software-pipelined by one tile (round 4): the NEXT tile's neighbour index is requested at the top of the
-    // CURRENT tile, the first half of its gathered rows (cv_rows_request<0>) right after layer 1, its direction and its two p1 slots
-    // inside the epilogue, whose WeightNet / neighbour-sum arithmetic (VALU + DPP) runs while they arrive.
+    // The tile loop is software-pipelined by one tile (round 4): the NEXT tile's neighbour index and direction (the dependent chain
+    // index -> coordinates, two of the three round trips in front of a tile's 64 row loads) are requested inside the CURRENT tile's
+    // epilogue, whose WeightNet / neighbour-sum arithmetic (VALU + DPP, ~3 us at one wave per SIMD) runs while they arrive.  No
+    // weight-stream DMA is in flight there (the stream has just been wrapped), so the compiler's vmcnt waits for these loads touch
+    // nothing else.  (Also requesting the gathered p2 row there, into the dead activation registers, was tried: 512 registers and a
+    // spill, 0.364 -> 0.384 ms.)
     int pt = bx * PPW + 2 * wave + pp;
     bool valid = pt < P.n1;
     long i = (long)b * P.n1 + (valid ? pt : P.n1 - 1);
     long nb = 0;
     float dx = 0.f, dy = 0.f, dz = 0.f;
-    f4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0;                          // p1 slots j and 16 + j of this lane's point
     if (bx < groups) {
         nb = (long)b * P.n2 + (long)P.knn[i * 16 + j];
-        cv_rows_request<0>(P.p2, (int)nb, rows, lane);
-        q0 = ldc4(P.p1 + i * 256 + 4 * hh + 8 * j); q1 = ldc4(P.p1 + i * 256 + 4 * hh + 8 * (16 + j));
         dx = __fsub_rn(P.xyz2[nb * 3], P.xyz1[i * 3]); dy = __fsub_rn(P.xyz2[nb * 3 + 1], P.xyz1[i * 3 + 1]);
         dz = __fsub_rn(P.xyz2[nb * 3 + 2], P.xyz1[i * 3 + 2]);
     }
     for (int G = bx; G < groups; G += nbx) {
         asm volatile("" ::: "memory");
-        // the next tile's neighbour index (wave-uniform condition)
-        const int Gn = G + nbx;
-        const bool more = Gn < groups;
-        const int ptn = Gn * PPW + 2 * wave + pp;
-        const bool validn = ptn < P.n1;
-        const long in_ = (long)b * P.n1 + (validn ? ptn : P.n1 - 1);
-        long knn_next = 0;
-        if (more) knn_next = (long)P.knn[in_ * 16 + j];
         // layer 1: leaky(p1[i] + p2[nb] + Wd.d)     (bias folded into p1)
         f4 h[32];
         {
+            const float *r1 = P.p1 + i * 256 + 4 * hh, *r2 = P.p2 + nb * 256 + 4 * hh;
             const float b0 = hh ? dy : dx, b1 = hh ? 0.f : dz;      // B[k = hh][col] of the two k-steps (k = 3: the zero column)
-            cv_rows_read<0>(rows, col, hh, h);
-            cv_rows_request<1>(P.p2, (int)nb, rows, lane);
-            cv_layer1_blocks<0, 4>(P, q0, q1, b0, b1, hh, col, h);
-            __builtin_amdgcn_sched_barrier(0);      // (round 1's reads wait for the DMA: hipcc would hoist them, and the wait, above the four blocks)
-            cv_rows_read<1>(rows, col, hh, h);
-            cv_layer1_blocks<4, 8>(P, q0, q1, b0, b1, hh, col, h);
+#pragma unroll
+            for (int v = 0; v < SPLIT_VB; ++v) {
+                f16v c;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f4 t = *reinterpret_cast<const f4 *>(r1 + 32 * v + 8 * q) + *reinterpret_cast<const f4 *>(r2 + 32 * v + 8 * q);
+                    c[4 * q] = t.x; c[4 * q + 1] = t.y; c[4 * q + 2] = t.z; c[4 * q + 3] = t.w;
+                }
+                const int ch = 32 * v + col;                         // A[i = col][k = hh]
+                const float *wr = P.wd + (ch >> 4) * 64 + (ch & 15);
+                c = mfma_f32x2(wr[16 * hh], b0, c);
+                c = mfma_f32x2(wr[16 * (2 + hh)], b1, c);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) h[4 * v + q] = leaky4((f4){c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]});
+            }
         }
-        const long nbn = (long)b * P.n2 + knn_next;       // (no next tile: row 0 of the sample, requested and never read)
         // byte offset of this lane's first 16-byte slot in a (position, 256) row (one 32-bit VGPR on uniform base pointers)
         const long pos = i * 16 + j;
         const unsigned ro = (unsigned)pos * 1024u + 16u * hh;
@@ -364,8 +238,8 @@ void cost_volume_split_kernel(const CvSplitParams P) {
         f16v acc[SPLIT_VB];
 #pragma unroll
         for (int v = 0; v < SPLIT_VB; ++v) acc[v] = split_bias(P.bias2, v, hh);
-        // a1 goes out while it is being consumed; the next tile's first round of rows is requested
-        split_layer<0>(ws, h, acc, CvLayer2Side<SAVE>{StoreRowsSide{P.sv1, ro, valid}, CvRowsRequest(P.p2, rows, (int)nbn, 0, lane)});
+        if (SAVE) split_layer<0>(ws, h, acc, StoreRowsSide{P.sv1, ro, valid});      // a1 goes out while it is being consumed
+        else split_layer<0>(ws, h, acc);
 #pragma unroll
         for (int v = 0; v < SPLIT_VB; ++v)
 #pragma unroll
@@ -381,6 +255,14 @@ void cost_volume_split_kernel(const CvSplitParams P) {
         if (SAVE) split_layer<SPLIT_NF>(ws, h, acc, StoreRowsSide{P.sv2, ro, valid});
         else split_layer<SPLIT_NF>(ws, h, acc);
         ws.sync();                                                   // wrap the stream to chunk 0
+        // ---- next tile, first request: its neighbour index (wave-uniform condition) -------------------------------------
+        const int Gn = G + nbx;
+        const bool more = Gn < groups;
+        const int ptn = Gn * PPW + 2 * wave + pp;
+        const bool validn = ptn < P.n1;
+        const long in_ = (long)b * P.n1 + (validn ? ptn : P.n1 - 1);
+        long knn_next = 0;
+        if (more) knn_next = (long)P.knn[in_ * 16 + j];
         if (SAVE && valid) {
 #pragma unroll
             for (int v = 0; v < SPLIT_VB; ++v)
@@ -388,44 +270,34 @@ void cost_volume_split_kernel(const CvSplitParams P) {
                 for (int q = 0; q < 4; ++q)
                     *cv_at(P.sv3, ro + 32u * (4 * v + q)) = leaky4((f4){acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]});
         }
-        WnBlock wk = wn_block(P.wn, 0, hh, col);                     // block 0's operands travel during the hidden layers
         float t2[8];
         wn_hidden(P.wn, dx, dy, dz, t2);
-        // out[i] = sum over the 16 neighbours of relu(Wc.t2 + bc) * a3, one 32-channel block at a time; block v + 1's four
-        // dependent MFMAs (K = 8 in steps of 2) run under block v's VALU / DPP work, block v + 2's operands travel meanwhile
+        // out[i] = sum over the 16 neighbours of relu(Wc.t2 + bc) * a3, one 32-channel block at a time
         float *o = P.out + i * P.out_pitch + 4 * hh;
-        f16v wpre = wn_pre(wk, hh, t2);
-        wk = wn_block(P.wn, 1, hh, col);
         auto out_block = [&](int v) {
-            const f16v w = wpre;
-            if (v + 1 < SPLIT_VB) wpre = wn_pre(wk, hh, t2);
-            if (v + 2 < SPLIT_VB) wk = wn_block(P.wn, v + 2, hh, col);
-            f4 r[4];
+            const f16v w = wn_out(P.wn, v, hh, col, t2);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                f4 r;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) r[q][e] = relu1(w[4 * q + e]) * leaky1(acc[v][4 * q + e]);
-                row_sum16_valu_f4(r[q]);
-            }
-            if (valid && j == 0) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) *reinterpret_cast<f4 *>(o + 32 * v + 8 * q) = r[q];
+                for (int e = 0; e < 4; ++e) r[e] = w[4 * q + e] * fmaxf(acc[v][4 * q + e], 0.1f * acc[v][4 * q + e]);
+                row_sum16_f4(r);
+                if (valid && j == 0) *reinterpret_cast<f4 *>(o + 32 * v + 8 * q) = r;
             }
         };
         out_block(0);
         out_block(1);
-        // ---- next tile: its direction and its p1 slots -------------------------------------------------------------------------
-        float cn[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};              // the six coordinates; subtracted after the last block (the
-        f4 q0n = q0, q1n = q1;                                        // subtraction is where the wave waits for them)
+        // ---- next tile, second request: its direction ---------------------------------------------------------------------------
+        long nbn = 0;
+        float dxn = 0.f, dyn = 0.f, dzn = 0.f;
         if (more) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { cn[c] = ldc(P.xyz2 + nbn * 3 + c); cn[3 + c] = ldc(P.xyz1 + in_ * 3 + c); }
-            q0n = ldc4(P.p1 + in_ * 256 + 4 * hh + 8 * j); q1n = ldc4(P.p1 + in_ * 256 + 4 * hh + 8 * (16 + j));
+            nbn = (long)b * P.n2 + knn_next;
+            dxn = __fsub_rn(P.xyz2[nbn * 3], P.xyz1[in_ * 3]); dyn = __fsub_rn(P.xyz2[nbn * 3 + 1], P.xyz1[in_ * 3 + 1]);
+            dzn = __fsub_rn(P.xyz2[nbn * 3 + 2], P.xyz1[in_ * 3 + 2]);
         }
 #pragma unroll
         for (int v = 2; v < SPLIT_VB; ++v) out_block(v);
-        pt = ptn; valid = validn; i = in_; nb = nbn; q0 = q0n; q1 = q1n;
-        dx = __fsub_rn(cn[0], cn[3]); dy = __fsub_rn(cn[1], cn[4]); dz = __fsub_rn(cn[2], cn[5]);
+        pt = ptn; valid = validn; i = in_; nb = nbn; dx = dxn; dy = dyn; dz = dzn;
     }
     ws.finish();
 }
@@ -735,7 +607,6 @@ static int cv_split_forward(const char *who, int samples, int n1, int n2, const 
     dim3 grid;
     if (cv_split_fill(who, P, samples, n1, n2, xyz1, xyz2, knn_idx, split_images, wn, grid) != RTK_OK) return RTK_ERR_INVALID;
     RTK_REQUIRE(p1 && p2 && wd_packed && bias2 && bias3 && out, "%s: bad arguments", who);
-    RTK_REQUIRE((double)samples * n2 <= 4194304.0, "%s: more than 2^22 rows in p2 (32-bit byte offsets of the row requests): split the batch", who);
     RTK_REQUIRE(out_pitch % 4 == 0 && out_pitch >= 256, "%s: bad out_pitch", who);
     const bool save = a1 != nullptr;
     RTK_REQUIRE(!save || ((double)samples * n1 * 16.0 * 1024.0 < 4294967296.0), "%s: more than 4 GiB per saved activation (32-bit row "

@@ -39,10 +39,9 @@ __device__ __forceinline__ void split3_word(const f4 x0, const f4 x1, u4v (&b)[3
     b[2][W] = pack_hi16(sa, sb);
 }
 
-// A chunk of F fragments is F / 6 group steps; the requests for the chunk after it go out during the first split_issue_groups(F)
-// of them (the last ones must be old enough at the chunk's closing vmcnt(0) to have made their L2 round trip): three of eight
-// (F = 48), two of four (F = 24).
-constexpr int split_issue_groups(int F) { return F / 6 > 4 ? 3 : 2; }
+#ifndef SPLIT_ISSUE_GROUPS
+#define SPLIT_ISSUE_GROUPS 3
+#endif
 constexpr int SPLIT_KS = 16;      // k-steps of a 256-channel contraction
 constexpr int SPLIT_VB = 8;       // 32-row output blocks of a 256-channel layer
 constexpr int SPLIT_NF = SPLIT_KS * SPLIT_VB * 3;      // fragments (KiB) of one 256 x 256 layer
@@ -146,7 +145,9 @@ struct SplitStep {
         constexpr int f0 = FBASE + GJ * 6;      // F % 6 == 0: a group never straddles two chunks
         if constexpr (PART == 0) {
             if constexpr (f0 % F == 0 && f0 != 0) ws.sync();
-            if constexpr ((f0 % F) / 6 < split_issue_groups(F)) ws.template issue_part<(f0 % F) / 6, split_issue_groups(F)>();
+            // the requests go out during the first SPLIT_ISSUE_GROUPS group steps of a chunk (the last ones must be old enough at
+            // the next sync() to have made their L2 round trip)
+            if constexpr ((f0 % F) / 6 < SPLIT_ISSUE_GROUPS) ws.template issue_part<(f0 % F) / 6, SPLIT_ISSUE_GROUPS>();
         }
         dst[2 * PART] = ws.template frag_async<(f0 + 2 * PART) % F>();
         dst[2 * PART + 1] = ws.template frag_async<(f0 + 2 * PART + 1) % F>();
@@ -211,18 +212,12 @@ __device__ __forceinline__ void split_layer(WStreamA<NW, F, NF> &ws, const f4 (&
     split_layer_impl<FBASE, WStreamA<NW, F, NF>, F, Side>(ws, h, acc, side, std::make_integer_sequence<int, SPLIT_KS * (SPLIT_VB / 2)>{});
 }
 
-// Loads of kernel-lifetime constants (weights, biases) through the constant address space: the compiler may move them over the
-// kernel's stores (a plain global load stays behind every store it might alias -- in the cost volume's epilogue that put one exposed
-// L2 round trip in front of each of the eight output blocks) and turns the wave-uniform ones into scalar loads.
-__device__ __forceinline__ float ldc(const float *p) { return *(const __attribute__((address_space(4))) float *)p; }
-__device__ __forceinline__ f4 ldc4(const float *p) { return *(const __attribute__((address_space(4))) f4 *)p; }
-
 // this lane's bias for output block v: channels 32 v + 8 q + 4 hh + r
 __device__ __forceinline__ f16v split_bias(const float *__restrict__ bias, int v, int hh) {
     f16v o;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f4 t = ldc4(bias + 32 * v + 8 * q + 4 * hh);
+        const f4 t = *reinterpret_cast<const f4 *>(bias + 32 * v + 8 * q + 4 * hh);
         o[4 * q] = t.x; o[4 * q + 1] = t.y; o[4 * q + 2] = t.z; o[4 * q + 3] = t.w;
     }
     return o;

@@ -3,6 +3,10 @@
 #include "rtk_fused.h"
 #include "split_mfma.h"
 
+__device__ unsigned long long g_cv_ticks[1024 * 16];
+#define CV_TICK(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); tk[k] += t_ - tprev; tprev = t_; \
+                     __builtin_amdgcn_sched_barrier(0); }
+
 namespace {
 
 #ifndef SP_NW
@@ -11,10 +15,6 @@ namespace {
 #ifndef SP_F
 #define SP_F 48           // fragments (KiB) per half of the LDS double buffer: a multiple of 6 (one group step)
 #endif
-// The forward cost volume streams in halves of 24 KiB (four group steps per chunk: the kernel's clock count is the same as with 48
-// -- tools/experiments/cv_ticks.py --totals-only: 685.6 k against 688.7 k --, chunk boundaries cost nothing measurable), which leaves
-// LDS for the staged rows of layer 1 AND for the small geometry kernels of the other batches in flight on the same CU.
-constexpr int CV_F = 24;
 
 // ---- packing: (256 x 256) row-major fp32 weights -> split image (split_mfma.h) ---------------------------------------------
 __global__ __launch_bounds__(256) void pack_split_kernel(int cout, int cin, const float *__restrict__ w, int transposed, u4v *__restrict__ out) {
@@ -203,8 +203,8 @@ __device__ __forceinline__ f4 leaky4(f4 t) { return (f4){leaky1(t.x), leaky1(t.y
 // while it is still in flight -- fetched again (tools/experiments/cv_ticks.py: 12 k of a tile's 86 k clocks went into layer 1, 6 k
 // of them gone when every lane reads the same row).  So the rows come through LDS instead: one global_load_lds per two positions
 // moves 2 x 512 contiguous bytes (channels 128 HALF .. 128 HALF + 127 of both rows) into the wave's own 16 KiB of LDS, every line
-// fetched once, and the lanes read their slots from there.  Two rounds per tile (HALF = 0, 1: 64 KiB per workgroup next to the
-// weight stream's 48, so that a CU keeps 48 KiB for other kernels' workgroups); round 0 of the NEXT tile is requested right after layer 1 and lands under layers 2 and 3.
+// fetched once, and the lanes read their slots from there.  Two rounds per tile (HALF = 0, 1: the LDS next to the weight stream's
+// 96 KiB holds half a tile's rows); round 0 of the NEXT tile is requested right after layer 1 and lands under layers 2 and 3.
 // Slot p of a position's 512 bytes holds source chunk p ^ (position & 15): the 16 lanes that read together (one hh, 16 positions)
 // then hit 16 different bank groups.
 constexpr int CV_ROWS_F4 = 32 * 32;      // f4 per wave: 32 positions x 32 slots of 16 bytes
@@ -242,8 +242,8 @@ struct CvLayer2Side {
     template <int GI>
     __device__ __forceinline__ void at(const f4 (&h)[32]) const {
         if constexpr (SAVE) st.template at<GI>(h);
-        constexpr int per_chunk = CV_F / 6, ig = split_issue_groups(CV_F), g = GI % per_chunk, n = (GI / per_chunk) * ig + g;
-        if constexpr (g < ig && 3 * n < 16) {
+        constexpr int per_chunk = SP_F / 6, g = GI % per_chunk, n = (GI / per_chunk) * SPLIT_ISSUE_GROUPS + g;
+        if constexpr (g < SPLIT_ISSUE_GROUPS && 3 * n < 16) {
             rq.template one<3 * n>();
             if constexpr (3 * n + 1 < 16) rq.template one<3 * n + 1>();
             if constexpr (3 * n + 2 < 16) rq.template one<3 * n + 2>();
@@ -303,7 +303,7 @@ __device__ __forceinline__ void cv_layer1_blocks(const CvSplitParams &P, const f
 template <bool SAVE>
 __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1), amdgpu_num_vgpr(CV_FWD_VGPRS)))
 void cost_volume_split_kernel(const CvSplitParams P) {
-    __shared__ __attribute__((aligned(16))) f4 s_w[2 * CV_F * 64];
+    __shared__ __attribute__((aligned(16))) f4 s_w[2 * SP_F * 64];
     __shared__ __attribute__((aligned(16))) f4 s_rows[SP_NW * CV_ROWS_F4];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hh = lane >> 5, col = lane & 31, pp = col >> 4,
               j = col & 15;      // wave index in an SGPR: the DMA's LDS destination (M0) is then scalar arithmetic
@@ -312,7 +312,7 @@ void cost_volume_split_kernel(const CvSplitParams P) {
     rtk_decode_block(P.gx, b, bx, nbx);
     constexpr int PPW = 2 * SP_NW;                                  // points per workgroup iteration
     const int groups = (P.n1 + PPW - 1) / PPW;
-    WStreamA<SP_NW, CV_F, 2 * SPLIT_NF> ws;
+    WStreamA<SP_NW, SP_F, 2 * SPLIT_NF> ws;
     ws.start_parts(P.blob, s_w, wave, lane);
     // The tile loop is software-pipelined by one tile (round 4): the NEXT tile's neighbour index is requested at the top of the
     // CURRENT tile, the first half of its gathered rows (cv_rows_request<0>) right after layer 1, its direction and its two p1 slots
@@ -330,8 +330,10 @@ void cost_volume_split_kernel(const CvSplitParams P) {
         dx = __fsub_rn(P.xyz2[nb * 3], P.xyz1[i * 3]); dy = __fsub_rn(P.xyz2[nb * 3 + 1], P.xyz1[i * 3 + 1]);
         dz = __fsub_rn(P.xyz2[nb * 3 + 2], P.xyz1[i * 3 + 2]);
     }
+    unsigned long long tk[16] = {}, tprev = __builtin_readcyclecounter(), t00 = tprev, w00 = wall_clock64();
     for (int G = bx; G < groups; G += nbx) {
         asm volatile("" ::: "memory");
+        CV_TICK(0)
         // the next tile's neighbour index (wave-uniform condition)
         const int Gn = G + nbx;
         const bool more = Gn < groups;
@@ -352,7 +354,7 @@ void cost_volume_split_kernel(const CvSplitParams P) {
             cv_layer1_blocks<4, 8>(P, q0, q1, b0, b1, hh, col, h);
         }
         const long nbn = (long)b * P.n2 + knn_next;       // (no next tile: row 0 of the sample, requested and never read)
-        // byte offset of this lane's first 16-byte slot in a (position, 256) row (one 32-bit VGPR on uniform base pointers)
+        CV_TICK(1)
         const long pos = i * 16 + j;
         const unsigned ro = (unsigned)pos * 1024u + 16u * hh;
         if (SAVE && valid) {
@@ -366,6 +368,7 @@ void cost_volume_split_kernel(const CvSplitParams P) {
         for (int v = 0; v < SPLIT_VB; ++v) acc[v] = split_bias(P.bias2, v, hh);
         // a1 goes out while it is being consumed; the next tile's first round of rows is requested
         split_layer<0>(ws, h, acc, CvLayer2Side<SAVE>{StoreRowsSide{P.sv1, ro, valid}, CvRowsRequest(P.p2, rows, (int)nbn, 0, lane)});
+        CV_TICK(2)
 #pragma unroll
         for (int v = 0; v < SPLIT_VB; ++v)
 #pragma unroll
@@ -378,9 +381,12 @@ void cost_volume_split_kernel(const CvSplitParams P) {
         }
 #pragma unroll
         for (int v = 0; v < SPLIT_VB; ++v) acc[v] = split_bias(P.bias3, v, hh);
+        CV_TICK(3)
         if (SAVE) split_layer<SPLIT_NF>(ws, h, acc, StoreRowsSide{P.sv2, ro, valid});
         else split_layer<SPLIT_NF>(ws, h, acc);
-        ws.sync();                                                   // wrap the stream to chunk 0
+        CV_TICK(4)
+        ws.sync();
+        CV_TICK(5)                                                   // wrap the stream to chunk 0
         if (SAVE && valid) {
 #pragma unroll
             for (int v = 0; v < SPLIT_VB; ++v)
@@ -393,6 +399,7 @@ void cost_volume_split_kernel(const CvSplitParams P) {
         wn_hidden(P.wn, dx, dy, dz, t2);
         // out[i] = sum over the 16 neighbours of relu(Wc.t2 + bc) * a3, one 32-channel block at a time; block v + 1's four
         // dependent MFMAs (K = 8 in steps of 2) run under block v's VALU / DPP work, block v + 2's operands travel meanwhile
+        CV_TICK(6)
         float *o = P.out + i * P.out_pitch + 4 * hh;
         f16v wpre = wn_pre(wk, hh, t2);
         wk = wn_block(P.wn, 1, hh, col);
@@ -413,7 +420,9 @@ void cost_volume_split_kernel(const CvSplitParams P) {
             }
         };
         out_block(0);
+        CV_TICK(7)
         out_block(1);
+        CV_TICK(8)
         // ---- next tile: its direction and its p1 slots -------------------------------------------------------------------------
         float cn[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};              // the six coordinates; subtracted after the last block (the
         f4 q0n = q0, q1n = q1;                                        // subtraction is where the wave waits for them)
@@ -422,12 +431,17 @@ void cost_volume_split_kernel(const CvSplitParams P) {
             for (int c = 0; c < 3; ++c) { cn[c] = ldc(P.xyz2 + nbn * 3 + c); cn[3 + c] = ldc(P.xyz1 + in_ * 3 + c); }
             q0n = ldc4(P.p1 + in_ * 256 + 4 * hh + 8 * j); q1n = ldc4(P.p1 + in_ * 256 + 4 * hh + 8 * (16 + j));
         }
+        CV_TICK(9)
 #pragma unroll
         for (int v = 2; v < SPLIT_VB; ++v) out_block(v);
+        CV_TICK(10)
         pt = ptn; valid = validn; i = in_; nb = nbn; q0 = q0n; q1 = q1n;
         dx = __fsub_rn(cn[0], cn[3]); dy = __fsub_rn(cn[1], cn[4]); dz = __fsub_rn(cn[2], cn[5]);
+        CV_TICK(11)
     }
     ws.finish();
+    tk[14] = __builtin_readcyclecounter() - t00; tk[15] = wall_clock64() - w00;
+    if (lane == 0) for (int k = 0; k < 16; ++k) g_cv_ticks[(blockIdx.x * SP_NW + wave) * 16 + k] = tk[k];
 }
 
 // ---- rtk_cost_volume_bwd on the split path ------------------------------------------------------------------------------
@@ -813,4 +827,8 @@ extern "C" int rtk_sa_scale_split(int samples, int n, int npoint, int nsample, c
     }
     RTK_CHECK_LAUNCH("sa_scale_split");
     return RTK_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int rtk_dbg_cv_ticks(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cv_ticks), sizeof(g_cv_ticks));
 }
