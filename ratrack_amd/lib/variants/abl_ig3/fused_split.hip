@@ -3,10 +3,6 @@
 #include "rtk_fused.h"
 #include "split_mfma.h"
 
-__device__ unsigned long long g_cv_ticks[1024 * 16];
-#define CV_TICK(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); tk[k] += t_ - tprev; tprev = t_; \
-                     __builtin_amdgcn_sched_barrier(0); }
-
 namespace {
 
 #ifndef SP_NW
@@ -334,10 +330,8 @@ void cost_volume_split_kernel(const CvSplitParams P) {
         dx = __fsub_rn(P.xyz2[nb * 3], P.xyz1[i * 3]); dy = __fsub_rn(P.xyz2[nb * 3 + 1], P.xyz1[i * 3 + 1]);
         dz = __fsub_rn(P.xyz2[nb * 3 + 2], P.xyz1[i * 3 + 2]);
     }
-    unsigned long long tk[16] = {}, tprev = __builtin_readcyclecounter(), t00 = tprev, w00 = wall_clock64();
     for (int G = bx; G < groups; G += nbx) {
         asm volatile("" ::: "memory");
-        CV_TICK(0)
         // the next tile's neighbour index (wave-uniform condition)
         const int Gn = G + nbx;
         const bool more = Gn < groups;
@@ -434,8 +428,6 @@ void cost_volume_split_kernel(const CvSplitParams P) {
         dx = __fsub_rn(cn[0], cn[3]); dy = __fsub_rn(cn[1], cn[4]); dz = __fsub_rn(cn[2], cn[5]);
     }
     ws.finish();
-    tk[14] = __builtin_readcyclecounter() - t00; tk[15] = wall_clock64() - w00;
-    if (lane == 0) for (int k = 0; k < 16; ++k) g_cv_ticks[(blockIdx.x * SP_NW + wave) * 16 + k] = tk[k];
 }
 
 // ---- rtk_cost_volume_bwd on the split path ------------------------------------------------------------------------------
@@ -821,8 +813,4 @@ extern "C" int rtk_sa_scale_split(int samples, int n, int npoint, int nsample, c
     }
     RTK_CHECK_LAUNCH("sa_scale_split");
     return RTK_OK;
-}
-
-extern "C" __attribute__((visibility("default"))) int rtk_dbg_cv_ticks(unsigned long long *out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cv_ticks), sizeof(g_cv_ticks));
 }
