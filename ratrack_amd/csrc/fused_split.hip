@@ -270,6 +270,19 @@ __device__ __forceinline__ f4 add_row_bcast(const f4 q, const f4 r) {
         : "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w), "v"(r.x), "v"(r.y), "v"(r.z), "v"(r.w), "n"(K));
     return o;
 }
+// r * q as held by lane K of this lane's row of 16 (the backward's dout row: the same for a point's 16 neighbours)
+template <int K>
+__device__ __forceinline__ f4 mul_row_bcast(const f4 q, const f4 r) {
+    f4 o;
+    asm("s_nop 1\n"
+        "v_mul_f32_dpp %0, %4, %8 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n"
+        "v_mul_f32_dpp %1, %5, %9 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n"
+        "v_mul_f32_dpp %2, %6, %10 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n"
+        "v_mul_f32_dpp %3, %7, %11 row_newbcast:%12 row_mask:0xf bank_mask:0xf"
+        : "=&v"(o.x), "=&v"(o.y), "=&v"(o.z), "=&v"(o.w)
+        : "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w), "v"(r.x), "v"(r.y), "v"(r.z), "v"(r.w), "n"(K));
+    return o;
+}
 template <int V0, int V1>
 __device__ __forceinline__ void cv_layer1_blocks(const CvSplitParams &P, const f4 q0, const f4 q1, float b0, float b1, int hh, int col, f4 (&h)[32]) {
     static_assert(V1 <= 8, "eight 32-channel blocks");
@@ -480,41 +493,60 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
         const unsigned ro = (unsigned)pos * 1024u + 16u * hh;
         if (valid && hh == 0) *reinterpret_cast<f4 *>(Q.d4 + pos * 4) = (f4){dx, dy, dz, 1.0f};
         uint2 m2[2] = {Q.mk2[pos * 4 + hh], Q.mk2[pos * 4 + 2 + hh]}, m1[2] = {Q.mk1[pos * 4 + hh], Q.mk1[pos * 4 + 2 + hh]};
+        // a3 = leaky(z3).  (Through LDS as the forward's p2 rows -- whole lines, once -- the phase gains 3.6 k clocks per tile and the
+        // two layers lose 6 k: next to this kernel's 32 KiB Wc^T image the rows only fit with 24 KiB halves of the weight buffer,
+        // whose twice as many chunk boundaries each wait for the dz stores in flight; and the next tile's rows come from HBM, not L2:
+        // requested as a layer's side job they are too young at three boundaries in a row: +9 k.  Not kept.)
         f4 h[32];
 #pragma unroll
-        for (int e = 0; e < 32; ++e) h[e] = *cv_at(Q.a3, ro + 32u * e);          // a3 = leaky(z3)
+        for (int e = 0; e < 32; ++e) h[e] = *cv_at(Q.a3, ro + 32u * e);
         // ---- out = sum_k wn * a3:  dz3 = dout wn leaky'(z3),  dq3 = dout a3 [wn > 0],  dt2 = Wc^T dq3 -------------------------
         float t2[8];
-        wn_hidden(P.wn, dx, dy, dz, t2);
+        WnBlock wk = wn_block(P.wn, 0, hh, col);
+        // the dout row of a point is the same for its 16 neighbours: each of them loads two of its 32 slots, the products take the
+        // owner's copy through DPP (mul_row_bcast)
         const float *dor = Q.dout + i * Q.dout_pitch + 4 * hh;
+        const f4 dq0 = ldc4(dor + 8 * j), dq1 = ldc4(dor + 8 * (16 + j));
+        wn_hidden(P.wn, dx, dy, dz, t2);
         f16v dt2;
 #pragma unroll
         for (int e = 0; e < 16; ++e) dt2[e] = 0.f;
+        f16v wpre = wn_pre(wk, hh, t2);
+        wk = wn_block(P.wn, 1, hh, col);
+        auto block_a = [&](auto vc) {
+            constexpr int v = decltype(vc)::value;
+            const f16v w = wpre;                                     // block v + 1's four MFMAs and block v + 2's operands travel under block v
+            if constexpr (v + 1 < SPLIT_VB) wpre = wn_pre(wk, hh, t2);
+            if constexpr (v + 2 < SPLIT_VB) wk = wn_block(P.wn, v + 2, hh, col);
+            auto slot = [&](auto qc) {
+                constexpr int q = decltype(qc)::value, e = 4 * v + q;
+                const f4 a = h[e];
+                f4 wv;
 #pragma unroll
-        for (int v = 0; v < SPLIT_VB; ++v) {
-            const f16v w = wn_out(P.wn, v, hh, col, t2);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f4 d = *reinterpret_cast<const f4 *>(dor + 32 * v + 8 * q);
-                const f4 a = h[4 * v + q];
+                for (int r = 0; r < 4; ++r) wv[r] = relu1(w[4 * q + r]);
+                const f4 da = mul_row_bcast<e & 15>(e < 16 ? dq0 : dq1, a);       // d * a
+                const f4 t = mul_row_bcast<e & 15>(e < 16 ? dq0 : dq1, wv);       // d * relu(w)   (== d * w wherever w > 0, +-0 elsewhere)
                 f4 qq, z;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float wv = w[4 * q + r];
-                    qq[r] = wv > 0.f ? d[r] * a[r] : 0.f;
-                    const float t = d[r] * wv;
-                    z[r] = a[r] > 0.f ? t : 0.1f * t;
+                    qq[r] = wv[r] > 0.f ? da[r] : 0.f;
+                    z[r] = a[r] > 0.f ? t[r] : 0.1f * t[r];
                     dt2 = mfma_f32x2(s_wct[(16 * v + 4 * q + r) * 64 + lane], qq[r], dt2);
                 }
-                h[4 * v + q] = z;
-                if (valid) *cv_at(Q.dq3, ro + 32u * (4 * v + q)) = qq;       // (dz3 goes out during the product that consumes it)
+                h[e] = z;
+                if (valid) *cv_at(Q.dq3, ro + 32u * e) = qq;       // (dz3 goes out during the product that consumes it)
                 if (Q.dbrows) {                      // (uniform) per-query neighbour sum: the host's bias sum shrinks 16x
                     f4 r = z;
-                    row_sum16_f4(r);
+                    row_sum16_valu_f4(r);
                     if (valid && j == 0) *reinterpret_cast<f4 *>(Q.dbrows + i * 512 + 32 * v + 8 * q + 4 * hh) = r;
                 }
-            }
-        }
+            };
+            slot(std::integral_constant<int, 0>{}); slot(std::integral_constant<int, 1>{});
+            slot(std::integral_constant<int, 2>{}); slot(std::integral_constant<int, 3>{});
+        };
+        block_a(std::integral_constant<int, 0>{}); block_a(std::integral_constant<int, 1>{}); block_a(std::integral_constant<int, 2>{});
+        block_a(std::integral_constant<int, 3>{}); block_a(std::integral_constant<int, 4>{}); block_a(std::integral_constant<int, 5>{});
+        block_a(std::integral_constant<int, 6>{}); block_a(std::integral_constant<int, 7>{});
         if (valid) *reinterpret_cast<f4 *>(Q.dt2 + pos * 8 + 4 * hh) = (f4){dt2[0], dt2[1], dt2[2], dt2[3]};      // rows 4 hh .. + 3 of the 8 hidden units
         // ---- da2 = W3^T dz3;  dz2 = da2 leaky'(z2) ----------------------------------------------------------------------------
         f16v acc[SPLIT_VB];
@@ -531,7 +563,7 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
                 h[4 * v + q] = z;
                 if (Q.dbrows) {
                     f4 r = z;
-                    row_sum16_f4(r);
+                    row_sum16_valu_f4(r);
                     if (valid && j == 0) *reinterpret_cast<f4 *>(Q.dbrows + i * 512 + 256 + 32 * v + 8 * q + 4 * hh) = r;
                 }
             }
@@ -565,10 +597,10 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
                 f4 r = leaky_grad_bits4((f4){acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]}, split_mask_bits(m1, v, q));
                 if (valid) *cv_at(Q.dz1, ro + 32u * (4 * v + q)) = r;
                 f4 rx = r * dx, ry = r * dy, rz = r * dz;
-                row_sum16_f4(r);
-                row_sum16_f4(rx);
-                row_sum16_f4(ry);
-                row_sum16_f4(rz);
+                row_sum16_valu_f4(r);
+                row_sum16_valu_f4(rx);
+                row_sum16_valu_f4(ry);
+                row_sum16_valu_f4(rz);
                 if (valid && j == 0) {
                     *reinterpret_cast<f4 *>(dpr + 32 * v + 8 * q) = r;
                     *reinterpret_cast<f4 *>(dpd + 32 * v + 8 * q) = rx;
