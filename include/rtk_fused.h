@@ -115,7 +115,8 @@ RTK_EXPORT int rtk_patch_cost(int samples, int n, const float *xyz, const int64_
  * standalone operator: what tests and tools time the matrix path with. */
 RTK_EXPORT int rtk_pack_split_layer(int cout, int cin, const float *w, int transposed, void *image, rtk_stream_t stream);
 /* rtk_cost_volume with its two 256 x 256 layers on the split path: same arguments, the layers as their split images (W2, W3
- * back to back, 2 * 393216 bytes) and fp32 biases instead of the packed rtk_layer_t pair. */
+ * back to back, 2 * 393216 bytes) and fp32 biases instead of the packed rtk_layer_t pair.  samples * n2 <= 2^22 (the gathered
+ * p2 rows are requested with 32-bit byte offsets; RTK_ERR_INVALID beyond: split the batch). */
 RTK_EXPORT int rtk_cost_volume_split(int samples, int n1, int n2, const float *xyz1, const float *xyz2,
                                      const int64_t *knn_idx, const float *p1, const float *p2, const float *wd_packed,
                                      const void *split_images, const float *bias2, const float *bias3,

@@ -149,6 +149,17 @@ struct WStream {
         __syncthreads();
         if (NCHUNKS > 1) issue(1, 1);
     }
+    // start() without its wait: chunk 0 is requested and the state is that of a stream whose previous pass has just ended (last
+    // chunk current, chunk 0 on its way into the other half), so that the caller's first next() -- placed AFTER it has issued its own
+    // first loads -- does the waiting: one round trip for the weights and the tile's inputs together instead of two in a row.
+    __device__ __forceinline__ void start_deferred(const f4 *blob_, f4 *lds_, int wave_, int lane_) {
+        static_assert(NCHUNKS > 1, "a blob of one chunk stays resident: start()");
+        lds = lds_; wave = wave_; lane = lane_;
+        blob = reinterpret_cast<const char *>(blob_);
+        lane_off = (unsigned)(wave * 64 + lane) * 16u;
+        cur = NCHUNKS - 1; buf = 1;
+        issue(0, 0);
+    }
     // move from the resident chunk to the next one (cyclic)
     __device__ __forceinline__ void next() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

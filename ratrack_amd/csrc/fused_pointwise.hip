@@ -107,8 +107,12 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void pointwise_mlp_kernel(const PwPa
     constexpr int F1 = SPLIT ? split16_nf(U, V1) : U * V1, F2 = SPLIT ? split16_nf(V1, V2) : V1 * V2,
                   F3 = SPLIT ? split16_nf(V2, V3) : V2 * V3, F4 = SPLIT ? split16_nf(V3, V4) : V3 * V4;
     constexpr int NF = F1 + F2 + F3 + F4;
+    // A blob of several chunks: the stream is entered at the top of every tile AFTER the tile's input loads have been issued (the
+    // wrap to chunk 0 -- for the first tile: the arrival of chunk 0 -- and those loads then share one round trip; most workgroups
+    // have exactly one tile, and the two round trips in a row were 1-2 us of a 10-25 us launch).
     WStream<PW_NW, PW_F, NF> ws;
-    ws.start(reinterpret_cast<const f4 *>(P.layer[0].w_packed), s_w, wave_in_wg, lane);
+    if constexpr (NF > PW_F) ws.start_deferred(reinterpret_cast<const f4 *>(P.layer[0].w_packed), s_w, wave_in_wg, lane);
+    else ws.start(reinterpret_cast<const f4 *>(P.layer[0].w_packed), s_w, wave_in_wg, lane);
 
     // 16-channel slot where each segment starts (wave-uniform)
     int ustart[RTK_MAX_SRC + 1];
@@ -188,6 +192,7 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void pointwise_mlp_kernel(const PwPa
         // ---- layer chain ------------------------------------------------------------------------------
         f4 a1[V1];
         init_bias<V1>(a1, P.layer[0].bias, g);
+        if constexpr (NF > PW_F) ws.next();      // chunk 0 (its request has been travelling with the loads above)
         if (P.sample_bias) {
             const float *sb = P.sample_bias + (size_t)b * 16 * V1;
 #pragma unroll
@@ -224,7 +229,6 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void pointwise_mlp_kernel(const PwPa
                 }
             }
         }
-        if (NF > PW_F) ws.next();   // wrap the weight stream around to chunk 0 for the next tile
     }
     ws.finish();
 }
