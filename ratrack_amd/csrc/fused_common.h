@@ -386,6 +386,24 @@ __device__ __forceinline__ void row_sum16_valu_f4(f4 &v) {
                  : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
 }
 
+// ... four of them at once, step by step over all sixteen registers: a rotation step's result is the next step's operand, and with
+// one f4 at a time the dependent DPP instructions are four apart -- closer than the cross-lane path's latency.
+#define RTK_DPP16(op, ctrl)                                                                                                          \
+    op " %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n" op " %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n"                   \
+    op " %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n" op " %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf\n"                   \
+    op " %4, %4, %4 " ctrl " row_mask:0xf bank_mask:0xf\n" op " %5, %5, %5 " ctrl " row_mask:0xf bank_mask:0xf\n"                   \
+    op " %6, %6, %6 " ctrl " row_mask:0xf bank_mask:0xf\n" op " %7, %7, %7 " ctrl " row_mask:0xf bank_mask:0xf\n"                   \
+    op " %8, %8, %8 " ctrl " row_mask:0xf bank_mask:0xf\n" op " %9, %9, %9 " ctrl " row_mask:0xf bank_mask:0xf\n"                   \
+    op " %10, %10, %10 " ctrl " row_mask:0xf bank_mask:0xf\n" op " %11, %11, %11 " ctrl " row_mask:0xf bank_mask:0xf\n"             \
+    op " %12, %12, %12 " ctrl " row_mask:0xf bank_mask:0xf\n" op " %13, %13, %13 " ctrl " row_mask:0xf bank_mask:0xf\n"             \
+    op " %14, %14, %14 " ctrl " row_mask:0xf bank_mask:0xf\n" op " %15, %15, %15 " ctrl " row_mask:0xf bank_mask:0xf\n"
+__device__ __forceinline__ void row_sum16_valu_f4x4(f4 (&v)[4]) {      // arguments: VALU results the compiler sees (row_sum16_valu_f4)
+    asm volatile("s_nop 1\n" RTK_DPP16("v_add_f32_dpp", "row_ror:8") RTK_DPP16("v_add_f32_dpp", "row_ror:4")
+                 RTK_DPP16("v_add_f32_dpp", "row_ror:2") RTK_DPP16("v_add_f32_dpp", "row_ror:1")
+                 : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[0].z), "+v"(v[0].w), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[1].z), "+v"(v[1].w),
+                   "+v"(v[2].x), "+v"(v[2].y), "+v"(v[2].z), "+v"(v[2].w), "+v"(v[3].x), "+v"(v[3].y), "+v"(v[3].z), "+v"(v[3].w));
+}
+
 // max over aligned sub-groups of GROUP (4, 8 or 16) lanes within the row
 template <int GROUP>
 __device__ __forceinline__ void row_max_group_f4(f4 &v) {

@@ -189,13 +189,27 @@ __device__ __forceinline__ f16v wn_out(const WnBlock &k, int hh, const float (&t
 __device__ __forceinline__ f16v wn_out(const WnSplit &W, int v, int hh, int col, const float (&t2)[8]) { return wn_out(wn_block(W, v, hh, col), hh, t2); }
 
 __device__ __forceinline__ f4 f4_max(f4 a, f4 b) { return (f4){fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)}; }
-__device__ __forceinline__ f4 f4_relu(f4 a) { return (f4){fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)}; }
-// max(x, 0.1 x) and max(x, 0) as medians with +inf: ONE instruction each.  fmaxf() costs two under IEEE mode -- hipcc first quiets a
-// possible signalling NaN in every operand it did not compute itself (v_max_f32 x, x, x on each accumulator read): 32 extra VALU
-// instructions per 32-channel block of the epilogue, 256 per layer boundary.  Same bits for every non-NaN input.
-__device__ __forceinline__ float leaky1(float x) { return __builtin_amdgcn_fmed3f(x, 0.1f * x, __builtin_inff()); }
-__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
+// max(x, 0.1 x) and max(x, 0) in ONE instruction each.  fmaxf() costs two under IEEE mode -- hipcc first quiets a possible signalling
+// NaN in every operand it did not compute itself (v_max_f32 x, x, x on each accumulator read): 32 extra VALU instructions per
+// 32-channel block of the epilogue, 256 per layer boundary -- and a median with a literal +inf (v_med3_f32) is folded back into
+// exactly that maxnum.  LeakyReLU: the v_max_f32 is written out; its second operand is a product the compiler sees, which is where
+// it places the wait states a matrix-core result needs (an asm statement gets none).  ReLU: the median with a +inf the optimiser
+// cannot see (an SGPR written by a volatile asm, once per kernel: rtk_hidden_inf) -- an instruction the compiler knows, so a
+// matrix-core operand is safe.  Same bits as fmaxf for every non-NaN input.
+__device__ __forceinline__ float rtk_hidden_inf() {
+    float v;
+    asm volatile("s_mov_b32 %0, 0x7f800000" : "=s"(v));
+    return v;
+}
+__device__ __forceinline__ float leaky1(float x) {
+    float o;
+    const float y = 0.1f * x;
+    asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(x), "v"(y));
+    return o;
+}
+__device__ __forceinline__ float relu1(float x, float inf) { return __builtin_amdgcn_fmed3f(x, 0.f, inf); }
 __device__ __forceinline__ f4 leaky4(f4 t) { return (f4){leaky1(t.x), leaky1(t.y), leaky1(t.z), leaky1(t.w)}; }
+__device__ __forceinline__ f4 f4_relu(f4 a) { return (f4){fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)}; }
 
 // ---- layer 1's operands ---------------------------------------------------------------------------------------------------
 // The tile layout gives a lane 32 bytes of a gathered p2 row per load instruction (its own position's row, two lanes per position):
@@ -316,6 +330,7 @@ __device__ __forceinline__ void cv_layer1_blocks(const CvSplitParams &P, const f
 template <bool SAVE>
 __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1), amdgpu_num_vgpr(CV_FWD_VGPRS)))
 void cost_volume_split_kernel(const CvSplitParams P) {
+    const float kinf = rtk_hidden_inf();
     __shared__ __attribute__((aligned(16))) f4 s_w[2 * CV_F * 64];
     __shared__ __attribute__((aligned(16))) f4 s_rows[SP_NW * CV_ROWS_F4];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hh = lane >> 5, col = lane & 31, pp = col >> 4,
@@ -415,11 +430,10 @@ void cost_volume_split_kernel(const CvSplitParams P) {
             if (v + 2 < SPLIT_VB) wk = wn_block(P.wn, v + 2, hh, col);
             f4 r[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) r[q][e] = relu1(w[4 * q + e]) * leaky1(acc[v][4 * q + e]);
-                row_sum16_valu_f4(r[q]);
-            }
+                for (int e = 0; e < 4; ++e) r[q][e] = relu1(w[4 * q + e], kinf) * leaky1(acc[v][4 * q + e]);
+            row_sum16_valu_f4x4(r);
             if (valid && j == 0) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) *reinterpret_cast<f4 *>(o + 32 * v + 8 * q) = r[q];
@@ -461,6 +475,7 @@ __device__ __forceinline__ f4 leaky_grad_bits4(f4 d, unsigned bits) {     // d *
 }
 
 __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1))) void cost_volume_bwd_split_kernel(const CvSplitBwdParams Q) {
+    const float kinf = rtk_hidden_inf();
     __shared__ __attribute__((aligned(16))) f4 s_w[2 * SP_F * 64];
     __shared__ float s_wct[128 * 64];                                    // [(v, q, r)][lane = 32 hh + o]: Wc[32 v + 8 q + 4 hh + r][o] (o < 8, else 0)
     const CvSplitParams &P = Q.f;
@@ -523,7 +538,7 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
                 const f4 a = h[e];
                 f4 wv;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) wv[r] = relu1(w[4 * q + r]);
+                for (int r = 0; r < 4; ++r) wv[r] = relu1(w[4 * q + r], kinf);
                 const f4 da = mul_row_bcast<e & 15>(e < 16 ? dq0 : dq1, a);       // d * a
                 const f4 t = mul_row_bcast<e & 15>(e < 16 ? dq0 : dq1, wv);       // d * relu(w)   (== d * w wherever w > 0, +-0 elsewhere)
                 f4 qq, z;
