@@ -279,14 +279,18 @@ def test_split_layers_adversarial_operands(case):
     assert abs(bias(y)) < 2.5e-7, (case, bias(y))                                   # two layers x 2^-23 worst case, fully coherent
 
 
-def test_cost_volume_split_agrees_with_fp32_mfma_kernel():
-    """Both kernels on the same operands: samples not a multiple of 8 (plain 2-D grid), a point count that leaves the last
-    workgroup iteration partly empty, and rows beyond the last point untouched."""
+@pytest.mark.parametrize("B,N", [(3, 243), (8, 250), (16, 64), (1, 1024), (2, 17)])
+def test_cost_volume_split_agrees_with_fp32_mfma_kernel(B, N):
+    """Both kernels on the same operands: samples not a multiple of 8 (plain 2-D grid) and a multiple (XCD-aware grid), point counts
+    that leave the last workgroup iteration partly empty, one tile per workgroup (16 x 64: no next tile to request rows for) and
+    sixteen (1 x 1024), barely more points than neighbours (17), repeated neighbours (frame 2 holds every point twice), and rows
+    beyond the last point untouched.  (The split kernel stages the gathered rows through LDS and broadcasts the p1 row across a
+    point's neighbours: every lane / slot / swizzle mistake shows here.)"""
     net = _net()
     eng = F.FusedBackbone(net)
-    B, N = 3, 243
-    torch.manual_seed(11)
+    torch.manual_seed(11 + B + N)
     x1, x2 = torch.randn(B, N, 3, device=DEV), torch.randn(B, N, 3, device=DEV)
+    x2[:, N // 2:] = x2[:, :N - N // 2]
     p1, p2 = torch.randn(B * N, 256, device=DEV), torch.randn(B * N, 256, device=DEV)
     k1 = PU.knn_point(16, x2, x1)
     out = []
