@@ -630,6 +630,14 @@ def main():
         # rocprofv3 --kernel-trace reports for it)
         alone = eng.time_dominant_kernel(20)
         alone_ms = sum(s.elapsed_time(e) for s, e in alone) / len(alone)
+        # ... and as the pipeline launches it from depth 3: on a share of the CUs (fused.cv_shared_workgroups)
+        shared_wgs = fused.cv_shared_workgroups(a.batch, a.npoints, dev) if (depth > 2 and not a.no_graph) else 0
+        alone_shared_ms = None
+        if shared_wgs:
+            eng.cv_shared = True
+            ev = eng.time_dominant_kernel(20)
+            eng.cv_shared = False
+            alone_shared_ms = sum(s.elapsed_time(e) for s, e in ev) / len(ev)
 
     res = None
     if rank == 0:
@@ -680,6 +688,10 @@ def main():
                                    "what": "the same launch with nothing else in flight (back-to-back launches between HIP events; what "
                                            "rocprofv3 --kernel-trace, which serialises dispatches, shows): in situ the kernel shares the "
                                            "CUs with the kernels of the other batches in flight, which is what the pipelining is for"},
+                         "alone_as_launched": ({"workgroups": shared_wgs, "kernel_ms": round(alone_shared_ms, 4),
+                                                "what": "the pipeline's launch (rtk_cost_volume_split_shared: the kernel keeps its CUs whole, so "
+                                                        "with several batches in flight it is given 3/4 of them) with nothing else in flight"}
+                                               if alone_shared_ms else None),
                          "measured": "in situ: %d launches between HIP events inside a timed region of the same pipelined workload "
                                      "(graphs split around the kernel, the measured kernels of the batches in flight chained by events "
                                      "so that they do not time-share the CUs; %.4f ms/step there)" % (len(events), insitu / a.steps * 1e3)},

@@ -121,6 +121,15 @@ RTK_EXPORT int rtk_cost_volume_split(int samples, int n1, int n2, const float *x
                                      const int64_t *knn_idx, const float *p1, const float *p2, const float *wd_packed,
                                      const void *split_images, const float *bias2, const float *bias3,
                                      const rtk_layer_t *wn, float *out, int out_pitch, rtk_stream_t stream);
+/* ... on a share of the chip.  The kernel keeps a CU whole (486 registers per lane, 112 KiB of LDS): launched with one workgroup per
+ * CU it stops every other kernel for its duration.  With several batches in flight (ratrack_amd.fused.GraphPipeline) the step is
+ * shorter when it takes `workgroups` < the CU count -- 3/4 of them at B = 64: the kernel itself runs 16 % longer, the pipelined
+ * forward 2 % faster, the other batches' kernels keep a quarter of every XCD.  workgroups = 0: all CUs (rtk_cost_volume_split);
+ * rounded down to a multiple of 8 (one share per XCD: all tiles of sample s run on XCD s % 8); ignored unless samples % 8 == 0. */
+RTK_EXPORT int rtk_cost_volume_split_shared(int samples, int n1, int n2, const float *xyz1, const float *xyz2,
+                                            const int64_t *knn_idx, const float *p1, const float *p2, const float *wd_packed,
+                                            const void *split_images, const float *bias2, const float *bias3,
+                                            const rtk_layer_t *wn, float *out, int out_pitch, int workgroups, rtk_stream_t stream);
 /* rtk_sa_scale for the scales whose MLP is offset layer (c1 = 32 or 64 channels) + ONE layer c1 -> 64, nsample 16 or 32 (sa2 scale 1,
  * sa3 scales 0 and 1 of the PNHead): same arguments, the layer as its split image (rtk_pack_split_layer(64, c1, ...)) + fp32 bias. */
 RTK_EXPORT int rtk_sa_scale_split(int samples, int n, int npoint, int nsample, const float *xyz, const float *new_xyz,

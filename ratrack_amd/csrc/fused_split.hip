@@ -336,10 +336,20 @@ void cost_volume_split_kernel(const CvSplitParams P) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hh = lane >> 5, col = lane & 31, pp = col >> 4,
               j = col & 15;      // wave index in an SGPR: the DMA's LDS destination (M0) is then scalar arithmetic
     f4 *rows = s_rows + wave * CV_ROWS_F4;
-    int b, bx, nbx;
-    rtk_decode_block(P.gx, b, bx, nbx);
     constexpr int PPW = 2 * SP_NW;                                  // points per workgroup iteration
     const int groups = (P.n1 + PPW - 1) / PPW;
+    // Tiles = (sample, group of eight points).  P.gx > 0 (samples % 8 == 0): a 1-D grid of P.gx workgroups, ALL tiles of sample s on
+    // XCD s % 8 -- workgroup L serves XCD L % 8 and strides over that XCD's tiles (sample-major) with the XCD's P.gx / 8 workgroups,
+    // so that the launcher can give the kernel any share of the CUs (cv_split_fill).  Else a plain 2-D grid, one sample per row.
+    const bool flat = P.gx > 0;
+    const int xcd = blockIdx.x & 7, t0 = flat ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, tstep = flat ? P.gx >> 3 : (int)gridDim.x;
+    const int ntiles = flat ? (P.samples >> 3) * groups : groups;
+    auto locate = [&](int t, int &b_, int &G_) {
+        if (flat) { const int sk = t / groups; b_ = sk * 8 + xcd; G_ = t - sk * groups; }
+        else { b_ = blockIdx.y; G_ = t; }
+    };
+    int b, bx;
+    locate(t0 < ntiles ? t0 : 0, b, bx);
     WStreamA<SP_NW, CV_F, 2 * SPLIT_NF> ws;
     ws.start_parts(P.blob, s_w, wave, lane);
     // The tile loop is software-pipelined by one tile (round 4): the NEXT tile's neighbour index is requested at the top of the
@@ -351,21 +361,22 @@ void cost_volume_split_kernel(const CvSplitParams P) {
     long nb = 0;
     float dx = 0.f, dy = 0.f, dz = 0.f;
     f4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0;                          // p1 slots j and 16 + j of this lane's point
-    if (bx < groups) {
+    if (t0 < ntiles) {
         nb = (long)b * P.n2 + (long)P.knn[i * 16 + j];
         cv_rows_request<0>(P.p2, (int)nb, rows, lane);
         q0 = ldc4(P.p1 + i * 256 + 4 * hh + 8 * j); q1 = ldc4(P.p1 + i * 256 + 4 * hh + 8 * (16 + j));
         dx = __fsub_rn(P.xyz2[nb * 3], P.xyz1[i * 3]); dy = __fsub_rn(P.xyz2[nb * 3 + 1], P.xyz1[i * 3 + 1]);
         dz = __fsub_rn(P.xyz2[nb * 3 + 2], P.xyz1[i * 3 + 2]);
     }
-    for (int G = bx; G < groups; G += nbx) {
+    for (int t = t0; t < ntiles; t += tstep) {
         asm volatile("" ::: "memory");
         // the next tile's neighbour index (wave-uniform condition)
-        const int Gn = G + nbx;
-        const bool more = Gn < groups;
+        const bool more = t + tstep < ntiles;
+        int bn, Gn;
+        locate(more ? t + tstep : t, bn, Gn);
         const int ptn = Gn * PPW + 2 * wave + pp;
         const bool validn = ptn < P.n1;
-        const long in_ = (long)b * P.n1 + (validn ? ptn : P.n1 - 1);
+        const long in_ = (long)bn * P.n1 + (validn ? ptn : P.n1 - 1);
         long knn_next = 0;
         if (more) knn_next = (long)P.knn[in_ * 16 + j];
         // layer 1: leaky(p1[i] + p2[nb] + Wd.d)     (bias folded into p1)
@@ -379,7 +390,7 @@ void cost_volume_split_kernel(const CvSplitParams P) {
             cv_rows_read<1>(rows, col, hh, h);
             cv_layer1_blocks<4, 8>(P, q0, q1, b0, b1, hh, col, h);
         }
-        const long nbn = (long)b * P.n2 + knn_next;       // (no next tile: row 0 of the sample, requested and never read)
+        const long nbn = (long)bn * P.n2 + knn_next;      // (no next tile: row 0 of the sample, requested and never read)
         // byte offset of this lane's first 16-byte slot in a (position, 256) row (one 32-bit VGPR on uniform base pointers)
         const long pos = i * 16 + j;
         const unsigned ro = (unsigned)pos * 1024u + 16u * hh;
@@ -777,7 +788,7 @@ static int cv_split_fill(const char *who, CvSplitParams &P, int samples, int n1,
 static int cv_split_forward(const char *who, int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
                             const float *p1, const float *p2, const float *wd_packed, const void *split_images, const float *bias2,
                             const float *bias3, const rtk_layer_t *wn, float *out, int out_pitch, float *a1, float *a2, float *a3,
-                            void *mask1, void *mask2, rtk_stream_t stream) {
+                            void *mask1, void *mask2, int workgroups, rtk_stream_t stream) {
     CvSplitParams P;
     dim3 grid;
     if (cv_split_fill(who, P, samples, n1, n2, xyz1, xyz2, knn_idx, split_images, wn, grid) != RTK_OK) return RTK_ERR_INVALID;
@@ -789,6 +800,14 @@ static int cv_split_forward(const char *who, int samples, int n1, int n2, const 
                 "offsets): split the batch", who);
     P.p1 = p1; P.p2 = p2; P.wd = wd_packed; P.bias2 = bias2; P.bias3 = bias3; P.out = out; P.out_pitch = out_pitch;
     P.sv1 = a1; P.sv2 = a2; P.sv3 = a3; P.mk1 = (uint2 *)mask1; P.mk2 = (uint2 *)mask2;
+    if (samples % 8 == 0) {      // flattened tiles (see the kernel): `workgroups` of them, a multiple of 8, at most one per tile
+        const int tiles_x = (samples / 8) * ((n1 + 2 * SP_NW - 1) / (2 * SP_NW));
+        int per_xcd = (workgroups > 0 ? workgroups : 256) / 8;
+        if (per_xcd < 1) per_xcd = 1;
+        if (per_xcd > tiles_x) per_xcd = tiles_x;
+        P.gx = 8 * per_xcd;
+        grid = dim3(P.gx);
+    }
     if (save) cost_volume_split_kernel<true><<<grid, 64 * SP_NW, 0, (hipStream_t)stream>>>(P);
     else cost_volume_split_kernel<false><<<grid, 64 * SP_NW, 0, (hipStream_t)stream>>>(P);
     RTK_CHECK_LAUNCH(who);
@@ -800,7 +819,16 @@ extern "C" int rtk_cost_volume_split(int samples, int n1, int n2, const float *x
                                      const float *bias2, const float *bias3, const rtk_layer_t *wn, float *out, int out_pitch,
                                      rtk_stream_t stream) {
     return cv_split_forward("cost_volume_split", samples, n1, n2, xyz1, xyz2, knn_idx, p1, p2, wd_packed, split_images, bias2, bias3, wn, out,
-                            out_pitch, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+                            out_pitch, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int rtk_cost_volume_split_shared(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
+                                            const float *p1, const float *p2, const float *wd_packed, const void *split_images,
+                                            const float *bias2, const float *bias3, const rtk_layer_t *wn, float *out, int out_pitch,
+                                            int workgroups, rtk_stream_t stream) {
+    RTK_REQUIRE(workgroups >= 0, "cost_volume_split_shared: workgroups = %d", workgroups);
+    return cv_split_forward("cost_volume_split_shared", samples, n1, n2, xyz1, xyz2, knn_idx, p1, p2, wd_packed, split_images, bias2, bias3,
+                            wn, out, out_pitch, nullptr, nullptr, nullptr, nullptr, nullptr, workgroups, stream);
 }
 
 extern "C" int rtk_cost_volume_split_train(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
@@ -809,7 +837,7 @@ extern "C" int rtk_cost_volume_split_train(int samples, int n1, int n2, const fl
                                            float *a1, float *a2, float *a3, void *mask1, void *mask2, rtk_stream_t stream) {
     RTK_REQUIRE(a1 && a2 && a3 && mask1 && mask2, "cost_volume_split_train: null activation buffer");
     return cv_split_forward("cost_volume_split_train", samples, n1, n2, xyz1, xyz2, knn_idx, p1, p2, wd_packed, split_images, bias2, bias3,
-                            wn, out, out_pitch, a1, a2, a3, mask1, mask2, stream);
+                            wn, out, out_pitch, a1, a2, a3, mask1, mask2, 0, stream);
 }
 
 extern "C" int rtk_cost_volume_bwd_split(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,

@@ -46,6 +46,7 @@ _lib.SIGNATURES.update({
     "rtk_patch_cost": [_ci] * 2 + [_vp] * 3 + [_ci, ctypes.POINTER(_Layer), _vp, _ci, _ci, _vp],
     "rtk_pack_split_layer": [_ci, _ci, _vp, _ci, _vp, _vp],
     "rtk_cost_volume_split": [_ci] * 3 + [_vp] * 9 + [ctypes.POINTER(_Layer), _vp, _ci, _vp],
+    "rtk_cost_volume_split_shared": [_ci] * 3 + [_vp] * 9 + [ctypes.POINTER(_Layer), _vp, _ci, _ci, _vp],
     "rtk_split_mlp2": [_ci, _vp, _vp, _vp, _vp, _vp, _vp],
     "rtk_sa_scale_split": [_ci] * 4 + [_vp] * 4 + [_ci, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _vp, _vp, _vp],
     "rtk_prepare_inputs": [_ci] * 2 + [_vp] * 6 + [_vp],
@@ -537,6 +538,21 @@ class Geometry:
         return g
 
 
+def cv_shared_workgroups(samples, n1, dev):
+    """Workgroups for the forward cost volume when other batches are in flight (rtk_cost_volume_split_shared): at most 3/4 of the CUs,
+    at least half, a multiple of 8 (a share per XCD), the largest count in that range that leaves the slowest workgroup no more than 5 %
+    above the average tile count -- else the best balanced one.  0 (all CUs) when the batch does not take the XCD-aware grid."""
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    if samples % 8 or cus % 8:
+        return 0
+    tiles = (samples // 8) * ((n1 + 7) // 8)                    # per XCD
+    lo, hi = max(1, cus // 16), max(1, cus // 8 * 3 // 4)
+    balance = lambda w: tiles / (w * -(-tiles // w))
+    ok = [w for w in range(hi, lo - 1, -1) if balance(w) >= 0.95]
+    w = ok[0] if ok else max(range(lo, hi + 1), key=balance)
+    return 8 * min(w, tiles)
+
+
 def sa_scale(geo, W, lvl, s, q, qcol, out, out_offset):
     """One MSG scale (level lvl, scale s) of PNHead weights W on geometry geo; q[:, qcol:] holds its layer-1 projection.
     Duplicate centroids (geo.nuniq) are skipped; gathers from duplicate source rows alias row 0."""
@@ -614,6 +630,7 @@ class FusedBackbone:
         self.kernel_token = None       # [last stop event] shared by the engines of a GraphPipeline while kernel_events is set
         self._split_hook = None
         self.side, self.use_side_stream = None, True    # geometry kernels on a forked stream (GraphPipeline drops it beyond depth 2)
+        self.cv_shared = False                          # the cost volume on a share of the CUs (GraphPipeline sets it from depth 3)
         self._last_cv = None
         self.enc = _PNHeadWeights(sd, "pn_head.", dev)
         self.dec = _PNHeadWeights(sd, "fd_layer.mse.", dev)
@@ -749,9 +766,10 @@ class FusedBackbone:
         if _TRACE is not None:      # per (point, neighbour) pair: direction term, layers 2+3, WeightNet 3-8-8-256, weighted sum
             _TRACE.append(("cost_volume", B * N * 16, 3 * 256 + 2 * 256 * 256 + (3 * 8 + 8 * 8 + 8 * 256) + 256))
         if self.cv_split:
-            _lib.call("rtk_cost_volume_split", B, N, N, x1.data_ptr(), x2.data_ptr(), knn1.data_ptr(), p1.data_ptr(), p2.data_ptr(),
+            wgs = cv_shared_workgroups(B, N, x1.device) if self.cv_shared else 0
+            _lib.call("rtk_cost_volume_split_shared", B, N, N, x1.data_ptr(), x2.data_ptr(), knn1.data_ptr(), p1.data_ptr(), p2.data_ptr(),
                       self.cv_wd.data_ptr(), self.cv_images.data_ptr(), self.cv_bias23[0].data_ptr(), self.cv_bias23[1].data_ptr(),
-                      self.wn1.arr, cor1.data_ptr(), 256, _stream())
+                      self.wn1.arr, cor1.data_ptr(), 256, wgs, _stream())
             return
         _lib.call("rtk_cost_volume", B, N, N, x1.data_ptr(), x2.data_ptr(), knn1.data_ptr(), p1.data_ptr(), p2.data_ptr(),
                   self.cv_wd.data_ptr(), self.cv_layers.arr, self.wn1.arr, cor1.data_ptr(), 256, _stream())
@@ -875,6 +893,10 @@ class GraphPipeline:
         if depth > 2:
             eng = copy.copy(eng)
             eng.use_side_stream, eng.side = False, None
+            # ... and the cost volume leaves a quarter of every XCD to the other batches: it keeps the CUs it runs on whole, and with
+            # one workgroup per CU nothing else runs for a third of the step (B = 64: 74.1 -> 76.0 k pairs/s at 192 of 256 workgroups,
+            # the kernel itself 0.33 -> 0.39 ms; 232: 73.2 k, 208: 74.4 k, 176: 74.9 k, 160: 75.7 k, 128: 75.5 k)
+            eng.cv_shared = True
         self.engines = [eng]
         for _ in range(depth - 1):
             e = copy.copy(eng)          # shallow: packed weights are shared, per-engine state is reset below
