@@ -728,3 +728,27 @@ def test_split16_image_is_packed_as_documented():
                     for t in range(8):
                         got = img[(((up * V + v) * 3 + p) * 64 + lane) * 8 + t]
                         assert got == pieces[p, 16 * v + i, 16 * (2 * up + t // 4) + 4 * g + t % 4]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N", [(8, 250), (16, 64), (32, 256)])
+def test_cost_volume_on_a_share_of_the_cus_is_the_same_result(B, N):
+    """rtk_cost_volume_split_shared (what GraphPipeline launches from depth 3: 3/4 of the CUs or fewer, tiles indexed flat per XCD)
+    against the full-chip launch: bit for bit."""
+    net = _net()
+    eng = F.FusedBackbone(net)
+    torch.manual_seed(B + N)
+    x1, x2 = torch.randn(B, N, 3, device=DEV), torch.randn(B, N, 3, device=DEV)
+    p1, p2 = torch.randn(B * N, 256, device=DEV), torch.randn(B * N, 256, device=DEV)
+    k1 = PU.knn_point(16, x2, x1)
+    out = []
+    for shared in (False, True):
+        eng.cv_shared = shared
+        o = torch.full((B * N + 4, 256), 7.0, device=DEV)
+        eng._cost_volume(B, N, x1, x2, k1, p1, p2, o)
+        assert torch.all(o[B * N:] == 7.0)
+        out.append(o[:B * N])
+    wgs = F.cv_shared_workgroups(B, N, DEV)
+    cus = torch.cuda.get_device_properties(DEV).multi_processor_count
+    assert 0 < wgs <= cus * 3 // 4 and wgs % 8 == 0
+    assert torch.equal(out[0], out[1])

@@ -80,3 +80,22 @@ def test_split_images_follow_their_index_formulas():
                 g, i = lane // 16, lane % 16
                 for t in range(8):
                     assert torch.equal(img[up, v, :, lane, t], p[:, 16 * v + i, 16 * (2 * up + t // 4) + 4 * g + t % 4])
+
+
+def test_shared_cost_volume_workgroup_policy(monkeypatch):
+    """fused.cv_shared_workgroups (host policy of rtk_cost_volume_split_shared): a multiple of 8, between half and three quarters of
+    the CUs, never more than one workgroup per tile, balanced (slowest workgroup <= 5 % above the mean) where such a count exists,
+    0 = all CUs when the batch does not take the XCD-aware grid."""
+    class Props:
+        multi_processor_count = 256
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda dev: Props)
+    assert F.cv_shared_workgroups(64, 256, "cuda") == 192
+    assert F.cv_shared_workgroups(3, 243, "cuda") == 0                        # samples % 8 != 0: plain 2-D grid, all CUs
+    for samples, n in [(64, 256), (32, 256), (32, 1024), (8, 256), (16, 64), (8, 17), (128, 256), (64, 242), (8, 8)]:
+        w = F.cv_shared_workgroups(samples, n, "cuda")
+        tiles = (samples // 8) * ((n + 7) // 8)
+        assert w % 8 == 0 and 0 < w <= 192 and w // 8 <= tiles, (samples, n, w)
+        per = w // 8
+        if per < tiles and per >= 16:
+            best = max(tiles / (c * -(-tiles // c)) for c in range(16, 25))
+            assert tiles / (per * -(-tiles // per)) >= min(0.95, best) - 1e-9, (samples, n, w)
