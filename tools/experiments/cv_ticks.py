@@ -33,9 +33,9 @@ extern "C" __attribute__((visibility("default"))) int rtk_dbg_cv_ticks(unsigned 
 '''
 PATCHES = [
     # (anchor, replacement) -- each anchor must occur exactly once in the forward kernel
-    ("    for (int G = bx; G < groups; G += nbx) {\n        asm volatile(\"\" ::: \"memory\");\n        // the next tile's neighbour index",
+    ("    for (int t = t0; t < ntiles; t += tstep) {\n        asm volatile(\"\" ::: \"memory\");\n        // the next tile's neighbour index",
      "    unsigned long long tk[%d] = {}, tprev = __builtin_readcyclecounter(), t00 = tprev, w00 = wall_clock64();\n"
-     "    for (int G = bx; G < groups; G += nbx) {\n        asm volatile(\"\" ::: \"memory\");\n        CV_TICK(0)\n        // the next tile's neighbour index" % NT),
+     "    for (int t = t0; t < ntiles; t += tstep) {\n        asm volatile(\"\" ::: \"memory\");\n        CV_TICK(0)\n        // the next tile's neighbour index" % NT),
     ("        // byte offset of this lane's first 16-byte slot in a (position, 256) row (one 32-bit VGPR on uniform base pointers)\n        const long pos = i * 16 + j;",
      "        CV_TICK(1)\n        const long pos = i * 16 + j;"),
     ("CvRowsRequest(P.p2, rows, (int)nbn, 0, lane)});\n", "CvRowsRequest(P.p2, rows, (int)nbn, 0, lane)});\n        CV_TICK(2)\n"),
