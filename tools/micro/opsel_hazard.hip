@@ -1,0 +1,313 @@
+// opsel_hazard.hip -- standalone reproducer (no torch, no library) for the round-4 finding of DESIGN section 8: a packed fp32
+// operation that takes a broadcast operand from the ODD half of a register pair through op_sel misread about once in 10^4
+// executions while waves of other kernels issuing bf16 MFMAs shared its SIMD.
+//
+//   hipcc -O2 --offload-arch=gfx950 tools/micro/opsel_hazard.hip -o tools/micro/opsel_hazard.bin && tools/micro/opsel_hazard.bin
+//
+// Victim: one wave per workgroup runs ROUNDS rounds of a furthest-point-selection-like dependent chain (the loop of
+// fps_wave_body, ops_pointnet2.hip): read the current point o = (x, y, z, id) with ONE uniform ds_read_b128, take the squared
+// distances of the lane's four points to it with packed fp32 arithmetic, keep running minima, pick the wave-wide maximum as the
+// next point.  The only thing that differs between the FORMs is how o's components reach the packed arithmetic:
+//   FORM 0  three v_mov copies into pairs of their own, op_sel_hi:[1,0]            (the form the library pins; never misread)
+//   FORM 1  straight out of the ds_read_b128 destination: y through op_sel:[0,1]    (the form round 4 blamed)
+//   FORM 2  as 1 with `s_nop 7` between the read's wait and the packed op
+//   FORM 3  as 1 with the packed SUBTRACT replaced by v_pk_fma_f32 (x * 1 + (-o)), op_sel:[0,0,1]
+//   FORM 6  as 1 with the read's destination at v[98:101]: (x, y) in register banks 2, 3 like the v[14:15] of the failing build
+//   FORM 4  two-piece fp16 split of the lane's values: residual through v_fma_mix_f32 taking the HIGH half of a packed f16
+//           pair (op_sel on a 16-bit half -- the form the round-5 split layers would use), checked against the low-half form
+//   FORM 5  v_fma_mixlo_f16 / v_fma_mixhi_f16 residuals (what split_f16.h uses)
+// Every form's trace is compared bit for bit with FORM 0's arithmetic run on an idle GPU (forms 4/5: with their own low-half
+// twins); mismatching workgroups are counted per launch, with and without the noise kernel (bf16 MFMA + LDS traffic, few
+// registers: its waves share SIMDs with the victim's) on a second stream.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+constexpr int NPTS = 256, ROUNDS = 255;
+
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const unsigned o = __shfl_xor(v, s, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+template <int FORM>
+__global__ __launch_bounds__(64) void victim(const float4 *__restrict__ clouds, int *__restrict__ trace) {
+    __shared__ float4 s_pt[NPTS];
+    const int lane = threadIdx.x, b = blockIdx.x;
+    for (int k = lane; k < NPTS; k += 64) s_pt[k] = clouds[(size_t)b * NPTS + k];
+    __syncthreads();
+    f2 x[2], y[2], z[2];
+    unsigned t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 v = s_pt[lane * 4 + i];
+        x[i / 2][i % 2] = v.x; y[i / 2][i % 2] = v.y; z[i / 2][i % 2] = v.z;
+        t[i] = __float_as_uint(1e10f);
+    }
+    int pos = 0;
+    int *tr = trace + (size_t)b * ROUNDS;
+    for (int j = 0; j < ROUNDS; ++j) {
+        const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)(s_pt) + 16u * (unsigned)pos;
+        f2 dx[2], dy[2], dz[2];
+        if constexpr (FORM == 0) {
+            f4 o;
+            asm volatile("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(o) : "v"(addr));
+            f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+            asm volatile("" : "+v"(ox), "+v"(oy), "+v"(oz));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { dx[h] = x[h] - ox; dy[h] = y[h] - oy; dz[h] = z[h] - oz; }
+        } else if constexpr ((FORM >= 1 && FORM <= 3) || FORM == 6) {
+            // the winner's coordinates stay where ds_read_b128 left them (v[100:103]); the packed ops select halves through op_sel
+#define PK(op, extra)                                                                                                         \
+            asm volatile("ds_read_b128 v[100:103], %6\n s_waitcnt lgkmcnt(0)\n" extra                                            \
+                         op(0, 7, "v[100:101]", "op_sel_hi:[1,0]") op(1, 8, "v[100:101]", "op_sel_hi:[1,0]")                     \
+                         op(2, 9, "v[100:101]", "op_sel:[0,1]") op(3, 10, "v[100:101]", "op_sel:[0,1]")                          \
+                         op(4, 11, "v[102:103]", "op_sel_hi:[1,0]") op(5, 12, "v[102:103]", "op_sel_hi:[1,0]")                   \
+                         : "=&v"(dx[0]), "=&v"(dx[1]), "=&v"(dy[0]), "=&v"(dy[1]), "=&v"(dz[0]), "=&v"(dz[1])                    \
+                         : "v"(addr), "v"(x[0]), "v"(x[1]), "v"(y[0]), "v"(y[1]), "v"(z[0]), "v"(z[1]), "v"(one)                 \
+                         : "v100", "v101", "v102", "v103", "memory")
+#define OP_ADD(d, s, pair, sel) "v_pk_add_f32 %" #d ", %" #s ", " pair " " sel " neg_lo:[0,1] neg_hi:[0,1]\n"
+            const f2 one = {1.0f, 1.0f};
+            if constexpr (FORM == 6) {
+                asm volatile("ds_read_b128 v[98:101], %6\n s_waitcnt lgkmcnt(0)\n"
+                             "v_pk_add_f32 %0, %7, v[98:99] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             "v_pk_add_f32 %1, %8, v[98:99] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             "v_pk_add_f32 %2, %9, v[98:99] op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             "v_pk_add_f32 %3, %10, v[98:99] op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             "v_pk_add_f32 %4, %11, v[100:101] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             "v_pk_add_f32 %5, %12, v[100:101] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             : "=&v"(dx[0]), "=&v"(dx[1]), "=&v"(dy[0]), "=&v"(dy[1]), "=&v"(dz[0]), "=&v"(dz[1])
+                             : "v"(addr), "v"(x[0]), "v"(x[1]), "v"(y[0]), "v"(y[1]), "v"(z[0]), "v"(z[1]), "v"(one)
+                             : "v98", "v99", "v100", "v101", "memory");
+            } else if constexpr (FORM == 1) PK(OP_ADD, "");
+            else if constexpr (FORM == 2) PK(OP_ADD, "s_nop 7\n");
+            else {
+                // v_pk_fma_f32 d, x, 1, -o : the three-operand op_sel list, odd half of src2 for y
+                asm volatile("ds_read_b128 v[100:103], %6\n s_waitcnt lgkmcnt(0)\n"
+                             "v_pk_fma_f32 %0, %7, %13, v[100:101] op_sel_hi:[1,1,0] neg_lo:[0,0,1] neg_hi:[0,0,1]\n"
+                             "v_pk_fma_f32 %1, %8, %13, v[100:101] op_sel_hi:[1,1,0] neg_lo:[0,0,1] neg_hi:[0,0,1]\n"
+                             "v_pk_fma_f32 %2, %9, %13, v[100:101] op_sel:[0,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n"
+                             "v_pk_fma_f32 %3, %10, %13, v[100:101] op_sel:[0,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n"
+                             "v_pk_fma_f32 %4, %11, %13, v[102:103] op_sel_hi:[1,1,0] neg_lo:[0,0,1] neg_hi:[0,0,1]\n"
+                             "v_pk_fma_f32 %5, %12, %13, v[102:103] op_sel_hi:[1,1,0] neg_lo:[0,0,1] neg_hi:[0,0,1]\n"
+                             : "=&v"(dx[0]), "=&v"(dx[1]), "=&v"(dy[0]), "=&v"(dy[1]), "=&v"(dz[0]), "=&v"(dz[1])
+                             : "v"(addr), "v"(x[0]), "v"(x[1]), "v"(y[0]), "v"(y[1]), "v"(z[0]), "v"(z[1]), "v"(one)
+                             : "v100", "v101", "v102", "v103", "memory");
+            }
+#undef PK
+        }
+        if constexpr (FORM <= 3 || FORM == 6) {
+            unsigned mloc = 0u;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f2 d = dx[h] * dx[h];
+                d = __builtin_elementwise_fma(dy[h], dy[h], d);
+                d = __builtin_elementwise_fma(dz[h], dz[h], d);
+                const unsigned d0 = __float_as_uint(d[0]), d1 = __float_as_uint(d[1]);
+                t[2 * h] = d0 < t[2 * h] ? d0 : t[2 * h];
+                t[2 * h + 1] = d1 < t[2 * h + 1] ? d1 : t[2 * h + 1];
+                const unsigned mm = t[2 * h] > t[2 * h + 1] ? t[2 * h] : t[2 * h + 1];
+                mloc = mm > mloc ? mm : mloc;
+            }
+            int sl = 0;
+#pragma unroll
+            for (int i = 3; i >= 0; --i) sl = t[i] == mloc ? i : sl;
+            const unsigned M = wave_max_u32(mloc);
+            const unsigned long long mask = __ballot(mloc == M);
+            const int wl = __builtin_ctzll(mask);
+            pos = wl * 4 + __builtin_amdgcn_readlane(sl, wl);
+            if (lane == 0) tr[j] = pos;
+        }
+    }
+}
+
+// FORMs 4, 5: the fp16 two-piece split.  x -> h = f16(x), l = f16(x - h); the residual takes h from the LOW or the HIGH half of
+// the packed pair.  A dependent chain: the next round's operands are this round's residual bits mixed back in.
+template <int FORM, bool TWIN>
+__global__ __launch_bounds__(64) void victim_f16(const float4 *__restrict__ clouds, unsigned *__restrict__ trace, int rounds) {
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const float4 v = clouds[(size_t)b * NPTS + lane * 4];
+    float a0 = v.x, a1 = v.y;
+    unsigned acc = 0u;
+    for (int j = 0; j < rounds; ++j) {
+        unsigned hp, lp;
+        float r0, r1;
+        asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(a0), "v"(a1));
+        if constexpr (FORM == 4) {
+            if constexpr (!TWIN) {
+                asm volatile("s_nop 1\n v_fma_mix_f32 %0, %2, 1.0, -%4 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n"
+                             "v_fma_mix_f32 %1, %3, 1.0, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                             : "=&v"(r0), "=&v"(r1) : "v"(a0), "v"(a1), "v"(hp));
+            } else {
+                unsigned hi;
+                asm volatile("s_nop 1\n v_lshrrev_b32 %0, 16, %1" : "=v"(hi) : "v"(hp));
+                asm volatile("s_nop 1\n v_fma_mix_f32 %0, %2, 1.0, -%4 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n"
+                             "v_fma_mix_f32 %1, %3, 1.0, -%5 op_sel:[0,0,0] op_sel_hi:[0,0,1]"
+                             : "=&v"(r0), "=&v"(r1) : "v"(a0), "v"(a1), "v"(hp), "v"(hi));
+            }
+            asm volatile("s_nop 1\n v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lp) : "v"(r0), "v"(r1));
+        } else {
+            if constexpr (!TWIN) {
+                lp = 0u;
+                asm volatile("s_nop 1\n v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n"
+                             "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                             : "+v"(lp) : "v"(a0), "v"(a1), "v"(hp));
+            } else {
+                unsigned hi;
+                asm volatile("s_nop 1\n v_lshrrev_b32 %0, 16, %1" : "=v"(hi) : "v"(hp));
+                asm volatile("s_nop 1\n v_fma_mix_f32 %0, %2, 1.0, -%4 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n"
+                             "v_fma_mix_f32 %1, %3, 1.0, -%5 op_sel:[0,0,0] op_sel_hi:[0,0,1]"
+                             : "=&v"(r0), "=&v"(r1) : "v"(a0), "v"(a1), "v"(hp), "v"(hi));
+                asm volatile("s_nop 1\n v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lp) : "v"(r0), "v"(r1));
+            }
+        }
+        acc = acc * 0x9E3779B1u + (hp ^ (lp * 0x85EBCA6Bu));
+        // next operands: a pseudo-random float in [1, 2) x a slowly varying scale, from the bits just produced
+        a0 = __uint_as_float(0x3f800000u | ((acc >> 9) & 0x7fffffu)) * 0.37f;
+        a1 = __uint_as_float(0x3f800000u | ((acc * 0xC2B2AE35u) >> 9)) * 1.91f;
+    }
+    trace[(size_t)b * 64 + lane] = acc;
+}
+
+// Noise: bf16 MFMA stream with LDS reads, 8 waves per workgroup, few registers -- the shape of the split per-point / SA kernels.
+__global__ __launch_bounds__(256) void noise(float *out, int iters) {
+    __shared__ float4 s_w[1024];
+    for (int i = threadIdx.x; i < 1024; i += 256) s_w[i] = make_float4(1e-3f * i, 2e-3f * i, 1.f, 0.5f);
+    __syncthreads();
+    f4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f4){0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+        const float4 w = s_w[(threadIdx.x + 64 * it) & 1023];
+        bf8v a = __builtin_bit_cast(bf8v, w), bb = __builtin_bit_cast(bf8v, s_w[(threadIdx.x * 7 + it) & 1023]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
+    if (s == 12345.678f) out[0] = s;
+}
+
+// Noise B: the shape of the library's split kernels -- a global_load_lds (LDS-DMA) weight stream through a double buffer, barriers,
+// 16-byte LDS reads, 32x32x16 bf16 MFMAs.
+typedef float f16v __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void noise_dma(const float4 *__restrict__ blob, float *out, int iters) {
+    __shared__ __attribute__((aligned(16))) float4 s_w[2 * 16 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f16v acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    int buf = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(blob + ((it * 16 + wave * 4 + f) & 1023) * 64 + lane),
+                                             (__attribute__((address_space(3))) void *)(s_w + (buf * 16 + wave * 4 + f) * 64), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const float4 a = s_w[(buf * 16 + f) * 64 + lane], bb = s_w[(buf * 16 + 8 + f) * 64 + lane];
+            acc[f & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, bb), acc[f & 1], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += acc[0][e] + acc[1][e];
+    if (s == 12345.678f) out[0] = s;
+}
+static const float4 *g_blob = nullptr;
+
+template <class Launch>
+static void campaign(const char *name, Launch launch, void *d_out, size_t bytes, const std::vector<unsigned char> &expect, int launches,
+                     int groups, size_t per_group, hipStream_t sv, hipStream_t sn, float *d_noise, long execs_per_launch) {
+    std::vector<unsigned char> got(bytes);
+    for (int with_noise = 0; with_noise < 3; ++with_noise) {
+        long bad_groups = 0, bad_launches = 0;
+        for (int L = 0; L < launches; ++L) {
+            if (with_noise == 1) noise<<<512, 256, 0, sn>>>(d_noise, 6000);
+            if (with_noise == 2) noise_dma<<<1024, 256, 0, sn>>>(g_blob, d_noise, 1500);
+            CHECK(hipMemsetAsync(d_out, 0, bytes, sv));
+            launch(sv);
+            CHECK(hipStreamSynchronize(sv));
+            CHECK(hipMemcpy(got.data(), d_out, bytes, hipMemcpyDeviceToHost));
+            long bad = 0;
+            for (int g = 0; g < groups; ++g) bad += memcmp(got.data() + g * per_group, expect.data() + g * per_group, per_group) != 0;
+            bad_groups += bad;
+            bad_launches += bad != 0;
+        }
+        CHECK(hipDeviceSynchronize());
+        printf("%-44s %-14s %3ld / %d launches differ, %6ld / %ld workgroups   (%.2e packed executions)\n", name,
+               with_noise == 2 ? "MFMA+DMA noise" : with_noise ? "MFMA noise" : "idle GPU", bad_launches, launches, bad_groups, (long)launches * groups,
+               (double)launches * execs_per_launch);
+        fflush(stdout);
+    }
+}
+
+int main(int argc, char **argv) {
+    const int launches = argc > 1 ? atoi(argv[1]) : 40, B = 2048;
+    std::vector<float4> clouds((size_t)B * NPTS);
+    unsigned s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)(s >> 8) / 16777216.0f; };
+    for (auto &p : clouds) p = make_float4(rnd() * 20.f - 10.f, rnd() * 20.f - 10.f, rnd() * 4.f, 0.f);
+    float4 *d_clouds; int *d_trace; unsigned *d_tr2; float *d_noise;
+    CHECK(hipMalloc(&d_clouds, clouds.size() * sizeof(float4)));
+    CHECK(hipMemcpy(d_clouds, clouds.data(), clouds.size() * sizeof(float4), hipMemcpyHostToDevice));
+    const size_t tb = (size_t)B * ROUNDS * sizeof(int), tb2 = (size_t)B * 64 * sizeof(unsigned);
+    CHECK(hipMalloc(&d_trace, tb)); CHECK(hipMalloc(&d_tr2, tb2)); CHECK(hipMalloc(&d_noise, 4));
+    float4 *d_blob;
+    CHECK(hipMalloc(&d_blob, 1024 * 64 * sizeof(float4)));
+    CHECK(hipMemset(d_blob, 0x3c, 1024 * 64 * sizeof(float4)));
+    g_blob = d_blob;
+    hipStream_t sv, sn;
+    CHECK(hipStreamCreate(&sv)); CHECK(hipStreamCreate(&sn));
+    // expected traces: FORM 0 on an idle GPU, three times (must agree with itself)
+    std::vector<unsigned char> expect(tb), again(tb);
+    for (int k = 0; k < 3; ++k) {
+        victim<0><<<B, 64, 0, sv>>>(d_clouds, d_trace);
+        CHECK(hipStreamSynchronize(sv));
+        CHECK(hipMemcpy(k ? again.data() : expect.data(), d_trace, tb, hipMemcpyDeviceToHost));
+        if (k && memcmp(again.data(), expect.data(), tb)) { printf("FORM 0 is not reproducible on an idle GPU\n"); return 1; }
+    }
+    const long ex = (long)B * ROUNDS * 6;
+#define VICTIM(F) [&](hipStream_t st) { victim<F><<<B, 64, 0, st>>>(d_clouds, d_trace); }
+    campaign("0: broadcast copies, op_sel_hi:[1,0]", VICTIM(0), d_trace, tb, expect, launches, B, ROUNDS * sizeof(int), sv, sn, d_noise, ex);
+    campaign("1: v_pk_add_f32 ... op_sel:[0,1]", VICTIM(1), d_trace, tb, expect, launches, B, ROUNDS * sizeof(int), sv, sn, d_noise, ex);
+    campaign("6: as 1, pair in banks 2,3 (v[98:99])", VICTIM(6), d_trace, tb, expect, launches, B, ROUNDS * sizeof(int), sv, sn, d_noise, ex);
+    campaign("2: as 1, s_nop 7 after the wait", VICTIM(2), d_trace, tb, expect, launches, B, ROUNDS * sizeof(int), sv, sn, d_noise, ex);
+    campaign("3: v_pk_fma_f32 ... op_sel:[0,0,1]", VICTIM(3), d_trace, tb, expect, launches, B, ROUNDS * sizeof(int), sv, sn, d_noise, ex);
+    const int r16 = 4000;
+    std::vector<unsigned char> e16(tb2), e16b(tb2);
+    victim_f16<4, true><<<B, 64, 0, sv>>>(d_clouds, d_tr2, r16);
+    CHECK(hipStreamSynchronize(sv));
+    CHECK(hipMemcpy(e16.data(), d_tr2, tb2, hipMemcpyDeviceToHost));
+    victim_f16<5, true><<<B, 64, 0, sv>>>(d_clouds, d_tr2, r16);
+    CHECK(hipStreamSynchronize(sv));
+    CHECK(hipMemcpy(e16b.data(), d_tr2, tb2, hipMemcpyDeviceToHost));
+    if (memcmp(e16.data(), e16b.data(), tb2)) { printf("the two low-half twins disagree\n"); return 1; }
+    const long ex16 = (long)B * 64 * r16;
+    campaign("4: v_fma_mix_f32, f16 HIGH half (op_sel)", [&](hipStream_t st) { victim_f16<4, false><<<B, 64, 0, st>>>(d_clouds, d_tr2, r16); },
+             d_tr2, tb2, e16, launches, B, 64 * sizeof(unsigned), sv, sn, d_noise, ex16);
+    campaign("5: v_fma_mixlo_f16 / v_fma_mixhi_f16", [&](hipStream_t st) { victim_f16<5, false><<<B, 64, 0, st>>>(d_clouds, d_tr2, r16); },
+             d_tr2, tb2, e16, launches, B, 64 * sizeof(unsigned), sv, sn, d_noise, ex16);
+    campaign("4t: low-half twin of 4 / 5", [&](hipStream_t st) { victim_f16<4, true><<<B, 64, 0, st>>>(d_clouds, d_tr2, r16); },
+             d_tr2, tb2, e16, launches, B, 64 * sizeof(unsigned), sv, sn, d_noise, ex16);
+    return 0;
+}
