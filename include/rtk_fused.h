@@ -101,26 +101,31 @@ RTK_EXPORT int rtk_patch_cost(int samples, int n, const float *xyz, const int64_
                               const float *feat, int feat_pitch, const rtk_layer_t *wn, float *out,
                               int out_pitch, int out_channel_major, rtk_stream_t stream);
 
-/* ---- split-bf16 matrix path (csrc/split_mfma.h): fp32 results from the bf16 matrix pipe --------------------------------
- * Every fp32 operand is the exact sum of three bf16 pieces; a product is the six partial products of total order <= 2,
- * accumulated in fp32.  The error is that of an fp32 fmaf chain (the dropped terms are below one fp32 rounding of the
- * product); the matrix time is 6/16 of the fp32-input MFMA's, the only exact-fp32 matrix instruction of gfx950.
+/* ---- split matrix path (csrc/split_mfma.h): fp32 results from the fp16 matrix pipe --------------------------------------
+ * Every fp32 operand, scaled by an exact power of two, is the sum of two fp16 pieces up to 2^-23 of itself; a product is the
+ * three partial products l.h + h.l + h.h accumulated in fp32.  The error is that of an fp32 fmaf chain (2.7e-7 of max|y| on a
+ * 256-deep product against float64; an fp32 GEMM: 6.4e-7); the matrix time is 3/16 of the fp32-input MFMA's, the only exact-fp32
+ * matrix instruction of gfx950.  Scales: one power of two per weight matrix (chosen by the packer), one per position (chosen by
+ * the kernels from the position's own largest activation) -- the path has no operand range to leave, inputs of any fp32
+ * magnitude give fp32-accurate results (non-finite inputs give non-finite outputs, as in the reference).
  *
  * rtk_pack_split_layer: w (cout, cin) row-major fp32 (transposed != 0: the layer is w^T, w stored (cin, cout) row-major -- the
- * backward's W^T products from the forward's weights), both multiples of 32 -> image of cin/16 * cout/32 * 3 fragments
- * of 1 KiB (6 * cout * cin bytes), fragment (s, v, p) = piece p of rows 32 v .. +31 against the 16 input channels of k-step s
- * in the lane order of v_mfma_f32_32x32x16_bf16.
+ * backward's W^T products from the forward's weights), both multiples of 32, cout * cin <= 2^22 -> image of cin/16 * cout/32 * 2
+ * fragments of 1 KiB (4 * cout * cin bytes), fragment (s, v, p) = piece p (0: h, 1: l) of 2^k W, rows 32 v .. +31 against the 16
+ * input channels of k-step s in the lane order of v_mfma_f32_32x32x16_f16; *inv_scale = 2^-k (k: max|W| 2^k in [2^14, 2^15)).
+ * Consumers take the image and a pointer to its inverse scale (layers back to back: images back to back, scales back to back).
  * rtk_split_mlp2: y = leaky(W2 leaky(W1 x + b1) + b2), LeakyReLU(0.1), x / y (positions, 256) point-major; images = the split
- * images of W1 and W2 back to back.  The inner layers of the cost volume (utils/model_utils/model_utils.py:216-236) as a
- * standalone operator: what tests and tools time the matrix path with. */
-RTK_EXPORT int rtk_pack_split_layer(int cout, int cin, const float *w, int transposed, void *image, rtk_stream_t stream);
+ * images of W1 and W2 back to back, image_scales = their two inverse scales.  The inner layers of the cost volume
+ * (utils/model_utils/model_utils.py:216-236) as a standalone operator: what tests and tools time the matrix path with. */
+RTK_EXPORT int rtk_pack_split_layer(int cout, int cin, const float *w, int transposed, void *image, float *inv_scale,
+                                    rtk_stream_t stream);
 /* rtk_cost_volume with its two 256 x 256 layers on the split path: same arguments, the layers as their split images (W2, W3
- * back to back, 2 * 393216 bytes) and fp32 biases instead of the packed rtk_layer_t pair.  samples * n2 <= 2^22 (the gathered
+ * back to back, 2 * 262144 bytes, with their two inverse scales) and fp32 biases instead of the packed rtk_layer_t pair.  samples * n2 <= 2^22 (the gathered
  * p2 rows are requested with 32-bit byte offsets; RTK_ERR_INVALID beyond: split the batch). */
 RTK_EXPORT int rtk_cost_volume_split(int samples, int n1, int n2, const float *xyz1, const float *xyz2,
                                      const int64_t *knn_idx, const float *p1, const float *p2, const float *wd_packed,
-                                     const void *split_images, const float *bias2, const float *bias3,
-                                     const rtk_layer_t *wn, float *out, int out_pitch, rtk_stream_t stream);
+                                     const void *split_images, const float *image_scales, const float *bias2,
+                                     const float *bias3, const rtk_layer_t *wn, float *out, int out_pitch, rtk_stream_t stream);
 /* ... on a share of the chip.  The kernel keeps a CU whole (486 registers per lane, 112 KiB of LDS): launched with one workgroup per
  * CU it stops every other kernel for its duration.  With several batches in flight (ratrack_amd.fused.GraphPipeline) the step is
  * shorter when it takes `workgroups` < the CU count -- 3/4 of them at B = 64: the kernel itself runs 16 % longer, the pipelined
@@ -128,16 +133,17 @@ RTK_EXPORT int rtk_cost_volume_split(int samples, int n1, int n2, const float *x
  * rounded down to a multiple of 8 (one share per XCD: all tiles of sample s run on XCD s % 8); ignored unless samples % 8 == 0. */
 RTK_EXPORT int rtk_cost_volume_split_shared(int samples, int n1, int n2, const float *xyz1, const float *xyz2,
                                             const int64_t *knn_idx, const float *p1, const float *p2, const float *wd_packed,
-                                            const void *split_images, const float *bias2, const float *bias3,
-                                            const rtk_layer_t *wn, float *out, int out_pitch, int workgroups, rtk_stream_t stream);
+                                            const void *split_images, const float *image_scales, const float *bias2,
+                                            const float *bias3, const rtk_layer_t *wn, float *out, int out_pitch, int workgroups,
+                                            rtk_stream_t stream);
 /* rtk_sa_scale for the scales whose MLP is offset layer (c1 = 32 or 64 channels) + ONE layer c1 -> 64, nsample 16 or 32 (sa2 scale 1,
- * sa3 scales 0 and 1 of the PNHead): same arguments, the layer as its split image (rtk_pack_split_layer(64, c1, ...)) + fp32 bias. */
+ * sa3 scales 0 and 1 of the PNHead): same arguments, the layer as its split image + inverse scale (rtk_pack_split_layer(64, c1, ...)) + fp32 bias. */
 RTK_EXPORT int rtk_sa_scale_split(int samples, int n, int npoint, int nsample, const float *xyz, const float *new_xyz,
                                   const int *idx, const float *q, int q_pitch, int c1, const float *w1xyz_packed,
-                                  const void *split_image, const float *bias2, float *out, int out_pitch, int out_offset,
-                                  const int *src_nuniq, const int *dst_nuniq, rtk_stream_t stream);
-RTK_EXPORT int rtk_split_mlp2(int positions, const float *x, const void *images, const float *bias1, const float *bias2,
-                              float *y, rtk_stream_t stream);
+                                  const void *split_image, const float *image_scale, const float *bias2, float *out, int out_pitch,
+                                  int out_offset, const int *src_nuniq, const int *dst_nuniq, rtk_stream_t stream);
+RTK_EXPORT int rtk_split_mlp2(int positions, const float *x, const void *images, const float *image_scales, const float *bias1,
+                              const float *bias2, float *y, rtk_stream_t stream);
 
 /* Layout glue of Track4D.backbone (models/track4d.py:104-105): (B,3,N)/(B,2,N) channel-major inputs of both
  * frames -> xyz (2B,N,3) and raw (2B,N,4) = (RCS, v_r, 0, 0) point-major, frame 1 first. */

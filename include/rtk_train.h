@@ -297,18 +297,18 @@ RTK_EXPORT int rtk_cost_volume_bwd(int samples, int n1, int n2, const float *xyz
                                    int dout_pitch, const float *a3, const void *mask1, const void *mask2, float *dz1, float *dz2, float *dz3,
                                    float *dq3, float *d4, float *dp1, float *dpd, float *dt2, float *dbias_rows, rtk_stream_t stream);
 
-/* The same two operators with their 256 x 256 products on the split-bf16 matrix path (rtk_fused.h, csrc/split_mfma.h): identical
- * arguments and tensor formats (activations, sign masks, gradients), except that the two layers arrive as split images --
- * forward: W2, W3 (rtk_pack_split_layer) + fp32 biases; backward: W3^T, W2^T (rtk_pack_split_layer with transposed = 1 on the
- * forward's weights) -- and that the backward builds its Wc^T operand itself (no wct_packed). */
+/* The same two operators with their 256 x 256 products on the split matrix path (rtk_fused.h, csrc/split_mfma.h): identical
+ * arguments and tensor formats (activations, sign masks, gradients), except that the two layers arrive as split images with their
+ * inverse scales -- forward: W2, W3 (rtk_pack_split_layer) + fp32 biases; backward: W3^T, W2^T (rtk_pack_split_layer with
+ * transposed = 1 on the forward's weights) -- and that the backward builds its Wc^T operand itself (no wct_packed). */
 RTK_EXPORT int rtk_cost_volume_split_train(int samples, int n1, int n2, const float *xyz1, const float *xyz2,
                                            const int64_t *knn_idx, const float *p1, const float *p2, const float *wd_packed,
-                                           const void *split_images, const float *bias2, const float *bias3,
-                                           const rtk_layer_t *wn, float *out, int out_pitch, float *a1, float *a2, float *a3,
-                                           void *mask1, void *mask2, rtk_stream_t stream);
+                                           const void *split_images, const float *image_scales, const float *bias2,
+                                           const float *bias3, const rtk_layer_t *wn, float *out, int out_pitch, float *a1, float *a2,
+                                           float *a3, void *mask1, void *mask2, rtk_stream_t stream);
 RTK_EXPORT int rtk_cost_volume_bwd_split(int samples, int n1, int n2, const float *xyz1, const float *xyz2,
-                                         const int64_t *knn_idx, const void *split_images_t, const rtk_layer_t *wn,
-                                         const float *dout, int dout_pitch, const float *a3, const void *mask1, const void *mask2,
+                                         const int64_t *knn_idx, const void *split_images_t, const float *image_scales_t,
+                                         const rtk_layer_t *wn, const float *dout, int dout_pitch, const float *a3, const void *mask1, const void *mask2,
                                          float *dz1, float *dz2, float *dz3, float *dq3, float *d4, float *dp1, float *dpd,
                                          float *dt2, float *dbias_rows, rtk_stream_t stream);
 

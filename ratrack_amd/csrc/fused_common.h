@@ -262,6 +262,60 @@ __device__ __forceinline__ void split3(const f4 x0, const f4 x1, u4v (&b)[3]) {
 }
 
 
+// ---- round 5: TWO fp16 pieces, THREE products (the scheme is described in split_mfma.h) -----------------------------------------
+// x s = h + l + e with h = fp16(x s), l = fp16(x s - h), both round-to-nearest: |e| <= 2^-23 |x s| while l is a normal fp16
+// number and <= 2^-25 absolutely below that (subnormal pieces are KEPT by the f16 matrix instructions and by v_cvt_pk_f16_f32 on
+// gfx950: tools/micro/f16_mfma_probe.hip).  s is an exact power of two chosen PER POSITION from the position's own largest
+// activation, so that nothing overflows and the absolute floor sits 2^-39 below that largest value: the scheme has no range to
+// leave.  Built from compiler-known instructions (v_pk_mul_f32, v_cvt_pk_f16_f32, v_fma_mixlo_f16 / v_fma_mixhi_f16 -- two VALU
+// operations per value with -fno-slp-vectorize; the bf16 three-way split took 5.5).
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+struct LaneScale {
+    float s;        // 2^k: max |x s| over the position's channels lies in [2^14, 2^15)   (fp16 overflows at 65520)
+    float inv;      // 2^-k
+};
+// from the bits of m = max |x| >= 0.  m = 0 or below 2^-112: k is clamped to 126 (everything scaled is then below 2^14 -- exact
+// all the same); m = inf: the scaled operand overflows to inf and the product is NaN, as non-finite as the reference's.
+__device__ __forceinline__ LaneScale lane_scale_of(unsigned mbits) {
+    const unsigned e = mbits >> 23;
+    unsigned sf = 268u - e;
+    sf = sf > 253u ? 253u : sf;
+    return LaneScale{__uint_as_float(sf << 23), __uint_as_float((254u - sf) << 23)};
+}
+// max |.| over a lane's activations, two per instruction (v_max3_f32 with |.| source modifiers; a NaN operand is ignored by the
+// maximum and comes back through the product)
+template <int N>
+__device__ __forceinline__ float abs_max_f4(const f4 (&h)[N]) {
+    float m = 0.f;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(h[e].x)), __builtin_fabsf(h[e].y));
+        m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(h[e].z)), __builtin_fabsf(h[e].w));
+    }
+    return m;
+}
+// the two fp16 pieces of two scaled activations, one register each (low half = first value)
+struct SplitWord { unsigned h, l; };
+__device__ __forceinline__ SplitWord split2_word(float xa, float xb, float s) {
+    const f2v xs = (f2v){xa, xb} * s;
+    const h2v h = __builtin_convertvector(xs, h2v);
+    const _Float16 la = (_Float16)__builtin_fmaf(xa, s, -(float)h[0]);      // x s - h is exact in fp32: ONE rounding, to fp16
+    const _Float16 lb = (_Float16)__builtin_fmaf(xb, s, -(float)h[1]);
+    return SplitWord{__builtin_bit_cast(unsigned, h), __builtin_bit_cast(unsigned, (h2v){la, lb})};
+}
+// ... of eight activations (one k-step of this lane's B operand): b[0] = h pieces, b[1] = l pieces
+__device__ __forceinline__ void split2(const f4 x0, const f4 x1, float s, u4v (&b)[2]) {
+    const SplitWord w0 = split2_word(x0.x, x0.y, s), w1 = split2_word(x0.z, x0.w, s), w2 = split2_word(x1.x, x1.y, s), w3 = split2_word(x1.z, x1.w, s);
+    b[0] = (u4v){w0.h, w1.h, w2.h, w3.h};
+    b[1] = (u4v){w0.l, w1.l, w2.l, w3.l};
+}
+__device__ __forceinline__ f4 mfma16_h(u4v a, u4v b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, a), __builtin_bit_cast(h8v, b), c, 0, 0, 0);
+}
+
 __device__ __forceinline__ f4 mfma16_bf(u4v a, u4v b, f4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
 }

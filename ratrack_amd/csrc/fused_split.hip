@@ -1,4 +1,5 @@
-// fused_split.hip -- kernels on the split-bf16 matrix path (split_mfma.h): fp32 results from v_mfma_f32_32x32x16_bf16.
+// fused_split.hip -- kernels on the split matrix path (split_mfma.h): fp32 results from v_mfma_f32_32x32x16_f16, two fp16 pieces
+// per operand, three products, a power-of-two scale per weight matrix and per position.
 #include "rtk_common.h"
 #include "rtk_fused.h"
 #include "split_mfma.h"
@@ -9,15 +10,32 @@ namespace {
 #define SP_NW 4           // waves per workgroup = one per SIMD: the tile keeps ~400 registers per lane
 #endif
 #ifndef SP_F
-#define SP_F 48           // fragments (KiB) per half of the LDS double buffer: a multiple of 6 (one group step)
+#define SP_F 32           // fragments (KiB) per half of the LDS double buffer: a power of two (a layer is 256 fragments)
 #endif
-// The forward cost volume streams in halves of 24 KiB (four group steps per chunk: the kernel's clock count is the same as with 48
-// -- tools/experiments/cv_ticks.py --totals-only: 685.6 k against 688.7 k --, chunk boundaries cost nothing measurable), which leaves
-// LDS for the staged rows of layer 1 AND for the small geometry kernels of the other batches in flight on the same CU.
-constexpr int CV_F = 24;
+// The forward cost volume streams in halves of 32 KiB (eight group steps of six MFMAs per chunk: the 1 536 matrix clocks the
+// 24 KiB halves of the six-product kernel lasted), next to the 64 KiB of staged rows of layer 1.
+constexpr int CV_F = 32;
 
-// ---- packing: (256 x 256) row-major fp32 weights -> split image (split_mfma.h) ---------------------------------------------
-__global__ __launch_bounds__(256) void pack_split_kernel(int cout, int cin, const float *__restrict__ w, int transposed, u4v *__restrict__ out) {
+// ---- packing: (cout x cin) row-major fp32 weights -> split image + the inverse of its power-of-two scale (split_mfma.h) ---------
+// Every workgroup scans the whole matrix for max|w| itself (at most 256 KiB, L2-resident: one launch, no atomics, no scratch).
+__global__ __launch_bounds__(256) void pack_split_kernel(int cout, int cin, const float *__restrict__ w, int transposed, u4v *__restrict__ out,
+                                                         float *__restrict__ inv_scale) {
+    __shared__ unsigned s_m[4];
+    float m = 0.f;
+    const f4 *w4 = reinterpret_cast<const f4 *>(w);
+    for (int i = threadIdx.x; i < cout * cin / 4; i += 256) {
+        const f4 t = w4[i];
+        m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(t.x)), __builtin_fabsf(t.y));
+        m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(t.z)), __builtin_fabsf(t.w));
+    }
+    unsigned mb = __float_as_uint(m);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const unsigned o = __shfl_xor(mb, d, 64); mb = o > mb ? o : mb; }
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mb;
+    __syncthreads();
+    mb = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+    const LaneScale sc = lane_scale_of(mb);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *inv_scale = sc.inv;
     const int VB = cout / 32, slot = blockIdx.x * 256 + threadIdx.x;      // slot = (s, v, lane)
     if (slot >= (cin / 16) * VB * 64) return;
     const int lane = slot & 63, v = (slot >> 6) % VB, s = (slot >> 6) / VB, hh = lane >> 5, i = lane & 31;
@@ -30,56 +48,55 @@ __global__ __launch_bounds__(256) void pack_split_kernel(int cout, int cin, cons
         const float *row = w + (size_t)o * cin + c0;
         x0 = *reinterpret_cast<const f4 *>(row); x1 = *reinterpret_cast<const f4 *>(row + 8);
     }
-    u4v b[3];
-    split3(x0, x1, b);
+    u4v b[2];
+    split2(x0, x1, sc.s, b);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) out[((size_t)(s * VB + v) * 3 + p) * 64 + lane] = b[p];
+    for (int p = 0; p < 2; ++p) out[((size_t)(s * VB + v) * 2 + p) * 64 + lane] = b[p];
 }
+
+// y = leaky(acc c + b) for a whole accumulator set (c = this lane's 2^-(kw + kx)): the epilogue between two split layers
+__device__ __forceinline__ float leaky_med(float x, float inf) { return __builtin_amdgcn_fmed3f(x, 0.1f * x, inf); }      // max(x, 0.1 x): one v_med3_f32 the compiler knows
+__device__ __forceinline__ f4 leaky_med4(f4 t, float inf) {
+    const f4 u = t * 0.1f;                                                  // two v_pk_mul_f32
+    return (f4){__builtin_amdgcn_fmed3f(t.x, u.x, inf), __builtin_amdgcn_fmed3f(t.y, u.y, inf), __builtin_amdgcn_fmed3f(t.z, u.z, inf),
+                __builtin_amdgcn_fmed3f(t.w, u.w, inf)};
+}
+__device__ __forceinline__ f4 scale_bias4(f4 a, float c, f4 b) { return __builtin_elementwise_fma(a, (f4){c, c, c, c}, b); }
+__device__ __forceinline__ float rtk_hidden_inf();
 
 // ---- two 256 x 256 layers with LeakyReLU(0.1) over a list of positions (the inner layers of the cost volume, standalone) ----
 __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void split_mlp2_kernel(int positions, const float *__restrict__ x, const f4 *__restrict__ blob, const float *__restrict__ bias1,
-                       const float *__restrict__ bias2, float *__restrict__ y) {
+void split_mlp2_kernel(int positions, const float *__restrict__ x, const f4 *__restrict__ blob, const float *__restrict__ wsc,
+                       const float *__restrict__ bias1, const float *__restrict__ bias2, float *__restrict__ y) {
+    const float kinf = rtk_hidden_inf();
     __shared__ __attribute__((aligned(16))) f4 s_w[2 * SP_F * 64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hh = lane >> 5, col = lane & 31;
     constexpr int NF = 2 * SPLIT_NF;
     WStreamA<SP_NW, SP_F, NF> ws;
     ws.start_parts(blob, s_w, wave, lane);
+    const float wi1 = ldc(wsc), wi2 = ldc(wsc + 1);
     const int tiles = (positions + 32 * SP_NW - 1) / (32 * SP_NW);
     for (int T = blockIdx.x; T < tiles; T += gridDim.x) {
         asm volatile("" ::: "memory");
         const long pos = (long)T * 32 * SP_NW + 32 * wave + col;
         const bool valid = pos < positions;
         const float *xr = x + (valid ? pos : (long)positions - 1) * 256 + 4 * hh;
-        f4 h[32];
+        f4 h[32], bq[2][8];
 #pragma unroll
         for (int i = 0; i < 32; ++i) h[i] = *reinterpret_cast<const f4 *>(xr + 8 * i);      // channels 32 (i/4) + 8 (i%4) + 4 hh ..
         f16v acc[SPLIT_VB];
-#pragma unroll
-        for (int v = 0; v < SPLIT_VB; ++v) acc[v] = split_bias(bias1, v, hh);
-        split_layer<0>(ws, h, acc);
-#pragma unroll
-        for (int v = 0; v < SPLIT_VB; ++v)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f4 t = (f4){acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]};
-                h[4 * v + q] = (f4){fmaxf(t.x, 0.1f * t.x), fmaxf(t.y, 0.1f * t.y), fmaxf(t.z, 0.1f * t.z), fmaxf(t.w, 0.1f * t.w)};
-            }
-#pragma unroll
-        for (int v = 0; v < SPLIT_VB; ++v) acc[v] = split_bias(bias2, v, hh);
-        split_layer<SPLIT_NF>(ws, h, acc);
+        LaneScale sc = lane_scale32(h);
+        split_layer<0>(ws, h, sc.s, acc, BiasSide{bias1 + 4 * hh, bq});
+        float c = sc.inv * wi1;
+        split_epilogue(acc, bias1 + 4 * hh, bq, [&](int e, f4 a, f4 b) { h[e] = leaky_med4(scale_bias4(a, c, b), kinf); });
+        sc = lane_scale32(h);
+        split_layer<SPLIT_NF>(ws, h, sc.s, acc, BiasSide{bias2 + 4 * hh, bq});
         ws.sync();
+        c = sc.inv * wi2;
         float *yr = y + pos * 256 + 4 * hh;
-        if (valid) {
-#pragma unroll
-            for (int v = 0; v < SPLIT_VB; ++v)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f4 t = (f4){acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]};
-                    *reinterpret_cast<f4 *>(yr + 32 * v + 8 * q) = (f4){fmaxf(t.x, 0.1f * t.x), fmaxf(t.y, 0.1f * t.y),
-                                                                        fmaxf(t.z, 0.1f * t.z), fmaxf(t.w, 0.1f * t.w)};
-                }
-        }
+        split_epilogue(acc, bias2 + 4 * hh, bq, [&](int e, f4 a, f4 b) {
+            if (valid) *reinterpret_cast<f4 *>(yr + 8 * e) = leaky_med4(scale_bias4(a, c, b), kinf);
+        });
     }
     ws.finish();
 }
@@ -103,7 +120,8 @@ struct CvSplitParams {
     const int64_t *knn;
     const float *p1, *p2;
     const float *wd;              // [16][64] image of [Wd | 0] (fused_common.h): Wd[c][k] = wd[(c / 16) * 64 + 16 k + c % 16]
-    const f4 *blob;               // split images of layers 2, 3
+    const f4 *blob;               // split images of layers 2, 3 ...
+    const float *wsc;             // ... and the inverses of their power-of-two weight scales (rtk_pack_split_layer)
     const float *bias2, *bias3;
     WnSplit wn;
     float *out;
@@ -192,23 +210,16 @@ __device__ __forceinline__ f4 f4_max(f4 a, f4 b) { return (f4){fmaxf(a.x, b.x), 
 // max(x, 0.1 x) and max(x, 0) in ONE instruction each.  fmaxf() costs two under IEEE mode -- hipcc first quiets a possible signalling
 // NaN in every operand it did not compute itself (v_max_f32 x, x, x on each accumulator read): 32 extra VALU instructions per
 // 32-channel block of the epilogue, 256 per layer boundary -- and a median with a literal +inf (v_med3_f32) is folded back into
-// exactly that maxnum.  LeakyReLU: the v_max_f32 is written out; its second operand is a product the compiler sees, which is where
-// it places the wait states a matrix-core result needs (an asm statement gets none).  ReLU: the median with a +inf the optimiser
-// cannot see (an SGPR written by a volatile asm, once per kernel: rtk_hidden_inf) -- an instruction the compiler knows, so a
-// matrix-core operand is safe.  Same bits as fmaxf for every non-NaN input.
+// exactly that maxnum.  Both are the median with a +inf the optimiser cannot see (an SGPR written by a volatile asm, once per
+// kernel: rtk_hidden_inf): ReLU = med3(x, 0, inf), LeakyReLU = med3(x, 0.1 x, inf) (leaky_med above) -- instructions the compiler
+// knows, so it places the wait states a matrix-core result needs itself (round 4's LeakyReLU was a written-out v_max_f32 that
+// relied on the product in front of it for that).  Same bits as fmaxf for every non-NaN input.
 __device__ __forceinline__ float rtk_hidden_inf() {
     float v;
     asm volatile("s_mov_b32 %0, 0x7f800000" : "=s"(v));
     return v;
 }
-__device__ __forceinline__ float leaky1(float x) {
-    float o;
-    const float y = 0.1f * x;
-    asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(x), "v"(y));
-    return o;
-}
 __device__ __forceinline__ float relu1(float x, float inf) { return __builtin_amdgcn_fmed3f(x, 0.f, inf); }
-__device__ __forceinline__ f4 leaky4(f4 t) { return (f4){leaky1(t.x), leaky1(t.y), leaky1(t.z), leaky1(t.w)}; }
 __device__ __forceinline__ f4 f4_relu(f4 a) { return (f4){fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)}; }
 
 // ---- layer 1's operands ---------------------------------------------------------------------------------------------------
@@ -256,7 +267,7 @@ struct CvLayer2Side {
     template <int GI>
     __device__ __forceinline__ void at(const f4 (&h)[32]) const {
         if constexpr (SAVE) st.template at<GI>(h);
-        constexpr int per_chunk = CV_F / 6, ig = split_issue_groups(CV_F), g = GI % per_chunk, n = (GI / per_chunk) * ig + g;
+        constexpr int per_chunk = CV_F / SPLIT_GF, ig = split_issue_groups(CV_F), g = GI % per_chunk, n = (GI / per_chunk) * ig + g;
         if constexpr (g < ig && 3 * n < 16) {
             rq.template one<3 * n>();
             if constexpr (3 * n + 1 < 16) rq.template one<3 * n + 1>();
@@ -298,7 +309,7 @@ __device__ __forceinline__ f4 mul_row_bcast(const f4 q, const f4 r) {
     return o;
 }
 template <int V0, int V1>
-__device__ __forceinline__ void cv_layer1_blocks(const CvSplitParams &P, const f4 q0, const f4 q1, float b0, float b1, int hh, int col, f4 (&h)[32]) {
+__device__ __forceinline__ void cv_layer1_blocks(const CvSplitParams &P, const f4 q0, const f4 q1, float b0, float b1, int hh, int col, float kinf, f4 (&h)[32]) {
     static_assert(V1 <= 8, "eight 32-channel blocks");
     auto block = [&](auto vc) {
         constexpr int v = decltype(vc)::value;
@@ -315,7 +326,7 @@ __device__ __forceinline__ void cv_layer1_blocks(const CvSplitParams &P, const f
         c = mfma_f32x2(ldc(wr + 16 * hh), b0, c);
         c = mfma_f32x2(ldc(wr + 16 * (2 + hh)), b1, c);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) h[4 * v + q] = leaky4((f4){c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]});
+        for (int q = 0; q < 4; ++q) h[4 * v + q] = leaky_med4((f4){c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]}, kinf);
     };
     block(std::integral_constant<int, V0>{}); block(std::integral_constant<int, V0 + 1>{});
     block(std::integral_constant<int, V0 + 2>{}); block(std::integral_constant<int, V0 + 3>{});
@@ -352,6 +363,7 @@ void cost_volume_split_kernel(const CvSplitParams P) {
     locate(t0 < ntiles ? t0 : 0, b, bx);
     WStreamA<SP_NW, CV_F, 2 * SPLIT_NF> ws;
     ws.start_parts(P.blob, s_w, wave, lane);
+    const float wi2 = ldc(P.wsc), wi3 = ldc(P.wsc + 1);
     // The tile loop is software-pipelined by one tile (round 4): the NEXT tile's neighbour index is requested at the top of the
     // CURRENT tile, the first half of its gathered rows (cv_rows_request<0>) right after layer 1, its direction and its two p1 slots
     // inside the epilogue, whose WeightNet / neighbour-sum arithmetic (VALU + DPP) runs while they arrive.
@@ -385,10 +397,10 @@ void cost_volume_split_kernel(const CvSplitParams P) {
             const float b0 = hh ? dy : dx, b1 = hh ? 0.f : dz;      // B[k = hh][col] of the two k-steps (k = 3: the zero column)
             cv_rows_read<0>(rows, col, hh, h);
             cv_rows_request<1>(P.p2, (int)nb, rows, lane);
-            cv_layer1_blocks<0, 4>(P, q0, q1, b0, b1, hh, col, h);
+            cv_layer1_blocks<0, 4>(P, q0, q1, b0, b1, hh, col, kinf, h);
             __builtin_amdgcn_sched_barrier(0);      // (round 1's reads wait for the DMA: hipcc would hoist them, and the wait, above the four blocks)
             cv_rows_read<1>(rows, col, hh, h);
-            cv_layer1_blocks<4, 8>(P, q0, q1, b0, b1, hh, col, h);
+            cv_layer1_blocks<4, 8>(P, q0, q1, b0, b1, hh, col, kinf, h);
         }
         const long nbn = (long)bn * P.n2 + knn_next;      // (no next tile: row 0 of the sample, requested and never read)
         // byte offset of this lane's first 16-byte slot in a (position, 256) row (one 32-bit VGPR on uniform base pointers)
@@ -401,31 +413,28 @@ void cost_volume_split_kernel(const CvSplitParams P) {
             P.mk1[pos * 4 + 2 + hh] = m[1];
         }
         f16v acc[SPLIT_VB];
-#pragma unroll
-        for (int v = 0; v < SPLIT_VB; ++v) acc[v] = split_bias(P.bias2, v, hh);
-        // a1 goes out while it is being consumed; the next tile's first round of rows is requested
-        split_layer<0>(ws, h, acc, CvLayer2Side<SAVE>{StoreRowsSide{P.sv1, ro, valid}, CvRowsRequest(P.p2, rows, (int)nbn, 0, lane)});
-#pragma unroll
-        for (int v = 0; v < SPLIT_VB; ++v)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) h[4 * v + q] = leaky4((f4){acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]});
+        f4 bq[2][8];
+        // a1 goes out while it is being consumed; the next tile's first round of rows is requested; the bias arrives during the last k-step
+        LaneScale sc = lane_scale32(h);
+        split_layer<0>(ws, h, sc.s, acc, SidePair<CvLayer2Side<SAVE>, BiasSide>{{StoreRowsSide{P.sv1, ro, valid}, CvRowsRequest(P.p2, rows, (int)nbn, 0, lane)},
+                                                                              BiasSide{P.bias2 + 4 * hh, bq}});
+        float c = sc.inv * wi2;
+        split_epilogue(acc, P.bias2 + 4 * hh, bq, [&](int e, f4 a, f4 b) { h[e] = leaky_med4(scale_bias4(a, c, b), kinf); });
         if (SAVE && valid) {
             uint2 m[2];
             split_sign_masks(h, m);
             P.mk2[pos * 4 + hh] = m[0];
             P.mk2[pos * 4 + 2 + hh] = m[1];
         }
-#pragma unroll
-        for (int v = 0; v < SPLIT_VB; ++v) acc[v] = split_bias(P.bias3, v, hh);
-        if (SAVE) split_layer<SPLIT_NF>(ws, h, acc, StoreRowsSide{P.sv2, ro, valid});
-        else split_layer<SPLIT_NF>(ws, h, acc);
+        sc = lane_scale32(h);
+        if (SAVE) split_layer<SPLIT_NF>(ws, h, sc.s, acc, SidePair<StoreRowsSide, BiasSide>{StoreRowsSide{P.sv2, ro, valid}, BiasSide{P.bias3 + 4 * hh, bq}});
+        else split_layer<SPLIT_NF>(ws, h, sc.s, acc, BiasSide{P.bias3 + 4 * hh, bq});
         ws.sync();                                                   // wrap the stream to chunk 0
+        c = sc.inv * wi3;
+        split_epilogue(acc, P.bias3 + 4 * hh, bq, [&](int e, f4 a, f4 b) { h[e] = leaky_med4(scale_bias4(a, c, b), kinf); });      // a3
         if (SAVE && valid) {
 #pragma unroll
-            for (int v = 0; v < SPLIT_VB; ++v)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *cv_at(P.sv3, ro + 32u * (4 * v + q)) = leaky4((f4){acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]});
+            for (int e = 0; e < 32; ++e) *cv_at(P.sv3, ro + 32u * e) = h[e];
         }
         WnBlock wk = wn_block(P.wn, 0, hh, col);                     // block 0's operands travel during the hidden layers
         float t2[8];
@@ -443,7 +452,7 @@ void cost_volume_split_kernel(const CvSplitParams P) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) r[q][e] = relu1(w[4 * q + e], kinf) * leaky1(acc[v][4 * q + e]);
+                for (int e = 0; e < 4; ++e) r[q][e] = relu1(w[4 * q + e], kinf) * h[4 * v + q][e];
             row_sum16_valu_f4x4(r);
             if (valid && j == 0) {
 #pragma unroll
@@ -502,6 +511,7 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
     const int groups = (P.n1 + PPW - 1) / PPW;
     WStreamA<SP_NW, SP_F, 2 * SPLIT_NF> ws;
     ws.start_parts(P.blob, s_w, wave, lane);                             // (its barrier also publishes s_wct)
+    const float wi3 = ldc(P.wsc), wi2 = ldc(P.wsc + 1);                  // images: W3^T, W2^T
     // software-pipelined by one tile like the forward kernel: the next tile's neighbour index and direction are requested in this
     // tile's epilogue (the dz1 / neighbour-sum phase), not in front of its own first loads
     int pt = bx * PPW + 2 * wave + pp;
@@ -576,16 +586,14 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
         if (valid) *reinterpret_cast<f4 *>(Q.dt2 + pos * 8 + 4 * hh) = (f4){dt2[0], dt2[1], dt2[2], dt2[3]};      // rows 4 hh .. + 3 of the 8 hidden units
         // ---- da2 = W3^T dz3;  dz2 = da2 leaky'(z2) ----------------------------------------------------------------------------
         f16v acc[SPLIT_VB];
-#pragma unroll
-        for (int v = 0; v < SPLIT_VB; ++v)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[v][e] = 0.f;
-        split_layer<0>(ws, h, acc, StoreRowsSide{Q.dz3, ro, valid});
+        LaneScale sc = lane_scale32(h);          // gradients span many orders of magnitude: the position's own scale is what keeps 22 bits
+        split_layer<0>(ws, h, sc.s, acc, StoreRowsSide{Q.dz3, ro, valid});
+        float c = sc.inv * wi3;
 #pragma unroll
         for (int v = 0; v < SPLIT_VB; ++v)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f4 z = leaky_grad_bits4((f4){acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]}, split_mask_bits(m2, v, q));
+                const f4 z = leaky_grad_bits4(acc_slot(acc, 4 * v + q) * c, split_mask_bits(m2, v, q));
                 h[4 * v + q] = z;
                 if (Q.dbrows) {
                     f4 r = z;
@@ -594,12 +602,10 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
                 }
             }
         // ---- da1 = W2^T dz2;  dz1 = da1 leaky'(z1);  dp1 = sum over the 16 neighbours; per-query partials of dWd = dz1^T d -----
-#pragma unroll
-        for (int v = 0; v < SPLIT_VB; ++v)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[v][e] = 0.f;
-        split_layer<SPLIT_NF>(ws, h, acc, StoreRowsSide{Q.dz2, ro, valid});
+        sc = lane_scale32(h);
+        split_layer<SPLIT_NF>(ws, h, sc.s, acc, StoreRowsSide{Q.dz2, ro, valid});
         ws.sync();                                                   // wrap the stream to chunk 0
+        c = sc.inv * wi2;
         // ---- next tile: neighbour index now, direction half way through the epilogue ---------------------------------------
         const int Gn = G + nbx;
         const bool more = Gn < groups;
@@ -620,7 +626,7 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                f4 r = leaky_grad_bits4((f4){acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]}, split_mask_bits(m1, v, q));
+                f4 r = leaky_grad_bits4(acc_slot(acc, 4 * v + q) * c, split_mask_bits(m1, v, q));
                 if (valid) *cv_at(Q.dz1, ro + 32u * (4 * v + q)) = r;
                 f4 rx = r * dx, ry = r * dy, rz = r * dz;
                 row_sum16_valu_f4(r);
@@ -651,7 +657,8 @@ struct SaSplitParams {
     const float *q;
     int q_pitch;
     const float *w1;        // offset layer image [C1 / 16][64] of [Wx | b1]
-    const f4 *image;        // split image of the C1 -> 64 layer
+    const f4 *image;        // split image of the C1 -> 64 layer ...
+    const float *wsc;       // ... and the inverse of its power-of-two weight scale
     const float *bias2;
     float *out;
     int out_pitch, out_offset;
@@ -666,7 +673,7 @@ struct SaSplitParams {
 #endif
 template <int NS, int C1>
 __global__ __launch_bounds__(256, SA_SPLIT_WAVES) void sa_scale_split_kernel(const SaSplitParams P) {
-    constexpr int KS = C1 / 16, VB1 = C1 / 32, NFR = KS * 2 * 3, CPT = 32 / NS;      // k-steps, 32-blocks of layer 1, fragments, centroids per tile
+    constexpr int KS = C1 / 16, VB1 = C1 / 32, NFR = KS * 2 * 2, CPT = 32 / NS;      // k-steps, 32-blocks of layer 1, fragments, centroids per tile
     __shared__ __attribute__((aligned(16))) f4 s_img[NFR * 64];
     const int lane = threadIdx.x & 63, hh = lane >> 5, col = lane & 31, pp = col / NS, slot = col % NS;
     int b, bx, nbx;
@@ -678,6 +685,7 @@ __global__ __launch_bounds__(256, SA_SPLIT_WAVES) void sa_scale_split_kernel(con
     for (int i = threadIdx.x; i < NFR * 64; i += blockDim.x) s_img[i] = P.image[i];
     __syncthreads();
     const int src_e = P.src_nuniq ? P.src_nuniq[b] : 0x7fffffff;
+    const float winv = ldc(P.wsc);
     for (int unit = bx * 4 + (threadIdx.x >> 6); unit < live_units; unit += nbx * 4) {
         int cl = unit * CPT + pp;                                  // centroid of this lane within the sample
         const bool valid = cl < live_c;
@@ -706,7 +714,9 @@ __global__ __launch_bounds__(256, SA_SPLIT_WAVES) void sa_scale_split_kernel(con
 #pragma unroll
             for (int q = 0; q < 4; ++q) h[4 * v + q] = f4_relu((f4){a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]});
         }
-        // layer 2 (C1 -> 64), bias + ReLU after the max
+        // layer 2 (C1 -> 64) on the split path, the position's activations scaled by its own power of two; ReLU after the max
+        const LaneScale sc = lane_scale32(h);
+        const float cs = sc.inv * winv;
         f16v acc[2];
 #pragma unroll
         for (int v = 0; v < 2; ++v)
@@ -714,15 +724,15 @@ __global__ __launch_bounds__(256, SA_SPLIT_WAVES) void sa_scale_split_kernel(con
             for (int e = 0; e < 16; ++e) acc[v][e] = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            u4v bp[3];
-            split3(h[2 * s], h[2 * s + 1], bp);
-            u4v fr[2][3];
+            u4v bp[2];
+            split2(h[2 * s], h[2 * s + 1], sc.s, bp);
+            u4v fr[2][2];
 #pragma unroll
             for (int v = 0; v < 2; ++v)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) fr[v][p] = __builtin_bit_cast(u4v, s_img[((s * 2 + v) * 3 + p) * 64 + lane]);
-#define RTK_SA_MM(pa, pb) acc[0] = mfma_bf(fr[0][pa], bp[pb], acc[0]); acc[1] = mfma_bf(fr[1][pa], bp[pb], acc[1]);
-            RTK_SA_MM(2, 0) RTK_SA_MM(0, 2) RTK_SA_MM(1, 1) RTK_SA_MM(1, 0) RTK_SA_MM(0, 1) RTK_SA_MM(0, 0)
+                for (int p = 0; p < 2; ++p) fr[v][p] = __builtin_bit_cast(u4v, s_img[((s * 2 + v) * 2 + p) * 64 + lane]);
+#define RTK_SA_MM(pa, pb) acc[0] = mfma_h(fr[0][pa], bp[pb], acc[0]); acc[1] = mfma_h(fr[1][pa], bp[pb], acc[1]);
+            RTK_SA_MM(1, 0) RTK_SA_MM(0, 1) RTK_SA_MM(0, 0)
 #undef RTK_SA_MM
         }
         float *o = P.out + (long)c * P.out_pitch + P.out_offset + 4 * hh;
@@ -734,8 +744,8 @@ __global__ __launch_bounds__(256, SA_SPLIT_WAVES) void sa_scale_split_kernel(con
                 // instruction the compiler knows, so it inserts the wait states an MFMA result needs before a VALU read; the inline-asm
                 // DPP reduction behind it only needs the VALU -> DPP ones its own s_nop covers.  Fed by the accumulators directly
                 // (register-capped build: accumulators in arch VGPRs) the asm computed wrong maxima.
-                f4 m = (f4){acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]} +
-                       *reinterpret_cast<const f4 *>(P.bias2 + 32 * v + 8 * q + 4 * hh);
+                f4 m = scale_bias4((f4){acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]}, cs,
+                                   *reinterpret_cast<const f4 *>(P.bias2 + 32 * v + 8 * q + 4 * hh));
                 row_max_group_f4<16>(m);
                 if constexpr (NS == 32) m = f4_max(m, (f4){__shfl_xor(m.x, 16, 64), __shfl_xor(m.y, 16, 64), __shfl_xor(m.z, 16, 64), __shfl_xor(m.w, 16, 64)});
                 m = f4_relu(m);
@@ -746,31 +756,34 @@ __global__ __launch_bounds__(256, SA_SPLIT_WAVES) void sa_scale_split_kernel(con
 
 }  // namespace
 
-extern "C" int rtk_pack_split_layer(int cout, int cin, const float *w, int transposed, void *image, rtk_stream_t stream) {
-    RTK_REQUIRE(cout > 0 && cin > 0 && cout % 32 == 0 && cin % 32 == 0 && w && image, "pack_split_layer: bad arguments");
+extern "C" int rtk_pack_split_layer(int cout, int cin, const float *w, int transposed, void *image, float *inv_scale, rtk_stream_t stream) {
+    RTK_REQUIRE(cout > 0 && cin > 0 && cout % 32 == 0 && cin % 32 == 0 && w && image && inv_scale, "pack_split_layer: bad arguments");
+    RTK_REQUIRE((long)cout * cin <= (1L << 22), "pack_split_layer: more than 2^22 weights (every workgroup scans the matrix for its scale)");
     const int slots = (cin / 16) * (cout / 32) * 64;
-    pack_split_kernel<<<(slots + 255) / 256, 256, 0, (hipStream_t)stream>>>(cout, cin, w, transposed, (u4v *)image);
+    pack_split_kernel<<<(slots + 255) / 256, 256, 0, (hipStream_t)stream>>>(cout, cin, w, transposed, (u4v *)image, inv_scale);
     RTK_CHECK_LAUNCH("pack_split_layer");
     return RTK_OK;
 }
 
-extern "C" int rtk_split_mlp2(int positions, const float *x, const void *images, const float *bias1, const float *bias2, float *y,
-                              rtk_stream_t stream) {
-    RTK_REQUIRE(positions > 0 && x && images && bias1 && bias2 && y, "split_mlp2: bad arguments");
+extern "C" int rtk_split_mlp2(int positions, const float *x, const void *images, const float *image_scales, const float *bias1,
+                              const float *bias2, float *y, rtk_stream_t stream) {
+    RTK_REQUIRE(positions > 0 && x && images && image_scales && bias1 && bias2 && y, "split_mlp2: bad arguments");
     const int tiles = (positions + 32 * SP_NW - 1) / (32 * SP_NW);
-    split_mlp2_kernel<<<tiles < 256 ? tiles : 256, 64 * SP_NW, 0, (hipStream_t)stream>>>(positions, x, (const f4 *)images, bias1, bias2, y);
+    split_mlp2_kernel<<<tiles < 256 ? tiles : 256, 64 * SP_NW, 0, (hipStream_t)stream>>>(positions, x, (const f4 *)images, image_scales, bias1, bias2, y);
     RTK_CHECK_LAUNCH("split_mlp2");
     return RTK_OK;
 }
 
 static int cv_split_fill(const char *who, CvSplitParams &P, int samples, int n1, int n2, const float *xyz1, const float *xyz2,
-                         const int64_t *knn_idx, const void *split_images, const rtk_layer_t *wn, dim3 &grid) {
-    RTK_REQUIRE(samples > 0 && samples <= 65535 && n1 > 0 && n2 >= 16 && xyz1 && xyz2 && knn_idx && split_images, "%s: bad arguments", who);
+                         const int64_t *knn_idx, const void *split_images, const float *image_scales, const rtk_layer_t *wn, dim3 &grid) {
+    RTK_REQUIRE(samples > 0 && samples <= 65535 && n1 > 0 && n2 >= 16 && xyz1 && xyz2 && knn_idx && split_images && image_scales,
+                "%s: bad arguments", who);
     RTK_REQUIRE(wn && wn[0].w_packed && wn[1].w_packed && wn[2].w_packed && wn[1].bias && wn[2].bias && wn[1].cin16 == 1 &&
                 wn[1].cout16 == 1 && wn[2].cin16 == 1 && wn[2].cout16 == 16, "%s: bad WeightNet layers", who);
     P.samples = samples; P.n1 = n1; P.n2 = n2;
     P.xyz1 = xyz1; P.xyz2 = xyz2; P.knn = knn_idx;
     P.blob = reinterpret_cast<const f4 *>(split_images);
+    P.wsc = image_scales;
     P.wn.wa = wn[0].w_packed; P.wn.wb = wn[1].w_packed; P.wn.wc = wn[2].w_packed; P.wn.bb = wn[1].bias; P.wn.bc = wn[2].bias;
     P.p1 = P.p2 = P.wd = P.bias2 = P.bias3 = nullptr;
     P.out = nullptr; P.out_pitch = 0; P.sv1 = P.sv2 = P.sv3 = nullptr; P.mk1 = P.mk2 = nullptr;
@@ -786,12 +799,12 @@ static int cv_split_fill(const char *who, CvSplitParams &P, int samples, int n1,
 }
 
 static int cv_split_forward(const char *who, int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
-                            const float *p1, const float *p2, const float *wd_packed, const void *split_images, const float *bias2,
-                            const float *bias3, const rtk_layer_t *wn, float *out, int out_pitch, float *a1, float *a2, float *a3,
-                            void *mask1, void *mask2, int workgroups, rtk_stream_t stream) {
+                            const float *p1, const float *p2, const float *wd_packed, const void *split_images, const float *image_scales,
+                            const float *bias2, const float *bias3, const rtk_layer_t *wn, float *out, int out_pitch, float *a1, float *a2,
+                            float *a3, void *mask1, void *mask2, int workgroups, rtk_stream_t stream) {
     CvSplitParams P;
     dim3 grid;
-    if (cv_split_fill(who, P, samples, n1, n2, xyz1, xyz2, knn_idx, split_images, wn, grid) != RTK_OK) return RTK_ERR_INVALID;
+    if (cv_split_fill(who, P, samples, n1, n2, xyz1, xyz2, knn_idx, split_images, image_scales, wn, grid) != RTK_OK) return RTK_ERR_INVALID;
     RTK_REQUIRE(p1 && p2 && wd_packed && bias2 && bias3 && out, "%s: bad arguments", who);
     RTK_REQUIRE((double)samples * n2 <= 4194304.0, "%s: more than 2^22 rows in p2 (32-bit byte offsets of the row requests): split the batch", who);
     RTK_REQUIRE(out_pitch % 4 == 0 && out_pitch >= 256, "%s: bad out_pitch", who);
@@ -816,38 +829,41 @@ static int cv_split_forward(const char *who, int samples, int n1, int n2, const 
 
 extern "C" int rtk_cost_volume_split(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
                                      const float *p1, const float *p2, const float *wd_packed, const void *split_images,
-                                     const float *bias2, const float *bias3, const rtk_layer_t *wn, float *out, int out_pitch,
-                                     rtk_stream_t stream) {
-    return cv_split_forward("cost_volume_split", samples, n1, n2, xyz1, xyz2, knn_idx, p1, p2, wd_packed, split_images, bias2, bias3, wn, out,
-                            out_pitch, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream);
+                                     const float *image_scales, const float *bias2, const float *bias3, const rtk_layer_t *wn, float *out,
+                                     int out_pitch, rtk_stream_t stream) {
+    return cv_split_forward("cost_volume_split", samples, n1, n2, xyz1, xyz2, knn_idx, p1, p2, wd_packed, split_images, image_scales, bias2, bias3,
+                            wn, out, out_pitch, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int rtk_cost_volume_split_shared(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
                                             const float *p1, const float *p2, const float *wd_packed, const void *split_images,
-                                            const float *bias2, const float *bias3, const rtk_layer_t *wn, float *out, int out_pitch,
-                                            int workgroups, rtk_stream_t stream) {
+                                            const float *image_scales, const float *bias2, const float *bias3, const rtk_layer_t *wn,
+                                            float *out, int out_pitch, int workgroups, rtk_stream_t stream) {
     RTK_REQUIRE(workgroups >= 0, "cost_volume_split_shared: workgroups = %d", workgroups);
-    return cv_split_forward("cost_volume_split_shared", samples, n1, n2, xyz1, xyz2, knn_idx, p1, p2, wd_packed, split_images, bias2, bias3,
-                            wn, out, out_pitch, nullptr, nullptr, nullptr, nullptr, nullptr, workgroups, stream);
+    return cv_split_forward("cost_volume_split_shared", samples, n1, n2, xyz1, xyz2, knn_idx, p1, p2, wd_packed, split_images, image_scales,
+                            bias2, bias3, wn, out, out_pitch, nullptr, nullptr, nullptr, nullptr, nullptr, workgroups, stream);
 }
 
 extern "C" int rtk_cost_volume_split_train(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
                                            const float *p1, const float *p2, const float *wd_packed, const void *split_images,
-                                           const float *bias2, const float *bias3, const rtk_layer_t *wn, float *out, int out_pitch,
-                                           float *a1, float *a2, float *a3, void *mask1, void *mask2, rtk_stream_t stream) {
+                                           const float *image_scales, const float *bias2, const float *bias3, const rtk_layer_t *wn,
+                                           float *out, int out_pitch, float *a1, float *a2, float *a3, void *mask1, void *mask2,
+                                           rtk_stream_t stream) {
     RTK_REQUIRE(a1 && a2 && a3 && mask1 && mask2, "cost_volume_split_train: null activation buffer");
-    return cv_split_forward("cost_volume_split_train", samples, n1, n2, xyz1, xyz2, knn_idx, p1, p2, wd_packed, split_images, bias2, bias3,
-                            wn, out, out_pitch, a1, a2, a3, mask1, mask2, 0, stream);
+    return cv_split_forward("cost_volume_split_train", samples, n1, n2, xyz1, xyz2, knn_idx, p1, p2, wd_packed, split_images, image_scales,
+                            bias2, bias3, wn, out, out_pitch, a1, a2, a3, mask1, mask2, 0, stream);
 }
 
 extern "C" int rtk_cost_volume_bwd_split(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
-                                         const void *split_images_t, const rtk_layer_t *wn, const float *dout, int dout_pitch,
+                                         const void *split_images_t, const float *image_scales_t, const rtk_layer_t *wn, const float *dout,
+                                         int dout_pitch,
                                          const float *a3, const void *mask1, const void *mask2, float *dz1, float *dz2, float *dz3,
                                          float *dq3, float *d4, float *dp1, float *dpd, float *dt2, float *dbias_rows,
                                          rtk_stream_t stream) {
     CvSplitBwdParams Q;
     dim3 grid;
-    if (cv_split_fill("cost_volume_bwd_split", Q.f, samples, n1, n2, xyz1, xyz2, knn_idx, split_images_t, wn, grid) != RTK_OK) return RTK_ERR_INVALID;
+    if (cv_split_fill("cost_volume_bwd_split", Q.f, samples, n1, n2, xyz1, xyz2, knn_idx, split_images_t, image_scales_t, wn, grid) != RTK_OK)
+        return RTK_ERR_INVALID;
     RTK_REQUIRE(dout && mask1 && mask2 && a3 && dz1 && dz2 && dz3 && dq3 && d4 && dp1 && dpd && dt2, "cost_volume_bwd_split: bad arguments");
     RTK_REQUIRE((double)samples * n1 * 16.0 * 1024.0 < 4294967296.0, "cost_volume_bwd_split: more than 4 GiB per (position, 256) tensor "
                 "(32-bit row offsets): split the batch");
@@ -861,9 +877,9 @@ extern "C" int rtk_cost_volume_bwd_split(int samples, int n1, int n2, const floa
 
 extern "C" int rtk_sa_scale_split(int samples, int n, int npoint, int nsample, const float *xyz, const float *new_xyz, const int *idx,
                                   const float *q, int q_pitch, int c1, const float *w1xyz_packed, const void *split_image,
-                                  const float *bias2, float *out, int out_pitch, int out_offset, const int *src_nuniq,
-                                  const int *dst_nuniq, rtk_stream_t stream) {
-    RTK_REQUIRE(samples > 0 && n > 0 && npoint > 0 && xyz && new_xyz && idx && q && w1xyz_packed && split_image && bias2 && out,
+                                  const float *image_scale, const float *bias2, float *out, int out_pitch, int out_offset,
+                                  const int *src_nuniq, const int *dst_nuniq, rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && n > 0 && npoint > 0 && xyz && new_xyz && idx && q && w1xyz_packed && split_image && image_scale && bias2 && out,
                 "sa_scale_split: bad arguments");
     RTK_REQUIRE(q_pitch % 4 == 0 && out_pitch % 4 == 0 && out_offset % 4 == 0, "sa_scale_split: pitches/offset must be multiples of 4");
     RTK_REQUIRE((long)samples * npoint * nsample < 0x7fffffffL && (long)samples * n < 0x7fffffffL && samples <= 65535,
@@ -871,7 +887,7 @@ extern "C" int rtk_sa_scale_split(int samples, int n, int npoint, int nsample, c
     SaSplitParams P;
     P.samples = samples; P.n = n; P.npoint = npoint;
     P.xyz = xyz; P.new_xyz = new_xyz; P.idx = idx; P.q = q; P.q_pitch = q_pitch; P.w1 = w1xyz_packed;
-    P.image = reinterpret_cast<const f4 *>(split_image); P.bias2 = bias2;
+    P.image = reinterpret_cast<const f4 *>(split_image); P.wsc = image_scale; P.bias2 = bias2;
     P.out = out; P.out_pitch = out_pitch; P.out_offset = out_offset; P.src_nuniq = src_nuniq; P.dst_nuniq = dst_nuniq;
     const int units = (npoint + 32 / nsample - 1) / (32 / nsample);
     int bx = (units + 3) / 4;

@@ -44,11 +44,11 @@ _lib.SIGNATURES.update({
     "rtk_sa_scale": [_ci] * 4 + [_vp] * 4 + [_ci, _ci, _vp, _ci, ctypes.POINTER(_Layer), _vp, _ci, _ci, _vp, _vp, _vp],
     "rtk_cost_volume": [_ci] * 3 + [_vp] * 6 + [ctypes.POINTER(_Layer), ctypes.POINTER(_Layer), _vp, _ci, _vp],
     "rtk_patch_cost": [_ci] * 2 + [_vp] * 3 + [_ci, ctypes.POINTER(_Layer), _vp, _ci, _ci, _vp],
-    "rtk_pack_split_layer": [_ci, _ci, _vp, _ci, _vp, _vp],
-    "rtk_cost_volume_split": [_ci] * 3 + [_vp] * 9 + [ctypes.POINTER(_Layer), _vp, _ci, _vp],
-    "rtk_cost_volume_split_shared": [_ci] * 3 + [_vp] * 9 + [ctypes.POINTER(_Layer), _vp, _ci, _ci, _vp],
-    "rtk_split_mlp2": [_ci, _vp, _vp, _vp, _vp, _vp, _vp],
-    "rtk_sa_scale_split": [_ci] * 4 + [_vp] * 4 + [_ci, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _vp, _vp, _vp],
+    "rtk_pack_split_layer": [_ci, _ci, _vp, _ci, _vp, _vp, _vp],
+    "rtk_cost_volume_split": [_ci] * 3 + [_vp] * 10 + [ctypes.POINTER(_Layer), _vp, _ci, _vp],
+    "rtk_cost_volume_split_shared": [_ci] * 3 + [_vp] * 10 + [ctypes.POINTER(_Layer), _vp, _ci, _ci, _vp],
+    "rtk_split_mlp2": [_ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "rtk_sa_scale_split": [_ci] * 4 + [_vp] * 4 + [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp, _vp, _vp],
     "rtk_prepare_inputs": [_ci] * 2 + [_vp] * 6 + [_vp],
     "rtk_fps_centroids": [_ci] * 3 + [_vp] * 8 + [_vp],
     "rtk_knn_point_masked": [_ci] * 4 + [_vp] * 4 + [_vp],
@@ -135,9 +135,13 @@ def pack_layer(w):
     return wp.reshape(V, 16, U, 4, 4).permute(2, 0, 3, 1, 4).contiguous().reshape(-1)   # (U, V, g, i, r)
 
 
+SPLIT_IMAGE_256 = 2 * 256 * 256      # int16 elements of the split image of a 256 x 256 layer (two fp16 pieces)
+
+
 def split3_bf16(w):
     """The three bf16 pieces of an fp32 tensor (truncation splits: p0 + p1 + p2 == w exactly), as the upper 16 bits of each
-    piece (int16), stacked on a new first axis.  csrc/split_mfma.h."""
+    piece (int16), stacked on a new first axis.  (Rounds 2-4's split; the 16-position per-point chains and the training kernels'
+    position contractions still take it: csrc/fused_common.h.)"""
     x = w.float().contiguous()
     out = []
     for _ in range(3):
@@ -147,15 +151,42 @@ def split3_bf16(w):
     return torch.stack(out)
 
 
+def pow2_scale(amax):
+    """The exact power of two s with amax * s in [2^14, 2^15) and its inverse, as csrc/fused_common.h lane_scale_of computes them from
+    the exponent field of amax (clamped: s <= 2^126; amax = 0 -> 2^126)."""
+    e = (torch.as_tensor(amax, dtype=torch.float32).reshape(1).view(torch.int32).item() >> 23) & 0xff
+    sf = min(268 - e, 253)
+    return 2.0 ** (sf - 127), 2.0 ** (127 - sf)
+
+
+def split2_f16(w, scale):
+    """The two fp16 pieces of w * scale (round to nearest: h = fp16(w s), l = fp16(w s - h)) as int16 bit patterns, stacked on a new
+    first axis.  csrc/split_mfma.h."""
+    x = w.float().contiguous() * scale                                    # exact: a power of two
+    h = x.half()
+    l = (x - h.float()).half()
+    return torch.stack([h.view(torch.int16), l.view(torch.int16)])
+
+
 def pack_layer_split(w):
-    """(Cout, Cin) fp32, both multiples of 32 -> split image of csrc/split_mfma.h as int16:
-    frag[s][v][p][lane = 32 hh + i][t] = piece_p(W[32 v + i][32 (s / 2) + 16 (s % 2) + 8 (t / 4) + 4 hh + t % 4]).
+    """(Cout, Cin) fp32, both multiples of 32 -> (split image of csrc/split_mfma.h as int16, inverse weight scale):
+    frag[s][v][p][lane = 32 hh + i][t] = piece_p(2^k W[32 v + i][32 (s / 2) + 16 (s % 2) + 8 (t / 4) + 4 hh + t % 4]).
     (The product path packs on the device, rtk_pack_split_layer; this is the host restatement the tests compare it with.)"""
     cout, cin = w.shape
     assert cout % 32 == 0 and cin % 32 == 0
-    p = split3_bf16(w)                                                   # (3, cout, cin)
-    p = p.reshape(3, cout // 32, 32, cin // 32, 2, 2, 2, 4)               # (p, v, i, a, e, d, hh, r): c = 32 a + 16 e + 8 d + 4 hh + r
-    return p.permute(3, 4, 1, 0, 6, 2, 5, 7).contiguous().reshape(-1)     # (a, e, v, p, hh, i, d, r): s = 2 a + e, t = 4 d + r
+    scale, inv = pow2_scale(w.float().abs().max())
+    p = split2_f16(w, scale)                                             # (2, cout, cin)
+    p = p.reshape(2, cout // 32, 32, cin // 32, 2, 2, 2, 4)               # (p, v, i, a, e, d, hh, r): c = 32 a + 16 e + 8 d + 4 hh + r
+    return p.permute(3, 4, 1, 0, 6, 2, 5, 7).contiguous().reshape(-1), inv     # (a, e, v, p, hh, i, d, r): s = 2 a + e, t = 4 d + r
+
+
+def pack_split_device(w, transposed=False):
+    """rtk_pack_split_layer on a (cout, cin) fp32 CUDA tensor (transposed: w is stored (cin, cout)) -> (image int16, inv_scale (1,) fp32)."""
+    cout, cin = (w.shape[1], w.shape[0]) if transposed else w.shape
+    image = torch.empty(2 * cout * cin, dtype=torch.int16, device=w.device)
+    inv = torch.empty(1, dtype=torch.float32, device=w.device)
+    _lib.call("rtk_pack_split_layer", cout, cin, w.data_ptr(), 1 if transposed else 0, image.data_ptr(), inv.data_ptr(), _stream())
+    return image, inv
 
 
 def pack_layer_split16(w):
@@ -318,8 +349,7 @@ class _SAScale:
         if SA_SPLIT and len(ws) == 2 and self.cout == 64 and self.c1 in (32, 64) and nsample in (16, 32) and torch.device(device).type == "cuda":
             w2 = ws[1][0].float().to(device).contiguous()
             self.split_bias = ws[1][1].float().to(device).contiguous()
-            self.split_image = torch.empty(3 * 64 * self.c1, dtype=torch.int16, device=device)
-            _lib.call("rtk_pack_split_layer", 64, self.c1, w2.data_ptr(), 0, self.split_image.data_ptr(), _stream())
+            self.split_image, self.split_scale = pack_split_device(w2)
             torch.cuda.current_stream().synchronize()
 
 
@@ -566,7 +596,8 @@ def sa_scale(geo, W, lvl, s, q, qcol, out, out_offset):
         _TRACE.append(("sa_scale", _live_rows(geo.nuniq[lvl], geo.npoint, geo.samples), macs))
     if sc.split_image is not None:
         _lib.call("rtk_sa_scale_split", geo.samples, src.shape[1], geo.npoint, sc.nsample, src.data_ptr(), dst.data_ptr(),
-                  geo.ball[lvl][s].data_ptr(), qptr, qpitch, sc.c1, sc.w1img.data_ptr(), sc.split_image.data_ptr(), sc.split_bias.data_ptr(),
+                  geo.ball[lvl][s].data_ptr(), qptr, qpitch, sc.c1, sc.w1img.data_ptr(), sc.split_image.data_ptr(), sc.split_scale.data_ptr(),
+                  sc.split_bias.data_ptr(),
                   optr, opitch, out_offset, src_nu, geo.nuniq[lvl].data_ptr(), _stream())
         return
     _lib.call("rtk_sa_scale", geo.samples, src.shape[1], geo.npoint, sc.nsample, src.data_ptr(), dst.data_ptr(),
@@ -647,13 +678,15 @@ class FusedBackbone:
         self.cv_wd = offset_image(torch.cat([w0[:, 512:515], z(256)[:, None]], 1), dev)
         self.cv_layers = Chain([(sd["fc_layer.mlp_convs.%d.weight" % i].double().reshape(256, 256),
                                  sd["fc_layer.mlp_convs.%d.bias" % i].double(), ACT_LEAKY) for i in (1, 2)], dev)
-        # the same two layers as split images (csrc/split_mfma.h): fp32 results from the bf16 matrix pipe, 6/16 of the matrix time
+        # the same two layers as split images (csrc/split_mfma.h): fp32 results from the fp16 matrix pipe, 3/16 of the matrix time
         self.cv_split = bool(split)
         w23 = [sd["fc_layer.mlp_convs.%d.weight" % i].double().reshape(256, 256).float().to(dev).contiguous() for i in (1, 2)]
         self.cv_bias23 = torch.stack([sd["fc_layer.mlp_convs.%d.bias" % i].double().float() for i in (1, 2)]).to(dev).contiguous()
-        self.cv_images = torch.empty(2 * 3 * 256 * 256, dtype=torch.int16, device=dev)
+        self.cv_images = torch.empty(2 * SPLIT_IMAGE_256, dtype=torch.int16, device=dev)
+        self.cv_scales = torch.empty(2, dtype=torch.float32, device=dev)
         for l, w in enumerate(w23):
-            _lib.call("rtk_pack_split_layer", 256, 256, w.data_ptr(), 0, self.cv_images[l * 3 * 256 * 256:].data_ptr(), _stream())
+            _lib.call("rtk_pack_split_layer", 256, 256, w.data_ptr(), 0, self.cv_images[l * SPLIT_IMAGE_256:].data_ptr(),
+                      self.cv_scales[l:].data_ptr(), _stream())
         torch.cuda.current_stream().synchronize()      # w23 may go
         self.wn1 = _WeightNet(sd, "fc_layer.weightnet1", dev)
         self.wn2 = _WeightNet(sd, "fc_layer.weightnet2", dev)
@@ -768,7 +801,8 @@ class FusedBackbone:
         if self.cv_split:
             wgs = cv_shared_workgroups(B, N, x1.device) if self.cv_shared else 0
             _lib.call("rtk_cost_volume_split_shared", B, N, N, x1.data_ptr(), x2.data_ptr(), knn1.data_ptr(), p1.data_ptr(), p2.data_ptr(),
-                      self.cv_wd.data_ptr(), self.cv_images.data_ptr(), self.cv_bias23[0].data_ptr(), self.cv_bias23[1].data_ptr(),
+                      self.cv_wd.data_ptr(), self.cv_images.data_ptr(), self.cv_scales.data_ptr(), self.cv_bias23[0].data_ptr(),
+                      self.cv_bias23[1].data_ptr(),
                       self.wn1.arr, cor1.data_ptr(), 256, wgs, _stream())
             return
         _lib.call("rtk_cost_volume", B, N, N, x1.data_ptr(), x2.data_ptr(), knn1.data_ptr(), p1.data_ptr(), p2.data_ptr(),

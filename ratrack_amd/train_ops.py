@@ -16,9 +16,9 @@ _LayerP = ctypes.POINTER(fused._Layer)
 _lib.SIGNATURES.update({
     "rtk_cost_volume_train": [_i] * 3 + [_p] * 6 + [_LayerP, _LayerP, _p, _i, _p, _p, _p, _p, _p, _p],
     "rtk_cost_volume_bwd": [_i] * 3 + [_p] * 3 + [_LayerP, _LayerP, _p, _p, _i] + [_p] * 12 + [_p],
-    "rtk_cost_volume_split_train": [_i] * 3 + [_p] * 9 + [_LayerP, _p, _i, _p, _p, _p, _p, _p, _p],
-    "rtk_cost_volume_bwd_split": [_i] * 3 + [_p] * 4 + [_LayerP, _p, _i] + [_p] * 12 + [_p],
-    "rtk_pack_split_layer": [_i, _i, _p, _i, _p, _p],
+    "rtk_cost_volume_split_train": [_i] * 3 + [_p] * 10 + [_LayerP, _p, _i, _p, _p, _p, _p, _p, _p],
+    "rtk_cost_volume_bwd_split": [_i] * 3 + [_p] * 5 + [_LayerP, _p, _i] + [_p] * 12 + [_p],
+    "rtk_pack_split_layer": [_i, _i, _p, _i, _p, _p, _p],
     "rtk_scatter_add_rows": [_i] * 4 + [_p] * 3 + [_p],
     "rtk_sa_first_layer": [_i] * 6 + [_p] * 4 + [_i] + [_p] * 3 + [_p],
     "rtk_group_inverse_index": [_i] * 3 + [_p] * 3 + [_p],
@@ -730,12 +730,12 @@ def _pack_weights(specs, device):
     return outs, (ws, keep)
 
 
-# The cost volume's 256 x 256 products run on the split-bf16 matrix path (csrc/split_mfma.h) at every batch size.  (At B = 1 the
+# The cost volume's 256 x 256 products run on the split matrix path (csrc/split_mfma.h: two fp16 pieces, three products) at every batch size.  (At B = 1 the
 # fp32-input kernels are 1 % faster per step -- 3.09 vs 3.13 ms: half as many, twice as heavy workgroups on a mostly empty chip --, not
 # worth a second product path selected by a batch-size threshold.)  CV_SPLIT = False selects the fp32-input MFMA kernels: the
 # comparison implementation of the tests (tests/test_train_gpu.py, tools/grad_parity_report.py --fp32-cv).
 CV_SPLIT = True
-_SPLIT_IMAGE = 3 * 256 * 256          # int16 elements of one layer's split image
+_SPLIT_IMAGE = fused.SPLIT_IMAGE_256      # int16 elements of one layer's split image
 
 
 def _cv_split(points=None):
@@ -754,9 +754,11 @@ class _CvWeights:
         if split:                                 # split images instead: W2 | W3 | W3^T | W2^T (the transposes straight from w3, w2)
             specs = []
             self.split = torch.empty((4 if backward else 2) * _SPLIT_IMAGE, dtype=torch.int16, device=dev)
+            self.split_scales = torch.empty(4, dtype=torch.float32, device=dev)      # inverse weight scales, image by image
             self._w = [w.detach().contiguous() for w in (w2, w3)]
             for k, (w, t) in enumerate([(self._w[0], 0), (self._w[1], 0)] + ([(self._w[1], 1), (self._w[0], 1)] if backward else [])):
-                _lib.call("rtk_pack_split_layer", 256, 256, w.data_ptr(), t, self.split[k * _SPLIT_IMAGE:].data_ptr(), _stream())
+                _lib.call("rtk_pack_split_layer", 256, 256, w.data_ptr(), t, self.split[k * _SPLIT_IMAGE:].data_ptr(),
+                          self.split_scales[k:].data_ptr(), _stream())
         nm = len(specs)
         specs += [(2, b2, False, None), (2, b3, False, None), (1, wd, False, None), (1, wa, False, ba), (0, wb, False, None), (2, bb, False, None),
                   (0, wc, False, None), (2, bc, False, None), (0, wc, True, None)]
@@ -832,7 +834,8 @@ class _CostVolume(torch.autograd.Function):
         masks = torch.empty(2, B * n1 * 16, 4, dtype=torch.int64, device=p1.device)          # sign bits of a1, a2 (kernel lane order)
         if W.is_split:
             _lib.call("rtk_cost_volume_split_train", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
-                      W.wd.data_ptr(), W.split.data_ptr(), W.b2.data_ptr(), W.b3.data_ptr(), W.wn, out.data_ptr(), 256, acts[0].data_ptr(),
+                      W.wd.data_ptr(), W.split.data_ptr(), W.split_scales.data_ptr(), W.b2.data_ptr(), W.b3.data_ptr(), W.wn, out.data_ptr(), 256,
+                      acts[0].data_ptr(),
                       acts[1].data_ptr(), acts[2].data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), _stream())
         else:
             _lib.call("rtk_cost_volume_train", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
@@ -860,7 +863,7 @@ class _CostVolume(torch.autograd.Function):
         dbr = torch.empty(B * n1, 512, dtype=torch.float32, device=dev)       # per-query neighbour sums of dz3 | dz2
         if W.is_split:
             _lib.call("rtk_cost_volume_bwd_split", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), W.split[2 * _SPLIT_IMAGE:].data_ptr(),
-                      W.wn, dout.data_ptr(), 256, a3.data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), dz1.data_ptr(), dz2.data_ptr(),
+                      W.split_scales[2:].data_ptr(), W.wn, dout.data_ptr(), 256, a3.data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), dz1.data_ptr(), dz2.data_ptr(),
                       dz3.data_ptr(), dq3.data_ptr(), d4.data_ptr(), dp1.data_ptr(), dpd.data_ptr(), dt2.data_ptr(), dbr.data_ptr(), _stream())
         else:
             _lib.call("rtk_cost_volume_bwd", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), W.layers_t, W.wn, W.wct.data_ptr(),
@@ -908,7 +911,7 @@ def time_cost_volume_bwd(batch, n, dev, iters=10):
     def launch():
         if W.is_split:
             _lib.call("rtk_cost_volume_bwd_split", B, n, n, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), W.split[2 * _SPLIT_IMAGE:].data_ptr(),
-                      W.wn, dout.data_ptr(), 256, acts[2].data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), big[0].data_ptr(),
+                      W.split_scales[2:].data_ptr(), W.wn, dout.data_ptr(), 256, acts[2].data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), big[0].data_ptr(),
                       big[1].data_ptr(), big[2].data_ptr(), big[3].data_ptr(), d4.data_ptr(), dp1.data_ptr(), dpd.data_ptr(), dt2.data_ptr(),
                       dbr.data_ptr(), st)
             return

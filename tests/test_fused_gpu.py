@@ -198,35 +198,55 @@ def test_fused_cost_volume_matches_modules(name, split):
     assert rel_err(got.cpu(), ref.cpu()) < 2e-5
 
 
-def test_split_images_are_exact_and_packed_as_documented():
-    """csrc/split_mfma.h: the three bf16 pieces sum to the fp32 weight EXACTLY, and the device packer writes the image the host
-    restatement (fused.pack_layer_split) describes."""
+def _pack2(ws):
+    """host restatement of the device packer for layers back to back: (images, inverse scales)"""
+    packed = [F.pack_layer_split(w) for w in ws]
+    return torch.cat([im for im, _ in packed]), torch.tensor([inv for _, inv in packed], dtype=torch.float32, device=ws[0].device)
+
+
+def _mlp2(positions, x, img, scales, b, y):
+    from ratrack_amd import _lib
+    _lib.call("rtk_split_mlp2", positions, x.data_ptr(), img.data_ptr(), scales.data_ptr(), b[0].data_ptr(), b[1].data_ptr(), y.data_ptr(),
+              F._stream())
+
+
+def test_split_images_are_two_fp16_pieces_and_packed_as_documented():
+    """csrc/split_mfma.h: with the packer's power-of-two scale the two fp16 pieces carry every fp32 weight within 2^-16 of the matrix's
+    largest to 2^-23 of itself (smaller ones to an absolute 2^-39 of the largest), and the device packer writes the image and the inverse scale the
+    host restatement (fused.pack_layer_split) describes -- bit for bit."""
     from ratrack_amd import _lib
     torch.manual_seed(3)
-    w = torch.randn(256, 256, device=DEV) * torch.logspace(-6, 2, 256, device=DEV)[:, None]      # 8 decades of magnitudes
-    w[0, :3] = torch.tensor([0.0, 1.0, -1.5], device=DEV)                                        # a zero, exact bf16 values
-    pieces = F.split3_bf16(w)                                                                   # (3, 256, 256) int16 = upper halves
-    back = sum((pieces[i].to(torch.int32) << 16).view(torch.float32).double() for i in range(3))
-    assert torch.equal(back.float(), w) and torch.equal(back, w.double())
-    img = torch.empty(3 * 256 * 256, dtype=torch.int16, device=DEV)
-    _lib.call("rtk_pack_split_layer", 256, 256, w.data_ptr(), 0, img.data_ptr(), F._stream())
-    assert torch.equal(img, F.pack_layer_split(w))
+    w = torch.randn(256, 256, device=DEV) * torch.logspace(-4, 0, 256, device=DEV)[:, None]      # 4 decades of magnitudes
+    w[0, :3] = torch.tensor([0.0, 1.0, -1.5], device=DEV)
+    scale, inv = F.pow2_scale(w.abs().max())
+    assert 2.0 ** 14 <= float(w.abs().max()) * scale < 2.0 ** 15 and scale * inv == 1.0
+    pieces = F.split2_f16(w, scale).view(torch.float16)                                         # (2, 256, 256)
+    back = (pieces[0].double() + pieces[1].double()) * inv
+    err = (back - w.double()).abs() * scale
+    ws = w.double().abs() * scale
+    assert bool((err <= 2.0 ** -25 + 2.0 ** -23 * ws).all())
+    assert bool((err[ws >= 0.25] <= 2.0 ** -23 * ws[ws >= 0.25]).all())
+    img, dinv = F.pack_split_device(w)
+    himg, hinv = F.pack_layer_split(w)
+    assert torch.equal(img, himg) and float(dinv) == hinv
+    imgt, dinvt = F.pack_split_device(w, transposed=True)                                       # the backward's W^T image from the same weights
+    himgt, hinvt = F.pack_layer_split(w.T.contiguous())
+    assert torch.equal(imgt, himgt) and float(dinvt) == hinvt
     with pytest.raises(_lib.RtkError):
-        _lib.call("rtk_pack_split_layer", 250, 256, w.data_ptr(), 0, img.data_ptr(), F._stream())
+        _lib.call("rtk_pack_split_layer", 250, 256, w.data_ptr(), 0, img.data_ptr(), dinv.data_ptr(), F._stream())
 
 
 @pytest.mark.parametrize("positions", [1, 77, 128, 5000])
 def test_split_layers_carry_fp32_accuracy(positions):
-    """Two 256x256 layers on the bf16 matrix pipe (six products of exact pieces) against float64: the error is that of an fp32
-    GEMM -- not of a bf16 one (2e-3) nor of a three-product split (3e-5)."""
-    from ratrack_amd import _lib
+    """Two 256x256 layers on the fp16 matrix pipe (three products of two pieces, a power-of-two scale per matrix and per position)
+    against float64: the error is that of an fp32 GEMM -- not of an fp16 one (1e-3) nor of a three-product bf16 split (3e-5)."""
     torch.manual_seed(positions)
     W = [torch.randn(256, 256, device=DEV) / 16 for _ in range(2)]
     b = [torch.randn(256, device=DEV) * 0.1 for _ in range(2)]
-    img = torch.cat([F.pack_layer_split(w) for w in W])
+    img, scales = _pack2(W)
     x = torch.randn(positions, 256, device=DEV) * 3
     y = torch.full((positions, 256), float("nan"), device=DEV)
-    _lib.call("rtk_split_mlp2", positions, x.data_ptr(), img.data_ptr(), b[0].data_ptr(), b[1].data_ptr(), y.data_ptr(), F._stream())
+    _mlp2(positions, x, img, scales, b, y)
     lk = lambda t: torch.nn.functional.leaky_relu(t, 0.1)
     r64 = lk(lk(x.double() @ W[0].double().T + b[0].double()) @ W[1].double().T + b[1].double())
     r32 = lk(lk(x @ W[0].T + b[0]) @ W[1].T + b[1])
@@ -234,13 +254,39 @@ def test_split_layers_carry_fp32_accuracy(positions):
     assert err(y) < 2e-6 and err(y) < 3 * err(r32) + 1e-7, (err(y), err(r32))
 
 
+@pytest.mark.parametrize("log2_scale", [-100, -60, -20, 0, 20, 60, 100])
+def test_split_layers_are_scale_invariant(log2_scale):
+    """The path has no operand range: activations scaled by 2^k (and the first layer's weights by 2^-k', the biases accordingly) give
+    results that are the unscaled ones times the same power of two BIT FOR BIT -- every scale is a power of two chosen from the data,
+    so the fp16 pieces are the same numbers.  k = +-100 puts the activations at 1e+-30, far outside fp16's (and bf16-exact fp32's) range."""
+    torch.manual_seed(5)
+    P = 384
+    W = [torch.randn(256, 256, device=DEV) / 16 for _ in range(2)]
+    b = [torch.randn(256, device=DEV) * 0.1 for _ in range(2)]
+    x = torch.randn(P, 256, device=DEV) * 3
+    x[7] = 0.0                                                                                  # an all-zero position
+    img, scales = _pack2(W)
+    y0 = torch.empty(P, 256, device=DEV)
+    _mlp2(P, x, img, scales, b, y0)
+    k = float(2.0 ** log2_scale)
+    # x k, W1 unchanged, b1 k: layer 1's output is k times the old one; W2 / k: layer 2's input term is back at the old magnitude
+    W2 = [W[0], W[1] / k]
+    img2, scales2 = _pack2(W2)
+    y1 = torch.empty(P, 256, device=DEV)
+    _mlp2(P, x * k, img2, scales2, [b[0] * k, b[1]], y1)
+    assert torch.isfinite(y1).all()
+    assert torch.equal(y0, y1)
+    assert torch.equal(y0[7], torch.nn.functional.leaky_relu(torch.nn.functional.leaky_relu(b[0], 0.1) @ W[1].T + b[1], 0.1)) or \
+        rel_err(y0[7].cpu(), torch.nn.functional.leaky_relu(torch.nn.functional.leaky_relu(b[0], 0.1) @ W[1].T + b[1], 0.1).cpu()) < 1e-6
+
+
 @pytest.mark.parametrize("case", ["same_sign", "scale_1e6", "scale_1e-6", "mixed_range", "tiny_1e-30", "post_relu"])
 def test_split_layers_adversarial_operands(case):
-    """Truncation splitting drops same-signed terms (a bias, not noise: <= 2 x 2^-24 |a||b| per product).  Operands chosen to make
-    that bias coherent -- all-positive activations x all-positive weights, as after a ReLU --, dynamic ranges of 1e+-6 between
-    activations and weights, activations spanning six decades inside one row, and activations so small that their third bf16
-    piece is subnormal; float64 is the truth, the framework's fp32 GEMM the yardstick."""
-    from ratrack_amd import _lib
+    """Operands chosen against the split: all-positive activations x all-positive weights, as after a ReLU (a dropped l.l term or a
+    biased rounding would add up coherently), dynamic ranges of 1e+-6 between activations and weights, activations spanning six
+    decades inside one row (the small ones lose their low piece to the position's scale: an ABSOLUTE error 2^-39 of the row's
+    largest), and activations at 1e-30 -- fifteen orders below fp16's smallest subnormal; float64 is the truth, the framework's fp32
+    GEMM the yardstick."""
     torch.manual_seed(7)
     P = 640
     W = [torch.randn(256, 256, device=DEV) / 16 for _ in range(2)]
@@ -256,14 +302,14 @@ def test_split_layers_adversarial_operands(case):
     elif case == "mixed_range":
         x = x * torch.pow(10.0, torch.randint(-3, 4, (P, 256), device=DEV).float())
     elif case == "tiny_1e-30":
-        x, W[0], b[0] = x * 1e-30, W[0], b[0] * 0      # third pieces ~1e-35 * 2^-16: below the smallest normal bf16 / fp32 (1.2e-38)
+        x, W[0], b[0] = x * 1e-30, W[0], b[0] * 0      # low pieces ~1e-33: fp32-normal only just, far below anything fp16 holds unscaled
         W[1], b[1] = W[1] * 1e10, b[1] * 0
     elif case == "post_relu":
         x = torch.relu(x)                                 # half zeros, half positive
         W = [w.abs() for w in W]
-    img = torch.cat([F.pack_layer_split(w) for w in W])
+    img, scales = _pack2(W)
     y = torch.full((P, 256), float("nan"), device=DEV)
-    _lib.call("rtk_split_mlp2", P, x.data_ptr(), img.data_ptr(), b[0].data_ptr(), b[1].data_ptr(), y.data_ptr(), F._stream())
+    _mlp2(P, x, img, scales, b, y)
     lk = lambda t: torch.nn.functional.leaky_relu(t, 0.1)
     r64 = lk(lk(x.double() @ W[0].double().T + b[0].double()) @ W[1].double().T + b[1].double())
     r32 = lk(lk(x @ W[0].T + b[0]) @ W[1].T + b[1])
@@ -276,7 +322,7 @@ def test_split_layers_adversarial_operands(case):
         case, rel(y), sc(y), bias(y), rel(r32), sc(r32), bias(r32)))
     assert torch.isfinite(y).all()
     assert sc(y) < 2e-6 and sc(y) < 3 * sc(r32) + 2e-7, (case, sc(y), sc(r32))
-    assert abs(bias(y)) < 2.5e-7, (case, bias(y))                                   # two layers x 2^-23 worst case, fully coherent
+    assert abs(bias(y)) < 2.5e-7, (case, bias(y))                                   # round-to-nearest pieces: no coherent bias
 
 
 @pytest.mark.parametrize("B,N", [(3, 243), (8, 250), (16, 64), (1, 1024), (2, 17)])
@@ -693,8 +739,7 @@ def test_sa_scale_split_agrees_with_fp32_mfma_kernel(nsample, c1, samples, n, np
     w2, b2 = torch.randn(64, c1, device=DEV) / 8, torch.randn(64, device=DEV) * 0.1
     w1img = F.offset_image(w1.double(), DEV)
     chain = F.Chain([(w2.double(), b2.double(), F.ACT_RELU)], DEV)
-    img = torch.empty(3 * 64 * c1, dtype=torch.int16, device=DEV)
-    _lib.call("rtk_pack_split_layer", 64, c1, w2.data_ptr(), 0, img.data_ptr(), F._stream())
+    img, inv = F.pack_split_device(w2)
     src_nu = torch.randint(n // 2, n + 1, (samples,), device=DEV, dtype=torch.int32)
     dst_nu = torch.randint(npoint // 2, npoint + 1, (samples,), device=DEV, dtype=torch.int32)
     a = torch.full((samples * npoint, 96), -5.0, device=DEV)
@@ -702,13 +747,13 @@ def test_sa_scale_split_agrees_with_fp32_mfma_kernel(nsample, c1, samples, n, np
     common = (samples, n, npoint, nsample, xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), q.data_ptr(), c1)
     _lib.call("rtk_sa_scale", *common, c1 // 16, w1img.data_ptr(), 1, chain.arr, a.data_ptr(), 96, 16, src_nu.data_ptr(), dst_nu.data_ptr(),
               F._stream())
-    _lib.call("rtk_sa_scale_split", *common, c1, w1img.data_ptr(), img.data_ptr(), b2.data_ptr(), b.data_ptr(), 96, 16, src_nu.data_ptr(),
-              dst_nu.data_ptr(), F._stream())
+    _lib.call("rtk_sa_scale_split", *common, c1, w1img.data_ptr(), img.data_ptr(), inv.data_ptr(), b2.data_ptr(), b.data_ptr(), 96, 16,
+              src_nu.data_ptr(), dst_nu.data_ptr(), F._stream())
     assert torch.equal(a == -5.0, b == -5.0)                                   # the same rows / columns are written
     assert rel_err(b.cpu(), a.cpu()) < 5e-6
     with pytest.raises(_lib.RtkError):
         _lib.call("rtk_sa_scale_split", samples, n, npoint, 8, xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), q.data_ptr(), c1, c1,
-                  w1img.data_ptr(), img.data_ptr(), b2.data_ptr(), b.data_ptr(), 96, 16, None, None, F._stream())
+                  w1img.data_ptr(), img.data_ptr(), inv.data_ptr(), b2.data_ptr(), b.data_ptr(), 96, 16, None, None, F._stream())
 
 
 def test_split16_image_is_packed_as_documented():

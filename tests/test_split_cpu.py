@@ -1,7 +1,10 @@
-"""CPU: the arithmetic the split-bf16 matrix path rests on (csrc/split_mfma.h), restated in numpy / torch-CPU -- no GPU involved.
-  * three bf16 pieces, split by truncation, sum to the fp32 number exactly;
-  * a bf16 x bf16 product is exact in fp32;
-  * six partial products (i + j <= 2) accumulated in fp32 carry the error of an fp32 product chain; three do not;
+"""CPU: the arithmetic the split matrix paths rest on (csrc/split_mfma.h, csrc/fused_common.h), restated in numpy / torch-CPU -- no GPU
+involved.
+  * round 5 -- TWO fp16 pieces of a power-of-two-scaled fp32 number carry it to 2^-23; a fp16 x fp16 product is exact in fp32; THREE
+    partial products (l.h + h.l + h.h) accumulated in fp32 carry the error of an fp32 product chain, at every operand magnitude once
+    the scale is taken from the data;
+  * rounds 2-4 (still used by the 16-position per-point chains and the training kernels' position contractions) -- three bf16
+    pieces, split by truncation, sum to the fp32 number exactly; six partial products carry fp32 accuracy, three do not;
   * the host packers write the images the headers describe."""
 import numpy as np
 import torch
@@ -59,11 +62,73 @@ def test_six_products_carry_fp32_accuracy_three_do_not():
     assert e3 > 10 * e32, (e3, e32)
 
 
+def _split2(x, scale):
+    xs = (x.astype(np.float32) * np.float32(scale)).astype(np.float32)
+    h = xs.astype(np.float16)
+    l = (xs - h.astype(np.float32)).astype(np.float16)
+    return h.astype(np.float32), l.astype(np.float32)
+
+
+def test_two_fp16_pieces_carry_23_bits_under_a_data_scale():
+    rng = np.random.default_rng(3)
+    for mag in (1e-30, 1e-6, 1.0, 300.0, 1e20):
+        x = (rng.standard_normal(100000) * mag).astype(np.float32)
+        scale, inv = F.pow2_scale(float(np.abs(x).max()))
+        assert 2.0 ** 14 <= float(np.abs(x).max()) * scale < 2.0 ** 15 and scale * inv == 1.0
+        h, l = _split2(x, scale)
+        assert np.isfinite(h).all()
+        xs = np.abs(x).astype(np.float64) * scale
+        err = np.abs((h.astype(np.float64) + l) - x.astype(np.float64) * scale)      # in scaled units
+        big = xs >= 2.0 ** -2                                                  # the low piece is a normal fp16 number there: 2^-16 of the largest
+        assert (err[big] <= 2.0 ** -23 * xs[big]).all()
+        assert (err <= 2.0 ** -25 + 2.0 ** -23 * xs).all()                      # below: an ABSOLUTE 2^-25 (fp16 subnormal spacing / 2) = 2^-39 of the largest
+    # the torch restatement the device packer is compared with produces the same pieces
+    x = rng.standard_normal(4096).astype(np.float32)
+    scale, _ = F.pow2_scale(float(np.abs(x).max()))
+    t = F.split2_f16(torch.from_numpy(x), scale).view(torch.float16).numpy().astype(np.float32)
+    h, l = _split2(x, scale)
+    assert np.array_equal(t[0], h) and np.array_equal(t[1], l)
+
+
+def test_fp16_products_are_exact_in_fp32():
+    rng = np.random.default_rng(4)
+    a = rng.standard_normal(100000).astype(np.float16).astype(np.float32) * np.float32(1024)
+    b = rng.standard_normal(100000).astype(np.float16).astype(np.float32) * np.float32(2.0 ** -10)
+    assert np.array_equal((a * b).astype(np.float64), a.astype(np.float64) * b.astype(np.float64))
+
+
+def test_three_fp16_products_carry_fp32_accuracy_at_every_magnitude():
+    rng = np.random.default_rng(5)
+    K = 256
+    W = (rng.standard_normal((64, K)) / 16).astype(np.float32)
+    for mag in (1e-25, 1e-4, 1.0, 300.0, 1e15):
+        X = (rng.standard_normal((K, 96)) * mag).astype(np.float32)
+        ref = W.astype(np.float64) @ X.astype(np.float64)
+        sw, iw = F.pow2_scale(float(np.abs(W).max()))
+        wh, wl = _split2(W, sw)
+        out = np.zeros(ref.shape, np.float32)
+        xh, xl, inv = np.zeros_like(X), np.zeros_like(X), np.zeros(96, np.float64)
+        for j in range(96):                                                    # one scale per position (column)
+            sx, ix = F.pow2_scale(float(np.abs(X[:, j]).max()))
+            xh[:, j], xl[:, j] = _split2(X[:, j], sx)
+            inv[j] = ix * iw
+        for k0 in range(0, K, 16):                                             # one MFMA k-step: 16 exact products, one fp32 accumulate
+            for a, b in ((wl, xh), (wh, xl), (wh, xh)):                        # the kernels' order: small terms first
+                out = out + (a[:, k0:k0 + 16].astype(np.float64) @ b[k0:k0 + 16].astype(np.float64)).astype(np.float32)
+        got = out.astype(np.float64) * inv[None, :]
+        err = lambda o: np.abs(o - ref).max() / np.abs(ref).max()
+        e32, e3 = err((W @ X).astype(np.float64)), err(got)
+        assert e3 < 1.5 * e32 + 1e-7, (mag, e3, e32)
+
+
 def test_split_images_follow_their_index_formulas():
     torch.manual_seed(0)
     w = torch.randn(64, 96)
-    p = F.split3_bf16(w)
-    img = F.pack_layer_split(w).view(6, 2, 3, 64, 8)                           # (s, v, piece, lane, t)
+    scale, inv = F.pow2_scale(w.abs().max())
+    p = F.split2_f16(w, scale)
+    img, inv2 = F.pack_layer_split(w)
+    assert inv2 == inv
+    img = img.view(6, 2, 2, 64, 8)                                             # (s, v, piece, lane, t)
     for s in range(6):
         for v in range(2):
             for lane in (0, 7, 31, 32, 50, 63):

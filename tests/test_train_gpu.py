@@ -626,7 +626,7 @@ def test_cost_volume_train_forward_keeps_what_the_backward_needs(B, N, split, mo
     acts = torch.full((3, M, 256), float("nan"), device=DEV)
     masks = torch.zeros(2, M, 4, dtype=torch.int64, device=DEV)
     common = (B, N, N, x1.data_ptr(), x2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(), W.wd.data_ptr())
-    common += (W.split.data_ptr(), W.b2.data_ptr(), W.b3.data_ptr(), W.wn) if split else (W.layers, W.wn)
+    common += (W.split.data_ptr(), W.split_scales.data_ptr(), W.b2.data_ptr(), W.b3.data_ptr(), W.wn) if split else (W.layers, W.wn)
     _lib.call("rtk_cost_volume_split" if split else "rtk_cost_volume", *common, out_a.data_ptr(), 256, st)
     _lib.call("rtk_cost_volume_split_train" if split else "rtk_cost_volume_train", *common, out_b.data_ptr(), 256, acts[0].data_ptr(),
               acts[1].data_ptr(), acts[2].data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), st)
@@ -918,9 +918,9 @@ def test_split_packer_transposed():
     from ratrack_amd import _lib, fused as F
     torch.manual_seed(2)
     w = torch.randn(256, 256, device=DEV)
-    img = torch.empty(3 * 256 * 256, dtype=torch.int16, device=DEV)
-    _lib.call("rtk_pack_split_layer", 256, 256, w.data_ptr(), 1, img.data_ptr(), F._stream())
-    assert torch.equal(img, F.pack_layer_split(w.t().contiguous()))
+    img, inv = F.pack_split_device(w, transposed=True)
+    himg, hinv = F.pack_layer_split(w.t().contiguous())
+    assert torch.equal(img, himg) and float(inv) == hinv
 
 
 @pytest.mark.gpu
