@@ -40,13 +40,15 @@ typedef struct {
 
 /* One 1x1-conv layer with folded BN: y = act(W x + b).  w_packed is [cin16][cout16][64][4] floats -- or, with RTK_LAYER_SPLIT
  * or-ed into act (rtk_pointwise_mlp only; all layers of a chain alike), the layer's 16-position split image: one 1 KiB fragment of
- * 64 lanes x 8 bf16 per (pair of 16-channel input blocks, 16-channel output block, piece), see csrc/fused_common.h. */
+ * 64 lanes x 8 fp16 per (pair of 16-channel input blocks, 16-channel output block, piece h / l) of 2^k W, see csrc/fused_common.h,
+ * with inv_scale = 2^-k (k: max|W| 2^k in [2^14, 2^15)). */
 #define RTK_LAYER_SPLIT 0x100
 typedef struct {
     const float *w_packed;
     const float *bias; /* 16*cout16 floats (zero padded) */
     int cin16, cout16; /* channel counts in units of 16 */
     int act;           /* RTK_ACT_* (0 none, 1 relu, 2 leaky 0.1, 3 sigmoid) */
+    float inv_scale;   /* split images only: the inverse of the image's power-of-two weight scale */
 } rtk_layer_t;
 
 /* Optional first segment produced by three-NN inverse-distance interpolation. */

@@ -160,6 +160,8 @@ struct WStream {
         cur = NCHUNKS - 1; buf = 1;
         issue(0, 0);
     }
+    // the first next() of a tile after start_deferred() (a one-chunk blob was started with start() and stays resident)
+    __device__ __forceinline__ void next_if_deferred() { if constexpr (NCHUNKS > 1) next(); }
     // move from the resident chunk to the next one (cyclic)
     __device__ __forceinline__ void next() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -231,12 +233,13 @@ __device__ __forceinline__ void mlp_layer_ws(WStream<NW, F, NF> &ws, const f4 (&
 }
 
 
-// ---- fp32 products on the bf16 matrix pipe (the scheme is described in split_mfma.h) -------------------------------------------
-// Shared pieces: the exact three-way bf16 split of eight activations, and the 16-position variant of the layer routine: the
-// tile, register layout and weight stream of mlp_layer_ws, with v_mfma_f32_16x16x32_bf16 (same C/D layout as the fp32-input
-// 16x16x4) taking two 16-channel input blocks per k-step -- lane (g, j) supplies B[k = 8 g + t][j] = channel
-// 16 (2 up + t / 4) + 4 g + t % 4, eight values it holds as h[2 up], h[2 up + 1].  Image: one 1 KiB fragment per
-// (input block pair, output block, piece): frag[up][v][p][lane = 16 g + i][t] = piece_p(W[16 v + i][16 (2 up + t / 4) + 4 g + t % 4]).
+// ---- fp32 products on the 16-bit matrix pipe (the scheme is described in split_mfma.h) -----------------------------------------
+// Shared pieces: the splits of eight activations (two fp16 pieces under a power-of-two scale: the layers; three exact bf16 pieces: the
+// training kernels' contractions over positions), and the 16-position variant of the layer routine: the tile, register layout and
+// weight stream of mlp_layer_ws, with v_mfma_f32_16x16x32_f16 (same C/D layout as the fp32-input 16x16x4) taking two 16-channel
+// input blocks per k-step -- lane (g, j) supplies B[k = 8 g + t][j] = channel 16 (2 up + t / 4) + 4 g + t % 4, eight values it
+// holds as h[2 up], h[2 up + 1].  Image: one 1 KiB fragment per (input block pair, output block, piece):
+// frag[up][v][p][lane = 16 g + i][t] = piece_p(2^k W[16 v + i][16 (2 up + t / 4) + 4 g + t % 4]), p = 0: h, 1: l.
 typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
@@ -320,52 +323,66 @@ __device__ __forceinline__ f4 mfma16_bf(u4v a, u4v b, f4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
 }
 
-constexpr int split16_nf(int U, int V) { return ((U + 1) / 2) * V * 3; }      // fragments of a layer's split image
+constexpr int split16_nf(int U, int V) { return ((U + 1) / 2) * V * 2; }      // fragments of a layer's split image
 
-// group step = one input block pair x two output blocks: six fragments, twelve MFMAs (the two blocks interleaved)
+// the activation scale of this lane's position in the 16-position tile: the four lanes j, 16 + j, 32 + j, 48 + j hold a quarter of
+// its channels each.  v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second,
+// v_permlane32_swap the upper half with the lower half: with both operands = m the two results hold a lane's and its partner's value.
+template <int N>
+__device__ __forceinline__ LaneScale lane_scale16(const f4 (&h)[N]) {
+    unsigned mb = __float_as_uint(abs_max_f4(h));                // m >= 0: the order of the bit patterns is the order of the values
+    auto r = __builtin_amdgcn_permlane16_swap(mb, mb, false, false);
+    mb = r[0] > r[1] ? r[0] : r[1];
+    r = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+    return lane_scale_of(r[0] > r[1] ? r[0] : r[1]);
+}
+
+// group step = one input block pair x two output blocks: four fragments (h and l piece of each block), six MFMAs (the two blocks
+// interleaved, small terms first)
 template <int U, int V, int FBASE, int GI, class WS, int F>
 struct LayerStepS {
     static constexpr int GV = (V + 1) / 2;
     static constexpr int NG = ((U + 1) / 2) * GV;
     template <int GJ>
-    static __device__ __forceinline__ void load(WS &ws, f4 (&dst)[6]) {
+    static __device__ __forceinline__ void load(WS &ws, f4 (&dst)[4]) {
         constexpr int up = GJ / GV, v0 = (GJ % GV) * 2;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            if (v0 + q / 3 < V) {
-                const int fi = FBASE + (up * V + v0 + q / 3) * 3 + q % 3;
+        for (int q = 0; q < 4; ++q) {
+            if (v0 + q / 2 < V) {
+                const int fi = FBASE + (up * V + v0 + q / 2) * 2 + q % 2;
                 if (fi % F == 0 && fi != 0) ws.next();
                 dst[q] = ws.frag(fi % F);
             }
         }
     }
-    static __device__ __forceinline__ void run(WS &ws, const f4 (&h)[U], f4 (&acc)[V], f4 (&a)[2][6], u4v (&b)[3]) {
+    static __device__ __forceinline__ void run(WS &ws, const f4 (&h)[U], float scale, f4 (&acc)[V], f4 (&a)[2][4], u4v (&b)[2]) {
         constexpr int up = GI / GV, v0 = (GI % GV) * 2;
         if constexpr (GI + 1 < NG) load<GI + 1>(ws, a[(GI + 1) & 1]);
-        if constexpr (GI % GV == 0) split3(h[2 * up], 2 * up + 1 < U ? h[2 * up + 1] : f4_zero(), b);
-        const f4(&c)[6] = a[GI & 1];
-#define RTK_S16_MM(pa, pb)                                                                             \
-        acc[v0] = mfma16_bf(__builtin_bit_cast(u4v, c[pa]), b[pb], acc[v0]);                            \
-        if constexpr (v0 + 1 < V) acc[v0 + 1] = mfma16_bf(__builtin_bit_cast(u4v, c[3 + pa]), b[pb], acc[v0 + 1]);
-        RTK_S16_MM(2, 0) RTK_S16_MM(0, 2) RTK_S16_MM(1, 1) RTK_S16_MM(1, 0) RTK_S16_MM(0, 1) RTK_S16_MM(0, 0)
+        if constexpr (GI % GV == 0) split2(h[2 * up], 2 * up + 1 < U ? h[2 * up + 1] : f4_zero(), scale, b);
+        const f4(&c)[4] = a[GI & 1];
+#define RTK_S16_MM(pa, pb)                                                                            \
+        acc[v0] = mfma16_h(__builtin_bit_cast(u4v, c[pa]), b[pb], acc[v0]);                            \
+        if constexpr (v0 + 1 < V) acc[v0 + 1] = mfma16_h(__builtin_bit_cast(u4v, c[2 + pa]), b[pb], acc[v0 + 1]);
+        RTK_S16_MM(1, 0) RTK_S16_MM(0, 1) RTK_S16_MM(0, 0)
 #undef RTK_S16_MM
         __builtin_amdgcn_sched_barrier(0);
     }
 };
 
 template <int U, int V, int FBASE, class WS, int F, int... GI>
-__device__ __forceinline__ void mlp_layer_split_impl(WS &ws, const f4 (&h)[U], f4 (&acc)[V], std::integer_sequence<int, GI...>) {
-    f4 a[2][6];
-    u4v b[3];
+__device__ __forceinline__ void mlp_layer_split_impl(WS &ws, const f4 (&h)[U], float scale, f4 (&acc)[V], std::integer_sequence<int, GI...>) {
+    f4 a[2][4];
+    u4v b[2];
     LayerStepS<U, V, FBASE, 0, WS, F>::template load<0>(ws, a[0]);
-    (LayerStepS<U, V, FBASE, GI, WS, F>::run(ws, h, acc, a, b), ...);
+    (LayerStepS<U, V, FBASE, GI, WS, F>::run(ws, h, scale, acc, a, b), ...);
 }
 
-// acc[v] += W . h on the split path; FBASE = index of the layer's first fragment in the (split) blob
+// acc[v] += 2^(kw + kx) W . h on the split path (scale = this lane's 2^kx, lane_scale16); FBASE = index of the layer's first fragment
+// in the (split) blob
 template <int U, int V, int FBASE, int NW, int F, int NF>
-__device__ __forceinline__ void mlp_layer_ws_split(WStream<NW, F, NF> &ws, const f4 (&h)[U], f4 (&acc)[V]) {
+__device__ __forceinline__ void mlp_layer_ws_split(WStream<NW, F, NF> &ws, const f4 (&h)[U], float scale, f4 (&acc)[V]) {
     constexpr int NG = ((U + 1) / 2) * ((V + 1) / 2);
-    mlp_layer_split_impl<U, V, FBASE, WStream<NW, F, NF>, F>(ws, h, acc, std::make_integer_sequence<int, NG>{});
+    mlp_layer_split_impl<U, V, FBASE, WStream<NW, F, NF>, F>(ws, h, scale, acc, std::make_integer_sequence<int, NG>{});
 }
 
 // Weights resident in LDS (image [U][V][64] f4 at `w`): same pipeline without the stream.

@@ -33,6 +33,39 @@ __device__ __forceinline__ void init_bias(f4 (&acc)[V], const float *__restrict_
 #pragma unroll
     for (int v = 0; v < V; ++v) acc[v] = bias_frag(bias, v, g);
 }
+template <int V>
+__device__ __forceinline__ void init_zero(f4 (&acc)[V]) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = f4_zero();
+}
+// split layers: y = acc c + b, c = this lane's 2^-(kw + kx)
+template <int V>
+__device__ __forceinline__ void scale_bias(f4 (&acc)[V], float c, const float *__restrict__ bias, int g) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = __builtin_elementwise_fma(acc[v], (f4){c, c, c, c}, bias_frag(bias, v, g));
+}
+
+// One layer of the chain: fp32-input MFMA with the bias in the accumulators, or (SPLIT) the fp16 split path -- the lane's power-of-two
+// scale from its position's largest input, zero accumulators, scale and bias in one fma afterwards.
+template <bool SPLIT, int U, int V, int FBASE, class WS>
+__device__ __forceinline__ void pw_layer(WS &ws, const f4 (&h)[U], f4 (&acc)[V], const rtk_layer_t &L, int g, const float *sample_bias, bool first) {
+    if constexpr (SPLIT) {
+        const LaneScale sc = lane_scale16(h);
+        init_zero<V>(acc);
+        if (first) ws.next_if_deferred();
+        mlp_layer_ws_split<U, V, FBASE>(ws, h, sc.s, acc);
+        scale_bias<V>(acc, sc.inv * L.inv_scale, L.bias, g);
+    } else {
+        init_bias<V>(acc, L.bias, g);
+        if (first) ws.next_if_deferred();
+        mlp_layer_ws<U, V, FBASE>(ws, h, acc);
+    }
+    if (sample_bias) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] += bias_frag(sample_bias, v, g);
+    }
+    apply_act<V>(acc, L.act);
+}
 
 template <int V>
 __device__ __forceinline__ void store_tile(const PwParams &P, const f4 (&acc)[V], int p, int b, int g, bool valid) {
@@ -87,8 +120,8 @@ __device__ __forceinline__ void store_tile(const PwParams &P, const f4 (&acc)[V]
                    // throughput with two batches in flight -- smaller footprints co-reside, tools/experiments/exp_pwf.sh)
 #endif
 
-// SPLIT: the layers on the bf16 matrix pipe (six products of exact operand pieces per fp32 product, fused_common.h): same tile,
-// registers and stream, the blob holds split images.
+// SPLIT: the layers on the fp16 matrix pipe (two pieces per operand, three products per fp32 product, a power-of-two scale per weight
+// matrix and per position: fused_common.h, split_mfma.h): same tile, registers and stream, the blob holds split images.
 template <int U, int V1, int V2, int V3, int V4, bool INTERP, bool SPLIT>
 __global__ __launch_bounds__(64 * PW_NW, 2) void pointwise_mlp_kernel(const PwParams P) {
     __shared__ __attribute__((aligned(16))) f4 s_w[2 * PW_F * 64];
@@ -190,41 +223,24 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void pointwise_mlp_kernel(const PwPa
         }
 
         // ---- layer chain ------------------------------------------------------------------------------
+        // (the first layer enters the weight stream: chunk 0's request has been travelling with the loads above)
         f4 a1[V1];
-        init_bias<V1>(a1, P.layer[0].bias, g);
-        if constexpr (NF > PW_F) ws.next();      // chunk 0 (its request has been travelling with the loads above)
-        if (P.sample_bias) {
-            const float *sb = P.sample_bias + (size_t)b * 16 * V1;
-#pragma unroll
-            for (int v = 0; v < V1; ++v) a1[v] += bias_frag(sb, v, g);
-        }
-        if constexpr (SPLIT) mlp_layer_ws_split<U, V1, 0>(ws, h, a1);
-        else mlp_layer_ws<U, V1, 0>(ws, h, a1);
-        apply_act<V1>(a1, P.layer[0].act);
+        pw_layer<SPLIT, U, V1, 0>(ws, h, a1, P.layer[0], g, P.sample_bias ? P.sample_bias + (size_t)b * 16 * V1 : nullptr, true);
         if constexpr (V2 == 0) {
             store_tile<V1>(P, a1, p, b, g, valid);
         } else {
             f4 a2[V2];
-            init_bias<V2>(a2, P.layer[1].bias, g);
-            if constexpr (SPLIT) mlp_layer_ws_split<V1, V2, F1>(ws, a1, a2);
-            else mlp_layer_ws<V1, V2, F1>(ws, a1, a2);
-            apply_act<V2>(a2, P.layer[1].act);
+            pw_layer<SPLIT, V1, V2, F1>(ws, a1, a2, P.layer[1], g, nullptr, false);
             if constexpr (V3 == 0) {
                 store_tile<V2>(P, a2, p, b, g, valid);
             } else {
                 f4 a3[V3];
-                init_bias<V3>(a3, P.layer[2].bias, g);
-                if constexpr (SPLIT) mlp_layer_ws_split<V2, V3, F1 + F2>(ws, a2, a3);
-                else mlp_layer_ws<V2, V3, F1 + F2>(ws, a2, a3);
-                apply_act<V3>(a3, P.layer[2].act);
+                pw_layer<SPLIT, V2, V3, F1 + F2>(ws, a2, a3, P.layer[2], g, nullptr, false);
                 if constexpr (V4 == 0) {
                     store_tile<V3>(P, a3, p, b, g, valid);
                 } else {
                     f4 a4[V4];
-                    init_bias<V4>(a4, P.layer[3].bias, g);
-                    if constexpr (SPLIT) mlp_layer_ws_split<V3, V4, F1 + F2 + F3>(ws, a3, a4);
-                    else mlp_layer_ws<V3, V4, F1 + F2 + F3>(ws, a3, a4);
-                    apply_act<V4>(a4, P.layer[3].act);
+                    pw_layer<SPLIT, V3, V4, F1 + F2 + F3>(ws, a3, a4, P.layer[3], g, nullptr, false);
                     store_tile<V4>(P, a4, p, b, g, valid);
                 }
             }

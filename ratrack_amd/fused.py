@@ -29,7 +29,7 @@ class _Src(ctypes.Structure):
 
 class _Layer(ctypes.Structure):
     _fields_ = [("w_packed", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("cin16", ctypes.c_int), ("cout16", ctypes.c_int),
-                ("act", ctypes.c_int)]
+                ("act", ctypes.c_int), ("inv_scale", ctypes.c_float)]
 
 
 class _Interp(ctypes.Structure):
@@ -190,15 +190,16 @@ def pack_split_device(w, transposed=False):
 
 
 def pack_layer_split16(w):
-    """(Cout, Cin) -> 16-position split image (csrc/fused_common.h), int16: one fragment per (pair of 16-channel input blocks,
-    16-channel output block, piece): frag[up][v][p][lane = 16 g + i][t] = piece_p(W[16 v + i][16 (2 up + t // 4) + 4 g + t % 4]),
-    zero beyond (Cout, Cin)."""
+    """(Cout, Cin) -> (16-position split image (csrc/fused_common.h) as int16, inverse weight scale): one fragment per (pair of
+    16-channel input blocks, 16-channel output block, piece): frag[up][v][p][lane = 16 g + i][t] =
+    piece_p(2^k W[16 v + i][16 (2 up + t // 4) + 4 g + t % 4]), zero beyond (Cout, Cin)."""
     cout, cin = w.shape
     V, U2 = ceil16(cout) // 16, (ceil16(cin) // 16 + 1) // 2
     wp = torch.zeros(V * 16, U2 * 32, dtype=torch.float32, device=w.device)
     wp[:cout, :cin] = w.float()
-    p = split3_bf16(wp).reshape(3, V, 16, U2, 2, 4, 4)                     # (p, v, i, up, d, g, r): c = 32 up + 16 d + 4 g + r
-    return p.permute(3, 1, 0, 5, 2, 4, 6).contiguous().reshape(-1)         # (up, v, p, g, i, d, r): lane = 16 g + i, t = 4 d + r
+    scale, inv = pow2_scale(wp.abs().max())
+    p = split2_f16(wp, scale).reshape(2, V, 16, U2, 2, 4, 4)               # (p, v, i, up, d, g, r): c = 32 up + 16 d + 4 g + r
+    return p.permute(3, 1, 0, 5, 2, 4, 6).contiguous().reshape(-1), inv    # (up, v, p, g, i, d, r): lane = 16 g + i, t = 4 d + r
 
 
 # The product path runs every wide layer on the split-bf16 matrix path (csrc/split_mfma.h).  The fp32-input MFMA kernels stay compiled as
@@ -219,7 +220,8 @@ class Chain:
     def split_arr(self):
         """The same chain as split images (rtk_pointwise_mlp with RTK_LAYER_SPLIT), built on first use."""
         if self._split is None:
-            blob = torch.cat([pack_layer_split16(w.to(self._device)) for w, _ in self._layers]).contiguous()
+            packed = [pack_layer_split16(w.to(self._device)) for w, _ in self._layers]
+            blob = torch.cat([im for im, _ in packed]).contiguous()
             arr = (_Layer * len(self._layers))()
             off = boff = 0
             for i, (w, act) in enumerate(self._layers):
@@ -227,8 +229,8 @@ class Chain:
                 u, v = ceil16(cin) // 16, ceil16(cout) // 16
                 arr[i].w_packed = blob.data_ptr() + 2 * off
                 arr[i].bias = self.bias.data_ptr() + 4 * boff
-                arr[i].cin16, arr[i].cout16, arr[i].act = u, v, act | LAYER_SPLIT
-                off += ((u + 1) // 2) * v * 3 * 512      # int16 elements per fragment: 64 lanes x 8
+                arr[i].cin16, arr[i].cout16, arr[i].act, arr[i].inv_scale = u, v, act | LAYER_SPLIT, packed[i][1]
+                off += ((u + 1) // 2) * v * 2 * 512      # int16 elements per fragment: 64 lanes x 8
                 boff += v * 16
             self._split = (arr, blob)
         return self._split[0]

@@ -761,17 +761,19 @@ def test_split16_image_is_packed_as_documented():
     torch.manual_seed(9)
     cout, cin = 40, 50
     w = torch.randn(cout, cin)
-    img = F.pack_layer_split16(w).view(-1)                                  # (up, v, p, lane, t) int16
-    pieces = F.split3_bf16(torch.nn.functional.pad(w, (0, 64 - cin, 0, 48 - cout)))      # (3, 48, 64)
+    img, inv = F.pack_layer_split16(w)                                     # (up, v, p, lane, t) int16
+    scale, inv2 = F.pow2_scale(w.abs().max())
+    assert inv == inv2
+    pieces = F.split2_f16(torch.nn.functional.pad(w, (0, 64 - cin, 0, 48 - cout)), scale)      # (2, 48, 64)
     V, U2 = 3, 2
-    assert img.numel() == U2 * V * 3 * 64 * 8
+    assert img.numel() == U2 * V * 2 * 64 * 8
     for up in range(U2):
         for v in range(V):
-            for p in range(3):
+            for p in range(2):
                 for lane in (0, 5, 17, 38, 63):
                     g, i = lane // 16, lane % 16
                     for t in range(8):
-                        got = img[(((up * V + v) * 3 + p) * 64 + lane) * 8 + t]
+                        got = img[(((up * V + v) * 2 + p) * 64 + lane) * 8 + t]
                         assert got == pieces[p, 16 * v + i, 16 * (2 * up + t // 4) + 4 * g + t % 4]
 
 

@@ -137,8 +137,11 @@ def test_split_images_follow_their_index_formulas():
                     c = 32 * (s // 2) + 16 * (s % 2) + 8 * (t // 4) + 4 * hh + t % 4
                     assert torch.equal(img[s, v, :, lane, t], p[:, 32 * v + i, c])
     w = torch.randn(40, 50)                                                    # ragged: zero padded to (48, 64)
-    p = F.split3_bf16(torch.nn.functional.pad(w, (0, 14, 0, 8)))
-    img = F.pack_layer_split16(w).view(2, 3, 3, 64, 8)                         # (up, v, piece, lane, t)
+    scale, inv = F.pow2_scale(w.abs().max())
+    p = F.split2_f16(torch.nn.functional.pad(w, (0, 14, 0, 8)), scale)
+    img, inv2 = F.pack_layer_split16(w)
+    assert inv2 == inv
+    img = img.view(2, 3, 2, 64, 8)                                             # (up, v, piece, lane, t)
     for up in range(2):
         for v in range(3):
             for lane in (0, 5, 17, 38, 63):
