@@ -12,15 +12,17 @@ already resident in HBM.  One process per GPU; frame-pairs are independent, so r
 batches with no data-path collective (weak scaling); the timed region is bracketed by a barrier +
 synchronize on both sides and the maximum over ranks is reported.
 
-The timed region is EXACTLY `steps` steps with steps = max(K asked for, the steps 1.5 s take) -- a K = 20 window is 18 ms, which nothing
-outside this process can check; the K-step window itself is reported as `k_step_window`.  NBATCH distinct resident batches rotate
+The timed region is EXACTLY `steps` steps with steps = max(K asked for, the steps HEADLINE_SECONDS = 10 s take) -- a K = 20 window is
+15 ms, which nothing outside this process can check (round 4's 1.5 s window was invisible to a 10 s utilisation sampler too); the
+K-step window itself is reported as `k_step_window`.  NBATCH distinct resident batches rotate
 through the steps (no step re-reads its predecessor's inputs).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   configs             BASELINE.json's other single-GPU forward configurations with the same method: config 2 (B=32, N=256) and
                       config 5 (B=32, N=1024): ms/step, pairs/s, the dominant kernel alone against the split matrix peak;
-  roofline            the dominant kernel (cost_volume_split_kernel) against its matrix peak (dense bf16 / 6 products per fp32
-                      product; the fp32-input MFMA kernel it replaced is the tests' comparison implementation); duration measured IN SITU:
+  roofline            the dominant kernel (cost_volume_split_kernel) against its matrix peak (dense fp16 / 3 products per fp32
+                      product; the fp32-input MFMA kernel it replaced is the tests' comparison implementation); duration measured IN SITU
+                      (the individual event timings go to profiles/ when --evidence NAME is given):
                       a second timed region replays the same pipelined workload with the graph split around the kernel,
                       which is launched eagerly between two HIP events on its own launch stream;
   whole_path          pairs/s against both rooflines (HBM on SURVEY's algorithmic bytes, fp32 on the reference
@@ -50,9 +52,14 @@ sys.path.insert(0, ROOT)
 ALG_BYTES_PER_PAIR = {256: 14154240, 1024: 25293312}
 ALG_FLOPS_PER_PAIR = {256: 4.003e9, 1024: 10.790e9}
 FP32_PEAK_TFLOPS = 157.3      # MI355X fp32 vector == fp32-input MFMA peak (MI355X_MICROARCH.md)
-BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak (MI355X_MICROARCH.md)
-# the split path (csrc/split_mfma.h) pays six bf16 MFMA products for one fp32 product: its matrix roofline in fp32-equivalent terms
-SPLIT_PEAK_TFLOPS = BF16_PEAK_TFLOPS / 6.0
+BF16_PEAK_TFLOPS = 2500.0     # dense bf16 = fp16 MFMA peak (MI355X_MICROARCH.md)
+# the split path (csrc/split_mfma.h) pays THREE fp16 MFMA products for one fp32 product (rounds 2-4: six bf16 products): its matrix
+# roofline in fp32-equivalent terms
+SPLIT_PRODUCTS = 3
+SPLIT_PEAK_TFLOPS = BF16_PEAK_TFLOPS / SPLIT_PRODUCTS
+DTYPE = "f32 (2xfp16 split MFMA: three fp16 products per fp32 product, fp32 accumulate, power-of-two scales per matrix and position)"
+HEADLINE_SECONDS = 10.0       # the headline timed region (a utilisation sampler outside the process must see it)
+CONFIG_SECONDS = 3.0          # configs 2 and 5
 HBM_PEAK_GBS = 8000.0
 NBATCH = 8                    # distinct synthetic batches resident in HBM, rotated through the timed steps
 PMC = {"forward": "r02_pmc_cost_volume.json", "train": "r02_pmc_cost_volume_bwd.json", "irregular": "r02_irregular_hbm.json"}
@@ -60,7 +67,7 @@ PMC = {"forward": "r02_pmc_cost_volume.json", "train": "r02_pmc_cost_volume_bwd.
 
 def train_roofline(a, kms, kflops, ach, pm, ms_step):
     """Roofline object of the train step's dominant kernel.  fp32-input MFMA kernel (train_ops.CV_SPLIT = False, tests only): matrix-bound against 157.3
-    TFLOP/s.  Split kernel: its matrix floor (flops / (2500 / 6) TFLOP/s) has dropped below its HBM floor, so HBM is the binding
+    TFLOP/s.  Split kernel: its matrix floor (flops / (2500 / 3) TFLOP/s) is far below its HBM floor, so HBM is the binding
     roofline: algorithmic bytes = per (point, neighbour) position a3 + two mask words read, dz1, dz2, dz3, dq3, d4, dt2 written
     (5232 B), per query point dout read, dp1, dpd, bias rows written (7168 B)."""
     from ratrack_amd import train_ops
@@ -75,7 +82,7 @@ def train_roofline(a, kms, kflops, ach, pm, ms_step):
     gbs = nbytes / (kms * 1e-3) / 1e9
     return dict({"kernel": "cost_volume_bwd_split_kernel", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_launch": nbytes,
-                 "mfma": {"achieved": round(ach, 2), "peak": round(SPLIT_PEAK_TFLOPS, 1), "unit": "TFLOP/s (fp32-equivalent; bf16 peak / 6)",
+                 "mfma": {"achieved": round(ach, 2), "peak": round(SPLIT_PEAK_TFLOPS, 1), "unit": "TFLOP/s (fp32-equivalent; fp16 peak / 3)",
                           "frac": round(ach / SPLIT_PEAK_TFLOPS, 4), "vs_fp32_mfma_peak": round(ach / FP32_PEAK_TFLOPS, 4)}}, **common)
 
 
@@ -387,7 +394,7 @@ def dry_run(a, world, rank):
     if rank == 0:
         print(json.dumps({"metric": "dry run (CPU stand-in step)", "value": round(a.batch * world * a.steps / el, 1), "unit": "frame-pairs/s",
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 4),
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
                           "config": {"workload": "dry run", "global_batch": a.batch * world},
                           "per_rank_ms_per_step": {"min": round(min(per_rank) / a.steps * 1e3, 3), "max": round(max(per_rank) / a.steps * 1e3, 3)}}),
               flush=True)
@@ -396,7 +403,7 @@ def dry_run(a, world, rank):
         dist.destroy_process_group()
 
 
-def forward_config(net, batch, n, depth, dev, seconds=0.8, case0=3000):
+def forward_config(net, batch, n, depth, dev, seconds=CONFIG_SECONDS, case0=3000):
     """One of BASELINE.json's other single-GPU forward configurations with the headline's method (captured graphs, `depth` batches in
     flight, NBATCH distinct resident batches in rotation, >= `seconds` timed after 0.3 s of untimed steps), plus its dominant kernel
     alone between HIP events."""
@@ -467,6 +474,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--pipeline", type=int, default=4, help="captured graphs in flight (batch-level pipelining on streams)")
     ap.add_argument("--train-steps", type=int, default=20)
+    ap.add_argument("--seconds", type=float, default=HEADLINE_SECONDS, help="length of the headline timed region (never fewer than --steps steps)")
+    ap.add_argument("--evidence", default=None, help="rank 0 writes the in-situ event timings of the dominant kernel behind roofline.kernel_ms to "
+                    "profiles/<NAME>_insitu_cost_volume.txt")
     ap.add_argument("--graph-collective", action="store_true", help="world > 1: capture the RCCL all-reduce inside the train graph (one graph) "
                                                                      "instead of graph | eager all-reduce | graph")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo run of the distributed control flow with a stand-in step (tests)")
@@ -528,7 +538,7 @@ def main():
         if rank == 0:
             res = {"metric": "radar frame-pairs/sec (train step) at B=%d,N=%d per GPU" % (a.batch, a.npoints), "value": tr["pairs_per_s"],
                    "unit": "frame-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": tr["ms_per_step"],
-                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
                    "config": {"workload": tr["workload"] + ", hipGraph=%s" % tr["hipGraph"], "global_batch": a.batch * world,
                               "parallelism": "dp%d, one flat RCCL all-reduce of %d bytes per step" % (world, tr["allreduce_bytes"])},
                    "roofline": tr["roofline"], "whole_step": tr["whole_step"],
@@ -604,9 +614,9 @@ def main():
         if a.no_graph:
             step_fn, drain_fn = (lambda: net.backbone(*next_batch(), h)), (lambda: None)
             kstep = timed(step_fn, drain_fn, a.steps, a.warmup, 0.5, "k_steps")
-            # the headline window: the same region over >= 1.5 s (never fewer than the K steps asked for) -- with the driver's
-            # --steps 20 the K-step window is 18 ms, which no clock outside this process resolves
-            timed_steps = max(a.steps, int(1.5 / max(kstep / a.steps, 1e-6)))
+            # the headline window: the same region over >= HEADLINE_SECONDS (never fewer than the K steps asked for) -- with the driver's
+            # --steps 20 the K-step window is 15 ms, which no clock outside this process resolves
+            timed_steps = max(a.steps, int(a.seconds / max(kstep / a.steps, 1e-6)))
             elapsed = timed(step_fn, drain_fn, timed_steps, 0, 0.0, "headline")
             eng.kernel_events = events = []
             insitu = timed(step_fn, drain_fn, a.steps, 2)
@@ -615,17 +625,19 @@ def main():
             pipe = fused.GraphPipeline(eng, (pc1, pc2, f1, f2, h), depth=depth)
             step_fn = lambda: pipe.submit(*next_batch(), h)      # inputs are copied into the slot's static buffers
             kstep = timed(step_fn, pipe.drain, a.steps, a.warmup, 0.5, "k_steps")
-            timed_steps = max(a.steps, int(1.5 / max(kstep / a.steps, 1e-6)))
+            timed_steps = max(a.steps, int(a.seconds / max(kstep / a.steps, 1e-6)))
             elapsed = timed(step_fn, pipe.drain, timed_steps, 0, 0.0, "headline")
             # second timed region, same workload and concurrency, graphs split around the dominant kernel: its duration in situ
             pipe2 = fused.GraphPipeline(eng, (pc1, pc2, f1, f2, h), depth=depth, split_cost_volume=True)
             events = []
             pipe2.set_kernel_events(events)
-            insitu = timed(lambda: pipe2.submit(*next_batch(), h), pipe2.drain, a.steps, 3)
+            insitu = timed(lambda: pipe2.submit(*next_batch(), h), pipe2.drain, max(a.steps, 50), 3)
             pipe2.set_kernel_events(None)
         torch.cuda.synchronize()
-        events = events[-a.steps:]
-        kern_ms = sum(s.elapsed_time(e) for s, e in events) / max(len(events), 1)
+        events = events[-max(a.steps, 50):] if not a.no_graph else events[-a.steps:]
+        insitu_steps = len(events)
+        kern_each = [s.elapsed_time(e) for s, e in events]
+        kern_ms = sum(kern_each) / max(len(kern_each), 1)
         # the same kernel on the same operands with nothing else on the GPU (what a serialising profiler such as
         # rocprofv3 --kernel-trace reports for it)
         alone = eng.time_dominant_kernel(20)
@@ -640,6 +652,16 @@ def main():
             alone_shared_ms = sum(s.elapsed_time(e) for s, e in ev) / len(ev)
 
     res = None
+    if rank == 0 and a.evidence and kern_each:
+        with open(os.path.join(ROOT, "profiles", a.evidence + "_insitu_cost_volume.txt"), "w") as f:
+            f.write("# bench.py --evidence %s: cost_volume_split_kernel IN SITU, B=%d N=%d, %d batches in flight -- one line per launch,\n"
+                    "# HIP events around the launch on its own launch stream inside a timed region of the pipelined workload (graphs split around\n"
+                    "# the kernel; the measured kernels of the batches in flight chained by events).  roofline.kernel_ms = their mean.\n"
+                    % (a.evidence, a.batch, a.npoints, depth))
+            for k, v in enumerate(kern_each):
+                f.write("%3d  %.4f ms\n" % (k, v))
+            f.write("# mean %.4f ms  median %.4f  min %.4f  max %.4f  (n = %d);  alone (nothing else in flight): %.4f ms\n"
+                    % (kern_ms, statistics.median(kern_each), min(kern_each), max(kern_each), len(kern_each), alone_ms))
     if rank == 0:
         pairs_per_s = a.batch * world * timed_steps / elapsed
         cv_flops = cost_volume_flops_per_pair(a.npoints) * a.batch
@@ -662,9 +684,9 @@ def main():
             "n_gpus": world, "steps": timed_steps, "steps_requested": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / timed_steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": DTYPE, "data": "synthetic",
             "per_rank_ms_per_step": spread.get("headline"),
-            "timed_region": "EXACTLY `steps` steps between barrier + synchronize, max over ranks; steps = max(K asked for, what 1.5 s take): "
+            "timed_region": "EXACTLY `steps` steps between barrier + synchronize, max over ranks; steps = max(K asked for, what %g s take): " % a.seconds +
                             "the K-step window alone is `k_step_window`; %d distinct resident batches rotate through the steps" % NBATCH,
             "k_step_window": {"steps": a.steps, "ms_per_step": round(kstep / a.steps * 1e3, 4),
                               "value": round(a.batch * world * a.steps / kstep, 1), "per_rank_ms_per_step": spread.get("k_steps"),
@@ -676,9 +698,9 @@ def main():
             "roofline": {"kernel": "cost_volume_split_kernel" if split else "cost_volume_kernel", "bound": "mfma",
                          "achieved": round(achieved, 2), "peak": round(cv_peak, 1),
                          "unit": "TFLOP/s", "frac": round(achieved / cv_peak, 4),
-                         "peak_is": ("fp32-equivalent: dense bf16 MFMA peak (2500) / 6 -- the kernel takes every fp32 product as six bf16 "
-                                     "MFMA products of exact operand pieces (csrc/split_mfma.h); `achieved` counts the algorithmic fp32 "
-                                     "flops, so `frac` is also the executed bf16 rate over 2500.  Against the fp32-input MFMA peak "
+                         "peak_is": ("fp32-equivalent: dense fp16 MFMA peak (2500) / 3 -- the kernel takes every fp32 product as three fp16 "
+                                     "MFMA products of two operand pieces each (csrc/split_mfma.h); `achieved` counts the algorithmic fp32 "
+                                     "flops, so `frac` is also the executed fp16 rate over 2500.  Against the fp32-input MFMA peak "
                                      "(157.3, the roofline of the round-1/2 kernel) the same launch is at %.2f in situ / %.2f alone"
                                      % (achieved / FP32_PEAK_TFLOPS, cv_flops / (alone_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS))
                                     if split else "fp32-input MFMA peak",
@@ -694,14 +716,16 @@ def main():
                                                if alone_shared_ms else None),
                          "measured": "in situ: %d launches between HIP events inside a timed region of the same pipelined workload "
                                      "(graphs split around the kernel, the measured kernels of the batches in flight chained by events "
-                                     "so that they do not time-share the CUs; %.4f ms/step there)" % (len(events), insitu / a.steps * 1e3)},
+                                     "so that they do not time-share the CUs; %.4f ms/step there)" % (len(events), insitu / max(insitu_steps, 1) * 1e3),
+                         "kernel_ms_each": {"min": round(min(kern_each), 4), "median": round(statistics.median(kern_each), 4),
+                                            "max": round(max(kern_each), 4), "n": len(kern_each)} if kern_each else None},
             # whole path per GPU against both rooflines (SURVEY.md H1 asks for both).  "algorithmic" = the reference
             # formulation's 14.15 MB / 4.003 GFLOP per pair; "executed" = the multiply-adds this design issues (per-point
             # layer-1 projections, duplicate centroids skipped), counted from this run's launch shapes.
             "whole_path": {"hbm_frac_algorithmic": round(per_gpu * ALG_BYTES_PER_PAIR.get(a.npoints, 0) / (HBM_PEAK_GBS * 1e9), 5),
                            "fp32_frac_algorithmic": round(per_gpu * ALG_FLOPS_PER_PAIR.get(a.npoints, 0) / (FP32_PEAK_TFLOPS * 1e12), 5),
                            "fp32_frac_executed": round(per_gpu * exec_flops_per_pair / (FP32_PEAK_TFLOPS * 1e12), 5),
-                           # against the matrix roofline of this design's own arithmetic (bf16 peak / 6 products per fp32 product):
+                           # against the matrix roofline of this design's own arithmetic (fp16 peak / 3 products per fp32 product):
                            # the ceiling of the path as formulated, and what the north star's "30 % of HBM" would need of it
                            "split_frac_executed": round(per_gpu * exec_flops_per_pair / (SPLIT_PEAK_TFLOPS * 1e12), 5),
                            "split_ceiling_pairs_per_s": round(SPLIT_PEAK_TFLOPS * 1e12 / exec_flops_per_pair, 0),
@@ -709,7 +733,7 @@ def main():
                            "executed_gflop_per_pair": round(exec_flops_per_pair / 1e9, 4),
                            "executed_gflop_per_pair_by_kernel": {k: round(2.0 * v / a.batch / 1e9, 4) for k, v in exec_by_kernel.items()}},
             # one eager pass, every launch between HIP events on one stream with nothing else in flight (what a serialising profiler
-            # shows); FLOP-carrying families: executed multiply-adds x 2 / time against the split matrix peak (bf16 / 6)
+            # shows); FLOP-carrying families: executed multiply-adds x 2 / time against the split matrix peak (fp16 / 3)
             "kernels_alone": {k: dict({"launches": v[0], "us": round(v[1], 1)},
                                       **({"gflop": round(2.0 * exec_by_kernel[k] / 1e9, 2),
                                           "tflops": round(2.0 * exec_by_kernel[k] / (v[1] * 1e-6) / 1e12, 1),
