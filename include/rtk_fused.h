@@ -227,7 +227,8 @@ RTK_EXPORT int rtk_log_sinkhorn(int m, int n, const float *scores, float alpha, 
  * feat: channel-major (C, pitch) per-point tensor of ONE frame; channels (8) int32 DEVICE array = the feature channels
  * entering the distance; score (n): a point takes part iff score > threshold (the motion-segmentation probability).
  * labels (n) int32: sklearn's cluster ids restricted to the participating points (numbered by first core point), -1 = noise or
- * not participating.  One workgroup; n <= ~2900 points. */
+ * not participating.  One workgroup; its tables live in LDS up to ~2900 points and in a stream-ordered global workspace beyond
+ * (n <= 65536; all pairs are tested by that one workgroup). */
 RTK_EXPORT int rtk_dbscan(int n, const float *feat, int pitch, const int *channels, const float *score, float threshold, double eps,
                           int min_samples, int *labels, rtk_stream_t stream);
 

@@ -331,11 +331,15 @@ __device__ __forceinline__ bool db_adjacent(const float *f, int i, int j, double
     return __dsqrt_rn(d2) <= eps;
 }
 
+// WORK = false: the tables live in LDS (clouds up to ~2900 points: every real frame).  WORK = true: the same single workgroup on a
+// global-memory workspace -- larger clouds are clustered on the device too (slower: O(m^2) distance tests from L2 instead of LDS),
+// nothing falls back to the host.
+template <bool WORK>
 __global__ __launch_bounds__(256) void dbscan_kernel(int n, const float *__restrict__ feat, int pitch, const int *__restrict__ chan,
                                                      const float *__restrict__ score, float thr, double eps, int min_samples,
-                                                     int *__restrict__ labels) {
+                                                     int *__restrict__ labels, unsigned char *__restrict__ work) {
     extern __shared__ __attribute__((aligned(16))) unsigned char db_smem[];
-    float *f = reinterpret_cast<float *>(db_smem);                 // (m, 8) compacted features
+    float *f = WORK ? reinterpret_cast<float *>(work) : reinterpret_cast<float *>(db_smem);                 // (m, 8) compacted features
     int *src = reinterpret_cast<int *>(f + (size_t)n * DB_D);      // mover -> input index
     int *lab = src + n;                                            // component label (smallest core index) or INT_MAX
     int *aux = lab + n;                                            // core flag, then cluster number of a representative
@@ -417,10 +421,22 @@ __global__ __launch_bounds__(256) void dbscan_kernel(int n, const float *__restr
 extern "C" int rtk_dbscan(int n, const float *feat, int pitch, const int *channels, const float *score, float threshold, double eps,
                           int min_samples, int *labels, rtk_stream_t stream) {
     RTK_REQUIRE(n > 0 && feat && channels && score && labels && pitch >= n && min_samples >= 1, "dbscan: bad arguments");
-    const size_t lds = (size_t)n * (DB_D * sizeof(float) + 3 * sizeof(int));
-    RTK_REQUIRE(lds <= 128 * 1024, "dbscan: %d points exceed the single-workgroup LDS budget", n);
-    (void)hipFuncSetAttribute((const void *)dbscan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);      // per device and cheap: every call
-    dbscan_kernel<<<1, 256, lds, (hipStream_t)stream>>>(n, feat, pitch, channels, score, threshold, eps, min_samples, labels);
+    RTK_REQUIRE(n <= 65536, "dbscan: n=%d > 65536 points (one workgroup tests all pairs)", n);
+    const size_t bytes = (size_t)n * (DB_D * sizeof(float) + 3 * sizeof(int));
+    hipStream_t st = (hipStream_t)stream;
+    if (bytes <= 128 * 1024) {
+        (void)hipFuncSetAttribute((const void *)dbscan_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);      // per device and cheap: every call
+        dbscan_kernel<false><<<1, 256, bytes, st>>>(n, feat, pitch, channels, score, threshold, eps, min_samples, labels, nullptr);
+    } else {      // beyond one workgroup's LDS: a stream-ordered workspace
+        void *work = nullptr;
+        if (hipMallocAsync(&work, bytes, st) != hipSuccess) {
+            (void)hipGetLastError();
+            rtk_set_error("dbscan: no %zu-byte workspace for n=%d points", bytes, n);
+            return RTK_ERR_LAUNCH;
+        }
+        dbscan_kernel<true><<<1, 256, 0, st>>>(n, feat, pitch, channels, score, threshold, eps, min_samples, labels, (unsigned char *)work);
+        (void)hipFreeAsync(work, st);
+    }
     RTK_CHECK_LAUNCH("dbscan");
     return RTK_OK;
 }

@@ -1163,16 +1163,74 @@ __global__ __launch_bounds__(256) void knn_point_kernel(int s, int n, int k, con
     }
 }
 
+// Any k (the reference's torch.topk takes any k <= n; the live k is 16): one wave per query, k rounds of "smallest (distance, index)
+// key above the last one taken" -- O(k n / 64) per query, no per-k register arrays.  Same distance arithmetic, same output order.
+template <bool USE_LDS>
+__global__ __launch_bounds__(256) void knn_point_select_kernel(int s, int n, int k, const float *__restrict__ query,
+                                                               const float *__restrict__ points, int64_t *__restrict__ idx,
+                                                               const int *__restrict__ nvalid) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bs = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    points += (size_t)bs * n * 3;
+    if (nvalid) {
+        const int nv = nvalid[bs];
+        n = nv < n ? (nv < k ? k : nv) : n;
+    }
+    float *sx = smem, *sy = smem + n, *sz = smem + 2 * n, *sn = smem + 3 * n;
+    if (USE_LDS) {
+        for (int j = tid; j < n; j += 256) {
+            const float px = points[j * 3 + 0], py = points[j * 3 + 1], pz = points[j * 3 + 2];
+            sx[j] = px; sy[j] = py; sz[j] = pz;
+            sn[j] = __fadd_rn(__fadd_rn(__fmul_rn(px, px), __fmul_rn(py, py)), __fmul_rn(pz, pz));
+        }
+        __syncthreads();
+    }
+    const int qi = blockIdx.x * 4 + (tid >> 6);
+    if (qi >= s) return;
+    const float *q = query + ((size_t)bs * s + qi) * 3;
+    const float qx = q[0], qy = q[1], qz = q[2];
+    const float qn = __fadd_rn(__fadd_rn(__fmul_rn(qx, qx), __fmul_rn(qy, qy)), __fmul_rn(qz, qz));
+    int64_t *o = idx + ((size_t)bs * s + qi) * k;
+    unsigned long long last = 0ull;
+    for (int r = 0; r < k; ++r) {
+        unsigned long long best = ~0ull;
+        for (int j = lane; j < n; j += 64) {
+            float px, py, pz, pn;
+            if (USE_LDS) { px = sx[j]; py = sy[j]; pz = sz[j]; pn = sn[j]; }
+            else {
+                px = points[j * 3 + 0]; py = points[j * 3 + 1]; pz = points[j * 3 + 2];
+                pn = __fadd_rn(__fadd_rn(__fmul_rn(px, px), __fmul_rn(py, py)), __fmul_rn(pz, pz));
+            }
+            const float dot = __fmaf_rn(qz, pz, __fmaf_rn(qy, py, __fmul_rn(qx, px)));
+            float dd = __fadd_rn(__fadd_rn(__fmul_rn(-2.f, dot), qn), pn);
+            dd = dd > 0.f ? dd : 0.f;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)j;      // dd >= 0: bit order = value order
+            if ((r == 0 || key > last) && key < best) best = key;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long other = __shfl_xor(best, d, 64);
+            best = other < best ? other : best;
+        }
+        last = best;
+        if (lane == 0) o[r] = (int64_t)(best & 0xffffffffull);
+    }
+}
+
 static int knn_point_impl(int b, int s, int n, int k, const float *query, const float *points, int64_t *idx, const int *nvalid,
                           rtk_stream_t stream) {
     RTK_REQUIRE(b > 0 && s > 0 && n > 0 && query && points && idx, "knn_point: bad arguments");
-    RTK_REQUIRE(k >= 1 && k <= 32 && k <= n, "knn_point: k=%d outside [1, min(32, n=%d)]", k, n);
+    RTK_REQUIRE(k >= 1 && k <= n, "knn_point: k=%d outside [1, n=%d]", k, n);
     RTK_REQUIRE(b <= 65535, "knn_point: b exceeds grid limits");
     dim3 grid(rtk_divup(s, 16), b);
     const size_t lds = (size_t)n * 4 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     const bool use_lds = lds <= 64 * 1024;
-    if (k <= 16) {
+    if (k > 32) {
+        const dim3 g4(rtk_divup(s, 4), b);
+        if (use_lds) knn_point_select_kernel<true><<<g4, 256, lds, st>>>(s, n, k, query, points, idx, nvalid);
+        else knn_point_select_kernel<false><<<g4, 256, 0, st>>>(s, n, k, query, points, idx, nvalid);
+    } else if (k <= 16) {
         if (use_lds) knn_point_kernel<16, true><<<grid, 256, lds, st>>>(s, n, k, query, points, idx, nvalid);
         else knn_point_kernel<16, false><<<grid, 256, 0, st>>>(s, n, k, query, points, idx, nvalid);
     } else {

@@ -203,9 +203,9 @@ class Track4D(nn.Module):
         assert pc1.shape[0] == 1, "detection / association is single-frame logic (B = 1), as in the reference"
         pc1_warp = pc1 + flow
         point_features = torch.cat((pc1_warp, pc1, flow, feature1, prop_features), dim=1)      # (1,139,N)
-        if point_features.is_cuda and point_features.shape[2] <= 2048:
+        if point_features.is_cuda:      # every cloud size on the device (rtk_dbscan: LDS tables up to ~2900 points, a global workspace beyond)
             objects_curr = A.cluster_objects_device(point_features, cls, eps=1.5, min_samples=self.min_obj_points)
-        else:       # host tensors (CPU tests of the bookkeeping) / clouds beyond one workgroup's LDS
+        else:       # host tensors only: the CPU tests of the association bookkeeping (the backbone itself has no CPU path)
             mov_mask = (cls > 0.5).squeeze(0)
             objects_curr = A.cluster_objects(point_features[:, :, mov_mask], eps=1.5, min_samples=self.min_obj_points)
         aff_list, aff_mat, indices1, confs, objects = self.associator(objects_curr, objects_prev or dict())

@@ -673,7 +673,7 @@ def test_fused_real_frames_match_reference_fixture():
 
 
 @pytest.mark.parametrize("n,eps,ms,seed", [(256, 1.5, 2, 0), (300, 1.5, 2, 1), (1000, 1.2, 4, 2), (2048, 0.9, 3, 3), (64, 0.5, 2, 4),
-                                           (500, 1.5, 6, 5), (10, 1.5, 2, 6)])
+                                           (500, 1.5, 6, 5), (10, 1.5, 2, 6), (3000, 1.1, 2, 8), (4096, 1.0, 3, 7)])      # > ~2900: global workspace
 def test_dbscan_kernel_matches_host_restatement(n, eps, ms, seed):
     """rtk_dbscan (mover selection + DBSCAN in one launch) against association.dbscan -- the host restatement that
     tests/test_association_cpu.py pins to scikit-learn -- on clustered clouds, incl. min_samples > 2 (border points, which

@@ -121,7 +121,8 @@ def test_gather_group_interpolate_and_grads():
     assert torch.allclose(f.grad.cpu(), ref, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("n,s,k", [(256, 256, 16), (1024, 1024, 16), (242, 242, 16), (50, 20, 3), (300, 10, 32), (20000, 5, 16)])
+@pytest.mark.parametrize("n,s,k", [(256, 256, 16), (1024, 1024, 16), (242, 242, 16), (50, 20, 3), (300, 10, 32), (20000, 5, 16),
+                                   (256, 256, 64), (300, 7, 200), (77, 9, 77), (20000, 3, 40)])      # k > 32: the any-k selection kernel
 def test_knn_point(n, s, k):
     a, b = cloud(2, max(n, s), 40 + n)
     xyz, q = a[:, :n].contiguous(), b[:, :s].contiguous()

@@ -38,10 +38,14 @@ PATCHES = [
      "    for (int t = t0; t < ntiles; t += tstep) {\n        asm volatile(\"\" ::: \"memory\");\n        CV_TICK(0)\n        // the next tile's neighbour index" % NT),
     ("        // byte offset of this lane's first 16-byte slot in a (position, 256) row (one 32-bit VGPR on uniform base pointers)\n        const long pos = i * 16 + j;",
      "        CV_TICK(1)\n        const long pos = i * 16 + j;"),
-    ("CvRowsRequest(P.p2, rows, (int)nbn, 0, lane)});\n", "CvRowsRequest(P.p2, rows, (int)nbn, 0, lane)});\n        CV_TICK(2)\n"),
-    ("        if (SAVE) split_layer<SPLIT_NF>(ws, h, acc, StoreRowsSide{P.sv2, ro, valid});\n        else split_layer<SPLIT_NF>(ws, h, acc);\n        ws.sync();",
-     "        CV_TICK(3)\n        if (SAVE) split_layer<SPLIT_NF>(ws, h, acc, StoreRowsSide{P.sv2, ro, valid});\n        else split_layer<SPLIT_NF>(ws, h, acc);\n"
-     "        CV_TICK(4)\n        ws.sync();\n        CV_TICK(5)"),
+    ("        LaneScale sc = lane_scale32(h);\n        split_layer<0>(ws, h, sc.s, acc, SidePair<CvLayer2Side<SAVE>",
+     "        LaneScale sc = lane_scale32(h);\n        CV_TICK(12)\n        split_layer<0>(ws, h, sc.s, acc, SidePair<CvLayer2Side<SAVE>"),
+    ("        float c = sc.inv * wi2;\n", "        CV_TICK(2)\n        float c = sc.inv * wi2;\n"),
+    ("        sc = lane_scale32(h);\n        if (SAVE) split_layer<SPLIT_NF>", "        sc = lane_scale32(h);\n        CV_TICK(3)\n        if (SAVE) split_layer<SPLIT_NF>"),
+    ("        ws.sync();                                                   // wrap the stream to chunk 0\n        c = sc.inv * wi3;\n",
+     "        CV_TICK(4)\n        ws.sync();                                                   // wrap the stream to chunk 0\n        CV_TICK(5)\n        c = sc.inv * wi3;\n"),
+    ("        WnBlock wk = wn_block(P.wn, 0, hh, col);                     // block 0's operands travel during the hidden layers",
+     "        CV_TICK(13)\n        WnBlock wk = wn_block(P.wn, 0, hh, col);                     // block 0's operands travel during the hidden layers"),
     ("        float *o = P.out + i * P.out_pitch + 4 * hh;\n        f16v wpre", "        CV_TICK(6)\n        float *o = P.out + i * P.out_pitch + 4 * hh;\n        f16v wpre"),
     ("        out_block(0);\n        out_block(1);\n", "        out_block(0);\n        CV_TICK(7)\n        out_block(1);\n        CV_TICK(8)\n"),
     ("#pragma unroll\n        for (int v = 2; v < SPLIT_VB; ++v) out_block(v);\n        pt = ptn;",
@@ -143,9 +147,10 @@ def main():
     groups = 256 // 8
     gx = max(1, min(256 // a.batch, groups))
     tiles = groups / gx
-    names = ["loop top", "layer 1 (64 row loads, Wd.d, leaky)", "layer 2 (64 group steps)", "leaky + bias", "layer 3 (64 group steps)",
-             "stream wrap sync", "epilogue: next index request, block 0 operands, WeightNet hidden layers", "epilogue: output block 0", "epilogue: output block 1",
-             "epilogue: next tile's coordinates requested", "epilogue: output blocks 2..7", "epilogue: next direction (waits for the coordinates)"]
+    names = ["loop top", "layer 1 (rows through LDS, Wd.d, leaky)", "layer 2 (64 group steps of 6 MFMAs)", "a2 = leaky(acc c + b), position scale",
+             "layer 3 (64 group steps)", "stream wrap sync", "epilogue: next index request, block 0 operands, WeightNet hidden layers",
+             "epilogue: output block 0", "epilogue: output block 1", "epilogue: next tile's coordinates requested", "epilogue: output blocks 2..7",
+             "epilogue: next direction (waits for the coordinates)", "position scale of a1 (max scan + swap)", "a3 = leaky(acc c + b)"]
     tot, wall = tk[:, 14].mean(), tk[:, 15].mean()
     print("%d waves, %.1f tiles each; kernel body %.0f clock ticks = %.0f wall ticks (100 MHz: %.1f us) -> clock runs at %.1f MHz"
           % (len(tk), tiles, tot, wall, wall / 100.0, tot / wall * 100.0))
@@ -156,7 +161,7 @@ def main():
         print("  %-75s %9.0f ticks/tile  %6.2f us/tile  %5.1f %%   (min %.0f max %.0f over waves)"
               % (nm, tk[:, k].mean() / tiles, us(tk[:, k].mean() / tiles), 100 * tk[:, k].mean() / tot, tk[:, k].min() / tiles, tk[:, k].max() / tiles))
     print("  %-75s %9.0f ticks" % ("outside the tile loop (start_parts, first index, finish)", tot - tk[:, :len(names)].sum(1).mean()))
-    print("  ideal MFMA time of a layer: 64 x 12 x 32 cycles = 24576 cycles")
+    print("  ideal MFMA time of a layer: 64 x 6 x 32 cycles = 12288 cycles")
 
 
 if __name__ == "__main__":
