@@ -475,6 +475,64 @@ __device__ __forceinline__ void row_sum16_valu_f4x4(f4 (&v)[4]) {      // argume
                    "+v"(v[2].x), "+v"(v[2].y), "+v"(v[2].z), "+v"(v[2].w), "+v"(v[3].x), "+v"(v[3].y), "+v"(v[3].z), "+v"(v[3].w));
 }
 
+// ---- transposing reductions (round 5) ------------------------------------------------------------------------------------------
+// The reductions above leave the full-row result of EVERY register in EVERY lane: log2(16) steps x N registers.  When N registers are
+// reduced at once, half of that is waste: a step that combines lanes l and l ^ k can at the same time HALVE the registers -- the lanes
+// with bit k clear keep register a's partial result, the lanes with bit k set keep register b's, in ONE register.  The DPP write masks
+// do this for free for k = 8 and k = 4 (bank_mask enables the four 4-lane banks of a row separately: a masked lane keeps the old
+// destination), v_permlane16_swap for k = 16 (row 1 of a <-> row 0 of b, row 3 <-> row 2: then one max / add); the last two steps
+// (k = 2, 1, inside a quad) run on the N / 4 (N / 8) registers that are left.  16 registers over a row: 16 + 8 + 4 + 4 = 32 cross-lane
+// operations instead of 64.  Afterwards register j of lane l holds the result of input register (j, bits 3 and 2 of l): pair8 keeps
+// `a` in lanes 0-7 and `b` in lanes 8-15 of each row, pair4 keeps `a` where bit 2 of the lane is clear.
+// Arguments: VALU results the compiler sees (see row_sum16_valu_f4); each block's s_nop covers VALU -> DPP.
+#define RTK_DPP_PAIR(op, c0, m0, c1, m1)                                                                                     \
+    asm volatile("s_nop 1\n"                                                                                                 \
+                 op " %0, %0, %0 " c0 " row_mask:0xf bank_mask:" m0 "\n" op " %1, %1, %1 " c0 " row_mask:0xf bank_mask:" m0 "\n"  \
+                 op " %2, %2, %2 " c0 " row_mask:0xf bank_mask:" m0 "\n" op " %3, %3, %3 " c0 " row_mask:0xf bank_mask:" m0 "\n"  \
+                 op " %0, %4, %4 " c1 " row_mask:0xf bank_mask:" m1 "\n" op " %1, %5, %5 " c1 " row_mask:0xf bank_mask:" m1 "\n"  \
+                 op " %2, %6, %6 " c1 " row_mask:0xf bank_mask:" m1 "\n" op " %3, %7, %7 " c1 " row_mask:0xf bank_mask:" m1 "\n"  \
+                 : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w) : "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w))
+__device__ __forceinline__ void row_max_pair8(f4 &a, const f4 b) { RTK_DPP_PAIR("v_max_f32_dpp", "row_ror:8", "0x3", "row_ror:8", "0xc"); }
+__device__ __forceinline__ void row_max_pair4(f4 &a, const f4 b) { RTK_DPP_PAIR("v_max_f32_dpp", "row_shl:4", "0x5", "row_shr:4", "0xa"); }
+__device__ __forceinline__ void row_sum_pair8(f4 &a, const f4 b) { RTK_DPP_PAIR("v_add_f32_dpp", "row_ror:8", "0x3", "row_ror:8", "0xc"); }
+__device__ __forceinline__ void row_sum_pair4(f4 &a, const f4 b) { RTK_DPP_PAIR("v_add_f32_dpp", "row_shl:4", "0x5", "row_shr:4", "0xa"); }
+#undef RTK_DPP_PAIR
+// the last two steps, inside each quad (every lane of a quad ends with the quad's result)
+__device__ __forceinline__ void quad_max_valu_f4(f4 &v) {
+    asm volatile("s_nop 1\n" RTK_DPP4("v_max_f32_dpp", "quad_perm:[1,0,3,2]") RTK_DPP4("v_max_f32_dpp", "quad_perm:[2,3,0,1]")
+                 : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+}
+__device__ __forceinline__ void quad_sum_valu_f4(f4 &v) {
+    asm volatile("s_nop 1\n" RTK_DPP4("v_add_f32_dpp", "quad_perm:[1,0,3,2]") RTK_DPP4("v_add_f32_dpp", "quad_perm:[2,3,0,1]")
+                 : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+}
+// rows 0 | 1 and 2 | 3 of the wave (lanes l and l ^ 16): a's combination in the even rows, b's in the odd rows
+// (inf: +infinity the optimiser cannot see -- max(x, y) = med3(x, y, inf) is ONE instruction, fmaxf under IEEE mode up to three)
+__device__ __forceinline__ f4 wave_max_pair16(const f4 a, const f4 b, float inf) {
+    f4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[r]), __float_as_uint(b[r]), false, false);
+        o[r] = __builtin_amdgcn_fmed3f(__uint_as_float(t[0]), __uint_as_float(t[1]), inf);
+    }
+    return o;
+}
+// Four f4 registers (index q) -> one: the maximum over the 16 lanes of each row; lane l ends with q = 2 (bit 3 of l) + (bit 2 of l)
+__device__ __forceinline__ f4 row_max16_transpose4(f4 q0, f4 q1, const f4 q2, const f4 q3) {
+    row_max_pair8(q0, q2);
+    row_max_pair8(q1, q3);
+    row_max_pair4(q0, q1);
+    quad_max_valu_f4(q0);
+    return q0;
+}
+__device__ __forceinline__ f4 row_sum16_transpose4(f4 q0, f4 q1, const f4 q2, const f4 q3) {
+    row_sum_pair8(q0, q2);
+    row_sum_pair8(q1, q3);
+    row_sum_pair4(q0, q1);
+    quad_sum_valu_f4(q0);
+    return q0;
+}
+
 // max over aligned sub-groups of GROUP (4, 8 or 16) lanes within the row
 template <int GROUP>
 __device__ __forceinline__ void row_max_group_f4(f4 &v) {

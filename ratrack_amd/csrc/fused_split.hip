@@ -220,6 +220,7 @@ __device__ __forceinline__ float rtk_hidden_inf() {
     return v;
 }
 __device__ __forceinline__ float relu1(float x, float inf) { return __builtin_amdgcn_fmed3f(x, 0.f, inf); }
+__device__ __forceinline__ f4 relu_med4(f4 t, float inf) { return (f4){relu1(t.x, inf), relu1(t.y, inf), relu1(t.z, inf), relu1(t.w, inf)}; }
 __device__ __forceinline__ f4 f4_relu(f4 a) { return (f4){fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)}; }
 
 // ---- layer 1's operands ---------------------------------------------------------------------------------------------------
@@ -453,11 +454,10 @@ void cost_volume_split_kernel(const CvSplitParams P) {
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) r[q][e] = relu1(w[4 * q + e], kinf) * h[4 * v + q][e];
-            row_sum16_valu_f4x4(r);
-            if (valid && j == 0) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) *reinterpret_cast<f4 *>(o + 32 * v + 8 * q) = r[q];
-            }
+            // sum over the 16 neighbours by the transposing reduction (fused_common.h): lane j ends with slot q = 2 (bit 3 of j) + (bit 2
+            // of j) of the block, the first lane of each quad stores -- 32 cross-lane operations and one store instead of 64 and four
+            const f4 t = row_sum16_transpose4(r[0], r[1], r[2], r[3]);
+            if (valid && (j & 3) == 0) *reinterpret_cast<f4 *>(o + 32 * v + 8 * (2 * ((j >> 3) & 1) + ((j >> 2) & 1))) = t;
         };
         out_block(0);
         out_block(1);
@@ -674,6 +674,7 @@ struct SaSplitParams {
 template <int NS, int C1>
 __global__ __launch_bounds__(256, SA_SPLIT_WAVES) void sa_scale_split_kernel(const SaSplitParams P) {
     constexpr int KS = C1 / 16, VB1 = C1 / 32, NFR = KS * 2 * 2, CPT = 32 / NS;      // k-steps, 32-blocks of layer 1, fragments, centroids per tile
+    const float kinf = rtk_hidden_inf();
     __shared__ __attribute__((aligned(16))) f4 s_img[NFR * 64];
     const int lane = threadIdx.x & 63, hh = lane >> 5, col = lane & 31, pp = col / NS, slot = col % NS;
     int b, bx, nbx;
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(256, SA_SPLIT_WAVES) void sa_scale_split_kernel(con
             a = mfma_f32x2(wr[16 * hh], b0, a);
             a = mfma_f32x2(wr[16 * (2 + hh)], b1, a);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) h[4 * v + q] = f4_relu((f4){a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]});
+            for (int q = 0; q < 4; ++q) h[4 * v + q] = relu_med4((f4){a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]}, kinf);
         }
         // layer 2 (C1 -> 64) on the split path, the position's activations scaled by its own power of two; ReLU after the max
         const LaneScale sc = lane_scale32(h);
@@ -735,22 +736,32 @@ __global__ __launch_bounds__(256, SA_SPLIT_WAVES) void sa_scale_split_kernel(con
             RTK_SA_MM(1, 0) RTK_SA_MM(0, 1) RTK_SA_MM(0, 0)
 #undef RTK_SA_MM
         }
-        float *o = P.out + (long)c * P.out_pitch + P.out_offset + 4 * hh;
+        // The maximum over the neighbours by a transposing reduction (fused_common.h): the eight f4 of a lane (v, q) end as ONE (32
+        // neighbours: the two v through v_permlane16_swap) or two (16 neighbours); lane (hh, col) then holds q = 2 (bit 3 of col) +
+        // (bit 2 of col) and -- 32 neighbours -- v = bit 4 of col, and the first lane of each quad stores.  Bias and scale BEFORE the
+        // maximum (an fma the compiler knows: it places the wait states an MFMA result needs; the position's scale differs lane by lane).
+        f4 m[2][4];
 #pragma unroll
         for (int v = 0; v < 2; ++v)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                // bias BEFORE the maximum (max_j(x_j) + b == max_j(x_j + b) bit for bit: rounding is monotonic): the add is a VALU
-                // instruction the compiler knows, so it inserts the wait states an MFMA result needs before a VALU read; the inline-asm
-                // DPP reduction behind it only needs the VALU -> DPP ones its own s_nop covers.  Fed by the accumulators directly
-                // (register-capped build: accumulators in arch VGPRs) the asm computed wrong maxima.
-                f4 m = scale_bias4((f4){acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]}, cs,
-                                   *reinterpret_cast<const f4 *>(P.bias2 + 32 * v + 8 * q + 4 * hh));
-                row_max_group_f4<16>(m);
-                if constexpr (NS == 32) m = f4_max(m, (f4){__shfl_xor(m.x, 16, 64), __shfl_xor(m.y, 16, 64), __shfl_xor(m.z, 16, 64), __shfl_xor(m.w, 16, 64)});
-                m = f4_relu(m);
-                if (valid && slot == 0) *reinterpret_cast<f4 *>(o + 32 * v + 8 * q) = m;
+            for (int q = 0; q < 4; ++q)
+                m[v][q] = scale_bias4((f4){acc[v][4 * q], acc[v][4 * q + 1], acc[v][4 * q + 2], acc[v][4 * q + 3]}, cs,
+                                      *reinterpret_cast<const f4 *>(P.bias2 + 32 * v + 8 * q + 4 * hh));
+        const int qo = 2 * ((col >> 3) & 1) + ((col >> 2) & 1);
+        float *o = P.out + (long)c * P.out_pitch + P.out_offset + 4 * hh + 8 * qo;
+        if constexpr (NS == 32) {
+            f4 t[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = wave_max_pair16(m[0][q], m[1][q], kinf);
+            const f4 r = relu_med4(row_max16_transpose4(t[0], t[1], t[2], t[3]), kinf);
+            if (valid && (col & 3) == 0) *reinterpret_cast<f4 *>(o + 32 * ((col >> 4) & 1)) = r;
+        } else {
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const f4 r = relu_med4(row_max16_transpose4(m[v][0], m[v][1], m[v][2], m[v][3]), kinf);
+                if (valid && (col & 3) == 0) *reinterpret_cast<f4 *>(o + 32 * v) = r;
             }
+        }
     }
 }
 
