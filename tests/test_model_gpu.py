@@ -133,3 +133,77 @@ def test_full_forward_matches_reference_two_frames():
                 assert np.array_equal(indices1.cpu().numpy(), case[p + "indices1"])
             assert np.allclose([float(c) for c in confs], case[p + "confs"], atol=1e-4)
             objects_prev = {k: v.clone().detach() for k, v in objects.items()}
+
+
+def test_full_loss_train_step_matches_reference():
+    """ONE TRAINING ITERATION AFTER PRE-TRAINING, as the reference's epoch loop runs it (main_utils.py:127-156): net.train(), frame 0
+    through forward() (its objects, detached, become objects_prev), frame 1 through forward() with them, total = 0.5 L_sf + 0.5 L_trk +
+    L_seg through the 19-argument track_4d_loss (losses/loss.py:8-31,48-72), backward.  Fixture: the same iteration through the
+    imported reference (tools/make_golden.py full_loss_case): the three loss terms, the Affinity MLP's list, and EVERY parameter's
+    gradient tensor -- the tracking term's gradient reaches affinity.* directly and the backbone through the pooled object
+    descriptors (fd_layer.* / pn_head.*)."""
+    from _util import grad_sample, probe_vector
+    from ratrack_amd import loss as L
+    case = load_case("train_full_b1_n256")
+    sd = reference_state_dict(DEV)
+    sd["fd_layer.cp.linear.bias"] = sd["fd_layer.cp.linear.bias"] + 0.09          # tools/make_golden.py FORWARD_CLS_BIAS_SHIFT
+    net = Track4D(Args()).to(DEV)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    g = lambda fi, k: torch.from_numpy(case["f%d_in_%s" % (fi, k)]).to(DEV)
+    h = torch.zeros(5, 1, 128, device=DEV)
+    h, _, _, _, _, _, _, objects, _, _ = net(g(0, "pc1"), g(0, "pc2"), g(0, "feature1"), g(0, "feature2"), h, dict())
+    assert list(objects.keys()) == case["f0_object_ids"].tolist()
+    assert [objects[k].shape[2] for k in objects] == case["f0_object_sizes"].tolist()
+    objects_prev = {k: v.clone().detach() for k, v in objects.items()}
+    net.zero_grad()
+    h1, pc1_warp, cls, aff_list, aff_mat, indices1, confs, objects, _, objects_curr = net(
+        g(1, "pc1"), g(1, "pc2"), g(1, "feature1"), g(1, "feature2"), h.detach(), objects_prev)
+    assert [o.shape[2] for o in objects_curr] == case["f1_object_sizes_curr"].tolist()
+    assert_close(pc1_warp.detach().cpu().numpy(), case["f1_pc1_warp"], RTOL, "pc1_warp (train mode)")
+    assert np.abs(cls.detach().cpu().numpy() - case["f1_cls"]).max() < 1e-5
+    assert np.abs(aff_list.detach().cpu().numpy().reshape(-1) - case["aff_list"].reshape(-1)).max() < 1e-4
+    mp = {int(k): i for i, k in enumerate(case["prev_keys"])}
+    mc = {int(k): i for i, k in enumerate(case["curr_keys"])}
+    gt, gt_cls = g(1, "gt_warp"), torch.from_numpy(case["f1_gt_cls_used"]).to(DEV)
+    total, items = L.track_4d_loss(objects_prev, objects, mp, mc, None, None, None, g(1, "pc1"), g(1, "pc2"), pc1_warp, cls, gt, aff_list,
+                                   None, gt_cls, None, None, None, pretrain=False)
+    keys = [str(k) for k in case["loss_keys"]]
+    np.testing.assert_allclose([float(items[k]) for k in keys], case["loss_vals"], rtol=1e-4, atol=1e-6)
+    assert float(items["TrackingLoss"]) > 0.1
+    total.backward()
+    grads = {k: (None if p.grad is None else p.grad.detach().float().cpu().numpy()) for k, p in net.named_parameters()}
+    # per tensor: max|mine - reference| over the fixture's sampled elements / the reference tensor's largest element, and the
+    # whole-tensor probe product.  Parameters whose exact gradient is zero (a bias in front of a BatchNorm, the GRU under B = 1 batch
+    # statistics) carry rounding noise in the reference as well: below 1e-5 of the model's largest gradient element they only have
+    # to be noise here too.
+    names = [str(k) for k in case["grad_names"]]
+    gmax = max(float(np.abs(case["grad/" + k]).max()) for k, n in zip(names, case["grad_norms"]) if n >= 0)
+    live = []
+    for i, (k, n) in enumerate(zip(names, case["grad_norms"])):
+        gk = grads.get(k)
+        if n < 0:
+            assert gk is None or float(np.abs(gk).max()) == 0.0, "%s: dead parameter has a gradient" % k
+            continue
+        assert gk is not None, "%s: no gradient" % k
+        ref, mine = case["grad/" + k].astype(np.float64), grad_sample(gk)
+        if float(np.abs(ref).max()) <= 1e-5 * gmax:
+            assert float(np.abs(mine).max()) <= 1e-4 * gmax, (k, float(np.abs(mine).max()), gmax)
+            continue
+        full = np.asarray(gk, dtype=np.float64).ravel()
+        live.append(dict(name=k, e_ref=float(np.abs(mine - ref).max() / np.abs(ref).max()), probe=float((full * probe_vector(k, full.size)).sum()),
+                         ref_probe=float(case["grad_probes"][i]), ref_norm=float(n)))
+    assert len(live) > 150
+    for prefix in ("affinity.", "fd_layer.cp.", "fd_layer.", "pn_head."):
+        assert any(r["name"].startswith(prefix) for r in live), prefix
+    worst = sorted(live, key=lambda r: -r["e_ref"])[:5]
+    print("\nfull-loss train step: worst gradient tensors vs the reference: " + ", ".join("%s %.1e" % (r["name"], r["e_ref"]) for r in worst))
+    # per tensor max|a - b| / max|b| over the sampled elements; two fp32 evaluations of a ReLU / max-pool network differ by flipped
+    # decisions (tests/test_varn_train_gpu.py): every tensor within 1e-2, nine in ten within 3e-3, the median within 1e-3
+    err = np.array([r["e_ref"] for r in live])
+    for r in live:
+        assert r["e_ref"] <= 1e-2, (r["name"], r["e_ref"])
+        assert abs(r["probe"] - r["ref_probe"]) <= 2.5e-2 * r["ref_norm"], r
+    assert np.median(err) <= 1e-3 and np.quantile(err, 0.9) <= 3e-3, (np.median(err), np.quantile(err, 0.9))
+    aff = np.array([r["e_ref"] for r in live if r["name"].startswith("affinity.")])
+    assert aff.size >= 4 and aff.max() <= 2e-3, aff

@@ -12,8 +12,8 @@ net = Track4D(Args()).to(dev).eval()
 synth.fill_state_dict(net.state_dict())
 d = synth.make_frame_pairs(64, 256, 1000)
 t = [torch.from_numpy(d[k]).to(dev) for k in ("pc1", "pc2", "feature1", "feature2")] + [torch.zeros(5, 64, 128, device=dev)]
-FAM = {"cost_volume": ["rtk_cost_volume_split"], "sa_scale": ["rtk_sa_scale", "rtk_sa_scale_split"], "pointwise": ["rtk_pointwise_mlp"],
-       "patch+gru": ["rtk_patch_cost", "rtk_gru_step"]}
+FAM = {"cost_volume": ["rtk_cost_volume_split", "rtk_cost_volume_split_shared"], "sa_scale": ["rtk_sa_scale", "rtk_sa_scale_split"], "pointwise": ["rtk_pointwise_mlp"],
+       "patch+gru": ["rtk_patch_cost", "rtk_gru_step"], "fps": ["rtk_fps_centroids", "rtk_fps_relevel"]}
 orig = _lib.call
 def run(skip):
     names = set(sum((FAM[f] for f in skip), []))

@@ -30,8 +30,9 @@ def main():
     for k in range(8):
         d = synth.make_frame_pairs(B, N, 100 + k)
         batches.append([torch.from_numpy(d[x]).to(dev) for x in ("pc1", "pc2", "feature1", "feature2")])
+    h = torch.zeros(5, B, 128, device=dev)
     with torch.no_grad():
-        net.backbone(*batches[0], None)
+        net.backbone(*batches[0], h)
         eng = net._fused_engine()
 
         def run(depth, share):
@@ -39,19 +40,19 @@ def main():
             if share is not None:
                 fused.cv_shared_workgroups = lambda *args: share
             try:
-                pipe = fused.GraphPipeline(eng, (*batches[0], None), depth=depth)
+                pipe = fused.GraphPipeline(eng, (*batches[0], h), depth=depth)
             finally:
                 fused.cv_shared_workgroups = saved
             i = 0
             t0 = time.perf_counter()
             while time.perf_counter() - t0 < 0.4:
-                pipe.submit(*batches[i % 8], None); i += 1
+                pipe.submit(*batches[i % 8], h); i += 1
             pipe.drain(); torch.cuda.synchronize()
             n = 0
             t0 = time.perf_counter()
             while time.perf_counter() - t0 < a.seconds:
                 for _ in range(32):
-                    pipe.submit(*batches[i % 8], None); i += 1; n += 1
+                    pipe.submit(*batches[i % 8], h); i += 1; n += 1
             pipe.drain(); torch.cuda.synchronize()
             el = time.perf_counter() - t0
             return B * n / el, el / n * 1e3

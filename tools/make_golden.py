@@ -349,6 +349,63 @@ def forward_case(name, Track4D, args, rec, outdir):
 
 
 
+def full_loss_case(name, Track4D, args, ref_loss, outdir):
+    """Round 5: ONE TRAINING ITERATION AFTER PRE-TRAINING through the reference's forward() (main_utils.py:127-156, losses/loss.py:8-31,
+    48-72): net.train(), frame 0 forward (its objects become objects_prev, detached, as the epoch loop does), frame 1 forward with
+    them, total = 0.5 L_sf + 0.5 L_trk + L_seg (pretrain = False), backward.  L_trk is the BCE between the Affinity-MLP's list and the
+    identity-match matrix of the two GT mappings, so its gradient reaches the Affinity MLP and, through the pooled object
+    descriptors, the backbone.  The mappings are synthetic (GT key lists of the right lengths with two matching keys): the loss
+    reads nothing but their keys (losses/loss.py:52-66)."""
+    net = build_net(Track4D, args, train=True)
+    with torch.no_grad():
+        net.state_dict()["fd_layer.cp.linear.bias"].add_(FORWARD_CLS_BIAS_SHIFT)
+    frames = [synth.make_frame_pairs(1, 256, 20), synth.make_frame_pairs(1, 256, 21)]
+    out = {}
+    for fi, d in enumerate(frames):
+        for k, v in d.items():
+            out["f%d_in_%s" % (fi, k)] = v
+    t0 = {k: torch.from_numpy(v) for k, v in frames[0].items() if k != "gt_cls"}
+    h = torch.zeros(5, 1, 128)
+    h, _, cls0, _, _, _, _, objects, _, oc0 = net(t0["pc1"], t0["pc2"], t0["feature1"], t0["feature2"], h, dict())
+    objects_prev = {k: v.clone().detach() for k, v in objects.items()}
+    h = h.detach()
+    out["f0_object_ids"] = np.array(list(objects_prev.keys()), dtype=np.int64)
+    out["f0_object_sizes"] = np.array([objects_prev[k].shape[2] for k in objects_prev], dtype=np.int64)
+    d = frames[1]
+    t1 = {k: torch.from_numpy(v) for k, v in d.items() if k != "gt_cls"}
+    h1, pc1_warp, cls, aff_list, aff_mat, indices1, confs, objects, _, objects_curr = net(t1["pc1"], t1["pc2"], t1["feature1"], t1["feature2"],
+                                                                                          h, objects_prev)
+    n_prev, n_curr = len(objects_prev), len(objects_curr)
+    assert n_prev >= 2 and n_curr >= 2 and aff_list.numel() == n_prev * n_curr, (n_prev, n_curr, aff_list.shape)
+    prev_keys = [10 + i for i in range(n_prev)]
+    curr_keys = [10 + ((i + 1) % max(n_prev, n_curr)) if i < 3 else 500 + i for i in range(n_curr)]      # some keys match, at shifted places
+    mp = {k: i for i, k in enumerate(prev_keys)}
+    mc = {k: i for i, k in enumerate(curr_keys)}
+    gt = torch.from_numpy(d["gt_warp"])
+    gt_cls = torch.from_numpy(d["gt_cls"][0])
+    if int(gt_cls.sum()) == 0 or int((~gt_cls).sum()) == 0:      # (this synthetic pair has no moving GT point: label every third one, so that
+        gt_cls = torch.arange(gt_cls.numel()) % 3 == 0           # the segmentation term is defined)
+    out["f1_gt_cls_used"] = gt_cls.numpy()
+    total, items = ref_loss.track_4d_loss(objects_prev, objects, mp, mc, None, None, None, t1["pc1"], t1["pc2"], pc1_warp, cls, gt, aff_list,
+                                          None, gt_cls, None, None, None, pretrain=False)
+    keys = ["Loss", "SceneFlowLoss", "TrackingLoss", "SegLoss"]
+    out["loss_keys"] = np.array(keys)
+    out["loss_vals"] = np.array([float(items[k]) for k in keys], dtype=np.float64)
+    assert float(items["TrackingLoss"]) > 0
+    out["prev_keys"], out["curr_keys"] = np.array(prev_keys, dtype=np.int64), np.array(curr_keys, dtype=np.int64)
+    out["aff_list"] = npf(aff_list)
+    out["f1_cls"], out["f1_pc1_warp"] = npf(cls), npf(pc1_warp)
+    out["f1_object_sizes_curr"] = np.array([o.shape[2] for o in objects_curr], dtype=np.int64)
+    net.zero_grad()
+    total.backward()
+    grad_records([(k, p.grad) for k, p in net.named_parameters()], out)
+    np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
+    nz = sum(1 for k, p in net.named_parameters() if p.grad is not None and float(p.grad.abs().max()) > 0)
+    print("wrote %s: %d x %d affinities, losses %s, %d parameters with a gradient (affinity.*: %s)"
+          % (name, n_prev, n_curr, [round(float(items[k]), 5) for k in keys], nz,
+             [round(float(p.grad.norm()), 6) for k, p in net.named_parameters() if k.startswith("affinity") and p.grad is not None][:4]))
+
+
 # ------------------------------------------------------------------------------------------------
 # round 3: gradient tensors, a batch that reaches the split-bf16 training kernels, real frames
 # ------------------------------------------------------------------------------------------------
@@ -555,6 +612,8 @@ def main():
         "eval_b1_n256_dups": lambda: eval_case("eval_b1_n256_dups", special_cloud(256), Track4D, args, rec, mu, ref_main_utils, a.out),
         "train_b1_n256": lambda: train_case("train_b1_n256", synth.make_frame_pairs(1, 256, 1), Track4D, args, rec, mu, ref_loss, a.out),
         "forward_b1_n256": lambda: forward_case("forward_b1_n256", Track4D, args, rec, a.out),
+        # round 5: a training iteration with the tracking term (forward() in train mode, pretrain = False), gradients of every parameter
+        "train_full_b1_n256": lambda: full_loss_case("train_full_b1_n256", Track4D, args, ref_loss, a.out),
         # round 3: 8 x 256 = 2 048 query points -> the split-bf16 training kernels; gradient tensors; float64 arbiter
         "train_b8_n256": lambda: train_batch_case("train_b8_n256", synth.make_frame_pairs(8, 256, 11), ref, a.out),
         # the reference's shipped radar frames, N = 322 / 352 / 242, every pair with N1 != N2
