@@ -198,12 +198,13 @@ def test_full_loss_train_step_matches_reference():
         assert any(r["name"].startswith(prefix) for r in live), prefix
     worst = sorted(live, key=lambda r: -r["e_ref"])[:5]
     print("\nfull-loss train step: worst gradient tensors vs the reference: " + ", ".join("%s %.1e" % (r["name"], r["e_ref"]) for r in worst))
-    # per tensor max|a - b| / max|b| over the sampled elements; two fp32 evaluations of a ReLU / max-pool network differ by flipped
-    # decisions (tests/test_varn_train_gpu.py): every tensor within 1e-2, nine in ten within 3e-3, the median within 1e-3
+    # per tensor max|a - b| / max|b| over the sampled elements.  The fixture's frame pairs were chosen free of flipped ReLU / max-pool
+    # decisions (tools/make_golden.py full_loss_case), so the bounds are those of the flip-free real pairs of tests/test_varn_train_gpu.py
     err = np.array([r["e_ref"] for r in live])
+    print("   %d tensors: median %.1e, 90th percentile %.1e, max %.1e" % (len(live), np.median(err), np.quantile(err, 0.9), err.max()))
     for r in live:
-        assert r["e_ref"] <= 1e-2, (r["name"], r["e_ref"])
-        assert abs(r["probe"] - r["ref_probe"]) <= 2.5e-2 * r["ref_norm"], r
-    assert np.median(err) <= 1e-3 and np.quantile(err, 0.9) <= 3e-3, (np.median(err), np.quantile(err, 0.9))
+        assert r["e_ref"] <= 5e-3, (r["name"], r["e_ref"])
+        assert abs(r["probe"] - r["ref_probe"]) <= 1e-2 * r["ref_norm"], r
+    assert np.median(err) <= 5e-4 and np.quantile(err, 0.9) <= 2e-3, (np.median(err), np.quantile(err, 0.9))
     aff = np.array([r["e_ref"] for r in live if r["name"].startswith("affinity.")])
     assert aff.size >= 4 and aff.max() <= 2e-3, aff
