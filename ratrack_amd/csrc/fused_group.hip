@@ -744,18 +744,27 @@ __global__ __launch_bounds__(256, 5) void patch_cost_kernel(const PcParams P) {
         const float bop = g < 3 ? __fsub_rn(P.xyz[nb * 3 + g], P.xyz[i * 3 + g]) : 1.0f;
         const f4 t2 = weightnet_hidden(P.wn, lane, g, bop);
         const float *fr = P.feat + nb * P.feat_pitch + 4 * g;
+        // four 16-channel blocks at a time: their neighbour sums by ONE transposing reduction (fused_common.h: 32 cross-lane operations
+        // for the four instead of 4 x 16), lane j ends with block 4 vg + 2 (bit 3 of j) + (bit 2 of j) and the first lane of each quad
+        // stores.  (The whole row up front: 122 vs 71 us -- registers; the group loop stays rolled.)
+        const int vq = 2 * ((j >> 3) & 1) + ((j >> 2) & 1);
 #pragma unroll 1
-        for (int v = 0; v < CV_V; ++v) {
-            const f4 w = weightnet_out(P.wn, lane, g, v, t2);
-            const f4 f = *reinterpret_cast<const f4 *>(fr + 16 * v);      // (requesting the whole row up front: 122 vs 71 us -- registers)
-            f4 r = w * f;
-            row_sum16_f4(r);
-            if (j == 0) {
+        for (int vg = 0; vg < CV_V / 4; ++vg) {
+            f4 r[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f4 w = weightnet_out(P.wn, lane, g, 4 * vg + q, t2);
+                const f4 f = *reinterpret_cast<const f4 *>(fr + 16 * (4 * vg + q));
+                r[q] = w * f;                       // (a product the compiler sees: it places the wait states the MFMA result needs)
+            }
+            const f4 t = row_sum16_transpose4(r[0], r[1], r[2], r[3]);
+            if ((j & 3) == 0) {
+                const int v = 4 * vg + vq;
                 if (!P.out_cm) {
-                    *reinterpret_cast<f4 *>(P.out + i * P.out_pitch + 16 * v + 4 * g) = r;
+                    *reinterpret_cast<f4 *>(P.out + i * P.out_pitch + 16 * v + 4 * g) = t;
                 } else {
                     float *o = P.out + ((long)b * 256 + 16 * v + 4 * g) * P.n + (i - (long)b * P.n);
-                    o[0] = r.x; o[P.n] = r.y; o[2 * (long)P.n] = r.z; o[3 * (long)P.n] = r.w;
+                    o[0] = t.x; o[P.n] = t.y; o[2 * (long)P.n] = t.z; o[3 * (long)P.n] = t.w;
                 }
             }
         }

@@ -51,3 +51,15 @@ def test_launcher_invocation_as_the_driver_does():
 def test_single_process_dry_run():
     d = _run(["--dry-run", "--steps", "5", "--warmup", "1"])
     assert d["n_gpus"] == 1 and 0.9 <= d["ms_per_step"] <= 3.0
+
+
+def test_eight_rank_launch_as_the_driver_will_run_it():
+    """`bench.py --gpus 8` -- the configuration BASELINE.json's config 4 names and no round has had hardware for -- through its own
+    self-spawn path with eight gloo ranks: rendezvous, barrier, max over eight ranks, one JSON line whose value is the whole job's
+    (8 x 64 frame-pairs per step), per-rank spread reported.  (Rank r sleeps r + 1 ms per step: the slowest rank, 8 ms, is the step.)"""
+    d = _run(["--gpus", "8", "--steps", "5", "--warmup", "1", "--dry-run"])
+    assert d["n_gpus"] == 8 and d["steps"] == 5 and d["scaling"] == "weak"
+    assert 8.0 <= d["ms_per_step"] <= 14.0, d
+    assert d["per_rank_ms_per_step"]["min"] <= d["per_rank_ms_per_step"]["max"]
+    assert abs(d["value"] - 64 * 8 / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]
+    assert d["config"]["global_batch"] == 512
