@@ -3,6 +3,9 @@
 // executions while waves of other kernels issuing bf16 MFMAs shared its SIMD.
 //
 //   hipcc -O2 --offload-arch=gfx950 tools/micro/opsel_hazard.hip -o tools/micro/opsel_hazard.bin && tools/micro/opsel_hazard.bin
+//   (with the library's own kernels as noise -- what shared the SIMDs with the failing kernel in round 4:
+//    hipcc -O2 --offload-arch=gfx950 -DWITH_LIBRARY -Iinclude tools/micro/opsel_hazard.hip -Lratrack_amd/lib -lrtk_hip
+//          -Wl,-rpath,$PWD/ratrack_amd/lib -o tools/micro/opsel_hazard_lib.bin)
 //
 // Victim: one wave per workgroup runs ROUNDS rounds of a furthest-point-selection-like dependent chain (the loop of
 // fps_wave_body, ops_pointnet2.hip): read the current point o = (x, y, z, id) with ONE uniform ds_read_b128, take the squared
@@ -20,6 +23,9 @@
 // twins); mismatching workgroups are counted per launch, with and without the noise kernel (bf16 MFMA + LDS traffic, few
 // registers: its waves share SIMDs with the victim's) on a second stream.
 #include <hip/hip_runtime.h>
+#ifdef WITH_LIBRARY      // -DWITH_LIBRARY -Iinclude -Lratrack_amd/lib -lrtk_hip: the library's own split kernels as a third kind of noise
+#include "rtk_fused.h"
+#endif
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -235,15 +241,55 @@ __global__ __launch_bounds__(256) void noise_dma(const float4 *__restrict__ blob
 }
 static const float4 *g_blob = nullptr;
 
+#ifdef WITH_LIBRARY
+// Noise C: rtk_pointwise_mlp (128 -> 128 on 32 768 rows, split images) and rtk_sa_scale_split (128 clouds x 256 centroids x 32
+// neighbours, 64 -> 64) of the library itself, on zero-filled operands (the instruction streams do not depend on the data).
+struct LibNoise {
+    float *rows, *out, *bias, *xyz, *q, *w1, *inv;
+    void *img;
+    int *idx, *nu;
+    void init() {
+        CHECK(hipMalloc(&rows, 32768 * 128 * 4)); CHECK(hipMemset(rows, 0, 32768 * 128 * 4));
+        CHECK(hipMalloc(&out, 65536 * 128 * 4)); CHECK(hipMalloc(&bias, 1024 * 4)); CHECK(hipMemset(bias, 0, 1024 * 4));
+        CHECK(hipMalloc(&img, 1 << 20)); CHECK(hipMemset(img, 0, 1 << 20));
+        CHECK(hipMalloc(&xyz, 128 * 512 * 3 * 4)); CHECK(hipMemset(xyz, 0, 128 * 512 * 3 * 4));
+        CHECK(hipMalloc(&q, 128 * 512 * 64 * 4)); CHECK(hipMemset(q, 0, 128 * 512 * 64 * 4));
+        CHECK(hipMalloc(&w1, 4096 * 4)); CHECK(hipMemset(w1, 0, 4096 * 4));
+        CHECK(hipMalloc(&idx, 128 * 512 * 32 * 4)); CHECK(hipMemset(idx, 0, 128 * 512 * 32 * 4));
+        CHECK(hipMalloc(&nu, 128 * 4));
+        int h[128]; for (int i = 0; i < 128; ++i) h[i] = 256;
+        CHECK(hipMemcpy(nu, h, sizeof(h), hipMemcpyHostToDevice));
+        CHECK(hipMalloc(&inv, 16)); float one[4] = {1.f, 1.f, 1.f, 1.f}; CHECK(hipMemcpy(inv, one, 16, hipMemcpyHostToDevice));
+    }
+    void launch(hipStream_t st) {
+        rtk_src_t src = {rows, 128, 128, 0};
+        rtk_layer_t L = {reinterpret_cast<const float *>(img), bias, 8, 8, RTK_LAYER_SPLIT | 1, 1.0f};
+        for (int k = 0; k < 6; ++k) {
+            if (rtk_pointwise_mlp(32768, 256, nullptr, 1, &src, nullptr, 1, &L, out, 128, 128, 0, nullptr, nullptr, (rtk_stream_t)st) != 0) { printf("rtk_pointwise_mlp failed\n"); exit(1); }
+            if (rtk_sa_scale_split(128, 512, 512, 32, xyz, xyz, idx, q, 64, 64, w1, img, inv, bias, out, 128, 0, nu, nu, (rtk_stream_t)st) != 0) { printf("rtk_sa_scale_split failed\n"); exit(1); }
+        }
+    }
+};
+static LibNoise g_lib;
+#endif
+
 template <class Launch>
 static void campaign(const char *name, Launch launch, void *d_out, size_t bytes, const std::vector<unsigned char> &expect, int launches,
                      int groups, size_t per_group, hipStream_t sv, hipStream_t sn, float *d_noise, long execs_per_launch) {
     std::vector<unsigned char> got(bytes);
-    for (int with_noise = 0; with_noise < 3; ++with_noise) {
+#ifdef WITH_LIBRARY
+    const int kinds = 4;
+#else
+    const int kinds = 3;
+#endif
+    for (int with_noise = 0; with_noise < kinds; ++with_noise) {
         long bad_groups = 0, bad_launches = 0;
         for (int L = 0; L < launches; ++L) {
             if (with_noise == 1) noise<<<512, 256, 0, sn>>>(d_noise, 6000);
             if (with_noise == 2) noise_dma<<<1024, 256, 0, sn>>>(g_blob, d_noise, 1500);
+#ifdef WITH_LIBRARY
+            if (with_noise == 3) g_lib.launch(sn);
+#endif
             CHECK(hipMemsetAsync(d_out, 0, bytes, sv));
             launch(sv);
             CHECK(hipStreamSynchronize(sv));
@@ -255,7 +301,7 @@ static void campaign(const char *name, Launch launch, void *d_out, size_t bytes,
         }
         CHECK(hipDeviceSynchronize());
         printf("%-44s %-14s %3ld / %d launches differ, %6ld / %ld workgroups   (%.2e packed executions)\n", name,
-               with_noise == 2 ? "MFMA+DMA noise" : with_noise ? "MFMA noise" : "idle GPU", bad_launches, launches, bad_groups, (long)launches * groups,
+               with_noise == 3 ? "library kernels" : with_noise == 2 ? "MFMA+DMA noise" : with_noise ? "MFMA noise" : "idle GPU", bad_launches, launches, bad_groups, (long)launches * groups,
                (double)launches * execs_per_launch);
         fflush(stdout);
     }
@@ -278,6 +324,9 @@ int main(int argc, char **argv) {
     g_blob = d_blob;
     hipStream_t sv, sn;
     CHECK(hipStreamCreate(&sv)); CHECK(hipStreamCreate(&sn));
+#ifdef WITH_LIBRARY
+    g_lib.init();
+#endif
     // expected traces: FORM 0 on an idle GPU, three times (must agree with itself)
     std::vector<unsigned char> expect(tb), again(tb);
     for (int k = 0; k < 3; ++k) {
