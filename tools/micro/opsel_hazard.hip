@@ -16,6 +16,8 @@
 //   FORM 2  as 1 with `s_nop 7` between the read's wait and the packed op
 //   FORM 3  as 1 with the packed SUBTRACT replaced by v_pk_fma_f32 (x * 1 + (-o)), op_sel:[0,0,1]
 //   FORM 6  as 1 with the read's destination at v[98:101]: (x, y) in register banks 2, 3 like the v[14:15] of the failing build
+//   FORM 7  the odd half through v_pk_mul_f32 op_sel:[0,1];  FORM 8  the pair in the OTHER operand slot (op_sel:[1,0]);
+//   FORM 9  as 1 on a v_mov copy of the pair (not the LDS read's own destination)
 //   FORM 4  two-piece fp16 split of the lane's values: residual through v_fma_mix_f32 taking the HIGH half of a packed f16
 //           pair (op_sel on a 16-bit half -- the form the round-5 split layers would use), checked against the low-half form
 //   FORM 5  v_fma_mixlo_f16 / v_fma_mixhi_f16 residuals (what split_f16.h uses)
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(64) void victim(const float4 *__restrict__ clouds, 
             asm volatile("" : "+v"(ox), "+v"(oy), "+v"(oz));
 #pragma unroll
             for (int h = 0; h < 2; ++h) { dx[h] = x[h] - ox; dy[h] = y[h] - oy; dz[h] = z[h] - oz; }
-        } else if constexpr ((FORM >= 1 && FORM <= 3) || FORM == 6) {
+        } else if constexpr ((FORM >= 1 && FORM <= 3) || (FORM >= 6 && FORM <= 9)) {
             // the winner's coordinates stay where ds_read_b128 left them (v[100:103]); the packed ops select halves through op_sel
 #define PK(op, extra)                                                                                                         \
             asm volatile("ds_read_b128 v[100:103], %6\n s_waitcnt lgkmcnt(0)\n" extra                                            \
@@ -87,7 +89,44 @@ __global__ __launch_bounds__(64) void victim(const float4 *__restrict__ clouds, 
                          : "v100", "v101", "v102", "v103", "memory")
 #define OP_ADD(d, s, pair, sel) "v_pk_add_f32 %" #d ", %" #s ", " pair " " sel " neg_lo:[0,1] neg_hi:[0,1]\n"
             const f2 one = {1.0f, 1.0f};
-            if constexpr (FORM == 6) {
+            if constexpr (FORM == 7) {          // the odd half through v_pk_MUL_f32 op_sel:[0,1] (one * o.y, exact), then a plain packed subtract
+                f2 oy0, oy1;
+                asm volatile("ds_read_b128 v[100:103], %8\n s_waitcnt lgkmcnt(0)\n"
+                             "v_pk_add_f32 %0, %9, v[100:101] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             "v_pk_add_f32 %1, %10, v[100:101] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             "v_pk_mul_f32 %6, %15, v[100:101] op_sel:[0,1]\n"
+                             "v_pk_mul_f32 %7, %15, v[100:101] op_sel:[0,1]\n"
+                             "v_pk_add_f32 %4, %13, v[102:103] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             "v_pk_add_f32 %5, %14, v[102:103] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             "v_pk_add_f32 %2, %11, %6 neg_lo:[0,1] neg_hi:[0,1]\n"
+                             "v_pk_add_f32 %3, %12, %7 neg_lo:[0,1] neg_hi:[0,1]\n"
+                             : "=&v"(dx[0]), "=&v"(dx[1]), "=&v"(dy[0]), "=&v"(dy[1]), "=&v"(dz[0]), "=&v"(dz[1]), "=&v"(oy0), "=&v"(oy1)
+                             : "v"(addr), "v"(x[0]), "v"(x[1]), "v"(y[0]), "v"(y[1]), "v"(z[0]), "v"(z[1]), "v"(one)
+                             : "v100", "v101", "v102", "v103", "memory");
+            } else if constexpr (FORM == 8) {   // the pair as src0: v_pk_add_f32 d, -o, x op_sel:[1,0] (the other operand slot)
+                asm volatile("ds_read_b128 v[100:103], %6\n s_waitcnt lgkmcnt(0)\n"
+                             "v_pk_add_f32 %0, %7, v[100:101] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             "v_pk_add_f32 %1, %8, v[100:101] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             "v_pk_add_f32 %2, v[100:101], %9 op_sel:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n"
+                             "v_pk_add_f32 %3, v[100:101], %10 op_sel:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n"
+                             "v_pk_add_f32 %4, %11, v[102:103] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             "v_pk_add_f32 %5, %12, v[102:103] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             : "=&v"(dx[0]), "=&v"(dx[1]), "=&v"(dy[0]), "=&v"(dy[1]), "=&v"(dz[0]), "=&v"(dz[1])
+                             : "v"(addr), "v"(x[0]), "v"(x[1]), "v"(y[0]), "v"(y[1]), "v"(z[0]), "v"(z[1]), "v"(one)
+                             : "v100", "v101", "v102", "v103", "memory");
+            } else if constexpr (FORM == 9) {   // as 1, but the pair is a VALU COPY of the read's destination (is it the LDS return path?)
+                asm volatile("ds_read_b128 v[100:103], %6\n s_waitcnt lgkmcnt(0)\n"
+                             "v_mov_b32 v104, v100\n v_mov_b32 v105, v101\n v_mov_b32 v106, v102\n v_mov_b32 v107, v103\n s_nop 1\n"
+                             "v_pk_add_f32 %0, %7, v[104:105] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             "v_pk_add_f32 %1, %8, v[104:105] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             "v_pk_add_f32 %2, %9, v[104:105] op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             "v_pk_add_f32 %3, %10, v[104:105] op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             "v_pk_add_f32 %4, %11, v[106:107] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             "v_pk_add_f32 %5, %12, v[106:107] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+                             : "=&v"(dx[0]), "=&v"(dx[1]), "=&v"(dy[0]), "=&v"(dy[1]), "=&v"(dz[0]), "=&v"(dz[1])
+                             : "v"(addr), "v"(x[0]), "v"(x[1]), "v"(y[0]), "v"(y[1]), "v"(z[0]), "v"(z[1]), "v"(one)
+                             : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "memory");
+            } else if constexpr (FORM == 6) {
                 asm volatile("ds_read_b128 v[98:101], %6\n s_waitcnt lgkmcnt(0)\n"
                              "v_pk_add_f32 %0, %7, v[98:99] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
                              "v_pk_add_f32 %1, %8, v[98:99] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
@@ -115,7 +154,7 @@ __global__ __launch_bounds__(64) void victim(const float4 *__restrict__ clouds, 
             }
 #undef PK
         }
-        if constexpr (FORM <= 3 || FORM == 6) {
+        if constexpr (FORM <= 3 || (FORM >= 6 && FORM <= 9)) {
             unsigned mloc = 0u;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -241,6 +280,56 @@ __global__ __launch_bounds__(256) void noise_dma(const float4 *__restrict__ blob
 }
 static const float4 *g_blob = nullptr;
 
+// Noise by INGREDIENT: one instruction class per kernel, 8 waves per workgroup, few registers (they share SIMDs with the victim).
+//   0 plain v_fma_f32   1 v_pk_fma_f32 / v_pk_mul_f32 (no op_sel)   2 v_pk_mul_f32 op_sel_hi:[1,0] (the lo-half broadcast compilers emit)
+//   3 v_max_f32_dpp row_ror   4 v_mfma_f32_32x32x2_f32 (fp32-input MFMA)   5 v_cvt_pk_f16_f32 + v_fma_mixlo/hi   6 v_permlane32_swap
+//   7 ds_read_b128 + ds_write_b128 traffic   8 v_pk_add_f32 op_sel:[0,1] itself   9-12 v_mfma_f32_16x16x32_f16 with, on its results, v_pk_fma /
+//   v_fma / v_pk_mul (broadcast) / v_max3   13 v_readlane + v_writelane   14 v_exp_f32 + v_rcp_f32   15 global_load_dwordx4
+template <int KIND>
+__global__ __launch_bounds__(256) void noise_kind(float *out, int iters) {
+    __shared__ float4 s_w[1024];
+    for (int i = threadIdx.x; i < 1024; i += 256) s_w[i] = make_float4(1e-3f * i, 2e-3f * i, 1.f, 0.5f);
+    __syncthreads();
+    f2 a = {1.0f + threadIdx.x * 1e-6f, 0.5f}, b = {0.999f, 1.001f}, c = {0.f, 1e-9f};
+    f16v acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    unsigned u = threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if constexpr (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a.x) : "v"(b.x), "v"(c.y));
+            else if constexpr (KIND == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %2\n v_pk_mul_f32 %0, %0, %1" : "+v"(a) : "v"(b), "v"(c));
+            else if constexpr (KIND == 2) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(a) : "v"(b));
+            else if constexpr (KIND == 3) asm volatile("s_nop 1\n v_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(a.x));
+            else if constexpr (KIND == 4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            else if constexpr (KIND == 5) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2\n s_nop 1\n v_fma_mixlo_f16 %0, %1, 1.0, -%0 op_sel_hi:[0,0,1]\n"
+                                                       "v_fma_mixhi_f16 %0, %2, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(u) : "v"(a.x), "v"(a.y));
+            else if constexpr (KIND == 6) { auto r = __builtin_amdgcn_permlane32_swap(u, u + k, false, false); u = r[0] ^ r[1]; }
+            else if constexpr (KIND == 7) { float4 t = s_w[(threadIdx.x * 5 + it + k) & 1023]; t.x += 1.f; s_w[(threadIdx.x + 64 * k) & 1023] = t; }
+            else if constexpr (KIND == 8) asm volatile("v_pk_add_f32 %0, %0, %1 op_sel:[0,1]" : "+v"(a) : "v"(b));
+            else if constexpr (KIND >= 9 && KIND <= 12) {      // a 16-bit MFMA with VALU work on its RESULTS in the same wave (a layer + its epilogue)
+                typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+                h8 ha, hb;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) { ha[t] = (_Float16)(a.x + t); hb[t] = (_Float16)(b.y + k); }
+                f4 c4 = {acc[0], acc[1], acc[2], acc[3]};
+                c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, c4, 0, 0, 0);
+                if constexpr (KIND == 9) { f2 lo = {c4.x, c4.y}, hi = {c4.z, c4.w}; lo = __builtin_elementwise_fma(lo, b, c); hi = lo * hi; acc[0] = lo.x; acc[1] = lo.y; acc[2] = hi.x; acc[3] = hi.y; }
+                else if constexpr (KIND == 10) { acc[0] = __builtin_fmaf(c4.x, b.x, c.y); acc[1] = c4.y * b.y; acc[2] = c4.z; acc[3] = c4.w; }
+                else if constexpr (KIND == 11) { f2 lo = {c4.x, c4.y}; lo = lo * b.x; acc[0] = lo.x; acc[1] = lo.y; acc[2] = c4.z; acc[3] = c4.w; }      // op_sel_hi:[1,0] broadcast
+                else { acc[0] = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(c4.x), __builtin_fabsf(c4.y)), c4.z); acc[1] = c4.y; acc[2] = c4.z; acc[3] = c4.w; }
+            } else if constexpr (KIND == 13) { unsigned sv_ = __builtin_amdgcn_readlane(u, k) + 1; asm volatile("v_writelane_b32 %0, %1, 3" : "+v"(u) : "s"(sv_)); }
+            else if constexpr (KIND == 14) asm volatile("v_exp_f32 %0, %0\n v_rcp_f32 %0, %0" : "+v"(a.x));
+            else { float4 t = reinterpret_cast<const float4 *>(out)[(blockIdx.x * 256 + threadIdx.x + 1024 * (it * 8 + k)) & 0xfffff]; a.x += t.x; }      // 15: global loads
+        }
+    }
+    float sum = a.x + a.y + (float)u + s_w[threadIdx.x].x;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sum += acc[e];
+    if (sum == 12345.678f) out[0] = sum;
+}
+
 #ifdef WITH_LIBRARY
 // Noise C: rtk_pointwise_mlp (128 -> 128 on 32 768 rows, split images) and rtk_sa_scale_split (128 clouds x 256 centroids x 32
 // neighbours, 64 -> 64) of the library itself, on zero-filled operands (the instruction streams do not depend on the data).
@@ -261,35 +350,37 @@ struct LibNoise {
         CHECK(hipMemcpy(nu, h, sizeof(h), hipMemcpyHostToDevice));
         CHECK(hipMalloc(&inv, 16)); float one[4] = {1.f, 1.f, 1.f, 1.f}; CHECK(hipMemcpy(inv, one, 16, hipMemcpyHostToDevice));
     }
-    void launch(hipStream_t st) {
+    void launch(hipStream_t st, int which) {      // which: 1 = rtk_pointwise_mlp, 2 = rtk_sa_scale_split, 3 = both
         rtk_src_t src = {rows, 128, 128, 0};
         rtk_layer_t L = {reinterpret_cast<const float *>(img), bias, 8, 8, RTK_LAYER_SPLIT | 1, 1.0f};
         for (int k = 0; k < 6; ++k) {
-            if (rtk_pointwise_mlp(32768, 256, nullptr, 1, &src, nullptr, 1, &L, out, 128, 128, 0, nullptr, nullptr, (rtk_stream_t)st) != 0) { printf("rtk_pointwise_mlp failed\n"); exit(1); }
-            if (rtk_sa_scale_split(128, 512, 512, 32, xyz, xyz, idx, q, 64, 64, w1, img, inv, bias, out, 128, 0, nu, nu, (rtk_stream_t)st) != 0) { printf("rtk_sa_scale_split failed\n"); exit(1); }
+            if ((which & 1) && rtk_pointwise_mlp(32768, 256, nullptr, 1, &src, nullptr, 1, &L, out, 128, 128, 0, nullptr, nullptr, (rtk_stream_t)st) != 0) { printf("rtk_pointwise_mlp failed\n"); exit(1); }
+            if ((which & 2) && rtk_sa_scale_split(128, 512, 512, 32, xyz, xyz, idx, q, 64, 64, w1, img, inv, bias, out, 128, 0, nu, nu, (rtk_stream_t)st) != 0) { printf("rtk_sa_scale_split failed\n"); exit(1); }
         }
     }
 };
 static LibNoise g_lib;
 #endif
 
+struct Noise { const char *name; void (*launch)(hipStream_t, float *); };
+template <int KIND> static void launch_kind(hipStream_t st, float *d) { noise_kind<KIND><<<1024, 256, 0, st>>>(d, 2500); }
+static void launch_mfma(hipStream_t st, float *d) { noise<<<512, 256, 0, st>>>(d, 6000); }
+static void launch_dma(hipStream_t st, float *d) { noise_dma<<<1024, 256, 0, st>>>(g_blob, d, 1500); }
+#ifdef WITH_LIBRARY
+static void launch_lib(hipStream_t st, float *) { g_lib.launch(st, 3); }
+static void launch_lib_pw(hipStream_t st, float *) { g_lib.launch(st, 1); }
+static void launch_lib_sa(hipStream_t st, float *) { g_lib.launch(st, 2); }
+#endif
+static std::vector<Noise> g_noises;
+
 template <class Launch>
 static void campaign(const char *name, Launch launch, void *d_out, size_t bytes, const std::vector<unsigned char> &expect, int launches,
                      int groups, size_t per_group, hipStream_t sv, hipStream_t sn, float *d_noise, long execs_per_launch) {
     std::vector<unsigned char> got(bytes);
-#ifdef WITH_LIBRARY
-    const int kinds = 4;
-#else
-    const int kinds = 3;
-#endif
-    for (int with_noise = 0; with_noise < kinds; ++with_noise) {
+    for (size_t kind = 0; kind <= g_noises.size(); ++kind) {
         long bad_groups = 0, bad_launches = 0;
         for (int L = 0; L < launches; ++L) {
-            if (with_noise == 1) noise<<<512, 256, 0, sn>>>(d_noise, 6000);
-            if (with_noise == 2) noise_dma<<<1024, 256, 0, sn>>>(g_blob, d_noise, 1500);
-#ifdef WITH_LIBRARY
-            if (with_noise == 3) g_lib.launch(sn);
-#endif
+            if (kind > 0) g_noises[kind - 1].launch(sn, d_noise);
             CHECK(hipMemsetAsync(d_out, 0, bytes, sv));
             launch(sv);
             CHECK(hipStreamSynchronize(sv));
@@ -300,8 +391,8 @@ static void campaign(const char *name, Launch launch, void *d_out, size_t bytes,
             bad_launches += bad != 0;
         }
         CHECK(hipDeviceSynchronize());
-        printf("%-44s %-14s %3ld / %d launches differ, %6ld / %ld workgroups   (%.2e packed executions)\n", name,
-               with_noise == 3 ? "library kernels" : with_noise == 2 ? "MFMA+DMA noise" : with_noise ? "MFMA noise" : "idle GPU", bad_launches, launches, bad_groups, (long)launches * groups,
+        printf("%-44s %-30s %3ld / %d launches differ, %6ld / %ld workgroups   (%.2e packed executions)\n", name,
+               kind ? g_noises[kind - 1].name : "idle GPU", bad_launches, launches, bad_groups, (long)launches * groups,
                (double)launches * execs_per_launch);
         fflush(stdout);
     }
@@ -309,6 +400,32 @@ static void campaign(const char *name, Launch launch, void *d_out, size_t bytes,
 
 int main(int argc, char **argv) {
     const int launches = argc > 1 ? atoi(argv[1]) : 40, B = 2048;
+    // noises: argv[2] = comma list out of  mfma,dma,fma,pk,pksel,dpp,mfma32,f16,swap,lds,pkodd,mfmapk,mfmafma,mfmabc,mfmamax,lane,trans,gload,lib,libpw,libsa  (default: mfma,dma[,lib])
+    const char *sel = argc > 2 ? argv[2] : "mfma,dma,lib";
+    auto want = [&](const char *k) { const char *p = strstr(sel, k); return p && (p == sel || p[-1] == ',') && (p[strlen(k)] == 0 || p[strlen(k)] == ','); };
+    if (want("mfma")) g_noises.push_back({"bf16 MFMA + LDS reads", launch_mfma});
+    if (want("dma")) g_noises.push_back({"bf16 MFMA + LDS-DMA stream", launch_dma});
+    if (want("fma")) g_noises.push_back({"v_fma_f32", launch_kind<0>});
+    if (want("pk")) g_noises.push_back({"v_pk_fma_f32 / v_pk_mul_f32", launch_kind<1>});
+    if (want("pksel")) g_noises.push_back({"v_pk_mul_f32 op_sel_hi:[1,0]", launch_kind<2>});
+    if (want("dpp")) g_noises.push_back({"v_max_f32_dpp", launch_kind<3>});
+    if (want("mfma32")) g_noises.push_back({"v_mfma_f32_32x32x2_f32", launch_kind<4>});
+    if (want("f16")) g_noises.push_back({"v_cvt_pk_f16_f32 + v_fma_mix", launch_kind<5>});
+    if (want("swap")) g_noises.push_back({"v_permlane32_swap", launch_kind<6>});
+    if (want("lds")) g_noises.push_back({"ds_read_b128 / ds_write_b128", launch_kind<7>});
+    if (want("pkodd")) g_noises.push_back({"v_pk_add_f32 op_sel:[0,1]", launch_kind<8>});
+    if (want("mfmapk")) g_noises.push_back({"f16 MFMA -> v_pk_fma_f32 on it", launch_kind<9>});
+    if (want("mfmafma")) g_noises.push_back({"f16 MFMA -> v_fma_f32 on it", launch_kind<10>});
+    if (want("mfmabc")) g_noises.push_back({"f16 MFMA -> v_pk_mul bcast", launch_kind<11>});
+    if (want("mfmamax")) g_noises.push_back({"f16 MFMA -> v_max3_f32", launch_kind<12>});
+    if (want("lane")) g_noises.push_back({"v_readlane / v_writelane", launch_kind<13>});
+    if (want("trans")) g_noises.push_back({"v_exp_f32 / v_rcp_f32", launch_kind<14>});
+    if (want("gload")) g_noises.push_back({"global_load_dwordx4", launch_kind<15>});
+#ifdef WITH_LIBRARY
+    if (want("lib")) g_noises.push_back({"library: pointwise + sa_scale_split", launch_lib});
+    if (want("libpw")) g_noises.push_back({"library: rtk_pointwise_mlp (split)", launch_lib_pw});
+    if (want("libsa")) g_noises.push_back({"library: rtk_sa_scale_split", launch_lib_sa});
+#endif
     std::vector<float4> clouds((size_t)B * NPTS);
     unsigned s = 12345u;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)(s >> 8) / 16777216.0f; };
@@ -317,7 +434,7 @@ int main(int argc, char **argv) {
     CHECK(hipMalloc(&d_clouds, clouds.size() * sizeof(float4)));
     CHECK(hipMemcpy(d_clouds, clouds.data(), clouds.size() * sizeof(float4), hipMemcpyHostToDevice));
     const size_t tb = (size_t)B * ROUNDS * sizeof(int), tb2 = (size_t)B * 64 * sizeof(unsigned);
-    CHECK(hipMalloc(&d_trace, tb)); CHECK(hipMalloc(&d_tr2, tb2)); CHECK(hipMalloc(&d_noise, 4));
+    CHECK(hipMalloc(&d_trace, tb)); CHECK(hipMalloc(&d_tr2, tb2)); CHECK(hipMalloc(&d_noise, 16 << 20)); CHECK(hipMemset(d_noise, 0, 16 << 20));
     float4 *d_blob;
     CHECK(hipMalloc(&d_blob, 1024 * 64 * sizeof(float4)));
     CHECK(hipMemset(d_blob, 0x3c, 1024 * 64 * sizeof(float4)));
@@ -339,6 +456,9 @@ int main(int argc, char **argv) {
 #define VICTIM(F) [&](hipStream_t st) { victim<F><<<B, 64, 0, st>>>(d_clouds, d_trace); }
     campaign("0: broadcast copies, op_sel_hi:[1,0]", VICTIM(0), d_trace, tb, expect, launches, B, ROUNDS * sizeof(int), sv, sn, d_noise, ex);
     campaign("1: v_pk_add_f32 ... op_sel:[0,1]", VICTIM(1), d_trace, tb, expect, launches, B, ROUNDS * sizeof(int), sv, sn, d_noise, ex);
+    campaign("7: v_pk_mul_f32 ... op_sel:[0,1]", VICTIM(7), d_trace, tb, expect, launches, B, ROUNDS * sizeof(int), sv, sn, d_noise, ex);
+    campaign("8: v_pk_add_f32 (pair as src0) op_sel:[1,0]", VICTIM(8), d_trace, tb, expect, launches, B, ROUNDS * sizeof(int), sv, sn, d_noise, ex);
+    campaign("9: as 1 on a VALU copy of the pair", VICTIM(9), d_trace, tb, expect, launches, B, ROUNDS * sizeof(int), sv, sn, d_noise, ex);
     campaign("6: as 1, pair in banks 2,3 (v[98:99])", VICTIM(6), d_trace, tb, expect, launches, B, ROUNDS * sizeof(int), sv, sn, d_noise, ex);
     campaign("2: as 1, s_nop 7 after the wait", VICTIM(2), d_trace, tb, expect, launches, B, ROUNDS * sizeof(int), sv, sn, d_noise, ex);
     campaign("3: v_pk_fma_f32 ... op_sel:[0,0,1]", VICTIM(3), d_trace, tb, expect, launches, B, ROUNDS * sizeof(int), sv, sn, d_noise, ex);
