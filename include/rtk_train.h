@@ -104,9 +104,12 @@ RTK_EXPORT int rtk_sa_first_layer(int samples, int channels, int rows, int ns, i
                                   const float *dxyz, const float *wx, int wx_pitch, const float *row_weight, float *z, double *sums,
                                   rtk_stream_t stream);
 
-/* Weight gradients that are contractions over positions, on the split-bf16 matrix path (fp32 in, fp32 out, the error of an fp32
- * fmaf chain; csrc/train_gemm.hip):  out[i][j] = sum_{r < m} x[r][i] * y[r][j]  for up to four (x, y, out) jobs in one launch.
- * x, y (m, 256) fp32 row-major, 16-byte aligned; out 256 rows of out_pitch >= 256 floats, fully written.  workspace: at least
+/* Weight gradients that are contractions over positions, on the split matrix path (two fp16 pieces per operand, three products;
+ * fp32 in, fp32 out, the error of an fp32 fmaf chain; csrc/train_gemm.hip):  out[i][j] = sum_{r < m} x[r][i] * y[r][j]  for up to
+ * four (x, y, out) jobs in one launch.  The contraction runs over the rows, so an operand takes ONE power-of-two scale: x_amax /
+ * y_amax point at a float >= max |element| of the operand (the cost-volume training kernels emit them; rtk_absmax computes one for
+ * any tensor).  Elements far below the maximum keep an absolute precision of 2^-39 of it -- below one fp32 rounding of the sums they
+ * enter.  x, y (m, 256) fp32 row-major, 16-byte aligned; out 256 rows of out_pitch >= 256 floats, fully written.  workspace: at least
  * njobs * 65536 floats; with njobs * 65536 * (256 / njobs) floats the grid is one slab per CU (the slabs' partial blocks are summed
  * by a second kernel: deterministic).  Replaces the batched library GEMM of the cost volume's backward
  * (utils/model_utils/model_utils.py:177-183,226-231: the two 256 x 256 convolutions over N x 16 positions). */
@@ -114,8 +117,11 @@ typedef struct {
     const float *x, *y;
     float *out;
     int out_pitch;
+    const float *x_amax, *y_amax;
 } rtk_tn_job_t;
 RTK_EXPORT int rtk_tn_gemm256_split(int njobs, const rtk_tn_job_t *jobs, long m, float *workspace, long workspace_floats, rtk_stream_t stream);
+/* *amax = max(*amax, max |x[0 .. n)|): an unsigned maximum on the float bits (*amax zero-initialised, or a previous maximum). */
+RTK_EXPORT int rtk_absmax(const float *x, long n, float *amax, rtk_stream_t stream);
 
 /* Kernel images of live (trained) weights, all of an operator's matrices in ONE launch (the training path re-packs every step).
  * kind 0: fragment-major MFMA A-operand image of a (rows, cols) matrix, packed[u][v][16g+i][r] = W[16v+i][16u+4g+r], zero padded to
@@ -300,17 +306,18 @@ RTK_EXPORT int rtk_cost_volume_bwd(int samples, int n1, int n2, const float *xyz
 /* The same two operators with their 256 x 256 products on the split matrix path (rtk_fused.h, csrc/split_mfma.h): identical
  * arguments and tensor formats (activations, sign masks, gradients), except that the two layers arrive as split images with their
  * inverse scales -- forward: W2, W3 (rtk_pack_split_layer) + fp32 biases; backward: W3^T, W2^T (rtk_pack_split_layer with
- * transposed = 1 on the forward's weights) -- and that the backward builds its Wc^T operand itself (no wct_packed). */
+ * transposed = 1 on the forward's weights) -- and that the backward builds its Wc^T operand itself (no wct_packed).  act_amax / dz_amax (optional, [2] floats,
+ * ZERO-INITIALISED by the caller): the largest |element| of (a1, a2) / (dz3, dz2), folded in by the kernels for rtk_tn_gemm256_split. */
 RTK_EXPORT int rtk_cost_volume_split_train(int samples, int n1, int n2, const float *xyz1, const float *xyz2,
                                            const int64_t *knn_idx, const float *p1, const float *p2, const float *wd_packed,
                                            const void *split_images, const float *image_scales, const float *bias2,
                                            const float *bias3, const rtk_layer_t *wn, float *out, int out_pitch, float *a1, float *a2,
-                                           float *a3, void *mask1, void *mask2, rtk_stream_t stream);
+                                           float *a3, void *mask1, void *mask2, float *act_amax, rtk_stream_t stream);
 RTK_EXPORT int rtk_cost_volume_bwd_split(int samples, int n1, int n2, const float *xyz1, const float *xyz2,
                                          const int64_t *knn_idx, const void *split_images_t, const float *image_scales_t,
                                          const rtk_layer_t *wn, const float *dout, int dout_pitch, const float *a3, const void *mask1, const void *mask2,
                                          float *dz1, float *dz2, float *dz3, float *dq3, float *d4, float *dp1, float *dpd,
-                                         float *dt2, float *dbias_rows, rtk_stream_t stream);
+                                         float *dt2, float *dbias_rows, float *dz_amax, rtk_stream_t stream);
 
 /* Backward of rtk_patch_cost (rtk_fused.h; same forward arguments; feat point-major).  dout (samples*n, dout_pitch).
  * Outputs over the M = samples*n*16 positions: dxg (M,256) = dout * wn (optional; scatter it onto feat's rows with

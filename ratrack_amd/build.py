@@ -26,7 +26,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-
 # flags it is built with and checks: a file that starts to produce the form fails the lint and joins this list).  Cost of the flag on
 # these five: none measurable on the forward, +0.4 % on the train step; library-wide it cost 0.7 % of the forward (more spills in
 # the per-point kernels), which is why it is per file.
-NO_SLP = {"fused_split.hip", "train_conv.hip", "train_group.hip", "train_loss.hip", "train_optim.hip"}
+NO_SLP = {"fused_split.hip", "train_conv.hip", "train_gemm.hip", "train_group.hip", "train_loss.hip", "train_optim.hip"}
 
 
 def flags_for(src):

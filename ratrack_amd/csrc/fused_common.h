@@ -279,6 +279,7 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 struct LaneScale {
     float s;        // 2^k: max |x s| over the position's channels lies in [2^14, 2^15)   (fp16 overflows at 65520)
     float inv;      // 2^-k
+    unsigned mb;    // the bits of max |x| the scale was taken from
 };
 // from the bits of m = max |x| >= 0.  m = 0 or below 2^-112: k is clamped to 126 (everything scaled is then below 2^14 -- exact
 // all the same); m = inf: the scaled operand overflows to inf and the product is NaN, as non-finite as the reference's.
@@ -286,8 +287,17 @@ __device__ __forceinline__ LaneScale lane_scale_of(unsigned mbits) {
     const unsigned e = mbits >> 23;
     unsigned sf = 268u - e;
     sf = sf > 253u ? 253u : sf;
-    return LaneScale{__uint_as_float(sf << 23), __uint_as_float((254u - sf) << 23)};
+    return LaneScale{__uint_as_float(sf << 23), __uint_as_float((254u - sf) << 23), mbits};
 }
+// The largest |element| of a whole TENSOR, for the consumers that contract over POSITIONS and therefore need ONE scale per tensor
+// (train_gemm.hip): the producing kernels fold their lanes' maxima (LaneScale::mb) into a zero-initialised word -- one wave reduction
+// and one atomic per tile and layer; an unsigned maximum on the bits of non-negative floats: order-independent, deterministic.
+__device__ __forceinline__ void tensor_amax_update(float *amax, unsigned mb) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)mb, d, 64); mb = o > mb ? o : mb; }
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(amax), mb);
+}
+
 // max |.| over a lane's activations, two per instruction (v_max3_f32 with |.| source modifiers; a NaN operand is ignored by the
 // maximum and comes back through the product)
 template <int N>

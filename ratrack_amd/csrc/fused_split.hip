@@ -126,6 +126,7 @@ struct CvSplitParams {
     WnSplit wn;
     float *out;
     int out_pitch;
+    float *amax;                  // training kernels: [2] zero-initialised, the largest |element| of (a1, a2) -- forward -- / (dz3, dz2) -- backward
     float *sv1, *sv2, *sv3;       // training forward (SAVE): the three activations (positions, 256) ...
     uint2 *mk1, *mk2;             // ... and the sign masks of a1, a2 in the format of cost_volume_kernel<true> (fused_group.hip): word
                                   // (position, g), bit 4 v16 + r = [a[channel 16 v16 + 4 g + r] > 0]
@@ -417,6 +418,7 @@ void cost_volume_split_kernel(const CvSplitParams P) {
         f4 bq[2][8];
         // a1 goes out while it is being consumed; the next tile's first round of rows is requested; the bias arrives during the last k-step
         LaneScale sc = lane_scale32(h);
+        if (SAVE && P.amax) tensor_amax_update(P.amax, sc.mb);
         split_layer<0>(ws, h, sc.s, acc, SidePair<CvLayer2Side<SAVE>, BiasSide>{{StoreRowsSide{P.sv1, ro, valid}, CvRowsRequest(P.p2, rows, (int)nbn, 0, lane)},
                                                                               BiasSide{P.bias2 + 4 * hh, bq}});
         float c = sc.inv * wi2;
@@ -428,6 +430,7 @@ void cost_volume_split_kernel(const CvSplitParams P) {
             P.mk2[pos * 4 + 2 + hh] = m[1];
         }
         sc = lane_scale32(h);
+        if (SAVE && P.amax) tensor_amax_update(P.amax + 1, sc.mb);
         if (SAVE) split_layer<SPLIT_NF>(ws, h, sc.s, acc, SidePair<StoreRowsSide, BiasSide>{StoreRowsSide{P.sv2, ro, valid}, BiasSide{P.bias3 + 4 * hh, bq}});
         else split_layer<SPLIT_NF>(ws, h, sc.s, acc, BiasSide{P.bias3 + 4 * hh, bq});
         ws.sync();                                                   // wrap the stream to chunk 0
@@ -501,6 +504,7 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
     const CvSplitParams &P = Q.f;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), hh = lane >> 5, col = lane & 31, pp = col >> 4,
               j = col & 15;
+    const int jq = 2 * ((j >> 3) & 1) + ((j >> 2) & 1);               // the slot a lane holds after a transposing reduction of four
     for (int e = threadIdx.x; e < 128 * 64; e += 64 * SP_NW) {
         const int l = e & 63, st = e >> 6, o = l & 31, ch = 32 * (st >> 4) + 8 * ((st >> 2) & 3) + 4 * (l >> 5) + (st & 3);
         s_wct[e] = o < 8 ? P.wn.wc[((ch >> 4) * 64 + (o >> 2) * 16 + (ch & 15)) * 4 + (o & 3)] : 0.f;
@@ -554,6 +558,7 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
             const f16v w = wpre;                                     // block v + 1's four MFMAs and block v + 2's operands travel under block v
             if constexpr (v + 1 < SPLIT_VB) wpre = wn_pre(wk, hh, t2);
             if constexpr (v + 2 < SPLIT_VB) wk = wn_block(P.wn, v + 2, hh, col);
+            f4 zs[4];
             auto slot = [&](auto qc) {
                 constexpr int q = decltype(qc)::value, e = 4 * v + q;
                 const f4 a = h[e];
@@ -570,15 +575,15 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
                     dt2 = mfma_f32x2(s_wct[(16 * v + 4 * q + r) * 64 + lane], qq[r], dt2);
                 }
                 h[e] = z;
+                zs[q] = z;
                 if (valid) *cv_at(Q.dq3, ro + 32u * e) = qq;       // (dz3 goes out during the product that consumes it)
-                if (Q.dbrows) {                      // (uniform) per-query neighbour sum: the host's bias sum shrinks 16x
-                    f4 r = z;
-                    row_sum16_valu_f4(r);
-                    if (valid && j == 0) *reinterpret_cast<f4 *>(Q.dbrows + i * 512 + 32 * v + 8 * q + 4 * hh) = r;
-                }
             };
             slot(std::integral_constant<int, 0>{}); slot(std::integral_constant<int, 1>{});
             slot(std::integral_constant<int, 2>{}); slot(std::integral_constant<int, 3>{});
+            if (Q.dbrows) {                          // (uniform) per-query neighbour sums of the block's four slots by ONE transposing reduction
+                const f4 r = row_sum16_transpose4(zs[0], zs[1], zs[2], zs[3]);      // (fused_common.h: lane j ends with slot jq; the host's bias sum shrinks 16x)
+                if (valid && (j & 3) == 0) *reinterpret_cast<f4 *>(Q.dbrows + i * 512 + 32 * v + 8 * jq + 4 * hh) = r;
+            }
         };
         block_a(std::integral_constant<int, 0>{}); block_a(std::integral_constant<int, 1>{}); block_a(std::integral_constant<int, 2>{});
         block_a(std::integral_constant<int, 3>{}); block_a(std::integral_constant<int, 4>{}); block_a(std::integral_constant<int, 5>{});
@@ -587,22 +592,21 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
         // ---- da2 = W3^T dz3;  dz2 = da2 leaky'(z2) ----------------------------------------------------------------------------
         f16v acc[SPLIT_VB];
         LaneScale sc = lane_scale32(h);          // gradients span many orders of magnitude: the position's own scale is what keeps 22 bits
+        if (P.amax) tensor_amax_update(P.amax, sc.mb);
         split_layer<0>(ws, h, sc.s, acc, StoreRowsSide{Q.dz3, ro, valid});
         float c = sc.inv * wi3;
 #pragma unroll
-        for (int v = 0; v < SPLIT_VB; ++v)
+        for (int v = 0; v < SPLIT_VB; ++v) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f4 z = leaky_grad_bits4(acc_slot(acc, 4 * v + q) * c, split_mask_bits(m2, v, q));
-                h[4 * v + q] = z;
-                if (Q.dbrows) {
-                    f4 r = z;
-                    row_sum16_valu_f4(r);
-                    if (valid && j == 0) *reinterpret_cast<f4 *>(Q.dbrows + i * 512 + 256 + 32 * v + 8 * q + 4 * hh) = r;
-                }
+            for (int q = 0; q < 4; ++q) h[4 * v + q] = leaky_grad_bits4(acc_slot(acc, 4 * v + q) * c, split_mask_bits(m2, v, q));
+            if (Q.dbrows) {
+                const f4 r = row_sum16_transpose4(h[4 * v], h[4 * v + 1], h[4 * v + 2], h[4 * v + 3]);
+                if (valid && (j & 3) == 0) *reinterpret_cast<f4 *>(Q.dbrows + i * 512 + 256 + 32 * v + 8 * jq + 4 * hh) = r;
             }
+        }
         // ---- da1 = W2^T dz2;  dz1 = da1 leaky'(z1);  dp1 = sum over the 16 neighbours; per-query partials of dWd = dz1^T d -----
         sc = lane_scale32(h);
+        if (P.amax) tensor_amax_update(P.amax + 1, sc.mb);
         split_layer<SPLIT_NF>(ws, h, sc.s, acc, StoreRowsSide{Q.dz2, ro, valid});
         ws.sync();                                                   // wrap the stream to chunk 0
         c = sc.inv * wi2;
@@ -624,21 +628,23 @@ __global__ __launch_bounds__(64 * SP_NW) __attribute__((amdgpu_waves_per_eu(1, 1
                 dxn = __fsub_rn(P.xyz2[nbn * 3], P.xyz1[in_ * 3]); dyn = __fsub_rn(P.xyz2[nbn * 3 + 1], P.xyz1[in_ * 3 + 1]);
                 dzn = __fsub_rn(P.xyz2[nbn * 3 + 2], P.xyz1[in_ * 3 + 2]);
             }
+            // the block's four slots: dz1 out, then the neighbour sums of dz1 and of dz1 (x) d, each by ONE transposing reduction of the
+            // four slots (32 cross-lane operations instead of 64; lane j ends with slot jq and the first lane of each quad stores)
+            f4 r[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                f4 r = leaky_grad_bits4(acc_slot(acc, 4 * v + q) * c, split_mask_bits(m1, v, q));
-                if (valid) *cv_at(Q.dz1, ro + 32u * (4 * v + q)) = r;
-                f4 rx = r * dx, ry = r * dy, rz = r * dz;
-                row_sum16_valu_f4(r);
-                row_sum16_valu_f4(rx);
-                row_sum16_valu_f4(ry);
-                row_sum16_valu_f4(rz);
-                if (valid && j == 0) {
-                    *reinterpret_cast<f4 *>(dpr + 32 * v + 8 * q) = r;
-                    *reinterpret_cast<f4 *>(dpd + 32 * v + 8 * q) = rx;
-                    *reinterpret_cast<f4 *>(dpd + 256 + 32 * v + 8 * q) = ry;
-                    *reinterpret_cast<f4 *>(dpd + 512 + 32 * v + 8 * q) = rz;
-                }
+                r[q] = leaky_grad_bits4(acc_slot(acc, 4 * v + q) * c, split_mask_bits(m1, v, q));
+                if (valid) *cv_at(Q.dz1, ro + 32u * (4 * v + q)) = r[q];
+            }
+            const f4 s0 = row_sum16_transpose4(r[0], r[1], r[2], r[3]);
+            const f4 sx = row_sum16_transpose4(r[0] * dx, r[1] * dx, r[2] * dx, r[3] * dx);
+            const f4 sy = row_sum16_transpose4(r[0] * dy, r[1] * dy, r[2] * dy, r[3] * dy);
+            const f4 sz = row_sum16_transpose4(r[0] * dz, r[1] * dz, r[2] * dz, r[3] * dz);
+            if (valid && (j & 3) == 0) {
+                *reinterpret_cast<f4 *>(dpr + 32 * v + 8 * jq) = s0;
+                *reinterpret_cast<f4 *>(dpd + 32 * v + 8 * jq) = sx;
+                *reinterpret_cast<f4 *>(dpd + 256 + 32 * v + 8 * jq) = sy;
+                *reinterpret_cast<f4 *>(dpd + 512 + 32 * v + 8 * jq) = sz;
             }
         }
         pt = ptn; valid = validn; i = in_; dx = dxn; dy = dyn; dz = dzn;
@@ -797,7 +803,7 @@ static int cv_split_fill(const char *who, CvSplitParams &P, int samples, int n1,
     P.wsc = image_scales;
     P.wn.wa = wn[0].w_packed; P.wn.wb = wn[1].w_packed; P.wn.wc = wn[2].w_packed; P.wn.bb = wn[1].bias; P.wn.bc = wn[2].bias;
     P.p1 = P.p2 = P.wd = P.bias2 = P.bias3 = nullptr;
-    P.out = nullptr; P.out_pitch = 0; P.sv1 = P.sv2 = P.sv3 = nullptr; P.mk1 = P.mk2 = nullptr;
+    P.out = nullptr; P.out_pitch = 0; P.sv1 = P.sv2 = P.sv3 = nullptr; P.mk1 = P.mk2 = nullptr; P.amax = nullptr;
     const int groups = (n1 + 2 * SP_NW - 1) / (2 * SP_NW);
     // one workgroup per CU (the tile keeps the whole register file); the rest is looped.  (Measured and rejected: 2 or 4 queued
     // workgroups per CU to shorten the tail when other kernels of the pipelined batches hold CUs -- 1 to 1.5 % slower.)
@@ -812,7 +818,7 @@ static int cv_split_fill(const char *who, CvSplitParams &P, int samples, int n1,
 static int cv_split_forward(const char *who, int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
                             const float *p1, const float *p2, const float *wd_packed, const void *split_images, const float *image_scales,
                             const float *bias2, const float *bias3, const rtk_layer_t *wn, float *out, int out_pitch, float *a1, float *a2,
-                            float *a3, void *mask1, void *mask2, int workgroups, rtk_stream_t stream) {
+                            float *a3, void *mask1, void *mask2, float *amax, int workgroups, rtk_stream_t stream) {
     CvSplitParams P;
     dim3 grid;
     if (cv_split_fill(who, P, samples, n1, n2, xyz1, xyz2, knn_idx, split_images, image_scales, wn, grid) != RTK_OK) return RTK_ERR_INVALID;
@@ -823,7 +829,7 @@ static int cv_split_forward(const char *who, int samples, int n1, int n2, const 
     RTK_REQUIRE(!save || ((double)samples * n1 * 16.0 * 1024.0 < 4294967296.0), "%s: more than 4 GiB per saved activation (32-bit row "
                 "offsets): split the batch", who);
     P.p1 = p1; P.p2 = p2; P.wd = wd_packed; P.bias2 = bias2; P.bias3 = bias3; P.out = out; P.out_pitch = out_pitch;
-    P.sv1 = a1; P.sv2 = a2; P.sv3 = a3; P.mk1 = (uint2 *)mask1; P.mk2 = (uint2 *)mask2;
+    P.sv1 = a1; P.sv2 = a2; P.sv3 = a3; P.mk1 = (uint2 *)mask1; P.mk2 = (uint2 *)mask2; P.amax = amax;
     if (samples % 8 == 0) {      // flattened tiles (see the kernel): `workgroups` of them, a multiple of 8, at most one per tile
         const int tiles_x = (samples / 8) * ((n1 + 2 * SP_NW - 1) / (2 * SP_NW));
         int per_xcd = (workgroups > 0 ? workgroups : 256) / 8;
@@ -843,7 +849,7 @@ extern "C" int rtk_cost_volume_split(int samples, int n1, int n2, const float *x
                                      const float *image_scales, const float *bias2, const float *bias3, const rtk_layer_t *wn, float *out,
                                      int out_pitch, rtk_stream_t stream) {
     return cv_split_forward("cost_volume_split", samples, n1, n2, xyz1, xyz2, knn_idx, p1, p2, wd_packed, split_images, image_scales, bias2, bias3,
-                            wn, out, out_pitch, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream);
+                            wn, out, out_pitch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int rtk_cost_volume_split_shared(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
@@ -852,17 +858,17 @@ extern "C" int rtk_cost_volume_split_shared(int samples, int n1, int n2, const f
                                             float *out, int out_pitch, int workgroups, rtk_stream_t stream) {
     RTK_REQUIRE(workgroups >= 0, "cost_volume_split_shared: workgroups = %d", workgroups);
     return cv_split_forward("cost_volume_split_shared", samples, n1, n2, xyz1, xyz2, knn_idx, p1, p2, wd_packed, split_images, image_scales,
-                            bias2, bias3, wn, out, out_pitch, nullptr, nullptr, nullptr, nullptr, nullptr, workgroups, stream);
+                            bias2, bias3, wn, out, out_pitch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workgroups, stream);
 }
 
 extern "C" int rtk_cost_volume_split_train(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
                                            const float *p1, const float *p2, const float *wd_packed, const void *split_images,
                                            const float *image_scales, const float *bias2, const float *bias3, const rtk_layer_t *wn,
                                            float *out, int out_pitch, float *a1, float *a2, float *a3, void *mask1, void *mask2,
-                                           rtk_stream_t stream) {
+                                           float *act_amax, rtk_stream_t stream) {
     RTK_REQUIRE(a1 && a2 && a3 && mask1 && mask2, "cost_volume_split_train: null activation buffer");
     return cv_split_forward("cost_volume_split_train", samples, n1, n2, xyz1, xyz2, knn_idx, p1, p2, wd_packed, split_images, image_scales,
-                            bias2, bias3, wn, out, out_pitch, a1, a2, a3, mask1, mask2, 0, stream);
+                            bias2, bias3, wn, out, out_pitch, a1, a2, a3, mask1, mask2, act_amax, 0, stream);
 }
 
 extern "C" int rtk_cost_volume_bwd_split(int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
@@ -870,7 +876,7 @@ extern "C" int rtk_cost_volume_bwd_split(int samples, int n1, int n2, const floa
                                          int dout_pitch,
                                          const float *a3, const void *mask1, const void *mask2, float *dz1, float *dz2, float *dz3,
                                          float *dq3, float *d4, float *dp1, float *dpd, float *dt2, float *dbias_rows,
-                                         rtk_stream_t stream) {
+                                         float *dz_amax, rtk_stream_t stream) {
     CvSplitBwdParams Q;
     dim3 grid;
     if (cv_split_fill("cost_volume_bwd_split", Q.f, samples, n1, n2, xyz1, xyz2, knn_idx, split_images_t, image_scales_t, wn, grid) != RTK_OK)
@@ -881,6 +887,7 @@ extern "C" int rtk_cost_volume_bwd_split(int samples, int n1, int n2, const floa
     RTK_REQUIRE(dout_pitch % 4 == 0 && dout_pitch >= 256, "cost_volume_bwd_split: bad dout_pitch");
     Q.dout = dout; Q.dout_pitch = dout_pitch; Q.a3 = a3; Q.mk1 = (const uint2 *)mask1; Q.mk2 = (const uint2 *)mask2;
     Q.dz1 = dz1; Q.dz2 = dz2; Q.dz3 = dz3; Q.dq3 = dq3; Q.d4 = d4; Q.dp1 = dp1; Q.dpd = dpd; Q.dt2 = dt2; Q.dbrows = dbias_rows;
+    Q.f.amax = dz_amax;
     cost_volume_bwd_split_kernel<<<grid, 64 * SP_NW, 0, (hipStream_t)stream>>>(Q);
     RTK_CHECK_LAUNCH("cost_volume_bwd_split");
     return RTK_OK;

@@ -1,10 +1,16 @@
-// train_gemm.hip -- weight gradients that are contractions over POSITIONS, on the split-bf16 matrix path (split_mfma.h):
+// train_gemm.hip -- weight gradients that are contractions over POSITIONS, on the split matrix path (split_mfma.h; round 5: two fp16
+// pieces per operand and three products, rounds 3-4: three bf16 pieces and six):
 //
 //     out[i][j] = sum_{r < m} x[r][i] * y[r][j]        x, y (m, 256) fp32 row-major, m in the hundred thousands
 //
 // (the cost volume's dW2 = dz2^T a1 and dW3 = dz3^T a2: utils/model_utils/model_utils.py:177-183,226-231 in the backward; 34 GFLOP
 // each at B = 64).  The fp32-input MFMA runs at the vector rate (157 TFLOP/s) and a library GEMM sat at 0.89 of that; here every
-// fp32 product is six bf16 MFMA products of exact operand pieces, fp32 accumulate -- the error of an fp32 fmaf chain.
+// fp32 product is three fp16 MFMA products of two operand pieces each, fp32 accumulate -- the error of an fp32 fmaf chain.
+// Scales: the contraction index is the ROW, so an operand can only take ONE power of two for the whole tensor (a per-position scale,
+// what the layers use, would have to multiply the accumulators): 2^k with max|x| 2^k in [2^14, 2^15), from the tensor's largest
+// |element| which the producing kernels hand over (rtk_cost_volume_split_train / rtk_cost_volume_bwd_split fold it into a word per
+// tensor; rtk_absmax for anything else).  A row far below the tensor's largest keeps an ABSOLUTE precision of 2^-39 of that largest --
+// relative to the sums it enters (dominated by the large rows) below one fp32 rounding.
 //
 // Both operands are contiguous along the CHANNEL, the contraction runs along the row index: the MFMA wants, per lane, eight
 // consecutive k (= rows) of one channel.  The transposition happens on the way into LDS and costs nothing extra because the operands
@@ -27,36 +33,29 @@
 namespace {
 
 constexpr int TN_T = 256;
-constexpr int TN_STAGE = 2 * 3 * 2 * 256 * 16;      // bytes: [operand 2][piece 3][k half 2][slot 256][16]
+constexpr int TN_NP = 2;                             // pieces per operand (h, l)
+constexpr int TN_STAGE = 2 * TN_NP * 2 * 256 * 16;   // bytes: [operand 2][piece 2][k half 2][slot 256][16]
 constexpr int TN_MAX_JOBS = 4;
 
 struct TnParams {
     const float *x[TN_MAX_JOBS], *y[TN_MAX_JOBS];
     float *out[TN_MAX_JOBS];
     int out_pitch[TN_MAX_JOBS];
+    const float *xmax[TN_MAX_JOBS], *ymax[TN_MAX_JOBS];      // the operands' largest |element| (device words)
     float *partial;      // (njobs, nslabs, 256 slots, 256 slots)
     long m;
     int steps_per_slab, nslabs;
 };
 
-typedef float f2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2v trunc2(f2v x) {
-    const float a = trunc_bf16((float)x.x), b = trunc_bf16((float)x.y);
-    return f2v{a, b};
-}
-
-// one (operand, channel) unit of a k-step: channel c of the four rows a thread holds -> the three pieces of its four k, 8 bytes each
-// (the exact subtractions two at a time: v_pk_add_f32)
+// one (operand, channel) unit of a k-step: channel c of the four rows a thread holds -> the two fp16 pieces of its four scaled k,
+// 8 bytes each (split2_word: v_pk_mul_f32, v_cvt_pk_f16_f32, v_fma_mixlo_f16 / v_fma_mixhi_f16)
 template <int C>
-__device__ __forceinline__ void tn_split_store(char *stage, int operand, const f4 (&v)[4], int cq, int kq) {
-    const f2v a0 = {v[0][C], v[1][C]}, a1 = {v[2][C], v[3][C]};
-    const f2v r0 = a0 - trunc2(a0), r1 = a1 - trunc2(a1);      // exact
-    const f2v s0 = r0 - trunc2(r0), s1 = r1 - trunc2(r1);      // exact; at most 8 significant bits are left
+__device__ __forceinline__ void tn_split_store(char *stage, int operand, const f4 (&v)[4], float scale, int cq, int kq) {
+    const SplitWord w0 = split2_word(v[0][C], v[1][C], scale), w1 = split2_word(v[2][C], v[3][C], scale);
     const unsigned slot = (unsigned)(C * 64 + cq);
-    char *dst = stage + ((((unsigned)operand * 3u) * 2u + (unsigned)(kq >> 1)) * 256u + slot) * 16u + (unsigned)(kq & 1) * 8u;
-    *reinterpret_cast<uint2 *>(dst) = make_uint2(pack_hi16(a0.x, a0.y), pack_hi16(a1.x, a1.y));
-    *reinterpret_cast<uint2 *>(dst + 2 * 256 * 16) = make_uint2(pack_hi16(r0.x, r0.y), pack_hi16(r1.x, r1.y));
-    *reinterpret_cast<uint2 *>(dst + 4 * 256 * 16) = make_uint2(pack_hi16(s0.x, s0.y), pack_hi16(s1.x, s1.y));
+    char *dst = stage + ((((unsigned)operand * TN_NP) * 2u + (unsigned)(kq >> 1)) * 256u + slot) * 16u + (unsigned)(kq & 1) * 8u;
+    *reinterpret_cast<uint2 *>(dst) = make_uint2(w0.h, w1.h);
+    *reinterpret_cast<uint2 *>(dst + 2 * 256 * 16) = make_uint2(w0.l, w1.l);
 }
 
 __global__ __launch_bounds__(TN_T) void tn_gemm256_split_kernel(const TnParams Q) {
@@ -66,6 +65,7 @@ __global__ __launch_bounds__(TN_T) void tn_gemm256_split_kernel(const TnParams Q
     const int cq = lane, kq = __builtin_amdgcn_readfirstlane(wave);      // the rows a wave loads are uniform: scalar address arithmetic
     const int job = blockIdx.y, slab = blockIdx.x;
     const float *X = Q.x[job], *Y = Q.y[job];
+    const float sx = lane_scale_of(__float_as_uint(ldc(Q.xmax[job]))).s, sy = lane_scale_of(__float_as_uint(ldc(Q.ymax[job]))).s;
     const long m = Q.m;
     // the slabs are INTERLEAVED: workgroup `slab` takes the 16-row steps slab, slab + nslabs, slab + 2 nslabs, ...  The grid walks
     // its slabs in lockstep, so at any moment the 256 CUs stream one contiguous stretch of x and of y -- with contiguous slabs they
@@ -97,46 +97,46 @@ __global__ __launch_bounds__(TN_T) void tn_gemm256_split_kernel(const TnParams Q
     };
     // this wave's fragments of a stage: A = x slots 128 wa + 32 ib + i, B = y slots 128 wb + 32 jb + i; k half h
     const unsigned a_off = (unsigned)(h * 256 + 128 * wa + i) * 16u;
-    const unsigned b_off = (unsigned)((3 * 2 + h) * 256 + 128 * wb + i) * 16u;
+    const unsigned b_off = (unsigned)((TN_NP * 2 + h) * 256 + 128 * wb + i) * 16u;
     auto frag = [&](const char *stage, unsigned off, int piece, int blk) {
         return *reinterpret_cast<const u4v *>(stage + off + (unsigned)(piece * 2 * 256 + 32 * blk) * 16u);
     };
-    // One k-step: 4 row blocks x 6 products x 4 column blocks = 24 groups of four independent MFMAs (small terms first; a group keeps
+    // One k-step: 4 row blocks x 3 products x 4 column blocks = 12 groups of four independent MFMAs (small terms first; a group keeps
     // the matrix pipe busy for 128 cycles).  Between the groups, in their shadow: the eight split-and-store units of the NEXT step
     // (held in nx, ny since the step before) into the other stage, and -- as soon as an operand's four units are done -- the loads
     // of the step after that into the same registers.
     auto step = [&](const char *cur, char *nxt, f4 (&nx)[4], f4 (&ny)[4], int t) {
-        u4v bf[4][3], af[2][3];
+        u4v bf[4][TN_NP], af[2][TN_NP];
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[jb][p] = frag(cur, b_off, p, jb);
+            for (int p = 0; p < TN_NP; ++p) bf[jb][p] = frag(cur, b_off, p, jb);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) af[0][p] = frag(cur, a_off, p, 0);
+        for (int p = 0; p < TN_NP; ++p) af[0][p] = frag(cur, a_off, p, 0);
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib) {
             // one row block: 24 MFMAs with, between them, two split-and-store units, the next row block's fragments and (odd blocks)
             // the loads that refill the operand whose four units are done -- pinned one MFMA : three VALU (hipcc left alone issues the
             // MFMAs back to back and the wave waits at each for the pipe; everything else then runs behind them, unhidden)
-            const u4v(&A)[3] = af[ib & 1];
+            const u4v(&A)[TN_NP] = af[ib & 1];
             if (ib < 3) {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) af[(ib + 1) & 1][p] = frag(cur, a_off, p, ib + 1);
+                for (int p = 0; p < TN_NP; ++p) af[(ib + 1) & 1][p] = frag(cur, a_off, p, ib + 1);
             }
-#define TN_PRODUCT(pa, pb) _Pragma("unroll") for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = mfma_bf(A[pa], bf[jb][pb], acc[ib][jb]);
-            TN_PRODUCT(2, 0) TN_PRODUCT(1, 1) TN_PRODUCT(0, 2) TN_PRODUCT(1, 0) TN_PRODUCT(0, 1) TN_PRODUCT(0, 0)
+#define TN_PRODUCT(pa, pb) _Pragma("unroll") for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = mfma_h(A[pa], bf[jb][pb], acc[ib][jb]);
+            TN_PRODUCT(1, 0) TN_PRODUCT(0, 1) TN_PRODUCT(0, 0)
 #undef TN_PRODUCT
-            if (ib == 0) { tn_split_store<0>(nxt, 0, nx, cq, kq); tn_split_store<1>(nxt, 0, nx, cq, kq); }
-            if (ib == 1) { tn_split_store<2>(nxt, 0, nx, cq, kq); tn_split_store<3>(nxt, 0, nx, cq, kq); gload(RX, t + 5, nx); }
-            if (ib == 2) { tn_split_store<0>(nxt, 1, ny, cq, kq); tn_split_store<1>(nxt, 1, ny, cq, kq); }
-            if (ib == 3) { tn_split_store<2>(nxt, 1, ny, cq, kq); tn_split_store<3>(nxt, 1, ny, cq, kq); gload(RY, t + 5, ny); }
+            if (ib == 0) { tn_split_store<0>(nxt, 0, nx, sx, cq, kq); tn_split_store<1>(nxt, 0, nx, sx, cq, kq); }
+            if (ib == 1) { tn_split_store<2>(nxt, 0, nx, sx, cq, kq); tn_split_store<3>(nxt, 0, nx, sx, cq, kq); gload(RX, t + 5, nx); }
+            if (ib == 2) { tn_split_store<0>(nxt, 1, ny, sy, cq, kq); tn_split_store<1>(nxt, 1, ny, sy, cq, kq); }
+            if (ib == 3) { tn_split_store<2>(nxt, 1, ny, sy, cq, kq); tn_split_store<3>(nxt, 1, ny, sy, cq, kq); gload(RY, t + 5, ny); }
 #pragma unroll
-            for (int k = 0; k < 24; ++k) {
+            for (int k = 0; k < 12; ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                if (k < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                    // next block's fragments
-                if (k % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);               // a piece leaves
-                if ((ib & 1) && k >= 16 && k < 20) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // a row is requested
+                if (k < TN_NP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                // next block's fragments
+                if (k % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);               // a piece leaves
+                if ((ib & 1) && k >= 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // a row is requested
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -151,10 +151,10 @@ __global__ __launch_bounds__(TN_T) void tn_gemm256_split_kernel(const TnParams Q
     gload(RX, 2, x2); gload(RY, 2, y2);
     gload(RX, 3, x3); gload(RY, 3, y3);
     {
-        tn_split_store<0>(s_stage, 0, x0, cq, kq); tn_split_store<1>(s_stage, 0, x0, cq, kq);
-        tn_split_store<2>(s_stage, 0, x0, cq, kq); tn_split_store<3>(s_stage, 0, x0, cq, kq);
-        tn_split_store<0>(s_stage, 1, y0, cq, kq); tn_split_store<1>(s_stage, 1, y0, cq, kq);
-        tn_split_store<2>(s_stage, 1, y0, cq, kq); tn_split_store<3>(s_stage, 1, y0, cq, kq);
+        tn_split_store<0>(s_stage, 0, x0, sx, cq, kq); tn_split_store<1>(s_stage, 0, x0, sx, cq, kq);
+        tn_split_store<2>(s_stage, 0, x0, sx, cq, kq); tn_split_store<3>(s_stage, 0, x0, sx, cq, kq);
+        tn_split_store<0>(s_stage, 1, y0, sy, cq, kq); tn_split_store<1>(s_stage, 1, y0, sy, cq, kq);
+        tn_split_store<2>(s_stage, 1, y0, sy, cq, kq); tn_split_store<3>(s_stage, 1, y0, sy, cq, kq);
     }
     gload(RX, 4, x0); gload(RY, 4, y0);
     __syncthreads();
@@ -191,7 +191,20 @@ __global__ __launch_bounds__(256) void tn_gemm256_reduce_kernel(const TnParams Q
     for (; s < Q.nslabs; ++s) a[0] += P[(size_t)s * 65536];
     const int sa = e >> 8, sb = e & 255;
     const int ca = 4 * (sa & 63) + (sa >> 6), cb = 4 * (sb & 63) + (sb >> 6);
-    Q.out[job][(size_t)ca * Q.out_pitch[job] + cb] = (a[0] + a[1]) + (a[2] + a[3]);
+    const float c = lane_scale_of(__float_as_uint(ldc(Q.xmax[job]))).inv * lane_scale_of(__float_as_uint(ldc(Q.ymax[job]))).inv;      // exact: powers of two
+    Q.out[job][(size_t)ca * Q.out_pitch[job] + cb] = ((a[0] + a[1]) + (a[2] + a[3])) * c;
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, long n, float *__restrict__ amax) {
+    float m = 0.f;
+    const long n4 = n / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f4 t = reinterpret_cast<const f4 *>(x)[i];
+        m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(t.x)), __builtin_fabsf(t.y));
+        m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(t.z)), __builtin_fabsf(t.w));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - 4 * n4) m = __builtin_fmaxf(m, __builtin_fabsf(x[4 * n4 + threadIdx.x]));
+    tensor_amax_update(amax, __float_as_uint(m));
 }
 
 }  // namespace
@@ -202,7 +215,9 @@ extern "C" int rtk_tn_gemm256_split(int njobs, const rtk_tn_job_t *jobs, long m,
     for (int k = 0; k < njobs; ++k) {
         RTK_REQUIRE(jobs[k].x && jobs[k].y && jobs[k].out && jobs[k].out_pitch >= 256, "rtk_tn_gemm256_split: job %d incomplete", k);
         RTK_REQUIRE(((size_t)jobs[k].x & 15) == 0 && ((size_t)jobs[k].y & 15) == 0, "rtk_tn_gemm256_split: operands must be 16-byte aligned");
+        RTK_REQUIRE(jobs[k].x_amax && jobs[k].y_amax, "rtk_tn_gemm256_split: job %d without the operands' largest |element| (rtk_absmax)", k);
         Q.x[k] = jobs[k].x; Q.y[k] = jobs[k].y; Q.out[k] = jobs[k].out; Q.out_pitch[k] = jobs[k].out_pitch;
+        Q.xmax[k] = jobs[k].x_amax; Q.ymax[k] = jobs[k].y_amax;
     }
     // about one workgroup per CU, slabs of a multiple of four (>= 8) 16-row steps
     const long total = (m + 15) / 16;
@@ -223,5 +238,14 @@ extern "C" int rtk_tn_gemm256_split(int njobs, const rtk_tn_job_t *jobs, long m,
     RTK_CHECK_LAUNCH("rtk_tn_gemm256_split");
     tn_gemm256_reduce_kernel<<<dim3(256, njobs), 256, 0, s>>>(Q);
     RTK_CHECK_LAUNCH("rtk_tn_gemm256_split");
+    return RTK_OK;
+}
+
+extern "C" int rtk_absmax(const float *x, long n, float *amax, rtk_stream_t stream) {
+    RTK_REQUIRE(x && n > 0 && amax && ((size_t)x & 15) == 0, "rtk_absmax: bad arguments");
+    long blocks = (n / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    absmax_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(x, n, amax);
+    RTK_CHECK_LAUNCH("rtk_absmax");
     return RTK_OK;
 }

@@ -16,8 +16,8 @@ _LayerP = ctypes.POINTER(fused._Layer)
 _lib.SIGNATURES.update({
     "rtk_cost_volume_train": [_i] * 3 + [_p] * 6 + [_LayerP, _LayerP, _p, _i, _p, _p, _p, _p, _p, _p],
     "rtk_cost_volume_bwd": [_i] * 3 + [_p] * 3 + [_LayerP, _LayerP, _p, _p, _i] + [_p] * 12 + [_p],
-    "rtk_cost_volume_split_train": [_i] * 3 + [_p] * 10 + [_LayerP, _p, _i, _p, _p, _p, _p, _p, _p],
-    "rtk_cost_volume_bwd_split": [_i] * 3 + [_p] * 5 + [_LayerP, _p, _i] + [_p] * 12 + [_p],
+    "rtk_cost_volume_split_train": [_i] * 3 + [_p] * 10 + [_LayerP, _p, _i, _p, _p, _p, _p, _p, _p, _p],
+    "rtk_cost_volume_bwd_split": [_i] * 3 + [_p] * 5 + [_LayerP, _p, _i] + [_p] * 13 + [_p],
     "rtk_pack_split_layer": [_i, _i, _p, _i, _p, _p, _p],
     "rtk_scatter_add_rows": [_i] * 4 + [_p] * 3 + [_p],
     "rtk_sa_first_layer": [_i] * 6 + [_p] * 4 + [_i] + [_p] * 3 + [_p],
@@ -782,23 +782,32 @@ class _CvWeights:
 
 
 class _TnJob(ctypes.Structure):          # rtk_tn_job_t (include/rtk_train.h)
-    _fields_ = [("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("out", ctypes.c_void_p), ("out_pitch", ctypes.c_int)]
+    _fields_ = [("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("out", ctypes.c_void_p), ("out_pitch", ctypes.c_int),
+                ("x_amax", ctypes.c_void_p), ("y_amax", ctypes.c_void_p)]
 
 
-_lib.SIGNATURES.update({"rtk_tn_gemm256_split": [_i, ctypes.POINTER(_TnJob), ctypes.c_long, _p, ctypes.c_long, _p]})
+_lib.SIGNATURES.update({"rtk_tn_gemm256_split": [_i, ctypes.POINTER(_TnJob), ctypes.c_long, _p, ctypes.c_long, _p],
+                        "rtk_absmax": [_p, ctypes.c_long, _p, _p]})
 
 
 TN_MAX_ROWS = (1 << 22) - 16      # rtk_tn_gemm256_split addresses its operands through 32-bit buffer resources: m < 2^22 rows per launch
 
 
-def tn_gemm256(pairs):
+def tn_gemm256(pairs, amax=None):
     """[(x, y), ...] with x, y (m, 256) fp32 contiguous -> (len(pairs), 256, 256): x^T y of every pair in one launch on the
-    split-bf16 matrix path (rtk_tn_gemm256_split).  More than TN_MAX_ROWS rows (B * N1 * 16 positions: B = 64 at N = 4096) go in
-    row chunks whose products are added."""
+    split matrix path (rtk_tn_gemm256_split: two fp16 pieces per operand under ONE power-of-two scale per tensor).  amax: [(ax, ay), ...]
+    one-element CUDA float tensors >= the operands' largest |element| (the cost-volume kernels hand them over); None: rtk_absmax passes.
+    More than TN_MAX_ROWS rows (B * N1 * 16 positions: B = 64 at N = 4096) go in row chunks whose products are added."""
     n, m = len(pairs), pairs[0][0].shape[0]
     dev = pairs[0][0].device
     for x, y in pairs:
         assert x.shape == (m, 256) and y.shape == (m, 256) and x.is_contiguous() and y.is_contiguous() and x.dtype == y.dtype == torch.float32
+    if amax is None:
+        buf = torch.zeros(2 * n, dtype=torch.float32, device=dev)
+        for k, (x, y) in enumerate(pairs):
+            _lib.call("rtk_absmax", x.data_ptr(), x.numel(), buf[2 * k:].data_ptr(), _stream())
+            _lib.call("rtk_absmax", y.data_ptr(), y.numel(), buf[2 * k + 1:].data_ptr(), _stream())
+        amax = [(buf[2 * k:2 * k + 1], buf[2 * k + 1:2 * k + 2]) for k in range(n)]
     total = None
     for r0 in range(0, m, TN_MAX_ROWS):
         mc = min(TN_MAX_ROWS, m - r0)
@@ -806,6 +815,7 @@ def tn_gemm256(pairs):
         jobs = (_TnJob * n)()
         for k, (x, y) in enumerate(pairs):
             jobs[k].x, jobs[k].y, jobs[k].out, jobs[k].out_pitch = x[r0:].data_ptr(), y[r0:].data_ptr(), out[k].data_ptr(), 256
+            jobs[k].x_amax, jobs[k].y_amax = amax[k][0].data_ptr(), amax[k][1].data_ptr()
         steps = (mc + 15) // 16
         slabs = max(1, min(256 // n, (steps + 7) // 8))
         ws = torch.empty(n * slabs * 65536, dtype=torch.float32, device=dev)
@@ -832,11 +842,14 @@ class _CostVolume(torch.autograd.Function):
         # weight-gradient GEMMs read the same tensors
         acts = torch.empty(3, B * n1 * 16, 256, dtype=torch.float32, device=p1.device)
         masks = torch.empty(2, B * n1 * 16, 4, dtype=torch.int64, device=p1.device)          # sign bits of a1, a2 (kernel lane order)
+        # the largest |element| of a1, a2 (forward) and dz3, dz2 (backward), folded in by the kernels: the weight-gradient contraction
+        # over the positions takes ONE power-of-two scale per tensor (rtk_tn_gemm256_split)
+        ctx.amax = amax = arena_zeros(4, torch.float32, p1.device)
         if W.is_split:
             _lib.call("rtk_cost_volume_split_train", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
                       W.wd.data_ptr(), W.split.data_ptr(), W.split_scales.data_ptr(), W.b2.data_ptr(), W.b3.data_ptr(), W.wn, out.data_ptr(), 256,
                       acts[0].data_ptr(),
-                      acts[1].data_ptr(), acts[2].data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), _stream())
+                      acts[1].data_ptr(), acts[2].data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), amax.data_ptr(), _stream())
         else:
             _lib.call("rtk_cost_volume_train", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(),
                       W.wd.data_ptr(), W.layers, W.wn, out.data_ptr(), 256, acts[0].data_ptr(), acts[1].data_ptr(), acts[2].data_ptr(),
@@ -864,7 +877,8 @@ class _CostVolume(torch.autograd.Function):
         if W.is_split:
             _lib.call("rtk_cost_volume_bwd_split", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), W.split[2 * _SPLIT_IMAGE:].data_ptr(),
                       W.split_scales[2:].data_ptr(), W.wn, dout.data_ptr(), 256, a3.data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), dz1.data_ptr(), dz2.data_ptr(),
-                      dz3.data_ptr(), dq3.data_ptr(), d4.data_ptr(), dp1.data_ptr(), dpd.data_ptr(), dt2.data_ptr(), dbr.data_ptr(), _stream())
+                      dz3.data_ptr(), dq3.data_ptr(), d4.data_ptr(), dp1.data_ptr(), dpd.data_ptr(), dt2.data_ptr(), dbr.data_ptr(),
+                      ctx.amax[2:].data_ptr(), _stream())
         else:
             _lib.call("rtk_cost_volume_bwd", B, n1, n2, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), W.layers_t, W.wn, W.wct.data_ptr(),
                       dout.data_ptr(), 256, a3.data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), dz1.data_ptr(), dz2.data_ptr(), dz3.data_ptr(),
@@ -873,7 +887,8 @@ class _CostVolume(torch.autograd.Function):
         _lib.call("rtk_scatter_add_rows", B, n1 * 16, n2, 256, knn.data_ptr(), dz1.data_ptr(), dp2.data_ptr(), _stream())
         # weight gradients: contractions over the M positions, dW2 = dz2^T a1 and dW3 = dz3^T a2, in one launch on the split-bf16
         # matrix path (rtk_tn_gemm256_split; until round 3 a batched library GEMM on the fp32 pipe)
-        dw2, dw3 = tn_gemm256([(dz2, a1), (dz3, a2)]).unbind(0)
+        am = ctx.amax if W.is_split else None        # (a1, a2, dz3, dz2); the fp32-input comparison kernels emit none: rtk_absmax passes
+        dw2, dw3 = tn_gemm256([(dz2, a1), (dz3, a2)], None if am is None else [(am[3:4], am[0:1]), (am[2:3], am[1:2])]).unbind(0)
         db3, db2 = dbr.sum(0).split(256)
         dwd = dpd.sum(0).t()
         dwa, dba, dwb, dbb, dwc, dbc = _weightnet_backward(d4, dq3, dt2, wa, ba, wb, bb, wc)
@@ -913,7 +928,7 @@ def time_cost_volume_bwd(batch, n, dev, iters=10):
             _lib.call("rtk_cost_volume_bwd_split", B, n, n, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), W.split[2 * _SPLIT_IMAGE:].data_ptr(),
                       W.split_scales[2:].data_ptr(), W.wn, dout.data_ptr(), 256, acts[2].data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), big[0].data_ptr(),
                       big[1].data_ptr(), big[2].data_ptr(), big[3].data_ptr(), d4.data_ptr(), dp1.data_ptr(), dpd.data_ptr(), dt2.data_ptr(),
-                      dbr.data_ptr(), st)
+                      dbr.data_ptr(), None, st)
             return
         _lib.call("rtk_cost_volume_bwd", B, n, n, xyz1.data_ptr(), xyz2.data_ptr(), knn.data_ptr(), W.layers_t, W.wn, W.wct.data_ptr(),
                   dout.data_ptr(), 256, acts[2].data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), big[0].data_ptr(), big[1].data_ptr(),

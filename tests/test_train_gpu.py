@@ -628,11 +628,14 @@ def test_cost_volume_train_forward_keeps_what_the_backward_needs(B, N, split, mo
     common = (B, N, N, x1.data_ptr(), x2.data_ptr(), knn.data_ptr(), p1.data_ptr(), p2.data_ptr(), W.wd.data_ptr())
     common += (W.split.data_ptr(), W.split_scales.data_ptr(), W.b2.data_ptr(), W.b3.data_ptr(), W.wn) if split else (W.layers, W.wn)
     _lib.call("rtk_cost_volume_split" if split else "rtk_cost_volume", *common, out_a.data_ptr(), 256, st)
+    amax = torch.zeros(2, device=DEV)
     _lib.call("rtk_cost_volume_split_train" if split else "rtk_cost_volume_train", *common, out_b.data_ptr(), 256, acts[0].data_ptr(),
-              acts[1].data_ptr(), acts[2].data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), st)
+              acts[1].data_ptr(), acts[2].data_ptr(), masks[0].data_ptr(), masks[1].data_ptr(), *((amax.data_ptr(),) if split else ()), st)
     torch.cuda.synchronize()
     assert torch.equal(out_a, out_b)
     assert torch.isfinite(acts).all()
+    if split:      # the tensors' largest |element|, folded in by the kernel for the weight-gradient contraction's scales
+        assert float(amax[0]) == float(acts[0].abs().max()) and float(amax[1]) == float(acts[1].abs().max())
     # layer 1 from its definition: leaky(p1[i] + p2[nbr] + Wd d)   (the kernel's offset product is an MFMA: compare with a tolerance)
     nbr = (knn + (torch.arange(B, device=DEV) * N).view(B, 1, 1)).view(-1)
     dvec = (x2.reshape(B * N, 3)[nbr] - x1.reshape(B * N, 3).repeat_interleave(16, 0))
@@ -791,8 +794,8 @@ def test_weight_gradient_workspaces_of_any_size_give_the_same_sums():
 @pytest.mark.gpu
 @pytest.mark.parametrize("m", [1, 15, 16, 17, 1000, 4096, 5152, 40000])
 def test_position_contraction_on_the_split_path_carries_fp32_accuracy(m):
-    """rtk_tn_gemm256_split (the cost volume's two weight gradients, x^T y over m rows, six bf16 MFMA products per fp32 product)
-    against float64, with torch's fp32 GEMM as the yardstick; row counts that end inside a 16-row step, inside a thread's four rows,
+    """rtk_tn_gemm256_split (the cost volume's two weight gradients, x^T y over m rows, three fp16 MFMA products per fp32 product under one
+    power-of-two scale per tensor) against float64, with torch's fp32 GEMM as the yardstick; row counts that end inside a 16-row step, inside a thread's four rows,
     and slabs that are rounded up with empty steps (out-of-range rows must read as zero)."""
     from ratrack_amd import _lib, train_ops as T
     g = torch.Generator(DEV).manual_seed(m)
@@ -809,10 +812,20 @@ def test_position_contraction_on_the_split_path_carries_fp32_accuracy(m):
     ws = torch.empty(65536, device=DEV)
     job = (T._TnJob * 1)()
     job[0].x, job[0].y, job[0].out, job[0].out_pitch = x[1].data_ptr(), y[1].data_ptr(), big.data_ptr(), 300
+    am = torch.stack([x[1].abs().max(), y[1].abs().max()]).contiguous()
+    job[0].x_amax, job[0].y_amax = am[0:].data_ptr(), am[1:].data_ptr()
     _lib.call("rtk_tn_gemm256_split", 1, job, m, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
     assert float((big[:, :256] - ref[1]).abs().max()) / scale <= max(2.0 * err_lib, 3e-7)
     assert bool((big[:, 256:] == 7.0).all())
-    assert torch.equal(T.tn_gemm256([(x[0], y[0]), (x[1], y[1])]), out)      # no atomics: the same bits every time
+    assert torch.equal(T.tn_gemm256([(x[0], y[0]), (x[1], y[1])]), out)      # no float atomics: the same bits every time
+    # the scales are powers of two taken from the data: operands scaled by 2^k give the same bits times 2^k (1e-30 .. 1e+30 operands)
+    for k in (-100.0, 60.0):
+        out2 = T.tn_gemm256([(x[0] * 2.0 ** k, y[0] * 2.0 ** -k), (x[1] * 2.0 ** k, y[1])])
+        assert torch.equal(out2[0], out[0]) and torch.equal(out2[1], out[1] * 2.0 ** k)
+    # rtk_absmax: the largest |element| as an unsigned maximum on the bits
+    a = torch.zeros(1, device=DEV)
+    _lib.call("rtk_absmax", x.data_ptr(), x.numel(), a.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert float(a) == float(x.abs().max())
     with pytest.raises(_lib.RtkError):
         _lib.call("rtk_tn_gemm256_split", 1, job, m, ws.data_ptr(), 65535, torch.cuda.current_stream().cuda_stream)
 
