@@ -395,11 +395,15 @@ void cost_volume_split_kernel(const CvSplitParams P) {
         if (more) knn_next = (long)P.knn[in_ * 16 + j];
         // layer 1: leaky(p1[i] + p2[nb] + Wd.d)     (bias folded into p1)
         f4 h[32];
+        float t2[8];
         {
             const float b0 = hh ? dy : dx, b1 = hh ? 0.f : dz;      // B[k = hh][col] of the two k-steps (k = 3: the zero column)
             cv_rows_read<0>(rows, col, hh, h);
             cv_rows_request<1>(P.p2, (int)nb, rows, lane);
             cv_layer1_blocks<0, 4>(P, q0, q1, b0, b1, hh, col, kinf, h);
+            // the WeightNet's hidden layers (3 -> 8 -> 8: ~100 VALU instructions on the direction only) HERE, where the wave would
+            // otherwise wait for round 1 of the rows -- they used to open the output epilogue, exposed (8 registers across the layers)
+            wn_hidden(P.wn, dx, dy, dz, t2);
             __builtin_amdgcn_sched_barrier(0);      // (round 1's reads wait for the DMA: hipcc would hoist them, and the wait, above the four blocks)
             cv_rows_read<1>(rows, col, hh, h);
             cv_layer1_blocks<4, 8>(P, q0, q1, b0, b1, hh, col, kinf, h);
@@ -440,9 +444,7 @@ void cost_volume_split_kernel(const CvSplitParams P) {
 #pragma unroll
             for (int e = 0; e < 32; ++e) *cv_at(P.sv3, ro + 32u * e) = h[e];
         }
-        WnBlock wk = wn_block(P.wn, 0, hh, col);                     // block 0's operands travel during the hidden layers
-        float t2[8];
-        wn_hidden(P.wn, dx, dy, dz, t2);
+        WnBlock wk = wn_block(P.wn, 0, hh, col);
         // out[i] = sum over the 16 neighbours of relu(Wc.t2 + bc) * a3, one 32-channel block at a time; block v + 1's four
         // dependent MFMAs (K = 8 in steps of 2) run under block v's VALU / DPP work, block v + 2's operands travel meanwhile
         float *o = P.out + i * P.out_pitch + 4 * hh;
