@@ -99,7 +99,8 @@ def _pmc(kind, batch, n):
     """Fabric-side bytes per launch from the committed PMC passes (profiles/, same workload only)."""
     try:
         if batch == 64 and n == 256:
-            for name in (PMC[kind].replace("r02_", "r04_"), PMC[kind].replace("r02_", "r03_"), PMC[kind], PMC[kind].replace("r02_", "r01_")):
+            for name in (PMC[kind].replace("r02_", "r05_"), PMC[kind].replace("r02_", "r04_"), PMC[kind].replace("r02_", "r03_"), PMC[kind],
+                         PMC[kind].replace("r02_", "r01_")):
                 p = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(p):
                     d = json.load(open(p))
@@ -113,7 +114,7 @@ def _pmc(kind, batch, n):
 def _train_total_traffic(a):
     """HBM-side bytes of the whole train step from the committed all-kernel PMC pass (tools/pmc_train_total.py) and their ratio to
     SURVEY 8(d)'s 3 x forward algorithmic bytes."""
-    name = next((n for n in ("r04_pmc_train_total.json", "r03_pmc_train_total.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+    name = next((n for n in ("r05_pmc_train_total.json", "r04_pmc_train_total.json", "r03_pmc_train_total.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
     if a.batch != 64 or a.npoints != 256 or name is None:
         return {}
     p = os.path.join(ROOT, "profiles", name)

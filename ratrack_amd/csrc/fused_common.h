@@ -295,7 +295,10 @@ __device__ __forceinline__ LaneScale lane_scale_of(unsigned mbits) {
 __device__ __forceinline__ void tensor_amax_update(float *amax, unsigned mb) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)mb, d, 64); mb = o > mb ? o : mb; }
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(amax), mb);
+    // (a look first: after the first tiles the word rarely grows, and tens of thousands of atomics on ONE address serialise in L2 -- a
+    // stale look only costs an atomic that changes nothing)
+    if ((threadIdx.x & 63) == 0 && mb > __atomic_load_n(reinterpret_cast<unsigned *>(amax), __ATOMIC_RELAXED))
+        atomicMax(reinterpret_cast<unsigned *>(amax), mb);
 }
 
 // max |.| over a lane's activations, two per instruction (v_max3_f32 with |.| source modifiers; a NaN operand is ignored by the
