@@ -233,6 +233,35 @@ def map_gt_objects(gt_obj_centres, gt_objs, objects, rng=random):
     return mapping, mapping_inv
 
 
+# ---- one pass of the epoch loop, up to the network call ----------------------------------------------------------------------
+
+FramePairGT = namedtuple("FramePairGT", "pc1 pc2 feature1 feature2 pc1_compensated gt_flow gt_cls gt_objs objs_idx objs_centre gt_mov_pts "
+                                        "labels1 labels2")
+
+
+def frame_pair_gt(later, earlier, min_obj_points=2, device="cpu"):
+    """What the reference's epoch loop derives from the files of a frame pair before it calls the network (main_utils.py:66-122,
+    dataset_classes/track_vod_3d.py:98-119): the clouds and features of both frames, the ego-motion compensated later cloud, the
+    moving labels, the per-frame GT (`filter_object_points`; the loss and the mapping take the rider-merged, size-filtered object
+    sets, main_utils.py:118-120) and the GT warped positions (`gt_scene_flow`).
+    later / earlier: dict(radar=, radar_calib=, lidar_calib=, pose=, labels=) of file paths -- `labels` the detection-format label
+    file whose second column is the moving flag -- + tracking=<list of tracking-format label lines of the frame>."""
+    from . import vod_io
+    tfs = [FrameTransforms(f["radar_calib"], f.get("lidar_calib"), f.get("pose")) for f in (later, earlier)]
+    scans = [vod_io.load_radar_bin(f["radar"]) for f in (later, earlier)]
+    pc1, pc2, f1, f2 = vod_io.frame_pair_tensors(scans[0], scans[1], device=device)
+    comp = vod_io.compensate_ego_motion(scans[0][:, :3], ego_motion(tfs[0], tfs[1]))
+    pc1_comp = torch.from_numpy(np.ascontiguousarray(comp[:, :3].T.astype(np.float32))).unsqueeze(0).to(device)
+    labels = []
+    for f in (later, earlier):
+        with open(f["labels"], "r") as fh:
+            labels.append(filter_moving_labels(fh.read().splitlines(), parse_tracking_labels(f["tracking"])))
+    r1 = filter_object_points(min_obj_points, labels[0], pc1, tfs[0])
+    r2 = filter_object_points(min_obj_points, labels[1], pc2, tfs[1])
+    gt = gt_scene_flow(r2[4], r1[1], r1[5], pc1, pc1_comp, r1[6], r2[6])
+    return FramePairGT(pc1, pc2, f1, f2, pc1_comp, gt, r1[1], r1[7], r1[8], r1[9], r1[0], labels[0], labels[1])
+
+
 # ---- variable-N batches (SURVEY H7) --------------------------------------------------------------------------------------
 
 def pad_frame_pairs(pairs, device="cpu"):

@@ -143,3 +143,21 @@ def test_pad_frame_pairs():
         assert (pc1[b, :, n1:] == p[0][0, :, :1]).all() and (f1[b, :, n1:] == p[2][0, :, :1]).all()
     m = vod_gt.valid_mask(nv[0], 352)
     assert m.sum(1).tolist() == [322, 352, 242]
+
+
+def test_frame_pair_gt_matches_the_reference_epoch_loop_preamble():
+    """vod_gt.frame_pair_gt (files of a frame pair -> everything the epoch loop hands to the network, the mapping and the loss)
+    against tests/golden/train_gt_real.npz: the reference's get_gt_flow_new on the same files (tools/make_golden_gt.py --train)."""
+    g = np.load(os.path.join(GOLDEN, "train_gt_real.npz"), allow_pickle=False)
+    frame = lambda f: dict(radar=os.path.join(EX, "radar_%s.bin" % f), radar_calib=os.path.join(EX, "radar_calib_%s.txt" % f),
+                           lidar_calib=os.path.join(EX, "lidar_calib_%s.txt" % f), pose=os.path.join(EX, "pose_%s.json" % f),
+                           labels=os.path.join(EX, "label_%s.txt" % f), tracking=_tracking_lines(f))
+    for it, (later, earlier) in enumerate([("01047", "01201"), ("00549", "01047")]):
+        r = vod_gt.frame_pair_gt(frame(later), frame(earlier))
+        pre = "p%d_" % it
+        assert r.pc1.shape[2] != r.pc2.shape[2]
+        assert np.array_equal(r.gt_cls.numpy(), g[pre + "gt_cls"]) and 0 < int(r.gt_cls.sum()) < r.gt_cls.numel()
+        assert np.abs(r.pc1_compensated.numpy() - g[pre + "pc1_comp"]).max() <= 2e-5
+        assert np.abs(r.gt_flow.numpy() - g[pre + "gt"]).max() <= 2e-5
+        assert list(r.gt_objs.keys()) == g[pre + "gt_obj_ids"].tolist()
+        assert set(r.objs_idx) == set(r.gt_objs) == set(r.objs_centre)

@@ -101,7 +101,7 @@ def main():
         f, len(my_labels), int(res1[1].sum()), pc1.shape[2]))
 
 
-if __name__ == "__main__" and "--affinity" not in sys.argv:
+if __name__ == "__main__" and "--affinity" not in sys.argv and "--train" not in sys.argv:
     main()
 
 
@@ -122,3 +122,101 @@ def affinity_loss_golden():
 
 if __name__ == "__main__" and "--affinity" in sys.argv:
     affinity_loss_golden()
+
+
+# ---- round 5: the shipped frames -> labels -> GT -> one training iteration after pre-training ----------------------------------------
+GT_TRAIN_PAIRS = [("01047", "01201"), ("00549", "01047")]       # (later = pc1, earlier = pc2): iteration 0 supplies objects_prev / mappings_prev
+
+
+def frame_files(f):
+    return dict(radar=os.path.join(EX, "radar_%s.bin" % f), radar_calib=os.path.join(EX, "radar_calib_%s.txt" % f),
+                lidar_calib=os.path.join(EX, "lidar_calib_%s.txt" % f), pose=os.path.join(EX, "pose_%s.json" % f),
+                labels=os.path.join(EX, "label_%s.txt" % f), tracking=tracking_lines(f))
+
+
+def frame_gt(later, earlier, ref_tu):
+    """What one pass of the reference's epoch loop derives from the files of a frame pair before it calls the network
+    (main_utils.py:66-122), with the labels through the reference's Tracklet_3D / filter_moving_boxes_det and the GT flow through
+    its get_gt_flow_new (boxes handed over as (center, R) namespaces -- Open3D is absent, the point-in-box test is
+    ratrack_amd.vod_gt's).  The product's own path is ratrack_amd.vod_gt.frame_pair_gt."""
+    from dataset_classes.kitti.kitti_trk_vod import Tracklet_3D
+    tf1, tf2 = (vod_gt.FrameTransforms(os.path.join(EX, "radar_calib_%s.txt" % f), os.path.join(EX, "lidar_calib_%s.txt" % f),
+                                       os.path.join(EX, "pose_%s.json" % f)) for f in (later, earlier))
+    a = vod_io.load_radar_bin(os.path.join(EX, "radar_%s.bin" % later))
+    b = vod_io.load_radar_bin(os.path.join(EX, "radar_%s.bin" % earlier))
+    pc1, pc2, f1, f2 = vod_io.frame_pair_tensors(a, b)
+    comp = vod_io.compensate_ego_motion(a[:, :3], vod_gt.ego_motion(tf1, tf2))
+    pc1_comp = torch.from_numpy(np.ascontiguousarray(comp[:, :3].T.astype(np.float32))).unsqueeze(0)
+    lab = {}
+    for f in (later, earlier):
+        det = open(os.path.join(EX, "label_%s.txt" % f)).read().splitlines()
+        ref_lab = ref_tu.filter_moving_boxes_det(det, Tracklet_3D(tracking_lines(f), int(f)).data[int(f)])
+        mine = vod_gt.filter_moving_labels(det, vod_gt.parse_tracking_labels(tracking_lines(f)))
+        assert list(ref_lab.keys()) == list(mine.keys())
+        lab[f] = mine                # (same ids and values: tests/test_vod_gt_cpu.py test_labels_match_reference)
+    r1 = vod_gt.filter_object_points(2, lab[later], pc1, tf1)
+    r2 = vod_gt.filter_object_points(2, lab[earlier], pc2, tf2)
+    ns = lambda bx: types.SimpleNamespace(R=bx.R, center=bx.center)
+    gt = ref_tu.get_gt_flow_new(r1[4], r2[4], r1[1], r1[5], r2[5], pc1, pc1_comp, {k: ns(v) for k, v in r1[6].items()},
+                                {k: ns(v) for k, v in r2[6].items()})
+    return dict(pc1=pc1, pc2=pc2, f1=f1, f2=f2, pc1_comp=pc1_comp, gt=gt.float(), gt_cls=r1[1], gt_objs=r1[7], objs_idx=r1[8], objs_centre=r1[9],
+                gt_mov_pts=r1[0], lbl1=lab[later], lbl2=lab[earlier])
+
+
+def gt_train_case():
+    """tests/golden/train_gt_real.npz: TWO consecutive passes of the reference's epoch loop after pre-training (main_utils.py:66-156)
+    on the shipped frames -- files -> labels -> GT flow / gt_cls / GT objects -> net.train() forward() -> map_gt_objects ->
+    track_4d_loss(pretrain=False) -> backward -- the second pass with the first one's objects and mappings as objects_prev /
+    mappings_prev.  Recorded: the GT tensors, the mappings' keys, the loss items and every parameter's gradient of the second pass.
+    (The three shipped frames are not consecutive in time: the ego motion between them is tens of metres, so the GT warped
+    positions are far from the cloud and the scene-flow term is large; the arithmetic is the epoch loop's.)"""
+    rec, Track4D, args, mu, ref_loss, _ = MG.import_reference()
+    import models.utils.track4d_utils as TU
+    net = MG.build_net(Track4D, args, train=True)
+    with torch.no_grad():
+        net.state_dict()["fd_layer.cp.linear.bias"].add_(MG.FORWARD_CLS_BIAS_SHIFT)
+    out = {}
+    objects_prev, mappings_prev, h = dict(), dict(), None
+    for it, (later, earlier) in enumerate(GT_TRAIN_PAIRS):
+        g = frame_gt(later, earlier, TU)
+        mine = vod_gt.frame_pair_gt(frame_files(later), frame_files(earlier))
+        print("pass %d (%s, %s): %d / %d GT moving points, GT objects %s, |gt - pc1| max %.1f m, mine vs reference GT: %.2e"
+              % (it, later, earlier, int(g["gt_cls"].sum()), g["gt_cls"].numel(), sorted(g["gt_objs"].keys()),
+                 float((g["gt"] - g["pc1"]).abs().max()), float((g["gt"] - mine.gt_flow).abs().max())))
+        if h is None:
+            h = torch.zeros(5, 1, 128)
+        h, pc1_warp, cls, aff_list, aff_mat, assig, confs, objects, _, objects_curr = net(g["pc1"], g["pc2"], g["f1"], g["f2"], h, objects_prev)
+        random.seed(100 + it)
+        mappings_curr, mappings_inv = TU.map_gt_objects(g["objs_centre"], g["gt_objs"], objects)
+        total, items = ref_loss.track_4d_loss(objects_prev, objects, mappings_prev, mappings_curr, mappings_inv, g["lbl1"], g["lbl2"], g["pc1"],
+                                              g["pc2"], pc1_warp, cls, g["gt"], aff_list, g["gt_mov_pts"], g["gt_cls"], g["gt_objs"], g["objs_idx"],
+                                              g["objs_centre"], pretrain=False)
+        keys = ["Loss", "SceneFlowLoss", "TrackingLoss", "SegLoss"]
+        pre = "p%d_" % it
+        out[pre + "gt"], out[pre + "gt_cls"], out[pre + "pc1_comp"] = g["gt"].numpy(), g["gt_cls"].numpy(), g["pc1_comp"].numpy()
+        out[pre + "gt_obj_ids"] = np.array(list(g["gt_objs"].keys()), dtype=np.int64)
+        out[pre + "object_ids"] = np.array(list(objects.keys()), dtype=np.int64)
+        out[pre + "object_sizes"] = np.array([objects[k].shape[2] for k in objects], dtype=np.int64)
+        out[pre + "map_keys"] = np.array(list(mappings_curr.keys()), dtype=np.float64)
+        out[pre + "map_vals"] = np.array(list(mappings_curr.values()), dtype=np.int64)
+        out[pre + "loss_vals"] = np.array([float(items[k]) for k in keys], dtype=np.float64)
+        out[pre + "cls"], out[pre + "pc1_warp"] = MG.npf(cls), MG.npf(pc1_warp)
+        out[pre + "aff_list"] = MG.npf(aff_list) if torch.is_tensor(aff_list) else np.zeros(0, np.float32)
+        print("   objects %s (prev %d), mapping keys %s, losses %s" % (list(objects.keys()), len(objects_prev), list(mappings_curr.keys()),
+                                                                    [round(float(items[k]), 5) for k in keys]))
+        if it == len(GT_TRAIN_PAIRS) - 1:
+            assert float(items["TrackingLoss"]) > 0 and len(mappings_prev) > 0
+            net.zero_grad()
+            total.backward()
+            MG.grad_records([(k, p.grad) for k, p in net.named_parameters()], out)
+        objects_prev = {k: v.clone().detach() for k, v in objects.items()}
+        mappings_prev = mappings_curr
+        h = h.detach()
+    out["loss_keys"] = np.array(keys)
+    path = os.path.join(ROOT, "tests", "golden", "train_gt_real.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__" and "--train" in sys.argv:
+    gt_train_case()
