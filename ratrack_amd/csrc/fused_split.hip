@@ -817,6 +817,13 @@ static int cv_split_fill(const char *who, CvSplitParams &P, int samples, int n1,
     return RTK_OK;
 }
 
+// compute units of the current device (one workgroup of the cost-volume kernels per CU); 256 if the runtime does not say
+static int cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) return 256;
+    return n;
+}
+
 static int cv_split_forward(const char *who, int samples, int n1, int n2, const float *xyz1, const float *xyz2, const int64_t *knn_idx,
                             const float *p1, const float *p2, const float *wd_packed, const void *split_images, const float *image_scales,
                             const float *bias2, const float *bias3, const rtk_layer_t *wn, float *out, int out_pitch, float *a1, float *a2,
@@ -834,7 +841,7 @@ static int cv_split_forward(const char *who, int samples, int n1, int n2, const 
     P.sv1 = a1; P.sv2 = a2; P.sv3 = a3; P.mk1 = (uint2 *)mask1; P.mk2 = (uint2 *)mask2; P.amax = amax;
     if (samples % 8 == 0) {      // flattened tiles (see the kernel): `workgroups` of them, a multiple of 8, at most one per tile
         const int tiles_x = (samples / 8) * ((n1 + 2 * SP_NW - 1) / (2 * SP_NW));
-        int per_xcd = (workgroups > 0 ? workgroups : 256) / 8;
+        int per_xcd = (workgroups > 0 ? workgroups : cu_count()) / 8;
         if (per_xcd < 1) per_xcd = 1;
         if (per_xcd > tiles_x) per_xcd = tiles_x;
         P.gx = 8 * per_xcd;

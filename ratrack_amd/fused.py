@@ -570,6 +570,9 @@ class Geometry:
         return g
 
 
+CV_SPLIT_MAX_ROWS = 1 << 22      # rtk_cost_volume_split*: rows of p2 per launch (csrc/fused_split.hip)
+
+
 def cv_shared_workgroups(samples, n1, dev):
     """Workgroups for the forward cost volume when other batches are in flight (rtk_cost_volume_split_shared): at most 3/4 of the CUs,
     at least half, a multiple of 8 (a share per XCD), the largest count in that range that leaves the slowest workgroup no more than 5 %
@@ -801,11 +804,16 @@ class FusedBackbone:
         if _TRACE is not None:      # per (point, neighbour) pair: direction term, layers 2+3, WeightNet 3-8-8-256, weighted sum
             _TRACE.append(("cost_volume", B * N * 16, 3 * 256 + 2 * 256 * 256 + (3 * 8 + 8 * 8 + 8 * 256) + 256))
         if self.cv_split:
-            wgs = cv_shared_workgroups(B, N, x1.device) if self.cv_shared else 0
-            _lib.call("rtk_cost_volume_split_shared", B, N, N, x1.data_ptr(), x2.data_ptr(), knn1.data_ptr(), p1.data_ptr(), p2.data_ptr(),
-                      self.cv_wd.data_ptr(), self.cv_images.data_ptr(), self.cv_scales.data_ptr(), self.cv_bias23[0].data_ptr(),
-                      self.cv_bias23[1].data_ptr(),
-                      self.wn1.arr, cor1.data_ptr(), 256, wgs, _stream())
+            # the kernel requests the gathered p2 rows with 32-bit byte offsets: at most CV_SPLIT_MAX_ROWS rows of p2 per launch --
+            # larger batches go in slices of whole samples (the samples are independent)
+            step = B if B * N <= CV_SPLIT_MAX_ROWS else max(1, CV_SPLIT_MAX_ROWS // N)
+            for b0 in range(0, B, step):
+                nb = min(step, B - b0)
+                wgs = cv_shared_workgroups(nb, N, x1.device) if self.cv_shared else 0
+                r0 = b0 * N
+                _lib.call("rtk_cost_volume_split_shared", nb, N, N, x1[b0:].data_ptr(), x2[b0:].data_ptr(), knn1[b0:].data_ptr(), p1[r0:].data_ptr(),
+                          p2[r0:].data_ptr(), self.cv_wd.data_ptr(), self.cv_images.data_ptr(), self.cv_scales.data_ptr(),
+                          self.cv_bias23[0].data_ptr(), self.cv_bias23[1].data_ptr(), self.wn1.arr, cor1[r0:].data_ptr(), 256, wgs, _stream())
             return
         _lib.call("rtk_cost_volume", B, N, N, x1.data_ptr(), x2.data_ptr(), knn1.data_ptr(), p1.data_ptr(), p2.data_ptr(),
                   self.cv_wd.data_ptr(), self.cv_layers.arr, self.wn1.arr, cor1.data_ptr(), 256, _stream())

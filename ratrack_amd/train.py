@@ -90,7 +90,11 @@ class Trainer:
     def _optimize(self):
         self.reducer.unpack()
         self.opt.step()
-        # a graph replay re-runs the optimizer kernel but not FusedAdam.step's version bump: the folded eval engine goes here
+        self._invalidate_folded_engine()
+
+    def _invalidate_folded_engine(self):
+        """The parameters have just changed in place.  FusedAdam.step bumps their version counters when it runs eagerly; a graph
+        replay runs no Python at all -- neither that bump nor anything in _optimize -- so step() calls this after every replay."""
         inv = getattr(self.model, "invalidate_fused", None)
         if inv is not None:
             inv()
@@ -150,4 +154,5 @@ class Trainer:
         if self._g_opt is not None:
             self.reducer.all_reduce()
             self._g_opt.replay()
+        self._invalidate_folded_engine()
         return self._out

@@ -308,15 +308,12 @@ def drop_deferred_wgrads():
 def flush_deferred_wgrads():
     """Issue the queued weight gradients and hand them to their parameters.  Always ends the deferral.
     The queued gradients bypass autograd's accumulator, so tensor hooks / post-accumulate-grad hooks on those parameters would
-    never fire: refused here rather than silently skipped.  (Queued dz / source tensors stay alive until this call.)"""
+    never fire: refused when the gradient is queued (inside the backward, whose failure drops the queue: no half-finished step)
+    rather than silently skipped.  (Queued dz / source tensors stay alive until this call.)"""
     global _DEFERRED
     q, _DEFERRED = _DEFERRED, None
     if not q or not q["jobs"]:
         return
-    for param, _ in q["assign"]:
-        if param._backward_hooks or getattr(param, "_post_accumulate_grad_hooks", None):
-            raise RuntimeError("deferred weight gradients are delivered to .grad directly: gradient hooks on the per-point layers' "
-                               "parameters do not fire (run the backward outside begin_deferred_wgrads() to use hooks)")
     _run_wgrad_jobs(q["jobs"])
     for param, grad in q["assign"]:
         g = grad.view_as(param)
@@ -341,6 +338,10 @@ def _pw_backward(ctx_needs, srcs, cols, W, dz, want_bias, dW=None, owner=None):
         dbias = _zeros((Co,), torch.float32, dz.device) if want_bias else None
     deferred = _DEFERRED is not None and owner is not None and owner[0] is not None and (dbias is None or owner[1] is not None)
     if deferred:
+        for param in owner:
+            if param is not None and (param._backward_hooks or getattr(param, "_post_accumulate_grad_hooks", None)):
+                raise RuntimeError("deferred weight gradients are delivered to .grad directly: gradient hooks on the per-point layers' "
+                                   "parameters do not fire (run the backward outside begin_deferred_wgrads() to use hooks)")
         _DEFERRED["jobs"].append((dz, list(srcs), list(cols), dW, dbias))
         _DEFERRED["assign"].append((owner[0], dW))
         if dbias is not None:

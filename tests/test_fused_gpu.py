@@ -799,3 +799,25 @@ def test_cost_volume_on_a_share_of_the_cus_is_the_same_result(B, N):
     cus = torch.cuda.get_device_properties(DEV).multi_processor_count
     assert 0 < wgs <= cus * 3 // 4 and wgs % 8 == 0
     assert torch.equal(out[0], out[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,limit", [(8, 250, 3 * 250), (16, 64, 5 * 64 + 7), (3, 243, 243)])
+def test_cost_volume_in_slices_of_the_batch_is_the_same_result(B, N, limit, monkeypatch):
+    """The split cost volume requests its gathered rows with 32-bit byte offsets (2^22 rows of p2 per launch, csrc/fused_split.hip);
+    FusedBackbone._cost_volume cuts larger batches into slices of whole samples.  With the limit lowered so that a small batch is cut
+    (into 3 + 3 + 2, 5 + 5 + 5 + 1 and 1 + 1 + 1 samples): bit for bit the one-launch result, nothing written beyond the batch."""
+    net = _net()
+    eng = F.FusedBackbone(net)
+    torch.manual_seed(B * N)
+    x1, x2 = torch.randn(B, N, 3, device=DEV), torch.randn(B, N, 3, device=DEV)
+    p1, p2 = torch.randn(B * N, 256, device=DEV), torch.randn(B * N, 256, device=DEV)
+    k1 = PU.knn_point(16, x2, x1)
+    out = []
+    for lim in (F.CV_SPLIT_MAX_ROWS, limit):
+        monkeypatch.setattr(F, "CV_SPLIT_MAX_ROWS", lim)
+        o = torch.full((B * N + 4, 256), 7.0, device=DEV)
+        eng._cost_volume(B, N, x1, x2, k1, p1, p2, o)
+        assert torch.all(o[B * N:] == 7.0)
+        out.append(o[:B * N])
+    assert torch.equal(out[0], out[1])

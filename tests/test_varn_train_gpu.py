@@ -44,7 +44,7 @@ def no_framework_dense_layers():
 # Gradient tolerances against the reference's fp32 gradients, per tensor, as max|a - b| / max|b| over the sampled elements:
 # (every tensor, 90th percentile, median) PER FIXTURE.  Two fp32 evaluations of a ReLU / max-pool network differ by discrete events --
 # an activation within rounding of 0 has its mask flipped and that element's upstream gradient appears in / vanishes from a sum.
-# Measured (tools/grad_parity_report.py, profiles/r03_grad_parity.txt, round 4 re-run in profiles/r04_grad_parity.txt):
+# Measured (tools/grad_parity_report.py, profiles/r03_grad_parity.txt; the B = 64 step: profiles/r05_fullsize_grad_parity.txt):
 #   * real_1201_549, real_1047_1201: no decision flips -- this path is as close to the reference as the reference is to float64
 #     (max 4e-5 / 1e-4, median 9e-6 / 1e-5): held to 2e-4 / 5e-4 for every tensor;
 #   * real_549_1047: max 8e-4, median 1.5e-4 (small flips in the decoder's set-abstraction levels);
