@@ -279,7 +279,7 @@ def run_train(a, net, d, dev, dist, world, rank, steps, warmup, live_traffic=Non
     from ratrack_amd.train import Trainer
     broadcast_parameters(net)
     use_graph = not a.no_graph
-    tr = Trainer(net, graph=use_graph, graph_collective=a.graph_collective)
+    tr = Trainer(net, graph=use_graph, graph_collective=a.graph_collective, deterministic=a.deterministic)
     ds = d if isinstance(d, (list, tuple)) else [d]      # distinct resident batches, rotated through the steps
     ts = [{k: torch.from_numpy(v).to(dev) for k, v in x.items()} for x in ds]
     h = torch.zeros(5, a.batch, 128, device=dev)
@@ -344,6 +344,7 @@ def run_train(a, net, d, dev, dist, world, rank, steps, warmup, live_traffic=Non
             pass
         res = {"ms_per_step": round(ms_step, 3), "pairs_per_s": round(a.batch * world * steps / el, 1), "steps": steps,
                "hipGraph": ("one graph" if world == 1 or not tr.split else "graph | RCCL all-reduce | graph") if use_graph else False,
+               "deterministic": bool(a.deterministic),
                "kernels_per_step": kernels,
                "workload": "Track4D.backbone train step (fwd + multi-task loss + bwd + grad all-reduce + Adam), B=%d x N=%d per GPU, %d distinct "
                            "resident batches in rotation" % (a.batch, a.npoints, len(ts)),
@@ -484,6 +485,7 @@ def main():
     ap.add_argument("--traffic", choices=["auto", "profiles", "off"], default="auto",
                     help="roofline.traffic: auto = measure now with two rocprofv3 --pmc child passes when rocprofv3 is present, else take the "
                          "committed profiles/ value (and say so); profiles = always the committed value")
+    ap.add_argument("--deterministic", action="store_true", help="train legs: Trainer(deterministic=True) -- order-independent sums, bit-reproducible steps")
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
                     help="forward = the headline metric (eval backbone, fused kernels) with the train step embedded as `train`; "
                          "train = the train step (BASELINE config 3/4) as the headline line")
@@ -543,7 +545,8 @@ def main():
                    "config": {"workload": tr["workload"] + ", hipGraph=%s" % tr["hipGraph"], "global_batch": a.batch * world,
                               "parallelism": "dp%d, one flat RCCL all-reduce of %d bytes per step" % (world, tr["allreduce_bytes"])},
                    "roofline": tr["roofline"], "whole_step": tr["whole_step"],
-                   "train": {"hipGraph": tr["hipGraph"], "kernels_per_step": tr["kernels_per_step"], "allreduce_bytes": tr["allreduce_bytes"],
+                   "train": {"hipGraph": tr["hipGraph"], "deterministic": tr["deterministic"], "kernels_per_step": tr["kernels_per_step"],
+                             "allreduce_bytes": tr["allreduce_bytes"],
                              "allreduce_gradient_bytes": tr["allreduce_gradient_bytes"], "allreduce_us": tr["allreduce_us"]},
                    "per_rank_ms_per_step": tr["per_rank_ms_per_step"]}
             if world == 1 and not a.no_cpu_baseline:

@@ -33,11 +33,18 @@
 extern "C" {
 #endif
 
-/* Batch-statistic buffers ("sums", "sums2" below) are float64 arrays of RTK_STAT_SLOTS replicas, (RTK_STAT_SLOTS, groups, C, 2),
- * ZERO-INITIALISED by the caller: a producer's workgroups add their partial sums (float64 atomics) to the replica picked by
- * their sample index, the consumers add the replicas up in a fixed order.  One replica made every statistics epilogue a chain
- * of 64..256 serialised atomics on the same address (8..22 us per launch, more than the layers themselves at these sizes). */
+/* Batch-statistic buffers ("sums", "sums2" below) are (slots, groups, C, 2) float64 arrays, ZERO-INITIALISED by the caller and opaque
+ * to it.  BIT 0 OF THE POINTER handed to a producer / consumer selects how the sums are kept (the same tag for every call that
+ * touches one buffer):
+ *   0: slots = RTK_STAT_SLOTS.  float64 atomics into eight replicas picked by the producer's sample index (one replica made every
+ *      statistics epilogue a chain of 64..256 serialised atomics on the same address: 8..22 us per launch, more than the layers
+ *      themselves at these sizes); the consumers add the replicas up.  The sum depends on the order of arrival in its last bits.
+ *   1: slots = RTK_STAT_SLOTS_ORDERED.  ORDER-INDEPENDENT sums -- 90-bit fixed point in three 30-bit limbs kept as integers in
+ *      float64 words, so that every atomic addition is exact (csrc/rtk_common.h rtk_stat_add), five replicas + a word of flags: with
+ *      rtk_sa_first_layer_bwd's dwx_ws (the other operators have no order-dependent sums) a train step is reproducible bit for
+ *      bit, at 2-3 % of its time. */
 #define RTK_STAT_SLOTS 8
+#define RTK_STAT_SLOTS_ORDERED 16
 
 /* Weighted per-(group, channel) sums.  sums (RTK_STAT_SLOTS, groups, C, 2) float64, ZERO-INITIALISED by the caller:
  * [..,0] += sum w z, [..,1] += sum w z^2.  ns must be a power of two; row_weight may be NULL (all ones). */
@@ -141,7 +148,10 @@ RTK_EXPORT int rtk_pack_weights(int njobs, const rtk_pack_job_t *jobs, rtk_strea
  * the positions referencing point q at inv[s][off[s][q] .. off[s][q+1]), ascending.  rtk_sa_first_layer_bwd reads dz
  * (samples, C, rows, ns) once: dproj (samples, C, n_src) = gather-sum of dz over each point's positions (fully written);
  * dwx (C rows of dwx_pitch >= 3 floats, e.g. the first three columns of the layer's full weight gradient), ZERO-INITIALISED by
- * the caller, += sum dz . dxyz (dxyz (samples, 3, rows, ns)).  ns % 4 == 0. */
+ * the caller, += sum dz . dxyz (dxyz (samples, 3, rows, ns)).  ns % 4 == 0.  dproj is reproducible bit for bit (the segmented sums
+ * are accumulated in per-plane fixed point, csrc/train_group.hip fx_plane).  dwx_ws (optional): workspace of samples * C * 3 floats --
+ * every sample's share of dwx, added up in a fixed order by a second launch (reproducible, +5 us); NULL: the shares are added
+ * to dwx with float atomics in the order of arrival. */
 RTK_EXPORT int rtk_group_inverse_index(int samples, int n_src, int positions, const int *idx, int *off, unsigned short *inv,
                                        rtk_stream_t stream);
 /* The same for several tables in ONE launch (up to 12; every table over the same `samples` clouds): a table is one workgroup per
@@ -168,7 +178,7 @@ RTK_EXPORT int rtk_three_interpolate_grad_gather(int b, int c, int n, int m, con
                                                  const unsigned short *inv, float *grad_points, const int *n_valid, rtk_stream_t stream);
 RTK_EXPORT int rtk_sa_first_layer_bwd(int samples, int channels, int rows, int ns, int n_src, const float *dz, const float *dxyz,
                                       const int *off, const unsigned short *inv, float *dproj, float *dwx, int dwx_pitch,
-                                      rtk_stream_t stream);
+                                      float *dwx_ws, rtk_stream_t stream);
 
 /* ---- 1x1 convolution fused with the BatchNorm work around it (set-abstraction SharedMLP layers 2, 3) ----------------
  * Tensors are NCHW planes (samples, C, rows*ns), ns a power of two >= 4, channel counts 16, 32 or 64.
@@ -407,8 +417,9 @@ RTK_EXPORT int rtk_gmax_cat_bwd(int samples, int channels, int n, const float *d
 
 /* Multi-task loss of the backbone trainer (losses/loss.py:8-31,85-89,124-146, batch mean) and its gradients in one launch.
  * pc1, flow, gt_warp (B,3,N) contiguous; cls (B,N) probabilities; gt_cls uint8/bool, sample b's row at gt_cls + b*gt_cls_stride
- * (stride 0: one label vector for the whole batch).  items (4) fp32 ZERO-INITIALISED: += [Loss, SceneFlowLoss, TrackingLoss (left
- * 0), SegLoss].  dflow (B,3,N) / dcls (B,N) (optional): d Loss / d flow (not written while pre-training: the loss does not depend
+ * (stride 0: one label vector for the whole batch).  items (5 + 2 B) fp32 ZERO-INITIALISED: [0..3] = [Loss, SceneFlowLoss,
+ * TrackingLoss (left 0), SegLoss], [4] an arrival counter, [5..] the samples' shares -- summed sample 0 first by the last workgroup
+ * to arrive (reproducible bit for bit).  dflow (B,3,N) / dcls (B,N) (optional): d Loss / d flow (not written while pre-training: the loss does not depend
  * on the flow then) and d Loss / d cls.  n_valid (B) int32, optional: padded batch -- sample b consists of its first n_valid[b]
  * points; the padding columns enter no mean and get zero gradients. */
 RTK_EXPORT int rtk_backbone_loss(int b, int n, const float *pc1, const float *flow, const float *gt_warp, const float *cls,

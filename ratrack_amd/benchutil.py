@@ -121,8 +121,9 @@ def irregular_ops(batch, n, dev, npoint=512, iters=20, pmc=None):
     add("inverse_index_kernel", 6, ms, S_ * (rows * ns * 4 + rows * ns * 2 + (rows + 1) * 4),
         "positions sorted by gathered source row, largest table: %d centroids x %d neighbours" % (rows, ns))
     dz, dproj, dwx = torch.randn(S_, C, rows, ns, device=dev), f32(S_, C, rows), torch.zeros(C, 3, device=dev)
+    dwx_ws = f32(S_ * C, 3)
     ms = _time(lambda: _lib.call("rtk_sa_first_layer_bwd", S_, C, rows, ns, rows, dz.data_ptr(), dxyz3.data_ptr(), off.data_ptr(),
-                                 inv.data_ptr(), dproj.data_ptr(), dwx.data_ptr(), 3, st()), iters)
+                                 inv.data_ptr(), dproj.data_ptr(), dwx.data_ptr(), 3, dwx_ws.data_ptr(), st()), iters)
     add("sa_first_layer_bwd_kernel", 12, ms, S_ * (C * rows * ns * 4 + 3 * rows * ns * 4 + rows * ns * 2 + C * rows * 4),
         "first-layer backward (projection gradient + offset-weight gradient), largest SA shape: %d ch x %d centroids x %d neighbours"
         % (C, rows, ns))

@@ -82,9 +82,9 @@ __global__ __launch_bounds__(BN_T) void bn_stats_kernel(int samples, int channel
     }
     block_sum2(s, ss);
     if (threadIdx.x == 0) {
-        double *dst = rtk_stat_slot(sums, (size_t)groups * channels * 2, blockIdx.y) + ((size_t)p.g * channels + blockIdx.x) * 2;
-        atomicAdd(dst, s);
-        atomicAdd(dst + 1, ss);
+        const size_t o2 = ((size_t)p.g * channels + blockIdx.x) * 2;
+        rtk_stat_add<RTK_STAT_FORWARD>(sums, (size_t)groups * channels * 2, blockIdx.y, o2, s);
+        rtk_stat_add<RTK_STAT_FORWARD>(sums, (size_t)groups * channels * 2, blockIdx.y, o2 + 1, ss);
     }
 }
 
@@ -141,9 +141,9 @@ __global__ __launch_bounds__(BN_T) void sa_first_layer_kernel(int samples, int c
         double a = s[q], c = ss[q];
         block_sum2(a, c);
         if (threadIdx.x == 0) {
-            double *dst = rtk_stat_slot(sums, (size_t)groups * channels * 2, b) + ((size_t)grp * channels + c0 + q) * 2;
-            atomicAdd(dst, a);
-            atomicAdd(dst + 1, c);
+            const size_t o2 = ((size_t)grp * channels + c0 + q) * 2;
+            rtk_stat_add<RTK_STAT_FORWARD>(sums, (size_t)groups * channels * 2, b, o2, a);
+            rtk_stat_add<RTK_STAT_FORWARD>(sums, (size_t)groups * channels * 2, b, o2 + 1, c);
         }
         __syncthreads();      // block_sum2's LDS scratch is reused by the next channel
     }
@@ -268,9 +268,8 @@ __global__ __launch_bounds__(BN_T) void pool_bwd_stats_arg_kernel(int samples, i
     s = wave_sum_f64(s);
     sx = wave_sum_f64(sx);
     if (lane == 0) {
-        double *dst = rtk_stat_slot(sums2, GC * 2, b) + o * 2;
-        atomicAdd(dst, s);
-        atomicAdd(dst + 1, sx);
+        rtk_stat_add<RTK_STAT_BACKWARD>(sums2, GC * 2, b, o * 2, s);
+        rtk_stat_add<RTK_STAT_BACKWARD>(sums2, GC * 2, b, o * 2 + 1, sx);
     }
 }
 
@@ -301,9 +300,8 @@ __global__ __launch_bounds__(BN_T) void bn_relu_bwd_stats_kernel(int samples, in
     }
     block_sum2(s, sx);
     if (threadIdx.x == 0) {
-        double *dst = rtk_stat_slot(sums2, GC * 2, blockIdx.y) + o * 2;
-        atomicAdd(dst, s);
-        atomicAdd(dst + 1, sx);
+        rtk_stat_add<RTK_STAT_BACKWARD>(sums2, GC * 2, blockIdx.y, o * 2, s);
+        rtk_stat_add<RTK_STAT_BACKWARD>(sums2, GC * 2, blockIdx.y, o * 2 + 1, sx);
     }
 }
 
@@ -334,9 +332,8 @@ __global__ __launch_bounds__(BN_T) void bn_relu_pool_bwd_stats_kernel(int sample
     }
     block_sum2(s, sx);
     if (threadIdx.x == 0) {
-        double *dst = rtk_stat_slot(sums2, GC * 2, blockIdx.y) + o * 2;
-        atomicAdd(dst, s);
-        atomicAdd(dst + 1, sx);
+        rtk_stat_add<RTK_STAT_BACKWARD>(sums2, GC * 2, blockIdx.y, o * 2, s);
+        rtk_stat_add<RTK_STAT_BACKWARD>(sums2, GC * 2, blockIdx.y, o * 2 + 1, sx);
     }
 }
 
@@ -399,9 +396,8 @@ __global__ __launch_bounds__(BN_T) void bn_relu_bwd_stats_small_kernel(int sampl
     s = wave_sum_f64(s);
     sx = wave_sum_f64(sx);
     if (lane == 0) {
-        double *dst = rtk_stat_slot(sums2, GC * 2, b) + o * 2;
-        atomicAdd(dst, s);
-        atomicAdd(dst + 1, sx);
+        rtk_stat_add<RTK_STAT_BACKWARD>(sums2, GC * 2, b, o * 2, s);
+        rtk_stat_add<RTK_STAT_BACKWARD>(sums2, GC * 2, b, o * 2 + 1, sx);
     }
 }
 
@@ -417,13 +413,21 @@ __global__ __launch_bounds__(BN_T) void bn_relu_bwd_apply_small_kernel(int sampl
     const float mean = par[o], rstd = par[GC + o], sc = par[2 * GC + o], sh = par[3 * GC + o];
     float c1 = 0.f, c2 = 0.f;
     if (lane == 0) {
-        c1 = (float)(rtk_stat_read(sums2, GC * 2, o * 2) / count);
-        c2 = (float)(rtk_stat_read(sums2, GC * 2, o * 2 + 1) / count);
+        {
+            double v0_, v1_;
+            rtk_stat_read2<RTK_STAT_BACKWARD>(sums2, GC * 2, o * 2, v0_, v1_);
+            c1 = (float)(v0_ / count);
+            c2 = (float)(v1_ / count);
+        }
         if (dgb && b == 0) {                                       // parameter gradients: sum over the groups
             double db = 0.0, dg = 0.0;
             for (int gg = 0; gg < groups; ++gg) {
-                db += rtk_stat_read(sums2, GC * 2, ((size_t)gg * channels + c) * 2);
-                dg += rtk_stat_read(sums2, GC * 2, ((size_t)gg * channels + c) * 2 + 1);
+                {
+                    double v0_, v1_;
+                    rtk_stat_read2<RTK_STAT_BACKWARD>(sums2, GC * 2, ((size_t)gg * channels + c) * 2, v0_, v1_);
+                    db += v0_;
+                    dg += v1_;
+                }
             }
             dgb[c] = (float)dg;
             dgb[channels + c] = (float)db;
@@ -541,13 +545,21 @@ __device__ __forceinline__ BwdCoef bwd_coef(int channels, int groups, int g, con
     const size_t GC = (size_t)groups * channels, o = (size_t)g * channels + c;
     BwdCoef k;
     k.mean = par[o]; k.rstd = par[GC + o]; k.sc = par[2 * GC + o]; k.sh = par[3 * GC + o];
-    k.c1 = (float)(rtk_stat_read(sums2, GC * 2, o * 2) / count);
-    k.c2 = (float)(rtk_stat_read(sums2, GC * 2, o * 2 + 1) / count);
+    {
+        double v0_, v1_;
+        rtk_stat_read2<RTK_STAT_BACKWARD>(sums2, GC * 2, o * 2, v0_, v1_);
+        k.c1 = (float)(v0_ / count);
+        k.c2 = (float)(v1_ / count);
+    }
     if (dgb && blockIdx.y == 0 && threadIdx.x == 0) {     // parameter gradients: sum over the groups
         double db = 0.0, dg = 0.0;
         for (int gg = 0; gg < groups; ++gg) {
-            db += rtk_stat_read(sums2, GC * 2, ((size_t)gg * channels + c) * 2);
-            dg += rtk_stat_read(sums2, GC * 2, ((size_t)gg * channels + c) * 2 + 1);
+            {
+                double v0_, v1_;
+                rtk_stat_read2<RTK_STAT_BACKWARD>(sums2, GC * 2, ((size_t)gg * channels + c) * 2, v0_, v1_);
+                db += v0_;
+                dg += v1_;
+            }
         }
         dgb[c] = (float)dg;
         dgb[channels + c] = (float)db;

@@ -109,8 +109,12 @@ __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
             s_sc[c] = has_pre ? Q.pre[2 * GC + o + c] : 1.f;
             s_sh[c] = has_pre ? Q.pre[3 * GC + o + c] : 0.f;
             if (MODE == 2) {
-                s_c1[c] = (float)(rtk_stat_read(Q.sums, GC * 2, (o + c) * 2) / Q.count);
-                s_c2[c] = (float)(rtk_stat_read(Q.sums, GC * 2, (o + c) * 2 + 1) / Q.count);
+                {
+                    double v0_, v1_;
+                    rtk_stat_read2<RTK_STAT_BACKWARD>(Q.sums, GC * 2, (o + c) * 2, v0_, v1_);
+                    s_c1[c] = (float)(v0_ / Q.count);
+                    s_c2[c] = (float)(v1_ / Q.count);
+                }
             }
         }
     }
@@ -122,15 +126,23 @@ __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
             s_pm[c] = Q.pool_par[o + c];
             s_pr[c] = Q.pool_par[GC + o + c];
             s_ps[c] = Q.pool_par[2 * GC + o + c];
-            s_p1[c] = (float)(rtk_stat_read(Q.pool_sums, GC * 2, (o + c) * 2) / Q.count);
-            s_p2[c] = (float)(rtk_stat_read(Q.pool_sums, GC * 2, (o + c) * 2 + 1) / Q.count);
+            {
+                double v0_, v1_;
+                rtk_stat_read2<RTK_STAT_BACKWARD>(Q.pool_sums, GC * 2, (o + c) * 2, v0_, v1_);
+                s_p1[c] = (float)(v0_ / Q.count);
+                s_p2[c] = (float)(v1_ / Q.count);
+            }
         }
         if (Q.pool_dgb && b == 0 && blockIdx.x == 0 && threadIdx.x < 16 * U) {
             const int c = threadIdx.x;
             double db = 0.0, dg = 0.0;
             for (int gg = 0; gg < Q.groups; ++gg) {
-                db += rtk_stat_read(Q.pool_sums, GC * 2, ((size_t)gg * 16 * U + c) * 2);
-                dg += rtk_stat_read(Q.pool_sums, GC * 2, ((size_t)gg * 16 * U + c) * 2 + 1);
+                {
+                    double v0_, v1_;
+                    rtk_stat_read2<RTK_STAT_BACKWARD>(Q.pool_sums, GC * 2, ((size_t)gg * 16 * U + c) * 2, v0_, v1_);
+                    db += v0_;
+                    dg += v1_;
+                }
             }
             Q.pool_dgb[c] = (float)dg;
             Q.pool_dgb[16 * U + c] = (float)db;
@@ -141,8 +153,12 @@ __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
         const int c = threadIdx.x;
         double db = 0.0, dg = 0.0;
         for (int gg = 0; gg < Q.groups; ++gg) {
-            db += rtk_stat_read(Q.sums, (size_t)Q.groups * 16 * V * 2, ((size_t)gg * 16 * V + c) * 2);
-            dg += rtk_stat_read(Q.sums, (size_t)Q.groups * 16 * V * 2, ((size_t)gg * 16 * V + c) * 2 + 1);
+            {
+                double v0_, v1_;
+                rtk_stat_read2<RTK_STAT_BACKWARD>(Q.sums, (size_t)Q.groups * 16 * V * 2, ((size_t)gg * 16 * V + c) * 2, v0_, v1_);
+                db += v0_;
+                dg += v1_;
+            }
         }
         Q.dgb[c] = (float)dg;
         Q.dgb[16 * V + c] = (float)db;
@@ -324,9 +340,9 @@ __global__ __launch_bounds__(TC_T, 2) void conv_bn_kernel(const TcParams Q) {
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
         for (int w = 0; w < TC_T / 64; ++w) { a0 += s_red[w][threadIdx.x][0]; a1 += s_red[w][threadIdx.x][1]; }
-        double *dst = rtk_stat_slot(Q.sums, (size_t)Q.groups * 16 * V * 2, b) + ((size_t)grp * 16 * V + threadIdx.x) * 2;
-        atomicAdd(dst, a0);
-        atomicAdd(dst + 1, a1);
+        const size_t o2 = ((size_t)grp * 16 * V + threadIdx.x) * 2;
+        rtk_stat_add<MODE == 0 ? RTK_STAT_FORWARD : RTK_STAT_BACKWARD>(Q.sums, (size_t)Q.groups * 16 * V * 2, b, o2, a0);
+        rtk_stat_add<MODE == 0 ? RTK_STAT_FORWARD : RTK_STAT_BACKWARD>(Q.sums, (size_t)Q.groups * 16 * V * 2, b, o2 + 1, a1);
     }
 }
 
@@ -484,8 +500,12 @@ __global__ __launch_bounds__(TC_T, TS_OCC) void conv_wgrad_stats_kernel(const Tc
             pk[v].mean = Q.pool_par[o + c];
             pk[v].rstd = Q.pool_par[GC + o + c];
             pk[v].sc = Q.pool_par[2 * GC + o + c];
-            pk[v].c1 = (float)(rtk_stat_read(Q.pool_sums, GC * 2, (o + c) * 2) / Q.count);
-            pk[v].c2 = (float)(rtk_stat_read(Q.pool_sums, GC * 2, (o + c) * 2 + 1) / Q.count);
+            {
+                double v0_, v1_;
+                rtk_stat_read2<RTK_STAT_BACKWARD>(Q.pool_sums, GC * 2, (o + c) * 2, v0_, v1_);
+                pk[v].c1 = (float)(v0_ / Q.count);
+                pk[v].c2 = (float)(v1_ / Q.count);
+            }
         }
     }
     f4 accG[V][U], accH[V][U];
@@ -599,7 +619,7 @@ __global__ __launch_bounds__(TC_T, TS_OCC) void conv_wgrad_stats_kernel(const Tc
 }
 
 // partials (wgs, 2, n) -> per group G_g, H_g (fixed summation order) -> dw[e] += sum_g gamma[ci] H_g + beta[ci] G_g, and the
-// BatchNorm-backward statistics stats[g][ci] += (W[co][ci] G_g, W[co][ci] H_g) (float64 atomics: 16V contributions per address)
+// BatchNorm-backward statistics stats[g][ci] += (W[co][ci] G_g, W[co][ci] H_g) (rtk_stat_add: 16V contributions per value)
 __global__ __launch_bounds__(256) void conv_wgrad_stats_reduce_kernel(int n, int cin, int wgs, int groups, const float *__restrict__ partial,
                                                                       const float *__restrict__ w, const float *__restrict__ gamma,
                                                                       const float *__restrict__ beta, float *__restrict__ dw,
@@ -636,9 +656,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_stats_reduce_kernel(int n, int
             for (int q = 0; q < 16; ++q) { G += s_part[0][q][el]; H += s_part[1][q][el]; }
             const int ci = e % cin;
             dwe += gamma[ci] * H + beta[ci] * G;
-            double *dst = stats + ((size_t)grp * cin + ci) * 2;          // replica 0 of (RTK_STAT_SLOTS, groups, cin, 2)
-            atomicAdd(dst, (double)w[e] * (double)G);
-            atomicAdd(dst + 1, (double)w[e] * (double)H);
+            const size_t o2 = ((size_t)grp * cin + ci) * 2;             // (RTK_STAT_SLOTS, groups, cin, 2)
+            rtk_stat_add<RTK_STAT_BACKWARD>(stats, (size_t)groups * cin * 2, blockIdx.x, o2, (double)w[e] * (double)G);
+            rtk_stat_add<RTK_STAT_BACKWARD>(stats, (size_t)groups * cin * 2, blockIdx.x, o2 + 1, (double)w[e] * (double)H);
         }
     }
     if (zl == 0 && e < n) dw[e] += dwe;

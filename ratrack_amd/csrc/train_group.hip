@@ -90,18 +90,77 @@ __global__ __launch_bounds__(II_T) void inverse_index_multi_kernel(const IIJobs 
     inverse_index_body(q.n_src, q.positions, q.idx, q.off, q.inv, blockIdx.x, q.live, q.live_mult);
 }
 
+// Order-independent segmented sums: the threads' run partials (floats, each summed in a fixed order) are added to the source point's
+// accumulator as 64-bit FIXED POINT with LDS integer atomics -- a run that straddles several threads' chunks gets the same sum
+// whatever order its pieces arrive in (float atomics rounded after every piece: the gradients of a step differed from run to run
+// in the last bits).  The unit is set per plane from its largest |dz|: 2^-k with k = 61 - ceil(log2 P) - exponent(max), so that the
+// P values of a plane cannot overflow 63 bits; what a piece loses is below 2^-(60 - log2 P) of the plane's largest element (2^-47 at
+// 8192 positions).  A plane with a non-finite element gives NaN sums.
+struct FxPlane {
+    double scale, inv;      // 2^k, 2^-k
+    bool bad;
+};
+__device__ __forceinline__ FxPlane fx_plane(float amax, bool bad, int pshift) {
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;      // amax >= 0 and finite unless bad
+    const int k = pshift - e;
+    FxPlane f;
+    f.scale = __hiloint2double((1023 + k) << 20, 0);
+    f.inv = __hiloint2double((1023 - k) << 20, 0);
+    f.bad = bad;
+    return f;
+}
+__device__ __forceinline__ void fx_add(long long *acc, float v, const FxPlane &f) {
+    atomicAdd(reinterpret_cast<unsigned long long *>(acc), (unsigned long long)__double2ll_rn((double)v * f.scale));
+}
+__device__ __forceinline__ float fx_value(long long q, const FxPlane &f) {
+    return f.bad ? __uint_as_float(0x7fc00000u) : (float)((double)q * f.inv);
+}
+__device__ __forceinline__ int fx_pshift(int P) {
+    int lg = 0;
+    while ((1 << lg) < P) ++lg;
+    return 61 - lg;
+}
+__device__ __forceinline__ float fx_amax4(float am, const float4 v, unsigned &bad) {
+    bad |= (!(fabsf(v.x) <= 3.0e38f)) | (!(fabsf(v.y) <= 3.0e38f)) | (!(fabsf(v.z) <= 3.0e38f)) | (!(fabsf(v.w) <= 3.0e38f));      // infinity or NaN
+    return fmaxf(am, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+}
+// wave partials of the plane's (dwx_x, dwx_y, dwx_z, max |dz|, non-finite flag) -> LDS; after the next barrier every thread combines them
+__device__ __forceinline__ void fx_wave_partials(float (&s_red)[4][5], int wave, int lane, float ax, float ay, float az, float am, unsigned bad) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ax += __shfl_xor(ax, o, 64); ay += __shfl_xor(ay, o, 64); az += __shfl_xor(az, o, 64);
+        am = fmaxf(am, __shfl_xor(am, o, 64));
+    }
+    const bool anybad = __ballot(bad != 0u) != 0ull;
+    if (lane == 0) { s_red[wave][0] = ax; s_red[wave][1] = ay; s_red[wave][2] = az; s_red[wave][3] = am; s_red[wave][4] = anybad ? 1.f : 0.f; }
+}
+
+// dwx[c][t] += the samples' shares (samples, channels, 3) in a fixed order, no atomics: one wave per element -- lane l adds samples
+// l, l + 64, ... (all loads in flight at once), then the xor tree over the lanes.  (A second launch: letting the last workgroup of the
+// main kernel to arrive do it kept every such launch waiting for one workgroup's 24 k loads -- train step 7.6 -> 7.9 ms.)
+__global__ __launch_bounds__(256) void dwx_reduce_kernel(int samples, int channels, const float *__restrict__ ws, float *__restrict__ dwx, int dwx_pitch) {
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= channels * 3) return;
+    float a = 0.f;
+    for (int s = lane; s < samples; s += 64) a += ws[(size_t)s * channels * 3 + e];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (lane == 0) dwx[(size_t)(e / 3) * dwx_pitch + e % 3] += a;
+}
+
 constexpr int FB_MAXQ = 8;      // float4 per thread and plane: planes up to 8192 positions keep their offsets in registers
 
 __global__ __launch_bounds__(256) void sa_first_layer_bwd_kernel(int channels, int cg, int n_src, int P, const float *__restrict__ dz,
                                                                  const float *__restrict__ dxyz, const int *__restrict__ off,
                                                                  const unsigned short *__restrict__ inv, float *__restrict__ dproj,
-                                                                 float *__restrict__ dwx, int dwx_pitch) {
+                                                                 float *__restrict__ dwx_ws, float *__restrict__ dwx, int dwx_pitch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem[];
-    float *s_plane = reinterpret_cast<float *>(fb_smem);                                  // [P]
-    int *s_off = reinterpret_cast<int *>(s_plane + ((P + 3) & ~3));                       // [n_src + 1]
-    float *s_out = reinterpret_cast<float *>(s_off + n_src + 1);                         // [n_src]
-    unsigned short *s_inv = reinterpret_cast<unsigned short *>(s_out + n_src);            // [P]
-    __shared__ float s_red[4][3];
+    float *s_plane = reinterpret_cast<float *>(fb_smem);                                  // [P + 4]
+    long long *s_out = reinterpret_cast<long long *>(s_plane + P + 4);                    // [n_src] fixed point (P % 4 == 0: 16-byte aligned)
+    int *s_off = reinterpret_cast<int *>(s_out + n_src);                                  // [n_src + 1]
+    unsigned short *s_inv = reinterpret_cast<unsigned short *>(s_off + n_src + 1);        // [P + 256]
+    __shared__ float s_red[4][5];
+    const int pshift = fx_pshift(P);
     const int s = blockIdx.y, c0 = blockIdx.x * cg, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (int q = t; q <= n_src; q += 256) s_off[q] = off[(size_t)s * (n_src + 1) + q];
     // thread t later walks the sorted positions [t E, (t+1) E): one pad element per chunk keeps the 64 lanes of a wave on
@@ -143,7 +202,8 @@ __global__ __launch_bounds__(256) void sa_first_layer_bwd_kernel(int channels, i
     for (int cc = 0; cc < nplanes; ++cc) {
         const int c = c0 + cc;
         const float4 *pl = reinterpret_cast<const float4 *>(dz + ((size_t)s * channels + c) * P);
-        float ax = 0.f, ay = 0.f, az = 0.f;
+        float ax = 0.f, ay = 0.f, az = 0.f, am = 0.f;
+        unsigned bad = 0u;
         __syncthreads();                           // the previous plane has been consumed
         if (in_regs) {
 #pragma unroll
@@ -151,6 +211,7 @@ __global__ __launch_bounds__(256) void sa_first_layer_bwd_kernel(int channels, i
                 const int e = t + 256 * i;
                 if (e < n4) {
                     reinterpret_cast<float4 *>(s_plane)[e] = v[i];
+                    am = fx_amax4(am, v[i], bad);
                     ax += (v[i].x * ox[i].x + v[i].y * ox[i].y) + (v[i].z * ox[i].z + v[i].w * ox[i].w);
                     ay += (v[i].x * oy[i].x + v[i].y * oy[i].y) + (v[i].z * oy[i].z + v[i].w * oy[i].w);
                     az += (v[i].x * oz[i].x + v[i].y * oz[i].y) + (v[i].z * oz[i].z + v[i].w * oz[i].w);
@@ -161,20 +222,26 @@ __global__ __launch_bounds__(256) void sa_first_layer_bwd_kernel(int channels, i
             for (int e = t; e < n4; e += 256) {
                 const float4 v = pl[e], a = dx4[e], b = dx4[n4 + e], d = dx4[2 * n4 + e];
                 reinterpret_cast<float4 *>(s_plane)[e] = v;
+                am = fx_amax4(am, v, bad);
                 ax += (v.x * a.x + v.y * a.y) + (v.z * a.z + v.w * a.w);
                 ay += (v.x * b.x + v.y * b.y) + (v.z * b.z + v.w * b.w);
                 az += (v.x * d.x + v.y * d.y) + (v.z * d.z + v.w * d.w);
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { ax += __shfl_xor(ax, o, 64); ay += __shfl_xor(ay, o, 64); az += __shfl_xor(az, o, 64); }
-        if (lane == 0) { s_red[wave][0] = ax; s_red[wave][1] = ay; s_red[wave][2] = az; }
-        __syncthreads();                           // plane staged, partials visible
-        if (t < 3) atomicAdd(dwx + (size_t)c * dwx_pitch + t, (s_red[0][t] + s_red[1][t]) + (s_red[2][t] + s_red[3][t]));
+        fx_wave_partials(s_red, wave, lane, ax, ay, az, am, bad);
+        for (int q = t; q < n_src; q += 256) s_out[q] = 0;
+        __syncthreads();                           // plane staged, partials visible, accumulator clear
+        // this sample's share of dwx[c]: summed over the samples in a fixed order by dwx_reduce_kernel, or (no workspace) added with a
+        // float atomic, in the order of arrival
+        if (t < 3) {
+            const float share = (s_red[0][t] + s_red[1][t]) + (s_red[2][t] + s_red[3][t]);
+            if (dwx_ws) dwx_ws[((size_t)s * channels + c) * 3 + t] = share;
+            else atomicAdd(dwx + (size_t)c * dwx_pitch + t, share);
+        }
+        const FxPlane fx = fx_plane(fmaxf(fmaxf(s_red[0][3], s_red[1][3]), fmaxf(s_red[2][3], s_red[3][3])),
+                                    (s_red[0][4] + s_red[1][4]) + (s_red[2][4] + s_red[3][4]) != 0.f, pshift);
         // balanced segmented sum: thread t owns the sorted positions [t E, (t+1) E); runs of one source point inside the chunk
         // are summed in registers, only the (few) run ends go to the LDS accumulator
-        for (int q = t; q < n_src; q += 256) s_out[q] = 0.f;
-        __syncthreads();
         {
             if (e0 < e1) {
                 int q = q_first, nb = s_off[q + 1];
@@ -191,7 +258,7 @@ __global__ __launch_bounds__(256) void sa_first_layer_bwd_kernel(int channels, i
                         const int e = eb + k;
                         if (e < e1) {
                             if (e >= nb) {
-                                atomicAdd(&s_out[q], acc);
+                                fx_add(&s_out[q], acc, fx);
                                 acc = 0.f;
                                 do { ++q; nb = s_off[q + 1]; } while (e >= nb);
                             }
@@ -199,12 +266,12 @@ __global__ __launch_bounds__(256) void sa_first_layer_bwd_kernel(int channels, i
                         }
                     }
                 }
-                atomicAdd(&s_out[q], acc);
+                fx_add(&s_out[q], acc, fx);
             }
         }
         __syncthreads();
         float *out = dproj + ((size_t)s * channels + c) * n_src;
-        for (int q = t; q < n_src; q += 256) out[q] = s_out[q];
+        for (int q = t; q < n_src; q += 256) out[q] = fx_value(s_out[q], fx);
     }
 }
 
@@ -219,14 +286,15 @@ template <int EMAX>
 __global__ __launch_bounds__(256, 2) void sa_first_layer_bwd_fast_kernel(int channels, int cg, int gx, int n_src, int P, const float *__restrict__ dz,
                                                                       const float *__restrict__ dxyz, const int *__restrict__ off,
                                                                       const unsigned short *__restrict__ inv, float *__restrict__ dproj,
-                                                                      float *__restrict__ dwx, int dwx_pitch) {
+                                                                      float *__restrict__ dwx_ws, float *__restrict__ dwx, int dwx_pitch) {
     constexpr int NQ = EMAX / 4;      // float4 per thread and plane (P <= 256 EMAX)
     extern __shared__ __attribute__((aligned(16))) unsigned char fb_smem[];
     float *s_plane = reinterpret_cast<float *>(fb_smem);                                  // [P + 4]: s_plane[P] = 0 (the slot of absent elements)
-    int *s_off = reinterpret_cast<int *>(s_plane + P + 4);                                // [n_src + 1]
-    float *s_out = reinterpret_cast<float *>(s_off + n_src + 1);                         // [n_src]
-    unsigned short *s_inv = reinterpret_cast<unsigned short *>(s_out + n_src);            // [P + 256] (padded, see the generic kernel)
-    __shared__ float s_red[4][3];
+    long long *s_out = reinterpret_cast<long long *>(s_plane + P + 4);                    // [n_src] fixed point (see fx_plane)
+    int *s_off = reinterpret_cast<int *>(s_out + n_src);                                  // [n_src + 1]
+    unsigned short *s_inv = reinterpret_cast<unsigned short *>(s_off + n_src + 1);        // [P + 256] (padded, see the generic kernel)
+    __shared__ float s_red[4][5];
+    const int pshift = fx_pshift(P);
     // gx > 0: 1-D grid decoded so that all workgroups of sample s run on XCD s % 8 (workgroup ids go round-robin over the XCDs, each
     // with its own L2): the sample's index table and offset planes (16 + 96 KiB at the largest shape) are fetched from HBM once, not
     // once per XCD that happens to get one of the sample's channel groups
@@ -291,25 +359,31 @@ __global__ __launch_bounds__(256, 2) void sa_first_layer_bwd_fast_kernel(int cha
     }
     for (int cc = 0; cc < nplanes; ++cc) {
         const int c = c0 + cc;
-        float ax = 0.f, ay = 0.f, az = 0.f;
+        float ax = 0.f, ay = 0.f, az = 0.f, am = 0.f;
+        unsigned bad = 0u;
         __syncthreads();                           // the previous plane has been consumed
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int e = t + 256 * i;
             if (e < n4) {
                 reinterpret_cast<float4 *>(s_plane)[e] = v[i];
+                am = fx_amax4(am, v[i], bad);
                 ax += (v[i].x * ox[i].x + v[i].y * ox[i].y) + (v[i].z * ox[i].z + v[i].w * ox[i].w);
                 ay += (v[i].x * oy[i].x + v[i].y * oy[i].y) + (v[i].z * oy[i].z + v[i].w * oy[i].w);
                 az += (v[i].x * oz[i].x + v[i].y * oz[i].y) + (v[i].z * oz[i].z + v[i].w * oz[i].w);
             }
         }
         if (cc + 1 < nplanes) request(c + 1);      // the next plane travels while this one is gathered
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { ax += __shfl_xor(ax, o, 64); ay += __shfl_xor(ay, o, 64); az += __shfl_xor(az, o, 64); }
-        if (lane == 0) { s_red[wave][0] = ax; s_red[wave][1] = ay; s_red[wave][2] = az; }
-        for (int q = t; q < n_src; q += 256) s_out[q] = 0.f;
+        fx_wave_partials(s_red, wave, lane, ax, ay, az, am, bad);
+        for (int q = t; q < n_src; q += 256) s_out[q] = 0;
         __syncthreads();                           // plane staged, partials visible, accumulator clear
-        if (t < 3) atomicAdd(dwx + (size_t)c * dwx_pitch + t, (s_red[0][t] + s_red[1][t]) + (s_red[2][t] + s_red[3][t]));
+        if (t < 3) {
+            const float share = (s_red[0][t] + s_red[1][t]) + (s_red[2][t] + s_red[3][t]);
+            if (dwx_ws) dwx_ws[((size_t)s * channels + c) * 3 + t] = share;
+            else atomicAdd(dwx + (size_t)c * dwx_pitch + t, share);
+        }
+        const FxPlane fx = fx_plane(fmaxf(fmaxf(s_red[0][3], s_red[1][3]), fmaxf(s_red[2][3], s_red[3][3])),
+                                    (s_red[0][4] + s_red[1][4]) + (s_red[2][4] + s_red[3][4]) != 0.f, pshift);
         float acc = 0.f;
         constexpr int VB = EMAX < 16 ? EMAX : 16;      // values in flight (32 at once spill at two workgroups per CU)
 #pragma unroll
@@ -321,14 +395,14 @@ __global__ __launch_bounds__(256, 2) void sa_first_layer_bwd_fast_kernel(int cha
             for (int k = 0; k < VB; ++k) {
                 acc += val[k];
                 if (endmask & (1u << (k0 + k))) {
-                    atomicAdd(&s_out[iq[k0 + k] >> 16], acc);
+                    fx_add(&s_out[iq[k0 + k] >> 16], acc, fx);
                     acc = 0.f;
                 }
             }
         }
         __syncthreads();
         float *out = dproj + ((size_t)s * channels + c) * n_src;
-        for (int q = t; q < n_src; q += 256) out[q] = s_out[q];
+        for (int q = t; q < n_src; q += 256) out[q] = fx_value(s_out[q], fx);
     }
 }
 
@@ -475,11 +549,12 @@ extern "C" int rtk_group_inverse_index_multi(int samples, int njobs, const rtk_i
 
 extern "C" int rtk_sa_first_layer_bwd(int samples, int channels, int rows, int ns, int n_src, const float *dz, const float *dxyz,
                                       const int *off, const unsigned short *inv, float *dproj, float *dwx, int dwx_pitch,
-                                      rtk_stream_t stream) {
+                                      float *dwx_ws, rtk_stream_t stream) {
     RTK_REQUIRE(samples > 0 && channels > 0 && rows > 0 && ns >= 4 && (ns & 3) == 0 && n_src > 0 && dz && dxyz && off && inv && dproj &&
                 dwx && dwx_pitch >= 3, "sa_first_layer_bwd: bad arguments");
     const int P = rows * ns;
-    const size_t lds = (size_t)(P + 4) * sizeof(float) + (size_t)(2 * n_src + 1) * sizeof(int) + (size_t)(P + 256) * sizeof(unsigned short);
+    const size_t lds = (size_t)(P + 4) * sizeof(float) + (size_t)n_src * sizeof(long long) + (size_t)(n_src + 1) * sizeof(int) +
+                       (size_t)(P + 256) * sizeof(unsigned short);
     RTK_REQUIRE(P <= 65536 && lds <= 150 * 1024 && samples <= 65535, "sa_first_layer_bwd: %d positions exceed the LDS budget", P);
     hipStream_t st = (hipStream_t)stream;
     if (P <= 8192 && n_src < 65536) {
@@ -493,10 +568,11 @@ extern "C" int rtk_sa_first_layer_bwd(int samples, int channels, int rows, int n
 #define FB_CASE(EM)                                                                                                                             \
     {                                                                                                                                           \
         (void)hipFuncSetAttribute((const void *)sa_first_layer_bwd_fast_kernel<EM>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);   \
-        sa_first_layer_bwd_fast_kernel<EM><<<grid, 256, lds, st>>>(channels, cg, gx, n_src, P, dz, dxyz, off, inv, dproj, dwx, dwx_pitch);          \
+        sa_first_layer_bwd_fast_kernel<EM><<<grid, 256, lds, st>>>(channels, cg, gx, n_src, P, dz, dxyz, off, inv, dproj, dwx_ws, dwx, dwx_pitch);           \
     }
         if (E <= 8) FB_CASE(8) else if (E <= 16) FB_CASE(16) else FB_CASE(32)
 #undef FB_CASE
+        if (dwx_ws) dwx_reduce_kernel<<<rtk_divup(channels * 3, 4), 256, 0, st>>>(samples, channels, dwx_ws, dwx, dwx_pitch);
         RTK_CHECK_LAUNCH("sa_first_layer_bwd");
         return RTK_OK;
     }
@@ -506,7 +582,8 @@ extern "C" int rtk_sa_first_layer_bwd(int samples, int channels, int rows, int n
     // ... at large batches; with few samples one plane per workgroup (the serial chain per workgroup is what counts there)
     const int cg = ((long)((channels + 3) / 4) * samples >= 256 ? 4 : 1);
     const dim3 grid((channels + cg - 1) / cg, samples);
-    sa_first_layer_bwd_kernel<<<grid, 256, lds, st>>>(channels, cg, n_src, P, dz, dxyz, off, inv, dproj, dwx, dwx_pitch);
+    sa_first_layer_bwd_kernel<<<grid, 256, lds, st>>>(channels, cg, n_src, P, dz, dxyz, off, inv, dproj, dwx_ws, dwx, dwx_pitch);
+    if (dwx_ws) dwx_reduce_kernel<<<rtk_divup(channels * 3, 4), 256, 0, st>>>(samples, channels, dwx_ws, dwx, dwx_pitch);
     RTK_CHECK_LAUNCH("sa_first_layer_bwd");
     return RTK_OK;
 }

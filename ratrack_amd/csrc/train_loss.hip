@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void backbone_loss_kernel(int B, int N, const 
                                                             float *__restrict__ items, float *__restrict__ dflow,
                                                             float *__restrict__ dcls, const int *__restrict__ n_valid) {
     __shared__ float s_red[4];
+    __shared__ int s_last;
     const int b = blockIdx.x, t = threadIdx.x;
     const int nv = n_valid ? n_valid[b] : N;        // padded batch: the sample's own point count (padding columns: zero gradient)
     const float *p1 = pc1 + (size_t)b * 3 * N, *fl = flow + (size_t)b * 3 * N, *g3 = gt + (size_t)b * 3 * N;
@@ -82,9 +83,34 @@ __global__ __launch_bounds__(256) void backbone_loss_kernel(int B, int N, const 
         sfb = sfb != sfb ? 0.f : sfb;                               // NaN -> 0 (losses/loss.py:15-20)
         const float segb = defined ? wp * spos + wn * sneg : 0.f;
         const float sfm = sfb / (float)B, segm = segb / (float)B;
-        atomicAdd(items + 1, sfm);                                   // SceneFlowLoss
-        atomicAdd(items + 3, segm);                                  // SegLoss
-        atomicAdd(items + 0, pretrain ? segm : 0.5f * sfm + segm);   // Loss  (items[2] = TrackingLoss stays 0)
+        // the batch means: every sample leaves its share, the last workgroup to arrive adds them up sample 0 first (float atomics
+        // summed in arrival order: the loss differed from run to run in its last bit)
+        float *share = items + 5;
+        int *ticket = reinterpret_cast<int *>(items + 4);
+        share[2 * b] = sfm;
+        share[2 * b + 1] = segm;
+        __threadfence();
+        s_last = atomicAdd(ticket, 1) == B - 1;
+    }
+    __syncthreads();
+    if (s_last && t < 64) {                                  // (workgroup-uniform: the last workgroup's first wave)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const float *share = items + 5;
+        float s_sf = 0.f, s_seg = 0.f, s_all = 0.f;
+        for (int k = t; k < B; k += 64) {                             // lane l: samples l, l + 64, ...; then the xor tree -- a fixed order
+            const float a = __builtin_nontemporal_load(share + 2 * k), c = __builtin_nontemporal_load(share + 2 * k + 1);
+            s_sf += a;
+            s_seg += c;
+            s_all += pretrain ? c : 0.5f * a + c;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s_sf += __shfl_xor(s_sf, o, 64); s_seg += __shfl_xor(s_seg, o, 64); s_all += __shfl_xor(s_all, o, 64); }
+        if (t == 0) {
+            items[1] = s_sf;                                          // SceneFlowLoss
+            items[3] = s_seg;                                         // SegLoss
+            items[0] = s_all;                                         // Loss  (items[2] = TrackingLoss stays 0)
+            *reinterpret_cast<int *>(items + 4) = 0;
+        }
     }
 }
 

@@ -284,9 +284,9 @@ __global__ __launch_bounds__(64 * NW) void pw_conv_kernel(const PwParams Q) {
 #pragma unroll
             for (int w = 0; w < NW; ++w) { a0 += s_red[w][threadIdx.x][0]; a1 += s_red[w][threadIdx.x][1]; }
             const int grp = b / (Q.samples / Q.groups);
-            double *dst = rtk_stat_slot(Q.sums, (size_t)Q.groups * Q.stat_channels * 2, b) + ((size_t)grp * Q.stat_channels + orow0 + threadIdx.x) * 2;
-            atomicAdd(dst, a0);
-            atomicAdd(dst + 1, a1);
+            const size_t o2 = ((size_t)grp * Q.stat_channels + orow0 + threadIdx.x) * 2;
+            rtk_stat_add<RTK_STAT_FORWARD>(Q.sums, (size_t)Q.groups * Q.stat_channels * 2, b, o2, a0);
+            rtk_stat_add<RTK_STAT_FORWARD>(Q.sums, (size_t)Q.groups * Q.stat_channels * 2, b, o2 + 1, a1);
         }
     }
 }

@@ -37,8 +37,13 @@ class Trainer:
     loss configuration re-captures.  The returned loss items and GRU state are the graph's static output tensors: every
     replay overwrites them in place, so copy (`.clone()` / `float()`) what must outlive the next step."""
 
-    def __init__(self, model, lr=1e-3, process_group=None, graph=False, graph_warmup=3, graph_collective=False, split_graph=None):
+    def __init__(self, model, lr=1e-3, process_group=None, graph=False, graph_warmup=3, graph_collective=False, split_graph=None,
+                 deterministic=False):
+        """deterministic: every step is reproducible bit for bit -- gradients, losses, outputs, hence the whole trajectory from the same
+        weights and batches (train_ops.set_deterministic: order-independent batch statistics and first-layer weight gradients; about
+        3 % slower at B = 64; across ranks the RCCL all-reduce sums in its own fixed order)."""
         self.model = model
+        self.deterministic = bool(deterministic)
         self._dev = next(model.parameters()).device
         if self._dev.type == "cuda":
             from . import train_ops
@@ -55,7 +60,17 @@ class Trainer:
         self._static = None
         self._key = None
 
-    def _forward_backward(self, pc1, pc2, feature1, feature2, gt_warp, gt_cls, h, n_valid, pretrain):
+    def _forward_backward(self, *args):
+        if self._dev.type != "cuda":
+            return self._forward_backward_impl(*args)
+        from . import train_ops
+        prev = train_ops.set_deterministic(self.deterministic)
+        try:
+            return self._forward_backward_impl(*args)
+        finally:
+            train_ops.set_deterministic(prev)
+
+    def _forward_backward_impl(self, pc1, pc2, feature1, feature2, gt_warp, gt_cls, h, n_valid, pretrain):
         if self._dev.type == "cuda":
             from . import train_ops
             self.opt.zero_grad(set_to_none=True)        # last step's gradients may be views of the arena that is cleared now

@@ -23,7 +23,7 @@ _lib.SIGNATURES.update({
     "rtk_sa_first_layer": [_i] * 6 + [_p] * 4 + [_i] + [_p] * 3 + [_p],
     "rtk_group_inverse_index": [_i] * 3 + [_p] * 3 + [_p],
     "rtk_three_interpolate_grad_gather": [_i] * 4 + [_p] * 6 + [_p],
-    "rtk_sa_first_layer_bwd": [_i] * 5 + [_p] * 6 + [_i, _p],
+    "rtk_sa_first_layer_bwd": [_i] * 5 + [_p] * 6 + [_i, _p, _p],
     "rtk_conv_bn_fwd": [_i] * 6 + [_p] * 7 + [_p],
     "rtk_conv_wgrad": [_i] * 6 + [_p] * 5 + [ctypes.c_long, _p],
     "rtk_conv_bn_bwd": [_i] * 6 + [_p] * 6 + [_d, _i, _p, _p, _p],
@@ -178,11 +178,11 @@ class _BNReLU(torch.autograd.Function):
         if row_weight is not None:
             assert row_weight.shape == (S_, rows) and row_weight.dtype == torch.float32 and row_weight.is_contiguous()
         dev = z.device
-        sums = _zeros((STAT_SLOTS, groups, C, 2), torch.float64, dev)
-        _lib.call("rtk_bn_train_stats", S_, C, rows, ns, groups, z.data_ptr(), _ptr(row_weight), sums.data_ptr(), _stream())
+        sums = _zeros((_stat_slots(), groups, C, 2), torch.float64, dev)
+        _lib.call("rtk_bn_train_stats", S_, C, rows, ns, groups, z.data_ptr(), _ptr(row_weight), _sums_ptr(sums), _stream())
         par = torch.empty(4, groups, C, dtype=torch.float32, device=dev)
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
-        fin = _BnFin(sums.data_ptr(), float(count), g.data_ptr(), b.data_ptr(), float(eps), float(momentum), _ptr(running_mean),
+        fin = _BnFin(_sums_ptr(sums), float(count), g.data_ptr(), b.data_ptr(), float(eps), float(momentum), _ptr(running_mean),
                      _ptr(running_var), _ptr(nbt), None)
         y = torch.empty((S_, C, rows) if pool else (S_, C, rows, ns), dtype=torch.float32, device=dev)
         _lib.call("rtk_bn_relu_fwd_fin", S_, C, rows, ns, groups, z.data_ptr(), ctypes.byref(fin), par.data_ptr(), int(pool), y.data_ptr(),
@@ -198,13 +198,13 @@ class _BNReLU(torch.autograd.Function):
         S_, C, rows, ns = z.shape
         dy = dy.contiguous()
         dev = z.device
-        sums2 = _zeros((STAT_SLOTS, groups, C, 2), torch.float64, dev)
+        sums2 = _zeros((_stat_slots(), groups, C, 2), torch.float64, dev)
         _lib.call("rtk_bn_relu_bwd_stats", S_, C, rows, ns, groups, z.data_ptr(), dy.data_ptr(), par.data_ptr(), int(pool),
-                  sums2.data_ptr(), _stream())
+                  _sums_ptr(sums2), _stream())
         dz = torch.empty_like(z)
         dgb = torch.empty(2, C, dtype=torch.float32, device=dev)
         _lib.call("rtk_bn_relu_bwd_apply", S_, C, rows, ns, groups, z.data_ptr(), dy.data_ptr(), par.data_ptr(), _ptr(row_weight),
-                  sums2.data_ptr(), float(count), None, int(pool), dz.data_ptr(), dgb.data_ptr(), _stream())
+                  _sums_ptr(sums2), float(count), None, int(pool), dz.data_ptr(), dgb.data_ptr(), _stream())
         return dz, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None
 
 
@@ -265,10 +265,35 @@ def _pw_like(t, channels=None, point_major=None):
 def _pw_forward(srcs, cols, W, bias, out, row_w=None, groups=1, sums=None):
     S_, _, P = srcs[0].shape
     _lib.call("rtk_pw_conv", S_, P, len(srcs), _pw_operands(srcs, cols), 1, _pw_operands([out], [0]), W.data_ptr(), W.stride(0), 0,
-              _ptr(bias), 0, _ptr(row_w), groups, _ptr(sums), out.shape[1], _stream())
+              _ptr(bias), 0, _ptr(row_w), groups, (_sums_ptr(sums) if sums is not None else None), out.shape[1], _stream())
 
 
-STAT_SLOTS = 8             # RTK_STAT_SLOTS (include/rtk_train.h): replicas of every batch-statistics buffer
+STAT_SLOTS, STAT_SLOTS_ORDERED = 8, 16      # RTK_STAT_SLOTS / RTK_STAT_SLOTS_ORDERED (include/rtk_train.h): float64 words per batch statistic
+DETERMINISTIC = False      # set_deterministic()
+
+
+def set_deterministic(on=True):
+    """Reproducible training: every sum of a step that used to depend on the order in which workgroups arrive is accumulated
+    order-independently -- the batch statistics as exact fixed-point limbs (the tag in bit 0 of the buffers' pointers,
+    csrc/rtk_common.h rtk_stat_add), the offset columns of the first layers' weight gradients as per-sample shares added in a fixed
+    order (rtk_sa_first_layer_bwd's dwx_ws); everything else in the step is order-independent in either mode.  Gradients, losses and
+    outputs are then bit-identical from run to run (tests/test_train_gpu.py, tools/hazard_train.py); the step takes about 3 % longer
+    at B = 64.  Off (the default): float64 / float atomics there, gradients differ from run to run at 1e-6 of a tensor's largest
+    element.  Returns the previous setting.  (A captured step keeps the mode it was captured in.)"""
+    global DETERMINISTIC
+    prev, DETERMINISTIC = DETERMINISTIC, bool(on)
+    return prev
+
+
+def _stat_slots():
+    return STAT_SLOTS_ORDERED if DETERMINISTIC else STAT_SLOTS
+
+
+def _sums_ptr(t):
+    """Device pointer of a batch-statistics buffer with the accumulation mode in bit 0 (include/rtk_train.h RTK_STAT_SLOTS)."""
+    p = t.data_ptr()
+    assert p % 8 == 0
+    return p | 1 if DETERMINISTIC else p
 _WGRAD_WS = 4 << 20        # floats: 1024 partial 64 x 64 blocks (rtk_pw_wgrad splits the position axis as far as this allows)
 
 
@@ -422,7 +447,7 @@ class _PwBnRelu(torch.autograd.Function):
         S_, _, P = srcs[0].shape
         Co = W2.shape[0]
         dev = srcs[0].device
-        sums = _zeros((STAT_SLOTS, groups, Co, 2), torch.float64, dev)
+        sums = _zeros((_stat_slots(), groups, Co, 2), torch.float64, dev)
         z = torch.empty(S_, Co, P, dtype=torch.float32, device=dev)
         _pw_forward(srcs, cols, W2, None, z, row_w, groups, sums)
         fin, par, _keep = _bn_fin(bn, sums, count, groups, gcounts)
@@ -448,9 +473,9 @@ class _PwBnRelu(torch.autograd.Function):
                       _ptr(gcounts), dz.data_ptr(), dgb.data_ptr(), int(split), _stream())
         else:
             dgb = torch.empty(2, Co, dtype=torch.float32, device=dev)
-            sums2 = _zeros((STAT_SLOTS, groups, Co, 2), torch.float64, dev)
-            _lib.call("rtk_bn_relu_bwd_stats", S_, Co, P, 1, groups, z.data_ptr(), dy.data_ptr(), par.data_ptr(), 0, sums2.data_ptr(), _stream())
-            _lib.call("rtk_bn_relu_bwd_apply", S_, Co, P, 1, groups, z.data_ptr(), dy.data_ptr(), par.data_ptr(), _ptr(row_w), sums2.data_ptr(),
+            sums2 = _zeros((_stat_slots(), groups, Co, 2), torch.float64, dev)
+            _lib.call("rtk_bn_relu_bwd_stats", S_, Co, P, 1, groups, z.data_ptr(), dy.data_ptr(), par.data_ptr(), 0, _sums_ptr(sums2), _stream())
+            _lib.call("rtk_bn_relu_bwd_apply", S_, Co, P, 1, groups, z.data_ptr(), dy.data_ptr(), par.data_ptr(), _ptr(row_w), _sums_ptr(sums2),
                       float(count), _ptr(gcounts), 0, dz.data_ptr(), dgb.data_ptr(), _stream())
         W2 = W.detach().reshape(W.shape[0], -1)
         dW, _, dsrcs, deferred = _pw_backward(ctx.needs_input_grad[4:], srcs, cols, W2, dz, False, owner=ctx.owner)
@@ -515,7 +540,7 @@ def _bn_fin(bn, sums, count, groups, group_counts=None):
     par = torch.empty(4, groups, C, dtype=torch.float32, device=sums.device)
     momentum = bn.momentum if bn.momentum is not None else 0.1
     track = bn.track_running_stats
-    f = _BnFin(sums.data_ptr(), float(count), bn.weight.detach().data_ptr(), bn.bias.detach().data_ptr(), float(bn.eps), float(momentum),
+    f = _BnFin(_sums_ptr(sums), float(count), bn.weight.detach().data_ptr(), bn.bias.detach().data_ptr(), float(bn.eps), float(momentum),
                _ptr(bn.running_mean if track else None), _ptr(bn.running_var if track else None),
                _ptr(bn.num_batches_tracked if track else None), _ptr(group_counts))
     return ctypes.byref(f), par, f
@@ -523,16 +548,17 @@ def _bn_fin(bn, sums, count, groups, group_counts=None):
 
 class _SumsPool:
     """The float64 statistics buffers of one chain pass, zeroed with ONE fill: call with a channel count to get the next
-    (STAT_SLOTS, groups, C, 2) slice."""
+    (slots, groups, C, 2) slice."""
 
     def __init__(self, groups, channels, device):
         self.groups = groups
-        self.buf = _zeros((STAT_SLOTS * groups * 2 * sum(channels),), torch.float64, device)
+        self.slots = _stat_slots()
+        self.buf = _zeros((self.slots * groups * 2 * sum(channels),), torch.float64, device)
         self.off = 0
 
     def __call__(self, c):
-        n = STAT_SLOTS * self.groups * c * 2
-        t = self.buf[self.off:self.off + n].view(STAT_SLOTS, self.groups, c, 2)
+        n = self.slots * self.groups * c * 2
+        t = self.buf[self.off:self.off + n].view(self.slots, self.groups, c, 2)
         self.off += n
         return t
 
@@ -566,7 +592,7 @@ class _SAChain(torch.autograd.Function):
         sums = f64(C1)
         z1 = torch.empty(S_, C1, rows, ns, dtype=torch.float32, device=dev)
         _lib.call("rtk_sa_first_layer", S_, C1, rows, ns, groups, n_src, proj.data_ptr(), idx.data_ptr(), dxyz.data_ptr(), W0.data_ptr(),
-                  W0.stride(0), _ptr(row_w), z1.data_ptr(), sums.data_ptr(), _stream())      # the offset columns = the first three of W0
+                  W0.stride(0), _ptr(row_w), z1.data_ptr(), _sums_ptr(sums), _stream())      # the offset columns = the first three of W0
         # every BatchNorm is finalised by the kernel that consumes it (the next convolution, the pooling pass at the end)
         zs, ys, pars = [z1], [], []
         fin, par, _keep = _bn_fin(bns[0], sums, count, groups)
@@ -577,7 +603,7 @@ class _SAChain(torch.autograd.Function):
             z = torch.empty(S_, Co, rows, ns, dtype=torch.float32, device=dev)
             sums = f64(Co)
             _lib.call("rtk_conv_bn_fwd_fin", S_, Ci, Co, rows, ns, groups, zs[-1].data_ptr(), fin, par.data_ptr(), wc.data_ptr(), z.data_ptr(),
-                      None, _ptr(row_w), sums.data_ptr(), _stream())      # the normalised input is NOT stored (rtk_conv_wgrad recomputes it)
+                      None, _ptr(row_w), _sums_ptr(sums), _stream())      # the normalised input is NOT stored (rtk_conv_wgrad recomputes it)
             pars.append(par)
             fin, par, _keep = _bn_fin(bns[i], sums, count, groups)
             zs.append(z)
@@ -617,9 +643,9 @@ class _SAChain(torch.autograd.Function):
         C = zs[-1].shape[1]
         sums_last = f64(C)
         _lib.call("rtk_pool_bwd_stats_arg", S_, C, rows, groups, dout.data_ptr(), zarg.data_ptr(), karg.data_ptr(), pars[-1].data_ptr(),
-                  sums_last.data_ptr(), _stream())
+                  _sums_ptr(sums_last), _stream())
         dgb_last = torch.empty(2, C, dtype=torch.float32, device=dev)
-        pool = _PoolSrc(dout.data_ptr(), karg.data_ptr(), pars[-1].data_ptr(), sums_last.data_ptr(), dgb_last.data_ptr())
+        pool = _PoolSrc(dout.data_ptr(), karg.data_ptr(), pars[-1].data_ptr(), _sums_ptr(sums_last), dgb_last.data_ptr())
         grads = {L - 1: (None, dgb_last[0], dgb_last[1])}
         dwbuf = _zeros((sum(w.numel() for w in weights[1:]) + W0.numel(),), torch.float32, dev)      # all dW of the chain | dW0
         dW0 = dwbuf[dwbuf.numel() - W0.numel():].view(W0.shape[0], W0.shape[1])
@@ -636,12 +662,12 @@ class _SAChain(torch.autograd.Function):
             sums2 = f64(Ci)
             # ONE pass over (dz, z[i-1]): the weight gradient AND the statistics of the previous BatchNorm's backward
             _lib.call("rtk_conv_wgrad_stats", S_, Ci, Co, rows, ns, groups, src.data_ptr(), src_pool, zs[i - 1].data_ptr(), pars[i - 1].data_ptr(),
-                      _ptr(row_w), float(count), wc.data_ptr(), ga.data_ptr(), be.data_ptr(), dW.data_ptr(), sums2.data_ptr(), ws.data_ptr(),
+                      _ptr(row_w), float(count), wc.data_ptr(), ga.data_ptr(), be.data_ptr(), dW.data_ptr(), _sums_ptr(sums2), ws.data_ptr(),
                       ws.numel(), _stream())
             dzp = torch.empty_like(zs[i - 1])
             dgb = torch.empty(2, Ci, dtype=torch.float32, device=dev)
             _lib.call("rtk_conv_bn_bwd_apply", S_, Ci, Co, rows, ns, groups, src.data_ptr(), src_pool, wc.data_ptr(), zs[i - 1].data_ptr(),
-                      pars[i - 1].data_ptr(), _ptr(row_w), sums2.data_ptr(), float(count), dzp.data_ptr(), dgb.data_ptr(), _stream())
+                      pars[i - 1].data_ptr(), _ptr(row_w), _sums_ptr(sums2), float(count), dzp.data_ptr(), dgb.data_ptr(), _stream())
             grads[i] = (dW, grads[i][1], grads[i][2])
             grads[i - 1] = (None, dgb[0], dgb[1])
             src, src_pool = dzp, None
@@ -657,8 +683,9 @@ class _SAChain(torch.autograd.Function):
             off, inv = ctx.inv[0], ctx.inv[1]
             if len(ctx.inv) > 2 and ctx.inv[2] is not None:        # table built on the geometry stream (TrainGeometry)
                 torch.cuda.current_stream().wait_event(ctx.inv[2])
+            dwx_ws = torch.empty(S_ * C1 * 3, dtype=torch.float32, device=dev) if DETERMINISTIC else None      # the samples' shares of the offset columns
             _lib.call("rtk_sa_first_layer_bwd", S_, C1, rows, ns, n_src, dz.data_ptr(), dxyz.data_ptr(), off.data_ptr(), inv.data_ptr(),
-                      dproj.data_ptr(), dW0.data_ptr(), dW0.stride(0), _stream())
+                      dproj.data_ptr(), dW0.data_ptr(), dW0.stride(0), _ptr(dwx_ws), _stream())
         else:
             _lib.call("rtk_group_points_grad_set", S_, C1, n_src, rows, ns, dz.data_ptr(), idx.data_ptr(), dproj.data_ptr(), _stream())
             dW0[:, :3] = torch.bmm(dz.view(S_, C1, -1), dxyz.view(S_, 3, -1).transpose(1, 2)).sum(0)
@@ -1177,12 +1204,13 @@ class _BackboneLoss(torch.autograd.Function):
         g = g.contiguous()
         stride = 0 if g.dim() == 1 else N
         # NOT from the zero arena: the caller keeps the items across steps (Trainer.step returns them without a host sync)
-        items = torch.zeros(4, dtype=torch.float32, device=dev)
+        items = torch.zeros(5 + 2 * B, dtype=torch.float32, device=dev)      # the four items | arrival counter | the samples' shares
         dflow = None if pretrain else torch.empty(B, 3, N, dtype=torch.float32, device=dev)
         dcls = torch.empty(B, N, dtype=torch.float32, device=dev)
         _lib.call("rtk_backbone_loss", B, N, pc1.data_ptr(), flow.data_ptr(), gt_warp.data_ptr(), cls.data_ptr(), g.data_ptr(), stride,
                   int(bool(pretrain)), items.data_ptr(), _ptr(dflow), dcls.data_ptr(), _ptr(n_valid), _stream())
         ctx.save_for_backward(dflow, dcls)
+        items = items[:4]
         ctx.mark_non_differentiable(items)
         return items[0], items                           # the differentiable total as its own output: no select_backward (zeros + copy)
 

@@ -81,6 +81,90 @@ def test_bn_relu_matches_expanded_batchnorm(ns, pool, groups, dedup):
     assert torch.allclose(bn.bias.grad.double(), ref.bias.grad, rtol=1e-4, atol=1e-5 * float(ref.bias.grad.abs().max()))
 
 
+@pytest.mark.parametrize("det", [True, False])
+@pytest.mark.parametrize("scale,shift,cot", [(1e-7, 0.0, 1.0), (1e-3, 5e-3, 1e-9), (1.0, 0.0, 1.0), (3e3, -1e4, 1e4), (1e6, 1e6, 1e-12)])
+def test_batch_statistics_hold_at_any_scale(scale, shift, cot, det, monkeypatch):
+    """det: the batch sums are accumulated in FIXED POINT (csrc/rtk_common.h rtk_stat_add: exact, order-independent float64 limbs; forward
+    sums in units of 2^-36, backward sums in units of 2^-66): activations from 1e-7 to 1e6 -- with means far from zero -- and
+    cotangents from 1e-12 to 1e4 against nn.BatchNorm2d in float64."""
+    from ratrack_amd import train_ops
+    monkeypatch.setattr(train_ops, "DETERMINISTIC", det)
+    torch.manual_seed(3)
+    S_, C, U, ns = 4, 24, 40, 8
+    z = (torch.randn(S_, C, U, ns, device=DEV) * scale + shift).requires_grad_(True)
+    bn = nn.BatchNorm2d(C).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    ref = nn.BatchNorm2d(C).to(DEV).double()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v.clone() for k, v in bn.state_dict().items()})
+    y = bn_relu(z, bn, None, S_ * U * ns, 1, False)
+    zd = z.detach().double().requires_grad_(True)
+    yref = F.relu(ref(zd))
+    assert torch.allclose(y.double(), yref, rtol=2e-5, atol=2e-5)
+    for k in ("running_mean", "running_var"):
+        assert torch.allclose(getattr(bn, k).double(), getattr(ref, k), rtol=1e-5, atol=1e-6 * max(1.0, scale * scale)), k
+    ct = torch.randn_like(y) * cot
+    y.backward(ct)
+    yref.backward(ct.double())
+    gs = float(zd.grad.abs().max())
+    assert torch.allclose(z.grad.double(), zd.grad, rtol=1e-3, atol=2e-4 * gs), float((z.grad.double() - zd.grad).abs().max() / gs)
+    assert torch.allclose(bn.weight.grad.double(), ref.weight.grad, rtol=1e-4, atol=1e-5 * float(ref.weight.grad.abs().max()))
+    assert torch.allclose(bn.bias.grad.double(), ref.bias.grad, rtol=1e-4, atol=1e-5 * float(ref.bias.grad.abs().max()))
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf"), 1e30])
+def test_batch_statistics_propagate_non_finite_and_out_of_range_inputs(bad, monkeypatch):
+    """Order-independent sums: an addend that is not finite, or too large for the fixed-point window (a partial sum of squares of 1e60), marks the sum: the
+    channel's statistics read as NaN -- as the float sums this replaces did for non-finite inputs -- and nothing leaks into the other
+    channels, whose outputs and running statistics are those of the clean batch."""
+    from ratrack_amd import train_ops
+    monkeypatch.setattr(train_ops, "DETERMINISTIC", True)
+    torch.manual_seed(4)
+    S_, C, U, ns = 2, 16, 32, 4
+    z = torch.randn(S_, C, U, ns, device=DEV)
+    z[1, 5, 7, 2] = bad
+    bn = nn.BatchNorm2d(C).to(DEV)
+    y = bn_relu(z, bn, None, S_ * U * ns, 1, False)
+    assert torch.isnan(bn.running_mean[5])
+    keep = [c for c in range(C) if c != 5]
+    bn2 = nn.BatchNorm2d(C - 1).to(DEV)
+    clean = bn_relu(z[:, keep].contiguous(), bn2, None, S_ * U * ns, 1, False)
+    assert torch.equal(y[:, keep], clean)
+    assert torch.equal(bn.running_mean[keep], bn2.running_mean) and torch.equal(bn.running_var[keep], bn2.running_var)
+
+
+def test_train_step_gradients_are_reproducible_bit_for_bit(monkeypatch):
+    """With train_ops.set_deterministic() / Trainer(deterministic=True): the same train step (forward, loss, backward) from the same weights ten times: every gradient tensor, the loss and the outputs
+    bit-identical.  Batch sums are exact fixed-point accumulations (rtk_stat_add), the first layer's gather sums per-plane fixed point
+    in LDS, the offset-weight gradients and the loss per-sample shares added in a fixed order, weight gradients per-workgroup partials
+    added in a fixed order: no sum in the step depends on the order in which workgroups or waves arrive.  (tools/hazard_train.py is
+    the same check at B = 64 over any number of repetitions.)"""
+    from ratrack_amd import train_ops
+    monkeypatch.setattr(train_ops, "DETERMINISTIC", True)
+    net = Track4D(Args()).to(DEV)
+    net.load_state_dict(reference_state_dict(DEV), strict=True)
+    net.train()
+    d = synth.make_frame_pairs(16, 256, 2031)
+    g = {k: torch.from_numpy(v).to(DEV) for k, v in d.items()}
+
+    def step():
+        net.zero_grad(set_to_none=True)
+        flow, h, cls, *_ = net.backbone(g["pc1"], g["pc2"], g["feature1"], g["feature2"], None)
+        total, items = train_ops.backbone_loss(g["pc1"], flow, cls, g["gt_warp"], g["gt_cls"], pretrain=False)
+        total.backward()
+        out = {"loss": total.detach().clone().reshape(1), "flow": flow.detach().clone(), "cls": cls.detach().clone(), "h": h.detach().clone()}
+        out.update({"grad/" + k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
+        return out
+    step()
+    ref = step()
+    assert len(ref) > 150
+    for _ in range(10):
+        cur = step()
+        bad = [k for k, v in cur.items() if not torch.equal(v.view(torch.int32), ref[k].view(torch.int32))]
+        assert not bad, bad[:8]
+
+
 def _train_once(dedup, B, N, pretrain=False):
     from ratrack_amd import loss as L
     net = Track4D(Args()).to(DEV)
@@ -563,7 +647,7 @@ def test_first_layer_backward_gather_form(S, C, rows, ns, n_src):
         dproj = torch.empty(S, C, n_src, device=DEV)
         dwx = torch.zeros(C, 3, device=DEV)
         _lib.call("rtk_sa_first_layer_bwd", S, C, rows, ns, n_src, dz.data_ptr(), dxyz.data_ptr(), off.data_ptr(), inv.data_ptr(),
-                  dproj.data_ptr(), dwx.data_ptr(), 3, st)
+                  dproj.data_ptr(), dwx.data_ptr(), 3, torch.empty(S * C * 3, device=DEV).data_ptr(), st)
         outs.append((dproj, dwx))
     ref = torch.zeros(S, C, n_src, dtype=torch.float64, device=DEV).scatter_add_(2, idx.view(S, 1, P).long().expand(-1, C, -1), dz.view(S, C, P).double())
     assert float((outs[0][0].double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())

@@ -24,7 +24,7 @@ for lvl in range(3):
         dproj = torch.empty(S_, C, n_src, device=dev)
         dwx = torch.zeros(C, 3, device=dev)
         t_new = _time(lambda: _lib.call("rtk_sa_first_layer_bwd", S_, C, rows, ns, n_src, dz.data_ptr(), dxyz.data_ptr(), off.data_ptr(),
-                                        inv.data_ptr(), dproj.data_ptr(), dwx.data_ptr(), 3, st), 10)
+                                        inv.data_ptr(), dproj.data_ptr(), dwx.data_ptr(), 3, torch.empty(S_ * C * 3, device=dz.device).data_ptr(), st), 10)
         t_old = _time(lambda: _lib.call("rtk_group_points_grad_set", S_, C, n_src, rows, ns, dz.data_ptr(), idx.data_ptr(), dproj.data_ptr(), st), 10)
         t_bmm = _time(lambda: torch.bmm(dz.view(S_, C, -1), dxyz.view(S_, 3, -1).transpose(1, 2)).sum(0), 10)
         mb = dz.numel() * 4 / 1e6

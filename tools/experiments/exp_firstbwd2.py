@@ -33,8 +33,9 @@ for C, radius, ns in [(16, 2.0, 4), (16, 4.0, 8), (32, 4.0, 8), (32, 8.0, 16), (
     dxyz = torch.randn(S_, 3, rows, ns, device=dev, generator=g)
     dproj = torch.empty(S_, C, n_src, device=dev)
     dwx = torch.zeros(C, 3, device=dev)
+    dwx_ws = torch.empty(S_ * C * 3, device=dz.device)
     fn = lambda: _lib.call("rtk_sa_first_layer_bwd", S_, C, rows, ns, n_src, dz.data_ptr(), dxyz.data_ptr(), off.data_ptr(), inv.data_ptr(),
-                           dproj.data_ptr(), dwx.data_ptr(), 3, st)
+                           dproj.data_ptr(), dwx.data_ptr(), 3, dwx_ws.data_ptr(), st)
     dwx.zero_(); fn(); torch.cuda.synchronize()
     ref = torch.zeros(S_, C, n_src, device=dev, dtype=torch.float64)
     ref.scatter_add_(2, idx.long().view(S_, 1, P).expand(S_, C, P), dz.double().view(S_, C, P))

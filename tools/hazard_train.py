@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--npoints", type=int, default=256)
     ap.add_argument("--iters", type=int, default=40)
+    ap.add_argument("--deterministic", action="store_true", help="train_ops.set_deterministic(): order-independent sums")
     a = ap.parse_args()
     from _util import reference_state_dict
     dev = "cuda"
@@ -34,6 +35,7 @@ def main():
     d = synth.make_frame_pairs(a.batch, a.npoints, 2030)
     g = {k: torch.from_numpy(v).to(dev) for k, v in d.items()}
     train_ops.enable_zero_arena(torch.device(dev))
+    train_ops.set_deterministic(a.deterministic)
 
     def step():
         net.zero_grad(set_to_none=True)
@@ -58,13 +60,16 @@ def main():
             if not torch.equal(v.view(torch.int32), ref[k].view(torch.int32)):
                 bad[k] = bad.get(k, 0) + 1
                 worst[k] = max(worst.get(k, 0.0), float((v - ref[k]).abs().max() / ref[k].abs().max().clamp_min(1e-30)))
-    print("train step B=%d N=%d, %d repetitions: %s" % (a.batch, a.npoints, a.iters,
+    print("train step B=%d N=%d%s, %d repetitions: %s" % (a.batch, a.npoints, ", deterministic mode" if a.deterministic else "", a.iters,
           "every gradient tensor, the loss and the outputs bit-identical" if not bad else
           "%d of %d tensors differed at least once; outputs: loss %s flow %s cls %s; largest relative difference of any tensor in any "
           "repetition %.1e; tensors ever beyond 1e-4: %s; the five largest: %s"
           % (len(bad), len(ref), bad.get("loss", 0), bad.get("flow", 0), bad.get("cls", 0), max(worst.values()),
              {k: "%.1e" % v for k, v in worst.items() if v > 1e-4},
              {k: "%.1e" % v for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:5]})))
+    if bad:
+        print("tensors that never differed: %s" % ", ".join(sorted(k for k in ref if k not in bad)))
+        print("tensors that differed (repetitions of %d): %s" % (a.iters, ", ".join("%s %d" % (k, v) for k, v in sorted(bad.items()))))
     return 1 if bad else 0
 
 
