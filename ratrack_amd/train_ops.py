@@ -305,6 +305,26 @@ _WGRAD_WS = 4 << 20        # floats: 1024 partial 64 x 64 blocks (rtk_pw_wgrad s
 _DEFERRED = None
 
 
+WGRAD_TWO_STREAMS = True
+_WGRAD_SIDE = {}
+
+
+def _split_wgrad_jobs(jobs):
+    """Chunks of eight jobs (one launch each) dealt alternately to two streams; jobs that accumulate into the same dW -- a parameter
+    used twice -- stay in their order on ONE stream (the sums keep their order).  None if a chunk would need both streams."""
+    owner, out = {}, ([], [])
+    for ci, k in enumerate(range(0, len(jobs), 8)):
+        chunk = jobs[k:k + 8]
+        prefs = {owner[j[3].data_ptr()] for j in chunk if j[3].data_ptr() in owner}
+        if len(prefs) > 1:
+            return None
+        which = prefs.pop() if prefs else ci % 2
+        for j in chunk:
+            owner[j[3].data_ptr()] = which
+        out[which].extend(chunk)
+    return out if out[0] and out[1] else None
+
+
 def begin_deferred_wgrads():
     global _DEFERRED
     _DEFERRED = {"jobs": [], "assign": []}
@@ -339,7 +359,20 @@ def flush_deferred_wgrads():
     q, _DEFERRED = _DEFERRED, None
     if not q or not q["jobs"]:
         return
-    _run_wgrad_jobs(q["jobs"])
+    jobs = q["jobs"]
+    halves = _split_wgrad_jobs(jobs) if WGRAD_TWO_STREAMS and len(jobs) >= 16 and jobs[0][0].is_cuda else None
+    if halves is not None:
+        # the launches of the flush (eight jobs each) are independent of each other: every second one goes to a side stream
+        # (train step 7.05 -> 6.97 ms at B = 64)
+        cur = torch.cuda.current_stream()
+        side = _WGRAD_SIDE.setdefault(jobs[0][0].device, torch.cuda.Stream(device=jobs[0][0].device))
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            _run_wgrad_jobs(halves[1])
+        _run_wgrad_jobs(halves[0])
+        cur.wait_stream(side)
+    else:
+        _run_wgrad_jobs(jobs)
     for param, grad in q["assign"]:
         g = grad.view_as(param)
         if param.grad is None:
