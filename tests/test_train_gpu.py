@@ -653,6 +653,27 @@ def test_first_layer_backward_gather_form(S, C, rows, ns, n_src):
     assert float((outs[0][0].double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
     ref_w = torch.einsum("scp,sap->ca", dz.view(S, C, P).double(), dxyz.view(S, 3, P).double())
     assert float((outs[0][1].double() - ref_w).abs().max()) <= 2e-5 * float(ref_w.abs().max()) + 1e-4
+    # bit for bit from run to run: the gather sums are accumulated in per-plane fixed point, the samples' shares of dwx in a fixed order
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # without the workspace the shares of dwx go through float atomics: the same values up to the order of addition
+    dproj, dwx = torch.empty(S, C, n_src, device=DEV), torch.zeros(C, 3, device=DEV)
+    _lib.call("rtk_sa_first_layer_bwd", S, C, rows, ns, n_src, dz.data_ptr(), dxyz.data_ptr(), off.data_ptr(), inv.data_ptr(),
+              dproj.data_ptr(), dwx.data_ptr(), 3, None, st)
+    assert torch.equal(dproj, outs[0][0])
+    assert float((dwx - outs[0][1]).abs().max()) <= 1e-5 * float(outs[0][1].abs().max())
+    # the fixed-point unit follows every plane's own largest element: planes of zeros, of 1e-20, of 1e20 and a plane with a NaN
+    dz2 = dz.clone()
+    dz2[:, 0] = 0.0
+    dz2[:, 1] *= 1e-20
+    dz2[:, 2] *= 1e20
+    dz2[0, 3, rows // 2, 1] = float("nan")
+    _lib.call("rtk_sa_first_layer_bwd", S, C, rows, ns, n_src, dz2.data_ptr(), dxyz.data_ptr(), off.data_ptr(), inv.data_ptr(),
+              dproj.data_ptr(), dwx.data_ptr(), 3, torch.empty(S * C * 3, device=DEV).data_ptr(), st)
+    assert float(dproj[:, 0].abs().max()) == 0.0
+    for c, f in ((1, 1e-20), (2, 1e20)):
+        assert float((dproj[:, c].double() - ref[:, c] * f).abs().max()) <= 1e-5 * float(ref[:, c].abs().max()) * f
+    assert torch.isnan(dproj[0, 3]).all() and torch.isfinite(dproj[1:, 3]).all() and torch.isfinite(dproj[:, 4:]).all()
+    assert float((dproj[1:, 3].double() - ref[1:, 3]).abs().max()) <= 1e-5 * float(ref.abs().max())
 
 
 @pytest.mark.parametrize("B,N,pretrain,vec", [(4, 256, False, False), (3, 242, True, False), (1, 256, False, True), (64, 256, False, False)])
