@@ -55,7 +55,6 @@ __global__ __launch_bounds__(256) void pack_split_kernel(int cout, int cin, cons
 }
 
 // y = leaky(acc c + b) for a whole accumulator set (c = this lane's 2^-(kw + kx)): the epilogue between two split layers
-__device__ __forceinline__ float leaky_med(float x, float inf) { return __builtin_amdgcn_fmed3f(x, 0.1f * x, inf); }      // max(x, 0.1 x): one v_med3_f32 the compiler knows
 __device__ __forceinline__ f4 leaky_med4(f4 t, float inf) {
     const f4 u = t * 0.1f;                                                  // two v_pk_mul_f32
     return (f4){__builtin_amdgcn_fmed3f(t.x, u.x, inf), __builtin_amdgcn_fmed3f(t.y, u.y, inf), __builtin_amdgcn_fmed3f(t.z, u.z, inf),
@@ -199,15 +198,6 @@ __device__ __forceinline__ f16v wn_pre(const WnBlock &k, int hh, const float (&t
     for (int st = 0; st < 4; ++st) w = mfma_f32x2(k.w[st], hh ? t2[2 * st + 1] : t2[2 * st], w);
     return w;
 }
-__device__ __forceinline__ f16v wn_out(const WnBlock &k, int hh, const float (&t2)[8]) {
-    f16v w = wn_pre(k, hh, t2);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) w[e] = fmaxf(w[e], 0.f);
-    return w;
-}
-__device__ __forceinline__ f16v wn_out(const WnSplit &W, int v, int hh, int col, const float (&t2)[8]) { return wn_out(wn_block(W, v, hh, col), hh, t2); }
-
-__device__ __forceinline__ f4 f4_max(f4 a, f4 b) { return (f4){fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)}; }
 // max(x, 0.1 x) and max(x, 0) in ONE instruction each.  fmaxf() costs two under IEEE mode -- hipcc first quiets a possible signalling
 // NaN in every operand it did not compute itself (v_max_f32 x, x, x on each accumulator read): 32 extra VALU instructions per
 // 32-channel block of the epilogue, 256 per layer boundary -- and a median with a literal +inf (v_med3_f32) is folded back into
@@ -222,7 +212,6 @@ __device__ __forceinline__ float rtk_hidden_inf() {
 }
 __device__ __forceinline__ float relu1(float x, float inf) { return __builtin_amdgcn_fmed3f(x, 0.f, inf); }
 __device__ __forceinline__ f4 relu_med4(f4 t, float inf) { return (f4){relu1(t.x, inf), relu1(t.y, inf), relu1(t.z, inf), relu1(t.w, inf)}; }
-__device__ __forceinline__ f4 f4_relu(f4 a) { return (f4){fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)}; }
 
 // ---- layer 1's operands ---------------------------------------------------------------------------------------------------
 // The tile layout gives a lane 32 bytes of a gathered p2 row per load instruction (its own position's row, two lanes per position):
