@@ -296,6 +296,45 @@ def test_scatter_add_rows_matches_index_add(m, n, C):
     assert torch.allclose(dst.double(), ref, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_deterministic_trainer_repeats_its_trajectory_bit_for_bit(graph):
+    """Trainer(deterministic=True): six optimisation steps (lr = 1e-3, Adam) from the same weights on the same batches, twice: the
+    losses of every step, every parameter, every optimizer moment and every BatchNorm running statistic end up bit-identical --
+    eagerly and as a captured hipGraph (warm-up steps, capture, replays).  (Without the mode two runs differ by 1e-3 after a few
+    steps: test_graphed_trainer_matches_eager.)"""
+    from ratrack_amd.train import Trainer
+    B, N = 4, 256
+    batches = []
+    for i in range(6):
+        d = synth.make_frame_pairs(B, N, 40 + i)
+        batches.append({k: torch.from_numpy(v).to(DEV) for k, v in d.items()})
+
+    def run():
+        net = Track4D(Args()).to(DEV)
+        net.load_state_dict(reference_state_dict(DEV), strict=True)
+        tr = Trainer(net, graph=graph, lr=1e-3, deterministic=True)
+        h = torch.zeros(5, B, 128, device=DEV)
+        losses = []
+        for t in batches:
+            items, _ = tr.step(t["pc1"], t["pc2"], t["feature1"], t["feature2"], t["gt_warp"], t["gt_cls"], h)
+            losses.append(items["Loss"].detach().clone())
+        torch.cuda.synchronize()
+        state = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        for gi, grp in enumerate(tr.opt.state_dict()["state"].items()):
+            for k, v in grp[1].items():
+                if torch.is_tensor(v):
+                    state["opt/%d/%s" % (grp[0], k)] = v.detach().clone()
+        return torch.stack(losses), state
+
+    la, sa = run()
+    lb, sb = run()
+    assert torch.equal(la, lb)
+    assert float((la[0] - la[-1]).abs()) > 0                      # the parameters did move
+    assert sa.keys() == sb.keys() and len(sa) > 400
+    bad = [k for k in sa if not torch.equal(sa[k], sb[k])]
+    assert not bad, bad[:8]
+
+
 def test_graphed_trainer_matches_eager():
     """Trainer(graph=True): 3 eager warm-up steps, capture, replays.  With lr = 0 (parameters frozen, everything else live)
     the captured step must reproduce the eager losses and BatchNorm running statistics on every batch -- the static input
