@@ -121,7 +121,8 @@ __device__ __forceinline__ int fx_pshift(int P) {
     return 61 - lg;
 }
 __device__ __forceinline__ float fx_amax4(float am, const float4 v, unsigned &bad) {
-    bad |= (!(fabsf(v.x) <= 3.0e38f)) | (!(fabsf(v.y) <= 3.0e38f)) | (!(fabsf(v.z) <= 3.0e38f)) | (!(fabsf(v.w) <= 3.0e38f));      // infinity or NaN
+    bad |= (unsigned)(!(fabsf(v.x) <= 3.0e38f)) | (unsigned)(!(fabsf(v.y) <= 3.0e38f)) | (unsigned)(!(fabsf(v.z) <= 3.0e38f)) |
+           (unsigned)(!(fabsf(v.w) <= 3.0e38f));      // infinity or NaN
     return fmaxf(am, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
 }
 // wave partials of the plane's (dwx_x, dwx_y, dwx_z, max |dz|, non-finite flag) -> LDS; after the next barrier every thread combines them
