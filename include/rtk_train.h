@@ -118,7 +118,12 @@ RTK_EXPORT int rtk_sa_first_layer(int samples, int channels, int rows, int ns, i
  * any tensor).  Elements far below the maximum keep an absolute precision of 2^-39 of it -- below one fp32 rounding of the sums they
  * enter.  x, y (m, 256) fp32 row-major, 16-byte aligned; out 256 rows of out_pitch >= 256 floats, fully written.  workspace: at least
  * njobs * 65536 floats; with njobs * 65536 * (256 / njobs) floats the grid is one slab per CU (the slabs' partial blocks are summed
- * by a second kernel: deterministic).  Replaces the batched library GEMM of the cost volume's backward
+ * by a second kernel: deterministic).  RANGE CONTRACT (one scale per tensor, round-5 advice): an element below 2^-25 of its tensor's
+ * largest |element| loses relative precision (its low piece is an fp16 subnormal), one below 2^-39 contributes zero; a non-finite
+ * element makes the scale, and with it the whole product, non-finite.  Callers whose rows span more than that (a gradient tensor with
+ * one outlier position 10^8 above the rest) see the small rows' weight-gradient rows at that absolute floor -- below one fp32 rounding
+ * of the sum the outlier dominates, but not below the RELATIVE precision a per-channel optimiser such as Adam normalises to
+ * (tests/test_train_gpu.py::test_tn_gemm256_split_outlier_rows pins the floor).  Replaces the batched library GEMM of the cost volume's backward
  * (utils/model_utils/model_utils.py:177-183,226-231: the two 256 x 256 convolutions over N x 16 positions). */
 typedef struct {
     const float *x, *y;

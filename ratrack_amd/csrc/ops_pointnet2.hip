@@ -556,18 +556,17 @@ extern "C" int rtk_ball_query(int b, int n, int npoint, float radius, int nsampl
 }
 
 // Both scales of an MSG level in one scan (radius1 <= radius2, so every scale-1 hit is a scale-2 hit).
-__global__ __launch_bounds__(64 * BQ_WAVES) void ball_query_pair_kernel(int n, int m, float r2a, int nsa, float r2b, int nsb,
-                                                                         const float *__restrict__ new_xyz,
-                                                                         const float *__restrict__ xyz, int *__restrict__ idxa,
-                                                                         int *__restrict__ idxb, const int *__restrict__ nuniq) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int bs = blockIdx.y;
+// (body: workgroup `chunk` of sample `bs`; smem = 3 n floats.  Shared by ball_query_pair_kernel and geometry_tables_kernel.)
+__device__ __forceinline__ void ball_query_pair_body(int bs, int chunk, int n, int m, float r2a, int nsa, float r2b, int nsb,
+                                                     const float *__restrict__ new_xyz, const float *__restrict__ xyz,
+                                                     int *__restrict__ idxa, int *__restrict__ idxb, const int *__restrict__ nuniq,
+                                                     float *smem) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     xyz += (size_t)bs * n * 3;
     float *sx = smem, *sy = smem + n, *sz = smem + 2 * n;
-    const int c0 = (blockIdx.x * BQ_WAVES + wave) * BQ_CENTROIDS_PER_WAVE;
+    const int c0 = (chunk * BQ_WAVES + wave) * BQ_CENTROIDS_PER_WAVE;
     const int climit = nuniq ? min(m, nuniq[bs]) : m;
-    if (blockIdx.x * BQ_WAVES * BQ_CENTROIDS_PER_WAVE >= climit) return;      // whole workgroup beyond the unique centroids
+    if (chunk * BQ_WAVES * BQ_CENTROIDS_PER_WAVE >= climit) return;      // whole workgroup beyond the unique centroids
     for (int k = tid; k < n; k += 64 * BQ_WAVES) {
         sx[k] = xyz[k * 3 + 0];
         sy[k] = xyz[k * 3 + 1];
@@ -611,6 +610,14 @@ __global__ __launch_bounds__(64 * BQ_WAVES) void ball_query_pair_kernel(int n, i
         if (fa >= 0 && ca < nsa) for (int l = ca + lane; l < nsa; l += 64) oa[l] = fa;
         if (fb >= 0 && cb < nsb) for (int l = cb + lane; l < nsb; l += 64) ob[l] = fb;
     }
+}
+
+__global__ __launch_bounds__(64 * BQ_WAVES) void ball_query_pair_kernel(int n, int m, float r2a, int nsa, float r2b, int nsb,
+                                                                         const float *__restrict__ new_xyz,
+                                                                         const float *__restrict__ xyz, int *__restrict__ idxa,
+                                                                         int *__restrict__ idxb, const int *__restrict__ nuniq) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    ball_query_pair_body(blockIdx.y, blockIdx.x, n, m, r2a, nsa, r2b, nsb, new_xyz, xyz, idxa, idxb, nuniq, smem);
 }
 
 extern "C" int rtk_ball_query_pair(int b, int n, int npoint, float radius1, int nsample1, float radius2, int nsample2,
@@ -844,14 +851,15 @@ __device__ __forceinline__ void kv_row_merge(unsigned (&d)[K], int (&i)[K]) {
 // Output: the 3 smallest squared distances ascending + indices, ties -> earlier index; fewer than 3
 // known points leave (+inf, 0) in the unfilled slots (the reference's double 1e40 narrowed to float).
 // ------------------------------------------------------------------------------------------------
+// (body: workgroup `chunk` -- 16 queries -- of sample `bs`; smem = 3 m floats with USE_LDS.  Shared by three_nn_kernel and
+// geometry_tables_kernel.)
 template <bool USE_LDS>
-__global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float *__restrict__ unknown,
-                                                       const float *__restrict__ known, float *__restrict__ dist2,
-                                                       int *__restrict__ idx, const int *__restrict__ unknown_nuniq,
-                                                       const int *__restrict__ known_nuniq) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int bs = blockIdx.y, tid = threadIdx.x;
-    if (unknown_nuniq && blockIdx.x * 16 >= unknown_nuniq[bs]) return;    // all 16 queries of this workgroup are duplicate rows
+__device__ __forceinline__ void three_nn_body(int bs, int chunk, int n, int m, const float *__restrict__ unknown,
+                                              const float *__restrict__ known, float *__restrict__ dist2,
+                                              int *__restrict__ idx, const int *__restrict__ unknown_nuniq,
+                                              const int *__restrict__ known_nuniq, float *smem) {
+    const int tid = threadIdx.x;
+    if (unknown_nuniq && chunk * 16 >= unknown_nuniq[bs]) return;    // all 16 queries of this workgroup are duplicate rows
     // known rows >= known_nuniq[b] are copies of known row 0: of those only the first two (lowest indices) can reach the
     // top 3, at the distance of row 0 -- scan the unique prefix and add these two candidates: identical result, half the scan
     const int m_full = m;
@@ -861,7 +869,7 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float
     float *sx = smem, *sy = smem + m, *sz = smem + 2 * m;
     // the query's coordinates are requested before the staging loop and its barrier: one global round trip instead of two in a row
     const int li = tid & 15;
-    const int pt_raw = blockIdx.x * 16 + (tid >> 4);
+    const int pt_raw = chunk * 16 + (tid >> 4);
     const int pt = pt_raw < n ? pt_raw : n - 1;
     const float *u = unknown + ((size_t)bs * n + pt) * 3;
     const float ux = u[0], uy = u[1], uz = u[2];
@@ -908,6 +916,15 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float
             oi[a] = d[a] == KEY_INF_D ? 0 : i[a];
         }
     }
+}
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float *__restrict__ unknown,
+                                                       const float *__restrict__ known, float *__restrict__ dist2,
+                                                       int *__restrict__ idx, const int *__restrict__ unknown_nuniq,
+                                                       const int *__restrict__ known_nuniq) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    three_nn_body<USE_LDS>(blockIdx.y, blockIdx.x, n, m, unknown, known, dist2, idx, unknown_nuniq, known_nuniq, smem);
 }
 
 extern "C" int rtk_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
@@ -1101,12 +1118,14 @@ extern "C" int rtk_three_interpolate_grad_set(int b, int c, int n, int m, const 
 // Distances follow the expansion formula of the arithmetic contract so the neighbour SET equals the
 // CPU reference's; output order is (distance, index) ascending.
 // ------------------------------------------------------------------------------------------------
+// (body: workgroup `chunk` -- 16 queries -- of sample `bs`; smem = 4 n floats with USE_LDS.  Component c of point j of a sample sits
+// at base + j * ps + c * cs: (ps, cs) = (3, 1) for point-major (n, 3) clouds, (1, pitch) for the API's channel-major (3, n) ones.
+// Shared by knn_point_kernel and geometry_front_kernel.)
 template <int K, bool USE_LDS>
-__global__ __launch_bounds__(256) void knn_point_kernel(int s, int n, int k, const float *__restrict__ query,
-                                                        const float *__restrict__ points, int64_t *__restrict__ idx,
-                                                        const int *__restrict__ nvalid) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int bs = blockIdx.y, tid = threadIdx.x;
+__device__ __forceinline__ void knn_point_body(int bs, int chunk, int s, int n, int k, const float *__restrict__ query, int q_ps, int q_cs,
+                                               const float *__restrict__ points, int p_ps, int p_cs, int64_t *__restrict__ idx,
+                                               const int *__restrict__ nvalid, float *smem) {
+    const int tid = threadIdx.x;
     points += (size_t)bs * n * 3;
     if (nvalid) {     // padded batch: only the sample's own first nvalid[bs] points are candidates (the row pitch stays n)
         const int nv = nvalid[bs];
@@ -1115,17 +1134,17 @@ __global__ __launch_bounds__(256) void knn_point_kernel(int s, int n, int k, con
     float *sx = smem, *sy = smem + n, *sz = smem + 2 * n, *sn = smem + 3 * n;
     if (USE_LDS) {
         for (int j = tid; j < n; j += 256) {
-            const float px = points[j * 3 + 0], py = points[j * 3 + 1], pz = points[j * 3 + 2];
+            const float px = points[j * p_ps], py = points[j * p_ps + p_cs], pz = points[j * p_ps + 2 * p_cs];
             sx[j] = px; sy[j] = py; sz[j] = pz;
             sn[j] = __fadd_rn(__fadd_rn(__fmul_rn(px, px), __fmul_rn(py, py)), __fmul_rn(pz, pz));
         }
         __syncthreads();
     }
     const int li = tid & 15;
-    const int qi_raw = blockIdx.x * 16 + (tid >> 4);
+    const int qi_raw = chunk * 16 + (tid >> 4);
     const int qi = qi_raw < s ? qi_raw : s - 1;
-    const float *q = query + ((size_t)bs * s + qi) * 3;
-    const float qx = q[0], qy = q[1], qz = q[2];
+    const float *q = query + (size_t)bs * s * 3 + (size_t)qi * q_ps;
+    const float qx = q[0], qy = q[q_cs], qz = q[2 * q_cs];
     const float qn = __fadd_rn(__fadd_rn(__fmul_rn(qx, qx), __fmul_rn(qy, qy)), __fmul_rn(qz, qz));
     unsigned bd[K];
     int bi[K];
@@ -1142,7 +1161,7 @@ __global__ __launch_bounds__(256) void knn_point_kernel(int s, int n, int k, con
                 float px, py, pz, pn;
                 if (USE_LDS) { px = sx[j]; py = sy[j]; pz = sz[j]; pn = sn[j]; }
                 else {
-                    px = points[j * 3 + 0]; py = points[j * 3 + 1]; pz = points[j * 3 + 2];
+                    px = points[j * p_ps]; py = points[j * p_ps + p_cs]; pz = points[j * p_ps + 2 * p_cs];
                     pn = __fadd_rn(__fadd_rn(__fmul_rn(px, px), __fmul_rn(py, py)), __fmul_rn(pz, pz));
                 }
                 const float dot = __fmaf_rn(qz, pz, __fmaf_rn(qy, py, __fmul_rn(qx, px)));
@@ -1161,6 +1180,14 @@ __global__ __launch_bounds__(256) void knn_point_kernel(int s, int n, int k, con
         for (int a = 0; a < K; ++a)
             if (a < k) o[a] = bi[a];
     }
+}
+
+template <int K, bool USE_LDS>
+__global__ __launch_bounds__(256) void knn_point_kernel(int s, int n, int k, const float *__restrict__ query,
+                                                        const float *__restrict__ points, int64_t *__restrict__ idx,
+                                                        const int *__restrict__ nvalid) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    knn_point_body<K, USE_LDS>(blockIdx.y, blockIdx.x, s, n, k, query, 3, 1, points, 3, 1, idx, nvalid, smem);
 }
 
 // Any k (the reference's torch.topk takes any k <= n; the live k is 16): one wave per query, k rounds of "smallest (distance, index)

@@ -44,8 +44,8 @@ class Track4D(nn.Module):
         self._fused = None     # lazily built fused inference engine (ratrack_amd.fused)
         self._fused_version = -1
         self._fused_tensors = None
-        self.use_fused = True
-        self.dedup_train = True   # training mode: PNHead on de-duplicated levels with the HIP BatchNorm operators (train_path.py)
+        self._use_fused = True
+        self._dedup_train = True   # training mode: PNHead on de-duplicated levels with the HIP BatchNorm operators (train_path.py)
 
     # ---- hot path ---------------------------------------------------------------------------------
     def backbone(self, pc1, pc2, feature1, feature2, h, n_valid=None):
@@ -56,9 +56,9 @@ class Track4D(nn.Module):
         itself only runs B = 1): every sample's valid columns equal its own unpadded B = 1 result."""
         # eval mode runs the fused inference engine -- also with autograd enabled (the reference's evaluation loop calls
         # net.eval() but never enters torch.no_grad(), main_utils.py:44-127), as long as no INPUT asks for a gradient; the
-        # outputs then carry no graph.  Set use_fused = False to differentiate through an eval-mode forward.
+        # outputs then carry no graph.  (An input that requires a gradient takes the module path below by itself; `_use_fused` is a test hook.)
         wants_graph = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (pc1, pc2, feature1, feature2, h))
-        if self.use_fused and not self.training and not wants_graph and pc1.is_cuda:
+        if self._use_fused and not self.training and not wants_graph and pc1.is_cuda:
             eng = self._fused_engine()
             N1, N2 = pc1.shape[2], pc2.shape[2]
             if N1 == N2:
@@ -74,13 +74,13 @@ class Track4D(nn.Module):
                     f1[:, :, :N1].contiguous(), f2[:, :, :N2].contiguous(), prop[:, :, :N1].contiguous())
         tg1 = nv = None
         cut = None
-        if self.training and self.dedup_train and pc1.is_cuda:
+        if self.training and self._dedup_train and pc1.is_cuda:
             from . import train_path as TP
             if not (TP.supported(self.pn_head) and TP.supported(self.fd_layer.mse) and TP.correlator_supported(self.fc_layer)):
                 # no silent drop to the framework's convolutions: the module path is an explicit choice
                 raise NotImplementedError("Track4D: this layer configuration is outside the hand-written training path (max-pooled MSG "
                                           "levels of Conv2d(no bias)+BatchNorm2d+ReLU, 3x256-channel correlator without BatchNorm); set "
-                                          "net.dedup_train = False to train it on the module path (PyTorch-ROCm dense layers)")
+                                          "the module path (PyTorch-ROCm dense layers) is reachable through the test hook net._dedup_train only")
             # training step: both frames as one stacked batch (per-frame BatchNorm statistics) on de-duplicated levels.
             # Clouds of different sizes -- every real consecutive pair (dataset_classes/track_vod_3d.py:80-84,119), or a padded
             # batch with n_valid -- are padded with copies of their own point 0 and travel with their true counts on the
@@ -162,7 +162,7 @@ class Track4D(nn.Module):
 
     def _fused_engine(self):
         """The folded / packed inference engine (ratrack_amd.fused.FusedBackbone), rebuilt when the weights moved.  There is no
-        fallback: a missing HIP library or fused module raises (the module path is an explicit choice, `use_fused = False`)."""
+        fallback: a missing HIP library or fused module raises (the module path is the tests' comparison implementation, behind the `_use_fused` hook)."""
         if self._fused is not None and self._fused_version != self._weights_version():
             self._fused = None          # weights were edited in place since the engine folded / packed them
         if self._fused is None:

@@ -41,7 +41,11 @@ class Trainer:
                  deterministic=False):
         """deterministic: every step is reproducible bit for bit -- gradients, losses, outputs, hence the whole trajectory from the same
         weights and batches (train_ops.set_deterministic: order-independent batch statistics and first-layer weight gradients; about
-        3 % slower at B = 64; across ranks the RCCL all-reduce sums in its own fixed order)."""
+        3 % slower at B = 64; across ranks the RCCL all-reduce sums in its own fixed order).
+        Range of the exact statistics (csrc/rtk_common.h rtk_stat_add): a forward addend must stay below 2^53 units of 2^-36, a backward
+        addend (an element of dy or dy.x_hat) below 2^23 = 8.4e6 in magnitude; beyond that -- a gradient spike, a loss scale of 1e7 --
+        the statistic reads NaN in this mode (the default mode's float64 atomics take such a step).  Addends are truncated towards zero
+        at their unit (2^-36 / 2^-66), a downward bias far below fp32 rounding."""
         self.model = model
         self.deterministic = bool(deterministic)
         self._dev = next(model.parameters()).device

@@ -360,6 +360,21 @@ def flush_deferred_wgrads():
     if not q or not q["jobs"]:
         return
     jobs = q["jobs"]
+    if jobs[0][0].is_cuda:
+        # explicit ordering (round-5 advice): a job queued by a backward that ran on one of the MSG side streams (train_path._msg_scales)
+        # has its dz / source tensors produced THERE; the flush reads them on the current stream (and the weight-gradient side stream,
+        # which forks from it below).  The autograd engine's end-of-backward stream sync happens to order the two today; this does not
+        # depend on it (stream waits are a few hundred nanoseconds each and graph-capturable).
+        from . import train_path as _TP
+        cur = torch.cuda.current_stream()
+        capturing = torch.cuda.is_current_stream_capturing()
+        for (dev_, _key), s_ in list(_TP._MSG_SIDE.items()):
+            if dev_ != jobs[0][0].device:
+                continue
+            with torch.cuda.stream(s_):
+                same = torch.cuda.is_current_stream_capturing() == capturing
+            if same:      # (a side stream this capture never forked has no work of this step, and may not be joined from inside it)
+                cur.wait_stream(s_)
     halves = _split_wgrad_jobs(jobs) if WGRAD_TWO_STREAMS and len(jobs) >= 16 and jobs[0][0].is_cuda else None
     if halves is not None:
         # the launches of the flush (eight jobs each) are independent of each other: every second one goes to a side stream

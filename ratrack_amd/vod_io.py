@@ -10,8 +10,8 @@
   authors' AB3DMOT-style evaluation.  Numbers are written with Python's repr of the float32 value promoted to float, as the
   reference's str(float(t)) does, so files compare byte for byte.
 
-Host-side code (numpy / file I/O); not part of the GPU path.  GT generation (tracking labels, oriented boxes) stays out of
-scope: it depends on the VoD devkit's label and calibration tooling.
+Host-side code (numpy / file I/O); not part of the GPU path.  GT generation (tracking labels, oriented boxes, GT flow and object
+mappings from the VoD label / calibration / pose files) is ratrack_amd/vod_gt.py.
 """
 import os
 

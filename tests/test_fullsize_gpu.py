@@ -54,7 +54,7 @@ def test_b32_n256_config2_forward():
             for name, a, b in zip(NAMES, full, one):
                 a_i = a[:, i:i + 1] if name == "h" else a[i:i + 1]
                 assert torch.equal(a_i, b), "sample %d: %s depends on the batch" % (i, name)
-        net.use_fused = False
+        net._use_fused = False
         ref = net.backbone(*t, None)
     for name, a, b in zip(NAMES, full, ref):
         assert rel_err(a.cpu(), b.cpu()) <= RTOL, name
@@ -91,7 +91,7 @@ def test_b64_fused_matches_module_path():
     net, t = make(64, 256, 1001)
     with torch.no_grad():
         fused = net.backbone(*t, None)
-        net.use_fused = False
+        net._use_fused = False
         ref = net.backbone(*t, None)
     for name, a, b in zip(NAMES, fused, ref):
         assert rel_err(a.cpu(), b.cpu()) <= RTOL, name
@@ -125,11 +125,11 @@ def test_n1024_stress_config():
     net, t = make(4, 1024, 1004)
     with torch.no_grad():
         fused = net.backbone(*t, None)
-        net.use_fused = False
+        net._use_fused = False
         ref = net.backbone(*t, None)
     for name, a, b in zip(NAMES, fused, ref):
         assert rel_err(a.cpu(), b.cpu()) <= RTOL, name
-    net.use_fused = True
+    net._use_fused = True
     net32, t32 = make(32, 1024, 1005)
     with torch.no_grad():
         out = net32.backbone(*t32, None)
@@ -143,7 +143,7 @@ def test_odd_shapes_fused_matches_module_path(b, n):
     net, t = make(b, n, 1100 + n)
     with torch.no_grad():
         fused = net.backbone(*t, None)
-        net.use_fused = False
+        net._use_fused = False
         ref = net.backbone(*t, None)
     for name, a, r in zip(NAMES, fused, ref):
         assert rel_err(a.cpu(), r.cpu()) <= RTOL, name

@@ -355,7 +355,7 @@ def test_fused_backbone_matches_golden(name):
     from _util import RTOL, assert_close, inputs_of, load_case
     case = load_case(name)
     net = _net()
-    assert net.use_fused
+    assert net._use_fused
     pc1, pc2, f1, f2 = inputs_of(case, DEV)
     with torch.no_grad():
         flow, h, cls, cor, pf1, pf2, prop = net.backbone(pc1, pc2, f1, f2, None)
@@ -575,10 +575,10 @@ def test_padded_variable_n_batch():
     with torch.no_grad():
         h0 = torch.randn(5, 3, 128, device=DEV, generator=torch.Generator(DEV).manual_seed(17)) * 0.1      # (seeded: the comparison is data dependent)
         out = net.backbone(pc1, pc2, f1, f2, h0, n_valid=nv)
-        net.use_fused = False
+        net._use_fused = False
         ref = net.backbone(pc1, pc2, f1, f2, h0, n_valid=nv)                  # per-sample, unpadded, module path
         singles = [net.backbone(*p, h0[:, b:b + 1].contiguous()) for b, p in enumerate(pairs)]
-        net.use_fused = True
+        net._use_fused = True
         fused_singles = [net.backbone(*p, h0[:, b:b + 1].contiguous()) for b, p in enumerate(pairs)]
     for b in range(3):
         n1, n2 = int(nv[0, b]), int(nv[1, b])

@@ -23,7 +23,7 @@ def make_net(train=False):
 def test_backbone_modules_match_golden(name):
     case = load_case(name)
     net = make_net()
-    net.use_fused = False
+    net._use_fused = False
     pc1, pc2, f1, f2 = inputs_of(case, DEV)
     with torch.no_grad():
         flow, h, cls, cor, pf1, pf2, prop = net.backbone(pc1, pc2, f1, f2, None)
@@ -301,3 +301,76 @@ def test_gt_train_iteration_on_shipped_frames_matches_reference():
         assert r["e_ref"] <= 5e-3, (r["name"], r["e_ref"])
         assert abs(r["probe"] - r["ref_probe"]) <= 1e-2 * r["ref_norm"], r
     assert np.median(err) <= 5e-4 and np.quantile(err, 0.9) <= 2e-3, (np.median(err), np.quantile(err, 0.9))
+
+
+def test_result_file_from_gpu_forward(tmp_path):
+    """SURVEY 8(f4) on the GPU path: Track4D.forward()'s `objects` / `confs` ON THE DEVICE -> vod_io.write_track_results -> one text file
+    per frame (main_utils.py:165-184), for (a) the two consecutive frames of the reference's own forward() fixture -- the file's track
+    ids, line count and per-object point counts are the reference's, the confidences its to 1e-4 -- and (b) an epoch-style pass over
+    the radar frames the reference ships (files -> vod_gt.frame_pair_gt -> forward()).  Every line is compared with the reference's own
+    string construction applied to the device tensors, and parsed back against them."""
+    from ratrack_amd import vod_gt, vod_io
+
+    def reference_lines(objects, confs):                                 # main_utils.py:170-182, literally
+        out, idx = [], -1
+        for obj_id, obj in objects.items():
+            idx += 1
+            s = "NA"
+            s += " 1"
+            s += " -1"
+            s += " -1"
+            s += " " + str(float(confs[idx]))
+            s += " " + str(obj_id)
+            for i in range(obj.size(2)):
+                s += " " + str(float(obj[0, 3, i]))
+                s += " " + str(float(obj[0, 4, i]))
+                s += " " + str(float(obj[0, 5, i]))
+            out.append(s + "\n")
+        return out
+
+    def check_file(path, objects, confs, pc1):
+        assert all(o.is_cuda for o in objects.values()), "the objects of a GPU forward() live on the device"
+        text = open(path).read()
+        assert text == "".join(reference_lines(objects, confs))
+        rows = vod_io.read_track_results(path)
+        assert [r[0] for r in rows] == list(objects.keys())
+        cloud = pc1[0].t().double().cpu().numpy()                        # (N, 3): every written point is a point of the input cloud
+        for k, (obj_id, conf, pts) in enumerate(rows):
+            obj = objects[obj_id]
+            assert abs(conf - float(confs[k])) < 1e-12 and 0.0 <= conf <= 1.0
+            assert pts.shape == (obj.shape[2], 3)
+            assert np.array_equal(pts, obj[0, 3:6].t().double().cpu().numpy())       # str(float(.)) round-trips a float32 exactly
+            assert all((np.abs(cloud - p).max(1) == 0).any() for p in pts)
+        return rows
+
+    sd = reference_state_dict(DEV)
+    sd["fd_layer.cp.linear.bias"] = sd["fd_layer.cp.linear.bias"] + 0.09          # tools/make_golden.py FORWARD_CLS_BIAS_SHIFT
+    net = Track4D(Args()).to(DEV)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    # (a) the reference's two-frame forward() fixture
+    case = load_case("forward_b1_n256")
+    objects_prev, h = dict(), torch.zeros(5, 1, 128, device=DEV)
+    with torch.no_grad():
+        for fi in range(2):
+            g = lambda k: torch.from_numpy(case["f%d_in_%s" % (fi, k)]).to(DEV)
+            h, _, _, _, _, _, confs, objects, _, _ = net(g("pc1"), g("pc2"), g("feature1"), g("feature2"), h, objects_prev)
+            path = vod_io.write_track_results(str(tmp_path), "fixture_seq", fi, objects, confs)
+            assert path.endswith("fixture_seq/%05d.txt" % fi)
+            rows = check_file(path, objects, confs, g("pc1"))
+            p = "f%d_" % fi
+            assert [r[0] for r in rows] == case[p + "object_ids"].tolist()
+            assert [r[2].shape[0] for r in rows] == case[p + "object_sizes"].tolist()
+            assert np.allclose([r[1] for r in rows], case[p + "confs"], atol=1e-4)
+            objects_prev = {k: v.clone().detach() for k, v in objects.items()}
+    # (b) the shipped radar frames, as the eval loop walks them (later frame = pc1)
+    objects_prev, h = dict(), torch.zeros(5, 1, 128, device=DEV)
+    written = 0
+    with torch.no_grad():
+        for index, (later, earlier) in enumerate([("01047", "01201"), ("00549", "01047")]):
+            g = vod_gt.frame_pair_gt(_example_frame(later), _example_frame(earlier), device=DEV)
+            h, _, _, _, _, _, confs, objects, _, _ = net(g.pc1, g.pc2, g.feature1, g.feature2, h, objects_prev)
+            path = vod_io.write_track_results(str(tmp_path), "delft_example", index, objects, confs)
+            written += len(check_file(path, objects, confs, g.pc1))
+            objects_prev = {k: v.clone().detach() for k, v in objects.items()}
+    assert written > 0, "no object on the shipped frames: the file path was not exercised"

@@ -11,7 +11,7 @@ DEV = "cuda"
 
 def run(dedup, dtype=torch.float32):
     net = T.make_net()
-    net.dedup_train = dedup
+    net._dedup_train = dedup
     if dtype == torch.float64:
         net = net.double()
     rec = {}

@@ -11,7 +11,7 @@ DEV = "cuda"
 
 def run(dedup):
     net = T.make_net()
-    net.dedup_train = dedup
+    net._dedup_train = dedup
     rec = {}
     fp = net.fd_layer.fp
     orig_fwd = fp.forward

@@ -17,7 +17,7 @@ def run(with_trk, dedup=True, sf=0.5):
     sd = reference_state_dict(DEV)
     sd["fd_layer.cp.linear.bias"] = sd["fd_layer.cp.linear.bias"] + 0.09
     net = Track4D(Args()).to(DEV); net.load_state_dict(sd, strict=True); net.train()
-    net.dedup_train = dedup
+    net._dedup_train = dedup
     g = lambda fi, k: torch.from_numpy(case["f%d_in_%s" % (fi, k)]).to(DEV)
     h = torch.zeros(5, 1, 128, device=DEV)
     h, _, _, _, _, _, _, objects, _, _ = net(g(0, "pc1"), g(0, "pc2"), g(0, "feature1"), g(0, "feature2"), h, dict())

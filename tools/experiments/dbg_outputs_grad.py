@@ -13,7 +13,7 @@ d = synth.make_frame_pairs(B, N, 21)
 t = {k: torch.from_numpy(v).to(DEV) for k, v in d.items()}
 names = ["flow", "h", "cls", "cor", "f1", "f2", "prop"]
 def run(dedup, which, sparse=False):
-    net = Track4D(Args()).to(DEV); net.load_state_dict(reference_state_dict(DEV), strict=True); net.train(); net.dedup_train = dedup
+    net = Track4D(Args()).to(DEV); net.load_state_dict(reference_state_dict(DEV), strict=True); net.train(); net._dedup_train = dedup
     outs = net.backbone(t["pc1"], t["pc2"], t["feature1"], t["feature2"], torch.zeros(5, B, 128, device=DEV))
     o = outs[which]
     g = torch.Generator(DEV).manual_seed(which)

@@ -38,7 +38,7 @@ timeit("three_nn 512x512", lambda: PU.three_nn(l1, l1))
 timeit("knn_point k=16", lambda: PU.knn_point(16, xyz, xyz))
 net = Track4D(Args()).to(dev).eval()
 synth.fill_state_dict(net.state_dict())
-net.use_fused = False
+net._use_fused = False
 with torch.no_grad():
     timeit("backbone (module path) B=%d" % B, lambda: net.backbone(pc1, pc2, f1, f2, None), iters=5)
     t0 = time.time(); net.backbone(pc1, pc2, f1, f2, None); torch.cuda.synchronize(); print("one fwd wall %.1f ms" % ((time.time() - t0) * 1e3))
