@@ -210,6 +210,28 @@ RTK_EXPORT int rtk_ball_query_pair(int b, int n, int npoint, float radius1, int 
 RTK_EXPORT int rtk_three_nn_masked(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
                                    const int *unknown_nuniq, const int *known_nuniq, rtk_stream_t stream);
 
+/* The geometry of a batch of frame pairs in two launches (round 6) -- bit for bit the tables of the eleven launches they replace
+ * (sampling_gpu.cu:94-209 x 3 levels, ball_query_gpu.cu:9-45 x 6, interpolate_gpu.cu:81-124 x 3, model_utils.py:85-99 x 2).
+ *
+ * rtk_geometry_front: everything that depends on the input clouds only.  frame1 / frame2: the b clouds of each frame,
+ * channel_major != 0: the API's (B,3,n) tensors, else point-major (B,n,3); clouds = 2 b, or b (frame 1 only, frame2 unused, no kNN; S below
+ * stands for `clouds`).  With xyz / raw (together, with the (B,2,n) features):
+ * rtk_prepare_inputs' outputs.  The three PNHead levels of rtk_fps_centroids + rtk_fps_relevel: fps_idx (3,S,npoint) int32,
+ * new_xyz (3,S,npoint,3), nuniq (3,S), tie (3,S), first_tie (S) (zero-initialised), snap (S,n).  n_valid (S) optional.
+ * knn12 / knn11 (B,n,16) int64 (optional, together): rtk_knn_point_masked of frame 1 in frame 2 / in frame 1, k = 16.
+ * n <= 2048, npoint <= 512. */
+RTK_EXPORT int rtk_geometry_front(int b, int clouds, int n, int npoint, const float *frame1, const float *frame2, int channel_major,
+                                  const float *feature1, const float *feature2, float *xyz, float *raw, int *fps_idx, float *new_xyz,
+                                  int *nuniq, int *tie, int *first_tie, float *snap, const int *n_valid, int64_t *knn12, int64_t *knn11,
+                                  rtk_stream_t stream);
+/* rtk_geometry_tables: the six ball queries (rtk_ball_query_pair per level) and the three three-NN tables (rtk_three_nn_masked) of a
+ * PNHead.  xyz0 (S,n,3) point-major clouds; new_xyz / nuniq as written by rtk_geometry_front.  radii, nsamples: HOST arrays of six
+ * (level-major, scale 0 then 1, radii ascending within a level); ball: host array of six device tables (S,npoint,nsample) int32,
+ * zero-initialised by the caller; nn_idx / nn_dist2: host arrays of three device tables [fp3, fp2, fp1]: (S,npoint,3) x 2, (S,n,3). */
+RTK_EXPORT int rtk_geometry_tables(int samples, int n, int npoint, const float *xyz0, const float *new_xyz, const int *nuniq,
+                                   const float *radii, const int *nsamples, int *const *ball, int *const *nn_idx, float *const *nn_dist2,
+                                   rtk_stream_t stream);
+
 /* Several rtk_to_channel_major jobs in one launch. */
 typedef struct {
     const float *src; float *dst;

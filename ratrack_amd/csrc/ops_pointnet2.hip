@@ -128,7 +128,10 @@ __device__ __forceinline__ int fps_wave_body(int n, int m, int block, const floa
                                              int &tie_out, float *__restrict__ snap = nullptr, int *__restrict__ first_tie = nullptr,
                                              int settle_from = -1, int nu_prev = 0, int j_start = 1,
                                              const float *__restrict__ st_snap = nullptr, const int *__restrict__ st_i1 = nullptr,
-                                             const int *__restrict__ st_i2 = nullptr) {
+                                             const int *__restrict__ st_i2 = nullptr, int ps = 3, int cs = 1, int *first_tie_val = nullptr) {
+    // (ps, cs): component c of point k sits at xyz[k * ps + c * cs] -- (3, 1) for point-major clouds, (1, pitch) for the API's
+    // channel-major (3, n) tensors (rtk_geometry_front reads those directly; level 1 only: the copies of the resumed / settled paths
+    // below are point-major).  first_tie_val (optional): the first tied round as a value (0: none), for a caller that goes on in-kernel.
     // Re-levelling (rtk_fps_relevel): settle_from = the previous level's last tied round; j_start > 1 = resume: rounds < j_start are
     // the identity (every level repeats level 1 exactly before level 1's FIRST tied round) and the min-distance state of round
     // j_start is level 1's, saved by ORIGINAL point index in st_snap -- a function of the point, carried to this level's cloud
@@ -138,7 +141,7 @@ __device__ __forceinline__ int fps_wave_body(int n, int m, int block, const floa
     const int bits = 31 - __builtin_clz(block);
     const int q = n >> bits, rem = n & (block - 1);
     for (int k = lane; k < n; k += 64)      // coalesced read of the cloud, scattered into tie order
-        s_pt[fps_index_to_pos(k, block, bits, q, rem)] = make_float4(xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2], __int_as_float(k));
+        s_pt[fps_index_to_pos(k, block, bits, q, rem)] = make_float4(xyz[k * ps], xyz[k * ps + cs], xyz[k * ps + 2 * cs], __int_as_float(k));
     __syncthreads();
 
     // LANE-MAJOR layout: lane l owns positions PPL*l .. PPL*l + PPL-1, so "smallest position among the maxima" =
@@ -222,6 +225,7 @@ __device__ __forceinline__ int fps_wave_body(int n, int m, int block, const floa
                 if (p < n) snap[__float_as_int(s_pt[p].w)] = __uint_as_float(t[i]);
             }
             if (lane == 0) *first_tie = j;
+            if (first_tie_val) *first_tie_val = j;
         }
         tie = tied_now ? j : tie;
         const int pos = wl * PPL + (w & 0xff);
@@ -258,6 +262,34 @@ __device__ __forceinline__ int fps_wave_body(int n, int m, int block, const floa
     return j;
 }
 
+// One level of one cloud by one wave; every pointer is the cloud's own.  tie_prev < 0: a first level; tie_prev == 0: re-levelling of a
+// cloud whose previous level had no tie (the identity, copied); tie_prev > 0: re-levelling that runs the selection (resumed at
+// j_start, settling past round tie_prev).  nvalid >= 0: padded cloud.  Returns the picks made before the cloud was exhausted.
+// (Shared by fps_wave_kernel and geometry_front_kernel.)
+template <int PPL>
+__device__ __forceinline__ int fps_cloud_level(int n, int m, int block, const float *__restrict__ xyz, int ps, int cs, float *__restrict__ temp,
+                                               int *__restrict__ idxs, float *__restrict__ new_xyz, float4 *s_pt, int lane, int &tie_out,
+                                               int nvalid, float *__restrict__ snap, int *__restrict__ first_tie, int tie_prev, int nu_prev,
+                                               int j_start, const float *__restrict__ snap1, const int *__restrict__ idx1,
+                                               const int *__restrict__ idx2, int *first_tie_val = nullptr) {
+    if (tie_prev == 0) {
+        // Re-levelling (rtk_fps_relevel; n == m): the previous level's selection of this cloud had no tie, so this level is the
+        // identity on the coordinates (proof at rtk_fps_relevel) -- idx = (0 .. U-1, 0, 0, ...), new_xyz = xyz, no tie.
+        for (int jj = lane; jj < m; jj += 64) idxs[jj] = jj < nu_prev ? jj : 0;
+        for (int jj = lane; jj < 3 * m; jj += 64) new_xyz[jj] = xyz[jj];
+        tie_out = 0;
+        return nu_prev;
+    }
+    if (nvalid >= 0) {     // padded batch: this sample's cloud is its first nvalid points; the tie rule follows ITS size
+        n = nvalid < n ? nvalid : n;
+        n = n < 1 ? 1 : n;
+        block = 1 << (31 - __builtin_clz(n));      // == cuda_utils.h:10-14 for every n < 2^21 (checked exhaustively)
+        block = block > 1024 ? 1024 : block;
+    }
+    return fps_wave_body<PPL>(n, m, block, xyz, temp, idxs, new_xyz, s_pt, lane, tie_out, snap, first_tie, tie_prev, tie_prev >= 0 ? nu_prev : 0,
+                              j_start, snap1, idx1, idx2, ps, cs, first_tie_val);
+}
+
 template <int PPL>
 __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, const float *__restrict__ xyz,
                                                       float *__restrict__ temp, int *__restrict__ idxs,
@@ -271,34 +303,13 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(int n, int m, int block, c
     const int b = blockIdx.x;
     int tied;
     const int pitch = n;
-    if (tie_prev && tie_prev[b] == 0) {
-        // Re-levelling (rtk_fps_relevel; n == m): the previous level's selection of this cloud had no tie, so this level is the
-        // identity on the coordinates (proof at rtk_fps_relevel) -- idx = (0 .. U-1, 0, 0, ...), new_xyz = xyz, no tie.
-        const int lane = (int)threadIdx.x, nu = nuniq_prev[b];
-        const float *src = xyz + (size_t)b * m * 3;
-        int *io = idxs + (size_t)b * m;
-        float *xo = new_xyz + (size_t)b * m * 3;
-        for (int jj = lane; jj < m; jj += 64) io[jj] = jj < nu ? jj : 0;
-        for (int jj = lane; jj < 3 * m; jj += 64) xo[jj] = src[jj];
-        if (lane == 0) {
-            nuniq[b] = nu;
-            if (tie) tie[b] = 0;
-        }
-        return;
-    }
-    if (nvalid) {     // padded batch: this sample's cloud is its first nvalid[b] points; the tie rule follows ITS size
-        n = nvalid[b] < n ? nvalid[b] : n;
-        n = n < 1 ? 1 : n;
-        block = 1 << (31 - __builtin_clz(n));      // == cuda_utils.h:10-14 for every n < 2^21 (checked exhaustively)
-        block = block > 1024 ? 1024 : block;
-    }
-    const int j = fps_wave_body<PPL>(n, m, block, xyz + (size_t)b * pitch * 3, temp ? temp + (size_t)b * pitch : nullptr,
-                                     idxs + (size_t)b * m, new_xyz ? new_xyz + (size_t)b * m * 3 : nullptr, s_pt,
-                                     (int)threadIdx.x, tied, snap ? snap + (size_t)b * pitch : nullptr, first_tie ? first_tie + b : nullptr,
-                                     tie_prev ? tie_prev[b] : -1, tie_prev ? nuniq_prev[b] : 0,
-                                     (first_tie1 && first_tie1[b] > 1 && first_tie1[b] < m) ? first_tie1[b] : 1,
-                                     snap1 ? snap1 + (size_t)b * snap_pitch : nullptr, idx1 ? idx1 + (size_t)b * m : nullptr,
-                                     idx2 ? idx2 + (size_t)b * m : nullptr);
+    const int j = fps_cloud_level<PPL>(n, m, block, xyz + (size_t)b * pitch * 3, 3, 1, temp ? temp + (size_t)b * pitch : nullptr,
+                                       idxs + (size_t)b * m, new_xyz ? new_xyz + (size_t)b * m * 3 : nullptr, s_pt, (int)threadIdx.x, tied,
+                                       nvalid ? nvalid[b] : -1, snap ? snap + (size_t)b * pitch : nullptr, first_tie ? first_tie + b : nullptr,
+                                       tie_prev ? tie_prev[b] : -1, tie_prev ? nuniq_prev[b] : 0,
+                                       (first_tie1 && first_tie1[b] > 1 && first_tie1[b] < m) ? first_tie1[b] : 1,
+                                       snap1 ? snap1 + (size_t)b * snap_pitch : nullptr, idx1 ? idx1 + (size_t)b * m : nullptr,
+                                       idx2 ? idx2 + (size_t)b * m : nullptr);
     if (threadIdx.x == 0) {
         if (nuniq) nuniq[b] = j;
         if (tie) tie[b] = tied;
@@ -1276,4 +1287,198 @@ extern "C" int rtk_knn_point(int b, int s, int n, int k, const float *query, con
 extern "C" int rtk_knn_point_masked(int b, int s, int n, int k, const float *query, const float *points, int64_t *idx,
                                     const int *n_valid, rtk_stream_t stream) {
     return knn_point_impl(b, s, n, k, query, points, idx, n_valid, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The geometry of a batch in TWO launches (round 6; the same tables, bit for bit, as the eleven launches
+// rtk_prepare_inputs + rtk_fps_centroids + 2 x rtk_fps_relevel + 3 x rtk_ball_query_pair + 3 x rtk_three_nn_masked +
+// 2 x rtk_knn_point_masked they replace -- those stay as the ops' own entry points and as what tests compare these with).
+//
+// rtk_geometry_front -- everything that depends on the input clouds only.  A heterogeneous grid of 256-thread workgroups:
+//   * workgroups [0, 2B): one per cloud.  All four waves convert the cloud's API tensors to the point-major layout the feature
+//     kernels read (rtk_prepare_inputs); then wave 0 runs the furthest-point selection of level 1 straight from the API's
+//     channel-major coordinates and goes on with levels 2 and 3 (rtk_fps_relevel's per-cloud decisions: copy / resume / settle) --
+//     a level of a cloud depends on nothing but the previous level of the SAME cloud, so the three levels need no launch boundary,
+//     only a fence between a level's stores and the next level's loads (same wave);
+//   * workgroups [2B, 2B + 2 B ceil(n / 16)): the two kNN tables of the cost volume (frame 1 -> frame 2, frame 1 -> frame 1),
+//     16 queries each, reading the API tensors as well.  They fill the chip while the 2B selection waves run their serial rounds.
+// rtk_geometry_tables -- everything that needs the three levels of centroids: the three ball-query pair scans and the three
+//   three-NN tables, one heterogeneous grid.
+// ------------------------------------------------------------------------------------------------
+struct GeoFrontParams {
+    int B, S, n, npoint, block_n, block_np;      // B clouds in frame 1 (= kNN pairs), S clouds in all (B or 2B)
+    const float *fr1, *fr2;      // the frames' clouds: component c of point k of sample b at fr[b * 3 n + k * ps + c * cs]
+    int ps, cs;
+    const float *f1, *f2;        // (B, 2, n) features (with xyz_out / raw_out)
+    float *xyz_out, *raw_out;    // (2B, n, 3), (2B n, 4) or NULL
+    int *fps_idx;                // (3, 2B, npoint)
+    float *new_xyz;              // (3, 2B, npoint, 3)
+    int *nuniq, *tie;            // (3, 2B) each
+    int *first_tie;              // (2B)
+    float *snap;                 // (2B, n)
+    const int *n_valid;          // (2B) or NULL
+    int64_t *knn12, *knn11;      // (B, n, 16) or NULL
+    int knn_chunks;
+};
+
+template <int PPL1, int PPL2>
+__global__ __launch_bounds__(256) void geometry_front_kernel(const GeoFrontParams P) {
+    extern __shared__ __attribute__((aligned(16))) float4 s_geo[];
+    const int S_ = P.S, n = P.n, m = P.npoint;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= S_) {                      // ---- a kNN chunk
+        const int r = (int)blockIdx.x - S_;
+        const int per = P.B * P.knn_chunks;
+        const int t = r / per, rem = r - t * per, b = rem / P.knn_chunks, chunk = rem - b * P.knn_chunks;
+        const int *nv = P.n_valid ? (t == 0 ? P.n_valid + P.B : P.n_valid) : nullptr;
+        knn_point_body<16, true>(b, chunk, n, n, 16, P.fr1, P.ps, P.cs, t == 0 ? P.fr2 : P.fr1, P.ps, P.cs, t == 0 ? P.knn12 : P.knn11, nv,
+                                 reinterpret_cast<float *>(s_geo));
+        return;
+    }
+    // ---- a cloud
+    const int s = blockIdx.x, second = s >= P.B, sb = second ? s - P.B : s;
+    const float *cloud = (second ? P.fr2 : P.fr1) + (size_t)sb * n * 3;
+    if (P.xyz_out) {
+        const float *f = (second ? P.f2 : P.f1) + (size_t)sb * 2 * n;
+        for (int p = tid; p < n; p += 256) {
+            const size_t t = (size_t)s * n + p;
+            P.xyz_out[t * 3 + 0] = cloud[p * P.ps];
+            P.xyz_out[t * 3 + 1] = cloud[p * P.ps + P.cs];
+            P.xyz_out[t * 3 + 2] = cloud[p * P.ps + 2 * P.cs];
+            *reinterpret_cast<float4 *>(P.raw_out + t * 4) = make_float4(f[p], f[n + p], 0.f, 0.f);
+        }
+    }
+    if (tid >= 64) return;                             // (a finished wave no longer counts at the barriers below)
+    const int lane = tid;
+    const size_t lv = (size_t)S_ * m;                  // one level of indices
+    int *i1 = P.fps_idx + (size_t)s * m, *i2 = i1 + lv, *i3 = i2 + lv;
+    float *x1 = P.new_xyz + (size_t)s * m * 3, *x2 = x1 + lv * 3, *x3 = x2 + lv * 3;
+    float *snap = P.snap + (size_t)s * n;
+    int tie1 = 0, tie2 = 0, tie3 = 0, ft1 = 0;
+    const int nu1 = fps_cloud_level<PPL1>(n, m, P.block_n, cloud, P.ps, P.cs, nullptr, i1, x1, s_geo, lane, tie1, P.n_valid ? P.n_valid[s] : -1, snap,
+                                          P.first_tie + s, -1, 0, 1, nullptr, nullptr, nullptr, &ft1);
+    __threadfence();                                   // level 1's centroids, indices and saved state are read back below
+    const int j_start = (ft1 > 1 && ft1 < m) ? ft1 : 1;
+    const int nu2 = fps_cloud_level<PPL2>(m, m, P.block_np, x1, 3, 1, nullptr, i2, x2, s_geo, lane, tie2, -1, nullptr, nullptr, tie1, nu1, j_start, snap, i1,
+                                          nullptr);
+    __threadfence();
+    const int nu3 = fps_cloud_level<PPL2>(m, m, P.block_np, x2, 3, 1, nullptr, i3, x3, s_geo, lane, tie3, -1, nullptr, nullptr, tie2, nu2, j_start, snap, i1,
+                                          i2);
+    if (lane == 0) {
+        P.nuniq[s] = nu1; P.nuniq[S_ + s] = nu2; P.nuniq[2 * S_ + s] = nu3;
+        P.tie[s] = tie1; P.tie[S_ + s] = tie2; P.tie[2 * S_ + s] = tie3;
+    }
+}
+
+extern "C" int rtk_geometry_front(int b, int clouds, int n, int npoint, const float *frame1, const float *frame2, int channel_major,
+                                  const float *feature1, const float *feature2, float *xyz, float *raw, int *fps_idx, float *new_xyz,
+                                  int *nuniq, int *tie, int *first_tie, float *snap, const int *n_valid, int64_t *knn12, int64_t *knn11,
+                                  rtk_stream_t stream) {
+    RTK_REQUIRE(b > 0 && n > 0 && npoint > 0 && frame1 && fps_idx && new_xyz && nuniq && tie && first_tie && snap,
+                "geometry_front: bad arguments (b=%d n=%d npoint=%d)", b, n, npoint);
+    RTK_REQUIRE(clouds == b || (clouds == 2 * b && frame2), "geometry_front: clouds=%d must be b or 2 b (b=%d) with both frames", clouds, b);
+    RTK_REQUIRE(n <= 2048 && npoint <= 512, "geometry_front: n=%d > 2048 or npoint=%d > 512 (use the separate entry points)", n, npoint);
+    RTK_REQUIRE((xyz == nullptr) == (raw == nullptr) && (!xyz || (feature1 && feature2)), "geometry_front: xyz, raw and the features go together");
+    RTK_REQUIRE((knn12 == nullptr) == (knn11 == nullptr) && (!knn12 || (n >= 16 && clouds == 2 * b)),
+                "geometry_front: the two kNN tables go together (n >= 16, both frames)");
+    GeoFrontParams P;
+    P.B = b; P.S = clouds; P.n = n; P.npoint = npoint; P.block_n = fps_block_size(n); P.block_np = fps_block_size(npoint);
+    P.fr1 = frame1; P.fr2 = frame2; P.ps = channel_major ? 1 : 3; P.cs = channel_major ? n : 1;
+    P.f1 = feature1; P.f2 = feature2; P.xyz_out = xyz; P.raw_out = raw;
+    P.fps_idx = fps_idx; P.new_xyz = new_xyz; P.nuniq = nuniq; P.tie = tie; P.first_tie = first_tie; P.snap = snap; P.n_valid = n_valid;
+    P.knn12 = knn12; P.knn11 = knn11; P.knn_chunks = rtk_divup(n, 16);
+    const int grid = clouds + (knn12 ? 2 * b * P.knn_chunks : 0);
+    const size_t lds = (size_t)(n > npoint ? n : npoint) * sizeof(float4);
+    hipStream_t s = (hipStream_t)stream;
+    if (n <= 64 * 4) geometry_front_kernel<4, 8><<<grid, 256, lds, s>>>(P);
+    else if (n <= 64 * 8) geometry_front_kernel<8, 8><<<grid, 256, lds, s>>>(P);
+    else if (n <= 64 * 16) geometry_front_kernel<16, 8><<<grid, 256, lds, s>>>(P);
+    else geometry_front_kernel<32, 8><<<grid, 256, lds, s>>>(P);
+    RTK_CHECK_LAUNCH("geometry_front");
+    return RTK_OK;
+}
+
+struct GeoBallTask {
+    int n_src, nsa, nsb;
+    float r2a, r2b;
+    const float *new_xyz, *xyz;
+    int *idxa, *idxb;
+    const int *nuniq;
+};
+struct GeoNnTask {
+    int n, m, chunks;
+    const float *unknown, *known;
+    float *dist2;
+    int *idx;
+    const int *unknown_nuniq, *known_nuniq;
+};
+struct GeoTablesParams {
+    int samples, npoint, ball_chunks;
+    GeoBallTask ball[3];
+    GeoNnTask nn[3];
+};
+
+__global__ __launch_bounds__(256) void geometry_tables_kernel(const GeoTablesParams P) {
+    extern __shared__ __attribute__((aligned(16))) float s_tab[];
+    int r = blockIdx.x;
+    const int per_ball = P.samples * P.ball_chunks;
+    if (r < 3 * per_ball) {
+        const int t = r / per_ball, rem = r - t * per_ball, bs = rem / P.ball_chunks, chunk = rem - bs * P.ball_chunks;
+        const GeoBallTask &T = P.ball[t];
+        ball_query_pair_body(bs, chunk, T.n_src, P.npoint, T.r2a, T.nsa, T.r2b, T.nsb, T.new_xyz, T.xyz, T.idxa, T.idxb, T.nuniq, s_tab);
+        return;
+    }
+    r -= 3 * per_ball;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const GeoNnTask &T = P.nn[t];
+        const int per = P.samples * T.chunks;
+        if (r < per) {
+            const int bs = r / T.chunks, chunk = r - bs * T.chunks;
+            three_nn_body<true>(bs, chunk, T.n, T.m, T.unknown, T.known, T.dist2, T.idx, T.unknown_nuniq, T.known_nuniq, s_tab);
+            return;
+        }
+        r -= per;
+    }
+}
+
+// xyz0 (S, n, 3): the clouds; new_xyz (3, S, npoint, 3), nuniq (3, S): the three levels of rtk_geometry_front.
+// radii / nsamples: (3 levels x 2 scales), radii[2 l] <= radii[2 l + 1].  ball[2 l + s] (S, npoint, nsamples[2 l + s]) int32, zero-initialised
+// by the caller (rtk_ball_query's contract).  nn_idx / nn_dist2 [fp3, fp2, fp1]: (S, npoint, 3), (S, npoint, 3), (S, n, 3).
+extern "C" int rtk_geometry_tables(int samples, int n, int npoint, const float *xyz0, const float *new_xyz, const int *nuniq,
+                                   const float *radii, const int *nsamples, int *const *ball, int *const *nn_idx, float *const *nn_dist2,
+                                   rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && n > 0 && npoint > 0 && xyz0 && new_xyz && nuniq && radii && nsamples && ball && nn_idx && nn_dist2,
+                "geometry_tables: bad arguments");
+    const int big = n > npoint ? n : npoint;
+    RTK_REQUIRE((size_t)big * 12 <= 64 * 1024, "geometry_tables: clouds of %d points do not fit the LDS stage", big);
+    GeoTablesParams P;
+    P.samples = samples; P.npoint = npoint; P.ball_chunks = rtk_divup(npoint, BQ_WAVES * BQ_CENTROIDS_PER_WAVE);
+    const size_t lv = (size_t)samples * npoint * 3;
+    const float *lvl_xyz[4] = {xyz0, new_xyz, new_xyz + lv, new_xyz + 2 * lv};
+    const int lvl_n[4] = {n, npoint, npoint, npoint};
+    for (int l = 0; l < 3; ++l) {
+        RTK_REQUIRE(radii[2 * l] <= radii[2 * l + 1] && nsamples[2 * l] > 0 && nsamples[2 * l + 1] > 0 && ball[2 * l] && ball[2 * l + 1],
+                    "geometry_tables: level %d: radii must ascend, tables must be given", l);
+        GeoBallTask &T = P.ball[l];
+        T.n_src = lvl_n[l]; T.nsa = nsamples[2 * l]; T.nsb = nsamples[2 * l + 1];
+        T.r2a = radii[2 * l] * radii[2 * l]; T.r2b = radii[2 * l + 1] * radii[2 * l + 1];      // fp32 products, as ball_query_gpu.cu:23
+        T.new_xyz = lvl_xyz[l + 1]; T.xyz = lvl_xyz[l]; T.idxa = ball[2 * l]; T.idxb = ball[2 * l + 1]; T.nuniq = nuniq + (size_t)l * samples;
+    }
+    // fp3: unknown level 2, known level 3; fp2: unknown level 1, known level 2; fp1: unknown level 0 (the points), known level 1
+    const int uk[3][2] = {{2, 3}, {1, 2}, {0, 1}};
+    int total = 3 * samples * P.ball_chunks;
+    for (int i = 0; i < 3; ++i) {
+        const int u = uk[i][0], k = uk[i][1];
+        RTK_REQUIRE(nn_idx[i] && nn_dist2[i], "geometry_tables: three-NN table %d missing", i);
+        GeoNnTask &T = P.nn[i];
+        T.n = lvl_n[u]; T.m = lvl_n[k]; T.chunks = rtk_divup(T.n, 16);
+        T.unknown = lvl_xyz[u]; T.known = lvl_xyz[k]; T.dist2 = nn_dist2[i]; T.idx = nn_idx[i];
+        T.unknown_nuniq = u > 0 ? nuniq + (size_t)(u - 1) * samples : nullptr;
+        T.known_nuniq = nuniq + (size_t)(k - 1) * samples;
+        total += samples * T.chunks;
+    }
+    geometry_tables_kernel<<<total, 256, (size_t)big * 12, (hipStream_t)stream>>>(P);
+    RTK_CHECK_LAUNCH("geometry_tables");
+    return RTK_OK;
 }

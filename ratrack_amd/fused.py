@@ -56,6 +56,9 @@ _lib.SIGNATURES.update({
     "rtk_gru_step": [_ci] * 3 + [_vp] * 8 + [_vp],
     "rtk_to_channel_major": [_ci] * 3 + [_vp, _ci, _ci, _vp, _ci, _ci, _vp],
     "rtk_ball_query_pair": [_ci] * 3 + [ctypes.c_float, _ci, ctypes.c_float, _ci] + [_vp] * 5 + [_vp],
+    "rtk_geometry_front": [_ci] * 4 + [_vp, _vp, _ci] + [_vp] * 13 + [_vp],
+    "rtk_geometry_tables": [_ci] * 3 + [_vp] * 3 + [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_ci), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                            ctypes.POINTER(_vp), _vp],
     "rtk_three_nn_masked": [_ci] * 3 + [_vp] * 6 + [_vp],
     "rtk_to_channel_major_multi": [_ci] * 3 + [_vp, _vp],
     "rtk_log_sinkhorn": [_ci, _ci, _vp, ctypes.c_float, _ci, _vp, _vp],
@@ -384,6 +387,8 @@ class _PNHeadWeights:
             self.fp[name] = Chain([(w, b, ACT_RELU)], device)
 
 
+FUSED_GEOMETRY = True          # the geometry of a batch in two launches (rtk_geometry_front / rtk_geometry_tables); False (tests): the eleven
+                               # launches of the separate entry points they replace -- the same tables bit for bit
 CHECK_FPS_RELEVEL = False      # debug: compare every re-levelling launch with the full selection (synchronises; tests set it)
 
 
@@ -416,8 +421,10 @@ class Geometry:
     """FPS centroids, ball-query indices and three-NN tables of one batch of clouds (feature independent,
     so the decoder's PNHead over pc1 reuses the encoder's)."""
 
-    def __init__(self, xyz, npoint, side=None, knn_frames=0, finite=False, n_valid=None, level_hook=None, tail_hook=None, zeros=None):
-        """xyz (S_,n,3).  With `side` (a torch.cuda.Stream) every geometry kernel is enqueued on that stream, forked from
+    def __init__(self, xyz, npoint, side=None, knn_frames=0, finite=False, n_valid=None, level_hook=None, tail_hook=None, zeros=None,
+                 prepare=None):
+        """xyz (S_,n,3).  prepare = (pc1, pc2, feature1, feature2, raw): xyz and raw (S_*n, 4) are OUTPUTS -- the API's channel-major
+        tensors of the two frames are converted on the way (rtk_prepare_inputs, inside rtk_geometry_front when the geometry is fused).  With `side` (a torch.cuda.Stream) every geometry kernel is enqueued on that stream, forked from
         the current one, and consumers call wait(stage) -- the feature kernels overlap the latency-bound FPS chain.
         knn_frames = B > 0: also the two kNN tables of the cost volume, frame 1 = xyz[:B], frame 2 = xyz[B:].
         finite: zero-fill the three-NN distances of the skipped (duplicate) rows instead of leaving them unwritten
@@ -467,10 +474,57 @@ class Geometry:
         # put one real frame pair in three off by 2e-3, only with warm allocator pools)
         self._scratch = (snap, temp, n_valid, xyz)
 
+        fused_geo = (FUSED_GEOMETRY and not big and npoint <= 512 and max(n, npoint) * 12 <= 64 * 1024 and (not B or (n >= 16 and S_ == 2 * B))
+                     and (prepare is None or S_ % 2 == 0))
+        self.fused_geometry = fused_geo
+        if prepare is not None and not fused_geo:      # on the caller's stream, before the fork: the feature kernels read raw there
+            pc1, pc2, f1, f2, raw = prepare
+            _lib.call("rtk_prepare_inputs", S_ // 2, n, pc1.data_ptr(), pc2.data_ptr(), f1.data_ptr(), f2.data_ptr(), xyz.data_ptr(), raw.data_ptr(),
+                      _stream())
+            self._scratch = self._scratch + (pc1, pc2, f1, f2, raw)
         main = torch.cuda.current_stream()
         if side is not None:
             side.wait_stream(main)
         ctx = torch.cuda.stream(side) if side is not None else _NullCtx()
+        self.ball = [[ball[lvl * 2 + s].view(S_, npoint, _PNHeadWeights.NSAMPLES[lvl][s]) for s in range(2)] for lvl in range(3)]
+        if fused_geo:
+            with ctx:
+                for lvl in range(3):
+                    self.xyz.append(new_xyz[lvl])
+                    self.nuniq.append(cnt[lvl])
+                b1 = S_ // 2 if (B or prepare is not None) else S_
+                if prepare is not None:
+                    pc1, pc2, f1, f2, raw = prepare
+                    fr = (pc1.data_ptr(), pc2.data_ptr(), 1, f1.data_ptr(), f2.data_ptr(), xyz.data_ptr(), raw.data_ptr())
+                    self._scratch = self._scratch + (pc1, pc2, f1, f2, raw)
+                else:
+                    fr = (xyz.data_ptr(), xyz[b1:].data_ptr() if b1 < S_ else None, 0, None, None, None, None)
+                _lib.call("rtk_geometry_front", b1, S_, n, npoint, *fr, fps_idx[0].data_ptr(), xyz_all.data_ptr(), cnt[0].data_ptr(),
+                          tie.data_ptr(), first_tie.data_ptr(), snap.data_ptr(), nv, self.knn[0].data_ptr() if B else None,
+                          self.knn[1].data_ptr() if B else None, _stream())
+                self._record("front", side)        # xyz / raw (prepare), the kNN tables and the three levels of centroids
+                if CHECK_FPS_RELEVEL and not torch.cuda.is_current_stream_capturing():
+                    check_fps_relevel(new_xyz[0], torch.stack(self.fps_idx[1:]), xyz_all[1:], torch.stack(list(cnt[1:3])))
+                radii = (ctypes.c_float * 6)(*[float(r) for row in _PNHeadWeights.RADII for r in row])
+                nsam = (_ci * 6)(*ns_all)
+                balls = (_vp * 6)(*[t.data_ptr() for t in ball])
+                self.nn = {}
+                for i, (name, (u, k)) in enumerate({"fp3": (2, 3), "fp2": (1, 2), "fp1": (0, 1)}.items()):
+                    self.nn[name] = (d2_parts[i].view(S_, nn_rows[i], 3), nn_idx[i].view(S_, nn_rows[i], 3), self.xyz[k].shape[1])
+                nni = (_vp * 3)(*[self.nn[k][1].data_ptr() for k in ("fp3", "fp2", "fp1")])
+                nnd = (_vp * 3)(*[self.nn[k][0].data_ptr() for k in ("fp3", "fp2", "fp1")])
+                _lib.call("rtk_geometry_tables", S_, n, npoint, xyz.data_ptr(), xyz_all.data_ptr(), cnt[0].data_ptr(), radii, nsam, balls, nni, nnd,
+                          _stream())
+                for lvl in range(3):
+                    if level_hook is not None:
+                        level_hook(self, lvl)
+                    self._record(lvl, side)
+                self._record("nn", side)
+                if B:
+                    self.events["knn"] = self.events.get("front")
+                if tail_hook is not None:
+                    tail_hook(self)
+            return
         with ctx:
             # ---- level 1: the only full furthest-point selection on the common path ---------------------------
             if not big:
@@ -732,13 +786,14 @@ class FusedBackbone:
         # keep the (possibly copied) contiguous inputs referenced until the launch is enqueued: a temporary freed
         # between two .data_ptr() calls could be recycled by the allocator for the next temporary
         ins = [t.contiguous() for t in (pc1, pc2, feature1, feature2)]
-        _lib.call("rtk_prepare_inputs", B, N, ins[0].data_ptr(), ins[1].data_ptr(), ins[2].data_ptr(), ins[3].data_ptr(),
-                  xyz.data_ptr(), raw.data_ptr(), _stream())
         if self.side is None and self.use_side_stream:
             self.side = torch.cuda.Stream(device=dev)
         if n_valid is not None:
             n_valid = n_valid.to(device=dev, dtype=torch.int32).reshape(2 * B).contiguous()
-        geo = Geometry(xyz, self.npoint, side=self.side if self.use_side_stream else None, knn_frames=B, n_valid=n_valid)
+        # layout conversion (rtk_prepare_inputs) + every geometry table: two launches (rtk_geometry_front, rtk_geometry_tables)
+        geo = Geometry(xyz, self.npoint, side=self.side if self.use_side_stream else None, knn_frames=B, n_valid=n_valid,
+                       prepare=(ins[0], ins[1], ins[2], ins[3], raw))
+        geo.wait("front")       # raw (and xyz) come out of the geometry's first launch when it runs on the side stream
         # ---- encoder over both frames at once (same weights; eval-mode BN is per-element) --------------
         q1 = pointwise(2 * B * N, N, [(raw, 2, False)], self.enc_q1, new(2 * B * N, 32))
         # pc{1,2}_features = [local (128) | global max broadcast (128)] (models/track4d.py:89-95) live in ONE point-major buffer:

@@ -821,3 +821,87 @@ def test_cost_volume_in_slices_of_the_batch_is_the_same_result(B, N, limit, monk
         assert torch.all(o[B * N:] == 7.0)
         out.append(o[:B * N])
     assert torch.equal(out[0], out[1])
+
+
+def _geometry_tables(geo):
+    """Every table of a fused.Geometry as a flat dict of tensors (for bit-for-bit comparison)."""
+    out = {"tie": geo.tie}
+    for l in range(3):
+        out["fps_idx%d" % l], out["xyz%d" % (l + 1)], out["nuniq%d" % l] = geo.fps_idx[l], geo.xyz[l + 1], geo.nuniq[l]
+        for s in range(2):
+            out["ball%d%d" % (l, s)] = geo.ball[l][s]
+    for name, (d2, idx, m) in geo.nn.items():
+        out["nn_idx_" + name], out["nn_d2_" + name] = idx, d2
+    if geo.knn is not None:
+        out["knn12"], out["knn11"] = geo.knn
+    return out
+
+
+@pytest.mark.parametrize("case", ["synthetic_b4_n256", "lattice_ties", "n1024", "padded", "odd_n", "tiny", "point_major_one_frame"])
+def test_two_launch_geometry_equals_the_separate_launches(case, monkeypatch):
+    """rtk_geometry_front + rtk_geometry_tables (two launches, the product path since round 6) against the eleven launches of the ops' own
+    entry points (rtk_prepare_inputs, rtk_fps_centroids, rtk_fps_relevel x 2, rtk_ball_query_pair x 3, rtk_three_nn_masked x 3,
+    rtk_knn_point_masked x 2): every table bit for bit -- FPS indices / centroids / exhausted-cloud and tie counters of the three levels,
+    the six ball tables, the three three-NN tables (indices and squared distances), both kNN tables, xyz and raw.  Clouds with exact
+    distance ties between distinct points (the tied levels resume and settle inside the one launch), duplicates, padded batches, odd
+    sizes; with the layout conversion from the API's channel-major tensors and without (the training path hands over point-major clouds)."""
+    from ratrack_amd import synth
+    g = torch.Generator().manual_seed(11)
+    nv = None
+    if case == "synthetic_b4_n256":
+        d = synth.make_frame_pairs(4, 256, case_id=3)
+        pc1, pc2 = torch.from_numpy(d["pc1"]).to(DEV), torch.from_numpy(d["pc2"]).to(DEV)
+    elif case == "lattice_ties":
+        pc1 = torch.randint(0, 6, (3, 3, 300), generator=g).float().to(DEV)
+        pc2 = torch.randint(0, 5, (3, 3, 300), generator=g).float().to(DEV)
+    elif case == "n1024":
+        d = synth.make_frame_pairs(2, 1024, case_id=5)
+        pc1, pc2 = torch.from_numpy(d["pc1"]).to(DEV), torch.from_numpy(d["pc2"]).to(DEV)
+    elif case == "padded":
+        d = synth.make_frame_pairs(3, 352, case_id=9)
+        pc1, pc2 = torch.from_numpy(d["pc1"]).to(DEV), torch.from_numpy(d["pc2"]).to(DEV)
+        nv = torch.tensor([[322, 352, 242], [300, 17, 352]], dtype=torch.int32, device=DEV)
+        for f, pc in enumerate((pc1, pc2)):       # padding = copies of the cloud's own point 0
+            for b in range(3):
+                pc[b, :, int(nv[f, b]):] = pc[b, :, :1]
+        nv = nv.reshape(-1).contiguous()
+    elif case == "odd_n":
+        pc1, pc2 = torch.randn(5, 3, 243, generator=g).to(DEV) * 6, torch.randn(5, 3, 243, generator=g).to(DEV) * 6
+    elif case == "tiny":
+        pc1, pc2 = torch.randn(2, 3, 16, generator=g).to(DEV), torch.randn(2, 3, 16, generator=g).to(DEV)
+    else:
+        pc1 = torch.randint(0, 7, (5, 3, 200), generator=g).float().to(DEV)
+        pc2 = None
+    if pc2 is not None:
+        B, _, N = pc1.shape
+        f1, f2 = torch.randn(B, 2, N, generator=g).to(DEV), torch.randn(B, 2, N, generator=g).to(DEV)
+
+        def build():
+            xyz = torch.empty(2 * B, N, 3, device=DEV)
+            raw = torch.full((2 * B * N, 4), float("nan"), device=DEV)
+            geo = F.Geometry(xyz, 512, knn_frames=B, n_valid=nv, finite=True, prepare=(pc1, pc2, f1, f2, raw))
+            torch.cuda.synchronize()
+            t = _geometry_tables(geo)
+            t["xyz0"], t["raw"] = xyz, raw
+            return geo, t
+    else:
+        xyz = pc1.permute(0, 2, 1).contiguous()       # five clouds of one frame, point-major, no kNN (the training path's call)
+
+        def build():
+            geo = F.Geometry(xyz, 512, finite=True)
+            torch.cuda.synchronize()
+            return geo, _geometry_tables(geo)
+    geo2, two = build()
+    assert geo2.fused_geometry
+    monkeypatch.setattr(F, "FUSED_GEOMETRY", False)
+    geo11, eleven = build()
+    assert not geo11.fused_geometry
+    assert two.keys() == eleven.keys()
+    for k in two:
+        assert two[k].shape == eleven[k].shape, k
+        if two[k].dtype.is_floating_point:      # same bits (NaN-safe)
+            assert torch.equal(two[k].view(torch.int32), eleven[k].view(torch.int32)), k
+        else:
+            assert torch.equal(two[k], eleven[k]), k
+    if case == "lattice_ties":
+        assert int(two["tie"].sum()) > 0 and bool((two["xyz2"] != two["xyz1"]).any()), "the lattice must exercise the tied levels"
