@@ -62,7 +62,8 @@ HEADLINE_SECONDS = 11.0       # the headline timed region (a utilisation sampler
 CONFIG_SECONDS = 3.0          # configs 2 and 5
 HBM_PEAK_GBS = 8000.0
 NBATCH = 8                    # distinct synthetic batches resident in HBM, rotated through the timed steps
-PMC = {"forward": "r02_pmc_cost_volume.json", "train": "r02_pmc_cost_volume_bwd.json", "irregular": "r02_irregular_hbm.json"}
+PMC = {"forward": "pmc_cost_volume.json", "train": "pmc_cost_volume_bwd.json", "irregular": "irregular_hbm.json"}      # profiles/rNN_<name>
+ROUNDS = ["r%02d" % r for r in range(6, 0, -1)]                                                                       # newest first
 
 
 def train_roofline(a, kms, kflops, ach, pm, ms_step):
@@ -99,8 +100,7 @@ def _pmc(kind, batch, n):
     """Fabric-side bytes per launch from the committed PMC passes (profiles/, same workload only)."""
     try:
         if batch == 64 and n == 256:
-            for name in (PMC[kind].replace("r02_", "r05_"), PMC[kind].replace("r02_", "r04_"), PMC[kind].replace("r02_", "r03_"), PMC[kind],
-                         PMC[kind].replace("r02_", "r01_")):
+            for name in ("%s_%s" % (r, PMC[kind]) for r in ROUNDS):
                 p = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(p):
                     d = json.load(open(p))
@@ -114,7 +114,7 @@ def _pmc(kind, batch, n):
 def _train_total_traffic(a):
     """HBM-side bytes of the whole train step from the committed all-kernel PMC pass (tools/pmc_train_total.py) and their ratio to
     SURVEY 8(d)'s 3 x forward algorithmic bytes."""
-    name = next((n for n in ("r05_pmc_train_total.json", "r04_pmc_train_total.json", "r03_pmc_train_total.json") if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+    name = next((n for n in ("%s_pmc_train_total.json" % r for r in ROUNDS) if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
     if a.batch != 64 or a.npoints != 256 or name is None:
         return {}
     p = os.path.join(ROOT, "profiles", name)
@@ -124,6 +124,74 @@ def _train_total_traffic(a):
                 "traffic_source": "profiles/%s (rocprofv3 --pmc passes over every kernel of the step)" % name}
     except Exception:
         return {}
+
+
+def profile_kernel_avg_us(pattern, stats="bench_default_kernel_stats.txt"):
+    """Average duration of the kernel whose name contains `pattern` in the newest committed rocprofv3 summary (profiles/rNN_<stats>, written
+    by tools/prof_summary.py from `rocprofv3 --kernel-trace --stats` of this bench) -> (us, file name) or (None, None)."""
+    for r in ROUNDS:
+        p = os.path.join(ROOT, "profiles", "%s_%s" % (r, stats))
+        if not os.path.exists(p):
+            continue
+        try:
+            for line in open(p):
+                if pattern in line:
+                    f = line[78:].split()
+                    return float(f[2]), os.path.basename(p)          # calls, total_us, avg_us, ...
+        except Exception:
+            pass
+    return None, None
+
+
+class _quiet_stdout:
+    """RCCL prints a version banner on file descriptor 1 when its first communicator comes up; this file's contract is ONE JSON line on
+    stdout.  Sends fd 1 to /dev/null for the duration (Python-level prints inside are lost too: there are none)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        self._null = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(self._null, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        os.close(self._null)
+        return False
+
+
+def allreduce_1rank_us(nfloats, dev, iters=20):
+    """The gradient bucket's all-reduce through a ONE-rank RCCL group on this GPU: the collective's launch + kernel latency, the only
+    term of DESIGN section 6's estimate a 1-GPU box can measure (no link traffic: with one rank RCCL copies in place)."""
+    import torch.distributed as dist
+    own = not dist.is_initialized()
+    if own:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        with _quiet_stdout():
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        buf = torch.zeros(nfloats, dtype=torch.float32, device=dev)
+        with _quiet_stdout():
+            for _ in range(3):
+                dist.all_reduce(buf)
+            torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            dist.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3
+    finally:
+        if own:
+            dist.destroy_process_group()
 
 
 def measure_traffic(batch, n, timeout_s=240):
@@ -230,11 +298,65 @@ def cpu_baseline(n, budget_s=20.0):
     finally:
         torch.set_num_threads(all_threads)
     best = max(rows, key=lambda r: r["pairs_per_s"])
+    try:      # ... and the whole host: P single-thread processes at once (the throughput the box's cores give, not one core's latency)
+        throughput = cpu_throughput_baseline(n, min(64, ncpu))
+    except Exception as e:
+        throughput = {"error": repr(e)[:200]}
     return {"value": best["pairs_per_s"], "unit": "frame-pairs/s", "cores": best["threads"], "kind": "port", "host_cpus": ncpu,
+            "throughput": throughput,
             "sample": "CPU oracle backbone forward, N=%d: best of (B=1, 1 thread), (B=1, %d threads), (B=32, %d threads) = B=%d with %d "
                       "threads (median of %d runs); %.0f s of CPU work in total"
                       % (n, all_threads, min(32, ncpu), best["batch"], best["threads"], best["runs"], time.perf_counter() - t_start),
             "runs": rows}
+
+
+def _cpu_throughput_worker(n, go_at, seconds):
+    """`python bench.py --cpu-worker N GO SECONDS`: one single-thread B=1 oracle forward loop; prints "<forwards> <seconds>"."""
+    torch.set_num_threads(1)
+    from oracle import track4d_ref as R
+    from ratrack_amd import synth
+    from ratrack_amd.track4d import Args, Track4D
+    net = Track4D(Args())
+    synth.fill_state_dict(net.state_dict())
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    d = synth.make_frame_pairs(1, n, case_id=99)
+    t = {k: torch.from_numpy(v) for k, v in d.items() if k != "gt_cls"}
+    with torch.no_grad():
+        R.backbone(sd, t["pc1"], t["pc2"], t["feature1"], t["feature2"], None)      # warm-up
+        while time.time() < go_at:
+            time.sleep(0.01)
+        t0, k = time.perf_counter(), 0
+        while time.perf_counter() - t0 < seconds:
+            R.backbone(sd, t["pc1"], t["pc2"], t["feature1"], t["feature2"], None)
+            k += 1
+        print(k, time.perf_counter() - t0, flush=True)
+
+
+def cpu_throughput_baseline(n, procs, seconds=8.0, startup_s=45.0):
+    """What the host can do when every core works: `procs` independent single-thread processes, each looping the CPU oracle's B=1 forward
+    (the fastest setting per core) over the same `seconds` window, started together.  -> pairs/s summed over the processes."""
+    import subprocess
+    go_at = time.time() + startup_s
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(n), repr(go_at), repr(seconds)], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(procs)]
+    done, late = [], 0
+    for p_ in ps:
+        try:
+            out, _ = p_.communicate(timeout=startup_s + seconds * 3 + 60)
+            k, el = out.split()
+            done.append((int(k), float(el)))
+        except Exception:
+            p_.kill()
+            late += 1
+    if not done:
+        raise RuntimeError("no CPU worker finished")
+    rate = sum(k / el for k, el in done)
+    return {"value": round(rate, 1), "unit": "frame-pairs/s", "cores": len(done), "processes_failed": late,
+            "sample": "%d independent single-thread processes, each the CPU oracle's B=1 forward in a loop for %.0f s (same window), "
+                      "N=%d: %d forwards in all" % (len(done), seconds, n, sum(k for k, _ in done))}
 
 
 def cpu_train_baseline(batch, n, budget_s=15.0):
@@ -317,6 +439,12 @@ def run_train(a, net, d, dev, dist, world, rank, steps, warmup, live_traffic=Non
         e1.record()
         torch.cuda.synchronize()
         ar_us = e0.elapsed_time(e1) / 20 * 1e3
+    ar1_us = None
+    if world == 1:      # a 1-rank RCCL group: the collective's launch + kernel latency on this box
+        try:
+            ar1_us = allreduce_1rank_us(sum(p.numel() for p in net.parameters() if p.requires_grad) + 5, dev)
+        except Exception:
+            ar1_us = None
     res = None
     if rank == 0:
         ms_step = el / steps * 1e3
@@ -351,6 +479,7 @@ def run_train(a, net, d, dev, dist, world, rank, steps, warmup, live_traffic=Non
                "allreduce_bytes": tr.reducer.bucket_bytes or 4 * sum(p.numel() for p in net.parameters() if p.requires_grad),
                "allreduce_gradient_bytes": tr.reducer.payload_bytes or 4 * sum(p.numel() for p in net.parameters() if p.grad is not None),
                "allreduce_us": None if ar_us is None else round(ar_us, 1),
+               "allreduce_us_1rank": None if ar1_us is None else round(ar1_us, 1),
                "per_rank_ms_per_step": {"min": round(min(per_rank) / steps * 1e3, 3), "max": round(max(per_rank) / steps * 1e3, 3)},
                "roofline": train_roofline(a, kms, kflops, ach, pm, ms_step),
                "whole_step": {**_train_total_traffic(a),"hbm_frac_algorithmic_3x": round(3 * ALG_BYTES_PER_PAIR.get(a.npoints, 0) * a.batch / (ms_step * 1e-3)
@@ -463,6 +592,8 @@ def _self_spawn(a):
 
 
 def main():
+    if len(sys.argv) == 5 and sys.argv[1] == "--cpu-worker":
+        return _cpu_throughput_worker(int(sys.argv[2]), float(sys.argv[3]), float(sys.argv[4]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -506,7 +637,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)      # RCCL
+        with _quiet_stdout():
+            dist.init_process_group("nccl", device_id=dev)      # RCCL
+            dist.barrier()                                      # (the communicator, and its banner, come up with the first collective)
     assert a.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (a.gpus, world)
 
     from ratrack_amd import synth
@@ -547,7 +680,8 @@ def main():
                    "roofline": tr["roofline"], "whole_step": tr["whole_step"],
                    "train": {"hipGraph": tr["hipGraph"], "deterministic": tr["deterministic"], "kernels_per_step": tr["kernels_per_step"],
                              "allreduce_bytes": tr["allreduce_bytes"],
-                             "allreduce_gradient_bytes": tr["allreduce_gradient_bytes"], "allreduce_us": tr["allreduce_us"]},
+                             "allreduce_gradient_bytes": tr["allreduce_gradient_bytes"], "allreduce_us": tr["allreduce_us"],
+                             "allreduce_us_1rank": tr["allreduce_us_1rank"]},
                    "per_rank_ms_per_step": tr["per_rank_ms_per_step"]}
             if world == 1 and not a.no_cpu_baseline:
                 try:
@@ -573,18 +707,23 @@ def main():
         eng.use_side_stream, side_saved = False, eng.use_side_stream
         net.backbone(pc1, pc2, f1, f2, h)
         torch.cuda.synchronize()
-        rtk_lib.TIMING = timing = []
-        net.backbone(pc1, pc2, f1, f2, h)
-        rtk_lib.TIMING = None
-        torch.cuda.synchronize()
-        eng.use_side_stream = side_saved
         fam_of = {"rtk_pointwise_mlp": "pointwise", "rtk_sa_scale": "sa_scale", "rtk_sa_scale_split": "sa_scale", "rtk_cost_volume_split": "cost_volume",
                   "rtk_cost_volume": "cost_volume", "rtk_patch_cost": "patch_cost", "rtk_gru_step": "gru"}
-        by_family = {}
-        for nm, e0, e1 in timing:
-            f = by_family.setdefault(fam_of.get(nm, nm.replace("rtk_", "")), [0, 0.0])
-            f[0] += 1
-            f[1] += e0.elapsed_time(e1) * 1e3
+        ALONE_PASSES = 7
+        passes = []
+        for _ in range(ALONE_PASSES):      # the MEDIAN over the passes, family by family (round 5 committed one pass: a 155 us outlier in it)
+            rtk_lib.TIMING = timing = []
+            net.backbone(pc1, pc2, f1, f2, h)
+            rtk_lib.TIMING = None
+            torch.cuda.synchronize()
+            fam = {}
+            for nm, e0, e1 in timing:
+                f = fam.setdefault(fam_of.get(nm, nm.replace("rtk_", "")), [0, 0.0])
+                f[0] += 1
+                f[1] += e0.elapsed_time(e1) * 1e3
+            passes.append(fam)
+        eng.use_side_stream = side_saved
+        by_family = {k: [passes[0][k][0], statistics.median(p_[k][1] for p_ in passes if k in p_)] for k in passes[0]}
 
         spread = {}
 
@@ -679,6 +818,7 @@ def main():
                 traffic = {"bytes": live["forward"], "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes (%s)" % live["calibration"]}
         per_gpu = pairs_per_s / world
         split = bool(getattr(eng, "cv_split", False))
+        prof_us, prof_file = profile_kernel_avg_us("cost_volume_split_kernel<false>" if split else "cost_volume_kernel<") if (a.batch, a.npoints) == (64, 256) else (None, None)
         cv_peak = SPLIT_PEAK_TFLOPS if split else FP32_PEAK_TFLOPS
         exec_flops_per_pair = 2.0 * exec_macs / a.batch
         res = {
@@ -710,6 +850,9 @@ def main():
                                     if split else "fp32-input MFMA peak",
                          "traffic": traffic["bytes"], "traffic_source": traffic["source"],
                          "kernel_ms": round(kern_ms, 4), "flops_per_launch": cv_flops,
+                         "profile_frac": (round(cv_flops / (prof_us * 1e-6) / 1e12 / cv_peak, 4) if prof_us else None),
+                         "profile_avg_us": prof_us, "profile_source": ("profiles/%s (rocprofv3 --kernel-trace --stats of this bench: dispatches "
+                                                                       "serialised by the profiler)" % prof_file) if prof_file else None,
                          "alone": {"kernel_ms": round(alone_ms, 4), "frac": round(cv_flops / (alone_ms * 1e-3) / 1e12 / cv_peak, 4),
                                    "what": "the same launch with nothing else in flight (back-to-back launches between HIP events; what "
                                            "rocprofv3 --kernel-trace, which serialises dispatches, shows): in situ the kernel shares the "
@@ -738,6 +881,7 @@ def main():
                            "executed_gflop_per_pair_by_kernel": {k: round(2.0 * v / a.batch / 1e9, 4) for k, v in exec_by_kernel.items()}},
             # one eager pass, every launch between HIP events on one stream with nothing else in flight (what a serialising profiler
             # shows); FLOP-carrying families: executed multiply-adds x 2 / time against the split matrix peak (fp16 / 3)
+            "kernels_alone_method": "median over %d eager passes, every launch between HIP events on one stream with nothing else in flight" % ALONE_PASSES,
             "kernels_alone": {k: dict({"launches": v[0], "us": round(v[1], 1)},
                                       **({"gflop": round(2.0 * exec_by_kernel[k] / 1e9, 2),
                                           "tflops": round(2.0 * exec_by_kernel[k] / (v[1] * 1e-6) / 1e12, 1),

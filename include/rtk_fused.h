@@ -190,6 +190,34 @@ RTK_EXPORT int rtk_gru_step(int b, int layers, int hidden, const float *x, const
                             const float *w_hh, const float *b_ih, const float *b_hh, float *h_out, float *y,
                             rtk_stream_t stream);
 
+/* rtk_gru_step with an epilogue: head_out (B, head_cout) = head_w y + head_bias, head_wt = head_w TRANSPOSED (H, head_cout) -- the
+ * per-sample bias the flow head's first layer takes from the GRU output (model_utils.py:297-300).  H % 16 == 0. */
+RTK_EXPORT int rtk_gru_step_head(int b, int layers, int hidden, const float *x, const float *h_in, const float *w_ih,
+                                 const float *w_hh, const float *b_ih, const float *b_hh, float *h_out, float *y, const float *head_wt,
+                                 const float *head_bias, float *head_out, int head_cout, rtk_stream_t stream);
+
+/* Everything that is a function of a sample's global (max-pooled) feature g (samples, cin) in one launch (models/track4d.py:89-95
+ * broadcasts it over the points and concatenates it to per-point inputs; a concatenated global half of a layer's input is a
+ * per-sample bias of that layer): jobs[j]: out[(s - s0), :cout] = W g[s] + bias for s in [s0, s0 + count), wt = W TRANSPOSED
+ * (cin, cout) fp32; and, with bcast, bcast[(s n + r) bcast_pitch + c] = g[s][c] for every row r < n of every sample.  cin % 16 == 0. */
+#define RTK_GT_MAX_JOBS 4
+typedef struct {
+    const float *wt, *bias;      /* (cin, cout), (cout) or NULL */
+    float *out;                  /* (count, out_pitch) */
+    int cout, s0, count, out_pitch;
+} rtk_gterm_job_t;
+RTK_EXPORT int rtk_global_terms(int samples, int cin, const float *g, int njobs, const rtk_gterm_job_t *jobs, float *bcast, int bcast_pitch,
+                                int n, rtk_stream_t stream);
+
+/* Up to RTK_COPY_MAX_JOBS device-to-device copies in one launch (sizes in bytes, multiples of 4; pointers 4-byte aligned). */
+#define RTK_COPY_MAX_JOBS 8
+typedef struct {
+    const void *src;
+    void *dst;
+    long bytes;
+} rtk_copy_job_t;
+RTK_EXPORT int rtk_copy_multi(int njobs, const rtk_copy_job_t *jobs, rtk_stream_t stream);
+
 /* (rows = samples*n, pitch) point-major -> (samples, channels, n) channel-major at channel offset
  * dst_channel_offset of a (samples, dst_channels, n) tensor; per_sample != 0 broadcasts a (samples, pitch)
  * source over the n points (the global-feature halves of pc{1,2}_features, models/track4d.py:89-95). */

@@ -45,7 +45,8 @@ __global__ __launch_bounds__(384) void gru_step_kernel(int b, int layers, int hi
                                                        const float *__restrict__ h_in, const float *__restrict__ w_ih,
                                                        const float *__restrict__ w_hh, const float *__restrict__ b_ih,
                                                        const float *__restrict__ b_hh, float *__restrict__ h_out,
-                                                       float *__restrict__ y) {
+                                                       float *__restrict__ y, const float *__restrict__ head_wt,
+                                                       const float *__restrict__ head_bias, float *__restrict__ head_out, int head_cout) {
     __shared__ float s_x[128], s_h[128], s_gi[384], s_gh[384];
     const int s = blockIdx.x, t = threadIdx.x, H = hidden;
     if (t < H) s_x[t] = x[(long)s * H + t];
@@ -87,6 +88,22 @@ __global__ __launch_bounds__(384) void gru_step_kernel(int b, int layers, int hi
         }
         __syncthreads();
     }
+    // optional epilogue: head_out[s] = head_w y[s] + head_bias (head_wt = the weight transposed, (H, head_cout)) -- the per-sample bias
+    // the flow head's first layer takes from the GRU output (model_utils.py:297-300: cat of the broadcast GRU feature), a launch of
+    // its own for 64 rows until round 6.  s_x holds y.
+    if (head_wt) {
+        for (int c = t; c < head_cout; c += blockDim.x) {
+            float acc = head_bias ? head_bias[c] : 0.f;
+            for (int k0 = 0; k0 < H; k0 += 16) {
+                float wv[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) wv[q] = head_wt[(long)(k0 + q) * head_cout + c];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc = fmaf(wv[q], s_x[k0 + q], acc);
+            }
+            head_out[(long)s * head_cout + c] = acc;
+        }
+    }
 }
 
 extern "C" int rtk_gru_step(int b, int layers, int hidden, const float *x, const float *h_in, const float *w_ih,
@@ -94,8 +111,134 @@ extern "C" int rtk_gru_step(int b, int layers, int hidden, const float *x, const
                             rtk_stream_t stream) {
     RTK_REQUIRE(b > 0 && layers > 0 && layers <= GRU_MAXL && hidden > 0 && hidden <= 128 && hidden % 4 == 0 && x && h_in && w_ih &&
                 w_hh && b_ih && b_hh && h_out && y, "gru_step: bad arguments (hidden=%d, layers=%d)", hidden, layers);
-    gru_step_kernel<<<b, 384, 0, (hipStream_t)stream>>>(b, layers, hidden, x, h_in, w_ih, w_hh, b_ih, b_hh, h_out, y);
+    gru_step_kernel<<<b, 384, 0, (hipStream_t)stream>>>(b, layers, hidden, x, h_in, w_ih, w_hh, b_ih, b_hh, h_out, y, nullptr, nullptr, nullptr, 0);
     RTK_CHECK_LAUNCH("gru_step");
+    return RTK_OK;
+}
+
+extern "C" int rtk_gru_step_head(int b, int layers, int hidden, const float *x, const float *h_in, const float *w_ih,
+                                 const float *w_hh, const float *b_ih, const float *b_hh, float *h_out, float *y, const float *head_wt,
+                                 const float *head_bias, float *head_out, int head_cout, rtk_stream_t stream) {
+    RTK_REQUIRE(b > 0 && layers > 0 && layers <= GRU_MAXL && hidden > 0 && hidden <= 128 && hidden % 16 == 0 && x && h_in && w_ih &&
+                w_hh && b_ih && b_hh && h_out && y && head_wt && head_out && head_cout > 0,
+                "gru_step_head: bad arguments (hidden=%d, layers=%d, head_cout=%d)", hidden, layers, head_cout);
+    gru_step_kernel<<<b, 384, 0, (hipStream_t)stream>>>(b, layers, hidden, x, h_in, w_ih, w_hh, b_ih, b_hh, h_out, y, head_wt, head_bias,
+                                                        head_out, head_cout);
+    RTK_CHECK_LAUNCH("gru_step_head");
+    return RTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rtk_global_terms: everything that is a function of a sample's global (max-pooled) feature g (samples, cin), in one launch
+// (models/track4d.py:89-95 broadcasts it over the points and concatenates; here a concatenated global half of a layer's input is a
+// per-sample bias of that layer): up to RTK_GT_MAX_JOBS linear maps out_j[s - s0_j] = W_j g[s] + b_j over sample ranges, and the
+// broadcast of g[s] over the n rows of sample s of a point-major tensor (the global half of pc{1,2}_features).  One workgroup per
+// sample.  (Until round 6: three 64-row launches of the per-point MLP kernel + a framework broadcast copy.)
+// ------------------------------------------------------------------------------------------------
+struct GtParams {
+    int samples, cin, njobs, n, bcast_pitch;
+    const float *g;
+    float *bcast;
+    rtk_gterm_job_t job[RTK_GT_MAX_JOBS];
+};
+
+__global__ __launch_bounds__(256) void global_terms_kernel(const GtParams P) {
+    __shared__ __attribute__((aligned(16))) float s_g[512];
+    const int s = blockIdx.x, t = threadIdx.x;
+    for (int k = t; k < P.cin; k += 256) s_g[k] = P.g[(long)s * P.cin + k];
+    __syncthreads();
+    for (int j = 0; j < P.njobs; ++j) {
+        const rtk_gterm_job_t &J = P.job[j];
+        if (s < J.s0 || s >= J.s0 + J.count) continue;
+        for (int c = t; c < J.cout; c += 256) {
+            float acc = J.bias ? J.bias[c] : 0.f;
+            for (int k0 = 0; k0 < P.cin; k0 += 16) {      // cin % 16 == 0; 16 weight loads in flight, summed k ascending
+                float wv[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) wv[q] = J.wt[(long)(k0 + q) * J.cout + c];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc = fmaf(wv[q], s_g[k0 + q], acc);
+            }
+            J.out[(long)(s - J.s0) * J.out_pitch + c] = acc;
+        }
+    }
+    if (P.bcast) {      // cin % 4 == 0: a thread owns one float4 of the row, rows strided by 1024 / cin
+        const int per_row = P.cin >> 2, rows_per_iter = 256 / per_row, q = t % per_row;
+        if (t < rows_per_iter * per_row) {
+            const float4 v = *reinterpret_cast<const float4 *>(s_g + 4 * q);
+            for (int r = t / per_row; r < P.n; r += rows_per_iter)
+                *reinterpret_cast<float4 *>(P.bcast + ((long)s * P.n + r) * P.bcast_pitch + 4 * q) = v;
+        }
+    }
+}
+
+extern "C" int rtk_global_terms(int samples, int cin, const float *g, int njobs, const rtk_gterm_job_t *jobs, float *bcast, int bcast_pitch,
+                                int n, rtk_stream_t stream) {
+    RTK_REQUIRE(samples > 0 && cin > 0 && cin <= 512 && cin % 16 == 0 && g && njobs >= 0 && njobs <= RTK_GT_MAX_JOBS && (njobs == 0 || jobs),
+                "global_terms: bad arguments (samples=%d cin=%d njobs=%d)", samples, cin, njobs);
+    RTK_REQUIRE(!bcast || (n > 0 && bcast_pitch >= cin && bcast_pitch % 4 == 0 && cin <= 1024), "global_terms: bad broadcast target");
+    GtParams P;
+    P.samples = samples; P.cin = cin; P.njobs = njobs; P.n = n; P.bcast_pitch = bcast_pitch; P.g = g; P.bcast = bcast;
+    for (int j = 0; j < njobs; ++j) {
+        RTK_REQUIRE(jobs[j].wt && jobs[j].out && jobs[j].cout > 0 && jobs[j].s0 >= 0 && jobs[j].count >= 0 && jobs[j].s0 + jobs[j].count <= samples &&
+                    jobs[j].out_pitch >= jobs[j].cout, "global_terms: bad job %d", j);
+        P.job[j] = jobs[j];
+    }
+    global_terms_kernel<<<samples, 256, 0, (hipStream_t)stream>>>(P);
+    RTK_CHECK_LAUNCH("global_terms");
+    return RTK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rtk_copy_multi: up to RTK_COPY_MAX_JOBS device-to-device copies in one launch (the inputs of a captured step into its static
+// buffers: the framework's multi-tensor copy was 18 us for 0.8 MB).  Sizes in bytes, multiples of 4; 16-byte path when aligned.
+// ------------------------------------------------------------------------------------------------
+struct CopyParams {
+    int njobs;
+    rtk_copy_job_t job[RTK_COPY_MAX_JOBS];
+    long first_block[RTK_COPY_MAX_JOBS + 1];
+};
+constexpr int COPY_BLOCK_BYTES = 256 * 16 * 4;      // 16 KiB per workgroup
+
+__global__ __launch_bounds__(256) void copy_multi_kernel(const CopyParams P) {
+    const long blk = blockIdx.x;
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < RTK_COPY_MAX_JOBS; ++q) j += (q < P.njobs && blk >= P.first_block[q]) ? 1 : 0;
+    const rtk_copy_job_t &J = P.job[j];
+    const long off = (blk - P.first_block[j]) * COPY_BLOCK_BYTES;
+    const char *src = reinterpret_cast<const char *>(J.src) + off;
+    char *dst = reinterpret_cast<char *>(J.dst) + off;
+    const long left = J.bytes - off;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long o = ((long)u * 256 + threadIdx.x) * 16;
+            if (o + 16 <= left) *reinterpret_cast<float4 *>(dst + o) = *reinterpret_cast<const float4 *>(src + o);
+            else for (long b = o; b < left && b < o + 16; b += 4) *reinterpret_cast<float *>(dst + b) = *reinterpret_cast<const float *>(src + b);
+        }
+    } else {
+        for (long o = (long)threadIdx.x * 4; o < left && o < COPY_BLOCK_BYTES; o += 256 * 4)
+            *reinterpret_cast<float *>(dst + o) = *reinterpret_cast<const float *>(src + o);
+    }
+}
+
+extern "C" int rtk_copy_multi(int njobs, const rtk_copy_job_t *jobs, rtk_stream_t stream) {
+    RTK_REQUIRE(njobs > 0 && njobs <= RTK_COPY_MAX_JOBS && jobs, "copy_multi: %d jobs (1..%d)", njobs, RTK_COPY_MAX_JOBS);
+    CopyParams P;
+    P.njobs = njobs;
+    long blocks = 0;
+    for (int j = 0; j < njobs; ++j) {
+        RTK_REQUIRE(jobs[j].src && jobs[j].dst && jobs[j].bytes > 0 && jobs[j].bytes % 4 == 0 &&
+                    (((uintptr_t)jobs[j].src | (uintptr_t)jobs[j].dst) & 3) == 0, "copy_multi: bad job %d", j);
+        P.job[j] = jobs[j];
+        P.first_block[j] = blocks;
+        blocks += (jobs[j].bytes + COPY_BLOCK_BYTES - 1) / COPY_BLOCK_BYTES;
+    }
+    P.first_block[njobs] = blocks;
+    RTK_REQUIRE(blocks < 0x7fffffffL, "copy_multi: too large");
+    copy_multi_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(P);
+    RTK_CHECK_LAUNCH("copy_multi");
     return RTK_OK;
 }
 

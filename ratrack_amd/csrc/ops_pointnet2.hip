@@ -568,58 +568,106 @@ extern "C" int rtk_ball_query(int b, int n, int npoint, float radius, int nsampl
 
 // Both scales of an MSG level in one scan (radius1 <= radius2, so every scale-1 hit is a scale-2 hit).
 // (body: workgroup `chunk` of sample `bs`; smem = 3 n floats.  Shared by ball_query_pair_kernel and geometry_tables_kernel.)
-__device__ __forceinline__ void ball_query_pair_body(int bs, int chunk, int n, int m, float r2a, int nsa, float r2b, int nsb,
+__device__ __forceinline__ void ball_query_pair_body(int bs, int chunk0, int chunk_stride, int n, int m, float r2a, int nsa, float r2b, int nsb,
                                                      const float *__restrict__ new_xyz, const float *__restrict__ xyz,
                                                      int *__restrict__ idxa, int *__restrict__ idxb, const int *__restrict__ nuniq,
-                                                     float *smem) {
+                                                     float *smem, const int *__restrict__ src_nuniq = nullptr) {
+    // src_nuniq (optional): source rows >= src_nuniq[bs] are copies of source row 0 (the centroids a level picked after its cloud was
+    // exhausted).  They are hits exactly when row 0 is one, and they follow every unique hit in index order: only the unique prefix
+    // is staged and scanned, and a ball that contains row 0 and is not full yet takes the indices src_nuniq[bs], src_nuniq[bs] + 1, ...
+    // -- the table the full scan writes, at half the scan for the levels above an over-sampled one.
+    // The workgroup takes chunks chunk0, chunk0 + chunk_stride, ... of its sample (a chunk = BQ_WAVES * BQ_CENTROIDS_PER_WAVE centroids):
+    // the cloud is staged once, and a launch of a few thousand fat workgroups is not bound by the rate workgroups can be dispatched at
+    // (rtk_geometry_tables: 35 k one-chunk workgroups took 90 us, the sum of the launches they came from).
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    constexpr int CPC = BQ_WAVES * BQ_CENTROIDS_PER_WAVE;
     xyz += (size_t)bs * n * 3;
     float *sx = smem, *sy = smem + n, *sz = smem + 2 * n;
-    const int c0 = (chunk * BQ_WAVES + wave) * BQ_CENTROIDS_PER_WAVE;
     const int climit = nuniq ? min(m, nuniq[bs]) : m;
-    if (chunk * BQ_WAVES * BQ_CENTROIDS_PER_WAVE >= climit) return;      // whole workgroup beyond the unique centroids
+    if (chunk0 * CPC >= climit) return;      // whole workgroup beyond the unique centroids
+    const int n_full = n;
+    if (src_nuniq) n = max(1, min(n, src_nuniq[bs]));
+    if (chunk0 == 0) {
+        // rows [climit, next multiple of 32) read as zeros: a consumer's last tile of centroids may load the index rows of the (skipped)
+        // duplicates next to the live ones before it masks them, and the tables need not be zero-filled by the caller for that
+        const int z1 = min(m, (climit + 31) & ~31);
+        int *za = idxa + ((size_t)bs * m + climit) * nsa, *zb = idxb + ((size_t)bs * m + climit) * nsb;
+        for (int l = tid; l < (z1 - climit) * nsa; l += 64 * BQ_WAVES) za[l] = 0;
+        for (int l = tid; l < (z1 - climit) * nsb; l += 64 * BQ_WAVES) zb[l] = 0;
+    }
     for (int k = tid; k < n; k += 64 * BQ_WAVES) {
         sx[k] = xyz[k * 3 + 0];
         sy[k] = xyz[k * 3 + 1];
         sz[k] = xyz[k * 3 + 2];
     }
     // the coordinates of all of this wave's centroids in ONE round trip (lane l: component l % 3 of centroid l / 3), handed out by
-    // shuffles: fetched at the top of each iteration they were eight dependent global-load latencies per wave -- most of the kernel
-    float cq = 0.f;
-    if (lane < 3 * BQ_CENTROIDS_PER_WAVE && c0 + lane / 3 < climit) cq = new_xyz[((size_t)bs * m + c0 + lane / 3) * 3 + lane % 3];
+    // shuffles: fetched at the top of each iteration they were eight dependent global-load latencies per wave -- most of the kernel;
+    // the next chunk's are requested before this chunk's scan
+    auto fetch = [&](int chunk) {
+        const int c0 = (chunk * BQ_WAVES + wave) * BQ_CENTROIDS_PER_WAVE;
+        float v = 0.f;
+        if (lane < 3 * BQ_CENTROIDS_PER_WAVE && c0 + lane / 3 < climit) v = new_xyz[((size_t)bs * m + c0 + lane / 3) * 3 + lane % 3];
+        return v;
+    };
+    float cq = fetch(chunk0);
     __syncthreads();
-    for (int ci = 0; ci < BQ_CENTROIDS_PER_WAVE; ++ci) {
-        const int pt = c0 + ci;
-        if (pt >= climit) break;
-        const float qx = __shfl(cq, 3 * ci, 64), qy = __shfl(cq, 3 * ci + 1, 64), qz = __shfl(cq, 3 * ci + 2, 64);
-        int *oa = idxa + ((size_t)bs * m + pt) * nsa;
-        int *ob = idxb + ((size_t)bs * m + pt) * nsb;
-        int ca = 0, cb = 0, fa = -1, fb = -1;
-        for (int base = 0; base < n && (ca < nsa || cb < nsb); base += 64) {
-            const int k = base + lane;
-            float d2 = INFINITY;
-            if (k < n) d2 = rtk_sqdist(qx, qy, qz, sx[k], sy[k], sz[k]);
-            const bool hb = d2 < r2b, ha = d2 < r2a;
-            const unsigned long long mb = __ballot(hb);
-            if (mb) {
-                const unsigned long long below = (1ull << lane) - 1ull;
-                if (cb < nsb) {
-                    if (fb < 0) fb = base + __builtin_ctzll(mb);
-                    const int rank = cb + __builtin_popcountll(mb & below);
-                    if (hb && rank < nsb) ob[rank] = k;
-                    cb += __builtin_popcountll(mb);
-                }
-                const unsigned long long ma = __ballot(ha);
-                if (ma && ca < nsa) {
-                    if (fa < 0) fa = base + __builtin_ctzll(ma);
-                    const int rank = ca + __builtin_popcountll(ma & below);
-                    if (ha && rank < nsa) oa[rank] = k;
-                    ca += __builtin_popcountll(ma);
+    for (int chunk = chunk0; chunk * CPC < climit; chunk += chunk_stride) {
+        const int c0 = (chunk * BQ_WAVES + wave) * BQ_CENTROIDS_PER_WAVE;
+        const float cq_next = (chunk_stride > 0 && (long)(chunk + chunk_stride) * CPC < climit) ? fetch(chunk + chunk_stride) : 0.f;
+        for (int ci = 0; ci < BQ_CENTROIDS_PER_WAVE; ++ci) {
+            const int pt = c0 + ci;
+            if (pt >= climit) break;
+            const float qx = __shfl(cq, 3 * ci, 64), qy = __shfl(cq, 3 * ci + 1, 64), qz = __shfl(cq, 3 * ci + 2, 64);
+            int *oa = idxa + ((size_t)bs * m + pt) * nsa;
+            int *ob = idxb + ((size_t)bs * m + pt) * nsb;
+            int ca = 0, cb = 0, fa = -1, fb = -1;
+            bool a0 = false, b0 = false;      // source row 0 inside the ball
+            for (int base = 0; base < n && (ca < nsa || cb < nsb); base += 64) {
+                const int k = base + lane;
+                float d2 = INFINITY;
+                if (k < n) d2 = rtk_sqdist(qx, qy, qz, sx[k], sy[k], sz[k]);
+                const bool hb = d2 < r2b, ha = d2 < r2a;
+                const unsigned long long mb = __ballot(hb);
+                if (mb) {
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    if (base == 0) b0 = (mb & 1ull) != 0ull;
+                    if (cb < nsb) {
+                        if (fb < 0) fb = base + __builtin_ctzll(mb);
+                        const int rank = cb + __builtin_popcountll(mb & below);
+                        if (hb && rank < nsb) ob[rank] = k;
+                        cb += __builtin_popcountll(mb);
+                    }
+                    const unsigned long long ma = __ballot(ha);
+                    if (base == 0) a0 = (ma & 1ull) != 0ull;
+                    if (ma && ca < nsa) {
+                        if (fa < 0) fa = base + __builtin_ctzll(ma);
+                        const int rank = ca + __builtin_popcountll(ma & below);
+                        if (ha && rank < nsa) oa[rank] = k;
+                        ca += __builtin_popcountll(ma);
+                    }
                 }
             }
+            if (n < n_full) {                 // the copies of row 0 beyond the unique prefix, in index order
+                if (a0 && ca < nsa) {
+                    const int cnt = min(nsa - ca, n_full - n);
+                    for (int l = lane; l < cnt; l += 64) oa[ca + l] = n + l;
+                    ca += cnt;
+                }
+                if (b0 && cb < nsb) {
+                    const int cnt = min(nsb - cb, n_full - n);
+                    for (int l = lane; l < cnt; l += 64) ob[cb + l] = n + l;
+                    cb += cnt;
+                }
+            }
+            if (fa >= 0 && ca < nsa) for (int l = ca + lane; l < nsa; l += 64) oa[l] = fa;
+            if (fb >= 0 && cb < nsb) for (int l = cb + lane; l < nsb; l += 64) ob[l] = fb;
+            // an empty ball reads as zeros (what the caller's zero-initialisation leaves there in the reference, lib/pointnet2_utils.py:246):
+            // written here, so that the fused geometry needs no fill of its 9 MB of tables
+            if (fa < 0) for (int l = lane; l < nsa; l += 64) oa[l] = 0;
+            if (fb < 0) for (int l = lane; l < nsb; l += 64) ob[l] = 0;
         }
-        if (fa >= 0 && ca < nsa) for (int l = ca + lane; l < nsa; l += 64) oa[l] = fa;
-        if (fb >= 0 && cb < nsb) for (int l = cb + lane; l < nsb; l += 64) ob[l] = fb;
+        if (chunk_stride <= 0) break;
+        cq = cq_next;
     }
 }
 
@@ -628,7 +676,7 @@ __global__ __launch_bounds__(64 * BQ_WAVES) void ball_query_pair_kernel(int n, i
                                                                          const float *__restrict__ xyz, int *__restrict__ idxa,
                                                                          int *__restrict__ idxb, const int *__restrict__ nuniq) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    ball_query_pair_body(blockIdx.y, blockIdx.x, n, m, r2a, nsa, r2b, nsb, new_xyz, xyz, idxa, idxb, nuniq, smem);
+    ball_query_pair_body(blockIdx.y, blockIdx.x, 0, n, m, r2a, nsa, r2b, nsb, new_xyz, xyz, idxa, idxb, nuniq, smem);
 }
 
 extern "C" int rtk_ball_query_pair(int b, int n, int npoint, float radius1, int nsample1, float radius2, int nsample2,
@@ -838,8 +886,8 @@ __device__ __forceinline__ unsigned dpp_pull(unsigned v) {   // row_shl:n -> lan
     return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
 }
 
-// merge the lists of the 16 lanes of a row into lane 0 of the row
-template <int K>
+// merge the lists of the LPQ (4 or 16) consecutive lanes that share a query into the first of them (the other lanes end with garbage)
+template <int K, int LPQ = 16>
 __device__ __forceinline__ void kv_row_merge(unsigned (&d)[K], int (&i)[K]) {
     unsigned od[K];
     int oi[K];
@@ -849,13 +897,25 @@ __device__ __forceinline__ void kv_row_merge(unsigned (&d)[K], int (&i)[K]) {
 #pragma unroll
     for (int a = 0; a < K; ++a) { od[a] = dpp_pull<0x102>(d[a]); oi[a] = (int)dpp_pull<0x102>((unsigned)i[a]); }
     kv_merge_low<K>(d, i, od, oi);
+    if constexpr (LPQ == 16) {
 #pragma unroll
-    for (int a = 0; a < K; ++a) { od[a] = dpp_pull<0x104>(d[a]); oi[a] = (int)dpp_pull<0x104>((unsigned)i[a]); }
-    kv_merge_low<K>(d, i, od, oi);
+        for (int a = 0; a < K; ++a) { od[a] = dpp_pull<0x104>(d[a]); oi[a] = (int)dpp_pull<0x104>((unsigned)i[a]); }
+        kv_merge_low<K>(d, i, od, oi);
 #pragma unroll
-    for (int a = 0; a < K; ++a) { od[a] = dpp_pull<0x108>(d[a]); oi[a] = (int)dpp_pull<0x108>((unsigned)i[a]); }
-    kv_merge_low<K>(d, i, od, oi);
+        for (int a = 0; a < K; ++a) { od[a] = dpp_pull<0x108>(d[a]); oi[a] = (int)dpp_pull<0x108>((unsigned)i[a]); }
+        kv_merge_low<K>(d, i, od, oi);
+    } else {
+        static_assert(LPQ == 4, "4 or 16 lanes per query");
+    }
 }
+
+// Lanes per query of the selection kernels.  Round 6: 4 (rounds 1-5: 16).  With 16 lanes the four cross-lane merge steps were a quarter
+// (three-NN) to a half (kNN) of a query's instructions -- the fastest way to ONE query's answer, and at B = 64 a launch of them is
+// bound by VALU issue, not by latency (three-NN: ~175 instructions per query with 16 lanes, ~100 with 4; kNN: ~475 -> ~220).
+#ifndef KV_LPQ
+#define KV_LPQ 4
+#endif
+constexpr int KV_QPW = 256 / KV_LPQ;      // queries per 256-thread workgroup (= per chunk)
 
 // ------------------------------------------------------------------------------------------------
 // three_nn   (interpolate_gpu.cu:81-124)
@@ -865,12 +925,15 @@ __device__ __forceinline__ void kv_row_merge(unsigned (&d)[K], int (&i)[K]) {
 // (body: workgroup `chunk` -- 16 queries -- of sample `bs`; smem = 3 m floats with USE_LDS.  Shared by three_nn_kernel and
 // geometry_tables_kernel.)
 template <bool USE_LDS>
-__device__ __forceinline__ void three_nn_body(int bs, int chunk, int n, int m, const float *__restrict__ unknown,
+__device__ __forceinline__ void three_nn_body(int bs, int chunk0, int chunk_stride, int n, int m, const float *__restrict__ unknown,
                                               const float *__restrict__ known, float *__restrict__ dist2,
                                               int *__restrict__ idx, const int *__restrict__ unknown_nuniq,
                                               const int *__restrict__ known_nuniq, float *smem) {
+    // chunks chunk0, chunk0 + chunk_stride, ... (KV_QPW queries each, KV_LPQ lanes per query; chunk_stride = 0: one chunk), the known
+    // cloud staged once
     const int tid = threadIdx.x;
-    if (unknown_nuniq && chunk * 16 >= unknown_nuniq[bs]) return;    // all 16 queries of this workgroup are duplicate rows
+    const int qlimit = unknown_nuniq ? min(n, unknown_nuniq[bs]) : n;      // queries >= unknown_nuniq[bs] are duplicate rows: not computed
+    if (chunk0 * KV_QPW >= qlimit) return;
     // known rows >= known_nuniq[b] are copies of known row 0: of those only the first two (lowest indices) can reach the
     // top 3, at the distance of row 0 -- scan the unique prefix and add these two candidates: identical result, half the scan
     const int m_full = m;
@@ -879,11 +942,15 @@ __device__ __forceinline__ void three_nn_body(int bs, int chunk, int n, int m, c
     m = ke;
     float *sx = smem, *sy = smem + m, *sz = smem + 2 * m;
     // the query's coordinates are requested before the staging loop and its barrier: one global round trip instead of two in a row
-    const int li = tid & 15;
-    const int pt_raw = chunk * 16 + (tid >> 4);
-    const int pt = pt_raw < n ? pt_raw : n - 1;
-    const float *u = unknown + ((size_t)bs * n + pt) * 3;
-    const float ux = u[0], uy = u[1], uz = u[2];
+    // (and the next chunk's before this chunk's scan)
+    const int li = tid & (KV_LPQ - 1);
+    auto query = [&](int chunk, float &x, float &y, float &z) {
+        const int pr = chunk * KV_QPW + tid / KV_LPQ;
+        const float *u = unknown + ((size_t)bs * n + (pr < n ? pr : n - 1)) * 3;
+        x = u[0]; y = u[1]; z = u[2];
+    };
+    float ux, uy, uz;
+    query(chunk0, ux, uy, uz);
     if (USE_LDS) {
         for (int k = tid; k < m; k += 256) {
             sx[k] = known[k * 3 + 0];
@@ -892,40 +959,48 @@ __device__ __forceinline__ void three_nn_body(int bs, int chunk, int n, int m, c
         }
         __syncthreads();
     }
-    unsigned d[4] = {KEY_INF_D, KEY_INF_D, KEY_INF_D, KEY_INF_D};
-    int i[4] = {KEY_INF_I, KEY_INF_I, KEY_INF_I, KEY_INF_I};
-    for (int k = li; k < m; k += 16) {
-        const float kx = USE_LDS ? sx[k] : known[k * 3 + 0];
-        const float ky = USE_LDS ? sy[k] : known[k * 3 + 1];
-        const float kz = USE_LDS ? sz[k] : known[k * 3 + 2];
-        const float dd = rtk_sqdist(ux, uy, uz, kx, ky, kz);
-        if (dd < INFINITY) {    // the reference's `d < 1e40` predicate: inf / NaN never enter
-            d[3] = __float_as_uint(dd); i[3] = k;
-            kv_cex(d[2], i[2], d[3], i[3]);
-            kv_cex(d[1], i[1], d[2], i[2]);
-            kv_cex(d[0], i[0], d[1], i[1]);
+    for (int chunk = chunk0; chunk * KV_QPW < qlimit; chunk += chunk_stride) {
+        const int pt_raw = chunk * KV_QPW + tid / KV_LPQ;
+        const int pt = pt_raw < n ? pt_raw : n - 1;
+        float nx = 0.f, ny = 0.f, nz = 0.f;
+        if (chunk_stride > 0 && (chunk + chunk_stride) * KV_QPW < qlimit) query(chunk + chunk_stride, nx, ny, nz);
+        unsigned d[4] = {KEY_INF_D, KEY_INF_D, KEY_INF_D, KEY_INF_D};
+        int i[4] = {KEY_INF_I, KEY_INF_I, KEY_INF_I, KEY_INF_I};
+        for (int k = li; k < m; k += KV_LPQ) {
+            const float kx = USE_LDS ? sx[k] : known[k * 3 + 0];
+            const float ky = USE_LDS ? sy[k] : known[k * 3 + 1];
+            const float kz = USE_LDS ? sz[k] : known[k * 3 + 2];
+            const float dd = rtk_sqdist(ux, uy, uz, kx, ky, kz);
+            if (dd < INFINITY) {    // the reference's `d < 1e40` predicate: inf / NaN never enter
+                d[3] = __float_as_uint(dd); i[3] = k;
+                kv_cex(d[2], i[2], d[3], i[3]);
+                kv_cex(d[1], i[1], d[2], i[2]);
+                kv_cex(d[0], i[0], d[1], i[1]);
+            }
         }
-    }
-    if (li >= 1 && li <= 2 && ke + li - 1 < m_full) {          // the two possible duplicate-of-row-0 candidates: indices ke, ke+1
-        const float kx = USE_LDS ? sx[0] : known[0], ky = USE_LDS ? sy[0] : known[1], kz = USE_LDS ? sz[0] : known[2];
-        const float dd = rtk_sqdist(ux, uy, uz, kx, ky, kz);
-        if (dd < INFINITY) {
-            d[3] = __float_as_uint(dd); i[3] = ke + li - 1;
-            kv_cex(d[2], i[2], d[3], i[3]);
-            kv_cex(d[1], i[1], d[2], i[2]);
-            kv_cex(d[0], i[0], d[1], i[1]);
+        if (li >= 1 && li <= 2 && ke + li - 1 < m_full) {          // the two possible duplicate-of-row-0 candidates: indices ke, ke+1
+            const float kx = USE_LDS ? sx[0] : known[0], ky = USE_LDS ? sy[0] : known[1], kz = USE_LDS ? sz[0] : known[2];
+            const float dd = rtk_sqdist(ux, uy, uz, kx, ky, kz);
+            if (dd < INFINITY) {
+                d[3] = __float_as_uint(dd); i[3] = ke + li - 1;
+                kv_cex(d[2], i[2], d[3], i[3]);
+                kv_cex(d[1], i[1], d[2], i[2]);
+                kv_cex(d[0], i[0], d[1], i[1]);
+            }
         }
-    }
-    d[3] = KEY_INF_D; i[3] = KEY_INF_I;
-    kv_row_merge<4>(d, i);
-    if (li == 0 && pt_raw < n) {
-        float *od = dist2 + ((size_t)bs * n + pt) * 3;
-        int *oi = idx + ((size_t)bs * n + pt) * 3;
+        d[3] = KEY_INF_D; i[3] = KEY_INF_I;
+        kv_row_merge<4, KV_LPQ>(d, i);
+        if (li == 0 && pt_raw < n) {
+            float *od = dist2 + ((size_t)bs * n + pt) * 3;
+            int *oi = idx + ((size_t)bs * n + pt) * 3;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            od[a] = __uint_as_float(d[a]);
-            oi[a] = d[a] == KEY_INF_D ? 0 : i[a];
+            for (int a = 0; a < 3; ++a) {
+                od[a] = __uint_as_float(d[a]);
+                oi[a] = d[a] == KEY_INF_D ? 0 : i[a];
+            }
         }
+        if (chunk_stride <= 0) break;
+        ux = nx; uy = ny; uz = nz;
     }
 }
 
@@ -935,14 +1010,14 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float
                                                        int *__restrict__ idx, const int *__restrict__ unknown_nuniq,
                                                        const int *__restrict__ known_nuniq) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    three_nn_body<USE_LDS>(blockIdx.y, blockIdx.x, n, m, unknown, known, dist2, idx, unknown_nuniq, known_nuniq, smem);
+    three_nn_body<USE_LDS>(blockIdx.y, blockIdx.x, 0, n, m, unknown, known, dist2, idx, unknown_nuniq, known_nuniq, smem);
 }
 
 extern "C" int rtk_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
                             rtk_stream_t stream) {
     RTK_REQUIRE(b > 0 && n > 0 && m > 0 && unknown && known && dist2 && idx, "three_nn: bad arguments");
     RTK_REQUIRE(b <= 65535, "three_nn: b exceeds grid limits");
-    dim3 grid(rtk_divup(n, 16), b);
+    dim3 grid(rtk_divup(n, KV_QPW), b);
     const size_t lds = (size_t)m * 3 * sizeof(float);
     if (lds <= 64 * 1024)
         three_nn_kernel<true><<<grid, 256, lds, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx, nullptr, nullptr);
@@ -956,7 +1031,7 @@ extern "C" int rtk_three_nn_masked(int b, int n, int m, const float *unknown, co
                                    const int *unknown_nuniq, const int *known_nuniq, rtk_stream_t stream) {
     RTK_REQUIRE(b > 0 && n > 0 && m > 0 && unknown && known && dist2 && idx, "three_nn_masked: bad arguments");
     RTK_REQUIRE(b <= 65535, "three_nn_masked: b exceeds grid limits");
-    dim3 grid(rtk_divup(n, 16), b);
+    dim3 grid(rtk_divup(n, KV_QPW), b);
     const size_t lds = (size_t)m * 3 * sizeof(float);
     if (lds <= 64 * 1024)
         three_nn_kernel<true><<<grid, 256, lds, (hipStream_t)stream>>>(n, m, unknown, known, dist2, idx, unknown_nuniq, known_nuniq);
@@ -1129,7 +1204,7 @@ extern "C" int rtk_three_interpolate_grad_set(int b, int c, int n, int m, const 
 // Distances follow the expansion formula of the arithmetic contract so the neighbour SET equals the
 // CPU reference's; output order is (distance, index) ascending.
 // ------------------------------------------------------------------------------------------------
-// (body: workgroup `chunk` -- 16 queries -- of sample `bs`; smem = 4 n floats with USE_LDS.  Component c of point j of a sample sits
+// (body: workgroup `chunk` -- KV_QPW queries -- of sample `bs`; smem = 4 n floats with USE_LDS.  Component c of point j of a sample sits
 // at base + j * ps + c * cs: (ps, cs) = (3, 1) for point-major (n, 3) clouds, (1, pitch) for the API's channel-major (3, n) ones.
 // Shared by knn_point_kernel and geometry_front_kernel.)
 template <int K, bool USE_LDS>
@@ -1151,8 +1226,8 @@ __device__ __forceinline__ void knn_point_body(int bs, int chunk, int s, int n, 
         }
         __syncthreads();
     }
-    const int li = tid & 15;
-    const int qi_raw = chunk * 16 + (tid >> 4);
+    const int li = tid & (KV_LPQ - 1);
+    const int qi_raw = chunk * KV_QPW + tid / KV_LPQ;
     const int qi = qi_raw < s ? qi_raw : s - 1;
     const float *q = query + (size_t)bs * s * 3 + (size_t)qi * q_ps;
     const float qx = q[0], qy = q[q_cs], qz = q[2 * q_cs];
@@ -1161,12 +1236,12 @@ __device__ __forceinline__ void knn_point_body(int bs, int chunk, int s, int n, 
     int bi[K];
 #pragma unroll
     for (int a = 0; a < K; ++a) { bd[a] = KEY_INF_D; bi[a] = KEY_INF_I; }
-    for (int base = 0; base < n; base += 16 * K) {
+    for (int base = 0; base < n; base += KV_LPQ * K) {
         unsigned cd[K];
         int ci[K];
 #pragma unroll
         for (int a = 0; a < K; ++a) {
-            const int j = base + li + 16 * a;
+            const int j = base + li + KV_LPQ * a;
             cd[a] = KEY_INF_D; ci[a] = KEY_INF_I;
             if (j < n) {
                 float px, py, pz, pn;
@@ -1184,7 +1259,7 @@ __device__ __forceinline__ void knn_point_body(int bs, int chunk, int s, int n, 
         kv_bitonic_sort<K>(cd, ci);
         kv_merge_low<K>(bd, bi, cd, ci);
     }
-    kv_row_merge<K>(bd, bi);
+    kv_row_merge<K, KV_LPQ>(bd, bi);
     if (li == 0 && qi_raw < s) {
         int64_t *o = idx + ((size_t)bs * s + qi) * k;
 #pragma unroll
@@ -1260,7 +1335,7 @@ static int knn_point_impl(int b, int s, int n, int k, const float *query, const 
     RTK_REQUIRE(b > 0 && s > 0 && n > 0 && query && points && idx, "knn_point: bad arguments");
     RTK_REQUIRE(k >= 1 && k <= n, "knn_point: k=%d outside [1, n=%d]", k, n);
     RTK_REQUIRE(b <= 65535, "knn_point: b exceeds grid limits");
-    dim3 grid(rtk_divup(s, 16), b);
+    dim3 grid(rtk_divup(s, KV_QPW), b);
     const size_t lds = (size_t)n * 4 * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     const bool use_lds = lds <= 64 * 1024;
@@ -1365,6 +1440,7 @@ __global__ __launch_bounds__(256) void geometry_front_kernel(const GeoFrontParam
     const int nu3 = fps_cloud_level<PPL2>(m, m, P.block_np, x2, 3, 1, nullptr, i3, x3, s_geo, lane, tie3, -1, nullptr, nullptr, tie2, nu2, j_start, snap, i1,
                                           i2);
     if (lane == 0) {
+        P.first_tie[s] = ft1;                          // (0: none -- written unconditionally: the workspace needs no zero fill)
         P.nuniq[s] = nu1; P.nuniq[S_ + s] = nu2; P.nuniq[2 * S_ + s] = nu3;
         P.tie[s] = tie1; P.tie[S_ + s] = tie2; P.tie[2 * S_ + s] = tie3;
     }
@@ -1386,7 +1462,7 @@ extern "C" int rtk_geometry_front(int b, int clouds, int n, int npoint, const fl
     P.fr1 = frame1; P.fr2 = frame2; P.ps = channel_major ? 1 : 3; P.cs = channel_major ? n : 1;
     P.f1 = feature1; P.f2 = feature2; P.xyz_out = xyz; P.raw_out = raw;
     P.fps_idx = fps_idx; P.new_xyz = new_xyz; P.nuniq = nuniq; P.tie = tie; P.first_tie = first_tie; P.snap = snap; P.n_valid = n_valid;
-    P.knn12 = knn12; P.knn11 = knn11; P.knn_chunks = rtk_divup(n, 16);
+    P.knn12 = knn12; P.knn11 = knn11; P.knn_chunks = rtk_divup(n, KV_QPW);
     const int grid = clouds + (knn12 ? 2 * b * P.knn_chunks : 0);
     const size_t lds = (size_t)(n > npoint ? n : npoint) * sizeof(float4);
     hipStream_t s = (hipStream_t)stream;
@@ -1403,39 +1479,41 @@ struct GeoBallTask {
     float r2a, r2b;
     const float *new_xyz, *xyz;
     int *idxa, *idxb;
-    const int *nuniq;
+    const int *nuniq, *src_nuniq;
 };
 struct GeoNnTask {
-    int n, m, chunks;
+    int n, m, wgs;               // wgs: workgroups per sample
     const float *unknown, *known;
     float *dist2;
     int *idx;
     const int *unknown_nuniq, *known_nuniq;
 };
 struct GeoTablesParams {
-    int samples, npoint, ball_chunks;
+    int samples, npoint, ball_wgs;      // ball_wgs: workgroups per (level, sample)
     GeoBallTask ball[3];
     GeoNnTask nn[3];
 };
 
+// Workgroup w of a (task, sample) takes the task's chunks w, w + W, w + 2 W, ... (interleaved: the chunks beyond the unique centroids,
+// which cost nothing, are spread evenly).
 __global__ __launch_bounds__(256) void geometry_tables_kernel(const GeoTablesParams P) {
     extern __shared__ __attribute__((aligned(16))) float s_tab[];
     int r = blockIdx.x;
-    const int per_ball = P.samples * P.ball_chunks;
+    const int per_ball = P.samples * P.ball_wgs;
     if (r < 3 * per_ball) {
-        const int t = r / per_ball, rem = r - t * per_ball, bs = rem / P.ball_chunks, chunk = rem - bs * P.ball_chunks;
+        const int t = r / per_ball, rem = r - t * per_ball, bs = rem / P.ball_wgs, w = rem - bs * P.ball_wgs;
         const GeoBallTask &T = P.ball[t];
-        ball_query_pair_body(bs, chunk, T.n_src, P.npoint, T.r2a, T.nsa, T.r2b, T.nsb, T.new_xyz, T.xyz, T.idxa, T.idxb, T.nuniq, s_tab);
+        ball_query_pair_body(bs, w, P.ball_wgs, T.n_src, P.npoint, T.r2a, T.nsa, T.r2b, T.nsb, T.new_xyz, T.xyz, T.idxa, T.idxb, T.nuniq, s_tab, T.src_nuniq);
         return;
     }
     r -= 3 * per_ball;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const GeoNnTask &T = P.nn[t];
-        const int per = P.samples * T.chunks;
+        const int per = P.samples * T.wgs;
         if (r < per) {
-            const int bs = r / T.chunks, chunk = r - bs * T.chunks;
-            three_nn_body<true>(bs, chunk, T.n, T.m, T.unknown, T.known, T.dist2, T.idx, T.unknown_nuniq, T.known_nuniq, s_tab);
+            const int bs = r / T.wgs, w = r - bs * T.wgs;
+            three_nn_body<true>(bs, w, T.wgs, T.n, T.m, T.unknown, T.known, T.dist2, T.idx, T.unknown_nuniq, T.known_nuniq, s_tab);
             return;
         }
         r -= per;
@@ -1453,7 +1531,10 @@ extern "C" int rtk_geometry_tables(int samples, int n, int npoint, const float *
     const int big = n > npoint ? n : npoint;
     RTK_REQUIRE((size_t)big * 12 <= 64 * 1024, "geometry_tables: clouds of %d points do not fit the LDS stage", big);
     GeoTablesParams P;
-    P.samples = samples; P.npoint = npoint; P.ball_chunks = rtk_divup(npoint, BQ_WAVES * BQ_CENTROIDS_PER_WAVE);
+    // workgroups per (task, sample): enough of them to fill the chip (~2 k in all over the nine tasks), never more than the task has chunks
+    const int want = rtk_divup(2048, 9 * samples);
+    const int ball_chunks = rtk_divup(npoint, BQ_WAVES * BQ_CENTROIDS_PER_WAVE);
+    P.samples = samples; P.npoint = npoint; P.ball_wgs = want < ball_chunks ? want : ball_chunks;
     const size_t lv = (size_t)samples * npoint * 3;
     const float *lvl_xyz[4] = {xyz0, new_xyz, new_xyz + lv, new_xyz + 2 * lv};
     const int lvl_n[4] = {n, npoint, npoint, npoint};
@@ -1464,19 +1545,20 @@ extern "C" int rtk_geometry_tables(int samples, int n, int npoint, const float *
         T.n_src = lvl_n[l]; T.nsa = nsamples[2 * l]; T.nsb = nsamples[2 * l + 1];
         T.r2a = radii[2 * l] * radii[2 * l]; T.r2b = radii[2 * l + 1] * radii[2 * l + 1];      // fp32 products, as ball_query_gpu.cu:23
         T.new_xyz = lvl_xyz[l + 1]; T.xyz = lvl_xyz[l]; T.idxa = ball[2 * l]; T.idxb = ball[2 * l + 1]; T.nuniq = nuniq + (size_t)l * samples;
+        T.src_nuniq = l > 0 ? nuniq + (size_t)(l - 1) * samples : nullptr;
     }
     // fp3: unknown level 2, known level 3; fp2: unknown level 1, known level 2; fp1: unknown level 0 (the points), known level 1
     const int uk[3][2] = {{2, 3}, {1, 2}, {0, 1}};
-    int total = 3 * samples * P.ball_chunks;
+    int total = 3 * samples * P.ball_wgs;
     for (int i = 0; i < 3; ++i) {
         const int u = uk[i][0], k = uk[i][1];
         RTK_REQUIRE(nn_idx[i] && nn_dist2[i], "geometry_tables: three-NN table %d missing", i);
         GeoNnTask &T = P.nn[i];
-        T.n = lvl_n[u]; T.m = lvl_n[k]; T.chunks = rtk_divup(T.n, 16);
+        T.n = lvl_n[u]; T.m = lvl_n[k]; T.wgs = want < rtk_divup(T.n, KV_QPW) ? want : rtk_divup(T.n, KV_QPW);
         T.unknown = lvl_xyz[u]; T.known = lvl_xyz[k]; T.dist2 = nn_dist2[i]; T.idx = nn_idx[i];
         T.unknown_nuniq = u > 0 ? nuniq + (size_t)(u - 1) * samples : nullptr;
         T.known_nuniq = nuniq + (size_t)(k - 1) * samples;
-        total += samples * T.chunks;
+        total += samples * T.wgs;
     }
     geometry_tables_kernel<<<total, 256, (size_t)big * 12, (hipStream_t)stream>>>(P);
     RTK_CHECK_LAUNCH("geometry_tables");

@@ -66,6 +66,33 @@ _lib.SIGNATURES.update({
 })
 
 
+class _GtJob(ctypes.Structure):
+    _fields_ = [("wt", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("out", ctypes.c_void_p), ("cout", ctypes.c_int), ("s0", ctypes.c_int),
+                ("count", ctypes.c_int), ("out_pitch", ctypes.c_int)]
+
+
+class _CopyJob(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("bytes", ctypes.c_long)]
+
+
+_lib.SIGNATURES.update({
+    "rtk_gru_step_head": [_ci] * 3 + [_vp] * 11 + [_ci, _vp],
+    "rtk_global_terms": [_ci, _ci, _vp, _ci, ctypes.POINTER(_GtJob), _vp, _ci, _ci, _vp],
+    "rtk_copy_multi": [_ci, ctypes.POINTER(_CopyJob), _vp],
+})
+
+
+def copy_multi(pairs):
+    """[(dst, src), ...] contiguous same-shape tensors: one launch (rtk_copy_multi) instead of a framework multi-tensor copy."""
+    for i in range(0, len(pairs), 8):
+        part = pairs[i:i + 8]
+        jobs = (_CopyJob * len(part))()
+        for j, (d, s_) in enumerate(part):
+            assert d.is_contiguous() and s_.is_contiguous() and d.shape == s_.shape and d.dtype == s_.dtype and d.device == s_.device
+            jobs[j].src, jobs[j].dst, jobs[j].bytes = s_.data_ptr(), d.data_ptr(), d.numel() * d.element_size()
+        _lib.call("rtk_copy_multi", len(part), jobs, _stream())
+
+
 class _LayoutJob(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("channels", ctypes.c_int), ("src_pitch", ctypes.c_int),
                 ("per_sample", ctypes.c_int), ("dst_channels", ctypes.c_int), ("dst_channel_offset", ctypes.c_int)]
@@ -389,6 +416,7 @@ class _PNHeadWeights:
 
 FUSED_GEOMETRY = True          # the geometry of a batch in two launches (rtk_geometry_front / rtk_geometry_tables); False (tests): the eleven
                                # launches of the separate entry points they replace -- the same tables bit for bit
+GEOMETRY_POISON = None         # tests: an int32 pattern for the (otherwise uninitialised) index workspace of the two-launch eval geometry
 CHECK_FPS_RELEVEL = False      # debug: compare every re-levelling launch with the full selection (synchronises; tests set it)
 
 
@@ -436,6 +464,7 @@ class Geometry:
         event is recorded / after the three-NN tables -- the training path enqueues its per-level tables there.
         zeros(n, dtype, device): allocator of the zero-initialised workspaces (default torch.zeros; the training path passes its
         step arena, whose one fill then covers these too)."""
+        zeros_given = zeros
         zeros = zeros or (lambda n_, dtype, device: torch.zeros(n_, dtype=dtype, device=device))
         S_, n, _ = xyz.shape
         if n_valid is not None:
@@ -453,7 +482,17 @@ class Geometry:
         ns_all = [ns for row in _PNHeadWeights.NSAMPLES for ns in row]
         nn_rows = [npoint, npoint, n]
         sizes = [S_ * npoint] * 3 + [S_] * 7 + [S_ * npoint * ns for ns in ns_all] + [S_ * r * 3 for r in nn_rows]
-        ws = zeros(sum(sizes), torch.int32, dev)
+        # The two-launch geometry writes every entry a consumer reads (the skipped rows of duplicate centroids are read by nothing:
+        # every consumer takes the duplicate-row counters), so the eval path's workspace is not filled (a 9 MB fill per batch until
+        # round 6); GEOMETRY_POISON (tests) fills it with an out-of-range index instead, which a stray read would turn into a fault.
+        fused_geo = (FUSED_GEOMETRY and n <= 2048 and npoint <= 512 and max(n, npoint) * 12 <= 64 * 1024 and
+                     (not knn_frames or (n >= 16 and S_ == 2 * knn_frames)) and (prepare is None or S_ % 2 == 0))
+        if fused_geo and zeros_given is None and not finite:
+            ws = torch.empty(sum(sizes), dtype=torch.int32, device=dev)
+            if GEOMETRY_POISON is not None:
+                ws.fill_(GEOMETRY_POISON)
+        else:
+            ws = zeros(sum(sizes), torch.int32, dev)
         parts = list(torch.split(ws, sizes))
         fps_idx, cnt, tie, tie23, first_tie, ball, nn_idx = parts[0:3], parts[3:6], parts[6], parts[7:9], parts[9], parts[10:16], parts[16:19]
         # level-1 min-distance state at the first tied round, by point index (written for tied clouds only)
@@ -474,8 +513,6 @@ class Geometry:
         # put one real frame pair in three off by 2e-3, only with warm allocator pools)
         self._scratch = (snap, temp, n_valid, xyz)
 
-        fused_geo = (FUSED_GEOMETRY and not big and npoint <= 512 and max(n, npoint) * 12 <= 64 * 1024 and (not B or (n >= 16 and S_ == 2 * B))
-                     and (prepare is None or S_ % 2 == 0))
         self.fused_geometry = fused_geo
         if prepare is not None and not fused_geo:      # on the caller's stream, before the fork: the feature kernels read raw there
             pc1, pc2, f1, f2, raw = prepare
@@ -731,9 +768,11 @@ class FusedBackbone:
         w0 = sd["fc_layer.mlp_convs.0.weight"].double().reshape(256, 515)
         b0 = sd["fc_layer.mlp_convs.0.bias"].double()
         self.p1_loc = Chain([(w0[:, 0:128], z(256), ACT_NONE)], dev)
-        self.p1_glob = Chain([(w0[:, 128:256], b0, ACT_NONE)], dev)          # per-sample term, carries the bias
         self.p2_loc = Chain([(w0[:, 256:384], z(256), ACT_NONE)], dev)
-        self.p2_glob = Chain([(w0[:, 384:512], z(256), ACT_NONE)], dev)
+        # the halves of conv0 that act on the broadcast global features are per-sample terms (rtk_global_terms: transposed fp32 weights)
+        tr = lambda w: w.float().t().contiguous().to(dev)
+        self.p1_glob_wt, self.p1_glob_b = tr(w0[:, 128:256]), b0.float().to(dev).contiguous()      # carries the layer's bias
+        self.p2_glob_wt = tr(w0[:, 384:512])
         self.cv_wd = offset_image(torch.cat([w0[:, 512:515], z(256)[:, None]], 1), dev)
         self.cv_layers = Chain([(sd["fc_layer.mlp_convs.%d.weight" % i].double().reshape(256, 256),
                                  sd["fc_layer.mlp_convs.%d.bias" % i].double(), ACT_LEAKY) for i in (1, 2)], dev)
@@ -763,7 +802,7 @@ class FusedBackbone:
         self.cls_head = Chain([tuple(x) for x in cp], dev)
         fp = predictor("fd_layer.fp", None)
         w_first = fp[0][0]
-        self.flow_glob = Chain([(w_first[:, 128:256], fp[0][1], ACT_NONE)], dev)   # per-sample GRU term + folded BN shift
+        self.flow_glob_wt, self.flow_glob_b = tr(w_first[:, 128:256]), fp[0][1].float().to(dev).contiguous()   # per-sample GRU term + folded BN shift
         fp[0] = [w_first[:, 0:128], z(128), ACT_RELU]
         fp.append([sd["fd_layer.fp.conv2.weight"].double().reshape(3, 32), z(3), ACT_NONE])
         self.flow_head = Chain([tuple(x) for x in fp], dev)
@@ -772,7 +811,7 @@ class FusedBackbone:
         wq_pad = torch.zeros(32, 16, dtype=torch.float64, device=wq.device)
         wq_pad[:, :2] = wq[:, 0:2]
         self.dec_q1 = Chain([(torch.cat([wq_pad, wq[:, 2:130], wq[:, 258:514]], 1), z(32), ACT_NONE)], dev)
-        self.dec_q1_glob = Chain([(wq[:, 130:258], z(32), ACT_NONE)], dev)
+        self.dec_q1_glob_wt = tr(wq[:, 130:258])
 
     # --------------------------------------------------------------------------------------------------
     def backbone(self, pc1, pc2, feature1, feature2, h, n_valid=None):
@@ -801,11 +840,14 @@ class FusedBackbone:
         # (B,256,N) tensors are permuted VIEWS of it -- no layout pass over the outputs
         feat12 = new(2 * B * N, 256)
         loc, glob = run_pnhead(self.enc, geo, q1, out=feat12[:, 0:128])                  # (2B*N, 128) view, (2B, 128)
-        feat12.view(2 * B, N, 256)[:, :, 128:] = glob.unsqueeze(1)
-        f1, f2, g1, g2 = loc[:B * N], loc[B * N:], glob[:B], glob[B:]
+        f1, f2 = loc[:B * N], loc[B * N:]
+        # everything that is a function of the global features, one launch: the per-sample terms of the cost volume's first layer
+        # (frame 1: with the layer's bias; frame 2) and of the decoder's sa1 projection, and the broadcast that fills the global half
+        # of pc{1,2}_features
+        sb1, sb2, sbq = new(B, 256), new(B, 256), new(B, 32)
+        global_terms(glob, [(self.p1_glob_wt, self.p1_glob_b, sb1, 0), (self.p2_glob_wt, None, sb2, B), (self.dec_q1_glob_wt, None, sbq, 0)],
+                     bcast=feat12[:, 128:], n=N)
         # ---- cost volume ---------------------------------------------------------------------------------
-        sb1 = pointwise(B, B, [(g1, 128, False)], self.p1_glob, new(B, 256))
-        sb2 = pointwise(B, B, [(g2, 128, False)], self.p2_glob, new(B, 256))
         p1 = pointwise(B * N, N, [(f1, 128, False)], self.p1_loc, new(B * N, 256), sample_bias=sb1)
         p2 = pointwise(B * N, N, [(f2, 128, False)], self.p2_loc, new(B * N, 256), sample_bias=sb2)
         x1, x2 = xyz[:B], xyz[B:]
@@ -837,14 +879,12 @@ class FusedBackbone:
         # ---- decoder -------------------------------------------------------------------------------------
         cls = torch.empty(B, N, dtype=torch.float32, device=dev)
         pointwise(B * N, N, [(cor, 256, False)], self.cls_head, cls, out_channels=1, channel_major=True)
-        sbq = pointwise(B, B, [(g1, 128, False)], self.dec_q1_glob, new(B, 32))
         q1d = pointwise(B * N, N, [(raw[:B * N], 2, False), (f1, 128, False), (cor, 256, False)], self.dec_q1, new(B * N, 32),
                         sample_bias=sbq)
         prop, gfeat = run_pnhead(self.dec, geo.head(B), q1d)                              # (B*N,128), (B,128)
         if h is None:
             h = torch.zeros(5, B, 128, device=dev, dtype=torch.float32)
-        gout, h_out = self._gru_step(gfeat, h)
-        sbf = pointwise(B, B, [(gout, 128, False)], self.flow_glob, new(B, 128))
+        gout, h_out, sbf = self._gru_step(gfeat, h)          # sbf: the flow head's per-sample term W_glob gout + b (the kernel's epilogue)
         flow = torch.empty(B, 3, N, dtype=torch.float32, device=dev)
         pointwise(B * N, N, [(prop, 128, False)], self.flow_head, flow, out_channels=3, sample_bias=sbf, channel_major=True)
         # ---- API layouts (B,C,N): permuted views of the point-major tensors (same values as the reference's, no copy) ------
@@ -877,12 +917,15 @@ class FusedBackbone:
         L, B, H = h.shape
         if _TRACE is not None:
             _TRACE.append(("gru", B * L, 2 * 3 * H * H))
+            _TRACE.append(("global_terms", B, H * self.flow_glob_wt.shape[1]))
         h_out = torch.empty_like(h)
         y = torch.empty(B, H, dtype=torch.float32, device=h.device)
+        sbf = torch.empty(B, self.flow_glob_wt.shape[1], dtype=torch.float32, device=h.device)
         h = h.contiguous()
-        _lib.call("rtk_gru_step", B, L, H, x.data_ptr(), h.data_ptr(), self.gru_wih.data_ptr(), self.gru_whh.data_ptr(),
-                  self.gru_bih.data_ptr(), self.gru_bhh.data_ptr(), h_out.data_ptr(), y.data_ptr(), _stream())
-        return y, h_out
+        _lib.call("rtk_gru_step_head", B, L, H, x.data_ptr(), h.data_ptr(), self.gru_wih.data_ptr(), self.gru_whh.data_ptr(),
+                  self.gru_bih.data_ptr(), self.gru_bhh.data_ptr(), h_out.data_ptr(), y.data_ptr(), self.flow_glob_wt.data_ptr(),
+                  self.flow_glob_b.data_ptr(), sbf.data_ptr(), sbf.shape[1], _stream())
+        return y, h_out, sbf
 
     def time_dominant_kernel(self, iters=20):
         """(start, stop) HIP-event pairs around `iters` launches of the cost-volume kernel on the current
@@ -920,8 +963,8 @@ class FusedBackbone:
 
             def step(*new_inputs):
                 pairs = [(d, s_) for d, s_ in zip(static, new_inputs) if s_ is not None]
-                if pairs:       # ONE multi-tensor copy into the static buffers instead of five device-to-device memcpys
-                    torch._foreach_copy_([p[0] for p in pairs], [p[1] for p in pairs])
+                if pairs:       # ONE launch (rtk_copy_multi) into the static buffers instead of five device-to-device memcpys
+                    _copy_inputs(pairs)
                 graph.replay()
                 return outs
             step.graph = graph
@@ -952,7 +995,7 @@ class FusedBackbone:
         def step(*new_inputs):
             pairs = [(d, s_) for d, s_ in zip(static, new_inputs) if s_ is not None]
             if pairs:
-                torch._foreach_copy_([p[0] for p in pairs], [p[1] for p in pairs])
+                _copy_inputs(pairs)
             g1.replay()
             ev = eng.kernel_events
             if ev is not None:
@@ -973,6 +1016,31 @@ class FusedBackbone:
             return outs
         step.graph = (g1, g2)
         return step
+
+
+def global_terms(g, jobs, bcast=None, n=0):
+    """rtk_global_terms: g (samples, cin); jobs [(wt (cin, cout), bias (cout) or None, out (count, cout), s0)]: out = W g[s0 : s0 + count] + b;
+    bcast (samples * n, pitch) view: g[s] copied into its first cin columns for every row of sample s."""
+    samples, cin = g.shape
+    arr = (_GtJob * max(len(jobs), 1))()
+    for j, (wt, bias, out, s0) in enumerate(jobs):
+        assert wt.shape == (cin, out.shape[1]) and out.is_contiguous() and wt.is_contiguous()
+        arr[j].wt, arr[j].bias, arr[j].out = wt.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr()
+        arr[j].cout, arr[j].s0, arr[j].count, arr[j].out_pitch = out.shape[1], s0, out.shape[0], out.shape[1]
+    if _TRACE is not None:
+        _TRACE.append(("global_terms", 1, sum(cin * o.shape[0] * o.shape[1] for _, _, o, _ in jobs)))
+    bptr, bpitch = _colptr(bcast) if bcast is not None else (None, 0)
+    _lib.call("rtk_global_terms", samples, cin, g.data_ptr(), len(jobs), arr, bptr, bpitch, n, _stream())
+
+
+def _copy_inputs(pairs):
+    """New inputs into a captured step's static buffers: one launch when every pair is a plain same-dtype contiguous copy, the framework's
+    multi-tensor copy otherwise (strided / other-dtype inputs)."""
+    if all(d.is_contiguous() and s_.is_contiguous() and d.shape == s_.shape and d.dtype == s_.dtype and d.device == s_.device and
+           d.element_size() == 4 for d, s_ in pairs):
+        copy_multi(pairs)
+    else:
+        torch._foreach_copy_([p[0] for p in pairs], [p[1] for p in pairs])
 
 
 class GraphPipeline:

@@ -180,8 +180,8 @@ def test_fused_cost_volume_matches_modules(name, split):
         pm = lambda t: t.permute(0, 2, 1).reshape(B * N, -1).contiguous()
         l1, l2 = pm(feat1[:, :128]), pm(feat2[:, :128])
         g1, g2 = feat1[:, 128:, 0].contiguous(), feat2[:, 128:, 0].contiguous()
-        sb1 = F.pointwise(B, 1, [(g1, 128, False)], eng.p1_glob, new(B, 256))
-        sb2 = F.pointwise(B, 1, [(g2, 128, False)], eng.p2_glob, new(B, 256))
+        sb1, sb2 = new(B, 256), new(B, 256)
+        F.global_terms(torch.cat([g1, g2]), [(eng.p1_glob_wt, eng.p1_glob_b, sb1, 0), (eng.p2_glob_wt, None, sb2, B)])
         p1 = F.pointwise(B * N, N, [(l1, 128, False)], eng.p1_loc, new(B * N, 256), sample_bias=sb1)
         p2 = F.pointwise(B * N, N, [(l2, 128, False)], eng.p2_loc, new(B * N, 256), sample_bias=sb2)
         x1 = pc1.permute(0, 2, 1).contiguous()
@@ -508,7 +508,7 @@ def test_ball_query_pair_and_masked_three_nn():
     for b in range(3):
         e = int(nuniq[b])
         assert torch.equal(idx[b, :e].cpu(), ri[b, :e]) and torch.equal(d2[b, :e].cpu(), rd[b, :e])
-        lim = (e + 15) // 16 * 16
+        lim = (e + 63) // 64 * 64            # a workgroup takes 64 queries (4 lanes each; 16 x 16 lanes until round 6)
         assert (idx[b, lim:] == -1).all()
 
 
@@ -905,3 +905,23 @@ def test_two_launch_geometry_equals_the_separate_launches(case, monkeypatch):
             assert torch.equal(two[k], eleven[k]), k
     if case == "lattice_ties":
         assert int(two["tie"].sum()) > 0 and bool((two["xyz2"] != two["xyz1"]).any()), "the lattice must exercise the tied levels"
+
+
+@pytest.mark.parametrize("B,N", [(4, 256), (3, 242), (2, 1000), (5, 37)])
+def test_unfilled_geometry_workspace_is_never_read(B, N, monkeypatch):
+    """The eval path no longer zero-fills the geometry's index workspace (9 MB per batch): the two launches write every entry a consumer
+    reads.  Two runs with the workspace pre-filled with two different (valid) indices must agree in every output bit -- a stray read
+    of an unwritten entry would gather a different row in the two runs."""
+    from ratrack_amd import synth
+    net = _net()
+    d = synth.make_frame_pairs(B, N, case_id=77)      # (N = 242, 37: the last tile of live centroids is partial)
+    t = [torch.from_numpy(d[k]).to(DEV) for k in ("pc1", "pc2", "feature1", "feature2")]
+    outs = []
+    for poison in (1, 200, None):
+        monkeypatch.setattr(F, "GEOMETRY_POISON", poison)
+        with torch.no_grad():
+            o = net.backbone(*t, None)
+        torch.cuda.synchronize()
+        outs.append([x.detach().clone() for x in o])
+    for a, b, c in zip(*outs):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)) and torch.equal(a.view(torch.int32), c.view(torch.int32))
