@@ -199,7 +199,7 @@ RTK_EXPORT int rtk_gru_step_head(int b, int layers, int hidden, const float *x, 
 /* Everything that is a function of a sample's global (max-pooled) feature g (samples, cin) in one launch (models/track4d.py:89-95
  * broadcasts it over the points and concatenates it to per-point inputs; a concatenated global half of a layer's input is a
  * per-sample bias of that layer): jobs[j]: out[(s - s0), :cout] = W g[s] + bias for s in [s0, s0 + count), wt = W TRANSPOSED
- * (cin, cout) fp32; and, with bcast, bcast[(s n + r) bcast_pitch + c] = g[s][c] for every row r < n of every sample.  cin % 16 == 0. */
+ * (cin, cout) fp32; and, with bcast, bcast[(s n + r) bcast_pitch + c] = g[s][c] for every row r < n of every sample.  cin % 32 == 0. */
 #define RTK_GT_MAX_JOBS 4
 typedef struct {
     const float *wt, *bias;      /* (cin, cout), (cout) or NULL */
@@ -247,11 +247,13 @@ RTK_EXPORT int rtk_three_nn_masked(int b, int n, int m, const float *unknown, co
  * rtk_prepare_inputs' outputs.  The three PNHead levels of rtk_fps_centroids + rtk_fps_relevel: fps_idx (3,S,npoint) int32,
  * new_xyz (3,S,npoint,3), nuniq (3,S), tie (3,S), first_tie (S) (zero-initialised), snap (S,n).  n_valid (S) optional.
  * knn12 / knn11 (B,n,16) int64 (optional, together): rtk_knn_point_masked of frame 1 in frame 2 / in frame 1, k = 16.
+ * q1_w (q1_cout, 2) / q1_out (S n, q1_cout) (optional, together, with xyz / raw): q1_out = q1_w . (feature row) -- the encoder's first
+ * per-point projection (lib/pointnet2_modules.py:37-53: layer 1 of sa1's MLPs restricted to the two feature channels), no bias.
  * n <= 2048, npoint <= 512. */
 RTK_EXPORT int rtk_geometry_front(int b, int clouds, int n, int npoint, const float *frame1, const float *frame2, int channel_major,
                                   const float *feature1, const float *feature2, float *xyz, float *raw, int *fps_idx, float *new_xyz,
                                   int *nuniq, int *tie, int *first_tie, float *snap, const int *n_valid, int64_t *knn12, int64_t *knn11,
-                                  rtk_stream_t stream);
+                                  const float *q1_w, float *q1_out, int q1_cout, rtk_stream_t stream);
 /* rtk_geometry_tables: the six ball queries (rtk_ball_query_pair per level) and the three three-NN tables (rtk_three_nn_masked) of a
  * PNHead.  xyz0 (S,n,3) point-major clouds; new_xyz / nuniq as written by rtk_geometry_front.  radii, nsamples: HOST arrays of six
  * (level-major, scale 0 then 1, radii ascending within a level); ball: host array of six device tables (S,npoint,nsample) int32,

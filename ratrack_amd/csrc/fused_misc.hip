@@ -147,26 +147,35 @@ __global__ __launch_bounds__(256) void global_terms_kernel(const GtParams P) {
     const int s = blockIdx.x, t = threadIdx.x;
     for (int k = t; k < P.cin; k += 256) s_g[k] = P.g[(long)s * P.cin + k];
     __syncthreads();
-    for (int j = 0; j < P.njobs; ++j) {
-        const rtk_gterm_job_t &J = P.job[j];
-        if (s < J.s0 || s >= J.s0 + J.count) continue;
-        for (int c = t; c < J.cout; c += 256) {
-            float acc = J.bias ? J.bias[c] : 0.f;
-            for (int k0 = 0; k0 < P.cin; k0 += 16) {      // cin % 16 == 0; 16 weight loads in flight, summed k ascending
-                float wv[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) wv[q] = J.wt[(long)(k0 + q) * J.cout + c];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc = fmaf(wv[q], s_g[k0 + q], acc);
-            }
-            J.out[(long)(s - J.s0) * J.out_pitch + c] = acc;
+    // the outputs of all of this sample's jobs as one list, a thread per output (k ascending), 32 weight loads in flight per thread: the
+    // launch is a handful of L2 round trips long
+    int total = 0;
+    if (blockIdx.y == 0)      // (the other workgroups of the sample only share the broadcast's rows)
+        for (int j = 0; j < P.njobs; ++j)
+            if (s >= P.job[j].s0 && s < P.job[j].s0 + P.job[j].count) total += P.job[j].cout;
+    for (int o = t; o < total; o += 256) {
+        int c = o, j = 0;
+        for (; j < P.njobs; ++j) {
+            if (s < P.job[j].s0 || s >= P.job[j].s0 + P.job[j].count) continue;
+            if (c < P.job[j].cout) break;
+            c -= P.job[j].cout;
         }
+        const rtk_gterm_job_t &J = P.job[j];
+        float acc = J.bias ? J.bias[c] : 0.f;
+        for (int k0 = 0; k0 < P.cin; k0 += 32) {          // cin % 32 == 0
+            float wv[32];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) wv[q] = J.wt[(long)(k0 + q) * J.cout + c];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) acc = fmaf(wv[q], s_g[k0 + q], acc);
+        }
+        J.out[(long)(s - J.s0) * J.out_pitch + c] = acc;
     }
-    if (P.bcast) {      // cin % 4 == 0: a thread owns one float4 of the row, rows strided by 1024 / cin
+    if (P.bcast) {      // a thread owns one float4 of the row, rows strided by 1024 / cin
         const int per_row = P.cin >> 2, rows_per_iter = 256 / per_row, q = t % per_row;
         if (t < rows_per_iter * per_row) {
             const float4 v = *reinterpret_cast<const float4 *>(s_g + 4 * q);
-            for (int r = t / per_row; r < P.n; r += rows_per_iter)
+            for (int r = blockIdx.y * rows_per_iter + t / per_row; r < P.n; r += rows_per_iter * gridDim.y)
                 *reinterpret_cast<float4 *>(P.bcast + ((long)s * P.n + r) * P.bcast_pitch + 4 * q) = v;
         }
     }
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(256) void global_terms_kernel(const GtParams P) {
 
 extern "C" int rtk_global_terms(int samples, int cin, const float *g, int njobs, const rtk_gterm_job_t *jobs, float *bcast, int bcast_pitch,
                                 int n, rtk_stream_t stream) {
-    RTK_REQUIRE(samples > 0 && cin > 0 && cin <= 512 && cin % 16 == 0 && g && njobs >= 0 && njobs <= RTK_GT_MAX_JOBS && (njobs == 0 || jobs),
+    RTK_REQUIRE(samples > 0 && cin > 0 && cin <= 512 && cin % 32 == 0 && g && njobs >= 0 && njobs <= RTK_GT_MAX_JOBS && (njobs == 0 || jobs),
                 "global_terms: bad arguments (samples=%d cin=%d njobs=%d)", samples, cin, njobs);
     RTK_REQUIRE(!bcast || (n > 0 && bcast_pitch >= cin && bcast_pitch % 4 == 0 && cin <= 1024), "global_terms: bad broadcast target");
     GtParams P;
@@ -184,7 +193,7 @@ extern "C" int rtk_global_terms(int samples, int cin, const float *g, int njobs,
                     jobs[j].out_pitch >= jobs[j].cout, "global_terms: bad job %d", j);
         P.job[j] = jobs[j];
     }
-    global_terms_kernel<<<samples, 256, 0, (hipStream_t)stream>>>(P);
+    global_terms_kernel<<<dim3(samples, bcast ? 8 : 1), 256, 0, (hipStream_t)stream>>>(P);
     RTK_CHECK_LAUNCH("global_terms");
     return RTK_OK;
 }

@@ -1386,6 +1386,9 @@ struct GeoFrontParams {
     int ps, cs;
     const float *f1, *f2;        // (B, 2, n) features (with xyz_out / raw_out)
     float *xyz_out, *raw_out;    // (2B, n, 3), (2B n, 4) or NULL
+    const float *q1_w;           // (q1_cout, 2) or NULL: q1_out (2B n, q1_cout) = q1_w . (the two raw features of the point)
+    float *q1_out;
+    int q1_cout;
     int *fps_idx;                // (3, 2B, npoint)
     float *new_xyz;              // (3, 2B, npoint, 3)
     int *nuniq, *tie;            // (3, 2B) each
@@ -1420,7 +1423,19 @@ __global__ __launch_bounds__(256) void geometry_front_kernel(const GeoFrontParam
             P.xyz_out[t * 3 + 0] = cloud[p * P.ps];
             P.xyz_out[t * 3 + 1] = cloud[p * P.ps + P.cs];
             P.xyz_out[t * 3 + 2] = cloud[p * P.ps + 2 * P.cs];
-            *reinterpret_cast<float4 *>(P.raw_out + t * 4) = make_float4(f[p], f[n + p], 0.f, 0.f);
+            const float fa = f[p], fb = f[n + p];
+            *reinterpret_cast<float4 *>(P.raw_out + t * 4) = make_float4(fa, fb, 0.f, 0.f);
+            if (P.q1_w) {      // the encoder's sa1 layer-1 projection of the raw features (both scales side by side): 2 -> q1_cout, no bias
+                float *qo = P.q1_out + t * P.q1_cout;
+                for (int c = 0; c < P.q1_cout; c += 4) {
+                    float4 o;
+                    o.x = __fmaf_rn(P.q1_w[2 * c + 1], fb, __fmul_rn(P.q1_w[2 * c], fa));
+                    o.y = __fmaf_rn(P.q1_w[2 * c + 3], fb, __fmul_rn(P.q1_w[2 * c + 2], fa));
+                    o.z = __fmaf_rn(P.q1_w[2 * c + 5], fb, __fmul_rn(P.q1_w[2 * c + 4], fa));
+                    o.w = __fmaf_rn(P.q1_w[2 * c + 7], fb, __fmul_rn(P.q1_w[2 * c + 6], fa));
+                    *reinterpret_cast<float4 *>(qo + c) = o;
+                }
+            }
         }
     }
     if (tid >= 64) return;                             // (a finished wave no longer counts at the barriers below)
@@ -1449,7 +1464,7 @@ __global__ __launch_bounds__(256) void geometry_front_kernel(const GeoFrontParam
 extern "C" int rtk_geometry_front(int b, int clouds, int n, int npoint, const float *frame1, const float *frame2, int channel_major,
                                   const float *feature1, const float *feature2, float *xyz, float *raw, int *fps_idx, float *new_xyz,
                                   int *nuniq, int *tie, int *first_tie, float *snap, const int *n_valid, int64_t *knn12, int64_t *knn11,
-                                  rtk_stream_t stream) {
+                                  const float *q1_w, float *q1_out, int q1_cout, rtk_stream_t stream) {
     RTK_REQUIRE(b > 0 && n > 0 && npoint > 0 && frame1 && fps_idx && new_xyz && nuniq && tie && first_tie && snap,
                 "geometry_front: bad arguments (b=%d n=%d npoint=%d)", b, n, npoint);
     RTK_REQUIRE(clouds == b || (clouds == 2 * b && frame2), "geometry_front: clouds=%d must be b or 2 b (b=%d) with both frames", clouds, b);
@@ -1457,7 +1472,10 @@ extern "C" int rtk_geometry_front(int b, int clouds, int n, int npoint, const fl
     RTK_REQUIRE((xyz == nullptr) == (raw == nullptr) && (!xyz || (feature1 && feature2)), "geometry_front: xyz, raw and the features go together");
     RTK_REQUIRE((knn12 == nullptr) == (knn11 == nullptr) && (!knn12 || (n >= 16 && clouds == 2 * b)),
                 "geometry_front: the two kNN tables go together (n >= 16, both frames)");
+    RTK_REQUIRE((q1_w == nullptr) == (q1_out == nullptr) && (!q1_w || (xyz && q1_cout > 0 && q1_cout % 4 == 0)),
+                "geometry_front: q1_w, q1_out go together (with the layout conversion; q1_cout a multiple of 4)");
     GeoFrontParams P;
+    P.q1_w = q1_w; P.q1_out = q1_out; P.q1_cout = q1_cout;
     P.B = b; P.S = clouds; P.n = n; P.npoint = npoint; P.block_n = fps_block_size(n); P.block_np = fps_block_size(npoint);
     P.fr1 = frame1; P.fr2 = frame2; P.ps = channel_major ? 1 : 3; P.cs = channel_major ? n : 1;
     P.f1 = feature1; P.f2 = feature2; P.xyz_out = xyz; P.raw_out = raw;

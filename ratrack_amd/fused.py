@@ -56,7 +56,7 @@ _lib.SIGNATURES.update({
     "rtk_gru_step": [_ci] * 3 + [_vp] * 8 + [_vp],
     "rtk_to_channel_major": [_ci] * 3 + [_vp, _ci, _ci, _vp, _ci, _ci, _vp],
     "rtk_ball_query_pair": [_ci] * 3 + [ctypes.c_float, _ci, ctypes.c_float, _ci] + [_vp] * 5 + [_vp],
-    "rtk_geometry_front": [_ci] * 4 + [_vp, _vp, _ci] + [_vp] * 13 + [_vp],
+    "rtk_geometry_front": [_ci] * 4 + [_vp, _vp, _ci] + [_vp] * 13 + [_vp, _vp, _ci, _vp],
     "rtk_geometry_tables": [_ci] * 3 + [_vp] * 3 + [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_ci), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                             ctypes.POINTER(_vp), _vp],
     "rtk_three_nn_masked": [_ci] * 3 + [_vp] * 6 + [_vp],
@@ -450,9 +450,11 @@ class Geometry:
     so the decoder's PNHead over pc1 reuses the encoder's)."""
 
     def __init__(self, xyz, npoint, side=None, knn_frames=0, finite=False, n_valid=None, level_hook=None, tail_hook=None, zeros=None,
-                 prepare=None):
+                 prepare=None, q1=None):
         """xyz (S_,n,3).  prepare = (pc1, pc2, feature1, feature2, raw): xyz and raw (S_*n, 4) are OUTPUTS -- the API's channel-major
-        tensors of the two frames are converted on the way (rtk_prepare_inputs, inside rtk_geometry_front when the geometry is fused).  With `side` (a torch.cuda.Stream) every geometry kernel is enqueued on that stream, forked from
+        tensors of the two frames are converted on the way (rtk_prepare_inputs, inside rtk_geometry_front when the geometry is fused).
+        q1 = (w (C, 2) fp32, out (S_*n, C)) with prepare: out = w . (the two raw features of every point), written by the same launch when
+        the geometry is fused (self.q1_done says whether it was).  With `side` (a torch.cuda.Stream) every geometry kernel is enqueued on that stream, forked from
         the current one, and consumers call wait(stage) -- the feature kernels overlap the latency-bound FPS chain.
         knn_frames = B > 0: also the two kNN tables of the cost volume, frame 1 = xyz[:B], frame 2 = xyz[B:].
         finite: zero-fill the three-NN distances of the skipped (duplicate) rows instead of leaving them unwritten
@@ -514,6 +516,8 @@ class Geometry:
         self._scratch = (snap, temp, n_valid, xyz)
 
         self.fused_geometry = fused_geo
+        self.q1_done = False
+        q1w = q1 is not None and prepare is not None
         if prepare is not None and not fused_geo:      # on the caller's stream, before the fork: the feature kernels read raw there
             pc1, pc2, f1, f2, raw = prepare
             _lib.call("rtk_prepare_inputs", S_ // 2, n, pc1.data_ptr(), pc2.data_ptr(), f1.data_ptr(), f2.data_ptr(), xyz.data_ptr(), raw.data_ptr(),
@@ -538,7 +542,9 @@ class Geometry:
                     fr = (xyz.data_ptr(), xyz[b1:].data_ptr() if b1 < S_ else None, 0, None, None, None, None)
                 _lib.call("rtk_geometry_front", b1, S_, n, npoint, *fr, fps_idx[0].data_ptr(), xyz_all.data_ptr(), cnt[0].data_ptr(),
                           tie.data_ptr(), first_tie.data_ptr(), snap.data_ptr(), nv, self.knn[0].data_ptr() if B else None,
-                          self.knn[1].data_ptr() if B else None, _stream())
+                          self.knn[1].data_ptr() if B else None, q1[0].data_ptr() if q1w else None, q1[1].data_ptr() if q1w else None,
+                          q1[1].shape[1] if q1w else 0, _stream())
+                self.q1_done = q1w
                 self._record("front", side)        # xyz / raw (prepare), the kNN tables and the three levels of centroids
                 if CHECK_FPS_RELEVEL and not torch.cuda.is_current_stream_capturing():
                     check_fps_relevel(new_xyz[0], torch.stack(self.fps_idx[1:]), xyz_all[1:], torch.stack(list(cnt[1:3])))
@@ -701,7 +707,7 @@ def sa_scale(geo, W, lvl, s, q, qcol, out, out_offset):
               sc.chain.n, sc.chain.arr, optr, opitch, out_offset, src_nu, geo.nuniq[lvl].data_ptr(), _stream())
 
 
-def run_pnhead(W, geo, q1, out=None):
+def run_pnhead(W, geo, q1, out=None, gmax=None):
     """q1 (samples*n, 32): per-point sa1 layer-1 projections (scale 0 | scale 1).  Returns l0_points (samples*n, 128) (written
     into `out`, a possibly column-sliced (samples*n, 128) view, when given).
     All centroid-level tensors hold valid data only in rows < geo.nuniq[level][sample]; the rest are duplicates of the
@@ -733,7 +739,8 @@ def run_pnhead(W, geo, q1, out=None):
     f2 = pointwise(S_ * S, S, [(t1[:, 0:32], 32, False)], W.fp["fp2"], new(S_ * S, 128), row_nuniq=nu[0],
                    interp=(f3, 128, m, idx.reshape(-1, 3), d2.reshape(-1, 3), nu[1]))
     d2, idx, m = geo.nn["fp1"]
-    gmax = torch.zeros(S_, 128, dtype=torch.float32, device=dev)          # global max-pool, fused into fp1's epilogue
+    if gmax is None:                                                      # global max-pool, fused into fp1's epilogue (ZERO-initialised)
+        gmax = torch.zeros(S_, 128, dtype=torch.float32, device=dev)
     out = pointwise(S_ * n, n, [], W.fp["fp1"], out if out is not None else new(S_ * n, 128),
                     interp=(f2, 128, m, idx.reshape(-1, 3), d2.reshape(-1, 3), nu[0]), colmax=gmax)
     return out, gmax
@@ -764,6 +771,7 @@ class FusedBackbone:
         z = lambda n: torch.zeros(n, dtype=torch.float64, device=sd["bin_score"].device)
         # encoder sa1 projection of the raw (RCS, v_r) features
         self.enc_q1 = Chain([(self.enc.wq1, z(32), ACT_NONE)], dev)
+        self.enc_q1_w = self.enc.wq1.float().to(dev).contiguous()            # (32, 2): evaluated by the geometry's first launch
         # cost volume (fc_layer): conv0 split by input segment [f1 loc|glob (256) || f2 loc|glob (256) || dir (3)]
         w0 = sd["fc_layer.mlp_convs.0.weight"].double().reshape(256, 515)
         b0 = sd["fc_layer.mlp_convs.0.bias"].double()
@@ -822,6 +830,7 @@ class FusedBackbone:
         new = lambda rows, c: torch.empty(rows, c, dtype=torch.float32, device=dev)
         xyz = torch.empty(2 * B, N, 3, dtype=torch.float32, device=dev)
         raw = new(2 * B * N, 4)
+        q1 = new(2 * B * N, 32)
         # keep the (possibly copied) contiguous inputs referenced until the launch is enqueued: a temporary freed
         # between two .data_ptr() calls could be recycled by the allocator for the next temporary
         ins = [t.contiguous() for t in (pc1, pc2, feature1, feature2)]
@@ -831,15 +840,19 @@ class FusedBackbone:
             n_valid = n_valid.to(device=dev, dtype=torch.int32).reshape(2 * B).contiguous()
         # layout conversion (rtk_prepare_inputs) + every geometry table: two launches (rtk_geometry_front, rtk_geometry_tables)
         geo = Geometry(xyz, self.npoint, side=self.side if self.use_side_stream else None, knn_frames=B, n_valid=n_valid,
-                       prepare=(ins[0], ins[1], ins[2], ins[3], raw))
-        geo.wait("front")       # raw (and xyz) come out of the geometry's first launch when it runs on the side stream
+                       prepare=(ins[0], ins[1], ins[2], ins[3], raw), q1=(self.enc_q1_w, q1))
+        geo.wait("front")       # raw, q1 (and xyz) come out of the geometry's first launch when it runs on the side stream
         # ---- encoder over both frames at once (same weights; eval-mode BN is per-element) --------------
-        q1 = pointwise(2 * B * N, N, [(raw, 2, False)], self.enc_q1, new(2 * B * N, 32))
+        if not geo.q1_done:
+            pointwise(2 * B * N, N, [(raw, 2, False)], self.enc_q1, q1)
+        elif _TRACE is not None:
+            _TRACE.append(("pointwise", 2 * B * N, 64))
         # pc{1,2}_features = [local (128) | global max broadcast (128)] (models/track4d.py:89-95) live in ONE point-major buffer:
         # the encoder's last layer writes the local half in place, one broadcast copy fills the global half, and the API's
         # (B,256,N) tensors are permuted VIEWS of it -- no layout pass over the outputs
         feat12 = new(2 * B * N, 256)
-        loc, glob = run_pnhead(self.enc, geo, q1, out=feat12[:, 0:128])                  # (2B*N, 128) view, (2B, 128)
+        gmax = torch.zeros(3 * B, 128, dtype=torch.float32, device=dev)                  # both PNHeads' global max-pools: one fill
+        loc, glob = run_pnhead(self.enc, geo, q1, out=feat12[:, 0:128], gmax=gmax[:2 * B])   # (2B*N, 128) view, (2B, 128)
         f1, f2 = loc[:B * N], loc[B * N:]
         # everything that is a function of the global features, one launch: the per-sample terms of the cost volume's first layer
         # (frame 1: with the layer's bias; frame 2) and of the decoder's sa1 projection, and the broadcast that fills the global half
@@ -881,7 +894,7 @@ class FusedBackbone:
         pointwise(B * N, N, [(cor, 256, False)], self.cls_head, cls, out_channels=1, channel_major=True)
         q1d = pointwise(B * N, N, [(raw[:B * N], 2, False), (f1, 128, False), (cor, 256, False)], self.dec_q1, new(B * N, 32),
                         sample_bias=sbq)
-        prop, gfeat = run_pnhead(self.dec, geo.head(B), q1d)                              # (B*N,128), (B,128)
+        prop, gfeat = run_pnhead(self.dec, geo.head(B), q1d, gmax=gmax[2 * B:])           # (B*N,128), (B,128)
         if h is None:
             h = torch.zeros(5, B, 128, device=dev, dtype=torch.float32)
         gout, h_out, sbf = self._gru_step(gfeat, h)          # sbf: the flow head's per-sample term W_glob gout + b (the kernel's epilogue)
