@@ -41,6 +41,9 @@ extern "C" int rtk_prepare_inputs(int b, int n, const float *pc1, const float *p
 // workgroups); the H-vectors live in LDS.
 // ------------------------------------------------------------------------------------------------
 #define GRU_MAXL 8
+// weight loads of each matrix in flight per thread: the gate loops are L2-latency bound (16 in flight: eight round trips per layer, 40 us for
+// five layers; 32: four).  The summation order stays k ascending per accumulator, so the results do not depend on it.
+constexpr int GRU_INFLIGHT = 32;
 __global__ __launch_bounds__(384) void gru_step_kernel(int b, int layers, int hidden, const float *__restrict__ x,
                                                        const float *__restrict__ h_in, const float *__restrict__ w_ih,
                                                        const float *__restrict__ w_hh, const float *__restrict__ b_ih,
@@ -60,15 +63,15 @@ __global__ __launch_bounds__(384) void gru_step_kernel(int b, int layers, int hi
             // 16 weight loads of each matrix in flight per thread (the loop is L2-latency bound otherwise); the summation
             // order is still k ascending per accumulator pair, combined once at the end
             float ai = b_ih[l * 3 * H + t], ah = b_hh[l * 3 * H + t];
-            for (int k0 = 0; k0 < H; k0 += 16) {
-                float wv[16], uv[16];
+            for (int k0 = 0; k0 < H; k0 += GRU_INFLIGHT) {      // (H % GRU_INFLIGHT == 0, checked by the launcher)
+                float wv[GRU_INFLIGHT], uv[GRU_INFLIGHT];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
+                for (int q = 0; q < GRU_INFLIGHT; ++q) {
                     wv[q] = wi[(long)(k0 + q) * 3 * H];
                     uv[q] = wh[(long)(k0 + q) * 3 * H];
                 }
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
+                for (int q = 0; q < GRU_INFLIGHT; ++q) {
                     ai = fmaf(wv[q], s_x[k0 + q], ai);
                     ah = fmaf(uv[q], s_h[k0 + q], ah);
                 }
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(384) void gru_step_kernel(int b, int layers, int hi
 extern "C" int rtk_gru_step(int b, int layers, int hidden, const float *x, const float *h_in, const float *w_ih,
                             const float *w_hh, const float *b_ih, const float *b_hh, float *h_out, float *y,
                             rtk_stream_t stream) {
-    RTK_REQUIRE(b > 0 && layers > 0 && layers <= GRU_MAXL && hidden > 0 && hidden <= 128 && hidden % 4 == 0 && x && h_in && w_ih &&
+    RTK_REQUIRE(b > 0 && layers > 0 && layers <= GRU_MAXL && hidden > 0 && hidden <= 128 && hidden % GRU_INFLIGHT == 0 && x && h_in && w_ih &&
                 w_hh && b_ih && b_hh && h_out && y, "gru_step: bad arguments (hidden=%d, layers=%d)", hidden, layers);
     gru_step_kernel<<<b, 384, 0, (hipStream_t)stream>>>(b, layers, hidden, x, h_in, w_ih, w_hh, b_ih, b_hh, h_out, y, nullptr, nullptr, nullptr, 0);
     RTK_CHECK_LAUNCH("gru_step");
@@ -119,7 +122,7 @@ extern "C" int rtk_gru_step(int b, int layers, int hidden, const float *x, const
 extern "C" int rtk_gru_step_head(int b, int layers, int hidden, const float *x, const float *h_in, const float *w_ih,
                                  const float *w_hh, const float *b_ih, const float *b_hh, float *h_out, float *y, const float *head_wt,
                                  const float *head_bias, float *head_out, int head_cout, rtk_stream_t stream) {
-    RTK_REQUIRE(b > 0 && layers > 0 && layers <= GRU_MAXL && hidden > 0 && hidden <= 128 && hidden % 16 == 0 && x && h_in && w_ih &&
+    RTK_REQUIRE(b > 0 && layers > 0 && layers <= GRU_MAXL && hidden > 0 && hidden <= 128 && hidden % GRU_INFLIGHT == 0 && x && h_in && w_ih &&
                 w_hh && b_ih && b_hh && h_out && y && head_wt && head_out && head_cout > 0,
                 "gru_step_head: bad arguments (hidden=%d, layers=%d, head_cout=%d)", hidden, layers, head_cout);
     gru_step_kernel<<<b, 384, 0, (hipStream_t)stream>>>(b, layers, hidden, x, h_in, w_ih, w_hh, b_ih, b_hh, h_out, y, head_wt, head_bias,
@@ -279,15 +282,15 @@ __global__ __launch_bounds__(384) void gru_step_bwd_kernel(int b, int layers, in
             // 16 weight loads of each matrix in flight per thread (the loop is L2-latency bound otherwise); the summation
             // order is still k ascending per accumulator pair, combined once at the end
             float ai = b_ih[l * 3 * H + t], ah = b_hh[l * 3 * H + t];
-            for (int k0 = 0; k0 < H; k0 += 16) {
-                float wv[16], uv[16];
+            for (int k0 = 0; k0 < H; k0 += GRU_INFLIGHT) {      // (H % GRU_INFLIGHT == 0, checked by the launcher)
+                float wv[GRU_INFLIGHT], uv[GRU_INFLIGHT];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
+                for (int q = 0; q < GRU_INFLIGHT; ++q) {
                     wv[q] = wi[(long)(k0 + q) * 3 * H];
                     uv[q] = wh[(long)(k0 + q) * 3 * H];
                 }
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
+                for (int q = 0; q < GRU_INFLIGHT; ++q) {
                     ai = fmaf(wv[q], s_x[k0 + q], ai);
                     ah = fmaf(uv[q], s_h[k0 + q], ah);
                 }

@@ -127,12 +127,15 @@ def _oracle_train_step(d, dtype):
     return items, flow.detach(), cls.detach(), grads, stats
 
 
-def test_train_step_matches_oracle_at_full_size():
-    """Config 3, B = 64, N = 256: one train step of the hand-written path (forward in train mode, multi-task loss, backward) against
-    the oracle's CPU autograd in fp32 and in float64.  Losses, train-mode flow / cls, BatchNorm running statistics within 1e-4;
-    gradients per tensor (ALL elements, not a sample)."""
-    B, N = 64, 256
-    d = synth.make_frame_pairs(B, N, 2030)
+def _train_step_parity(seed, B=64, N=256, copies=1):
+    """One train step of the hand-written path at (B, N) on synthetic batch `seed` (copies > 1: B / copies distinct frame pairs, each
+    `copies` times -- the same activations, BatchNorm statistics and decisions as the small batch, at the full batch's launch shapes) against the oracle's CPU autograd in fp32 and float64:
+    asserts losses, train-mode flow / cls and BatchNorm running statistics within 1e-4; returns the per-tensor gradient rows
+    (name, exact-zero?, error vs the fp32 oracle, error vs float64, the fp32 oracle's own error vs float64), each max|a - b| / max|b|."""
+    assert B % copies == 0
+    d = synth.make_frame_pairs(B // copies, N, seed)
+    if copies > 1:
+        d = {k: np.ascontiguousarray(np.concatenate([v] * copies, 0)) for k, v in d.items()}
     net = Track4D(Args()).to(DEV)
     net.load_state_dict(reference_state_dict(DEV), strict=True)
     net.train()
@@ -147,7 +150,7 @@ def test_train_step_matches_oracle_at_full_size():
     t0 = time.time()
     it32, flow32, cls32, g32, st32 = _oracle_train_step(d, torch.float32)
     it64, flow64, cls64, g64, _ = _oracle_train_step(d, torch.float64)
-    print("\noracle train step B=%d N=%d in fp32 and float64: %.0f s on the host" % (B, N, time.time() - t0))
+    print("\noracle train step B=%d N=%d seed %d in fp32 and float64: %.0f s on the host" % (B, N, seed, time.time() - t0))
     for k in ("Loss", "SceneFlowLoss", "SegLoss"):
         assert abs(float(items[k]) - it32[k]) <= 1e-4 * abs(it32[k]) + 1e-6, (k, float(items[k]), it32[k], it64[k])
     assert rel_err(flow.detach().cpu().numpy(), flow32.numpy()) <= RTOL and rel_err(cls.detach().cpu().numpy(), cls32.numpy()) <= RTOL
@@ -172,25 +175,47 @@ def test_train_step_matches_oracle_at_full_size():
     live = [r for r in rows if not r[1]]
     e_arb = np.array([r[3] for r in live])
     floor = np.array([r[4] for r in live])
-    print("%d gradient tensors, error vs float64: median %.1e, 90th percentile %.1e, max %.1e;  the fp32 oracle's own: median %.1e, "
-          "90th %.1e, max %.1e" % (len(live), np.median(e_arb), np.quantile(e_arb, 0.9), e_arb.max(), np.median(floor),
+    print("seed %d: %d gradient tensors, error vs float64: median %.1e, 90th percentile %.1e, max %.1e;  the fp32 oracle's own: median %.1e, "
+          "90th %.1e, max %.1e" % (seed, len(live), np.median(e_arb), np.quantile(e_arb, 0.9), e_arb.max(), np.median(floor),
                                    np.quantile(floor, 0.9), floor.max()))
     for r in sorted(live, key=lambda r: -r[3])[:8]:
         print("   %-50s vs fp32 oracle %.2e | vs float64 %.2e | fp32 oracle vs float64 %.2e" % (r[0], r[2], r[3], r[4]))
     assert len(rows) > 100
+    for k, zero, e_ref, e_a, fl in rows:
+        if zero:
+            assert e_a <= 1.0, (k, "exact-zero gradient carries more than rounding noise", e_a)
+    return rows, e_arb, floor
+
+
+def test_train_step_matches_oracle_at_full_size():
+    """Config 3, B = 64, N = 256: one train step of the hand-written path (forward in train mode, multi-task loss, backward) against
+    the oracle's CPU autograd in fp32 and in float64.  Losses, train-mode flow / cls, BatchNorm running statistics within 1e-4;
+    gradients per tensor (ALL elements, not a sample)."""
+    rows, e_arb, floor = _train_step_parity(2030)
     # Bounds.  At B = 64 the two fp32 evaluations (the oracle's and this path's) differ from float64 by DISCRETE events -- ReLU /
     # max-pool decisions within rounding of a tie -- and the oracle's own fp32 run is the yardstick for how much that is on this
     # batch (measured, round 4: this path median 2.2e-4 / 90th percentile 7.6e-4 / max 3.3e-3 from float64, the fp32 oracle
     # 9.0e-4 / 1.6e-3 / 1.1e-2).  Required: no further from float64 than the reference arithmetic itself, with absolute floors for
     # batches on which the oracle happens to have no flipped decision.
     for k, zero, e_ref, e_a, fl in rows:
-        if zero:
-            assert e_a <= 1.0, (k, "exact-zero gradient carries more than rounding noise", e_a)
-        else:
+        if not zero:
             assert e_a <= max(GRAD_MAX, 3.0 * fl), (k, e_ref, e_a, fl)
     assert np.median(e_arb) <= max(GRAD_MEDIAN, 1.5 * np.median(floor)), (np.median(e_arb), np.median(floor))
     assert np.quantile(e_arb, 0.9) <= max(GRAD_P90, 2.0 * np.quantile(floor, 0.9)), (np.quantile(e_arb, 0.9), np.quantile(floor, 0.9))
     assert e_arb.max() <= max(GRAD_MAX, 1.5 * floor.max()), (e_arb.max(), floor.max())
+
+
+def test_train_step_on_a_full_size_batch_without_flipped_decisions():
+    """The same step at the same launch shapes (B = 64, N = 256) on a batch where nothing is decided within rounding of a tie, so that
+    the bound is the arithmetic's and not a statistic of flipped decisions: <= 1e-3 of the largest element for EVERY gradient tensor,
+    median <= 2e-4, against float64.
+    No batch of 64 distinct synthetic pairs is free of flips (tools/experiments/scan_fullsize_seed.py, round 6: on eight of eight the fp32
+    ORACLE is 5e-3 ... 1.9e-2 from float64), and of 24 batches of 8 pairs most are not either -- where neither evaluation flips, this
+    path sits at median 5e-6 ... 8e-6.  Batch 3012 (8 pairs: this path median 7.5e-6 / max 3.5e-4, the fp32 oracle 1.0e-5 / 6.1e-4) taken
+    EIGHT TIMES is a B = 64 batch with the small batch's activations, BatchNorm statistics and decisions -- every kernel runs its
+    full-size grid, every reduction over the batch sums 64 samples."""
+    rows, e_arb, floor = _train_step_parity(3012, B=64, N=256, copies=8)
+    assert e_arb.max() <= 1e-3 and np.median(e_arb) <= 2e-4, (e_arb.max(), np.median(e_arb), floor.max(), np.median(floor))
 
 
 # Absolute floors of the per-tensor bounds at B = 64 (every tensor; median; 90th percentile), as max|a - b| / max|b| against float64.
