@@ -67,6 +67,28 @@ def irregular_ops(batch, n, dev, npoint=512, iters=20, pmc=None):
 
     i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
     f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    # ---- the product path's geometry: two launches (round 6), timed where the backbone issues them ---------------------------------
+    import statistics
+    api = [torch.from_numpy(d[k]).to(dev) for k in ("pc1", "pc2", "feature1", "feature2")]
+    q1w = torch.randn(32, 2, device=dev)
+    per = {"rtk_geometry_front": [], "rtk_geometry_tables": []}
+    for _ in range(9):
+        _lib.TIMING = rec = []
+        g2 = fused.Geometry(f32(S_, n, 3), npoint, side=None, knn_frames=batch, prepare=(*api, f32(S_ * n, 4)), q1=(q1w, f32(S_ * n, 32)))
+        _lib.TIMING = None
+        torch.cuda.synchronize()
+        for nm, e0, e1 in rec:
+            if nm in per:
+                per[nm].append(e0.elapsed_time(e1))
+        del g2
+    if per["rtk_geometry_front"]:
+        ns_all = [ns for row in fused._PNHeadWeights.NSAMPLES for ns in row]
+        front = S_ * (n * 20 + n * (12 + 16 + 128) + sum(U) * 16 + 24) + 2 * batch * n * 16 * 8
+        tables = S_ * (n * 12 + 2 * sum(U) * 12 + sum(U[l] * 4 * (ns_all[2 * l] + ns_all[2 * l + 1]) for l in range(3)) + (U[1] + U[0] + n) * 24)
+        add("geometry_front_kernel", 1, statistics.median(per["rtk_geometry_front"]), front,
+            "layout conversion + sa1 projection of the raw features + FPS levels 1-3 (one wave per cloud) + both kNN tables, %d clouds" % S_)
+        add("geometry_tables_kernel", 1, statistics.median(per["rtk_geometry_tables"]), tables,
+            "six ball queries + three three-NN tables over the unique centroids, %d clouds" % S_)
     # ---- furthest point sampling + centroid gather, level 1 (the 511-round dependent chain) ----------------------------
     idx, nx, cnt, tie = i32(S_, npoint), f32(S_, npoint, 3), i32(S_), i32(S_)
     tie23, first, snap = i32(2, S_), i32(S_), f32(S_, n)

@@ -68,7 +68,7 @@ def main(fetch_db, write_db, trace_db, out_dir, tag="r02"):
                 "traffic_bytes_per_launch": int((f * fetch_scale + w) * 1024), "avg_duration_us": round(dur[1] / 1e3, 2),
                 "GB/s": round((f * fetch_scale + w) * 1024 / max(dur[1], 1), 2)}
 
-    irregular = {"fps_wave_kernel": "fps_wave_kernel", "fps_relevel_kernel": "fps_relevel_kernel", "ball_query_pair_kernel": "ball_query_pair_kernel",
+    irregular = {"geometry_front_kernel": "geometry_front_kernel", "geometry_tables_kernel": "geometry_tables_kernel", "fps_wave_kernel": "fps_wave_kernel", "fps_relevel_kernel": "fps_relevel_kernel", "ball_query_pair_kernel": "ball_query_pair_kernel",
                  "three_nn_kernel": "three_nn_kernel", "knn_point_kernel": "knn_point_kernel", "scatter_add_rows_kernel": "scatter_rows256_kernel",
                  "group_points_grad_kernel": "group_points_grad_lds_kernel", "sa_first_layer_bwd_kernel": "sa_first_layer_bwd_kernel",
                  "three_interpolate_grad_kernel": "three_interp_grad_gather_kernel", "inverse_index_kernel": "inverse_index_kernel"}
