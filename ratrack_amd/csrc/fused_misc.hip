@@ -150,13 +150,12 @@ __global__ __launch_bounds__(256) void global_terms_kernel(const GtParams P) {
     const int s = blockIdx.x, t = threadIdx.x;
     for (int k = t; k < P.cin; k += 256) s_g[k] = P.g[(long)s * P.cin + k];
     __syncthreads();
-    // the outputs of all of this sample's jobs as one list, a thread per output (k ascending), 32 weight loads in flight per thread: the
-    // launch is a handful of L2 round trips long
+    // the outputs of all of this sample's jobs as one list, spread over the sample's workgroups, a thread per output (k ascending), 64 weight
+    // loads in flight per thread: the launch is a few L2 round trips long
     int total = 0;
-    if (blockIdx.y == 0)      // (the other workgroups of the sample only share the broadcast's rows)
-        for (int j = 0; j < P.njobs; ++j)
-            if (s >= P.job[j].s0 && s < P.job[j].s0 + P.job[j].count) total += P.job[j].cout;
-    for (int o = t; o < total; o += 256) {
+    for (int j = 0; j < P.njobs; ++j)
+        if (s >= P.job[j].s0 && s < P.job[j].s0 + P.job[j].count) total += P.job[j].cout;
+    for (int o = blockIdx.y * 256 + t; o < total; o += 256 * gridDim.y) {
         int c = o, j = 0;
         for (; j < P.njobs; ++j) {
             if (s < P.job[j].s0 || s >= P.job[j].s0 + P.job[j].count) continue;
@@ -165,12 +164,13 @@ __global__ __launch_bounds__(256) void global_terms_kernel(const GtParams P) {
         }
         const rtk_gterm_job_t &J = P.job[j];
         float acc = J.bias ? J.bias[c] : 0.f;
-        for (int k0 = 0; k0 < P.cin; k0 += 32) {          // cin % 32 == 0
-            float wv[32];
+        for (int k0 = 0; k0 < P.cin; k0 += 64) {          // cin % 32 == 0
+            float wv[64];
 #pragma unroll
-            for (int q = 0; q < 32; ++q) wv[q] = J.wt[(long)(k0 + q) * J.cout + c];
+            for (int q = 0; q < 64; ++q) wv[q] = J.wt[(long)min(k0 + q, P.cin - 1) * J.cout + c];
 #pragma unroll
-            for (int q = 0; q < 32; ++q) acc = fmaf(wv[q], s_g[k0 + q], acc);
+            for (int q = 0; q < 64; ++q)
+                if (k0 + q < P.cin) acc = fmaf(wv[q], s_g[k0 + q], acc);
         }
         J.out[(long)(s - J.s0) * J.out_pitch + c] = acc;
     }
@@ -196,7 +196,7 @@ extern "C" int rtk_global_terms(int samples, int cin, const float *g, int njobs,
                     jobs[j].out_pitch >= jobs[j].cout, "global_terms: bad job %d", j);
         P.job[j] = jobs[j];
     }
-    global_terms_kernel<<<dim3(samples, bcast ? 8 : 1), 256, 0, (hipStream_t)stream>>>(P);
+    global_terms_kernel<<<dim3(samples, bcast ? 8 : 2), 256, 0, (hipStream_t)stream>>>(P);
     RTK_CHECK_LAUNCH("global_terms");
     return RTK_OK;
 }

@@ -925,3 +925,46 @@ def test_unfilled_geometry_workspace_is_never_read(B, N, monkeypatch):
         outs.append([x.detach().clone() for x in o])
     for a, b, c in zip(*outs):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32)) and torch.equal(a.view(torch.int32), c.view(torch.int32))
+
+
+def test_global_terms_copy_multi_and_gru_head():
+    """The three small entry points of round 6 against the framework: rtk_global_terms (per-sample linear maps of the global feature over
+    sample ranges + the broadcast over a sample's rows), rtk_copy_multi (several copies, one launch; odd sizes and unaligned tails),
+    rtk_gru_step_head (rtk_gru_step + a linear map of its output)."""
+    from ratrack_amd import _lib
+    g = torch.Generator().manual_seed(3)
+    S, cin, n = 6, 128, 37
+    glob = torch.randn(S, cin, generator=g).to(DEV)
+    w1, b1, w2, w3 = (torch.randn(256, cin, generator=g).to(DEV), torch.randn(256, generator=g).to(DEV), torch.randn(40, cin, generator=g).to(DEV),
+                      torch.randn(32, cin, generator=g).to(DEV))
+    o1, o2, o3 = torch.empty(3, 256, device=DEV), torch.empty(3, 40, device=DEV), torch.empty(6, 32, device=DEV)
+    dst = torch.full((S * n, 200), -7.0, device=DEV)
+    F.global_terms(glob, [(w1.t().contiguous(), b1, o1, 0), (w2.t().contiguous(), None, o2, 3), (w3.t().contiguous(), None, o3, 0)],
+                   bcast=dst[:, 64:], n=n)
+    ref = lambda w, b, x: (x.double() @ w.double().t() + (0 if b is None else b.double())).float()
+    assert rel_err(o1.cpu(), ref(w1, b1, glob[:3]).cpu()) < 1e-6 and rel_err(o2.cpu(), ref(w2, None, glob[3:]).cpu()) < 1e-6
+    assert rel_err(o3.cpu(), ref(w3, None, glob).cpu()) < 1e-6
+    assert torch.equal(dst[:, 64:64 + cin], glob.repeat_interleave(n, 0)) and (dst[:, :64] == -7).all() and (dst[:, 64 + cin:] == -7).all()
+    # copies
+    srcs = [torch.randn(k, generator=g).to(DEV) for k in (1, 5, 4096, 70001, 16384 * 3 + 2)] + [torch.arange(999, dtype=torch.int32, device=DEV)]
+    big = torch.randn(100003, generator=g).to(DEV)
+    srcs.append(big[1:])                                      # 4-byte aligned only
+    dsts = [torch.zeros_like(s_) for s_ in srcs[:-1]] + [torch.zeros(100002, device=DEV)]
+    F.copy_multi(list(zip(dsts, [s_.contiguous() for s_ in srcs])))
+    for d_, s_ in zip(dsts, srcs):
+        assert torch.equal(d_, s_)
+    # GRU step with the head epilogue
+    B, L, H = 5, 5, 128
+    gru = torch.nn.GRU(H, H, L).to(DEV)
+    x, h0 = torch.randn(B, H, generator=g).to(DEV), torch.randn(L, B, H, generator=g).to(DEV)
+    wh, bh = torch.randn(96, H, generator=g).to(DEV), torch.randn(96, generator=g).to(DEV)
+    st = lambda k: torch.stack([getattr(gru, "%s_l%d" % (k, l)).detach() for l in range(L)])
+    wih, whh = st("weight_ih").transpose(1, 2).contiguous(), st("weight_hh").transpose(1, 2).contiguous()
+    bih, bhh = st("bias_ih").contiguous(), st("bias_hh").contiguous()
+    h_out, y, head = torch.empty_like(h0), torch.empty(B, H, device=DEV), torch.empty(B, 96, device=DEV)
+    _lib.call("rtk_gru_step_head", B, L, H, x.data_ptr(), h0.data_ptr(), wih.data_ptr(), whh.data_ptr(), bih.data_ptr(), bhh.data_ptr(),
+              h_out.data_ptr(), y.data_ptr(), wh.t().contiguous().data_ptr(), bh.data_ptr(), head.data_ptr(), 96, F._stream())
+    with torch.no_grad():
+        yr, hr = gru(x.unsqueeze(0), h0)
+    assert rel_err(y.cpu(), yr[0].cpu()) < 1e-5 and rel_err(h_out.cpu(), hr.cpu()) < 1e-5
+    assert rel_err(head.cpu(), ref(wh, bh, y).cpu()) < 1e-6
