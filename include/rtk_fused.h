@@ -227,7 +227,10 @@ RTK_EXPORT int rtk_to_channel_major(int samples, int n, int channels, const floa
 /* Both ball queries of one MSG level in a single scan of the source cloud (lib/pointnet2_modules.py:37-38 issues
  * one ball_query per scale over the same centroids): identical results to two rtk_ball_query calls with
  * (radius1, nsample1) and (radius2, nsample2), radius1 <= radius2.  idx1/idx2 zero-initialised by the caller.
- * nuniq (optional, (B)): centroids >= nuniq[b] (duplicates of centroid 0, see rtk_fps_centroids) are skipped. */
+ * nuniq (optional, (B)): centroids >= nuniq[b] (duplicates of centroid 0, see rtk_fps_centroids) are skipped -- their rows keep the
+ * caller's zeros, except that the rows up to the next multiple of 32 are WRITTEN as zeros (round 6: a consumer's last tile may load
+ * them before it masks them; rtk_geometry_tables relies on this instead of a zero-filled workspace).  An empty ball's row is written
+ * as zeros as well (what the caller's initialisation leaves there in the reference). */
 RTK_EXPORT int rtk_ball_query_pair(int b, int n, int npoint, float radius1, int nsample1, float radius2, int nsample2,
                                    const float *new_xyz, const float *xyz, int *idx1, int *idx2, const int *nuniq,
                                    rtk_stream_t stream);
