@@ -63,3 +63,20 @@ def test_eight_rank_launch_as_the_driver_will_run_it():
     assert d["per_rank_ms_per_step"]["min"] <= d["per_rank_ms_per_step"]["max"]
     assert abs(d["value"] - 64 * 8 / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]
     assert d["config"]["global_batch"] == 512
+
+
+def test_round6_evidence_helpers():
+    """bench.py's evidence helpers that need no GPU: the rocprofv3 summary lookup behind roofline.profile_frac (the newest committed
+    profiles/rNN_bench_default_kernel_stats.txt), the whole-host CPU baseline (P single-thread processes over one window; here P = 2,
+    2 s) and the stdout guard that keeps RCCL's banner out of the one JSON line."""
+    sys.path.insert(0, ROOT)
+    import bench
+    us, name = bench.profile_kernel_avg_us("cost_volume_split_kernel<false>")
+    assert name and name.startswith("r") and 100.0 < us < 1000.0, (us, name)
+    assert bench.profile_kernel_avg_us("no_such_kernel") == (None, None)
+    r = bench.cpu_throughput_baseline(256, 2, seconds=2.0, startup_s=20.0)
+    assert r["cores"] == 2 and r["processes_failed"] == 0 and r["value"] > 0.5, r
+    out = subprocess.run([sys.executable, "-c", "import os, sys; sys.path.insert(0, %r); import bench\n"
+                          "with bench._quiet_stdout():\n    os.write(1, b'banner\\n')\nprint('{\"ok\": 1}')" % ROOT],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == '{"ok": 1}', (out.stdout, out.stderr[-500:])
