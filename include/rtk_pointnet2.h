@@ -100,7 +100,7 @@ RTK_EXPORT int rtk_three_interpolate_grad_set(int b, int c, int n, int m, const 
 
 /* replaces knn_point()   utils/model_utils/model_utils.py:17-39,85-99  (square_distance + torch.topk)
  * query (B,S,3) = `new_xyz`, points (B,N,3) = `xyz` -> idx int64 (B,S,k): the k nearest under
- * d = max(((-2*dot) + |q|^2) + |p|^2, 0), ordered by (d, index) ascending.  1 <= k <= N (k <= 32: sorting networks, 16 lanes per
+ * d = max(((-2*dot) + |q|^2) + |p|^2, 0), ordered by (d, index) ascending.  1 <= k <= N (k <= 32: sorting networks, 4 lanes per
  * query; larger k: one wave per query, k selection rounds). */
 RTK_EXPORT int rtk_knn_point(int b, int s, int n, int k, const float *query, const float *points, int64_t *idx,
                   rtk_stream_t stream);

@@ -820,10 +820,10 @@ extern "C" int rtk_group_points_grad_set(int b, int c, int n, int npoint, int ns
 }
 
 // ------------------------------------------------------------------------------------------------
-// K-smallest selection as branch-free sorting networks over 16 lanes per query.
+// K-smallest selection as branch-free sorting networks over KV_LPQ lanes per query (4; 16 until round 6).
 //
 // The reference scans all candidates serially per query thread (three_nn, knn) or materialises the
-// (B,S,N) distance matrix and calls torch.topk (knn_point).  Here the 16 lanes of a DPP row share a
+// (B,S,N) distance matrix and calls torch.topk (knn_point).  Here KV_LPQ neighbouring lanes of a DPP row share a
 // query: each lane sorts / merges its share of the candidates in registers with compare-exchange
 // networks on 64-bit keys (distance bits : index) -- non-negative floats order like unsigned ints, so
 // one v_cmp_lt_u64 implements "smaller distance, ties -> smaller index", exactly the order a serial
@@ -922,7 +922,7 @@ constexpr int KV_QPW = 256 / KV_LPQ;      // queries per 256-thread workgroup (=
 // Output: the 3 smallest squared distances ascending + indices, ties -> earlier index; fewer than 3
 // known points leave (+inf, 0) in the unfilled slots (the reference's double 1e40 narrowed to float).
 // ------------------------------------------------------------------------------------------------
-// (body: workgroup `chunk` -- 16 queries -- of sample `bs`; smem = 3 m floats with USE_LDS.  Shared by three_nn_kernel and
+// (body: workgroup `chunk` -- KV_QPW queries -- of sample `bs`; smem = 3 m floats with USE_LDS.  Shared by three_nn_kernel and
 // geometry_tables_kernel.)
 template <bool USE_LDS>
 __device__ __forceinline__ void three_nn_body(int bs, int chunk0, int chunk_stride, int n, int m, const float *__restrict__ unknown,
@@ -1199,7 +1199,7 @@ extern "C" int rtk_three_interpolate_grad_set(int b, int c, int n, int m, const 
 // knn_point   (utils/model_utils/model_utils.py:17-39,85-99: square_distance + torch.topk)
 //
 // The reference materialises the (B,S,N) distance matrix with a matmul and runs torch.topk on it.
-// Here 16 lanes share a query: each lane takes candidates j = lane + 16c in chunks of K, sorts the
+// Here KV_LPQ lanes share a query: each lane takes candidates j = lane + KV_LPQ c in chunks of K, sorts the
 // chunk with a bitonic network and merges it into its running K-best; kv_row_merge folds the 16 lists.
 // Distances follow the expansion formula of the arithmetic contract so the neighbour SET equals the
 // CPU reference's; output order is (distance, index) ascending.
@@ -1375,8 +1375,8 @@ extern "C" int rtk_knn_point_masked(int b, int s, int n, int k, const float *que
 //     channel-major coordinates and goes on with levels 2 and 3 (rtk_fps_relevel's per-cloud decisions: copy / resume / settle) --
 //     a level of a cloud depends on nothing but the previous level of the SAME cloud, so the three levels need no launch boundary,
 //     only a fence between a level's stores and the next level's loads (same wave);
-//   * workgroups [2B, 2B + 2 B ceil(n / 16)): the two kNN tables of the cost volume (frame 1 -> frame 2, frame 1 -> frame 1),
-//     16 queries each, reading the API tensors as well.  They fill the chip while the 2B selection waves run their serial rounds.
+//   * workgroups [2B, 2B + 2 B ceil(n / KV_QPW)): the two kNN tables of the cost volume (frame 1 -> frame 2, frame 1 -> frame 1),
+//     KV_QPW = 64 queries each, reading the API tensors as well.  They fill the chip while the 2B selection waves run their serial rounds.
 // rtk_geometry_tables -- everything that needs the three levels of centroids: the three ball-query pair scans and the three
 //   three-NN tables, one heterogeneous grid.
 // ------------------------------------------------------------------------------------------------
