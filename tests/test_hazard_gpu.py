@@ -32,9 +32,10 @@ def test_geometry_launches_are_reproducible_next_to_the_matrix_kernels():
     with torch.cuda.stream(sa):
         ref = H.run_levels(xyz, 512, sa, True)
         full = H.run_levels(xyz, 512, sa, False)
+        one = H.run_levels(xyz, 512, sa, front=True)
     torch.cuda.synchronize()
-    for x, y in zip(ref[:3], full[:3]):
-        assert torch.equal(x, y)                                   # quiet GPU: re-levelling == the full selection level after level
+    for x, y, z in zip(ref[:3], full[:3], one[:3]):
+        assert torch.equal(x, y) and torch.equal(x, z)             # quiet GPU: re-levelling == the full selection level after level == the one launch
     assert int((ref[3][0] > 0).sum()) >= 6, "the batch must contain tied clouds"
     net = make_net()
     h8 = torch.zeros(5, 8, 128, device="cuda")
@@ -48,8 +49,9 @@ def test_geometry_launches_are_reproducible_next_to_the_matrix_kernels():
                     _lib.call(nm, *(args[:-1] + (sb.cuda_stream,)))
             with torch.cuda.stream(sa):
                 cur = H.run_levels(xyz, 512, sa, True)
+                cur1 = H.run_levels(xyz, 512, sa, front=True)          # the product's launch (rtk_geometry_front)
             sa.synchronize()
-            bad += int(any(not torch.equal(c, r) for c, r in zip(cur[:3], ref[:3])))
+            bad += int(any(not torch.equal(c, r) for c, r in zip(cur[:3], ref[:3])) or any(not torch.equal(c, r) for c, r in zip(cur1[:3], ref[:3])))
         torch.cuda.synchronize()
         assert bad == 0, "%d of 400 iterations differ with %s running next to the selection kernels" % (bad, noise)
 

@@ -28,9 +28,10 @@ from ratrack_amd import fused as F  # noqa: E402
 from hazard_harness import DEV, tie_batch  # noqa: E402
 
 
-def run_levels(xyz, npoint, stream, relevel=True):
-    """-> (idx (3,S,npoint), xyz (3,S,npoint,3), nuniq (3,S)) through the product's two launches, or (relevel=False) through the full
-    selection kernel level after level."""
+def run_levels(xyz, npoint, stream, relevel=True, front=False):
+    """-> (idx (3,S,npoint), xyz (3,S,npoint,3), nuniq (3,S)) through the selection + re-levelling launches, or (relevel=False) through
+    the full selection kernel level after level, or (front=True) through rtk_geometry_front -- the three levels of a cloud by one wave in
+    one launch, what the product path issues since round 6."""
     S_, n, _ = xyz.shape
     h = stream.cuda_stream
     idx = torch.zeros(3, S_, npoint, dtype=torch.int32, device=DEV)
@@ -39,7 +40,10 @@ def run_levels(xyz, npoint, stream, relevel=True):
     tie = torch.zeros(3, S_, dtype=torch.int32, device=DEV)
     first = torch.zeros(S_, dtype=torch.int32, device=DEV)
     snap = torch.empty(S_, n, dtype=torch.float32, device=DEV)
-    if relevel:
+    if front:
+        _lib.call("rtk_geometry_front", S_, S_, n, npoint, xyz.data_ptr(), None, 0, None, None, None, None, idx.data_ptr(), out.data_ptr(), cnt.data_ptr(),
+                  tie.data_ptr(), first.data_ptr(), snap.data_ptr(), None, None, None, None, None, 0, h)
+    elif relevel:
         _lib.call("rtk_fps_centroids", S_, n, npoint, xyz.data_ptr(), idx[0].data_ptr(), out[0].data_ptr(), cnt[0].data_ptr(), tie[0].data_ptr(), None,
                   snap.data_ptr(), first.data_ptr(), h)
         _lib.call("rtk_fps_relevel", S_, npoint, 2, out[0].data_ptr(), cnt[0].data_ptr(), tie[0].data_ptr(), idx[1].data_ptr(), out[1].data_ptr(),
