@@ -31,7 +31,11 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                       all-reduce + Adam) at the same B, N, with the roofline of ITS dominant kernel (cost_volume_bwd_kernel);
   roofline_irregular  FPS / ball query / three-NN / kNN / gather-scatter gradients: algorithmic bytes / live duration vs 8 TB/s;
   cpu_baseline        the CPU oracle (oracle/track4d_ref.py: C restatement of the native ops + PyTorch-CPU dense layers)
-                      on this box's host cores, a bounded sample (~20 s): B=1 x {1, all} threads, B=32 x 32 threads, medians.
+                      on this box's host cores, a bounded sample (~20 s): B=1 x {1, all} threads, B=32 x 32 threads, medians; and
+                      `throughput`: P = min(64, host CPUs) single-thread processes looping the B=1 forward over one 8 s window.
+Round 6: roofline.profile_frac (the same FLOPs / the kernel's average in the newest committed rocprofv3 summary of this bench, next
+to the in-situ frac), kernels_alone as the median of 7 eager passes, train.allreduce_us_1rank (the gradient bucket through a 1-rank
+RCCL group), roofline_irregular with the product path's two geometry launches.
 
 `--mode train` makes the train step the headline line instead (same fields).
 """
