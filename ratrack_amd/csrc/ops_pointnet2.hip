@@ -897,15 +897,16 @@ __device__ __forceinline__ void kv_row_merge(unsigned (&d)[K], int (&i)[K]) {
 #pragma unroll
     for (int a = 0; a < K; ++a) { od[a] = dpp_pull<0x102>(d[a]); oi[a] = (int)dpp_pull<0x102>((unsigned)i[a]); }
     kv_merge_low<K>(d, i, od, oi);
-    if constexpr (LPQ == 16) {
+    static_assert(LPQ == 4 || LPQ == 8 || LPQ == 16, "4, 8 or 16 lanes per query");
+    if constexpr (LPQ >= 8) {
 #pragma unroll
         for (int a = 0; a < K; ++a) { od[a] = dpp_pull<0x104>(d[a]); oi[a] = (int)dpp_pull<0x104>((unsigned)i[a]); }
         kv_merge_low<K>(d, i, od, oi);
+    }
+    if constexpr (LPQ == 16) {
 #pragma unroll
         for (int a = 0; a < K; ++a) { od[a] = dpp_pull<0x108>(d[a]); oi[a] = (int)dpp_pull<0x108>((unsigned)i[a]); }
         kv_merge_low<K>(d, i, od, oi);
-    } else {
-        static_assert(LPQ == 4, "4 or 16 lanes per query");
     }
 }
 
@@ -1492,6 +1493,9 @@ extern "C" int rtk_geometry_front(int b, int clouds, int n, int npoint, const fl
     return RTK_OK;
 }
 
+#ifndef GEO_TABLES_WGS
+#define GEO_TABLES_WGS 2048      // workgroups of rtk_geometry_tables (about eight per CU: 1024 / 4096 measured within 1 %)
+#endif
 struct GeoBallTask {
     int n_src, nsa, nsb;
     float r2a, r2b;
@@ -1550,7 +1554,7 @@ extern "C" int rtk_geometry_tables(int samples, int n, int npoint, const float *
     RTK_REQUIRE((size_t)big * 12 <= 64 * 1024, "geometry_tables: clouds of %d points do not fit the LDS stage", big);
     GeoTablesParams P;
     // workgroups per (task, sample): enough of them to fill the chip (~2 k in all over the nine tasks), never more than the task has chunks
-    const int want = rtk_divup(2048, 9 * samples);
+    const int want = rtk_divup(GEO_TABLES_WGS, 9 * samples);
     const int ball_chunks = rtk_divup(npoint, BQ_WAVES * BQ_CENTROIDS_PER_WAVE);
     P.samples = samples; P.npoint = npoint; P.ball_wgs = want < ball_chunks ? want : ball_chunks;
     const size_t lv = (size_t)samples * npoint * 3;
