@@ -113,15 +113,24 @@ def tie_batch(b, n, case_id):
 
 
 def geometry_tensors(geo):
+    """Every table of a geometry, restricted to what a consumer reads: since round 6 the eval path's index workspace is not zero-filled
+    and the rows of duplicate centroids (>= the level's exhausted-cloud counter) are written by nothing (ball tables: every consumer
+    skips them; three-NN tables of the centroid levels: likewise) -- they are masked to zero here, on the device, so that a difference
+    that is left IS a defect."""
     out = {"tie": geo.tie}
+    rows = torch.arange(geo.npoint, device=geo.tie.device)
+
+    def live(t, nu):      # (S, npoint, k) table, (S) counters -> rows >= the counter zeroed
+        return torch.where((rows[None, :] < nu[:, None].to(rows.dtype))[:, :, None], t, torch.zeros_like(t))
     for l in range(3):
         out["fps_idx%d" % l] = geo.fps_idx[l]
         out["xyz%d" % (l + 1)] = geo.xyz[l + 1]
         out["nuniq%d" % l] = geo.nuniq[l]
         for s in range(2):
-            out["ball%d%d" % (l, s)] = geo.ball[l][s]
+            out["ball%d%d" % (l, s)] = live(geo.ball[l][s], geo.nuniq[l])
     for k, (d2, idx, m) in geo.nn.items():
-        out["nn_idx_" + k] = idx
+        u = {"fp3": 2, "fp2": 1, "fp1": 0}[k]
+        out["nn_idx_" + k] = live(idx, geo.nuniq[u - 1]) if u > 0 else idx
     if geo.knn is not None:
         out["knn0"], out["knn1"] = geo.knn
     return out
