@@ -734,7 +734,13 @@ struct PcParams {
 // Register budget: five waves per SIMD and the block loop NOT unrolled (58 registers; fully unrolled hipcc hoists all sixteen row
 // loads and WeightNet fragments to the top: 200 registers, two waves per SIMD).  69.9 -> 54.6 us alone, and the kernel fits on a
 // SIMD next to another batch's forward cost volume: +1.5 % frame-pairs/s.
-__global__ __launch_bounds__(256, 5) void patch_cost_kernel(const PcParams P) {
+#ifndef PC_WAVES
+#define PC_WAVES 5
+#endif
+#ifndef PC_WGS_TARGET
+#define PC_WGS_TARGET 4096
+#endif
+__global__ __launch_bounds__(256, PC_WAVES) void patch_cost_kernel(const PcParams P) {
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     int b, bx, nbx;                                                 // one sample per workgroup, its points strided
     rtk_decode_block(P.gx, b, bx, nbx);
@@ -784,7 +790,7 @@ extern "C" int rtk_patch_cost(int samples, int n, const float *xyz, const int64_
     P.out = out; P.out_pitch = out_pitch; P.out_cm = out_channel_major;
     RTK_REQUIRE(samples <= 65535, "patch_cost: too many samples");
     int gx = (n + 3) / 4;
-    while ((long)gx * samples > 4096 && gx > 1) gx = (gx + 1) / 2;
+    while ((long)gx * samples > PC_WGS_TARGET && gx > 1) gx = (gx + 1) / 2;
     P.gx = samples % 8 == 0 ? gx : 0;
     patch_cost_kernel<<<P.gx ? dim3(gx * samples) : dim3(gx, samples), 256, 0, (hipStream_t)stream>>>(P);
     RTK_CHECK_LAUNCH("patch_cost");

@@ -115,6 +115,9 @@ __device__ __forceinline__ void store_tile(const PwParams &P, const f4 (&acc)[V]
 }
 
 #define PW_NW 4    // waves per workgroup
+#ifndef PW_WGS_TARGET
+#define PW_WGS_TARGET 512      // workgroups per launch (round 6, same box: 384: +0.4 %, 768: -0.1 %)
+#endif
 #ifndef PW_F
 #define PW_F 16    // fragments (KiB) per half of the LDS weight double buffer (16 vs 32: same kernel speed, 1 % more end-to-end
                    // throughput with two batches in flight -- smaller footprints co-reside, tools/experiments/exp_pwf.sh)
@@ -254,7 +257,7 @@ static int launch_pw(const PwParams &P0, bool interp, bool split, hipStream_t s)
     PwParams P = P0;
     const int samples = P.rows / P.rows_per_sample;
     const int groups = (P.rows_per_sample + PW_NW * 16 - 1) / (PW_NW * 16);
-    int gx = 512 / samples;           // 2 workgroups per CU (64 KiB LDS each); the rest is looped (measured: 1024 is 5% slower end to end)
+    int gx = PW_WGS_TARGET / samples;           // 2 workgroups per CU (64 KiB LDS each); the rest is looped (measured: 1024 is 5% slower end to end)
     if (gx < 1) gx = 1;
     if (gx > groups) gx = groups;
     P.gx = samples % 8 == 0 ? gx : 0;

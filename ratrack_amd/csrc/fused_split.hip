@@ -668,6 +668,9 @@ struct SaSplitParams {
 #ifndef SA_SPLIT_WAVES
 #define SA_SPLIT_WAVES 5
 #endif
+#ifndef SA_WGS_TARGET
+#define SA_WGS_TARGET 1024
+#endif
 template <int NS, int C1>
 __global__ __launch_bounds__(256, SA_SPLIT_WAVES) void sa_scale_split_kernel(const SaSplitParams P) {
     constexpr int KS = C1 / 16, VB1 = C1 / 32, NFR = KS * 2 * 2, CPT = 32 / NS;      // k-steps, 32-blocks of layer 1, fragments, centroids per tile
@@ -907,7 +910,7 @@ extern "C" int rtk_sa_scale_split(int samples, int n, int npoint, int nsample, c
     P.out = out; P.out_pitch = out_pitch; P.out_offset = out_offset; P.src_nuniq = src_nuniq; P.dst_nuniq = dst_nuniq;
     const int units = (npoint + 32 / nsample - 1) / (32 / nsample);
     int bx = (units + 3) / 4;
-    while ((long)bx * samples > 1024 && bx > 1) bx = (bx + 1) / 2;      // few, fat workgroups: the LDS image fill is paid per workgroup
+    while ((long)bx * samples > SA_WGS_TARGET && bx > 1) bx = (bx + 1) / 2;      // few, fat workgroups: the LDS image fill is paid per workgroup
     P.gx = samples % 8 == 0 ? bx : 0;
     const dim3 blocks = P.gx ? dim3(bx * samples) : dim3(bx, samples);
     hipStream_t s = (hipStream_t)stream;
