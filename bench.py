@@ -314,8 +314,9 @@ def cpu_baseline(n, budget_s=20.0):
             "runs": rows}
 
 
-def _cpu_throughput_worker(n, go_at, seconds):
-    """`python bench.py --cpu-worker N GO SECONDS`: one single-thread B=1 oracle forward loop; prints "<forwards> <seconds>"."""
+def _cpu_throughput_worker(n, rendezvous, seconds):
+    """`python bench.py --cpu-worker N DIR SECONDS`: one single-thread B=1 oracle forward loop; announces itself in DIR (ready.<pid>), starts
+    when DIR/go appears, prints "<forwards> <seconds>"."""
     torch.set_num_threads(1)
     from oracle import track4d_ref as R
     from ratrack_amd import synth
@@ -327,7 +328,9 @@ def _cpu_throughput_worker(n, go_at, seconds):
     t = {k: torch.from_numpy(v) for k, v in d.items() if k != "gt_cls"}
     with torch.no_grad():
         R.backbone(sd, t["pc1"], t["pc2"], t["feature1"], t["feature2"], None)      # warm-up
-        while time.time() < go_at:
+        open(os.path.join(rendezvous, "ready.%d" % os.getpid()), "w").close()
+        t_wait = time.time()
+        while not os.path.exists(os.path.join(rendezvous, "go")) and time.time() - t_wait < 300:
             time.sleep(0.01)
         t0, k = time.perf_counter(), 0
         while time.perf_counter() - t0 < seconds:
@@ -336,25 +339,35 @@ def _cpu_throughput_worker(n, go_at, seconds):
         print(k, time.perf_counter() - t0, flush=True)
 
 
-def cpu_throughput_baseline(n, procs, seconds=8.0, startup_s=45.0):
+def cpu_throughput_baseline(n, procs, seconds=8.0, startup_s=120.0):
     """What the host can do when every core works: `procs` independent single-thread processes, each looping the CPU oracle's B=1 forward
-    (the fastest setting per core) over the same `seconds` window, started together.  -> pairs/s summed over the processes."""
+    (the fastest setting per core) over the same `seconds` window -- started together, once all of them have loaded and warmed up (or
+    `startup_s` have passed).  -> pairs/s summed over the processes."""
+    import shutil
     import subprocess
-    go_at = time.time() + startup_s
+    import tempfile
+    rdv = tempfile.mkdtemp(prefix="rtk_cpu_", dir="/tmp")
     env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(n), repr(go_at), repr(seconds)], env=env,
-                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(procs)]
-    done, late = [], 0
-    for p_ in ps:
-        try:
-            out, _ = p_.communicate(timeout=startup_s + seconds * 3 + 60)
-            k, el = out.split()
-            done.append((int(k), float(el)))
-        except Exception:
-            p_.kill()
-            late += 1
+    try:
+        ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(n), rdv, repr(seconds)], env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(procs)]
+        t0 = time.time()
+        while time.time() - t0 < startup_s and sum(f.startswith("ready.") for f in os.listdir(rdv)) < procs:
+            time.sleep(0.05)
+        open(os.path.join(rdv, "go"), "w").close()
+        done, late = [], 0
+        for p_ in ps:
+            try:
+                out, _ = p_.communicate(timeout=startup_s + seconds * 3 + 60)
+                k, el = out.split()
+                done.append((int(k), float(el)))
+            except Exception:
+                p_.kill()
+                late += 1
+    finally:
+        shutil.rmtree(rdv, ignore_errors=True)
     if not done:
         raise RuntimeError("no CPU worker finished")
     rate = sum(k / el for k, el in done)
@@ -597,7 +610,7 @@ def _self_spawn(a):
 
 def main():
     if len(sys.argv) == 5 and sys.argv[1] == "--cpu-worker":
-        return _cpu_throughput_worker(int(sys.argv[2]), float(sys.argv[3]), float(sys.argv[4]))
+        return _cpu_throughput_worker(int(sys.argv[2]), sys.argv[3], float(sys.argv[4]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)

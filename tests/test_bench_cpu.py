@@ -74,7 +74,7 @@ def test_round6_evidence_helpers():
     us, name = bench.profile_kernel_avg_us("cost_volume_split_kernel<false>")
     assert name and name.startswith("r") and 100.0 < us < 1000.0, (us, name)
     assert bench.profile_kernel_avg_us("no_such_kernel") == (None, None)
-    r = bench.cpu_throughput_baseline(256, 2, seconds=2.0, startup_s=20.0)
+    r = bench.cpu_throughput_baseline(256, 2, seconds=2.0, startup_s=60.0)
     assert r["cores"] == 2 and r["processes_failed"] == 0 and r["value"] > 0.5, r
     out = subprocess.run([sys.executable, "-c", "import os, sys; sys.path.insert(0, %r); import bench\n"
                           "with bench._quiet_stdout():\n    os.write(1, b'banner\\n')\nprint('{\"ok\": 1}')" % ROOT],
