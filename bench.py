@@ -160,6 +160,11 @@ class _quiet_stdout:
 
     def __exit__(self, *exc):
         sys.stdout.flush()
+        try:      # the banner is written with C stdio, which buffers when fd 1 is a pipe or a file: flush it while fd 1 is still /dev/null
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         os.dup2(self._saved, 1)
         os.close(self._saved)
         os.close(self._null)

@@ -77,6 +77,7 @@ def test_round6_evidence_helpers():
     r = bench.cpu_throughput_baseline(256, 2, seconds=2.0, startup_s=60.0)
     assert r["cores"] == 2 and r["processes_failed"] == 0 and r["value"] > 0.5, r
     out = subprocess.run([sys.executable, "-c", "import os, sys; sys.path.insert(0, %r); import bench\n"
-                          "with bench._quiet_stdout():\n    os.write(1, b'banner\\n')\nprint('{\"ok\": 1}')" % ROOT],
+                          "import ctypes\nwith bench._quiet_stdout():\n    os.write(1, b'banner\\n'); ctypes.CDLL(None).puts(b'buffered C stdio banner')\n"
+                          "print('{\"ok\": 1}')" % ROOT],
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip() == '{"ok": 1}', (out.stdout, out.stderr[-500:])
