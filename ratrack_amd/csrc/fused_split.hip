@@ -326,6 +326,8 @@ __device__ __forceinline__ void cv_layer1_blocks(const CvSplitParams &P, const f
 // Register cap of the forward kernel.  Left alone (512) hipcc spreads the tile over 500 registers and nothing else fits on the SIMD;
 // capped it allocates 404 without a spill, and the small-register geometry kernels of the other batches in flight (FPS 20, ball
 // query 16, three-NN 12, kNN 40 registers) can share the SIMDs with it: +0.7 % frame-pairs/s, the kernel alone unchanged.
+// (Round 6: with the hipcc of ROCm 7.2 the attribute no longer binds -- the code object reports .vgpr_count 496 (256 + 240 accumulation
+// registers) for any cap from 320 to 512, with or without amdgpu_waves_per_eu: one wave owns the SIMD's register file.)
 #ifndef CV_FWD_VGPRS
 #define CV_FWD_VGPRS 448
 #endif
