@@ -837,7 +837,7 @@ def _geometry_tables(geo):
     return out
 
 
-@pytest.mark.parametrize("case", ["synthetic_b4_n256", "lattice_ties", "n1024", "padded", "odd_n", "tiny", "point_major_one_frame"])
+@pytest.mark.parametrize("case", ["synthetic_b4_n256", "lattice_ties", "n1024", "n2048", "n600", "padded", "odd_n", "tiny", "point_major_one_frame"])
 def test_two_launch_geometry_equals_the_separate_launches(case, monkeypatch):
     """rtk_geometry_front + rtk_geometry_tables (two launches, the product path since round 6) against the eleven launches of the ops' own
     entry points (rtk_prepare_inputs, rtk_fps_centroids, rtk_fps_relevel x 2, rtk_ball_query_pair x 3, rtk_three_nn_masked x 3,
@@ -854,8 +854,8 @@ def test_two_launch_geometry_equals_the_separate_launches(case, monkeypatch):
     elif case == "lattice_ties":
         pc1 = torch.randint(0, 6, (3, 3, 300), generator=g).float().to(DEV)
         pc2 = torch.randint(0, 5, (3, 3, 300), generator=g).float().to(DEV)
-    elif case == "n1024":
-        d = synth.make_frame_pairs(2, 1024, case_id=5)
+    elif case in ("n1024", "n2048", "n600"):      # 16, 32 and 16 points per lane in the selection wave; 2048 = the largest fused cloud
+        d = synth.make_frame_pairs(2, int(case[1:]), case_id=5)
         pc1, pc2 = torch.from_numpy(d["pc1"]).to(DEV), torch.from_numpy(d["pc2"]).to(DEV)
     elif case == "padded":
         d = synth.make_frame_pairs(3, 352, case_id=9)
