@@ -25,6 +25,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
                 skip |= {id(W.trans[0]), id(W.trans[1]), id(W.lin3)}
         if mode in ("heads", "both"):
             skip |= {id(eng.cls_head), id(eng.dec_q1)}
+        if mode == "p12":
+            skip |= {id(eng.p1_loc), id(eng.p2_loc)}
+        if mode == "fp":
+            for W in (eng.enc, eng.dec):
+                skip |= {id(W.fp["fp3"]), id(W.fp["fp2"])}
         orig = fused.pointwise
 
         def pw(rows, rps, srcs, chain, out, *a, **k):
@@ -42,7 +47,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
         pipe.drain(); torch.cuda.synchronize()
         print("ONE %.4f" % ((time.perf_counter() - t0) / 2000 * 1e3), flush=True)
     sys.exit(0)
-for mode in ("none", "transitions", "heads", "none", "transitions"):
+for mode in ("none", "p12", "fp", "transitions", "heads", "none", "p12", "fp"):
     out = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", mode], capture_output=True, text=True).stdout
     ms = float([l for l in out.split("\n") if l.startswith("ONE ")][-1].split()[1])
     print("skipped: %-12s %.4f ms/batch = %.1f k pairs/s" % (mode, ms, 64 / ms), flush=True)
