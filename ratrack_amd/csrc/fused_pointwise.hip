@@ -116,7 +116,9 @@ __device__ __forceinline__ void store_tile(const PwParams &P, const f4 (&acc)[V]
 
 #define PW_NW 4    // waves per workgroup
 #ifndef PW_WGS_TARGET
-#define PW_WGS_TARGET 512      // workgroups per launch (round 6, same box: 384: +0.4 %, 768: -0.1 %)
+#define PW_WGS_TARGET 256      // workgroups per launch: about one per CU, the rest is looped.  Round 6, same box, alternating (ab_knobs.py):
+                               // 512 (rounds 2-5): base; 448 / 384 / 320: +0.4 ... +0.5 %; 256: +0.9 % (B=64, N=256), +1.0 % (B=32, N=1024), +-0.1 %
+                               // (B=32 / 8 / 1, N=256); 192: -0.5 %; 128: -0.1 %
 #endif
 #ifndef PW_F
 #define PW_F 16    // fragments (KiB) per half of the LDS weight double buffer (16 vs 32: same kernel speed, 1 % more end-to-end
@@ -257,7 +259,7 @@ static int launch_pw(const PwParams &P0, bool interp, bool split, hipStream_t s)
     PwParams P = P0;
     const int samples = P.rows / P.rows_per_sample;
     const int groups = (P.rows_per_sample + PW_NW * 16 - 1) / (PW_NW * 16);
-    int gx = PW_WGS_TARGET / samples;           // 2 workgroups per CU (64 KiB LDS each); the rest is looped (measured: 1024 is 5% slower end to end)
+    int gx = PW_WGS_TARGET / samples;           // (1024: 5 % slower end to end)
     if (gx < 1) gx = 1;
     if (gx > groups) gx = groups;
     P.gx = samples % 8 == 0 ? gx : 0;

@@ -7,12 +7,9 @@ sys.path.insert(0, ROOT)
 VAR = os.path.join(ROOT, "ratrack_amd", "lib", "variants")
 VARIANTS = {      # tag -> (source file, extra flags)
     "base": (None, []),
-    "pw384": ("fused_pointwise.hip", ["-DPW_WGS_TARGET=384"]), "pw768": ("fused_pointwise.hip", ["-DPW_WGS_TARGET=768"]),
-    "pwF32": ("fused_pointwise.hip", ["-DPW_F=32"]),
-    "sa768": ("fused_split.hip", ["-DSA_WGS_TARGET=768"]), "sa2048": ("fused_split.hip", ["-DSA_WGS_TARGET=2048"]),
-    "saW4": ("fused_split.hip", ["-DSA_SPLIT_WAVES=4"]), "saW6": ("fused_split.hip", ["-DSA_SPLIT_WAVES=6"]),
-    "pcW4": ("fused_group.hip", ["-DPC_WAVES=4"]), "pcW6": ("fused_group.hip", ["-DPC_WAVES=6"]),
-    "pc2048": ("fused_group.hip", ["-DPC_WGS_TARGET=2048"]), "pc8192": ("fused_group.hip", ["-DPC_WGS_TARGET=8192"]),
+    "pw128": ("fused_pointwise.hip", ["-DPW_WGS_TARGET=128"]), "pw192": ("fused_pointwise.hip", ["-DPW_WGS_TARGET=192"]),
+    "pw256": ("fused_pointwise.hip", ["-DPW_WGS_TARGET=256"]), "pw320": ("fused_pointwise.hip", ["-DPW_WGS_TARGET=320"]),
+    "pw384": ("fused_pointwise.hip", ["-DPW_WGS_TARGET=384"]), "pw448": ("fused_pointwise.hip", ["-DPW_WGS_TARGET=448"]),
 }
 if "--build" in sys.argv:
     from ratrack_amd import build as B
@@ -40,10 +37,11 @@ elif "--one" in sys.argv:
     dev = torch.device("cuda")
     net = Track4D(Args()).to(dev).eval()
     synth.fill_state_dict(net.state_dict())
+    BB, NN = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (64, 256)
     batches = []
     for i in range(8):
-        d = synth.make_frame_pairs(64, 256, 1000 + 100 * i)
-        batches.append([torch.from_numpy(d[k]).to(dev) for k in ("pc1", "pc2", "feature1", "feature2")] + [torch.zeros(5, 64, 128, device=dev)])
+        d = synth.make_frame_pairs(BB, NN, 1000 + 100 * i)
+        batches.append([torch.from_numpy(d[k]).to(dev) for k in ("pc1", "pc2", "feature1", "feature2")] + [torch.zeros(5, BB, 128, device=dev)])
     with torch.no_grad():
         net.backbone(*batches[0])
         pipe = fused.GraphPipeline(net._fused, tuple(batches[0]), depth=4)
@@ -57,10 +55,13 @@ elif "--one" in sys.argv:
         print("ONE %.4f" % ((time.perf_counter() - t0) / 3000 * 1e3), flush=True)
 else:
     rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 2
-    res = {t: [] for t in VARIANTS}
+    shape = sys.argv[sys.argv.index("--shape") + 1].split("x") if "--shape" in sys.argv else ["64", "256"]
+    only = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else list(VARIANTS)
+    print("B=%s N=%s" % tuple(shape), flush=True)
+    res = {t: [] for t in VARIANTS if t in only}
     for r in range(rounds):
-        for tag in VARIANTS:
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", tag], capture_output=True, text=True)
+        for tag in res:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", tag] + shape, capture_output=True, text=True)
             ms = [l for l in out.stdout.split("\n") if l.startswith("ONE ")]
             if ms:
                 res[tag].append(float(ms[-1].split()[1]))
@@ -70,4 +71,4 @@ else:
     for tag, v in res.items():
         if v:
             m = sum(v) / len(v)
-            print("%-8s %s  mean %.4f ms = %.1f k pairs/s  (%+.2f %% vs base)" % (tag, " ".join("%.4f" % x for x in v), m, 64 / m, 100 * (b / m - 1)), flush=True)
+            print("%-8s %s  mean %.4f ms = %.1f k pairs/s  (%+.2f %% vs base)" % (tag, " ".join("%.4f" % x for x in v), m, int(shape[0]) / m, 100 * (b / m - 1)), flush=True)
