@@ -5,8 +5,11 @@ import glob, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 VAR = os.path.join(ROOT, "ratrack_amd", "lib", "variants")
-VARIANTS = {      # tag -> (source file, extra flags)
+VARIANTS = {      # tag -> (source file, extra flags); edit for the sweep at hand (HISTORY.md lists the ones that were run)
     "base": (None, []),
+    "pw512": ("fused_pointwise.hip", ["-DPW_WGS_TARGET=512"]), "pw128": ("fused_pointwise.hip", ["-DPW_WGS_TARGET=128"]),
+    "sa1280": ("fused_split.hip", ["-DSA_WGS_TARGET=1280"]), "san2048": ("fused_group.hip", ["-DSA_MAX_WGS=2048"]),
+    "cv232": ("fused_split.hip", ["-DCV_FWD_VGPRS=232"]),
     "pw128": ("fused_pointwise.hip", ["-DPW_WGS_TARGET=128"]), "pw192": ("fused_pointwise.hip", ["-DPW_WGS_TARGET=192"]),
     "pw256": ("fused_pointwise.hip", ["-DPW_WGS_TARGET=256"]), "pw320": ("fused_pointwise.hip", ["-DPW_WGS_TARGET=320"]),
     "pw384": ("fused_pointwise.hip", ["-DPW_WGS_TARGET=384"]), "pw448": ("fused_pointwise.hip", ["-DPW_WGS_TARGET=448"]),
