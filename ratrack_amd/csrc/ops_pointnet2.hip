@@ -142,7 +142,10 @@ __device__ __forceinline__ int fps_wave_body(int n, int m, int block, const floa
     const int q = n >> bits, rem = n & (block - 1);
     for (int k = lane; k < n; k += 64)      // coalesced read of the cloud, scattered into tie order
         s_pt[fps_index_to_pos(k, block, bits, q, rem)] = make_float4(xyz[k * ps], xyz[k * ps + cs], xyz[k * ps + 2 * cs], __int_as_float(k));
-    __syncthreads();
+    // s_pt belongs to THIS wave (the body is run by exactly one wave, also inside rtk_geometry_front's 256-thread workgroups, whose other
+    // waves have left by then): a wave's LDS operations execute in order, so what the scattered writes need before the reads below is
+    // that they have been issued and counted -- not a workgroup barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     // LANE-MAJOR layout: lane l owns positions PPL*l .. PPL*l + PPL-1, so "smallest position among the maxima" =
     // lowest lane with the maximum, then its lowest slot.  Slots are processed in pairs with packed fp32 math
@@ -1439,7 +1442,7 @@ __global__ __launch_bounds__(256) void geometry_front_kernel(const GeoFrontParam
             }
         }
     }
-    if (tid >= 64) return;                             // (a finished wave no longer counts at the barriers below)
+    if (tid >= 64) return;                             // (the selection below is one wave's work; it contains no workgroup barrier)
     const int lane = tid;
     const size_t lv = (size_t)S_ * m;                  // one level of indices
     int *i1 = P.fps_idx + (size_t)s * m, *i2 = i1 + lv, *i3 = i2 + lv;
